@@ -1,0 +1,227 @@
+/*
+ * panmap_amd.h -- C ABI of the MI355X-native panmap hot path (index -> place -> align).
+ *
+ * One shared library, libpanmap_amd.so: plain pointers and sizes, no C++/torch types.  Every
+ * entry point cites the reference interface it stands in for (paths relative to amkram/panmap).
+ * All functions returning int use 0 = success, negative = error (pmx_last_error() has the text);
+ * there is NO CPU fallback: device entry points fail with PMX_ERR_NO_DEVICE when no gfx950 GPU is
+ * usable.  Handles are thread-compatible, not thread-safe; one pmx_ctx per GPU.
+ */
+#ifndef PANMAP_AMD_H
+#define PANMAP_AMD_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_OK 0
+#define PMX_ERR_ARG (-1)
+#define PMX_ERR_IO (-2)
+#define PMX_ERR_FORMAT (-3)
+#define PMX_ERR_NO_DEVICE (-4)
+#define PMX_ERR_DEVICE (-5)
+#define PMX_ERR_CAPACITY (-6)
+#define PMX_ERR_UNSUPPORTED (-7)
+
+const char *pmx_last_error(void);
+const char *pmx_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * PanMAN + node genomes (host).  Replaces loadPanMAN (src/main.cpp:313-325, external panman
+ * library) and panmapUtils::getStringFromReference (src/panmap_utils.cpp:182-190), which
+ * runAlignment uses to materialise the placed node's genome (src/main.cpp:1757-1771).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pmx_panman pmx_panman;
+int pmx_panman_open(const char *path, pmx_panman **out);
+void pmx_panman_close(pmx_panman *pm);
+int64_t pmx_panman_num_nodes(const pmx_panman *pm);
+int64_t pmx_panman_num_blocks(const pmx_panman *pm);
+int64_t pmx_panman_num_columns(const pmx_panman *pm);
+const char *pmx_panman_node_id(const pmx_panman *pm, int64_t dfs_index);
+int64_t pmx_panman_parent(const pmx_panman *pm, int64_t dfs_index);
+int64_t pmx_panman_find_node(const pmx_panman *pm, const char *node_id); /* -1 if absent */
+/* writes the ungapped genome (no NUL) into buf if cap suffices; always returns its length */
+int64_t pmx_panman_node_genome(const pmx_panman *pm, int64_t dfs_index, char *buf, int64_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Seed index (host).  Replaces IndexBuilder::buildIndexParallel (src/index_single_mode.hpp:207-214)
+ * and the zero-copy SoA binding the place stage does on the loaded index
+ * (src/placement.cpp:1054-1085; layout src/index_lite.capnp:36-70).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pmx_index pmx_index;
+typedef struct {
+    int32_t k, s, t, l;
+    int32_t open_syncmer;
+    int32_t hpc;
+    int32_t flank_mask;
+    int32_t reserved;
+    int64_t n_nodes;
+    int64_t n_changes;
+} pmx_index_info;
+
+int pmx_index_build(const pmx_panman *pm, int k, int s, int t, int l, int open_syncmer, int flank_mask,
+                    pmx_index **out);
+/* adopt caller-provided SoA arrays (copied): parent[n], offsets[n+1], hash/pc/cc[offsets[n]] */
+int pmx_index_from_arrays(const pmx_index_info *info, const uint32_t *parent, const uint64_t *offsets,
+                          const uint64_t *hash, const int16_t *parent_count, const int16_t *child_count,
+                          pmx_index **out);
+void pmx_index_close(pmx_index *idx);
+int pmx_index_get_info(const pmx_index *idx, pmx_index_info *info);
+const uint32_t *pmx_index_parents(const pmx_index *idx);      /* n_nodes   */
+const uint64_t *pmx_index_offsets(const pmx_index *idx);      /* n_nodes+1 */
+const uint64_t *pmx_index_hashes(const pmx_index *idx);       /* n_changes */
+const int16_t *pmx_index_parent_counts(const pmx_index *idx); /* n_changes */
+const int16_t *pmx_index_child_counts(const pmx_index *idx);  /* n_changes */
+
+/* ------------------------------------------------------------------------------------------
+ * Device context (one per GPU / per process rank).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pmx_ctx pmx_ctx;
+int pmx_ctx_create(int device_ordinal, pmx_ctx **out);
+void pmx_ctx_destroy(pmx_ctx *ctx);
+int pmx_ctx_synchronize(pmx_ctx *ctx);
+/* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */
+void *pmx_ctx_stream(pmx_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Read sets.  The reference hands reads around as std::vector<std::string>
+ * (extractReadSequences src/placement.cpp:164-197; readFastqPaired src/seeding.cpp:231-269).
+ * Here: one concatenated ASCII buffer + n+1 offsets, uploaded once; pmx_readset_pack converts it
+ * on the GPU to 2 bits/base + an ambiguity bitmask (every read starts on a 32-base word).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pmx_readset pmx_readset;
+int pmx_readset_upload(pmx_ctx *ctx, const char *concat, const int64_t *offsets, int64_t n_reads,
+                       pmx_readset **out);
+/* wrap ASCII reads already resident in device memory (d_concat: total bytes, d_offsets: n+1 int64) */
+int pmx_readset_wrap_device(pmx_ctx *ctx, const void *d_concat, const void *d_offsets, int64_t n_reads,
+                            int64_t total_bytes, int64_t max_read_len, pmx_readset **out);
+int pmx_readset_pack(pmx_ctx *ctx, pmx_readset *rs);
+void pmx_readset_free(pmx_ctx *ctx, pmx_readset *rs);
+int64_t pmx_readset_num_reads(const pmx_readset *rs);
+
+/* ------------------------------------------------------------------------------------------
+ * PLACE stage on the GPU.  Together these replace placement::placeLite
+ * (src/placement.hpp:237-244, src/placement.cpp:986-2018).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    /* TraversalParams fields that change results (src/placement.hpp:28-54); k/s/t/l/open come
+       from the index (src/placement.cpp:1094-1101) */
+    double seed_mask_fraction; /* CLI default 0 (src/main.cpp:1967) */
+    int32_t min_read_support;  /* -1 = auto */
+    int32_t trim_start, trim_end;
+    int32_t dedup_reads;       /* --dedup: each distinct sequence counted once */
+    int32_t force_leaf;
+    int32_t reserved[3];
+} pmx_place_params;
+
+typedef struct {
+    double best_score[5];     /* log_raw, log_cosine, containment, weighted_containment, log_containment */
+    uint32_t best_index[5];   /* lowest tied DFS index; UINT32_MAX if none */
+    int64_t n_tied[5];
+    int64_t n_reads;
+    int64_t n_unique_seeds;   /* histogram size after homopolymer/mask erase */
+    int64_t n_kept_seeds;     /* readUniqueSeedCount */
+    int64_t total_seed_freq;  /* totalReadSeedFrequency */
+    int64_t min_support;      /* resolved */
+    double log_read_magnitude;
+    double log_containment_den;
+    double weighted_containment_den;
+} pmx_place_result;
+
+typedef struct pmx_place pmx_place; /* device-resident index + working buffers for one sample */
+
+/* uploads the index SoA (replicated per GPU) and precomputes BFS levels */
+int pmx_place_create(pmx_ctx *ctx, const pmx_index *idx, pmx_place **out);
+void pmx_place_free(pmx_ctx *ctx, pmx_place *pl);
+
+/* [hot] reads -> syncmers -> k-min-mers -> seed histogram (src/placement.cpp:1611-1686).
+   Accumulates into the place object's device histogram; call once per read shard. */
+int pmx_place_reset(pmx_ctx *ctx, pmx_place *pl);
+int pmx_place_add_reads(pmx_ctx *ctx, pmx_place *pl, const pmx_readset *rs, const pmx_place_params *pp);
+/* export / import of the (hash,count) histogram, ascending hash: the multi-GPU exchange step
+   (all-gather of per-rank histograms, then merge) */
+int64_t pmx_place_histogram_size(pmx_ctx *ctx, pmx_place *pl);
+int pmx_place_histogram_export(pmx_ctx *ctx, pmx_place *pl, uint64_t *hash, int64_t *count, int64_t cap);
+int pmx_place_histogram_merge(pmx_ctx *ctx, pmx_place *pl, const uint64_t *hash, const int64_t *count, int64_t n);
+
+/* read-side filters + magnitudes (src/placement.cpp:1703-1856), then [hot] per-node delta scoring
+   down the tree (src/placement.cpp:242-345, 701-918) and the sequential best/tie rule (:355-401) */
+int pmx_place_score(pmx_ctx *ctx, pmx_place *pl, const pmx_place_params *pp, int64_t n_reads_total,
+                    pmx_place_result *res);
+/* tied DFS indices of metric m (ascending), after pmx_place_score */
+int pmx_place_tied(const pmx_place *pl, int metric, uint32_t *out, int64_t cap);
+/* optional per-node outputs (host copies): scores [n_nodes][5] double, metrics [n_nodes][5] double,
+   counts [n_nodes][2] int64; any pointer may be NULL */
+int pmx_place_node_outputs(pmx_ctx *ctx, pmx_place *pl, double *scores5, double *metrics5, int64_t *counts2);
+/* kept read seeds after filtering: hash ascending + log1p(count) */
+int64_t pmx_place_kept_seeds(pmx_ctx *ctx, pmx_place *pl, uint64_t *hash, double *logc, int64_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * ALIGN stage.  B-align boundary: identical to the reference's C ABI (src/mm_align.h:20-53).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t pos;    /* 1-based ref position (INT_MAX if unmapped) */
+    int32_t rs, re; /* 0-based ref start/end */
+    int32_t qs, qe; /* query start/end */
+    uint8_t mapq;
+    uint8_t rev;
+    uint8_t proper_frag;
+    int32_t n_cigar;
+    uint32_t *cigar; /* BAM-encoded; malloc'd, caller frees */
+    char *md;
+} read_align_t;
+
+typedef struct {
+    read_align_t r1;
+    read_align_t r2;
+    int mapped;
+} align_pair_result_t;
+
+/* Drop-in for src/mm_align.h:44-53 (selected through the aligner function pointer at
+   src/conversion.cpp:416-426).  Same argument meaning; n_threads is accepted and ignored (the GPU
+   owns the parallelism).  On failure returns with `results` untouched, like the reference. */
+void pmx_align_reads_direct(const char *reference, const char *refName, int n_reads, const char **reads,
+                            const char **quality, const char **read_names, const int *r_lens,
+                            align_pair_result_t *results, bool pairedEndReads, int n_threads);
+
+/* Device-resident form used by the pipeline / benchmark: fixed 32-byte records + CIGAR arena. */
+typedef struct {
+    int32_t rs, re, qs, qe;
+    uint8_t mapq, rev, proper_frag, mapped;
+    uint16_t n_cigar;
+    uint16_t flags;      /* PMX_ALN_* status bits */
+    uint32_t cigar_off;  /* index into the CIGAR arena (uint32 ops) */
+    int32_t score;       /* dp_max of the primary */
+} pmx_aln_record;
+
+#define PMX_ALN_OVERFLOW 0x1     /* a fixed-capacity work buffer overflowed: record is invalid */
+#define PMX_ALN_UNSUPPORTED 0x2  /* hit a reference branch not implemented on the GPU yet */
+
+typedef struct pmx_aligner pmx_aligner;
+/* builds the minimizer index of one reference genome on the device; preset chosen from the mean
+   read length exactly as setup_minimap2(for_scoring=1) does (src/mm_align.c:118-188) */
+int pmx_aligner_create(pmx_ctx *ctx, const char *reference, int64_t ref_len, int mean_read_len, pmx_aligner **out);
+void pmx_aligner_free(pmx_ctx *ctx, pmx_aligner *al);
+/* [hot] map + align every read (pair) of a packed read set.  revcomp_mate2 != 0: odd-indexed reads
+   are reverse-complemented on the fly (what readFastqPaired does on the host, src/seeding.cpp:251).
+   Results stay on the device until fetched. */
+int pmx_align_readset(pmx_ctx *ctx, pmx_aligner *al, const pmx_readset *rs, int paired, int revcomp_mate2);
+int64_t pmx_align_num_records(const pmx_aligner *al);
+int64_t pmx_align_cigar_words(pmx_ctx *ctx, pmx_aligner *al);
+int pmx_align_fetch(pmx_ctx *ctx, pmx_aligner *al, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,
+                    int64_t arena_cap);
+/* device pointers of the last result (for RCCL gathers without a host bounce) */
+const void *pmx_align_device_records(const pmx_aligner *al);
+const void *pmx_align_device_cigars(const pmx_aligner *al);
+
+/* kernel timing: average duration (ms) of the dominant kernel of the last call, measured with HIP
+   events on the context stream; name selects "seed", "score", "align" */
+double pmx_last_kernel_ms(pmx_ctx *ctx, const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,130 @@
+// C ABI, host-only part: PanMAN access, node genomes, seed-index build (see include/panmap_amd.h).
+#include <cstring>
+#include <string>
+
+#include "api_internal.hpp"
+#include "host/index_build.hpp"
+#include "host/panman.hpp"
+
+namespace pmx {
+thread_local std::string g_last_error;
+void set_error(const std::string& s) { g_last_error = s; }
+}  // namespace pmx
+
+struct pmx_panman {
+    pmx::Panman pm;
+};
+
+struct pmx_index {
+    pmx::LiteIndex ix;
+};
+
+extern "C" {
+
+const char* pmx_last_error(void) { return pmx::g_last_error.c_str(); }
+const char* pmx_version(void) { return "panmap_amd 0.1 (gfx950)"; }
+
+int pmx_panman_open(const char* path, pmx_panman** out) {
+    if (!path || !out) return PMX_ERR_ARG;
+    try {
+        pmx_panman* p = new pmx_panman();
+        pmx::load_panman(path, p->pm);
+        *out = p;
+        return PMX_OK;
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return PMX_ERR_FORMAT;
+    }
+}
+void pmx_panman_close(pmx_panman* pm) { delete pm; }
+int64_t pmx_panman_num_nodes(const pmx_panman* pm) { return pm ? (int64_t)pm->pm.nodes.size() : 0; }
+int64_t pmx_panman_num_blocks(const pmx_panman* pm) { return pm ? pm->pm.n_blocks : 0; }
+int64_t pmx_panman_num_columns(const pmx_panman* pm) { return pm ? pm->pm.n_cols : 0; }
+const char* pmx_panman_node_id(const pmx_panman* pm, int64_t i) {
+    if (!pm || i < 0 || i >= (int64_t)pm->pm.nodes.size()) return nullptr;
+    return pm->pm.nodes[i].id.c_str();
+}
+int64_t pmx_panman_parent(const pmx_panman* pm, int64_t i) {
+    if (!pm || i < 0 || i >= (int64_t)pm->pm.nodes.size()) return -1;
+    return pm->pm.nodes[i].parent;
+}
+int64_t pmx_panman_find_node(const pmx_panman* pm, const char* id) {
+    if (!pm || !id) return -1;
+    return pm->pm.find_node(id);
+}
+int64_t pmx_panman_node_genome(const pmx_panman* pm, int64_t i, char* buf, int64_t cap) {
+    if (!pm || i < 0 || i >= (int64_t)pm->pm.nodes.size()) return -1;
+    try {
+        std::string g = pmx::node_genome(pm->pm, (int32_t)i);
+        if (buf && cap >= (int64_t)g.size()) std::memcpy(buf, g.data(), g.size());
+        return (int64_t)g.size();
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return -1;
+    }
+}
+
+int pmx_index_build(const pmx_panman* pm, int k, int s, int t, int l, int open_syncmer, int flank_mask, pmx_index** out) {
+    if (!pm || !out) return PMX_ERR_ARG;
+    // same validation as the CLI (src/main.cpp:2221-2235)
+    if (k <= 0 || s <= 0 || s > k || t < 0 || t > k - s || l < 0 || k > 64) {
+        pmx::set_error("invalid seeding parameters");
+        return PMX_ERR_ARG;
+    }
+    try {
+        pmx_index* ix = new pmx_index();
+        pmx::SyncmerParams p;
+        p.k = k; p.s = s; p.t = t; p.l = l; p.open = open_syncmer != 0;
+        pmx::build_lite_index(pm->pm, p, flank_mask, ix->ix);
+        *out = ix;
+        return PMX_OK;
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return PMX_ERR_UNSUPPORTED;
+    }
+}
+
+int pmx_index_from_arrays(const pmx_index_info* info, const uint32_t* parent, const uint64_t* offsets, const uint64_t* hash,
+                          const int16_t* pc, const int16_t* cc, pmx_index** out) {
+    if (!info || !parent || !offsets || !out || info->n_nodes <= 0) return PMX_ERR_ARG;
+    const int64_t n = info->n_nodes, m = (int64_t)offsets[n];
+    if (m != info->n_changes || (m > 0 && (!hash || !pc || !cc))) { pmx::set_error("index arrays inconsistent"); return PMX_ERR_ARG; }
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets[i] > offsets[i + 1] || (i > 0 && parent[i] >= (uint32_t)i)) { pmx::set_error("index arrays: offsets not monotone or parent >= child"); return PMX_ERR_FORMAT; }
+    pmx_index* ix = new pmx_index();
+    pmx::LiteIndex& L = ix->ix;
+    L.params.k = info->k; L.params.s = info->s; L.params.t = info->t; L.params.l = info->l;
+    L.params.open = info->open_syncmer != 0;
+    L.hpc = info->hpc != 0;
+    L.flank_mask = info->flank_mask;
+    L.parent.assign(parent, parent + n);
+    L.offsets.assign(offsets, offsets + n + 1);
+    L.hash.assign(hash, hash + m);
+    L.parent_count.assign(pc, pc + m);
+    L.child_count.assign(cc, cc + m);
+    L.node_id.resize(n);
+    *out = ix;
+    return PMX_OK;
+}
+
+void pmx_index_close(pmx_index* idx) { delete idx; }
+
+int pmx_index_get_info(const pmx_index* idx, pmx_index_info* info) {
+    if (!idx || !info) return PMX_ERR_ARG;
+    const pmx::LiteIndex& L = idx->ix;
+    std::memset(info, 0, sizeof(*info));
+    info->k = L.params.k; info->s = L.params.s; info->t = L.params.t; info->l = L.params.l;
+    info->open_syncmer = L.params.open; info->hpc = L.hpc; info->flank_mask = L.flank_mask;
+    info->n_nodes = (int64_t)L.parent.size();
+    info->n_changes = (int64_t)L.hash.size();
+    return PMX_OK;
+}
+const uint32_t* pmx_index_parents(const pmx_index* idx) { return idx ? idx->ix.parent.data() : nullptr; }
+const uint64_t* pmx_index_offsets(const pmx_index* idx) { return idx ? idx->ix.offsets.data() : nullptr; }
+const uint64_t* pmx_index_hashes(const pmx_index* idx) { return idx ? idx->ix.hash.data() : nullptr; }
+const int16_t* pmx_index_parent_counts(const pmx_index* idx) { return idx ? idx->ix.parent_count.data() : nullptr; }
+const int16_t* pmx_index_child_counts(const pmx_index* idx) { return idx ? idx->ix.child_count.data() : nullptr; }
+
+}  // extern "C"
+
+const pmx::LiteIndex* pmx_index_internal(const pmx_index* idx) { return idx ? &idx->ix : nullptr; }

@@ -1,0 +1,306 @@
+// Incremental DFS index producer (see index_build.hpp).
+//
+// Rule implemented (validated end-to-end against the reference's golden placement TSV, SURVEY.md
+// Appendix E-4/E-7):
+//   * apply the node's mutations to the column array, recording each mutated column range;
+//   * the *dirty* k-mer starts are the starts of every k-mer overlapping a recorded range;
+//   * a dirty start inside the node's own hard flank mask [col of base #flank, col of base #n-flank+1]
+//     takes the from-scratch syncmer verdict for this node's genome; everything else (dirty starts
+//     outside the mask, all non-dirty columns) inherits the parent's state
+//     (src/index_single_mode.cpp:1768-1780, 1850-1854, 1883-1914);
+//   * the node's seed multiset is the k-min-mers of the syncmers in column order; the stored changes
+//     are the multiset difference to the parent, sorted by hash (:2105-2162, :2530-2534).
+// The syncmer map and the k-min-mer counts are updated incrementally: only windows of l consecutive
+// syncmers whose column span contains a changed column are removed / re-added.
+#include "index_build.hpp"
+
+#include <algorithm>
+#include <map>
+#include <stdexcept>
+#include <unordered_map>
+
+namespace pmx {
+namespace {
+
+struct SynChange {
+    uint32_t col;
+    bool had;
+    uint64_t old_hash;
+};
+
+struct NodeUndo {
+    UndoLog cols;
+    std::vector<SynChange> syn;
+    std::vector<std::pair<uint64_t, int32_t>> counts;  // (hash, delta applied)
+};
+
+struct Pending {
+    bool present;
+    uint64_t hash;
+};
+
+struct Builder {
+    const Panman& pm;
+    SyncmerParams p;
+    int flank;
+    PanmanState st;
+    std::map<uint32_t, uint64_t> syn;                // column of the k-mer's first base -> syncmer hash
+    std::unordered_map<uint64_t, int32_t> counts;    // running k-min-mer multiset
+    // scratch
+    std::vector<uint32_t> lc;
+    std::string lseq;
+    std::vector<uint8_t> is_sync;
+    std::vector<uint64_t> shash;
+
+    Builder(const Panman& pm_, const SyncmerParams& p_, int flank_) : pm(pm_), p(p_), flank(flank_) { st.init(pm); }
+
+    inline bool is_base(uint32_t c) const {
+        char ch = st.cols[c];
+        return ch != '-' && ch != 'x' && st.block_exists[pm.col_block[c]];
+    }
+    // smallest base column >= c, or n_cols
+    uint32_t next_base(uint32_t c) const {
+        const uint32_t n = pm.n_cols;
+        while (c < n) {
+            uint32_t b = pm.col_block[c];
+            if (!st.block_exists[b]) { c = pm.block_col0[b + 1]; continue; }
+            char ch = st.cols[c];
+            if (ch != '-' && ch != 'x') return c;
+            ++c;
+        }
+        return n;
+    }
+    // largest base column <= c, or -1
+    int64_t prev_base(int64_t c) const {
+        while (c >= 0) {
+            uint32_t b = pm.col_block[c];
+            if (!st.block_exists[b]) { c = (int64_t)pm.block_col0[b] - 1; continue; }
+            char ch = st.cols[c];
+            if (ch != '-' && ch != 'x') return c;
+            --c;
+        }
+        return -1;
+    }
+
+    void enum_windows(const std::vector<uint32_t>& changed, std::vector<uint64_t>& seeds) const {
+        const int l = p.l < 1 ? 1 : p.l;
+        int64_t last_start = -1;
+        uint64_t h[32];
+        for (uint32_t c : changed) {
+            auto it = syn.lower_bound(c);
+            const bool c_in = it != syn.end() && it->first == c;
+            auto first = it;
+            for (int back = 0; back < l - 1 && first != syn.begin(); ++back) --first;
+            for (auto s = first; s != syn.end(); ++s) {
+                if (c_in ? s->first > c : s->first >= c) break;
+                if ((int64_t)s->first <= last_start) continue;
+                auto q = s;
+                int cnt = 0;
+                uint32_t lastcol = 0;
+                for (; cnt < l && q != syn.end(); ++q, ++cnt) { h[cnt] = q->second; lastcol = q->first; }
+                if (cnt < l) break;
+                if (lastcol < c) continue;
+                last_start = s->first;
+                uint64_t seed;
+                if (kminmer_seed(h, p.k, l, &seed)) seeds.push_back(seed);
+            }
+        }
+    }
+
+    void process(int32_t ni, NodeUndo& u, std::vector<uint64_t>& out_hash, std::vector<int16_t>& out_pc,
+                 std::vector<int16_t>& out_cc) {
+        std::vector<ColRange> ranges;
+        apply_node(pm, ni, st, &u.cols, &ranges);
+        if (ranges.empty()) return;
+        for (int32_t b = 0; b < pm.n_blocks; ++b)
+            if (st.block_exists[b] && !st.block_fwd[b])
+                throw std::runtime_error("index build: inverted blocks are not supported yet (node " + pm.nodes[ni].id + ")");
+        std::sort(ranges.begin(), ranges.end(), [](const ColRange& x, const ColRange& y) { return x.a < y.a; });
+        std::vector<ColRange> merged;
+        for (const ColRange& r : ranges) {
+            if (!merged.empty() && (uint64_t)r.a <= (uint64_t)merged.back().b + 1) merged.back().b = std::max(merged.back().b, r.b);
+            else merged.push_back(r);
+        }
+        // hard flank mask of THIS node's genome (src/panmap_utils.hpp:893-970)
+        int64_t hms = 0, hme = (int64_t)pm.n_cols - 1;
+        bool all_masked = false;
+        if (flank > 0) {
+            uint32_t c = 0;
+            int got = 0;
+            hms = -1;
+            while ((c = next_base(c)) < pm.n_cols) { if (++got == flank) { hms = c; break; } ++c; }
+            int64_t d = (int64_t)pm.n_cols - 1;
+            got = 0;
+            hme = -1;
+            while ((d = prev_base(d)) >= 0) { if (++got == flank) { hme = d; break; } --d; }
+            if (hms < 0 || hme < 0 || hms > hme) all_masked = true;
+        }
+        auto masked = [&](uint32_t c) { return all_masked || (int64_t)c < hms || (int64_t)c > hme; };
+
+        std::map<uint32_t, Pending> pending;
+        const int K = p.k;
+        for (const ColRange& r : merged) {
+            uint32_t L = next_base(r.a);
+            // walk K-1 bases to the left of L
+            int64_t s0 = L;
+            {
+                int64_t cur = (int64_t)L;
+                for (int i = 0; i < K - 1; ++i) {
+                    int64_t pb = prev_base(cur - 1);
+                    if (pb < 0) break;
+                    cur = pb;
+                }
+                s0 = cur;
+            }
+            int64_t R = prev_base(r.b);
+            if (R >= 0 && s0 <= R && s0 < (int64_t)pm.n_cols) {
+                lc.clear();
+                lseq.clear();
+                size_t n_starts = 0;
+                uint32_t c = (uint32_t)s0;
+                while ((c = next_base(c)) < pm.n_cols) {
+                    if ((int64_t)c <= R) ++n_starts;
+                    else if (lc.size() >= n_starts + (size_t)(K - 1)) break;
+                    lc.push_back(c);
+                    lseq.push_back(st.cols[c]);
+                    ++c;
+                }
+                host_syncmers(lseq.data(), (int64_t)lseq.size(), p, is_sync, shash);
+                for (size_t j = 0; j < n_starts; ++j) {
+                    uint32_t col = lc[j];
+                    if (masked(col)) continue;
+                    bool is_s = j < is_sync.size() && is_sync[j];
+                    pending[col] = Pending{is_s, is_s ? shash[j] : 0};
+                }
+            }
+            // gap columns inside the range that still hold a syncmer
+            for (auto it = syn.lower_bound(r.a); it != syn.end() && it->first <= r.b; ++it) {
+                uint32_t col = it->first;
+                if (!is_base(col) && !masked(col)) pending[col] = Pending{false, 0};
+            }
+        }
+        // keep real changes only
+        std::vector<uint32_t> changed;
+        for (auto it = pending.begin(); it != pending.end();) {
+            auto cur = syn.find(it->first);
+            bool had = cur != syn.end();
+            if ((had && it->second.present && cur->second == it->second.hash) || (!had && !it->second.present)) it = pending.erase(it);
+            else { changed.push_back(it->first); ++it; }
+        }
+        if (changed.empty()) return;
+
+        std::vector<uint64_t> old_seeds, new_seeds;
+        enum_windows(changed, old_seeds);
+        for (const auto& kv : pending) {
+            auto cur = syn.find(kv.first);
+            if (cur != syn.end()) {
+                u.syn.push_back(SynChange{kv.first, true, cur->second});
+                if (kv.second.present) cur->second = kv.second.hash;
+                else syn.erase(cur);
+            } else {
+                u.syn.push_back(SynChange{kv.first, false, 0});
+                syn.emplace(kv.first, kv.second.hash);
+            }
+        }
+        enum_windows(changed, new_seeds);
+
+        std::unordered_map<uint64_t, int32_t> delta;
+        for (uint64_t h : old_seeds) --delta[h];
+        for (uint64_t h : new_seeds) ++delta[h];
+        std::vector<std::pair<uint64_t, std::pair<int32_t, int32_t>>> changes;
+        for (const auto& kv : delta) {
+            if (kv.second == 0) continue;
+            auto it = counts.find(kv.first);
+            int32_t pc = it == counts.end() ? 0 : it->second;
+            int32_t cc = pc + kv.second;
+            if (cc < 0) throw std::runtime_error("index build: negative seed count (internal error)");
+            if (cc > INT16_MAX || pc > INT16_MAX) throw std::runtime_error("index build: seed count exceeds int16");
+            if (cc == 0) counts.erase(it);
+            else if (it == counts.end()) counts.emplace(kv.first, cc);
+            else it->second = cc;
+            u.counts.push_back({kv.first, kv.second});
+            changes.push_back({kv.first, {pc, cc}});
+        }
+        std::sort(changes.begin(), changes.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        for (const auto& c : changes) {
+            out_hash.push_back(c.first);
+            out_pc.push_back((int16_t)c.second.first);
+            out_cc.push_back((int16_t)c.second.second);
+        }
+    }
+
+    void undo(const NodeUndo& u) {
+        for (size_t i = u.counts.size(); i-- > 0;) {
+            auto it = counts.find(u.counts[i].first);
+            int32_t v = (it == counts.end() ? 0 : it->second) - u.counts[i].second;
+            if (v == 0) { if (it != counts.end()) counts.erase(it); }
+            else if (it == counts.end()) counts.emplace(u.counts[i].first, v);
+            else it->second = v;
+        }
+        for (size_t i = u.syn.size(); i-- > 0;) {
+            const SynChange& c = u.syn[i];
+            if (c.had) syn[c.col] = c.old_hash;
+            else syn.erase(c.col);
+        }
+        undo_node(st, u.cols);
+    }
+};
+
+}  // namespace
+
+void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, LiteIndex& out) {
+    if (p.l > 32) throw std::runtime_error("index build: l > 32 unsupported");
+    out = LiteIndex();
+    out.params = p;
+    out.flank_mask = flank_mask;
+    const size_t n = pm.nodes.size();
+    out.node_id.resize(n);
+    out.parent.resize(n);
+    out.offsets.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) {
+        out.node_id[i] = pm.nodes[i].id;
+        out.parent[i] = pm.nodes[i].parent < 0 ? 0u : (uint32_t)pm.nodes[i].parent;
+    }
+    if (n == 0) return;
+    Builder b(pm, p, flank_mask);
+    // Pre-order numbering == node index, so visiting nodes in index order with an explicit
+    // ancestor stack is the DFS; undo when leaving a subtree.
+    std::vector<int32_t> stack;
+    std::vector<NodeUndo> undos;
+    for (size_t i = 0; i < n; ++i) {
+        int32_t par = pm.nodes[i].parent;
+        while (!stack.empty() && stack.back() != par) {
+            b.undo(undos.back());
+            undos.pop_back();
+            stack.pop_back();
+        }
+        undos.emplace_back();
+        stack.push_back((int32_t)i);
+        b.process((int32_t)i, undos.back(), out.hash, out.parent_count, out.child_count);
+        out.offsets[i + 1] = out.hash.size();
+    }
+}
+
+void genome_seed_counts(const std::string& genome, const SyncmerParams& p, int flank_mask,
+                        std::vector<std::pair<uint64_t, int32_t>>& sorted_counts) {
+    std::vector<uint8_t> is_sync;
+    std::vector<uint64_t> sh;
+    host_syncmers(genome.data(), (int64_t)genome.size(), p, is_sync, sh);
+    std::vector<uint64_t> h;
+    const int64_t n = (int64_t)genome.size();
+    for (int64_t i = 0; i < (int64_t)is_sync.size(); ++i) {
+        if (!is_sync[i]) continue;
+        if (flank_mask > 0 && (i < flank_mask - 1 || i > n - flank_mask)) continue;
+        h.push_back(sh[i]);
+    }
+    std::unordered_map<uint64_t, int32_t> cnt;
+    const int l = p.l < 1 ? 1 : p.l;
+    for (size_t j = 0; j + l <= h.size(); ++j) {
+        uint64_t seed;
+        if (kminmer_seed(&h[j], p.k, l, &seed)) ++cnt[seed];
+    }
+    sorted_counts.assign(cnt.begin(), cnt.end());
+    std::sort(sorted_counts.begin(), sorted_counts.end());
+}
+
+}  // namespace pmx
