@@ -1,0 +1,205 @@
+"""ctypes wrappers of the parity checkers -- TEST INFRASTRUCTURE ONLY.
+
+  liboracle.so            oracle_place.c, the CPU restatement of the place stage
+  _ref/libpanmap_ref.so   the reference's own aligner (src/mm_align.c + vendored minimap2),
+                          compiled from /root/reference by oracle/Makefile
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libpanmap_ref.so")
+
+
+def build(quiet=True):
+    subprocess.run(["make", "-C", HERE, "all"], check=True, stdout=subprocess.DEVNULL if quiet else None)
+
+
+_o = None
+
+
+def olib():
+    global _o
+    if _o is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = C.CDLL(ORACLE_SO)
+        vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+        L.orc_chash.restype = C.c_uint64
+        L.orc_chash.argtypes = [i32]
+        L.orc_hash_seq.argtypes = [C.c_char_p, i32, vp, vp]
+        L.orc_homopolymer_hash.restype = C.c_uint64
+        L.orc_homopolymer_hash.argtypes = [i32, i32]
+        L.orc_rolling_syncmers.restype = i64
+        L.orc_rolling_syncmers.argtypes = [C.c_char_p, i64, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        L.orc_read_seeds.restype = i64
+        L.orc_read_seeds.argtypes = [C.c_char_p, i64, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.orc_hist_new.restype = vp
+        L.orc_hist_free.argtypes = [vp]
+        L.orc_hist_add.argtypes = [vp, C.c_uint64, i64]
+        L.orc_hist_add_read.argtypes = [vp, C.c_char_p, i64, i32, i32, i32, i32, i32, i32, i32, i64]
+        L.orc_hist_size.restype = i64
+        L.orc_hist_size.argtypes = [vp]
+        L.orc_hist_export_sorted.argtypes = [vp, vp, vp]
+        L.orc_finalize_reads.restype = i64
+        L.orc_finalize_reads.argtypes = [vp, vp, i64, i32, dbl, i32, vp, vp, vp]
+        L.orc_score_nodes.argtypes = [i64, vp, vp, vp, vp, vp, i64, vp, vp, dbl, dbl, vp, vp, vp, vp]
+        L.orc_best_ties.argtypes = [i64, vp, vp, i32, vp, vp, vp, i64, vp]
+        _o = L
+    return _o
+
+
+class ReadState(C.Structure):
+    _fields_ = [("min_support", C.c_int64), ("n_unique_in", C.c_int64), ("n_kept", C.c_int64),
+                ("total_freq", C.c_int64), ("log_magnitude", C.c_double), ("log_cont_den", C.c_double),
+                ("est_coverage", C.c_double)]
+
+
+def hash_seq(s: bytes):
+    f, r = C.c_uint64(), C.c_uint64()
+    rc = olib().orc_hash_seq(s, len(s), C.byref(f), C.byref(r))
+    if rc != 0:
+        raise ValueError("Kmer contains non canonical base")
+    return f.value, r.value
+
+
+def rolling_syncmers(seq: bytes, k, s, open_syncmer=False, t=0, return_all=True):
+    """seeding::rollingSyncmers: list of (hash, isReverse, isSyncmer, startPos)."""
+    n = max(len(seq) - k + 1, 0)
+    if n == 0:
+        return []
+    h = np.zeros(n, np.uint64); r = np.zeros(n, np.uint8); sy = np.zeros(n, np.uint8); p = np.zeros(n, np.int64)
+    m = olib().orc_rolling_syncmers(seq, len(seq), k, s, int(open_syncmer), t, int(return_all), h.ctypes.data, r.ctypes.data,
+                                    sy.ctypes.data, p.ctypes.data)
+    return [(int(h[i]), bool(r[i]), bool(sy[i]), int(p[i])) for i in range(m)]
+
+
+def read_seeds(seq: bytes, k, s, l, open_syncmer=False, t=0, trim_start=0, trim_end=0):
+    out = np.zeros(max(len(seq), 1), np.uint64)
+    n = olib().orc_read_seeds(seq, len(seq), k, s, l, int(open_syncmer), t, trim_start, trim_end, out.ctypes.data)
+    return out[:n].copy()
+
+
+def histogram(reads, k, s, l, open_syncmer=False, t=0, trim_start=0, trim_end=0, dedup=False):
+    """(hash asc, count) of all read seeds.  dedup: each distinct sequence counted once
+    (src/placement.cpp:1619-1620); otherwise counts are additive per read."""
+    L = olib()
+    h = C.c_void_p(L.orc_hist_new())
+    it = set(reads) if dedup else reads
+    for r in it:
+        L.orc_hist_add_read(h, r, len(r), k, s, l, int(open_syncmer), t, trim_start, trim_end, 1)
+    n = L.orc_hist_size(h)
+    hs, cn = np.zeros(n, np.uint64), np.zeros(n, np.int64)
+    L.orc_hist_export_sorted(h, hs.ctypes.data, cn.ctypes.data)
+    L.orc_hist_free(h)
+    return hs, cn
+
+
+def finalize_reads(hs, cn, k, mask_fraction=0.0, min_support=-1):
+    n = len(hs)
+    hs = np.ascontiguousarray(hs, np.uint64); cn = np.ascontiguousarray(cn, np.int64)
+    kh, kl = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.float64)
+    st = ReadState()
+    nk = olib().orc_finalize_reads(hs.ctypes.data, cn.ctypes.data, n, k, mask_fraction, min_support, kh.ctypes.data, kl.ctypes.data, C.byref(st))
+    return kh[:nk].copy(), kl[:nk].copy(), st
+
+
+def score_nodes(parent, offsets, ch_hash, ch_par, ch_child, kept_hash, kept_log, st: ReadState):
+    n = len(parent)
+    parent = np.ascontiguousarray(parent, np.uint32); offsets = np.ascontiguousarray(offsets, np.uint64)
+    ch_hash = np.ascontiguousarray(ch_hash, np.uint64)
+    ch_par = np.ascontiguousarray(ch_par, np.int16); ch_child = np.ascontiguousarray(ch_child, np.int16)
+    kept_hash = np.ascontiguousarray(kept_hash, np.uint64); kept_log = np.ascontiguousarray(kept_log, np.float64)
+    met, cts, sc = np.zeros((n, 5)), np.zeros((n, 2), np.int64), np.zeros((n, 5))
+    wc = C.c_double()
+    olib().orc_score_nodes(n, parent.ctypes.data, offsets.ctypes.data, ch_hash.ctypes.data, ch_par.ctypes.data, ch_child.ctypes.data,
+                           len(kept_hash), kept_hash.ctypes.data, kept_log.ctypes.data, st.log_magnitude, st.log_cont_den,
+                           C.byref(wc), met.ctypes.data, cts.ctypes.data, sc.ctypes.data)
+    return sc, met, cts, wc.value
+
+
+def best_ties(parent, scores, force_leaf=False, cap=1 << 16):
+    n = len(parent)
+    parent = np.ascontiguousarray(parent, np.uint32); scores = np.ascontiguousarray(scores, np.float64)
+    best = np.zeros(5); idx = np.zeros(5, np.uint32); ties = np.zeros((5, cap), np.uint32); nt = np.zeros(5, np.int64)
+    olib().orc_best_ties(n, parent.ctypes.data, scores.ctypes.data, int(force_leaf), best.ctypes.data, idx.ctypes.data, ties.ctypes.data, cap,
+                         nt.ctypes.data)
+    return best, idx, [ties[m, :nt[m]].copy() for m in range(5)]
+
+
+def place(reads, idx_arrays, k, s, l, open_syncmer=False, t=0, trim_start=0, trim_end=0, mask_fraction=0.0, min_support=-1,
+          force_leaf=False, dedup=False):
+    """Whole place stage on the CPU oracle.  Returns dict with everything the GPU path reports."""
+    hs, cn = histogram(reads, k, s, l, open_syncmer, t, trim_start, trim_end, dedup)
+    kh, kl, st = finalize_reads(hs, cn, k, mask_fraction, min_support)
+    sc, met, cts, wc = score_nodes(idx_arrays["parent"], idx_arrays["offsets"], idx_arrays["hash"], idx_arrays["parent_count"],
+                                   idx_arrays["child_count"], kh, kl, st)
+    best, bidx, ties = best_ties(idx_arrays["parent"], sc, force_leaf)
+    return dict(hist_hash=hs, hist_count=cn, kept_hash=kh, kept_log=kl, state=st, scores=sc, metrics=met, counts=cts, wc_den=wc,
+                best=best, best_idx=bidx, ties=ties)
+
+
+# ----------------------------------------------------------------------- reference aligner
+class ReadAlign(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("rs", C.c_int32), ("re", C.c_int32), ("qs", C.c_int32), ("qe", C.c_int32),
+                ("mapq", C.c_uint8), ("rev", C.c_uint8), ("proper_frag", C.c_uint8),
+                ("n_cigar", C.c_int32), ("cigar", C.POINTER(C.c_uint32)), ("md", C.c_char_p)]
+
+
+class AlignPairResult(C.Structure):
+    _fields_ = [("r1", ReadAlign), ("r2", ReadAlign), ("mapped", C.c_int)]
+
+
+_r = None
+
+
+def rlib():
+    global _r
+    if _r is None:
+        if not os.path.exists(REF_SO):
+            build()
+        if not os.path.exists(REF_SO):
+            raise FileNotFoundError(REF_SO + " (reference tree absent and no prebuilt copy)")
+        L = C.CDLL(REF_SO)
+        L.align_reads_direct.restype = None
+        L.align_reads_direct.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                         C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(AlignPairResult), C.c_bool, C.c_int]
+        _r = L
+    return _r
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _unpack(ra: ReadAlign):
+    cig = [ra.cigar[i] for i in range(ra.n_cigar)] if ra.cigar else []
+    if ra.cigar:
+        _libc.free(C.cast(ra.cigar, C.c_void_p))
+    return dict(pos=ra.pos, rs=ra.rs, re=ra.re, qs=ra.qs, qe=ra.qe, mapq=ra.mapq, rev=ra.rev, proper_frag=ra.proper_frag, cigar=cig)
+
+
+def call_align_reads_direct(fn, reference: bytes, reads, paired: bool, n_threads=1):
+    """Call an align_reads_direct-compatible entry point (the reference's or the product's)."""
+    n = len(reads)
+    arr = (C.c_char_p * n)(*reads)
+    quals = (C.c_char_p * n)(*[b"I" * len(r) for r in reads])
+    names = (C.c_char_p * n)(*[b"r%d" % i for i in range(n)])
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    n_res = n // 2 if paired else n
+    res = (AlignPairResult * max(n_res, 1))()
+    fn(reference, b"ref", n, arr, quals, names, lens, res, paired, n_threads)
+    out = []
+    for i in range(n_res):
+        out.append(dict(mapped=res[i].mapped, r1=_unpack(res[i].r1), r2=_unpack(res[i].r2) if paired else None))
+    return out
+
+
+def ref_align_reads_direct(reference: bytes, reads, paired: bool, n_threads=1):
+    return call_align_reads_direct(rlib().align_reads_direct, reference, reads, paired, n_threads)

@@ -1,0 +1,435 @@
+"""Host-side mirror of the reference's interfaces for the index -> place -> align path.
+
+Names follow the reference: ``TraversalParams`` (src/placement.hpp:28-54), ``PlacementResult``
+(:157-235), ``place_lite`` = placement::placeLite (:237-244), ``align_reads_direct``
+(src/mm_align.h:44-53).  All compute goes through the C ABI of libpanmap_amd.so.
+"""
+import ctypes as C
+import dataclasses
+import gzip
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+METRICS = ("log_raw", "log_cosine", "containment", "weighted_containment", "log_containment")
+
+
+# ------------------------------------------------------------------------------------- host
+class Panman:
+    """PanMAN pangenome (replaces loadPanMAN, src/main.cpp:313-325)."""
+
+    def __init__(self, path: str):
+        self._h = C.c_void_p()
+        check(lib.pmx_panman_open(path.encode(), C.byref(self._h)), f"pmx_panman_open({path})")
+        self.path = path
+
+    def close(self):
+        if self._h:
+            lib.pmx_panman_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_nodes(self) -> int:
+        return lib.pmx_panman_num_nodes(self._h)
+
+    @property
+    def num_blocks(self) -> int:
+        return lib.pmx_panman_num_blocks(self._h)
+
+    def node_id(self, i: int) -> str:
+        s = lib.pmx_panman_node_id(self._h, i)
+        if s is None:
+            raise IndexError(i)
+        return s.decode()
+
+    def parent(self, i: int) -> int:
+        return lib.pmx_panman_parent(self._h, i)
+
+    def find_node(self, node_id: str) -> int:
+        return lib.pmx_panman_find_node(self._h, node_id.encode())
+
+    def genome(self, node) -> bytes:
+        """panmapUtils::getStringFromReference (src/panmap_utils.cpp:182-190), ungapped."""
+        i = node if isinstance(node, int) else self.find_node(node)
+        if i < 0:
+            raise KeyError(node)
+        n = lib.pmx_panman_node_genome(self._h, i, None, 0)
+        if n < 0:
+            raise _lib.PmxError(-3, "pmx_panman_node_genome")
+        buf = C.create_string_buffer(max(n, 1))
+        lib.pmx_panman_node_genome(self._h, i, buf, n)
+        return buf.raw[:n]
+
+
+class Index:
+    """Single-sample seed index (IndexBuilder, src/index_single_mode.hpp:207-214)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.info = _lib.IndexInfo()
+        check(lib.pmx_index_get_info(self._h, C.byref(self.info)), "pmx_index_get_info")
+
+    @classmethod
+    def build(cls, pm: Panman, k=19, s=8, t=0, l=3, open_syncmer=False, flank_mask=250) -> "Index":
+        h = C.c_void_p()
+        check(lib.pmx_index_build(pm._h, k, s, t, l, int(open_syncmer), flank_mask, C.byref(h)), "pmx_index_build")
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, k, s, t, l, open_syncmer, parent, offsets, hashes, parent_counts, child_counts, flank_mask=0):
+        parent = np.ascontiguousarray(parent, np.uint32)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        pc = np.ascontiguousarray(parent_counts, np.int16)
+        cc = np.ascontiguousarray(child_counts, np.int16)
+        info = _lib.IndexInfo(k, s, t, l, int(open_syncmer), 0, flank_mask, 0, len(parent), len(hashes))
+        h = C.c_void_p()
+        check(lib.pmx_index_from_arrays(C.byref(info), parent.ctypes.data, offsets.ctypes.data, hashes.ctypes.data,
+                                        pc.ctypes.data, cc.ctypes.data, C.byref(h)), "pmx_index_from_arrays")
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            lib.pmx_index_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _arr(self, fn, dtype, n):
+        p = fn(self._h)
+        if not p or n == 0:
+            return np.zeros(0, dtype)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).copy()
+
+    def arrays(self):
+        n, m = self.info.n_nodes, self.info.n_changes
+        return dict(parent=self._arr(lib.pmx_index_parents, np.uint32, n),
+                    offsets=self._arr(lib.pmx_index_offsets, np.uint64, n + 1),
+                    hash=self._arr(lib.pmx_index_hashes, np.uint64, m),
+                    parent_count=self._arr(lib.pmx_index_parent_counts, np.int16, m),
+                    child_count=self._arr(lib.pmx_index_child_counts, np.int16, m))
+
+
+# ------------------------------------------------------------------------------------ reads
+def _open_maybe_gz(path):
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    return gzip.open(path, "rb") if magic == b"\x1f\x8b" else open(path, "rb")
+
+
+def read_fastx(path: str):
+    """FASTA/FASTQ(.gz) -> (names, seqs, quals); quals '' for FASTA.  kseq semantics: multi-line
+    records tolerated, name = up to first whitespace (src/seeding.cpp:237-243)."""
+    names, seqs, quals = [], [], []
+    with _open_maybe_gz(path) as f:
+        data = f.read()
+    lines = data.split(b"\n")
+    i, n = 0, len(lines)
+    while i < n:
+        ln = lines[i].rstrip(b"\r")
+        if not ln:
+            i += 1
+            continue
+        if ln[:1] == b">":
+            name = ln[1:].split()[0] if len(ln) > 1 else b""
+            i += 1
+            parts = []
+            while i < n and lines[i][:1] not in (b">", b"@"):
+                parts.append(lines[i].rstrip(b"\r"))
+                i += 1
+            names.append(name); seqs.append(b"".join(parts)); quals.append(b"")
+        elif ln[:1] == b"@":
+            name = ln[1:].split()[0] if len(ln) > 1 else b""
+            i += 1
+            parts = []
+            while i < n and lines[i][:1] != b"+":
+                parts.append(lines[i].rstrip(b"\r"))
+                i += 1
+            seq = b"".join(parts)
+            i += 1  # '+'
+            q = b""
+            while i < n and len(q) < len(seq):
+                q += lines[i].rstrip(b"\r")
+                i += 1
+            names.append(name); seqs.append(seq); quals.append(q)
+        else:
+            i += 1
+    return names, seqs, quals
+
+
+_RC = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def reverse_complement(seq: bytes) -> bytes:
+    """seeding::reverseComplement (src/seeding.cpp:271-284): only upper-case ACGT are complemented."""
+    return seq.translate(_RC)[::-1]
+
+
+def extract_read_sequences(reads1: str, reads2: str = "") -> List[bytes]:
+    """extractReadSequences (src/placement.cpp:164-197): R1 then R2, interleaved; R2 NOT rev-comped."""
+    s1 = read_fastx(reads1)[1]
+    if not reads2:
+        return s1
+    s2 = read_fastx(reads2)[1]
+    if len(s1) != len(s2):
+        raise ValueError(f"File {reads2} does not contain the same number of reads as {reads1}")
+    out = [None] * (2 * len(s1))
+    out[0::2] = s1
+    out[1::2] = s2
+    return out
+
+
+def read_fastq_paired(reads1: str, reads2: str = ""):
+    """seeding::readFastqPaired (src/seeding.cpp:231-269): R2 reverse-complemented, quals reversed,
+    pairs interleaved; missing quals -> 'I'."""
+    n1, s1, q1 = read_fastx(reads1)
+    q1 = [q if q else b"I" * len(s) for s, q in zip(s1, q1)]
+    if not reads2:
+        return s1, q1, n1
+    n2, s2, q2 = read_fastx(reads2)
+    if len(s1) != len(s2):
+        raise ValueError(f"Error: {reads2} does not contain the same number of reads as {reads1}")
+    s2 = [reverse_complement(s) for s in s2]
+    q2 = [(q if q else b"I" * len(s))[::-1] for s, q in zip(s2, q2)]
+    n = len(s1)
+    seqs, quals, names = [None] * (2 * n), [None] * (2 * n), [None] * (2 * n)
+    seqs[0::2], seqs[1::2] = s1, s2
+    quals[0::2], quals[1::2] = q1, q2
+    names[0::2], names[1::2] = n1, n2
+    return seqs, quals, names
+
+
+def concat_reads(reads: Sequence[bytes]):
+    lens = np.fromiter((len(r) for r in reads), np.int64, len(reads))
+    off = np.zeros(len(reads) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    return b"".join(reads), off
+
+
+# ----------------------------------------------------------------------------------- device
+class Context:
+    """One GPU (one process rank)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        check(lib.pmx_ctx_create(device, C.byref(self._h)), "pmx_ctx_create")
+        self.device = device
+
+    def synchronize(self):
+        check(lib.pmx_ctx_synchronize(self._h), "pmx_ctx_synchronize")
+
+    @property
+    def stream(self) -> int:
+        return lib.pmx_ctx_stream(self._h) or 0
+
+    def kernel_ms(self, name: str) -> float:
+        return lib.pmx_last_kernel_ms(self._h, name.encode())
+
+    def close(self):
+        if self._h:
+            lib.pmx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ReadSet:
+    def __init__(self, ctx: Context, reads=None, concat: Optional[bytes] = None, offsets=None, pack=True):
+        self.ctx = ctx
+        if reads is not None:
+            concat, offsets = concat_reads(reads)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        self._h = C.c_void_p()
+        self._keep = (concat, offsets)
+        buf = (C.c_char * max(len(concat), 1)).from_buffer_copy(concat if len(concat) else b"\0") if not isinstance(concat, np.ndarray) else None
+        ptr = C.addressof(buf) if buf is not None else concat.ctypes.data
+        check(lib.pmx_readset_upload(ctx._h, ptr, offsets.ctypes.data, len(offsets) - 1, C.byref(self._h)), "pmx_readset_upload")
+        self.n_reads = len(offsets) - 1
+        self.total_bases = int(offsets[-1] - offsets[0])
+        if pack:
+            self.pack()
+
+    @classmethod
+    def wrap_device(cls, ctx: Context, d_concat_ptr: int, d_offsets_ptr: int, n_reads: int, total_bytes: int, max_len: int, keepalive=None):
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        self._keep = keepalive
+        check(lib.pmx_readset_wrap_device(ctx._h, d_concat_ptr, d_offsets_ptr, n_reads, total_bytes, max_len, C.byref(self._h)),
+              "pmx_readset_wrap_device")
+        self.n_reads = n_reads
+        self.total_bases = total_bytes
+        return self
+
+    def pack(self):
+        check(lib.pmx_readset_pack(self.ctx._h, self._h), "pmx_readset_pack")
+
+    def close(self):
+        if self._h:
+            lib.pmx_readset_free(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclasses.dataclass
+class TraversalParams:
+    """Result-affecting subset of placement::TraversalParams (src/placement.hpp:28-54); k/s/t/l/open
+    always come from the index (src/placement.cpp:1094-1101).  seedMaskFraction defaults to the CLI
+    value 0 (src/main.cpp:1967), not the struct's 0.001."""
+    seedMaskFraction: float = 0.0
+    minSeedQuality: int = 0
+    dedupReads: bool = False
+    trimStart: int = 0
+    trimEnd: int = 0
+    minReadSupport: int = -1
+    forceLeaf: bool = False
+
+    def to_c(self) -> _lib.PlaceParams:
+        if self.minSeedQuality > 0:
+            raise NotImplementedError("--min-seed-quality is not implemented on the device yet")
+        p = _lib.PlaceParams()
+        p.seed_mask_fraction = self.seedMaskFraction
+        p.min_read_support = self.minReadSupport
+        p.trim_start, p.trim_end = self.trimStart, self.trimEnd
+        p.dedup_reads = int(self.dedupReads)
+        p.force_leaf = int(self.forceLeaf)
+        return p
+
+
+@dataclasses.dataclass
+class PlacementResult:
+    """placement::PlacementResult (src/placement.hpp:157-235), per metric in TSV order."""
+    best_score: List[float]
+    best_index: List[int]
+    tied_indices: List[np.ndarray]
+    n_reads: int = 0
+    n_unique_seeds: int = 0
+    readUniqueSeedCount: int = 0
+    totalReadSeedFrequency: int = 0
+    min_support: int = 0
+    readMagnitude: float = 0.0
+    logContainmentDenominator: float = 0.0
+    weightedContainmentDenominator: float = 0.0
+
+    @property
+    def bestLogContainmentNodeIndex(self):
+        return self.best_index[4]
+
+
+class Placer:
+    """Device-resident index + seed histogram of one sample (the place stage)."""
+
+    def __init__(self, ctx: Context, index: Index):
+        self.ctx, self.index = ctx, index
+        self._h = C.c_void_p()
+        check(lib.pmx_place_create(ctx._h, index._h, C.byref(self._h)), "pmx_place_create")
+        self.n_nodes = index.info.n_nodes
+
+    def reset(self):
+        check(lib.pmx_place_reset(self.ctx._h, self._h), "pmx_place_reset")
+
+    def add_reads(self, rs: ReadSet, params: TraversalParams = TraversalParams()):
+        cp = params.to_c()
+        check(lib.pmx_place_add_reads(self.ctx._h, self._h, rs._h, C.byref(cp)), "pmx_place_add_reads")
+
+    def histogram(self):
+        n = lib.pmx_place_histogram_size(self.ctx._h, self._h)
+        if n < 0:
+            raise _lib.PmxError(n, "pmx_place_histogram_size")
+        h, c = np.zeros(n, np.uint64), np.zeros(n, np.int64)
+        check(lib.pmx_place_histogram_export(self.ctx._h, self._h, h.ctypes.data, c.ctypes.data, n), "pmx_place_histogram_export")
+        return h, c
+
+    def merge(self, hashes, counts):
+        hashes = np.ascontiguousarray(hashes, np.uint64)
+        counts = np.ascontiguousarray(counts, np.int64)
+        check(lib.pmx_place_histogram_merge(self.ctx._h, self._h, hashes.ctypes.data, counts.ctypes.data, len(hashes)),
+              "pmx_place_histogram_merge")
+
+    def score(self, params: TraversalParams = TraversalParams(), n_reads: int = 0) -> PlacementResult:
+        cp, res = params.to_c(), _lib.PlaceResult()
+        check(lib.pmx_place_score(self.ctx._h, self._h, C.byref(cp), n_reads, C.byref(res)), "pmx_place_score")
+        tied = []
+        for m in range(5):
+            t = np.zeros(res.n_tied[m], np.uint32)
+            check(lib.pmx_place_tied(self._h, m, t.ctypes.data, len(t)), "pmx_place_tied")
+            tied.append(t)
+        return PlacementResult(list(res.best_score), list(res.best_index), tied, res.n_reads, res.n_unique_seeds,
+                               res.n_kept_seeds, res.total_seed_freq, res.min_support, res.log_read_magnitude,
+                               res.log_containment_den, res.weighted_containment_den)
+
+    def node_outputs(self):
+        n = self.n_nodes
+        sc, me, ct = np.zeros((n, 5)), np.zeros((n, 5)), np.zeros((n, 2), np.int64)
+        check(lib.pmx_place_node_outputs(self.ctx._h, self._h, sc.ctypes.data, me.ctypes.data, ct.ctypes.data), "pmx_place_node_outputs")
+        return sc, me, ct
+
+    def kept_seeds(self):
+        n = lib.pmx_place_kept_seeds(self.ctx._h, self._h, None, None, 0)
+        h, l = np.zeros(max(n, 0), np.uint64), np.zeros(max(n, 0), np.float64)
+        if n > 0:
+            lib.pmx_place_kept_seeds(self.ctx._h, self._h, h.ctypes.data, l.ctypes.data, n)
+        return h, l
+
+    def close(self):
+        if self._h:
+            lib.pmx_place_free(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_placement_tsv(result: PlacementResult, node_id) -> str:
+    """The `<prefix>.placement.tsv` text (src/placement.cpp:1952-2003): score %.6f, tied ids comma-joined."""
+    lines = ["metric\tscore\tnodes"]
+    for m, name in enumerate(METRICS):
+        tied = result.tied_indices[m]
+        if len(tied):
+            ids = ",".join(node_id(int(t)) for t in tied)
+        else:
+            ids = node_id(result.best_index[m]) if result.best_index[m] != 0xFFFFFFFF else ""
+        lines.append("%s\t%.6f\t%s" % (name, result.best_score[m], ids))
+    return "\n".join(lines) + "\n"
+
+
+def place_lite(ctx: Context, placer: Placer, reads1: str, reads2: str, output_path: str,
+               params: TraversalParams = TraversalParams(), node_id=None) -> PlacementResult:
+    """placement::placeLite (src/placement.hpp:237-244): reads -> seed histogram -> node scores ->
+    best/tied nodes, and the TSV at output_path."""
+    seqs = extract_read_sequences(reads1, reads2) if reads1 else []
+    placer.reset()
+    if seqs:
+        rs = ReadSet(ctx, seqs)
+        placer.add_reads(rs, params)
+        rs.close()
+    res = placer.score(params, len(seqs))
+    if output_path and node_id is not None:
+        with open(output_path, "w") as f:
+            f.write(format_placement_tsv(res, node_id))
+    return res

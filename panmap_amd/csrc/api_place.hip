@@ -1,0 +1,620 @@
+// C ABI, device part 1: context, read sets, PLACE stage orchestration (see include/panmap_amd.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "device/dev_util.hpp"
+#include "device/pmx_math.h"
+#include "host/index_build.hpp"
+#include "place_kernels.h"
+#include "readset.hpp"
+
+using namespace pmx;
+
+// --------------------------------------------------------------------------------- objects
+struct pmx_place {
+    // index (device, replicated per GPU)
+    int64_t n_nodes = 0, n_changes = 0;
+    SyncmerParams params;
+    DevBuf<uint32_t> parent;
+    DevBuf<uint64_t> offsets, ch_hash;
+    DevBuf<int16_t> ch_par, ch_child;
+    DevBuf<uint32_t> level_nodes;          // nodes sorted by (depth, DFS index) == single-thread BFS order
+    std::vector<int64_t> level_off;        // host: per-level ranges into level_nodes
+    std::vector<uint32_t> h_parent, h_order;
+    std::vector<uint8_t> h_has_child;
+    uint64_t root_beg = 0, root_end = 0;
+    // seed table
+    DevBuf<uint64_t> keys;
+    DevBuf<unsigned long long> vals;
+    uint64_t cap = 0;
+    DevBuf<unsigned long long> counters;   // PMX_CTR_N
+    int64_t n_reads_added = 0;
+    // finalised histogram
+    DevBuf<uint64_t> hist_hash, hist_hash_tmp;
+    DevBuf<int64_t> hist_count, hist_count_tmp;
+    int64_t n_hist = 0;
+    bool hist_sorted = false;
+    DevBuf<uint8_t> dead;
+    DevBuf<uint32_t> flag, pos;
+    DevBuf<uint64_t> kept_hash;
+    DevBuf<double> kept_log;
+    int64_t n_kept = 0;
+    DevBuf<uint64_t> tkeys;
+    DevBuf<double> tvals;
+    uint64_t tcap = 0;
+    DevBuf<double> scalars;                // [0]=sum L^2 [1]=sum L [2]=wc_den
+    DevBuf<unsigned long long> stats;
+    DevBuf<char> tmp;                      // rocprim temp storage
+    // node outputs
+    DevBuf<double> metrics5, scores5;
+    DevBuf<int64_t> counts2;
+    std::vector<double> h_scores;
+    std::vector<std::vector<uint32_t>> tied;
+};
+
+namespace {
+
+int fail(int code, const std::string& msg) {
+    set_error(msg);
+    return code;
+}
+
+#define PMX_TRY try {
+#define PMX_CATCH                                                      \
+    }                                                                  \
+    catch (const HipError& e) { return fail(PMX_ERR_DEVICE, e.msg); }  \
+    catch (const std::exception& e) { return fail(PMX_ERR_DEVICE, e.what()); }
+
+void table_alloc(pmx_ctx* ctx, pmx_place* pl, uint64_t cap) {
+    pl->keys.alloc(cap);
+    pl->vals.alloc(cap);
+    pl->cap = cap;
+    hipLaunchKernelGGL(k_fill_u64, dim3(grid_for((int64_t)cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p, PMX_EMPTY_KEY, cap);
+    PMX_HIP(hipMemsetAsync(pl->vals.p, 0, cap * sizeof(unsigned long long), ctx->stream));
+}
+
+uint64_t next_pow2(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// make room for `bound_new` more distinct keys at load factor <= 0.7 (never overflows afterwards)
+void table_reserve(pmx_ctx* ctx, pmx_place* pl, uint64_t bound_new) {
+    unsigned long long h_ctr[PMX_CTR_N];
+    PMX_HIP(hipMemcpyAsync(h_ctr, pl->counters.p, sizeof(h_ctr), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t entries = h_ctr[PMX_CTR_ENTRIES];
+    uint64_t need = next_pow2((uint64_t)((double)(entries + bound_new) / 0.7) + 1024);
+    if (need < (1u << 16)) need = 1u << 16;
+    if (pl->cap >= need) return;
+    if (pl->cap == 0 || entries == 0) {
+        table_alloc(ctx, pl, need);
+        return;
+    }
+    DevBuf<uint64_t> okeys;
+    DevBuf<unsigned long long> ovals;
+    okeys.swap(pl->keys);
+    ovals.swap(pl->vals);
+    const uint64_t ocap = pl->cap;
+    table_alloc(ctx, pl, need);
+    unsigned long long zero = 0;
+    PMX_HIP(hipMemcpyAsync(pl->counters.p + PMX_CTR_ENTRIES, &zero, sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_table_rehash, dim3(grid_for((int64_t)ocap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, okeys.p, ovals.p, ocap,
+                       pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+// table -> hash-sorted (hash,count) arrays
+void finalize_histogram(pmx_ctx* ctx, pmx_place* pl) {
+    if (pl->hist_sorted) return;
+    unsigned long long h_ctr[PMX_CTR_N];
+    PMX_HIP(hipMemcpyAsync(h_ctr, pl->counters.p, sizeof(h_ctr), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_ctr[PMX_CTR_OVERFLOW]) throw std::runtime_error("seed table overflow (internal sizing error)");
+    const int64_t n = (int64_t)h_ctr[PMX_CTR_ENTRIES];
+    pl->n_hist = n;
+    pl->hist_hash.ensure(n);
+    pl->hist_count.ensure(n);
+    pl->hist_hash_tmp.ensure(n);
+    pl->hist_count_tmp.ensure(n);
+    if (n > 0) {
+        unsigned long long zero = 0;
+        PMX_HIP(hipMemcpyAsync(pl->counters.p + PMX_CTR_COMPACT, &zero, sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_table_compact, dim3(grid_for((int64_t)pl->cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p,
+                           pl->vals.p, pl->cap, pl->hist_hash_tmp.p, pl->hist_count_tmp.p, pl->counters.p + PMX_CTR_COMPACT);
+        size_t bytes = 0;
+        PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->hist_hash_tmp.p, pl->hist_hash.p, pl->hist_count_tmp.p, pl->hist_count.p,
+                                          (size_t)n, 0, 64, ctx->stream));
+        pl->tmp.ensure(bytes);
+        PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->hist_hash_tmp.p, pl->hist_hash.p, pl->hist_count_tmp.p, pl->hist_count.p,
+                                          (size_t)n, 0, 64, ctx->stream));
+    }
+    pl->hist_sorted = true;
+}
+
+uint64_t homopolymer_hash(int code, int k) {   // src/placement.cpp:41-76
+    uint64_t b = kBaseHash[code], c = kBaseHash[3 - code], f = 0, r = 0;
+    for (int i = 0; i < k; ++i) { f ^= h_rol(b, (unsigned)(k - i - 1)); r ^= h_rol(c, (unsigned)(k - i - 1)); }
+    return f < r ? f : r;
+}
+
+// PlacementResult::update*Score (src/placement.cpp:355-371)
+struct Best {
+    double best = 0.0;
+    uint32_t idx = UINT32_MAX;
+    std::vector<uint32_t> tied;
+    void update(uint32_t node, double score) {
+        double tol = std::max(best * 0.0001, 1e-9);
+        if (score > best + tol) {
+            best = score;
+            idx = node;
+            tied.clear();
+            tied.push_back(node);
+        } else if (score >= best - tol && score > 0) {
+            if (tied.empty() || tied.back() != idx) tied.push_back(idx);
+            if (node != idx) tied.push_back(node);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------- context
+int pmx_ctx_create(int device_ordinal, pmx_ctx** out) {
+    if (!out) return PMX_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PMX_ERR_NO_DEVICE, "no HIP device available (the GPU path has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(PMX_ERR_ARG, "device ordinal out of range");
+    PMX_TRY
+    PMX_HIP(hipSetDevice(device_ordinal));
+    pmx_ctx* c = new pmx_ctx();
+    c->device = device_ordinal;
+    hipDeviceProp_t prop;
+    PMX_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    PMX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+void pmx_ctx_destroy(pmx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto& kv : ctx->timers) {
+        if (kv.second.e0) (void)hipEventDestroy(kv.second.e0);
+        if (kv.second.e1) (void)hipEventDestroy(kv.second.e1);
+    }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pmx_ctx_synchronize(pmx_ctx* ctx) {
+    if (!ctx) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
+void* pmx_ctx_stream(pmx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+double pmx_last_kernel_ms(pmx_ctx* ctx, const char* name) {
+    if (!ctx || !name) return -1.0;
+    auto it = ctx->timers.find(name);
+    if (it == ctx->timers.end() || !it->second.pending) return -1.0;
+    float ms = 0.f;
+    if (hipEventSynchronize(it->second.e1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, it->second.e0, it->second.e1) != hipSuccess) return -1.0;
+    return it->second.launches > 0 ? (double)ms / it->second.launches : (double)ms;
+}
+
+// --------------------------------------------------------------------------------- read sets
+static int readset_finish(pmx_ctx* ctx, pmx_readset* rs, const int64_t* h_off) {
+    // every read starts on a 32-base word
+    std::vector<int64_t> woff((size_t)rs->n + 1);
+    int64_t w = 0, maxlen = 0, total = 0;
+    for (int64_t i = 0; i < rs->n; ++i) {
+        woff[i] = w;
+        int64_t len = h_off[i + 1] - h_off[i];
+        if (len < 0) throw std::runtime_error("read offsets are not monotone");
+        w += (len + 31) / 32;
+        maxlen = std::max(maxlen, len);
+        total += len;
+    }
+    woff[rs->n] = w;
+    rs->n_words = w;
+    rs->max_len = maxlen;
+    rs->total = total;
+    rs->woff.alloc((size_t)rs->n + 1);
+    PMX_HIP(hipMemcpyAsync(rs->woff.p, woff.data(), sizeof(int64_t) * ((size_t)rs->n + 1), hipMemcpyHostToDevice, ctx->stream));
+    rs->words.alloc((size_t)w);
+    rs->amb.alloc((size_t)w);
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+}
+
+int pmx_readset_upload(pmx_ctx* ctx, const char* concat, const int64_t* offsets, int64_t n_reads, pmx_readset** out) {
+    if (!ctx || !offsets || !out || n_reads < 0 || (!concat && n_reads > 0 && offsets[n_reads] > 0)) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    pmx_readset* rs = new pmx_readset();
+    rs->n = n_reads;
+    const int64_t total = offsets[n_reads] - offsets[0];
+    rs->ascii.alloc((size_t)total + 32);
+    rs->off.alloc((size_t)n_reads + 1);
+    if (total > 0) PMX_HIP(hipMemcpyAsync(rs->ascii.p, concat + offsets[0], (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int64_t> rel((size_t)n_reads + 1);
+    for (int64_t i = 0; i <= n_reads; ++i) rel[i] = offsets[i] - offsets[0];
+    PMX_HIP(hipMemcpyAsync(rs->off.p, rel.data(), sizeof(int64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
+    readset_finish(ctx, rs, rel.data());
+    *out = rs;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_readset_wrap_device(pmx_ctx* ctx, const void* d_concat, const void* d_offsets, int64_t n_reads, int64_t total_bytes,
+                            int64_t max_read_len, pmx_readset** out) {
+    (void)total_bytes; (void)max_read_len;
+    if (!ctx || !d_concat || !d_offsets || !out || n_reads < 0) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    pmx_readset* rs = new pmx_readset();
+    rs->n = n_reads;
+    rs->ascii.wrap((uint8_t*)d_concat, (size_t)total_bytes);
+    rs->off.wrap((int64_t*)d_offsets, (size_t)n_reads + 1);
+    std::vector<int64_t> h_off((size_t)n_reads + 1);
+    PMX_HIP(hipMemcpy(h_off.data(), d_offsets, sizeof(int64_t) * ((size_t)n_reads + 1), hipMemcpyDeviceToHost));
+    if (h_off[0] != 0) { delete rs; return fail(PMX_ERR_ARG, "device offsets must start at 0"); }
+    readset_finish(ctx, rs, h_off.data());
+    *out = rs;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_readset_pack(pmx_ctx* ctx, pmx_readset* rs) {
+    if (!ctx || !rs) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    if (rs->n_words > 0)
+        hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(rs->n_words, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p,
+                           rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p);
+    PMX_HIP(hipGetLastError());
+    rs->packed = true;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+void pmx_readset_free(pmx_ctx* ctx, pmx_readset* rs) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    delete rs;
+}
+int64_t pmx_readset_num_reads(const pmx_readset* rs) { return rs ? rs->n : 0; }
+
+// ------------------------------------------------------------------------------------- place
+int pmx_place_create(pmx_ctx* ctx, const pmx_index* idx, pmx_place** out) {
+    if (!ctx || !idx || !out) return PMX_ERR_ARG;
+    const LiteIndex* L = pmx_index_internal(idx);
+    if (L->params.k > 32 || L->params.k < 1) return fail(PMX_ERR_UNSUPPORTED, "device seeding supports 1 <= k <= 32");
+    if (L->params.l > 64) return fail(PMX_ERR_UNSUPPORTED, "device seeding supports l <= 64");
+    if (L->hpc) return fail(PMX_ERR_UNSUPPORTED, "HPC indexes are not supported on the device yet");
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    pmx_place* pl = new pmx_place();
+    const int64_t n = (int64_t)L->parent.size(), m = (int64_t)L->hash.size();
+    pl->n_nodes = n;
+    pl->n_changes = m;
+    pl->params = L->params;
+    pl->parent.alloc(n); pl->offsets.alloc(n + 1); pl->ch_hash.alloc(m); pl->ch_par.alloc(m); pl->ch_child.alloc(m);
+    PMX_HIP(hipMemcpyAsync(pl->parent.p, L->parent.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(pl->offsets.p, L->offsets.data(), sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (m > 0) {
+        PMX_HIP(hipMemcpyAsync(pl->ch_hash.p, L->hash.data(), sizeof(uint64_t) * m, hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(pl->ch_par.p, L->parent_count.data(), sizeof(int16_t) * m, hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(pl->ch_child.p, L->child_count.data(), sizeof(int16_t) * m, hipMemcpyHostToDevice, ctx->stream));
+    }
+    pl->root_beg = L->offsets[0];
+    pl->root_end = L->offsets[1];
+    // BFS levels: visit order of the single-threaded traversal = ascending (depth, DFS index)
+    pl->h_parent = L->parent;
+    std::vector<int32_t> depth(n);
+    pl->h_has_child.assign(n, 0);
+    int32_t maxd = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        depth[i] = i == 0 ? 0 : depth[L->parent[i]] + 1;
+        if (i > 0) pl->h_has_child[L->parent[i]] = 1;
+        maxd = std::max(maxd, depth[i]);
+    }
+    pl->level_off.assign((size_t)maxd + 2, 0);
+    for (int64_t i = 0; i < n; ++i) ++pl->level_off[depth[i] + 1];
+    for (int32_t d = 0; d <= maxd; ++d) pl->level_off[d + 1] += pl->level_off[d];
+    pl->h_order.resize(n);
+    {
+        std::vector<int64_t> fill(pl->level_off.begin(), pl->level_off.end());
+        for (int64_t i = 0; i < n; ++i) pl->h_order[fill[depth[i]]++] = (uint32_t)i;
+    }
+    pl->level_nodes.alloc(n);
+    PMX_HIP(hipMemcpyAsync(pl->level_nodes.p, pl->h_order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    pl->counters.alloc(PMX_CTR_N);
+    PMX_HIP(hipMemsetAsync(pl->counters.p, 0, sizeof(unsigned long long) * PMX_CTR_N, ctx->stream));
+    pl->scalars.alloc(8);
+    pl->stats.alloc(8);
+    pl->metrics5.alloc(5 * (size_t)n);
+    pl->scores5.alloc(5 * (size_t)n);
+    pl->counts2.alloc(2 * (size_t)n);
+    pl->tied.assign(5, {});
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    *out = pl;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+void pmx_place_free(pmx_ctx* ctx, pmx_place* pl) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    delete pl;
+}
+
+int pmx_place_reset(pmx_ctx* ctx, pmx_place* pl) {
+    if (!ctx || !pl) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    PMX_HIP(hipMemsetAsync(pl->counters.p, 0, sizeof(unsigned long long) * PMX_CTR_N, ctx->stream));
+    if (pl->cap) {
+        hipLaunchKernelGGL(k_fill_u64, dim3(grid_for((int64_t)pl->cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p, PMX_EMPTY_KEY,
+                           pl->cap);
+        PMX_HIP(hipMemsetAsync(pl->vals.p, 0, pl->cap * sizeof(unsigned long long), ctx->stream));
+    }
+    pl->n_reads_added = 0;
+    pl->hist_sorted = false;
+    pl->n_hist = 0;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, const pmx_place_params* pp) {
+    if (!ctx || !pl || !rs || !pp) return PMX_ERR_ARG;
+    if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack first)");
+    if (pp->dedup_reads) return fail(PMX_ERR_UNSUPPORTED, "--dedup is not implemented on the device yet");
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    table_reserve(ctx, pl, (uint64_t)rs->total);
+    SeedParams sp;
+    sp.k = pl->params.k; sp.s = pl->params.s; sp.t = pl->params.t; sp.l = pl->params.l; sp.open = pl->params.open ? 1 : 0;
+    sp.trim_start = pp->trim_start; sp.trim_end = pp->trim_end;
+    const int w = sp.k - sp.s + 1, l = sp.l < 1 ? 1 : sp.l;
+    const size_t lds = (size_t)(2 * w + l) * PMX_SEED_BLOCK * sizeof(uint64_t);
+    if (lds > 160 * 1024) return fail(PMX_ERR_UNSUPPORTED, "k-s+1 too large for the LDS ring");
+    if (lds > 64 * 1024)
+        PMX_HIP(hipFuncSetAttribute((const void*)k_seed_histogram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (rs->n > 0) {
+        timer_begin(ctx, "seed");
+        hipLaunchKernelGGL(k_seed_histogram, dim3(grid_for(rs->n, PMX_SEED_BLOCK, ctx->n_cu * 16)), dim3(PMX_SEED_BLOCK), lds, ctx->stream,
+                           rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, rs->n, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
+        timer_end(ctx, "seed", 1);
+        PMX_HIP(hipGetLastError());
+    }
+    pl->n_reads_added += rs->n;
+    pl->hist_sorted = false;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int64_t pmx_place_histogram_size(pmx_ctx* ctx, pmx_place* pl) {
+    if (!ctx || !pl) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    finalize_histogram(ctx, pl);
+    return pl->n_hist;
+    PMX_CATCH
+}
+
+int pmx_place_histogram_export(pmx_ctx* ctx, pmx_place* pl, uint64_t* hash, int64_t* count, int64_t cap) {
+    if (!ctx || !pl || (cap > 0 && (!hash || !count))) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    finalize_histogram(ctx, pl);
+    if (cap < pl->n_hist) return fail(PMX_ERR_CAPACITY, "histogram export buffer too small");
+    if (pl->n_hist > 0) {
+        PMX_HIP(hipMemcpyAsync(hash, pl->hist_hash.p, sizeof(uint64_t) * pl->n_hist, hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(count, pl->hist_count.p, sizeof(int64_t) * pl->n_hist, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_place_histogram_merge(pmx_ctx* ctx, pmx_place* pl, const uint64_t* hash, const int64_t* count, int64_t n) {
+    if (!ctx || !pl || n < 0 || (n > 0 && (!hash || !count))) return PMX_ERR_ARG;
+    if (n == 0) return PMX_OK;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    table_reserve(ctx, pl, (uint64_t)n);
+    DevBuf<uint64_t> dh;
+    DevBuf<int64_t> dc;
+    dh.alloc(n); dc.alloc(n);
+    PMX_HIP(hipMemcpyAsync(dh.p, hash, sizeof(uint64_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(dc.p, count, sizeof(int64_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_table_merge, dim3(grid_for(n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, dh.p, dc.p, n, pl->keys.p, pl->vals.p,
+                       pl->cap - 1, pl->counters.p);
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    pl->hist_sorted = false;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int64_t n_reads_total, pmx_place_result* res) {
+    if (!ctx || !pl || !pp || !res) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    std::memset(res, 0, sizeof(*res));
+    for (int m = 0; m < 5; ++m) res->best_index[m] = UINT32_MAX;
+    finalize_histogram(ctx, pl);
+    const int64_t n = pl->n_hist;
+    const int G = ctx->n_cu * 8;
+    hipStream_t st = ctx->stream;
+    res->n_reads = n_reads_total;
+
+    // ---- read-side filters (src/placement.cpp:1703-1856)
+    pl->dead.ensure(n);
+    pl->flag.ensure(n + 1);
+    pl->pos.ensure(n + 1);
+    pl->kept_hash.ensure(n);
+    pl->kept_log.ensure(n);
+    int64_t n_kept = 0, min_support = pp->min_read_support;
+    unsigned long long h_stats[4] = {0, 0, 0, 0};
+    if (n > 0) {
+        hipLaunchKernelGGL(k_mark_homopolymer, dim3(grid_for(n, 256, G)), dim3(256), 0, st, pl->hist_hash.p, n, homopolymer_hash(0, pl->params.k),
+                           homopolymer_hash(1, pl->params.k), homopolymer_hash(2, pl->params.k), homopolymer_hash(3, pl->params.k), pl->dead.p);
+        if (pp->seed_mask_fraction > 0.0) {
+            // unique seeds after homopolymer erase
+            PMX_HIP(hipMemsetAsync(pl->stats.p, 0, 4 * sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(k_hist_stats, dim3(grid_for(n, 256, G)), dim3(256), 0, st, pl->hist_count.p, pl->dead.p, n, pl->stats.p);
+            PMX_HIP(hipMemcpyAsync(h_stats, pl->stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
+            PMX_HIP(hipStreamSynchronize(st));
+            const int64_t n_mask = (int64_t)(pp->seed_mask_fraction * (double)h_stats[3]);   // :1775
+            if (n_mask > 0) {
+                DevBuf<uint64_t> key, key2;
+                DevBuf<uint32_t> idx, idx2;
+                key.alloc(n); key2.alloc(n); idx.alloc(n); idx2.alloc(n);
+                hipLaunchKernelGGL(k_mask_keys, dim3(grid_for(n, 256, G)), dim3(256), 0, st, pl->hist_count.p, pl->dead.p, n, key.p, idx.p);
+                size_t bytes = 0;
+                PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key2.p, idx.p, idx2.p, (size_t)n, 0, 64, st));
+                pl->tmp.ensure(bytes);
+                PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, key.p, key2.p, idx.p, idx2.p, (size_t)n, 0, 64, st));
+                const int64_t nm = std::min<int64_t>(n_mask, (int64_t)h_stats[3]);
+                hipLaunchKernelGGL(k_mask_apply, dim3(grid_for(nm, 256, G)), dim3(256), 0, st, idx2.p, nm, pl->dead.p);
+                PMX_HIP(hipStreamSynchronize(st));
+            }
+        }
+        PMX_HIP(hipMemsetAsync(pl->stats.p, 0, 4 * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_hist_stats, dim3(grid_for(n, 256, G)), dim3(256), 0, st, pl->hist_count.p, pl->dead.p, n, pl->stats.p);
+        PMX_HIP(hipMemcpyAsync(h_stats, pl->stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
+        PMX_HIP(hipStreamSynchronize(st));
+        if (min_support < 0) {   // resolveMinReadSupport, src/placement.cpp:931-955
+            const double est = h_stats[1] > 0 ? (double)h_stats[0] / (double)h_stats[1] : 0.0;
+            min_support = est > 3.0 ? 2 : 1;
+        }
+        hipLaunchKernelGGL(k_keep_flags, dim3(grid_for(n, 256, G)), dim3(256), 0, st, pl->hist_count.p, pl->dead.p, n, min_support, pl->flag.p);
+        size_t bytes = 0;
+        PMX_HIP(rocprim::exclusive_scan(nullptr, bytes, pl->flag.p, pl->pos.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+        pl->tmp.ensure(bytes);
+        PMX_HIP(rocprim::exclusive_scan(pl->tmp.p, bytes, pl->flag.p, pl->pos.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+        uint32_t last_pos = 0, last_flag = 0;
+        PMX_HIP(hipMemcpyAsync(&last_pos, pl->pos.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PMX_HIP(hipMemcpyAsync(&last_flag, pl->flag.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PMX_HIP(hipStreamSynchronize(st));
+        n_kept = (int64_t)last_pos + last_flag;
+        hipLaunchKernelGGL(k_keep_scatter, dim3(grid_for(n, 256, G)), dim3(256), 0, st, pl->hist_hash.p, pl->hist_count.p, pl->flag.p, pl->pos.p, n,
+                           pl->kept_hash.p, pl->kept_log.p);
+    } else if (min_support < 0) min_support = 1;
+    pl->n_kept = n_kept;
+    // canonical-order sums (src/placement.cpp:957-984)
+    hipLaunchKernelGGL(k_sequential_sums, dim3(1), dim3(64), 0, st, pl->kept_log.p, n_kept, pl->scalars.p);
+    // probe table for the kept seeds
+    pl->tcap = next_pow2((uint64_t)std::max<int64_t>(n_kept, 1) * 2 + 64);
+    pl->tkeys.ensure(pl->tcap);
+    pl->tvals.ensure(pl->tcap);
+    hipLaunchKernelGGL(k_fill_u64, dim3(grid_for((int64_t)pl->tcap, 256, G)), dim3(256), 0, st, pl->tkeys.p, PMX_EMPTY_KEY, pl->tcap);
+    if (n_kept > 0)
+        hipLaunchKernelGGL(k_kept_table_build, dim3(grid_for(n_kept, 256, G)), dim3(256), 0, st, pl->kept_hash.p, pl->kept_log.p, n_kept, pl->tkeys.p,
+                           pl->tvals.p, pl->tcap - 1);
+    hipLaunchKernelGGL(k_wc_denominator, dim3(1), dim3(64), 0, st, pl->ch_hash.p, pl->ch_child.p, pl->root_beg, pl->root_end, pl->tkeys.p, pl->tvals.p,
+                       pl->tcap - 1, n_kept > 0 ? 1 : 0, pl->scalars.p + 2);
+    double h_scal[3];
+    PMX_HIP(hipMemcpyAsync(h_scal, pl->scalars.p, sizeof(h_scal), hipMemcpyDeviceToHost, st));
+    PMX_HIP(hipStreamSynchronize(st));
+    const double log_mag = std::sqrt(h_scal[0]), log_cont_den = h_scal[1], wc_den = h_scal[2];
+
+    // ---- node scoring, one launch per BFS level (src/placement.cpp:701-918)
+    const int n_levels = (int)pl->level_off.size() - 1;
+    timer_begin(ctx, "score");
+    for (int lv = 0; lv < n_levels; ++lv) {
+        const int64_t beg = pl->level_off[lv], cnt = pl->level_off[lv + 1] - beg;
+        if (cnt <= 0) continue;
+        hipLaunchKernelGGL(k_score_level, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, pl->level_nodes.p + beg, cnt, pl->parent.p, pl->offsets.p,
+                           pl->ch_hash.p, pl->ch_par.p, pl->ch_child.p, pl->tkeys.p, pl->tvals.p, pl->tcap - 1, n_kept > 0 ? 1 : 0, pl->metrics5.p,
+                           pl->counts2.p);
+    }
+    timer_end(ctx, "score", 1);
+    hipLaunchKernelGGL(k_score_getters, dim3(grid_for(pl->n_nodes, 256, G)), dim3(256), 0, st, pl->metrics5.p, pl->counts2.p, pl->n_nodes, log_mag,
+                       log_cont_den, wc_den, n_kept, pl->scores5.p);
+    PMX_HIP(hipGetLastError());
+    pl->h_scores.resize(5 * (size_t)pl->n_nodes);
+    PMX_HIP(hipMemcpyAsync(pl->h_scores.data(), pl->scores5.p, sizeof(double) * 5 * (size_t)pl->n_nodes, hipMemcpyDeviceToHost, st));
+    PMX_HIP(hipStreamSynchronize(st));
+
+    // ---- sequential best/tie rule in BFS visit order (src/placement.cpp:355-401)
+    Best best[5];
+    for (int64_t j = 0; j < pl->n_nodes; ++j) {
+        const uint32_t nd = pl->h_order[j];
+        if (pp->force_leaf && pl->h_has_child[nd]) continue;
+        for (int m = 0; m < 5; ++m) best[m].update(nd, pl->h_scores[5 * (size_t)nd + m]);
+    }
+    for (int m = 0; m < 5; ++m) {
+        std::vector<uint32_t>& t = best[m].tied;
+        if (!t.empty()) {
+            std::sort(t.begin(), t.end());
+            t.erase(std::unique(t.begin(), t.end()), t.end());
+            best[m].idx = t.front();
+        }
+        pl->tied[m] = t;
+        res->best_score[m] = best[m].best;
+        res->best_index[m] = best[m].idx;
+        res->n_tied[m] = (int64_t)t.size();
+    }
+    res->n_unique_seeds = (int64_t)h_stats[3];
+    res->n_kept_seeds = n_kept;
+    res->total_seed_freq = (int64_t)h_stats[2];
+    res->min_support = min_support;
+    res->log_read_magnitude = log_mag;
+    res->log_containment_den = log_cont_den;
+    res->weighted_containment_den = wc_den;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_place_tied(const pmx_place* pl, int metric, uint32_t* out, int64_t cap) {
+    if (!pl || metric < 0 || metric >= 5) return PMX_ERR_ARG;
+    const std::vector<uint32_t>& t = pl->tied[metric];
+    if ((int64_t)t.size() > cap) return fail(PMX_ERR_CAPACITY, "tie buffer too small");
+    if (!t.empty()) std::memcpy(out, t.data(), sizeof(uint32_t) * t.size());
+    return PMX_OK;
+}
+
+int pmx_place_node_outputs(pmx_ctx* ctx, pmx_place* pl, double* scores5, double* metrics5, int64_t* counts2) {
+    if (!ctx || !pl) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)pl->n_nodes;
+    if (scores5) PMX_HIP(hipMemcpyAsync(scores5, pl->scores5.p, sizeof(double) * 5 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (metrics5) PMX_HIP(hipMemcpyAsync(metrics5, pl->metrics5.p, sizeof(double) * 5 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts2) PMX_HIP(hipMemcpyAsync(counts2, pl->counts2.p, sizeof(int64_t) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int64_t pmx_place_kept_seeds(pmx_ctx* ctx, pmx_place* pl, uint64_t* hash, double* logc, int64_t cap) {
+    if (!ctx || !pl) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    if (cap < pl->n_kept) return pl->n_kept;
+    if (pl->n_kept > 0) {
+        if (hash) PMX_HIP(hipMemcpyAsync(hash, pl->kept_hash.p, sizeof(uint64_t) * pl->n_kept, hipMemcpyDeviceToHost, ctx->stream));
+        if (logc) PMX_HIP(hipMemcpyAsync(logc, pl->kept_log.p, sizeof(double) * pl->n_kept, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return pl->n_kept;
+    PMX_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Host-side helpers for the device translation units: error plumbing, RAII device buffers, context.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../api_internal.hpp"
+
+namespace pmx {
+
+struct HipError {
+    std::string msg;
+};
+
+#define PMX_HIP(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess)                                                                              \
+            throw pmx::HipError{std::string(#expr) + ": " + hipGetErrorString(_e)};                        \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    bool owned = true;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p && owned) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        owned = true;
+    }
+    void alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        PMX_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count) {
+        if (count > n) alloc(count);
+    }
+    void wrap(T* ptr, size_t count) {
+        release();
+        p = ptr;
+        n = count;
+        owned = false;
+    }
+    void swap(DevBuf& o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(owned, o.owned);
+    }
+};
+
+struct KernelTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int launches = 0;
+    bool pending = false;
+};
+
+}  // namespace pmx
+
+struct pmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::string, pmx::KernelTimer> timers;
+    int n_cu = 256;
+};
+
+namespace pmx {
+inline void timer_begin(pmx_ctx* ctx, const char* name) {
+    KernelTimer& t = ctx->timers[name];
+    if (!t.e0) { PMX_HIP(hipEventCreate(&t.e0)); PMX_HIP(hipEventCreate(&t.e1)); }
+    PMX_HIP(hipEventRecord(t.e0, ctx->stream));
+}
+inline void timer_end(pmx_ctx* ctx, const char* name, int launches) {
+    KernelTimer& t = ctx->timers[name];
+    PMX_HIP(hipEventRecord(t.e1, ctx->stream));
+    t.launches = launches;
+    t.pending = true;
+}
+inline int grid_for(int64_t n, int block, int max_blocks) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+}  // namespace pmx

@@ -1,0 +1,45 @@
+// Declarations shared between place_kernels.hip and the host orchestration in api_device.hip.
+#pragma once
+#include <stdint.h>
+
+#define PMX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
+#define PMX_SEED_BLOCK 128
+enum { PMX_CTR_ENTRIES = 0, PMX_CTR_OVERFLOW = 1, PMX_CTR_SEEDS = 2, PMX_CTR_COMPACT = 3, PMX_CTR_N = 8 };
+
+namespace pmx {
+
+struct SeedParams {
+    int k, s, t, l, open;
+    int trim_start, trim_end;
+};
+
+__global__ void k_pack_reads(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int64_t n_reads, int64_t n_words,
+                             uint64_t* words, uint32_t* amb);
+__global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t n_reads,
+                                 SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters);
+__global__ void k_table_merge(const uint64_t* hash, const int64_t* count, int64_t n, uint64_t* keys, unsigned long long* vals,
+                              uint64_t mask, unsigned long long* counters);
+__global__ void k_table_rehash(const uint64_t* okeys, const unsigned long long* ovals, uint64_t ocap, uint64_t* keys,
+                               unsigned long long* vals, uint64_t mask, unsigned long long* counters);
+__global__ void k_table_compact(const uint64_t* keys, const unsigned long long* vals, uint64_t cap, uint64_t* out_hash,
+                                int64_t* out_count, unsigned long long* n_out);
+__global__ void k_mark_homopolymer(const uint64_t* hash, int64_t n, uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3, uint8_t* dead);
+__global__ void k_mask_keys(const int64_t* count, const uint8_t* dead, int64_t n, uint64_t* key, uint32_t* idx);
+__global__ void k_mask_apply(const uint32_t* idx, int64_t n_mask, uint8_t* dead);
+__global__ void k_hist_stats(const int64_t* count, const uint8_t* dead, int64_t n, unsigned long long* stats);
+__global__ void k_keep_flags(const int64_t* count, const uint8_t* dead, int64_t n, int64_t min_support, uint32_t* flag);
+__global__ void k_keep_scatter(const uint64_t* hash, const int64_t* count, const uint32_t* flag, const uint32_t* pos, int64_t n,
+                               uint64_t* kept_hash, double* kept_log);
+__global__ void k_sequential_sums(const double* kept_log, int64_t n, double* out);
+__global__ void k_kept_table_build(const uint64_t* kept_hash, const double* kept_log, int64_t n, uint64_t* tkeys, double* tvals,
+                                   uint64_t mask);
+__global__ void k_wc_denominator(const uint64_t* ch_hash, const int16_t* ch_child, uint64_t beg, uint64_t end, const uint64_t* tkeys,
+                                 const double* tvals, uint64_t mask, int has_kept, double* out);
+__global__ void k_score_level(const uint32_t* level_nodes, int64_t n_level, const uint32_t* parent, const uint64_t* offsets,
+                              const uint64_t* ch_hash, const int16_t* ch_par, const int16_t* ch_child, const uint64_t* tkeys,
+                              const double* tvals, uint64_t mask, int has_kept, double* metrics5, int64_t* counts2);
+__global__ void k_score_getters(const double* metrics5, const int64_t* counts2, int64_t n_nodes, double log_mag, double log_cont_den,
+                                double wc_den, int64_t n_kept, double* scores5);
+__global__ void k_fill_u64(uint64_t* p, uint64_t v, uint64_t n);
+
+}  // namespace pmx

@@ -1,0 +1,410 @@
+// PLACE stage kernels for gfx950 (wave64): read packing, syncmer / k-min-mer seeding fused with
+// the seed-histogram insert, histogram finalisation, and per-node delta scoring down the tree.
+//
+// Everything here is integer hashing / FP64 accumulation on HBM- and latency-bound access
+// patterns: no MFMA.  Reference behaviour: src/seeding.cpp:47-229 (syncmers),
+// src/placement.cpp:1611-1686 (k-min-mers + histogram), :931-984 (read magnitudes),
+// :242-345 (computeChildMetrics), src/placement.hpp:120-149 (score getters).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device/pmx_math.h"
+#include "place_kernels.h"
+
+namespace pmx {
+
+// ------------------------------------------------------------------------------------- pack
+// One thread per output word (32 bases): 2-bit code + ambiguity bit.  Under an ambiguity bit the
+// code field is 3 for 'U'/'u' (minimap2's nt4 table maps U to T, the seeding hash does not) else 0.
+__global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ off,
+                             const int64_t* __restrict__ woff, int64_t n_reads, int64_t n_words,
+                             uint64_t* __restrict__ words, uint32_t* __restrict__ amb) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+        // read r with woff[r] <= w < woff[r+1]
+        int64_t lo = 0, hi = n_reads;
+        while (hi - lo > 1) {
+            int64_t mid = (lo + hi) >> 1;
+            if (woff[mid] <= w) lo = mid; else hi = mid;
+        }
+        const int64_t r = lo;
+        const int64_t base0 = (w - woff[r]) * 32;
+        const int64_t len = off[r + 1] - off[r];
+        const uint8_t* p = ascii + off[r] + base0;
+        int nb = (int)(len - base0 < 32 ? len - base0 : 32);
+        uint64_t v = 0;
+        uint32_t a = 0;
+        for (int j = 0; j < nb; ++j) {
+            uint8_t ch = p[j];
+            uint32_t code, am = 0;
+            switch (ch) {
+                case 'A': case 'a': code = 0; break;
+                case 'C': case 'c': code = 1; break;
+                case 'G': case 'g': code = 2; break;
+                case 'T': case 't': code = 3; break;
+                case 'U': case 'u': code = 3; am = 1; break;
+                default: code = 0; am = 1; break;
+            }
+            v |= (uint64_t)code << (2 * j);
+            a |= am << j;
+        }
+        words[w] = v;
+        amb[w] = a;
+    }
+}
+
+// --------------------------------------------------------------------------------- seeding
+__device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long* vals, uint64_t mask, uint64_t key,
+                                             unsigned long long mult, unsigned long long* counters) {
+    uint64_t slot = mix64(key) & mask;
+    for (uint64_t probes = 0; probes <= mask; ++probes) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)key);
+        if (prev == PMX_EMPTY_KEY) atomicAdd(&counters[PMX_CTR_ENTRIES], 1ULL);
+        if (prev == PMX_EMPTY_KEY || prev == key) {
+            atomicAdd(&vals[slot], mult);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+    atomicAdd(&counters[PMX_CTR_OVERFLOW], 1ULL);
+}
+
+// One thread per read; rolling k-mer / s-mer hashes in registers, the (k-s+1)-deep s-mer ring and the
+// l-deep syncmer ring of every thread in LDS, laid out [slot][thread] (conflict-free ds_read_b64).
+__global__ void __launch_bounds__(PMX_SEED_BLOCK)
+k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
+                 const int64_t* __restrict__ off, int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals,
+                 uint64_t mask, unsigned long long* counters) {
+    extern __shared__ uint64_t lds[];
+    const int w = sp.k - sp.s + 1;
+    const int l = sp.l < 1 ? 1 : sp.l;
+    uint64_t* ringF = lds;                                   // [w][B]
+    uint64_t* ringR = lds + (size_t)w * PMX_SEED_BLOCK;      // [w][B]
+    uint64_t* ringS = lds + (size_t)2 * w * PMX_SEED_BLOCK;  // [l][B]
+    const int tid = threadIdx.x;
+    const uint64_t HB[4] = {0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x20323ed082572324ULL, 0x295549f54be24456ULL};
+    unsigned long long n_seeds = 0;
+
+    for (int64_t r = (int64_t)blockIdx.x * PMX_SEED_BLOCK + tid; r < n_reads; r += (int64_t)gridDim.x * PMX_SEED_BLOCK) {
+        const int64_t len = off[r + 1] - off[r];
+        if (len < sp.k) continue;
+        const uint64_t* rw = words + woff[r];
+        const uint32_t* ra = amb + woff[r];
+        const int64_t valid_start = sp.trim_start, valid_end = len - sp.trim_end - sp.k;
+        uint64_t fS = 0, rS = 0, fK = 0, rK = 0;
+        uint64_t hist2 = 0;   // last 32 base codes, newest in bits 1:0
+        uint32_t hista = 0;   // last 32 ambiguity bits, newest in bit 0
+        int64_t last_amb = -1;
+        uint64_t cw = 0;
+        uint32_t ca = 0;
+        uint64_t F = 0, R = 0;  // k-min-mer rolling hashes
+        int64_t n_sync = 0;
+        for (int64_t i = 0; i < len; ++i) {
+            if ((i & 31) == 0) { cw = rw[i >> 5]; ca = ra[i >> 5]; }
+            const uint32_t code = (uint32_t)(cw & 3u);
+            const uint32_t am = ca & 1u;
+            cw >>= 2; ca >>= 1;
+            const uint64_t hb = am ? 0 : HB[code], hc = am ? 0 : HB[3 - code];
+            if (am) last_amb = i;
+            // outgoing bases (distance s and k behind)
+            if (i < sp.s) { fS ^= rotl64(hb, (unsigned)(sp.s - 1 - i)); rS ^= rotl64(hc, (unsigned)i); }
+            else {
+                const uint32_t oc = (uint32_t)(hist2 >> (2 * (sp.s - 1))) & 3u, oa = (hista >> (sp.s - 1)) & 1u;
+                const uint64_t ob = oa ? 0 : HB[oc], ocm = oa ? 0 : HB[3 - oc];
+                fS = rotl64(fS, 1) ^ rotl64(ob, (unsigned)sp.s) ^ hb;
+                rS = rotr64(rS, 1) ^ rotr64(ocm, 1) ^ rotl64(hc, (unsigned)(sp.s - 1));
+            }
+            if (i < sp.k) { fK ^= rotl64(hb, (unsigned)(sp.k - 1 - i)); rK ^= rotl64(hc, (unsigned)i); }
+            else {
+                const uint32_t oc = (uint32_t)(hist2 >> (2 * (sp.k - 1))) & 3u, oa = (hista >> (sp.k - 1)) & 1u;
+                const uint64_t ob = oa ? 0 : HB[oc], ocm = oa ? 0 : HB[3 - oc];
+                fK = rotl64(fK, 1) ^ rotl64(ob, (unsigned)sp.k) ^ hb;
+                rK = rotr64(rK, 1) ^ rotr64(ocm, 1) ^ rotl64(hc, (unsigned)(sp.k - 1));
+            }
+            hist2 = (hist2 << 2) | code;
+            hista = (hista << 1) | am;
+            if (i >= sp.s - 1) {
+                const int slot = (int)((i - sp.s + 1) % w);
+                ringF[(size_t)slot * PMX_SEED_BLOCK + tid] = fS;
+                ringR[(size_t)slot * PMX_SEED_BLOCK + tid] = rS;
+            }
+            if (i < sp.k - 1) continue;
+            const int64_t ks = i - sp.k + 1;
+            if (last_amb >= ks || fK == rK) continue;
+            uint64_t fmin = UINT64_MAX, rmin = UINT64_MAX;
+            for (int j = 0; j < w; ++j) {
+                const uint64_t a = ringF[(size_t)j * PMX_SEED_BLOCK + tid], b = ringR[(size_t)j * PMX_SEED_BLOCK + tid];
+                fmin = a < fmin ? a : fmin;
+                rmin = b < rmin ? b : rmin;
+            }
+            const int s_first = (int)((ks + sp.t) % w), s_last = (int)((ks + sp.k - sp.s - sp.t) % w);
+            bool fs, rs;
+            if (sp.open) {
+                fs = ringF[(size_t)s_first * PMX_SEED_BLOCK + tid] == fmin;
+                rs = ringR[(size_t)s_last * PMX_SEED_BLOCK + tid] == rmin;
+            } else {
+                fs = ringF[(size_t)s_first * PMX_SEED_BLOCK + tid] == fmin || ringF[(size_t)s_last * PMX_SEED_BLOCK + tid] == fmin;
+                rs = ringR[(size_t)s_last * PMX_SEED_BLOCK + tid] == rmin || ringR[(size_t)s_first * PMX_SEED_BLOCK + tid] == rmin;
+            }
+            if (!(fs || rs)) continue;
+            if (ks < valid_start || ks > valid_end) continue;   // primer trim (src/placement.cpp:1629-1648)
+            const uint64_t h = fK < rK ? fK : rK;
+            ++n_sync;
+            if (sp.l <= 1) {
+                table_insert(keys, vals, mask, h, 1ULL, counters);
+                ++n_seeds;
+                continue;
+            }
+            bool have = false;
+            if (n_sync <= l) {
+                F = rotl64(F, (unsigned)sp.k) ^ h;
+                R ^= rotl64(h, (unsigned)(sp.k * (int)(n_sync - 1)));
+                have = n_sync == l;
+            } else {
+                const uint64_t prev = ringS[(size_t)((n_sync - 1) % l) * PMX_SEED_BLOCK + tid];
+                F = rotl64(F, (unsigned)sp.k) ^ rotl64(prev, (unsigned)(sp.k * l)) ^ h;
+                R = rotr64(R, (unsigned)sp.k) ^ rotr64(prev, (unsigned)sp.k) ^ rotl64(h, (unsigned)(sp.k * (l - 1)));
+                have = true;
+            }
+            ringS[(size_t)((n_sync - 1) % l) * PMX_SEED_BLOCK + tid] = h;
+            if (have && F != R) {
+                table_insert(keys, vals, mask, F < R ? F : R, 1ULL, counters);
+                ++n_seeds;
+            }
+        }
+    }
+    if (n_seeds) atomicAdd(&counters[PMX_CTR_SEEDS], n_seeds);
+}
+
+// merge externally supplied (hash,count) pairs into the table (multi-GPU histogram exchange)
+__global__ void k_table_merge(const uint64_t* __restrict__ hash, const int64_t* __restrict__ count, int64_t n, uint64_t* keys,
+                              unsigned long long* vals, uint64_t mask, unsigned long long* counters) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        table_insert(keys, vals, mask, hash[i], (unsigned long long)count[i], counters);
+}
+
+__global__ void k_table_rehash(const uint64_t* __restrict__ okeys, const unsigned long long* __restrict__ ovals, uint64_t ocap,
+                               uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ocap; i += (uint64_t)gridDim.x * blockDim.x)
+        if (okeys[i] != PMX_EMPTY_KEY) table_insert(keys, vals, mask, okeys[i], ovals[i], counters);
+}
+
+__global__ void k_table_compact(const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ vals, uint64_t cap,
+                                uint64_t* out_hash, int64_t* out_count, unsigned long long* n_out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[i];
+        if (k == PMX_EMPTY_KEY) continue;
+        const unsigned long long j = atomicAdd(n_out, 1ULL);
+        out_hash[j] = k;
+        out_count[j] = (int64_t)vals[i];
+    }
+}
+
+// ------------------------------------------------------------------------------- finalise
+// dead[i] = 1 for the 4 homopolymer k-mer hashes (src/placement.cpp:1708-1722)
+__global__ void k_mark_homopolymer(const uint64_t* __restrict__ hash, int64_t n, uint64_t h0, uint64_t h1, uint64_t h2, uint64_t h3,
+                                   uint8_t* dead) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = hash[i];
+        dead[i] = (h == h0 || h == h1 || h == h2 || h == h3) ? 1 : 0;
+    }
+}
+
+// keys for the top-fraction mask: ascending sort of ~count keeps ascending hash among equal counts
+__global__ void k_mask_keys(const int64_t* __restrict__ count, const uint8_t* __restrict__ dead, int64_t n, uint64_t* key, uint32_t* idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        key[i] = dead[i] ? UINT64_MAX : ~(uint64_t)count[i];
+        idx[i] = (uint32_t)i;
+    }
+}
+__global__ void k_mask_apply(const uint32_t* __restrict__ idx, int64_t n_mask, uint8_t* dead) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_mask; i += (int64_t)gridDim.x * blockDim.x) dead[idx[i]] = 1;
+}
+
+// integer statistics for resolveMinReadSupport (src/placement.cpp:931-955):
+// stats[0]=sum of counts>=2, [1]=number of counts>=2, [2]=sum of all alive counts, [3]=alive entries
+__global__ void k_hist_stats(const int64_t* __restrict__ count, const uint8_t* __restrict__ dead, int64_t n, unsigned long long* stats) {
+    unsigned long long s2 = 0, c2 = 0, tot = 0, alive = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (dead[i]) continue;
+        const int64_t c = count[i];
+        ++alive; tot += (unsigned long long)c;
+        if (c >= 2) { s2 += (unsigned long long)c; ++c2; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s2 += __shfl_down(s2, o); c2 += __shfl_down(c2, o); tot += __shfl_down(tot, o); alive += __shfl_down(alive, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[0], s2); atomicAdd(&stats[1], c2); atomicAdd(&stats[2], tot); atomicAdd(&stats[3], alive);
+    }
+}
+
+__global__ void k_keep_flags(const int64_t* __restrict__ count, const uint8_t* __restrict__ dead, int64_t n, int64_t min_support,
+                             uint32_t* flag) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        flag[i] = (!dead[i] && count[i] >= min_support) ? 1u : 0u;
+}
+
+// stable compaction (pos = exclusive scan of flag) + log1p of the read count (src/placement.cpp:970)
+__global__ void k_keep_scatter(const uint64_t* __restrict__ hash, const int64_t* __restrict__ count, const uint32_t* __restrict__ flag,
+                               const uint32_t* __restrict__ pos, int64_t n, uint64_t* kept_hash, double* kept_log) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!flag[i]) continue;
+        kept_hash[pos[i]] = hash[i];
+        kept_log[pos[i]] = log1p_count(count[i]);
+    }
+}
+
+// Canonical-order FP sums (ascending hash, strictly sequential):
+// out[0] = sum L^2, out[1] = sum L.   One thread.
+__global__ void k_sequential_sums(const double* __restrict__ kept_log, int64_t n, double* out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double m2 = 0.0, s = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double L = kept_log[i];
+        m2 += L * L;
+        s += L;
+    }
+    out[0] = m2;
+    out[1] = s;
+}
+
+__global__ void k_kept_table_build(const uint64_t* __restrict__ kept_hash, const double* __restrict__ kept_log, int64_t n,
+                                   uint64_t* tkeys, double* tvals, uint64_t mask) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = kept_hash[i];
+        uint64_t slot = mix64(key) & mask;
+        while (true) {
+            unsigned long long prev = atomicCAS((unsigned long long*)&tkeys[slot], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)key);
+            if (prev == PMX_EMPTY_KEY) { tvals[slot] = kept_log[i]; break; }
+            slot = (slot + 1) & mask;
+        }
+    }
+}
+
+__device__ __forceinline__ bool kept_lookup(const uint64_t* __restrict__ tkeys, const double* __restrict__ tvals, uint64_t mask,
+                                            uint64_t key, double* L) {
+    uint64_t slot = mix64(key) & mask;
+    while (true) {
+        const uint64_t k = tkeys[slot];
+        if (k == key) { *L = tvals[slot]; return true; }
+        if (k == PMX_EMPTY_KEY) return false;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// weighted-containment denominator: root changes in stored order (src/placement.cpp:1863-1876).  One wave:
+// lanes probe 64 changes at a time, then the additions run in stored order.
+__global__ void k_wc_denominator(const uint64_t* __restrict__ ch_hash, const int16_t* __restrict__ ch_child, uint64_t beg, uint64_t end,
+                                 const uint64_t* __restrict__ tkeys, const double* __restrict__ tvals, uint64_t mask, int has_kept,
+                                 double* out) {
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (uint64_t base = beg; base < end; base += 64) {
+        const uint64_t i = base + lane;
+        double inv = 0.0;
+        int hit = 0;
+        if (i < end) {
+            const int16_t cc = ch_child[i];
+            double L;
+            if (cc > 0 && has_kept && kept_lookup(tkeys, tvals, mask, ch_hash[i], &L)) { inv = 1.0 / (double)cc; hit = 1; }
+        }
+        const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+        for (int j = 0; j < cnt; ++j) {
+            const int hj = __shfl(hit, j);
+            const double ij = __shfl(inv, j);
+            if (hj) acc += ij;
+        }
+    }
+    if (threadIdx.x == 0) out[0] = acc;
+}
+
+// --------------------------------------------------------------------------- node scoring
+// One wave per node of one BFS level.  Child state = parent state + own deltas applied in stored order
+// (src/placement.cpp:242-345, :772-774).  Lanes fetch/probe/evaluate 64 changes in parallel; the
+// additions are replayed strictly in order so every accumulator sees the reference's operation sequence.
+__global__ void __launch_bounds__(256)
+k_score_level(const uint32_t* __restrict__ level_nodes, int64_t n_level, const uint32_t* __restrict__ parent,
+              const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ ch_hash, const int16_t* __restrict__ ch_par,
+              const int16_t* __restrict__ ch_child, const uint64_t* __restrict__ tkeys, const double* __restrict__ tvals,
+              uint64_t mask, int has_kept, double* metrics5, int64_t* counts2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wv >= n_level) return;
+    const uint32_t nd = level_nodes[wv];
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+    int64_t c0 = 0, c1 = 0;
+    if (nd != 0) {
+        const uint32_t pa = parent[nd];
+        m0 = metrics5[5 * (size_t)pa + 0]; m1 = metrics5[5 * (size_t)pa + 1]; m2 = metrics5[5 * (size_t)pa + 2];
+        m3 = metrics5[5 * (size_t)pa + 3]; m4 = metrics5[5 * (size_t)pa + 4];
+        c0 = counts2[2 * (size_t)pa + 0]; c1 = counts2[2 * (size_t)pa + 1];
+    }
+    const uint64_t beg = offsets[nd], end = offsets[nd + 1];
+    for (uint64_t base = beg; base < end; base += 64) {
+        const uint64_t i = base + lane;
+        double d_raw = 0, d_cos = 0, d_wc = 0, d_lc = 0, d_mag = 0;
+        int d_pres = 0, d_uniq = 0, hit = 0;
+        if (i < end) {
+            const int64_t pc = ch_par[i], cc = ch_child[i];
+            const double logC = cc > 0 ? log1p_count(cc) : 0.0;
+            const double logP = pc > 0 ? log1p_count(pc) : 0.0;
+            d_mag = logC * logC - logP * logP;
+            d_uniq = (cc > 0) - (pc > 0);
+            double L;
+            if (cc != pc && has_kept && kept_lookup(tkeys, tvals, mask, ch_hash[i], &L)) {
+                hit = 1;
+                d_pres = (int)((pc == 0) & (cc != 0)) - (int)((cc == 0) & (pc != 0));
+                const double o1 = pc > 0 ? L / (double)pc : 0.0, n1 = cc > 0 ? L / (double)cc : 0.0;
+                d_raw = n1 - o1;
+                d_cos = L * (logC - logP);
+                const double o2 = pc > 0 ? 1.0 / (double)pc : 0.0, n2 = cc > 0 ? 1.0 / (double)cc : 0.0;
+                d_wc = n2 - o2;
+                d_lc = (double)d_pres * L;
+            }
+        }
+        const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+        for (int j = 0; j < cnt; ++j) {
+            m4 += __shfl(d_mag, j);
+            c1 += __shfl(d_uniq, j);
+            if (__shfl(hit, j)) {
+                c0 += __shfl(d_pres, j);
+                m0 += __shfl(d_raw, j);
+                m1 += __shfl(d_cos, j);
+                m2 += __shfl(d_wc, j);
+                m3 += __shfl(d_lc, j);
+            }
+        }
+    }
+    if (lane == 0) {
+        metrics5[5 * (size_t)nd + 0] = m0; metrics5[5 * (size_t)nd + 1] = m1; metrics5[5 * (size_t)nd + 2] = m2;
+        metrics5[5 * (size_t)nd + 3] = m3; metrics5[5 * (size_t)nd + 4] = m4;
+        counts2[2 * (size_t)nd + 0] = c0; counts2[2 * (size_t)nd + 1] = c1;
+    }
+}
+
+// score getters (src/placement.hpp:120-149); TSV order log_raw, log_cosine, containment,
+// weighted_containment, log_containment
+__global__ void k_score_getters(const double* __restrict__ metrics5, const int64_t* __restrict__ counts2, int64_t n_nodes,
+                                double log_mag, double log_cont_den, double wc_den, int64_t n_kept, double* scores5) {
+    for (int64_t nd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; nd < n_nodes; nd += (int64_t)gridDim.x * blockDim.x) {
+        const double* m = metrics5 + 5 * nd;
+        double* sc = scores5 + 5 * nd;
+        sc[0] = log_mag <= 0.0 ? 0.0 : m[0] / log_mag;
+        const double gm = sqrt(m[4]);
+        if (log_mag <= 0.0 || gm <= 0.0) sc[1] = 0.0;
+        else {
+            const double v = m[1] / (log_mag * gm);
+            sc[1] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        }
+        sc[2] = n_kept > 0 ? (double)(uint64_t)counts2[2 * nd] / (double)(uint64_t)n_kept : 0.0;
+        sc[3] = wc_den > 0.0 ? m[2] / wc_den : 0.0;
+        sc[4] = log_cont_den > 0.0 ? m[3] / log_cont_den : 0.0;
+    }
+}
+
+__global__ void k_fill_u64(uint64_t* p, uint64_t v, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace pmx

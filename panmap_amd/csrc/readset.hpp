@@ -1,0 +1,16 @@
+// Device-resident read set shared by the place and align translation units.
+#pragma once
+#include "device/dev_util.hpp"
+
+struct pmx_readset {
+    int64_t n = 0;          // reads
+    int64_t total = 0;      // bases
+    int64_t max_len = 0;
+    int64_t n_words = 0;    // 32-base words
+    bool packed = false;
+    pmx::DevBuf<uint8_t> ascii;    // concatenated ASCII
+    pmx::DevBuf<int64_t> off;      // n+1 byte offsets into ascii
+    pmx::DevBuf<int64_t> woff;     // n+1 word offsets into words/amb
+    pmx::DevBuf<uint64_t> words;   // 2 bits per base
+    pmx::DevBuf<uint32_t> amb;     // 1 bit per base: not A/C/G/T
+};

@@ -1,0 +1,53 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver at round end)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure the HIP library and the oracle are built (cross-compiles without a GPU)."""
+    import __graft_entry__ as g
+    g.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def pmx(built):
+    import panmap_amd
+    return panmap_amd
+
+
+@pytest.fixture(scope="session")
+def oracle(built):
+    from oracle import oracle as orc
+    return orc
+
+
+@pytest.fixture(scope="session")
+def sars(pmx):
+    return pmx.Panman(os.path.join(GOLDEN, "sars_20000_twilight_dipper.panman"))
+
+
+@pytest.fixture(scope="session")
+def sars_index(pmx, sars):
+    return pmx.Index.build(sars, k=19, s=8, t=0, l=3, open_syncmer=False, flank_mask=250)
+
+
+@pytest.fixture(scope="session")
+def isolate_reads(pmx):
+    return pmx.extract_read_sequences(os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz"))
+
+
+@pytest.fixture(scope="session")
+def ctx(pmx):
+    return pmx.Context(0)

@@ -1,0 +1,143 @@
+"""CPU suite: host logic of the product (PanMAN reader, genome materialiser, index stage, FASTQ
+readers) and the C-ABI surface.  No device compute."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def _fa(path):
+    return b"".join(l.strip() for l in open(path, "rb") if not l.startswith(b">"))
+
+
+def test_abi_exports_every_declared_symbol(pmx):
+    header = open(os.path.join(ROOT, "include", "panmap_amd.h")).read()
+    declared = set(re.findall(r"\b(pmx_[a-z0-9_]+)\s*\(", header))
+    declared -= {"pmx_ctx", "pmx_place", "pmx_index", "pmx_panman", "pmx_readset", "pmx_aligner"}
+    assert declared, "no declarations parsed"
+    assert not pmx._lib.MISSING
+    for name in declared:
+        assert hasattr(pmx.lib, name), name
+    assert set(pmx._lib.SIGNATURES) >= declared
+
+
+def test_no_gpu_fails_loudly(pmx):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pmx.PmxError) as e:
+        pmx.Context(0)
+    assert "NO_DEVICE" in str(e.value)
+
+
+def test_product_does_not_touch_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "panmap_amd")):
+        if "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle/" not in txt and "liboracle" not in txt and "libpanmap_ref" not in txt, os.path.join(dirpath, f)
+
+
+def test_node_genomes_match_reference_fixtures(pmx, sars):
+    assert sars.num_nodes == 39999 and sars.num_blocks == 1
+    i = sars.find_node("node_7618")
+    assert i == 15189
+    assert sars.genome(i) == _fa(os.path.join(GOLDEN, "isolate.ref.fa"))
+    rsv = pmx.Panman(os.path.join(GOLDEN, "rsv_4K.panman"))           # multi-block, gap lists, inverted blocks
+    assert rsv.genome("MZ515733.1") == _fa(os.path.join(GOLDEN, "MZ515733.1.fa"))
+    assert rsv.genome("node_1330") == _fa(os.path.join(GOLDEN, "rsv_4K.panman.random.node_1330.fa"))
+    assert rsv.find_node("no_such_node") == -1
+
+
+def test_index_invariants(pmx, sars, sars_index, oracle):
+    # src/test/test_index.cpp:41-78: offsets monotone, parentCount == running count along the path,
+    # only changed counts stored, changes sorted by hash within a node
+    a = sars_index.arrays()
+    info = sars_index.info
+    assert (info.k, info.s, info.t, info.l) == (19, 8, 0, 3)
+    assert info.n_nodes == 39999 and info.n_changes == 2422076
+    off = a["offsets"].astype(np.int64)
+    assert off[0] == 0 and np.all(np.diff(off) >= 0) and off[-1] == info.n_changes
+    assert off[1] == 8889
+    assert np.all(a["parent_count"] != a["child_count"])
+    assert np.all(a["parent"][1:] < np.arange(1, info.n_nodes))
+    rng = np.random.default_rng(11)
+    for leaf in rng.integers(0, info.n_nodes, 6):
+        path = []
+        x = int(leaf)
+        while True:
+            path.append(x)
+            if x == 0:
+                break
+            x = int(a["parent"][x])
+        counts = {}
+        for nd in reversed(path):
+            h = a["hash"][off[nd]:off[nd + 1]]
+            assert np.all(h[1:] > h[:-1])
+            for hh, pc, cc in zip(h.tolist(), a["parent_count"][off[nd]:off[nd + 1]].tolist(), a["child_count"][off[nd]:off[nd + 1]].tolist()):
+                assert counts.get(hh, 0) == pc
+                if cc:
+                    counts[hh] = cc
+                else:
+                    counts.pop(hh, None)
+        assert all(v > 0 for v in counts.values())
+
+
+def test_index_flank0_l1_equals_direct_extraction(pmx, sars, oracle):
+    # src/test/test_index.cpp:80-110: delta reconstruction == direct extractSeeds(genome) at l=1, flank 0
+    idx = pmx.Index.build(sars, k=15, s=8, t=0, l=1, open_syncmer=False, flank_mask=0)
+    a = idx.arrays()
+    off = a["offsets"].astype(np.int64)
+    for nd in (0, 15189, 25000, 39998):
+        path = []
+        x = nd
+        while True:
+            path.append(x)
+            if x == 0:
+                break
+            x = int(a["parent"][x])
+        counts = {}
+        for p in reversed(path):
+            for hh, cc in zip(a["hash"][off[p]:off[p + 1]].tolist(), a["child_count"][off[p]:off[p + 1]].tolist()):
+                if cc:
+                    counts[hh] = cc
+                else:
+                    counts.pop(hh, None)
+        g = sars.genome(nd)
+        want = {}
+        for h, _, _, _ in oracle.rolling_syncmers(g, 15, 8, False, 0, False):
+            want[h] = want.get(h, 0) + 1
+        assert counts == want
+
+
+def test_fastq_readers(pmx, tmp_path):
+    fq1 = tmp_path / "a_R1.fastq"
+    fq2 = tmp_path / "a_R2.fastq"
+    fq1.write_text("@r1 x\nACGTN\n+\nIIIII\n@r2\nGGGTT\n+\nIIIII\n")
+    fq2.write_text("@r1\nAACCg\n+\nABCDE\n@r2\nTTTTT\n+\nIIIII\n")
+    assert pmx.extract_read_sequences(str(fq1), str(fq2)) == [b"ACGTN", b"AACCg", b"GGGTT", b"TTTTT"]
+    seqs, quals, names = pmx.read_fastq_paired(str(fq1), str(fq2))
+    assert seqs == [b"ACGTN", b"gGGTT", b"GGGTT", b"AAAAA"]        # lower-case left as-is, then reversed
+    assert quals[1] == b"EDCBA" and names[0] == b"r1"
+    fq2.write_text("@r1\nAACCG\n+\nABCDE\n")
+    with pytest.raises(ValueError):
+        pmx.extract_read_sequences(str(fq1), str(fq2))
+    fa = tmp_path / "x.fa"
+    fa.write_text(">s1 desc\nACGT\nACGT\n>s2\nTT\n")
+    n, s, q = pmx.read_fastx(str(fa))
+    assert s == [b"ACGTACGT", b"TT"] and n == [b"s1", b"s2"]
+
+
+def test_synthetic_reads_are_deterministic_and_fr(pmx, sars):
+    g = sars.genome("node_7618")
+    c1, o1 = pmx.simulate_paired_reads(g, 500, seed=42)
+    c2, o2 = pmx.simulate_paired_reads(g, 500, seed=42)
+    assert np.array_equal(c1, c2) and np.array_equal(o1, o2) and len(o1) == 1001
+    c3, _ = pmx.simulate_paired_reads(g, 500, seed=42, sub_rate=0.0)
+    r1 = bytes(c3[o1[0]:o1[1]]); r2 = bytes(c3[o1[1]:o1[2]])
+    assert r1 in g and pmx.reverse_complement(r2) in g

@@ -1,0 +1,153 @@
+"""GPU parity tests for the PLACE stage: HIP path (through the C ABI) vs the oracle, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _as_reads(concat, off):
+    return [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+
+
+def _check_place(pmx, oracle, ctx, index, reads, params=None, k=19, s=8, l=3, open_syncmer=False, t=0):
+    params = params or pmx.TraversalParams()
+    placer = pmx.Placer(ctx, index)
+    placer.reset()
+    if reads:
+        rs = pmx.ReadSet(ctx, reads)
+        placer.add_reads(rs, params)
+    res = placer.score(params, len(reads))
+    want = oracle.place(reads, index.arrays(), k, s, l, open_syncmer, t, params.trimStart, params.trimEnd, params.seedMaskFraction,
+                        params.minReadSupport, params.forceLeaf)
+    hh, hc = placer.histogram()
+    assert np.array_equal(hh, want["hist_hash"]), "seed set differs"
+    assert np.array_equal(hc, want["hist_count"]), "seed counts differ"
+    kh, kl = placer.kept_seeds()
+    assert np.array_equal(kh, want["kept_hash"])
+    assert np.array_equal(kl.view(np.uint64), want["kept_log"].view(np.uint64)), "log1p(count) not bit-equal"
+    st = want["state"]
+    assert res.min_support == st.min_support and res.readUniqueSeedCount == st.n_kept
+    assert res.totalReadSeedFrequency == st.total_freq and res.n_unique_seeds == st.n_unique_in
+    assert np.float64(res.readMagnitude).view(np.uint64) == np.float64(st.log_magnitude).view(np.uint64)
+    assert np.float64(res.logContainmentDenominator).view(np.uint64) == np.float64(st.log_cont_den).view(np.uint64)
+    assert np.float64(res.weightedContainmentDenominator).view(np.uint64) == np.float64(want["wc_den"]).view(np.uint64)
+    sc, met, cts = placer.node_outputs()
+    assert np.array_equal(cts, want["counts"])
+    assert np.array_equal(met.view(np.uint64), want["metrics"].view(np.uint64)), "node accumulators not bit-equal"
+    assert np.array_equal(sc.view(np.uint64), want["scores"].view(np.uint64)), "node scores not bit-equal"
+    for m in range(5):
+        assert res.best_score[m] == want["best"][m] and res.best_index[m] == want["best_idx"][m]
+        assert np.array_equal(res.tied_indices[m], want["ties"][m])
+    placer.close()
+    return res
+
+
+def test_log1p_device_restatement_is_exact(pmx, oracle, ctx, sars_index):
+    # counts 1..N appear as read counts: build a histogram with count c for key c via merge()
+    placer = pmx.Placer(ctx, sars_index)
+    placer.reset()
+    n = 200000
+    keys = np.arange(1, n + 1, dtype=np.uint64) * np.uint64(2654435761)
+    counts = np.concatenate([np.arange(1, n // 2 + 1), np.random.default_rng(1).integers(1, 2 ** 40, n - n // 2)]).astype(np.int64)
+    placer.merge(keys, counts)
+    placer.score(pmx.TraversalParams(minReadSupport=1), 0)
+    kh, kl = placer.kept_seeds()
+    order = np.argsort(keys)
+    assert np.array_equal(kh, keys[order])
+    want = np.log1p(counts[order].astype(np.float64))
+    assert np.array_equal(kl.view(np.uint64), want.view(np.uint64))
+
+
+def test_place_synthetic_pairs_bit_exact(pmx, oracle, ctx, sars, sars_index):
+    g = sars.genome("node_7618")
+    concat, off = pmx.simulate_paired_reads(g, 3000, seed=1)
+    _check_place(pmx, oracle, ctx, sars_index, _as_reads(concat, off))
+
+
+def test_place_edge_cases(pmx, oracle, ctx, sars, sars_index):
+    g = sars.genome("node_100")
+    rng = np.random.default_rng(2)
+    reads = []
+    for i in range(400):
+        n = int(rng.integers(1, 400))
+        st = int(rng.integers(0, len(g) - n))
+        r = bytearray(g[st:st + n])
+        if i % 5 == 0 and n > 3:
+            r[int(rng.integers(0, n))] = ord("N")
+        if i % 7 == 0:
+            r = bytearray(bytes(r).lower())
+        if i % 11 == 0 and n > 10:
+            r[5:8] = b"RYK"
+        reads.append(bytes(r))
+    reads += [b"A" * 150, b"ACGT" * 40, b"", b"N" * 60, b"ACGTACGTACGTACGTACG"]   # homopolymer, periodic, empty, all-N, exactly k
+    _check_place(pmx, oracle, ctx, sars_index, reads)
+    _check_place(pmx, oracle, ctx, sars_index, reads, pmx.TraversalParams(trimStart=10, trimEnd=25, minReadSupport=1))
+    _check_place(pmx, oracle, ctx, sars_index, [])                                  # no reads at all
+    _check_place(pmx, oracle, ctx, sars_index, reads, pmx.TraversalParams(forceLeaf=True, seedMaskFraction=0.01))
+
+
+@pytest.mark.parametrize("k,s,l,open_syncmer,t", [(15, 8, 1, False, 0), (31, 6, 3, False, 0), (19, 8, 2, True, 3), (21, 10, 4, False, 2)])
+def test_place_other_parameters(pmx, oracle, ctx, sars, k, s, l, open_syncmer, t):
+    # a small hand-made index over the real hashes keeps this fast: root = seeds of one genome
+    g = sars.genome("node_5")
+    hs, cn = oracle.histogram([g], k, s, l, open_syncmer, t)
+    keep = cn < 30000
+    hs, cn = hs[keep], cn[keep]
+    half = len(hs) // 2
+    parent = np.array([0, 0, 1], np.uint32)
+    offsets = np.array([0, len(hs), len(hs) + half, len(hs) + half + 10], np.uint64)
+    hash_ = np.concatenate([hs, hs[:half], hs[half:half + 10]])
+    pc = np.concatenate([np.zeros(len(hs)), cn[:half], cn[half:half + 10]]).astype(np.int16)
+    cc = np.concatenate([cn, cn[:half] + 1, np.zeros(10)]).astype(np.int16)
+    index = pmx.Index.from_arrays(k, s, t, l, open_syncmer, parent, offsets, hash_, pc, cc)
+    concat, off = pmx.simulate_paired_reads(g, 1500, seed=3)
+    _check_place(pmx, oracle, ctx, index, _as_reads(concat, off), None, k, s, l, open_syncmer, t)
+
+
+def test_golden_placement_tsv_on_gpu(pmx, ctx, sars, sars_index, tmp_path):
+    """examples/check_examples.sh:52-70 through the HIP path: byte-exact isolate.placement.tsv."""
+    placer = pmx.Placer(ctx, sars_index)
+    out = tmp_path / "isolate.placement.tsv"
+    res = pmx.place_lite(ctx, placer, os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz"), str(out),
+                         pmx.TraversalParams(), sars.node_id)
+    assert out.read_text() == open(os.path.join(GOLDEN, "isolate.placement.tsv")).read()
+    assert sars.node_id(res.bestLogContainmentNodeIndex) == "node_7618"
+    assert res.n_reads == 102338 and res.n_unique_seeds == 317148 and res.readUniqueSeedCount == 117645
+
+
+def test_histogram_shard_merge_equals_single_pass(pmx, ctx, sars, sars_index):
+    """multi-GPU exchange step: per-shard histograms merged == one pass over all reads."""
+    g = sars.genome("node_7618")
+    concat, off = pmx.simulate_paired_reads(g, 4000, seed=5)
+    reads = _as_reads(concat, off)
+    a = pmx.Placer(ctx, sars_index); a.reset(); a.add_reads(pmx.ReadSet(ctx, reads))
+    h_all, c_all = a.histogram()
+    b = pmx.Placer(ctx, sars_index); b.reset(); b.add_reads(pmx.ReadSet(ctx, reads[:3000]))
+    c = pmx.Placer(ctx, sars_index); c.reset(); c.add_reads(pmx.ReadSet(ctx, reads[3000:]))
+    hb, cb = b.histogram()
+    c.merge(hb, cb)
+    h2, c2 = c.histogram()
+    assert np.array_equal(h_all, h2) and np.array_equal(c_all, c2)
+    ra = a.score(pmx.TraversalParams(), len(reads)); rc = c.score(pmx.TraversalParams(), len(reads))
+    assert ra.best_score == rc.best_score and ra.best_index == rc.best_index
+
+
+def test_full_size_properties(pmx, ctx, sars, sars_index):
+    """BASELINE config 2 size (1M reads): size-independent checks -- total seed frequency equals the number
+    of emitted seeds, and doubling the read set doubles every count (linearity of the histogram)."""
+    g = sars.genome("node_7618")
+    concat, off = pmx.simulate_paired_reads(g, 500000, seed=42)
+    rs = pmx.ReadSet(ctx, concat=concat, offsets=off)
+    p = pmx.Placer(ctx, sars_index); p.reset(); p.add_reads(rs)
+    h1, c1 = p.histogram()
+    p.add_reads(rs)
+    h2, c2 = p.histogram()
+    assert np.array_equal(h1, h2) and np.array_equal(c2, 2 * c1)
+    assert np.all(h1[1:] > h1[:-1])
+    res = p.score(pmx.TraversalParams(), 2 * (len(off) - 1))
+    assert sars.node_id(res.best_index[4]) in {sars.node_id(int(t)) for t in res.tied_indices[4]}
+    assert "node_7618" in {sars.node_id(int(t)) for t in res.tied_indices[0]}
