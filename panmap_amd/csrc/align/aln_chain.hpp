@@ -1,0 +1,176 @@
+// ALIGN stage, part 2: anchor chaining (mg_lchain_dp, lchain.c:113-230), chain backtracking (:9-76)
+// and compaction (:78-111).  Scores mix int32 and float32 arithmetic; the float expressions keep the
+// reference's operand order and are compiled without contraction.
+#pragma once
+#include "aln_sort.hpp"
+#include "aln_types.hpp"
+
+namespace pmx {
+namespace aln {
+
+// mg_log2 (mmpriv.h:118-126); only valid for x >= 2
+PMX_HD float mg_log2f(float x) {
+    uint32_t zi;
+    memcpy(&zi, &x, 4);
+    float log_2 = (float)(((zi >> 23) & 255) - 128);
+    zi &= ~(255u << 23);
+    zi += 127u << 23;
+    float zf;
+    memcpy(&zf, &zi, 4);
+    log_2 += (-0.34484843f * zf + 2.02466578f) * zf - 0.67487759f;
+    return log_2;
+}
+
+// comput_sc (lchain.c:113-141), is_cdna == 0
+PMX_HD int32_t chain_score(const A128 ai, const A128 aj, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, float chn_pen_gap,
+                           float chn_pen_skip, int n_seg) {
+    const int32_t dq = (int32_t)ai.y - (int32_t)aj.y;
+    const int32_t sidi = (int32_t)((ai.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
+    const int32_t sidj = (int32_t)((aj.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
+    if (dq <= 0 || dq > max_dist_x) return INT32_MIN;
+    const int32_t dr = (int32_t)(ai.x - aj.x);
+    if (sidi == sidj && (dr == 0 || dq > max_dist_y)) return INT32_MIN;
+    const int32_t dd = dr > dq ? dr - dq : dq - dr;
+    if (sidi == sidj && dd > bw) return INT32_MIN;
+    if (n_seg > 1 && sidi == sidj && dr > max_dist_y) return INT32_MIN;
+    const int32_t dg = dr < dq ? dr : dq;
+    const int32_t q_span = (int32_t)(aj.y >> 32 & 0xff);
+    int32_t sc = q_span < dg ? q_span : dg;
+    if (dd || dg > q_span) {
+        const float lin_pen = chn_pen_gap * (float)dd + chn_pen_skip * (float)dg;
+        const float log_pen = dd >= 1 ? mg_log2f((float)(dd + 1)) : 0.0f;
+        if (sidi != sidj) {
+            if (dr == 0) ++sc;   // overlapping paired ends
+            else sc -= (int)(lin_pen < log_pen ? lin_pen : log_pen);
+        } else sc -= (int)(lin_pen + .5f * log_pen);
+    }
+    return sc;
+}
+
+// mg_chain_bk_end (lchain.c:9-25)
+PMX_HD int64_t chain_bk_end(int32_t max_drop, const A128* z, const int32_t* f, const int32_t* p, int32_t* t, int64_t k) {
+    int64_t i = (int64_t)z[k].y, end_i = -1, max_i = i;
+    int32_t max_s = 0;
+    if (i < 0 || t[i] != 0) return i;
+    do {
+        t[i] = 2;
+        end_i = i = p[i];
+        const int32_t s = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
+        if (s > max_s) { max_s = s; max_i = i; }
+        else if (max_s - s > max_drop) break;
+    } while (i >= 0 && t[i] == 0);
+    for (i = (int64_t)z[k].y; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
+    return max_i;
+}
+
+// mg_lchain_dp (lchain.c:148-230) followed by mg_chain_backtrack (:27-76) and compact_a (:78-111).
+// In: W.a[0..n_a) sorted anchors.  Out: W.a holds the chained anchors grouped by chain, W.u[0..n_u)
+// = score<<32 | count, chains ordered by the target position of their first anchor.
+PMX_HD void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int n_seg) {
+    const int64_t n = W.n_a;
+    const int bw = o.bw, max_skip = o.max_chain_skip, max_iter = o.max_chain_iter, min_cnt = o.min_cnt, min_sc = o.min_chain_score;
+    const float chn_pen_gap = o.chn_pen_gap, chn_pen_skip = o.chn_pen_skip;
+    W.n_u = 0;
+    if (n == 0) return;
+    A128* a = W.a;
+    int32_t *f = W.f, *t = W.t, *v = W.v, *p = W.p;
+    const int32_t max_drop = bw;
+    if (max_dist_x < bw) max_dist_x = bw;
+    if (max_dist_y < bw) max_dist_y = bw;
+    for (int64_t i = 0; i < n; ++i) t[i] = 0;
+    int64_t st = 0, max_ii = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t max_j = -1, end_j;
+        int32_t max_f = (int32_t)(a[i].y >> 32 & 0xff), n_skip = 0;
+        while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist_x)) ++st;
+        if (i - st > max_iter) st = i - max_iter;
+        int64_t j;
+        for (j = i - 1; j >= st; --j) {
+            int32_t sc = chain_score(a[i], a[j], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+            if (sc == INT32_MIN) continue;
+            sc += f[j];
+            if (sc > max_f) {
+                max_f = sc;
+                max_j = j;
+                if (n_skip > 0) --n_skip;
+            } else if (t[j] == (int32_t)i) {
+                if (++n_skip > max_skip) break;
+            }
+            if (p[j] >= 0) t[p[j]] = (int32_t)i;
+        }
+        end_j = j;
+        if (max_ii < 0 || (int64_t)(a[i].x - a[max_ii].x) > (int64_t)max_dist_x) {
+            int32_t mx = INT32_MIN;
+            max_ii = -1;
+            for (j = i - 1; j >= st; --j)
+                if (mx < f[j]) { mx = f[j]; max_ii = j; }
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            const int32_t tmp = chain_score(a[i], a[max_ii], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+            if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
+        }
+        f[i] = max_f;
+        p[i] = (int32_t)max_j;
+        v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
+        if (max_ii < 0 || ((int64_t)(a[i].x - a[max_ii].x) <= (int64_t)max_dist_x && f[max_ii] < f[i])) max_ii = i;
+    }
+
+    // ---- backtrack (lchain.c:27-76)
+    A128* z = W.z;
+    int64_t n_z = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (f[i] >= min_sc) { z[n_z].x = (uint64_t)(int64_t)f[i]; z[n_z].y = (uint64_t)i; ++n_z; }
+    if (n_z == 0) { W.n_a = 0; return; }
+    radix_sort_128x(z, z + n_z, &W.status);
+    for (int64_t i = 0; i < n; ++i) t[i] = 0;
+    int64_t n_v = 0;
+    int32_t n_u = 0;
+    uint64_t* u = W.u;
+    // (the reference runs this loop twice, first only to size u[]; one pass gives the same u[] and v[])
+    for (int64_t k = n_z - 1; k >= 0; --k) {
+        if (t[z[k].y] == 0) {
+            const int64_t n_v0 = n_v;
+            const int64_t end_i = chain_bk_end(max_drop, z, f, p, t, k);
+            int64_t i;
+            for (i = (int64_t)z[k].y; i != end_i; i = p[i]) { v[n_v++] = (int32_t)i; t[i] = 1; }
+            const int32_t sc = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
+            if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
+                if (n_u < W.caps.max_reg * 4) u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(n_v - n_v0);
+                else { W.status |= PMX_ST_OVERFLOW; n_v = n_v0; }
+            } else n_v = n_v0;
+        }
+    }
+    if (n_u == 0) { W.n_a = 0; W.n_u = 0; return; }
+
+    // ---- compact (lchain.c:78-111): chains reversed into ascending order, then sorted by target position
+    A128* b = W.a2;
+    int64_t kk = 0;
+    for (int32_t i = 0; i < n_u; ++i) {
+        const int64_t k0 = kk;
+        const int32_t ni = (int32_t)u[i];
+        for (int32_t j = 0; j < ni; ++j) b[kk++] = a[v[k0 + (ni - j - 1)]];
+    }
+    A128* wv = W.z;   // z[] is free again
+    kk = 0;
+    for (int32_t i = 0; i < n_u; ++i) {
+        wv[i].x = b[kk].x;
+        wv[i].y = (uint64_t)kk << 32 | (uint32_t)i;
+        kk += (int32_t)u[i];
+    }
+    radix_sort_128x(wv, wv + n_u, &W.status);
+    uint64_t* u2 = W.u2;
+    kk = 0;
+    for (int32_t i = 0; i < n_u; ++i) {
+        const int32_t j = (int32_t)wv[i].y, nn = (int32_t)u[j];
+        u2[i] = u[j];
+        const int64_t src = (int64_t)(wv[i].y >> 32);
+        for (int32_t q = 0; q < nn; ++q) a[kk + q] = b[src + q];
+        kk += nn;
+    }
+    for (int32_t i = 0; i < n_u; ++i) u[i] = u2[i];
+    W.n_a = kk;
+    W.n_u = n_u;
+}
+
+}  // namespace aln
+}  // namespace pmx

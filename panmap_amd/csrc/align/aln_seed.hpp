@@ -1,0 +1,285 @@
+// ALIGN stage, part 1: minimizer sketch, index lookup, seed filtering and the heap merge that turns
+// minimizer occurrences into sorted anchors.
+// Reference behaviour: sketch.c:28-143 (mm_sketch, hash64), index.c:81-99 (mm_idx_get), seed.c:28-131
+// (mm_seed_collect_all, mm_seed_select, mm_collect_matches), map.c:59-166 (collect_minimizers,
+// collect_seed_hits_heap).
+#pragma once
+#include "aln_types.hpp"
+
+namespace pmx {
+namespace aln {
+
+// invertible integer hash restricted to 2k bits (sketch.c:28-38)
+PMX_HD uint64_t mz_hash64(uint64_t key, uint64_t mask) {
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+// (w,k)-minimizers of one segment, appended to W.mv (no HPC).  seq holds nt4 codes (>=4 ambiguous).
+// Output layout as the reference: x = hash<<8 | span, y = rid<<32 | lastPos<<1 | strand.
+PMX_HD void sketch_segment(Work& W, const uint8_t* seq, int len, int w, int k, uint32_t rid) {
+    const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
+    uint64_t kmer0 = 0, kmer1 = 0;
+    int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
+    A128* buf = W.sk_buf;
+    A128 mn;
+    mn.x = mn.y = UINT64_MAX;
+    for (int j = 0; j < w; ++j) buf[j].x = buf[j].y = UINT64_MAX;
+#define PMX_MV_PUSH(val)                                              \
+    do {                                                              \
+        if (W.n_mv < W.caps.max_mini) W.mv[W.n_mv] = (val);           \
+        else W.status |= PMX_ST_OVERFLOW;                             \
+        if (W.n_mv < W.caps.max_mini) ++W.n_mv;                       \
+    } while (0)
+    for (int i = 0; i < len; ++i) {
+        const int c = seq[i];
+        A128 info;
+        info.x = info.y = UINT64_MAX;
+        if (c < 4) {
+            kmer_span = l + 1 < k ? l + 1 : k;
+            kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+            kmer1 = (kmer1 >> 2) | (uint64_t)(3 ^ c) << shift1;
+            if (kmer0 == kmer1) continue;   // strand-symmetric k-mer: skipped without advancing the window
+            const int z = kmer0 < kmer1 ? 0 : 1;
+            ++l;
+            if (l >= k && kmer_span < 256) {
+                info.x = mz_hash64(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
+                info.y = (uint64_t)rid << 32 | (uint32_t)i << 1 | (uint32_t)z;
+            }
+        } else {
+            l = 0;
+            kmer_span = 0;
+        }
+        buf[buf_pos] = info;
+        if (l == w + k - 1 && mn.x != UINT64_MAX) {   // first full window: emit earlier identical k-mers
+            for (int j = buf_pos + 1; j < w; ++j)
+                if (mn.x == buf[j].x && buf[j].y != mn.y) PMX_MV_PUSH(buf[j]);
+            for (int j = 0; j < buf_pos; ++j)
+                if (mn.x == buf[j].x && buf[j].y != mn.y) PMX_MV_PUSH(buf[j]);
+        }
+        if (info.x <= mn.x) {                          // new minimum: flush the old one
+            if (l >= w + k && mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
+            mn = info;
+            min_pos = buf_pos;
+        } else if (buf_pos == min_pos) {               // the minimum slid out of the window
+            if (l >= w + k - 1 && mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
+            mn.x = UINT64_MAX;
+            for (int j = buf_pos + 1; j < w; ++j)
+                if (mn.x >= buf[j].x) { mn = buf[j]; min_pos = j; }   // >= keeps the right-most
+            for (int j = 0; j <= buf_pos; ++j)
+                if (mn.x >= buf[j].x) { mn = buf[j]; min_pos = j; }
+            if (l >= w + k - 1 && mn.x != UINT64_MAX) {
+                for (int j = buf_pos + 1; j < w; ++j)
+                    if (mn.x == buf[j].x && mn.y != buf[j].y) PMX_MV_PUSH(buf[j]);
+                for (int j = 0; j <= buf_pos; ++j)
+                    if (mn.x == buf[j].x && mn.y != buf[j].y) PMX_MV_PUSH(buf[j]);
+            }
+        }
+        if (++buf_pos == w) buf_pos = 0;
+    }
+    if (mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
+#undef PMX_MV_PUSH
+}
+
+// collect_minimizers (map.c:59-73): segment s gets rid = s and its positions shifted by the summed
+// lengths of the previous segments.  (sdust masking is off: options.c:23.)
+PMX_HD void collect_minimizers(Work& W, const Opt& o) {
+    W.n_mv = 0;
+    int sum = 0;
+    for (int s = 0; s < W.n_segs; ++s) {
+        const int n0 = W.n_mv;
+        sketch_segment(W, W.qseq[s][0], W.qlen[s], o.w, o.k, (uint32_t)s);
+        for (int j = n0; j < W.n_mv; ++j) W.mv[j].y += (uint64_t)sum << 1;
+        sum += W.qlen[s];
+    }
+}
+
+// mm_idx_get (index.c:81-99)
+PMX_HD uint32_t index_lookup(const RefIndex& ri, uint64_t minier, uint32_t* off) {
+    uint32_t slot = (uint32_t)mix64(minier) & ri.ht_mask;
+    while (true) {
+        const uint64_t key = ri.ht_key[slot];
+        if (key == minier) { *off = ri.ht_off[slot]; return ri.ht_cnt[slot]; }
+        if (key == UINT64_MAX) return 0;
+        slot = (slot + 1) & ri.ht_mask;
+    }
+}
+
+// binary heaps exactly as ksort.h:43-59 builds them (ties must break the same way)
+PMX_HD void heap_down_min_x(A128* l, int i, int n) {   // "less" = a.x > b.x  -> min-heap on x (map.c:76)
+    int k = i;
+    const A128 tmp = l[i];
+    while ((k = (k << 1) + 1) < n) {
+        if (k != n - 1 && l[k].x > l[k + 1].x) ++k;
+        if (l[k].x > tmp.x) break;
+        l[i] = l[k];
+        i = k;
+    }
+    l[i] = tmp;
+}
+PMX_HD void heap_down_max_u64(uint64_t* l, int i, int n) {   // ks_heapdown_uint64_t: max-heap
+    int k = i;
+    const uint64_t tmp = l[i];
+    while ((k = (k << 1) + 1) < n) {
+        if (k != n - 1 && l[k] < l[k + 1]) ++k;
+        if (l[k] < tmp) break;
+        l[i] = l[k];
+        i = k;
+    }
+    l[i] = tmp;
+}
+
+// mm_seed_select (seed.c:56-96): within a streak of high-occurrence minimizers keep the
+// max_high_occ least frequent ones.
+PMX_HD void seed_select(int n, Seed* a, int len, int max_occ, int max_max_occ, int dist) {
+    if (n == 0 || n == 1) return;
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if ((int)a[i].n > max_occ) ++m;
+    if (m == 0) return;
+    uint64_t b[128];
+    int last0 = -1;
+    for (int i = 0; i <= n; ++i) {
+        if (i == n || (int)a[i].n <= max_occ) {
+            if (i - last0 > 1) {
+                const int ps = last0 < 0 ? 0 : (int)(a[last0].q_pos >> 1);
+                const int pe = i == n ? len : (int)(a[i].q_pos >> 1);
+                const int st = last0 + 1, en = i;
+                int max_high_occ = (int)((double)(pe - ps) / dist + .499);
+                if (max_high_occ > 0) {
+                    if (max_high_occ > 128) max_high_occ = 128;
+                    int j, k;
+                    for (j = st, k = 0; j < en && k < max_high_occ; ++j, ++k) b[k] = (uint64_t)a[j].n << 32 | (uint32_t)j;
+                    for (int q = (k >> 1) - 1; q >= 0; --q) heap_down_max_u64(b, q, k);
+                    for (; j < en; ++j) {
+                        if ((int)a[j].n < (int)(b[0] >> 32)) {
+                            b[0] = (uint64_t)a[j].n << 32 | (uint32_t)j;
+                            heap_down_max_u64(b, 0, k);
+                        }
+                    }
+                    for (j = 0; j < k; ++j) a[(uint32_t)b[j]].flt = 1;
+                }
+                for (int j = st; j < en; ++j) a[j].flt ^= 1;
+                for (int j = st; j < en; ++j)
+                    if ((int)a[j].n > max_max_occ) a[j].flt = 1;
+            }
+            last0 = i;
+        }
+    }
+}
+
+// mm_collect_matches (seed.c:98-131) + mm_seed_collect_all (:28-52)
+PMX_HD void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
+    int n_m0 = 0;
+    for (int i = 0; i < W.n_mv; ++i) {
+        const A128 p = W.mv[i];
+        uint32_t off = 0;
+        const uint32_t t = index_lookup(ri, p.x >> 8, &off);
+        if (t == 0) continue;
+        Seed q;
+        q.q_pos = (uint32_t)p.y;
+        q.q_span = (uint32_t)(p.x & 0xff);
+        q.off = off;
+        q.n = t;
+        q.seg_id = (uint32_t)(p.y >> 32);
+        q.is_tandem = q.flt = 0;
+        if (i > 0 && p.x >> 8 == W.mv[i - 1].x >> 8) q.is_tandem = 1;
+        if (i < W.n_mv - 1 && p.x >> 8 == W.mv[i + 1].x >> 8) q.is_tandem = 1;
+        W.seeds[n_m0++] = q;
+    }
+    if (o.occ_dist > 0 && o.max_max_occ > max_occ) seed_select(n_m0, W.seeds, qlen, max_occ, o.max_max_occ, o.occ_dist);
+    else
+        for (int i = 0; i < n_m0; ++i)
+            if ((int)W.seeds[i].n > max_occ) W.seeds[i].flt = 1;
+    int rep_st = 0, rep_en = 0, n_m = 0, rep_len = 0;
+    int64_t n_a = 0;
+    W.n_mini_pos = 0;
+    for (int i = 0; i < n_m0; ++i) {
+        const Seed q = W.seeds[i];
+        if (q.flt) {
+            const int en = (int)(q.q_pos >> 1) + 1, st = en - (int)q.q_span;
+            if (st > rep_en) {
+                rep_len += rep_en - rep_st;
+                rep_st = st;
+                rep_en = en;
+            } else rep_en = en;
+        } else {
+            n_a += q.n;
+            W.mini_pos[W.n_mini_pos++] = (uint64_t)q.q_span << 32 | q.q_pos >> 1;
+            W.seeds[n_m++] = q;
+        }
+    }
+    rep_len += rep_en - rep_st;
+    W.n_seeds = n_m;
+    W.n_a = n_a;
+    W.rep_len = rep_len;
+}
+
+// collect_seed_hits_heap (map.c:102-166): k-way merge of the occurrence lists by reference position;
+// forward-strand anchors first, then the reverse-strand ones, both ascending.
+PMX_HD void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
+    collect_matches(W, o, ri, qlen, max_occ);
+    if (W.n_a > W.caps.max_anchor) {
+        W.status |= PMX_ST_OVERFLOW;
+        W.n_a = 0;
+        return;
+    }
+    const int n_m = W.n_seeds;
+    const int64_t n_a = W.n_a;
+    A128* heap = W.heap;
+    A128* a = W.a;
+    int heap_size = 0;
+    for (int i = 0; i < n_m; ++i) {
+        if (W.seeds[i].n > 0) {
+            heap[heap_size].x = ri.pos[W.seeds[i].off];
+            heap[heap_size].y = (uint64_t)i << 32;
+            ++heap_size;
+        }
+    }
+    for (int q = (heap_size >> 1) - 1; q >= 0; --q) heap_down_min_x(heap, q, heap_size);
+    int64_t n_for = 0, n_rev = 0;
+    while (heap_size > 0) {
+        const Seed q = W.seeds[heap[0].y >> 32];
+        const uint64_t r = heap[0].x;
+        const int32_t rpos = (int32_t)((uint32_t)r >> 1);
+        A128 p;
+        if ((r & 1) == (q.q_pos & 1)) {   // forward strand
+            p.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+            p.y = (uint64_t)q.q_span << 32 | q.q_pos >> 1;
+            p.y |= (uint64_t)q.seg_id << PMX_SEED_SEG_SHIFT;
+            if (q.is_tandem) p.y |= PMX_SEED_TANDEM;
+            a[n_for++] = p;
+        } else {                          // reverse strand: query position mirrored
+            p.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+            p.y = (uint64_t)q.q_span << 32 | (uint32_t)(qlen - ((int)(q.q_pos >> 1) + 1 - (int)q.q_span) - 1);
+            p.y |= (uint64_t)q.seg_id << PMX_SEED_SEG_SHIFT;
+            if (q.is_tandem) p.y |= PMX_SEED_TANDEM;
+            a[n_a - (++n_rev)] = p;
+        }
+        if ((uint32_t)heap[0].y < q.n - 1) {
+            ++heap[0].y;
+            heap[0].x = ri.pos[W.seeds[heap[0].y >> 32].off + (uint32_t)heap[0].y];
+        } else {
+            heap[0] = heap[heap_size - 1];
+            --heap_size;
+        }
+        heap_down_min_x(heap, 0, heap_size);
+    }
+    // the reverse-strand block was filled back to front
+    for (int64_t j = 0; j < n_rev >> 1; ++j) {
+        const A128 t = a[n_a - 1 - j];
+        a[n_a - 1 - j] = a[n_a - (n_rev - j)];
+        a[n_a - (n_rev - j)] = t;
+    }
+    // (no seed is skipped on this path: MM_F_NO_DIAG/NO_DUAL/FOR_ONLY/REV_ONLY are never set, so
+    //  n_for + n_rev == n_a; map.c:161-164 is a no-op)
+}
+
+}  // namespace aln
+}  // namespace pmx

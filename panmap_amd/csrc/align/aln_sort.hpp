@@ -1,0 +1,92 @@
+// Sorting primitives with the reference's exact (unstable, but deterministic) behaviour.
+// minimap2 sorts everything with KRADIX_SORT (ksort.h:98-153): insertion sort up to 64 elements, else
+// an in-place MSD byte radix sort that falls back to insertion sort on buckets <= 64.  Equal keys keep
+// whatever order these procedures leave them in, and that order leaks into results (chain order,
+// hit order), so the procedures are restated here step for step.
+#pragma once
+#include "aln_types.hpp"
+
+namespace pmx {
+namespace aln {
+
+struct KeyX {
+    PMX_HD static uint64_t key(const A128& a) { return a.x; }
+};
+struct KeyU64 {
+    PMX_HD static uint64_t key(const uint64_t& a) { return a; }
+};
+
+template <class T, class K>
+PMX_HD void rs_insertsort(T* beg, T* end) {
+    for (T* i = beg + 1; i < end; ++i) {
+        if (K::key(*i) < K::key(*(i - 1))) {
+            T *j, tmp = *i;
+            for (j = i; j > beg && K::key(tmp) < K::key(*(j - 1)); --j) *j = *(j - 1);
+            *j = tmp;
+        }
+    }
+}
+
+// one level of the American-flag pass on byte `s/8`; iterative over an explicit stack of pending
+// sub-ranges (the reference recurses; the visiting order of disjoint buckets does not matter)
+template <class T, class K>
+PMX_HD void rs_sort_level(T* beg, T* end, int s, T** stk_b, T** stk_e, int* stk_s, int& sp, int stk_cap, uint32_t* overflow) {
+    // bucket boundaries: 256 (begin,end) pairs kept as offsets
+    int32_t bb[256], be[256];
+    for (int k = 0; k < 256; ++k) bb[k] = be[k] = 0;
+    for (T* i = beg; i != end; ++i) ++be[(K::key(*i) >> s) & 255];
+    for (int k = 1; k < 256; ++k) { be[k] += be[k - 1]; bb[k] = be[k - 1]; }
+    for (int k = 0; k < 256;) {
+        if (bb[k] != be[k]) {
+            int l = (int)((K::key(beg[bb[k]]) >> s) & 255);
+            if (l != k) {
+                T tmp = beg[bb[k]], swp;
+                do {
+                    swp = tmp;
+                    tmp = beg[bb[l]];
+                    beg[bb[l]++] = swp;
+                    l = (int)((K::key(tmp) >> s) & 255);
+                } while (l != k);
+                beg[bb[k]++] = tmp;
+            } else ++bb[k];
+        } else ++k;
+    }
+    bb[0] = 0;
+    for (int k = 1; k < 256; ++k) bb[k] = be[k - 1];
+    if (s) {
+        const int s2 = s > 8 ? s - 8 : 0;
+        for (int k = 0; k < 256; ++k) {
+            const int n = be[k] - bb[k];
+            if (n > 64) {
+                if (sp < stk_cap) { stk_b[sp] = beg + bb[k]; stk_e[sp] = beg + be[k]; stk_s[sp] = s2; ++sp; }
+                else *overflow |= PMX_ST_OVERFLOW;
+            } else if (n > 1) rs_insertsort<T, K>(beg + bb[k], beg + be[k]);
+        }
+    }
+}
+
+template <class T, class K>
+PMX_HD void radix_sort(T* beg, T* end, uint32_t* status) {
+    if (end - beg <= 64) {
+        rs_insertsort<T, K>(beg, end);
+        return;
+    }
+    T* stk_b[64];
+    T* stk_e[64];
+    int stk_s[64];
+    int sp = 0;
+    stk_b[0] = beg; stk_e[0] = end; stk_s[0] = 56; sp = 1;
+    while (sp > 0) {
+        --sp;
+        T* b = stk_b[sp];
+        T* e = stk_e[sp];
+        const int s = stk_s[sp];
+        rs_sort_level<T, K>(b, e, s, stk_b, stk_e, stk_s, sp, 64, status);
+    }
+}
+
+PMX_HD void radix_sort_128x(A128* beg, A128* end, uint32_t* status) { radix_sort<A128, KeyX>(beg, end, status); }
+PMX_HD void radix_sort_64(uint64_t* beg, uint64_t* end, uint32_t* status) { radix_sort<uint64_t, KeyU64>(beg, end, status); }
+
+}  // namespace aln
+}  // namespace pmx

@@ -1,0 +1,192 @@
+// ALIGN stage: shared types of the per-read(-pair) mapping pipeline.
+//
+// The pipeline restates, for one wave64 per read pair, what the reference's aligner boundary does per
+// pair (src/mm_align.c:304-354 -> mm_map_frag, src/3rdparty/minimap2/map.c:236-390): sketch -> seed
+// lookup -> chaining DP -> region bookkeeping -> ksw2 dual-affine extension -> mapq -> pairing.
+// All code in align/*.hpp is PMX_HD: it is compiled by hipcc for gfx950 (PMX_W = 64 lanes of one wave
+// execute it; scalar bookkeeping runs redundantly-uniform on every lane, the DP anti-diagonals are
+// spread over the lanes) and by g++ with PMX_W = 1 for the CPU unit tests of the host logic
+// (tests/hostsim; never part of libpanmap_amd.so).
+#pragma once
+#include <stdint.h>
+
+#include "../device/pmx_math.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PMX_W 64
+#else
+#define PMX_W 1
+#endif
+
+namespace pmx {
+namespace aln {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }   // one wave per workgroup
+#else
+inline int lane_id() { return 0; }
+inline void wave_sync() {}
+#endif
+
+struct A128 {
+    uint64_t x, y;
+};
+
+// anchor flag bits in A128::y (mmpriv.h:17-23)
+#define PMX_SEED_LONG_JOIN (1ULL << 40)
+#define PMX_SEED_IGNORE (1ULL << 41)
+#define PMX_SEED_TANDEM (1ULL << 42)
+#define PMX_SEED_SELF (1ULL << 43)
+#define PMX_SEED_SEG_SHIFT 48
+#define PMX_SEED_SEG_MASK (0xffULL << PMX_SEED_SEG_SHIFT)
+
+#define PMX_PARENT_UNSET (-1)
+#define PMX_PARENT_TMP_PRI (-2)
+
+// ksw2 flags (ksw2.h:8-19)
+#define PMX_EZ_SCORE_ONLY 0x01
+#define PMX_EZ_RIGHT 0x02
+#define PMX_EZ_APPROX_MAX 0x08
+#define PMX_EZ_APPROX_DROP 0x10
+#define PMX_EZ_EXTZ_ONLY 0x40
+#define PMX_EZ_REV_CIGAR 0x80
+#define PMX_KSW_NEG_INF (-0x40000000)
+
+// Mapping options actually read on this path: the option block of setup_minimap2(for_scoring=1)
+// (src/mm_align.c:118-188) on top of mm_mapopt_init (options.c:14-64) and mm_mapopt_update (:66-81).
+struct Opt {
+    int k, w;                       // minimizer index parameters
+    int is_sr_like;                 // mean read length < 500 branch (FRAG_MODE | HEAP_SORT)
+    int seed;
+    int bw, bw_long, max_gap, max_gap_ref, max_frag_len, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
+    float chain_gap_scale, chain_skip_scale;
+    float chn_pen_gap, chn_pen_skip;  // chain_gap_scale * 0.01 * k, evaluated on the host (map.c:282-283)
+    float mask_level;
+    int mask_len;
+    float pri_ratio;
+    int best_n;
+    float alt_drop;
+    int a, b, q, e, q2, e2, sc_ambi, zdrop, zdrop_inv, end_bonus, min_dp_max, min_ksw_len;
+    float max_clip_ratio;
+    int rank_min_len;
+    float rank_frac;
+    int pe_ori, pe_bonus;
+    int mid_occ, max_occ, max_max_occ, occ_dist;
+    float q_occ_frac;
+    int64_t max_sw_mat;
+    int rmq_rescue_size;
+    float rmq_rescue_ratio;
+    int8_t mat[25];
+    int ref_len;
+};
+
+// Device-resident minimizer index of ONE reference sequence (replaces mm_idx_str / mm_idx_get,
+// index.c:81-99, 408-451): open-addressing table keyed by the minimizer value, occurrence lists sorted
+// ascending (index.c:252 sorts by position).
+struct RefIndex {
+    const uint8_t* seq;     // nt4 codes 0..4, ref_len bytes
+    int32_t len;
+    uint32_t ht_mask;       // table size - 1
+    const uint64_t* ht_key; // minimizer (x >> 8); UINT64_MAX = empty
+    const uint32_t* ht_off; // first occurrence in pos[]
+    const uint32_t* ht_cnt; // number of occurrences
+    const uint64_t* pos;    // y values: rid<<32 | lastPos<<1 | strand
+    // logf tables computed by the host libm (hit.c:440-457, pe.c:160): bit-identical mapq without
+    // relying on a device logf.   logf_ratio[d] = logf((float)d / a) ; logf_int[n] = logf((float)n)
+    const float* logf_ratio;
+    const float* logf_int;
+    int32_t n_logf;
+};
+
+struct Seed {           // mm_seed_t (mmpriv.h:42-49)
+    uint32_t n, q_pos, q_span, flt, seg_id, is_tandem, off;
+};
+
+struct Reg {            // mm_reg1_t + mm_extra_t (minimap.h:98-128)
+    int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
+    uint32_t hash;
+    float div;
+    uint8_t mapq, split, rev, inv, sam_pri, proper_frag, pe_thru, seg_split, seg_id, split_inv, is_alt, strand_retained;
+    // extra
+    uint8_t has_p;
+    int32_t dp_score, dp_max, dp_max2;
+    uint32_t n_ambi;
+    uint32_t n_cigar;
+    uint32_t cig_slot;   // index of this region's CIGAR buffer in the per-wave CIGAR pool
+};
+
+struct Ez {             // ksw_extz_t (ksw2.h:27-36)
+    uint32_t max;
+    int zdropped;
+    int max_q, max_t, mqe, mqe_t, mte, mte_q, score, n_cigar, reach_end;
+};
+
+// status bits reported per record
+#define PMX_ST_OVERFLOW 0x1
+#define PMX_ST_UNSUPPORTED 0x2
+
+// Capacities of the per-wave work memory (chosen by the host from the read-length regime).
+struct Caps {
+    int max_qlen;      // per segment
+    int max_mini;      // minimizers per fragment
+    int max_anchor;    // anchors per fragment
+    int max_reg;       // regions per list
+    int max_cigar;     // CIGAR ops per region
+    int max_tlen;      // DP target length
+    int n_cig_slots;   // CIGAR buffers in the pool
+};
+
+// Per-wave work memory: plain pointers into the LDS arena ("fast") or the global scratch slab ("slow");
+// which array lives where is decided by the host planner (align_layout()).
+struct Work {
+    Caps caps;
+    // sequences
+    uint8_t* qseq[2][2];   // [segment][strand] nt4 codes; strand 1 = reverse complement
+    int qlen[2];
+    int n_segs;
+    // sketch / seeds
+    A128* mv;
+    int n_mv;
+    A128* sk_buf;          // minimizer window ring (w entries)
+    Seed* seeds;
+    int n_seeds;
+    uint64_t* mini_pos;
+    int n_mini_pos;
+    A128* heap;
+    // anchors + chaining
+    A128* a;
+    A128* a2;
+    int64_t n_a;
+    int32_t *f, *t, *v, *p;
+    A128* z;
+    uint64_t* u;
+    uint64_t* u2;
+    int n_u;
+    // regions
+    Reg* regs0;
+    Reg* regs[2];
+    Reg* reg_tmp;
+    int n_regs0, n_regs[2];
+    A128* seg_a[2];
+    uint64_t* seg_u[2];
+    int seg_n_a[2], seg_n_u[2];
+    uint64_t* aux64;       // small sort scratch (max_reg * 2)
+    A128* aux128;
+    // DP
+    int8_t *du, *dv, *dx, *dy, *dx2, *dy2, *ds;
+    uint8_t *sf, *qr;
+    int32_t* H;
+    int32_t *off, *off_end;
+    uint8_t* tb;           // traceback matrix (global)
+    uint8_t* tseq;
+    uint32_t* cig_tmp;     // ez->cigar
+    uint32_t* cig_pool;    // n_cig_slots * max_cigar
+    int cig_next;
+    uint32_t status;
+    int rep_len;
+    int frag_gap;
+};
+
+}  // namespace aln
+}  // namespace pmx

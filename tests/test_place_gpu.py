@@ -58,7 +58,9 @@ def test_log1p_device_restatement_is_exact(pmx, oracle, ctx, sars_index):
     kh, kl = placer.kept_seeds()
     order = np.argsort(keys)
     assert np.array_equal(kh, keys[order])
-    want = np.log1p(counts[order].astype(np.float64))
+    # the checker is glibc's log1p (through the oracle), NOT numpy's own log1p (differs in ~1% of inputs)
+    wh, want, _ = oracle.finalize_reads(keys[order], counts[order], 19, 0.0, 1)
+    assert np.array_equal(wh, kh)
     assert np.array_equal(kl.view(np.uint64), want.view(np.uint64))
 
 
