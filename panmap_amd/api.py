@@ -433,3 +433,95 @@ def place_lite(ctx: Context, placer: Placer, reads1: str, reads2: str, output_pa
         with open(output_path, "w") as f:
             f.write(format_placement_tsv(res, node_id))
     return res
+
+
+# ------------------------------------------------------------------------------------ align
+REC_DTYPE = np.dtype([("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"), ("mapq", "u1"), ("rev", "u1"),
+                      ("proper_frag", "u1"), ("mapped", "u1"), ("n_cigar", "<u2"), ("flags", "<u2"), ("cigar_off", "<u4"),
+                      ("score", "<i4")])
+ALN_OVERFLOW, ALN_UNSUPPORTED, ALN_HAS_ALN = 1, 2, 4
+INT_MAX = 2147483647
+
+
+class Aligner:
+    """Device-resident minimizer index of one reference genome + the map/align kernel
+    (setup_minimap2 + align workers, src/mm_align.c:118-188, 304-354)."""
+
+    def __init__(self, ctx: Context, reference: bytes, mean_read_len: int):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        self._ref = bytes(reference)
+        check(lib.pmx_aligner_create(ctx._h, self._ref, len(self._ref), int(mean_read_len), C.byref(self._h)), "pmx_aligner_create")
+
+    def align_readset(self, rs: ReadSet, paired: bool, revcomp_mate2: bool = False):
+        check(lib.pmx_align_readset(self.ctx._h, self._h, rs._h, int(paired), int(revcomp_mate2)), "pmx_align_readset")
+
+    def fetch(self):
+        n = lib.pmx_align_num_records(self._h)
+        words = lib.pmx_align_cigar_words(self.ctx._h, self._h)
+        if words < 0:
+            raise _lib.PmxError(int(words), "pmx_align_cigar_words")
+        recs = np.zeros(max(n, 1), REC_DTYPE)
+        cig = np.zeros(max(words, 1), np.uint32)
+        check(lib.pmx_align_fetch(self.ctx._h, self._h, recs.ctypes.data, len(recs), cig.ctypes.data, len(cig)), "pmx_align_fetch")
+        return recs[:n], cig[:words]
+
+    def align_reads(self, reads, paired: bool, revcomp_mate2: bool = False):
+        """-> list of per-pair (or per-read) dicts shaped like align_pair_result_t."""
+        rs = ReadSet(self.ctx, reads)
+        self.align_readset(rs, paired, revcomp_mate2)
+        recs, cig = self.fetch()
+        rs.close()
+        return records_to_results(recs, cig, paired)
+
+    def close(self):
+        if self._h:
+            lib.pmx_aligner_free(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _one_result(r, cig):
+    if not r["mapped"] or not (r["flags"] & ALN_HAS_ALN):
+        return dict(pos=INT_MAX, rs=0, re=0, qs=0, qe=0, mapq=0, rev=0, proper_frag=0, cigar=[])
+    return dict(pos=int(r["rs"]) + 1, rs=int(r["rs"]), re=int(r["re"]), qs=int(r["qs"]), qe=int(r["qe"]), mapq=int(r["mapq"]),
+                rev=int(r["rev"]), proper_frag=int(r["proper_frag"]),
+                cigar=[int(x) for x in cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]])
+
+
+def records_to_results(recs, cig, paired: bool):
+    out = []
+    if paired:
+        for i in range(len(recs) // 2):
+            a, b = recs[2 * i], recs[2 * i + 1]
+            out.append(dict(mapped=int(a["mapped"]), r1=_one_result(a, cig), r2=_one_result(b, cig), flags=int(a["flags"] | b["flags"])))
+    else:
+        for r in recs:
+            out.append(dict(mapped=int(r["mapped"]), r1=_one_result(r, cig), r2=None, flags=int(r["flags"])))
+    return out
+
+
+def align_reads_direct(reference: bytes, reads, paired: bool, n_threads: int = 1):
+    """The reference's C-ABI boundary (src/mm_align.h:44-53) through libpanmap_amd.so."""
+    n = len(reads)
+    arr = (C.c_char_p * n)(*reads)
+    quals = (C.c_char_p * n)(*[b"I" * len(r) for r in reads])
+    names = (C.c_char_p * n)(*[b"r%d" % i for i in range(n)])
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    n_res = n // 2 if paired else n
+    res = (_lib.AlignPairResult * max(n_res, 1))()
+    lib.pmx_align_reads_direct(reference, b"ref", n, arr, quals, names, lens, res, paired, n_threads)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+
+    def unpack(ra):
+        cg = [ra.cigar[i] for i in range(ra.n_cigar)] if ra.cigar else []
+        if ra.cigar:
+            libc.free(C.cast(ra.cigar, C.c_void_p))
+        return dict(pos=ra.pos, rs=ra.rs, re=ra.re, qs=ra.qs, qe=ra.qe, mapq=ra.mapq, rev=ra.rev, proper_frag=ra.proper_frag, cigar=cg)
+    return [dict(mapped=res[i].mapped, r1=unpack(res[i].r1), r2=unpack(res[i].r2) if paired else None) for i in range(n_res)]

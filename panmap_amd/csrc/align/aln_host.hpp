@@ -1,0 +1,307 @@
+// ALIGN stage, host side (plain C++, no HIP): option presets, reference minimizer index build, work
+// memory layout.  Shared by the product (api_align.hip) and the CPU unit-test build (tests/hostsim).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "aln_map.hpp"
+
+namespace pmx {
+namespace aln {
+
+// mm_mapopt_init + mm_idxopt_init (options.c:5-64), then the branch setup_minimap2(for_scoring=1) takes
+// for the mean read length (src/mm_align.c:118-180; "map-hifi" per options.c:109-116).
+// mid_occ for the long-read presets is filled in by finish_opt() once the index is known.
+inline Opt make_opt(int mean_read_len) {
+    Opt o;
+    memset(&o, 0, sizeof(o));
+    o.k = 15; o.w = 10;
+    o.seed = 11;
+    float mid_occ_frac = 2e-4f;
+    (void)mid_occ_frac;
+    o.q_occ_frac = 0.01f;
+    o.min_cnt = 3; o.min_chain_score = 40;
+    o.bw = 500; o.bw_long = 20000;
+    o.max_gap = 5000; o.max_gap_ref = -1;
+    o.max_chain_skip = 25; o.max_chain_iter = 5000;
+    o.rmq_rescue_size = 1000; o.rmq_rescue_ratio = 0.1f;
+    o.chain_gap_scale = 0.8f; o.chain_skip_scale = 0.0f;
+    o.max_max_occ = 4095; o.occ_dist = 500;
+    o.mask_level = 0.5f; o.mask_len = INT32_MAX;
+    o.pri_ratio = 0.8f; o.best_n = 5;
+    o.alt_drop = 0.15f;
+    o.a = 2; o.b = 4; o.q = 4; o.e = 2; o.q2 = 24; o.e2 = 1;
+    o.sc_ambi = 1;
+    o.zdrop = 400; o.zdrop_inv = 200;
+    o.end_bonus = -1;
+    o.min_dp_max = o.min_chain_score * o.a;
+    o.min_ksw_len = 200;
+    o.max_clip_ratio = 1.0f;
+    o.max_sw_mat = 100000000;
+    o.rank_min_len = 500; o.rank_frac = 0.9f;
+    o.pe_ori = 0; o.pe_bonus = 33;
+    o.mid_occ = 0; o.max_occ = 0;
+    if (mean_read_len < 500) {   // src/mm_align.c:140-166
+        o.is_sr_like = 1;
+        o.k = 21; o.w = 11;
+        o.a = 2; o.b = 8; o.q = 12; o.e = 2; o.q2 = 24; o.e2 = 1;
+        o.zdrop = 100; o.zdrop_inv = 100;
+        o.end_bonus = 10;
+        o.max_frag_len = 800;
+        o.max_gap = 100;
+        o.bw = 100; o.bw_long = 100;
+        o.pri_ratio = 0.5f;
+        o.min_cnt = 2; o.min_chain_score = 25; o.min_dp_max = 40;
+        o.best_n = 20;
+        o.mid_occ = 1000; o.max_occ = 5000;
+        o.pe_ori = 0 << 1 | 1;
+        o.pe_bonus = 33;
+    } else if (mean_read_len < 5000) {
+        // "map-ont" == defaults
+    } else {   // "map-hifi"
+        o.k = 19; o.w = 19;
+        o.max_gap = 10000;
+        o.a = 1; o.b = 4; o.q = 6; o.q2 = 26; o.e = 2; o.e2 = 1;
+        o.occ_dist = 500;
+        o.min_dp_max = 200;
+    }
+    return o;
+}
+
+struct HostRefIndex {
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> ht_key;
+    std::vector<uint32_t> ht_off, ht_cnt;
+    std::vector<uint64_t> pos;
+    std::vector<float> logf_ratio, logf_int;
+    std::vector<uint32_t> occ;   // occurrences per distinct minimizer
+    RefIndex view() const {
+        RefIndex r;
+        r.seq = seq.data();
+        r.len = (int32_t)seq.size();
+        r.ht_mask = (uint32_t)ht_key.size() - 1;
+        r.ht_key = ht_key.data();
+        r.ht_off = ht_off.data();
+        r.ht_cnt = ht_cnt.data();
+        r.pos = pos.data();
+        r.logf_ratio = logf_ratio.data();
+        r.logf_int = logf_int.data();
+        r.n_logf = (int32_t)logf_int.size();
+        return r;
+    }
+};
+
+inline uint8_t nt4_of_char(unsigned char c) {   // seq_nt4_table (sketch.c:9-26)
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+// mm_idx_str(w, k, 0, 14, 1, &ref) (index.c:408-451): sketch the reference, group occurrences by minimizer
+inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp_score, HostRefIndex& out) {
+    out = HostRefIndex();
+    out.seq.resize((size_t)ref_len);
+    for (int64_t i = 0; i < ref_len; ++i) out.seq[i] = nt4_of_char((unsigned char)ref[i]);
+    o.ref_len = (int)ref_len;
+    Work W;
+    memset(&W, 0, sizeof(W));
+    std::vector<A128> mv((size_t)ref_len + 16), buf(256);
+    W.mv = mv.data();
+    W.sk_buf = buf.data();
+    W.caps.max_mini = (int)mv.size();
+    W.n_mv = 0;
+    if (ref_len > 0) sketch_segment(W, out.seq.data(), (int)ref_len, o.w, o.k, 0);
+    mv.resize(W.n_mv);
+    std::stable_sort(mv.begin(), mv.end(), [](const A128& a, const A128& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    size_t n_keys = 0;
+    for (size_t i = 0; i < mv.size(); ++i)
+        if (i == 0 || mv[i].x >> 8 != mv[i - 1].x >> 8) ++n_keys;
+    size_t cap = 16;
+    while (cap < n_keys * 2 + 2) cap <<= 1;
+    out.ht_key.assign(cap, UINT64_MAX);
+    out.ht_off.assign(cap, 0);
+    out.ht_cnt.assign(cap, 0);
+    out.pos.resize(mv.size());
+    for (size_t i = 0; i < mv.size();) {
+        size_t j = i;
+        while (j < mv.size() && mv[j].x >> 8 == mv[i].x >> 8) ++j;
+        std::vector<uint64_t> ys;
+        for (size_t q = i; q < j; ++q) ys.push_back(mv[q].y);
+        std::sort(ys.begin(), ys.end());
+        for (size_t q = i; q < j; ++q) out.pos[q] = ys[q - i];
+        const uint64_t key = mv[i].x >> 8;
+        uint32_t slot = (uint32_t)mix64(key) & (uint32_t)(cap - 1);
+        while (out.ht_key[slot] != UINT64_MAX) slot = (slot + 1) & (uint32_t)(cap - 1);
+        out.ht_key[slot] = key;
+        out.ht_off[slot] = (uint32_t)i;
+        out.ht_cnt[slot] = (uint32_t)(j - i);
+        out.occ.push_back((uint32_t)(j - i));
+        i = j;
+    }
+    // mm_mapopt_update (options.c:66-81): mid_occ from the index when the preset left it unset
+    if (o.mid_occ <= 0) {
+        const float f = 2e-4f;
+        int32_t thres = INT32_MAX;
+        if (!out.occ.empty()) {
+            std::vector<uint32_t> a = out.occ;
+            const size_t kk = (size_t)(uint32_t)((1. - f) * a.size());
+            std::nth_element(a.begin(), a.begin() + std::min(kk, a.size() - 1), a.end());
+            thres = (int32_t)a[std::min(kk, a.size() - 1)] + 1;
+        }
+        int min_mid_occ = 10, max_mid_occ = 1000000;
+        if (o.k == 19 && o.w == 19) { min_mid_occ = 50; max_mid_occ = 500; }   // map-hifi
+        o.mid_occ = thres;
+        if (o.mid_occ < min_mid_occ) o.mid_occ = min_mid_occ;
+        if (max_mid_occ > min_mid_occ && o.mid_occ > max_mid_occ) o.mid_occ = max_mid_occ;
+    }
+    if (o.bw_long < o.bw) o.bw_long = o.bw;
+    o.chn_pen_gap = (float)(o.chain_gap_scale * 0.01 * o.k);
+    o.chn_pen_skip = (float)(o.chain_skip_scale * 0.01 * o.k);
+    gen_simple_mat(o.mat, (int8_t)o.a, (int8_t)o.b, (int8_t)o.sc_ambi);
+    // logf tables from the host libm (hit.c:440-457, pe.c:160)
+    const int n = max_dp_score + 2;
+    out.logf_ratio.resize(n);
+    out.logf_int.resize(n);
+    for (int i = 0; i < n; ++i) {
+        out.logf_ratio[i] = logf((float)i / o.a);
+        out.logf_int[i] = logf((float)i);
+    }
+}
+
+// ------------------------------------------------------------------------------ work memory layout
+enum { PMX_FAST = 0, PMX_SLOW = 1 };
+
+struct Layout {
+    Caps caps;
+    size_t fast_bytes = 0, slow_bytes = 0;
+    size_t tb_cap = 0;
+    struct Ent { uint32_t space; size_t off; };
+    Ent qseq, mv, sk_buf, seeds, mini_pos, heap, a, a2, f, t, v, p, z, u, u2, regs0, regs1, regs2, reg_tmp, seg_a0, seg_a1, seg_u0,
+        seg_u1, aux64, aux128, du, sf, qr, H, off_, tseq, cig_tmp, cig_pool, tb;
+};
+
+// Capacities for a read-length regime; fast = LDS budget (bytes) per wave.
+inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fast_budget) {
+    Layout L;
+    Caps& c = L.caps;
+    c.max_qlen = (max_read_len + 15) / 16 * 16 + 16;
+    const int qsum = c.max_qlen * n_segs;
+    c.max_mini = std::max(64, (int)(qsum * 2 / (o.w + 1)) * 2 + 32);
+    c.max_anchor = std::max(256, c.max_mini * 2);
+    c.max_reg = 32;
+    c.max_cigar = std::max(64, max_read_len / 2 + 16);
+    // DP target length: extension <= query part + gap allowance (align.c:652-688)
+    c.max_tlen = ((std::min(max_read_len, std::max(o.max_gap, o.min_ksw_len + 2 * o.k) * 4) + 2 * o.max_gap + 64) + 15) / 16 * 16 + 32;
+    if (c.max_tlen < c.max_qlen + 64) c.max_tlen = c.max_qlen + 64;
+    c.n_cig_slots = c.max_reg * 2 * n_segs + 4;
+    const int wband = (int)(std::max(o.bw, o.bw_long) * 1.5 + 1.);
+    const int n_col = ((std::min(std::min(c.max_tlen, c.max_qlen), wband + 1) + 15) / 16 + 1) * 16;
+    L.tb_cap = (size_t)(c.max_qlen + c.max_tlen) * n_col;
+
+    size_t used[2] = {0, 0};
+    auto place = [&](Layout::Ent& e, size_t bytes, int pref) {
+        bytes = (bytes + 15) & ~(size_t)15;
+        int sp = pref;
+        if (sp == PMX_FAST && used[PMX_FAST] + bytes > fast_budget) sp = PMX_SLOW;
+        e.space = (uint32_t)sp;
+        e.off = used[sp];
+        used[sp] += bytes;
+    };
+    // hot small arrays first so they win the LDS budget
+    place(L.du, (size_t)7 * (c.max_tlen + 32), PMX_FAST);       // u,v,x,y,x2,y2,s
+    place(L.sf, (size_t)c.max_tlen + 32, PMX_FAST);
+    place(L.qr, (size_t)c.max_tlen + 64, PMX_FAST);
+    place(L.qseq, (size_t)4 * c.max_qlen, PMX_FAST);
+    place(L.tseq, (size_t)c.max_tlen + 32, PMX_FAST);
+    place(L.a, sizeof(A128) * c.max_anchor, PMX_FAST);
+    place(L.f, 4 * (size_t)c.max_anchor, PMX_FAST);
+    place(L.p, 4 * (size_t)c.max_anchor, PMX_FAST);
+    place(L.t, 4 * (size_t)c.max_anchor, PMX_FAST);
+    place(L.v, 4 * (size_t)c.max_anchor, PMX_FAST);
+    place(L.regs0, sizeof(Reg) * c.max_reg, PMX_FAST);
+    place(L.regs1, sizeof(Reg) * c.max_reg, PMX_FAST);
+    place(L.regs2, sizeof(Reg) * c.max_reg, PMX_FAST);
+    place(L.mv, sizeof(A128) * c.max_mini, PMX_FAST);
+    place(L.sk_buf, sizeof(A128) * 256, PMX_SLOW);
+    place(L.seeds, sizeof(Seed) * c.max_mini, PMX_FAST);
+    place(L.H, 4 * (size_t)(c.max_tlen + 32), PMX_FAST);
+    place(L.off_, 8 * (size_t)(c.max_qlen + c.max_tlen), PMX_FAST);
+    place(L.cig_tmp, 4 * (size_t)c.max_cigar, PMX_FAST);
+    place(L.aux64, 8 * (size_t)c.max_reg * 8, PMX_FAST);
+    place(L.aux128, sizeof(A128) * c.max_reg * 4, PMX_FAST);
+    place(L.u, 8 * (size_t)c.max_reg * 4, PMX_FAST);
+    place(L.u2, 8 * (size_t)c.max_reg * 4, PMX_FAST);
+    place(L.mini_pos, 8 * (size_t)c.max_mini, PMX_SLOW);
+    place(L.heap, sizeof(A128) * c.max_mini, PMX_SLOW);
+    place(L.a2, sizeof(A128) * c.max_anchor, PMX_SLOW);
+    place(L.z, sizeof(A128) * c.max_anchor, PMX_SLOW);
+    place(L.reg_tmp, sizeof(Reg) * c.max_reg, PMX_SLOW);
+    place(L.seg_a0, sizeof(A128) * c.max_anchor, PMX_SLOW);
+    place(L.seg_a1, sizeof(A128) * c.max_anchor, PMX_SLOW);
+    place(L.seg_u0, 8 * (size_t)c.max_reg * 4, PMX_SLOW);
+    place(L.seg_u1, 8 * (size_t)c.max_reg * 4, PMX_SLOW);
+    place(L.cig_pool, 4 * (size_t)c.max_cigar * c.n_cig_slots, PMX_SLOW);
+    place(L.tb, L.tb_cap + 64, PMX_SLOW);
+    L.fast_bytes = used[PMX_FAST];
+    L.slow_bytes = used[PMX_SLOW];
+    return L;
+}
+
+PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow) {
+    uint8_t* base[2] = {fast, slow};
+#define PMX_AT(T, e) ((T*)(base[L.e.space] + L.e.off))
+    W.caps = L.caps;
+    const int mq = L.caps.max_qlen;
+    uint8_t* qs = PMX_AT(uint8_t, qseq);
+    W.qseq[0][0] = qs; W.qseq[0][1] = qs + mq; W.qseq[1][0] = qs + 2 * mq; W.qseq[1][1] = qs + 3 * mq;
+    W.mv = PMX_AT(A128, mv); W.sk_buf = PMX_AT(A128, sk_buf); W.seeds = PMX_AT(Seed, seeds);
+    W.mini_pos = PMX_AT(uint64_t, mini_pos); W.heap = PMX_AT(A128, heap);
+    W.a = PMX_AT(A128, a); W.a2 = PMX_AT(A128, a2);
+    W.f = PMX_AT(int32_t, f); W.t = PMX_AT(int32_t, t); W.v = PMX_AT(int32_t, v); W.p = PMX_AT(int32_t, p);
+    W.z = PMX_AT(A128, z); W.u = PMX_AT(uint64_t, u); W.u2 = PMX_AT(uint64_t, u2);
+    W.regs0 = PMX_AT(Reg, regs0); W.regs[0] = PMX_AT(Reg, regs1); W.regs[1] = PMX_AT(Reg, regs2); W.reg_tmp = PMX_AT(Reg, reg_tmp);
+    W.seg_a[0] = PMX_AT(A128, seg_a0); W.seg_a[1] = PMX_AT(A128, seg_a1);
+    W.seg_u[0] = PMX_AT(uint64_t, seg_u0); W.seg_u[1] = PMX_AT(uint64_t, seg_u1);
+    W.aux64 = PMX_AT(uint64_t, aux64); W.aux128 = PMX_AT(A128, aux128);
+    int8_t* d = PMX_AT(int8_t, du);
+    const int T = L.caps.max_tlen + 32;
+    W.du = d; W.dv = d + T; W.dx = d + 2 * T; W.dy = d + 3 * T; W.dx2 = d + 4 * T; W.dy2 = d + 5 * T; W.ds = d + 6 * T;
+    W.sf = PMX_AT(uint8_t, sf); W.qr = PMX_AT(uint8_t, qr);
+    W.H = PMX_AT(int32_t, H);
+    W.off = PMX_AT(int32_t, off_); W.off_end = W.off + (L.caps.max_qlen + L.caps.max_tlen);
+    W.tb = PMX_AT(uint8_t, tb); W.tb_cap = L.tb_cap;
+    W.tseq = PMX_AT(uint8_t, tseq);
+    W.cig_tmp = PMX_AT(uint32_t, cig_tmp); W.cig_pool = PMX_AT(uint32_t, cig_pool);
+#undef PMX_AT
+    W.status = 0;
+    W.cig_next = 0;
+}
+
+// fixed-size output record (== pmx_aln_record in include/panmap_amd.h)
+struct AlnRecord {
+    int32_t rs, re, qs, qe;
+    uint8_t mapq, rev, proper_frag, mapped;
+    uint16_t n_cigar;
+    uint16_t flags;
+    uint32_t cigar_off;
+    int32_t score;
+};
+#define PMX_REC_OVERFLOW 0x1
+#define PMX_REC_UNSUPPORTED 0x2
+#define PMX_REC_HAS_ALN 0x4
+
+// extract_align_result + the mapped test of align_worker_func (src/mm_align.c:271-354)
+PMX_HD bool frag_is_mapped(const Work& W, int paired) {
+    if (paired) return W.n_regs[0] > 0 && W.n_regs[1] > 0 && W.regs[0][0].score > 0 && W.regs[1][0].score > 0;
+    return W.n_regs[0] > 0 && W.regs[0][0].score > 0 && W.regs[0][0].score <= W.qlen[0];
+}
+
+}  // namespace aln
+}  // namespace pmx

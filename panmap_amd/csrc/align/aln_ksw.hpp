@@ -1,0 +1,325 @@
+// ALIGN stage, part 4: dual-affine-gap extension / global alignment in the Suzuki-Kasahara difference
+// formulation, one anti-diagonal at a time, cells of a diagonal spread over the lanes of the wave.
+//
+// Restates ksw_extd2_sse (ksw2_extd2_sse.c:27-401) including everything that is observable in its
+// results: wrapping int8 difference arithmetic, the 16-cell rounding of the computed range [st,en]
+// (cells outside the true band are computed from whatever the arrays hold, exactly like the SSE lanes
+// do), boundary injection, the exact-max H[] tracking with its 4-way tie order, approximate max, z-drop,
+// end bonus, and ksw_backtrack (ksw2.h:127-162).  Integer DP: VALU + LDS, no MFMA.
+#pragma once
+#include "aln_types.hpp"
+
+namespace pmx {
+namespace aln {
+
+PMX_HD void ez_reset(Ez& ez) {   // ksw_reset_extz (ksw2.h:164-169)
+    ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
+    ez.max = 0;
+    ez.score = ez.mqe = ez.mte = PMX_KSW_NEG_INF;
+    ez.n_cigar = 0;
+    ez.zdropped = 0;
+    ez.reach_end = 0;
+}
+
+// ksw_apply_zdrop (ksw2.h:171-188), is_rot == 1
+PMX_HD int ez_apply_zdrop(Ez& ez, int32_t H, int r, int t, int zdrop, int8_t e) {
+    if (H > (int32_t)ez.max) {
+        ez.max = (uint32_t)H;
+        ez.max_t = t;
+        ez.max_q = r - t;
+    } else if (t >= ez.max_t && r - t >= ez.max_q) {
+        const int tl = t - ez.max_t, ql = (r - t) - ez.max_q;
+        const int l = tl > ql ? tl - ql : ql - tl;
+        if (zdrop >= 0 && (int32_t)ez.max - H > zdrop + l * e) {
+            ez.zdropped = 1;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+PMX_HD void push_cigar(uint32_t* cigar, int* n_cigar, int cap, uint32_t op, int len, uint32_t* status) {   // ksw_push_cigar
+    if (*n_cigar == 0 || op != (cigar[*n_cigar - 1] & 0xf)) {
+        if (*n_cigar < cap) cigar[(*n_cigar)++] = (uint32_t)len << 4 | op;
+        else *status |= PMX_ST_OVERFLOW;
+    } else cigar[*n_cigar - 1] += (uint32_t)len << 4;
+}
+
+// ksw_backtrack (ksw2.h:127-162) with is_rot = 1, min_intron_len = 0
+PMX_HD void ksw_backtrack(Work& W, int is_rev, const uint8_t* p, const int32_t* off, const int32_t* off_end, int n_col, int i0, int j0,
+                          int* n_cigar_) {
+    int n_cigar = 0, i = i0, j = j0, state = 0;
+    uint32_t* cigar = W.cig_tmp;
+    const int cap = W.caps.max_cigar;
+    while (i >= 0 && j >= 0) {
+        int force_state = -1;
+        const int r = i + j;
+        if (i < off[r]) force_state = 2;
+        if (i > off_end[r]) force_state = 1;
+        const uint32_t tmp = force_state < 0 ? p[(size_t)r * n_col + i - off[r]] : 0;
+        if (state == 0) state = tmp & 7;
+        else if (!(tmp >> (state + 2) & 1)) state = 0;
+        if (state == 0) state = tmp & 7;
+        if (force_state >= 0) state = force_state;
+        if (state == 0) { push_cigar(cigar, &n_cigar, cap, 0, 1, &W.status); --i; --j; }
+        else if (state == 1 || state == 3) { push_cigar(cigar, &n_cigar, cap, 2, 1, &W.status); --i; }
+        else { push_cigar(cigar, &n_cigar, cap, 1, 1, &W.status); --j; }
+    }
+    if (i >= 0) push_cigar(cigar, &n_cigar, cap, 2, i + 1, &W.status);
+    if (j >= 0) push_cigar(cigar, &n_cigar, cap, 1, j + 1, &W.status);
+    if (!is_rev)
+        for (i = 0; i < n_cigar >> 1; ++i) { const uint32_t t = cigar[i]; cigar[i] = cigar[n_cigar - 1 - i]; cigar[n_cigar - 1 - i] = t; }
+    *n_cigar_ = n_cigar;
+}
+
+#if PMX_W > 1
+// max over the wave of a 64-bit key
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t other = __shfl_xor(v, o);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+#else
+inline int64_t wave_max_i64(int64_t v) { return v; }
+#endif
+
+// ksw_extd2_sse.  query/target hold nt4 codes; with_cigar always on.  Results in ez and W.cig_tmp.
+PMX_HD void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+                      int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+    const int lane = lane_id();
+    const int approx_max = !!(flag & PMX_EZ_APPROX_MAX);
+    ez_reset(ez);
+    if (qlen <= 0 || tlen <= 0) return;
+    if (q2 + e2 < q + e) { int8_t t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e;
+    const int8_t sc_mch = mat[0], sc_mis = mat[1], sc_N = mat[24] == 0 ? (int8_t)-e2 : mat[24];
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    const int wl = w, wr = w;
+    const int tlen_ = (tlen + 15) / 16;
+    int n_col_ = qlen < tlen ? qlen : tlen;
+    n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+    const int n_col = n_col_ * 16;
+    {   // "otherwise, we won't see any mismatches" (ksw2_extd2_sse.c:100)
+        int min_sc = mat[1];
+        for (int t = 1; t < 25; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
+        if (-min_sc > 2 * (q + e)) return;
+    }
+    if (tlen_ * 16 > W.caps.max_tlen || qlen > W.caps.max_tlen || (size_t)(qlen + tlen - 1) * (size_t)n_col > W.tb_cap) {
+        W.status |= PMX_ST_OVERFLOW;
+        ez.zdropped = 1;
+        return;
+    }
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+
+    int8_t *u = W.du, *v = W.dv, *x = W.dx, *y = W.dy, *x2 = W.dx2, *y2 = W.dy2, *s = W.ds;
+    uint8_t *sf = W.sf, *qr = W.qr;
+    int32_t* H = W.H;
+    int32_t *off = W.off, *off_end = W.off_end;
+    uint8_t* p = W.tb;
+    const int T16 = tlen_ * 16;
+    // initial fill (ksw2_extd2_sse.c:107-126): every lane takes a stride
+    for (int t = lane; t < T16; t += PMX_W) {
+        u[t] = v[t] = x[t] = y[t] = (int8_t)(-q - e);
+        x2[t] = y2[t] = (int8_t)(-q2 - e2);
+        if (!approx_max) H[t] = PMX_KSW_NEG_INF;
+    }
+    for (int t = lane; t < T16 + 16; t += PMX_W) {
+        s[t] = 0;
+        sf[t] = t < tlen ? target[t] : 0;
+    }
+    const int Q16 = (qlen + 15) / 16 * 16;
+    for (int t = lane; t < Q16 + 32; t += PMX_W) qr[t] = t < qlen ? query[qlen - 1 - t] : 0;
+    wave_sync();
+
+    int last_st = -1, last_en = -1;
+    int32_t H0 = 0, last_H0_t = 0;
+    for (int r = 0; r < qlen + tlen - 1; ++r) {
+        int st = 0, en = tlen - 1;
+        if (st < r - qlen + 1) st = r - qlen + 1;
+        if (en > r) en = r;
+        if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
+        if (en > (r + wl) >> 1) en = (r + wl) >> 1;
+        if (st > en) { ez.zdropped = 1; break; }
+        const int st0 = st, en0 = en;
+        st = st / 16 * 16;
+        en = (en + 16) / 16 * 16 - 1;
+        // boundary conditions (ksw2_extd2_sse.c:150-166)
+        int8_t x1, x21, v1;
+        if (st > 0) {
+            if (st - 1 >= last_st && st - 1 <= last_en) { x1 = x[st - 1]; x21 = x2[st - 1]; v1 = v[st - 1]; }
+            else { x1 = (int8_t)(-q - e); x21 = (int8_t)(-q2 - e2); v1 = (int8_t)(-q - e); }
+        } else {
+            x1 = (int8_t)(-q - e);
+            x21 = (int8_t)(-q2 - e2);
+            v1 = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)-e : r == long_thres ? (int8_t)long_diff : (int8_t)-e2;
+        }
+        wave_sync();   // x1/x21/v1 were read before anybody overwrites; boundary stores below
+        if (en >= r) {
+            y[r] = (int8_t)(-q - e);
+            y2[r] = (int8_t)(-q2 - e2);
+            u[r] = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)-e : r == long_thres ? (int8_t)long_diff : (int8_t)-e2;
+        }
+        // scores (loop fission, :168-189): 16-wide chunks starting at st0
+        const uint8_t* qrr = qr + (qlen - 1 - r);
+        const int s_end = st0 + ((en0 - st0) / 16 + 1) * 16;
+        for (int t = st0 + lane; t < s_end; t += PMX_W) {
+            const uint8_t sq = sf[t], sq2 = qrr[t];
+            int8_t val = sq == sq2 ? sc_mch : sc_mis;
+            if (sq == 4 || sq2 == 4) val = sc_N;
+            s[t] = val;
+        }
+        wave_sync();
+        // core recurrence on [st, en], highest chunk first so that every chunk still sees the previous
+        // diagonal in x[t-1], v[t-1], x2[t-1]
+        off[r] = st;
+        off_end[r] = en;
+        uint8_t* pr = p + (size_t)r * n_col - st;
+        const int n_chunk = (en - st + PMX_W) / PMX_W;
+        for (int c = n_chunk - 1; c >= 0; --c) {
+            const int t = st + c * PMX_W + lane;
+            const bool act = t <= en;
+            int8_t z = 0, a = 0, b = 0, a2 = 0, b2 = 0, vt1 = 0, ut = 0;
+            if (act) {
+                z = s[t];
+                const int8_t xt1 = t == st ? x1 : x[t - 1];
+                vt1 = t == st ? v1 : v[t - 1];
+                const int8_t x2t1 = t == st ? x21 : x2[t - 1];
+                ut = u[t];
+                a = (int8_t)(xt1 + vt1);
+                b = (int8_t)(y[t] + ut);
+                a2 = (int8_t)(x2t1 + vt1);
+                b2 = (int8_t)(y2[t] + ut);
+            }
+            wave_sync();   // all loads of the old diagonal done before any store
+            if (act) {
+                uint8_t d;
+                if (!(flag & PMX_EZ_RIGHT)) {   // gap left-alignment (:228-268)
+                    d = a > z ? 1 : 0;
+                    z = z > a ? z : a;
+                    d = b > z ? 2 : d;
+                    z = z > b ? z : b;
+                    d = a2 > z ? 3 : d;
+                    z = z > a2 ? z : a2;
+                    d = b2 > z ? 4 : d;
+                    z = z > b2 ? z : b2;
+                    z = z < sc_mch ? z : sc_mch;
+                } else {                        // gap right-alignment (:269-321)
+                    d = z > a ? 0 : 1;
+                    z = z > a ? z : a;
+                    d = z > b ? d : 2;
+                    z = z > b ? z : b;
+                    d = z > a2 ? d : 3;
+                    z = z > a2 ? z : a2;
+                    d = z > b2 ? d : 4;
+                    z = z > b2 ? z : b2;
+                    z = z < sc_mch ? z : sc_mch;
+                }
+                u[t] = (int8_t)(z - vt1);
+                v[t] = (int8_t)(z - ut);
+                int8_t tmp = (int8_t)(z - q);
+                a = (int8_t)(a - tmp);
+                b = (int8_t)(b - tmp);
+                tmp = (int8_t)(z - q2);
+                a2 = (int8_t)(a2 - tmp);
+                b2 = (int8_t)(b2 - tmp);
+                if (!(flag & PMX_EZ_RIGHT)) {
+                    x[t] = (int8_t)((a > 0 ? a : 0) - qe);
+                    d |= a > 0 ? 0x08 : 0;
+                    y[t] = (int8_t)((b > 0 ? b : 0) - qe);
+                    d |= b > 0 ? 0x10 : 0;
+                    x2[t] = (int8_t)((a2 > 0 ? a2 : 0) - (q2 + e2));
+                    d |= a2 > 0 ? 0x20 : 0;
+                    y2[t] = (int8_t)((b2 > 0 ? b2 : 0) - (q2 + e2));
+                    d |= b2 > 0 ? 0x40 : 0;
+                } else {
+                    x[t] = (int8_t)((0 > a ? 0 : a) - qe);
+                    d |= 0 > a ? 0 : 0x08;
+                    y[t] = (int8_t)((0 > b ? 0 : b) - qe);
+                    d |= 0 > b ? 0 : 0x10;
+                    x2[t] = (int8_t)((0 > a2 ? 0 : a2) - (q2 + e2));
+                    d |= 0 > a2 ? 0 : 0x20;
+                    y2[t] = (int8_t)((0 > b2 ? 0 : b2) - (q2 + e2));
+                    d |= 0 > b2 ? 0 : 0x40;
+                }
+                pr[t] = d;
+            }
+            wave_sync();
+        }
+        if (!approx_max) {   // exact max through the int32 H[] band (:323-366)
+            int32_t max_H, max_t;
+            if (r > 0) {
+                const int32_t h_en0 = en0 > 0 ? H[en0 - 1] + u[en0] : H[en0] + v[en0];
+                wave_sync();
+                // candidate order among equal H: en0 first, then the four t-classes of the vector loop
+                // (smaller class, then smaller t), then the scalar tail in ascending t
+                const int en1 = st0 + (en0 - st0) / 4 * 4;
+                int64_t best = (int64_t)((uint64_t)(uint32_t)h_en0 << 32 | 0x7fffffffu);
+                for (int t = st0 + lane; t < en0; t += PMX_W) {
+                    const int32_t h = H[t] + (int32_t)v[t];
+                    H[t] = h;
+                    uint32_t prio;   // larger = preferred
+                    if (t < en1) prio = 0x7ffffffeu - ((uint32_t)((t - st0) & 3) << 24) - (uint32_t)((t - st0) >> 2);
+                    else prio = 0x7ffffffeu - (5u << 24) - (uint32_t)(t - st0);
+                    const int64_t key = (int64_t)((uint64_t)(uint32_t)h << 32 | prio);
+                    best = key > best ? key : best;
+                }
+                if (lane == 0 || PMX_W == 1) H[en0] = h_en0;
+                best = wave_max_i64(best);
+                wave_sync();
+                max_H = (int32_t)(best >> 32);
+                const uint32_t prio = (uint32_t)best;
+                if (prio == 0x7fffffffu) max_t = en0;
+                else {
+                    const uint32_t d = 0x7ffffffeu - prio;
+                    const uint32_t cls = d >> 24, idx = d & 0xffffffu;
+                    max_t = cls >= 5 ? st0 + (int)idx : st0 + (int)(idx * 4 + cls);
+                }
+            } else {
+                if (lane == 0 || PMX_W == 1) H[0] = v[0] - qe;
+                wave_sync();
+                max_H = H[0];
+                max_t = 0;
+            }
+            if (en0 == tlen - 1 && H[en0] > ez.mte) { ez.mte = H[en0]; ez.mte_q = r - en0; }
+            if (r - st0 == qlen - 1 && H[st0] > ez.mqe) { ez.mqe = H[st0]; ez.mqe_t = st0; }
+            if (ez_apply_zdrop(ez, max_H, r, max_t, zdrop, e2)) break;
+            if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[tlen - 1];
+        } else {             // approximate max along one path (:367-383)
+            if (r > 0) {
+                if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+                    const int32_t d0 = v[last_H0_t], d1 = u[last_H0_t + 1];
+                    if (d0 > d1) H0 += d0;
+                    else { H0 += d1; ++last_H0_t; }
+                } else if (last_H0_t >= st0 && last_H0_t <= en0) {
+                    H0 += v[last_H0_t];
+                } else {
+                    ++last_H0_t;
+                    H0 += u[last_H0_t];
+                }
+            } else { H0 = v[0] - qe; last_H0_t = 0; }
+            if ((flag & PMX_EZ_APPROX_DROP) && ez_apply_zdrop(ez, H0, r, last_H0_t, zdrop, e2)) break;
+            if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
+        }
+        last_st = st;
+        last_en = en;
+    }
+    wave_sync();
+    // backtrack (:388-399)
+    const int rev_cigar = !!(flag & PMX_EZ_REV_CIGAR);
+    if (!ez.zdropped && !(flag & PMX_EZ_EXTZ_ONLY)) {
+        ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, tlen - 1, qlen - 1, &ez.n_cigar);
+    } else if (!ez.zdropped && (flag & PMX_EZ_EXTZ_ONLY) && ez.mqe + end_bonus > (int)ez.max) {
+        ez.reach_end = 1;
+        ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, ez.mqe_t, qlen - 1, &ez.n_cigar);
+    } else if (ez.max_t >= 0 && ez.max_q >= 0) {
+        ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, ez.max_t, ez.max_q, &ez.n_cigar);
+    }
+    wave_sync();
+}
+
+}  // namespace aln
+}  // namespace pmx

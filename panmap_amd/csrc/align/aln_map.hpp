@@ -1,0 +1,221 @@
+// ALIGN stage, part 6: pairing of the two mates' hits (pe.c:45-177) and the per-fragment driver that
+// strings the parts together the way mm_map_frag does (map.c:236-390), ending with the record the
+// reference's boundary extracts (extract_align_result / align_worker_func, src/mm_align.c:271-354).
+#pragma once
+#include "aln_align.hpp"
+#include "aln_chain.hpp"
+#include "aln_hit.hpp"
+#include "aln_seed.hpp"
+#include "aln_types.hpp"
+
+namespace pmx {
+namespace aln {
+
+PMX_HD uint32_t wang_hash(uint32_t key) {   // __ac_Wang_hash (khash.h)
+    key += ~(key << 15);
+    key ^= (key >> 10);
+    key += (key << 3);
+    key ^= (key >> 6);
+    key += ~(key << 11);
+    key ^= (key >> 16);
+    return key;
+}
+
+// mm_set_pe_thru (pe.c:45-64)
+PMX_HD void set_pe_thru(const int* qlens, const int* n_regs, Reg* const* regs) {
+    int n_pri[2] = {0, 0}, pri[2] = {-1, -1};
+    for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < n_regs[s]; ++i)
+            if (regs[s][i].id == regs[s][i].parent) { ++n_pri[s]; pri[s] = i; }
+    if (n_pri[0] == 1 && n_pri[1] == 1) {
+        Reg& p = regs[0][pri[0]];
+        Reg& q = regs[1][pri[1]];
+        const int d1 = p.rs - q.rs < 0 ? q.rs - p.rs : p.rs - q.rs, d2 = p.re - q.re < 0 ? q.re - p.re : p.re - q.re;
+        if (p.rid == q.rid && p.rev == q.rev && d1 < 3 && d2 < 3 &&
+            ((p.qs == 0 && qlens[1] - q.qe == 0) || (q.qs == 0 && qlens[0] - p.qe == 0)))
+            p.pe_thru = q.pe_thru = 1;
+    }
+}
+
+// mm_pair (pe.c:76-177)
+PMX_HD void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, const int* qlens, int* n_regs,
+                      Reg* const* regs) {
+    // pair array (s, rev, key, reg index) kept as parallel arrays in the idle chaining scratch
+    const int cap = W.caps.max_reg * 2;
+    uint64_t* key = W.aux64;                       // [cap]
+    int32_t* ps = (int32_t*)(W.aux64 + cap);       // [cap] segment
+    int32_t* pi = ps + cap;                        // [cap] index in regs[s]
+    uint64_t* sc = (uint64_t*)W.z;                 // pair scores
+    const int sc_cap = W.caps.max_anchor * 2;      // z holds max_anchor A128
+    int n = 0, segs = 0, dp_thres = 0;
+    for (int s = 0; s < 2; ++s) {
+        int mx = 0;
+        for (int i = 0; i < n_regs[s]; ++i) {
+            const Reg& r = regs[s][i];
+            ps[n] = s;
+            pi[n] = i;
+            key[n] = (uint64_t)(uint32_t)r.rid << 32 | (uint32_t)(r.rs << 1) | (uint32_t)(s ^ r.rev);
+            mx = mx > r.dp_max ? mx : r.dp_max;
+            ++n;
+            segs |= 1 << s;
+        }
+        dp_thres += mx;
+    }
+    if (segs != 3) return;   // only one end is mapped
+    dp_thres -= pe_bonus;
+    if (dp_thres < 0) dp_thres = 0;
+    if (n > 64) { W.status |= PMX_ST_UNSUPPORTED; return; }   // beyond the stable insertion-sort regime of radix_sort_pair
+    for (int i = 1; i < n; ++i) {   // rs_insertsort on key
+        if (key[i] < key[i - 1]) {
+            const uint64_t tk = key[i];
+            const int32_t ts = ps[i], ti = pi[i];
+            int j;
+            for (j = i; j > 0 && tk < key[j - 1]; --j) { key[j] = key[j - 1]; ps[j] = ps[j - 1]; pi[j] = pi[j - 1]; }
+            key[j] = tk; ps[j] = ts; pi[j] = ti;
+        }
+    }
+    int64_t mx = -1;
+    int max_idx[2] = {-1, -1}, last[2] = {-1, -1};
+    int n_sc = 0;
+    for (int i = 0; i < n; ++i) {
+        const Reg& ri_ = regs[ps[i]][pi[i]];
+        const int rev_i = ri_.rev;
+        if (key[i] & 1) {   // reverse first read or forward second read
+            if (last[rev_i] < 0) continue;
+            const Reg* q = &regs[ps[last[rev_i]]][pi[last[rev_i]]];
+            if (ri_.rid != q->rid || ri_.rs - q->re > max_gap_ref) continue;
+            for (int j = last[rev_i]; j >= 0; --j) {
+                q = &regs[ps[j]][pi[j]];
+                if (q->rev != rev_i || ps[j] == ps[i]) continue;
+                if (ri_.rid != q->rid || ri_.rs - q->re > max_gap_ref) break;
+                if (ri_.dp_max + q->dp_max < dp_thres) continue;
+                const int64_t score = (int64_t)(ri_.dp_max + q->dp_max) << 32 | (uint32_t)(ri_.hash + q->hash);
+                if (score > mx) { mx = score; max_idx[ps[j]] = j; max_idx[ps[i]] = i; }
+                if (n_sc < sc_cap) sc[n_sc++] = (uint64_t)score;
+                else W.status |= PMX_ST_OVERFLOW;
+            }
+        } else last[rev_i] = i;
+    }
+    if (n_sc > 1) radix_sort_64(sc, sc + n_sc, &W.status);
+    if (n_sc > 0 && mx > 0) {
+        int n_sub = 0, mapq_pe;
+        Reg* r[2];
+        r[0] = &regs[0][pi[max_idx[0]]];
+        r[1] = &regs[1][pi[max_idx[1]]];
+        r[0]->proper_frag = r[1]->proper_frag = 1;
+        for (int s = 0; s < 2; ++s) {
+            if (r[s]->id != r[s]->parent) {   // lift to primary and update parent
+                Reg* p = &regs[s][r[s]->parent];
+                const int pid = p->id;
+                for (int i = 0; i < n_regs[s]; ++i)
+                    if (regs[s][i].parent == pid) regs[s][i].parent = r[s]->id;
+                p->mapq = 0;
+            }
+            if (!r[s]->sam_pri) {
+                for (int i = 0; i < n_regs[s]; ++i) regs[s][i].sam_pri = 0;
+                r[s]->sam_pri = 1;
+            }
+        }
+        mapq_pe = r[0]->mapq > r[1]->mapq ? r[0]->mapq : r[1]->mapq;
+        for (int i = 0; i < n_sc; ++i)
+            if ((sc[i] >> 32) + (uint64_t)sub_diff >= (uint64_t)mx >> 32) ++n_sub;
+        if (n_sc > 1) {
+            if (n_sub >= ri.n_logf) { W.status |= PMX_ST_UNSUPPORTED; n_sub = ri.n_logf - 1; }
+            const int mapq_pe_alt = (int)(6.02f * (float)((mx >> 32) - (int64_t)(sc[n_sc - 2] >> 32)) / match_sc - 4.343f * ri.logf_int[n_sub]);
+            mapq_pe = mapq_pe < mapq_pe_alt ? mapq_pe : mapq_pe_alt;
+        }
+        if (r[0]->mapq < mapq_pe) r[0]->mapq = (uint8_t)(int)(.2f * r[0]->mapq + .8f * mapq_pe + .499f);
+        if (r[1]->mapq < mapq_pe) r[1]->mapq = (uint8_t)(int)(.2f * r[1]->mapq + .8f * mapq_pe + .499f);
+        if (n_sc == 1) {
+            if (r[0]->mapq < 2) r[0]->mapq = 2;
+            if (r[1]->mapq < 2) r[1]->mapq = 2;
+        } else if ((uint64_t)mx >> 32 > sc[n_sc - 2] >> 32) {
+            if (r[0]->mapq < 1) r[0]->mapq = 1;
+            if (r[1]->mapq < 1) r[1]->mapq = 1;
+        }
+    }
+    set_pe_thru(qlens, n_regs, regs);
+}
+
+// mm_map_frag (map.c:236-390) for n_segs in {1,2}.  Regions end up in W.regs[s] / W.n_regs[s].
+PMX_HD void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
+    const int n_segs = W.n_segs;
+    int qlen_sum = 0;
+    for (int i = 0; i < n_segs; ++i) { qlen_sum += W.qlen[i]; W.n_regs[i] = 0; }
+    W.n_regs0 = 0;
+    W.cig_next = 0;
+    if (qlen_sum == 0) return;
+    // qname is NULL at the boundary (src/mm_align.c:316): hash depends on lengths and the seed only
+    uint32_t hash = 0;
+    hash ^= wang_hash((uint32_t)qlen_sum) + wang_hash((uint32_t)o.seed);
+    hash = wang_hash(hash);
+
+    collect_minimizers(W, o);
+    if (o.q_occ_frac > 0.0f && W.n_mv > o.mid_occ && o.mid_occ > 0) W.status |= PMX_ST_UNSUPPORTED;   // mm_seed_mz_flt (seed.c:5-26)
+    collect_seed_hits_heap(W, o, ri, qlen_sum, o.mid_occ);
+
+    const int max_chain_gap_qry = o.max_gap;   // not MM_F_SR
+    int max_chain_gap_ref;
+    if (o.max_gap_ref > 0) max_chain_gap_ref = o.max_gap_ref;
+    else if (o.max_frag_len > 0) {
+        max_chain_gap_ref = o.max_frag_len - qlen_sum;
+        if (max_chain_gap_ref < o.max_gap) max_chain_gap_ref = o.max_gap;
+    } else max_chain_gap_ref = o.max_gap;
+
+    chain_dp(W, o, max_chain_gap_ref, max_chain_gap_qry, n_segs);
+
+    if (o.bw_long > o.bw && n_segs == 1 && W.n_u > 1) {   // long-join re-chaining (map.c:296-305): RMQ chaining not restated yet
+        const int32_t st = (int32_t)W.a[0].y, en = (int32_t)W.a[(int32_t)W.u[0] - 1].y;
+        if (qlen_sum - (en - st) > o.rmq_rescue_size || en - st > qlen_sum * o.rmq_rescue_ratio) W.status |= PMX_ST_UNSUPPORTED;
+    } else if (o.max_occ > o.mid_occ && W.rep_len > 0) {   // re-chain with a higher occurrence cap (map.c:306-330)
+        int rechain = 0;
+        if (W.n_u > 0) {
+            int n_chained_segs = 1, mx = 0, max_i = -1, max_off = -1, off = 0;
+            for (int i = 0; i < W.n_u; ++i) {
+                if (mx < (int)(W.u[i] >> 32)) { mx = (int)(W.u[i] >> 32); max_i = i; max_off = off; }
+                off += (int32_t)W.u[i];
+            }
+            for (int i = 1; i < (int32_t)W.u[max_i]; ++i)
+                if ((W.a[max_off + i].y & PMX_SEED_SEG_MASK) != (W.a[max_off + i - 1].y & PMX_SEED_SEG_MASK)) ++n_chained_segs;
+            if (n_chained_segs < n_segs) rechain = 1;
+        } else rechain = 1;
+        if (rechain) {
+            collect_seed_hits_heap(W, o, ri, qlen_sum, o.max_occ);
+            chain_dp(W, o, max_chain_gap_ref, max_chain_gap_qry, n_segs);
+        }
+    }
+    W.frag_gap = max_chain_gap_ref;
+
+    W.n_regs0 = gen_regs(W, hash, qlen_sum, W.n_u, W.u, W.a, W.regs0);
+
+    // chain_post (map.c:206-213)
+    set_parent(W, o.mask_level, o.mask_len, W.n_regs0, W.regs0, o.a * 2 + o.b);
+    if (n_segs <= 1) select_sub(W, o.pri_ratio, o.k * 2, o.best_n, 1, (int)(o.max_gap * 0.8), &W.n_regs0, W.regs0);
+    else select_sub_multi(W, o.pri_ratio, 0.2f, 0.7f, max_chain_gap_ref, o.k * 2, o.best_n, n_segs, W.qlen, &W.n_regs0, W.regs0);
+    // mm_est_err only feeds Reg::div, read by mm_filter_strand_retained for strand_retained hits
+    // (single-segment mode only): not evaluated, flagged when it would matter
+    if (n_segs == 1)
+        for (int i = 0; i < W.n_regs0; ++i)
+            if (W.regs0[i].strand_retained) W.status |= PMX_ST_UNSUPPORTED;
+
+    if (n_segs == 1) {
+        for (int i = 0; i < W.n_regs0; ++i) W.regs[0][i] = W.regs0[i];
+        W.n_regs[0] = W.n_regs0;
+        align_regs(W, o, ri, 0, &W.n_regs[0], W.regs[0], W.a);
+        set_mapq(ri, W.n_regs[0], W.regs[0], o.min_chain_score, o.a, W.rep_len, 0, &W.status);
+    } else {
+        seg_gen(W, hash, W.qlen, W.n_regs0, W.regs0, W.a);
+        for (int s = 0; s < n_segs; ++s) {
+            set_parent(W, o.mask_level, o.mask_len, W.n_regs[s], W.regs[s], o.a * 2 + o.b);
+            align_regs(W, o, ri, s, &W.n_regs[s], W.regs[s], W.seg_a[s]);
+            set_mapq(ri, W.n_regs[s], W.regs[s], o.min_chain_score, o.a, W.rep_len, 0, &W.status);
+        }
+        if (n_segs == 2 && o.pe_ori >= 0) {
+            Reg* rr[2] = {W.regs[0], W.regs[1]};
+            pair_hits(W, ri, max_chain_gap_ref, o.pe_bonus, o.a * 2 + o.b, o.a, W.qlen, W.n_regs, rr);
+        }
+    }
+}
+
+}  // namespace aln
+}  // namespace pmx

@@ -179,6 +179,7 @@ struct Work {
     int32_t* H;
     int32_t *off, *off_end;
     uint8_t* tb;           // traceback matrix (global)
+    size_t tb_cap;
     uint8_t* tseq;
     uint32_t* cig_tmp;     // ez->cigar
     uint32_t* cig_pool;    // n_cig_slots * max_cigar
@@ -186,6 +187,7 @@ struct Work {
     uint32_t status;
     int rep_len;
     int frag_gap;
+    uint64_t tmp64;        // lane-0 -> wave broadcast slot
 };
 
 }  // namespace aln

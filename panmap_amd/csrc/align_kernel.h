@@ -1,0 +1,35 @@
+// Launch interface of the ALIGN kernel (align_kernel.hip), shared with api_align.hip.
+#pragma once
+#include "align/aln_host.hpp"
+
+#define PMX_ALIGN_WORK_BYTES 1024   // LDS bytes reserved for the Work descriptor
+
+namespace pmx {
+namespace aln {
+
+struct AlignArgs {
+    // packed reads
+    const uint64_t* words;
+    const uint32_t* amb;
+    const int64_t* woff;
+    const int64_t* off;
+    int64_t n_items;        // pairs (paired) or reads
+    int paired;
+    int revcomp_mate2;
+    // reference + options
+    Opt opt;
+    RefIndex ri;
+    Layout layout;
+    uint8_t* slow_base;
+    size_t slow_stride;
+    // outputs
+    AlnRecord* records;
+    uint32_t* cigars;
+    uint64_t cigar_cap;
+    unsigned long long* cigar_used;
+};
+
+__global__ void k_align_reads(AlignArgs A);
+
+}  // namespace aln
+}  // namespace pmx

@@ -1,16 +1,232 @@
-// C ABI, device part 2: ALIGN stage (placeholder until the alignment kernels land).
+// C ABI, device part 2: ALIGN stage (see include/panmap_amd.h).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "align_kernel.h"
 #include "device/dev_util.hpp"
+#include "readset.hpp"
+
+using namespace pmx;
+using namespace pmx::aln;
+
+static_assert(sizeof(Work) <= PMX_ALIGN_WORK_BYTES, "Work descriptor exceeds its LDS reservation");
+static_assert(sizeof(AlnRecord) == sizeof(pmx_aln_record), "record layout mismatch");
+
+struct pmx_aligner {
+    Opt opt;
+    HostRefIndex host;
+    DevBuf<uint8_t> d_seq;
+    DevBuf<uint64_t> d_key, d_pos;
+    DevBuf<uint32_t> d_off, d_cnt;
+    DevBuf<float> d_logf_ratio, d_logf_int;
+    RefIndex ri;
+    int mean_len = 150;
+    // last result
+    DevBuf<AlnRecord> records;
+    DevBuf<uint32_t> cigars;
+    DevBuf<unsigned long long> cigar_used;
+    DevBuf<uint8_t> slow;
+    int64_t n_records = 0;
+    uint64_t cigar_cap = 0;
+    double last_occupancy = 0;
+};
+
+namespace {
+int fail(int code, const std::string& msg) {
+    set_error(msg);
+    return code;
+}
+#define PMX_TRY try {
+#define PMX_CATCH                                                      \
+    }                                                                  \
+    catch (const HipError& e) { return fail(PMX_ERR_DEVICE, e.msg); }  \
+    catch (const std::exception& e) { return fail(PMX_ERR_DEVICE, e.what()); }
+
+template <class T>
+void upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t st) {
+    d.alloc(h.size());
+    if (!h.empty()) PMX_HIP(hipMemcpyAsync(d.p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, st));
+}
+}  // namespace
 
 extern "C" {
-void pmx_align_reads_direct(const char*, const char*, int, const char**, const char**, const char**, const int*, align_pair_result_t*, bool, int) {
-    pmx::set_error("align stage not implemented yet");
+
+int pmx_aligner_create(pmx_ctx* ctx, const char* reference, int64_t ref_len, int mean_read_len, pmx_aligner** out) {
+    if (!ctx || !reference || ref_len <= 0 || !out) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<pmx_aligner> al(new pmx_aligner());
+    al->mean_len = mean_read_len;
+    al->opt = make_opt(mean_read_len);
+    const int max_score = std::max(8192, (mean_read_len * 4 + 1024) * (al->opt.a + 1));
+    build_ref_index(reference, ref_len, al->opt, max_score, al->host);
+    upload(al->d_seq, al->host.seq, ctx->stream);
+    upload(al->d_key, al->host.ht_key, ctx->stream);
+    upload(al->d_off, al->host.ht_off, ctx->stream);
+    upload(al->d_cnt, al->host.ht_cnt, ctx->stream);
+    upload(al->d_pos, al->host.pos, ctx->stream);
+    upload(al->d_logf_ratio, al->host.logf_ratio, ctx->stream);
+    upload(al->d_logf_int, al->host.logf_int, ctx->stream);
+    RefIndex& r = al->ri;
+    r.seq = al->d_seq.p;
+    r.len = (int32_t)ref_len;
+    r.ht_mask = (uint32_t)al->host.ht_key.size() - 1;
+    r.ht_key = al->d_key.p;
+    r.ht_off = al->d_off.p;
+    r.ht_cnt = al->d_cnt.p;
+    r.pos = al->d_pos.p;
+    r.logf_ratio = al->d_logf_ratio.p;
+    r.logf_int = al->d_logf_int.p;
+    r.n_logf = (int32_t)al->host.logf_int.size();
+    al->cigar_used.alloc(1);
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    *out = al.release();
+    return PMX_OK;
+    PMX_CATCH
 }
-int pmx_aligner_create(pmx_ctx*, const char*, int64_t, int, pmx_aligner**) { pmx::set_error("align stage not implemented yet"); return PMX_ERR_UNSUPPORTED; }
-void pmx_aligner_free(pmx_ctx*, pmx_aligner*) {}
-int pmx_align_readset(pmx_ctx*, pmx_aligner*, const pmx_readset*, int, int) { return PMX_ERR_UNSUPPORTED; }
-int64_t pmx_align_num_records(const pmx_aligner*) { return 0; }
-int64_t pmx_align_cigar_words(pmx_ctx*, pmx_aligner*) { return 0; }
-int pmx_align_fetch(pmx_ctx*, pmx_aligner*, pmx_aln_record*, int64_t, uint32_t*, int64_t) { return PMX_ERR_UNSUPPORTED; }
-const void* pmx_align_device_records(const pmx_aligner*) { return nullptr; }
-const void* pmx_align_device_cigars(const pmx_aligner*) { return nullptr; }
+
+void pmx_aligner_free(pmx_ctx* ctx, pmx_aligner* al) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    delete al;
 }
+
+int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2) {
+    if (!ctx || !al || !rs) return PMX_ERR_ARG;
+    if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack first)");
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    const int64_t n_items = paired ? rs->n / 2 : rs->n;   // an odd trailing read is ignored (src/mm_align.c:372)
+    al->n_records = rs->n;
+    al->records.ensure((size_t)std::max<int64_t>(rs->n, 1));
+    PMX_HIP(hipMemsetAsync(al->records.p, 0, sizeof(AlnRecord) * (size_t)std::max<int64_t>(rs->n, 1), ctx->stream));
+    al->cigar_cap = (uint64_t)std::max<int64_t>(rs->n * 16, 4096);
+    al->cigars.ensure(al->cigar_cap);
+    PMX_HIP(hipMemsetAsync(al->cigar_used.p, 0, sizeof(unsigned long long), ctx->stream));
+    if (n_items <= 0) return PMX_OK;
+
+    const size_t lds_budget = 20 * 1024;
+    AlignArgs A;
+    A.layout = plan_layout((int)rs->max_len, paired ? 2 : 1, al->opt, lds_budget);
+    const size_t lds_bytes = PMX_ALIGN_WORK_BYTES + A.layout.fast_bytes + 16;
+    if (lds_bytes > 160 * 1024) return fail(PMX_ERR_UNSUPPORTED, "reads too long for the LDS work arena");
+    if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)k_align_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int waves_per_cu = (int)std::min<size_t>(16, (size_t)(160 * 1024) / lds_bytes);
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    int64_t grid = (int64_t)ctx->n_cu * waves_per_cu;
+    if (grid > n_items) grid = n_items;
+    A.slow_stride = (A.layout.slow_bytes + 255) & ~(size_t)255;
+    al->slow.ensure(A.slow_stride * (size_t)grid);
+    A.slow_base = al->slow.p;
+    A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
+    A.n_items = n_items;
+    A.paired = paired ? 1 : 0;
+    A.revcomp_mate2 = revcomp_mate2 ? 1 : 0;
+    A.opt = al->opt;
+    A.ri = al->ri;
+    A.records = al->records.p;
+    A.cigars = al->cigars.p;
+    A.cigar_cap = al->cigar_cap;
+    A.cigar_used = al->cigar_used.p;
+    timer_begin(ctx, "align");
+    hipLaunchKernelGGL(k_align_reads, dim3((unsigned)grid), dim3(64), lds_bytes, ctx->stream, A);
+    timer_end(ctx, "align", 1);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int64_t pmx_align_num_records(const pmx_aligner* al) { return al ? al->n_records : 0; }
+
+int64_t pmx_align_cigar_words(pmx_ctx* ctx, pmx_aligner* al) {
+    if (!ctx || !al) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    unsigned long long used = 0;
+    PMX_HIP(hipMemcpyAsync(&used, al->cigar_used.p, sizeof(used), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return (int64_t)std::min<unsigned long long>(used, al->cigar_cap);
+    PMX_CATCH
+}
+
+int pmx_align_fetch(pmx_ctx* ctx, pmx_aligner* al, pmx_aln_record* records, int64_t n_records, uint32_t* cigar_arena, int64_t arena_cap) {
+    if (!ctx || !al || !records || n_records < al->n_records) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    const int64_t used = pmx_align_cigar_words(ctx, al);
+    if (used < 0) return (int)used;
+    if (used > arena_cap || (used > 0 && !cigar_arena)) return fail(PMX_ERR_CAPACITY, "CIGAR arena buffer too small");
+    if (al->n_records > 0)
+        PMX_HIP(hipMemcpyAsync(records, al->records.p, sizeof(AlnRecord) * (size_t)al->n_records, hipMemcpyDeviceToHost, ctx->stream));
+    if (used > 0) PMX_HIP(hipMemcpyAsync(cigar_arena, al->cigars.p, sizeof(uint32_t) * (size_t)used, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
+const void* pmx_align_device_records(const pmx_aligner* al) { return al ? al->records.p : nullptr; }
+const void* pmx_align_device_cigars(const pmx_aligner* al) { return al ? al->cigars.p : nullptr; }
+
+// Drop-in for align_reads_direct (src/mm_align.h:44-53): host strings in, read_align_t out.
+void pmx_align_reads_direct(const char* reference, const char* refName, int n_reads, const char** reads, const char** quality,
+                            const char** read_names, const int* r_lens, align_pair_result_t* results, bool pairedEndReads, int n_threads) {
+    (void)refName; (void)quality; (void)read_names; (void)n_threads;
+    if (!reference || !reads || !r_lens || !results || n_reads <= 0) return;
+    pmx_ctx* ctx = nullptr;
+    pmx_readset* rs = nullptr;
+    pmx_aligner* al = nullptr;
+    int dev = 0;
+    if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
+    if (pmx_ctx_create(dev, &ctx) != PMX_OK) return;   // like the reference: results stay untouched on failure
+    do {
+        int64_t total = 0;
+        std::vector<int64_t> off((size_t)n_reads + 1, 0);
+        for (int i = 0; i < n_reads; ++i) { off[i] = total; total += r_lens[i]; }
+        off[n_reads] = total;
+        std::string concat;
+        concat.reserve((size_t)total);
+        for (int i = 0; i < n_reads; ++i) concat.append(reads[i], (size_t)r_lens[i]);
+        const int avg_len = (int)(total / n_reads);   // src/mm_align.c:124-130
+        if (pmx_readset_upload(ctx, concat.data(), off.data(), n_reads, &rs) != PMX_OK) break;
+        if (pmx_readset_pack(ctx, rs) != PMX_OK) break;
+        if (pmx_aligner_create(ctx, reference, (int64_t)strlen(reference), avg_len, &al) != PMX_OK) break;
+        if (pmx_align_readset(ctx, al, rs, pairedEndReads ? 1 : 0, 0) != PMX_OK) break;
+        std::vector<pmx_aln_record> recs((size_t)n_reads);
+        const int64_t words = pmx_align_cigar_words(ctx, al);
+        if (words < 0) break;
+        std::vector<uint32_t> arena((size_t)std::max<int64_t>(words, 1));
+        if (pmx_align_fetch(ctx, al, recs.data(), n_reads, arena.data(), (int64_t)arena.size()) != PMX_OK) break;
+        auto fill = [&](const pmx_aln_record& r, read_align_t* o) {
+            memset(o, 0, sizeof(*o));
+            if (r.mapped && (r.flags & PMX_REC_HAS_ALN)) {
+                o->pos = r.rs + 1; o->rs = r.rs; o->re = r.re; o->qs = r.qs; o->qe = r.qe;
+                o->mapq = r.mapq; o->rev = r.rev; o->proper_frag = r.proper_frag;
+                o->n_cigar = r.n_cigar;
+                o->cigar = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)std::max<int>(r.n_cigar, 1));
+                memcpy(o->cigar, arena.data() + r.cigar_off, sizeof(uint32_t) * r.n_cigar);
+            } else o->pos = INT_MAX;
+        };
+        const int n_items = pairedEndReads ? n_reads / 2 : n_reads;
+        for (int k = 0; k < n_items; ++k) {
+            align_pair_result_t* res = &results[k];
+            memset(res, 0, sizeof(*res));
+            if (pairedEndReads) {
+                const pmx_aln_record &a = recs[2 * k], &b = recs[2 * k + 1];
+                if (a.mapped) { res->mapped = 1; fill(a, &res->r1); fill(b, &res->r2); }
+                else { res->mapped = 0; res->r1.pos = INT_MAX; res->r2.pos = INT_MAX; }
+            } else {
+                const pmx_aln_record& a = recs[k];
+                if (a.mapped) { res->mapped = 1; fill(a, &res->r1); }
+                else res->r1.pos = INT_MAX;
+            }
+        }
+    } while (0);
+    if (al) pmx_aligner_free(ctx, al);
+    if (rs) pmx_readset_free(ctx, rs);
+    pmx_ctx_destroy(ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""Helpers shared by the align tests: run the reference aligner (oracle/_ref), the CPU unit-test build
+(tests/hostsim) and the HIP path, and compare per-read results field by field."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Rec(C.Structure):
+    _fields_ = [("rs", C.c_int32), ("re", C.c_int32), ("qs", C.c_int32), ("qe", C.c_int32),
+                ("mapq", C.c_uint8), ("rev", C.c_uint8), ("proper_frag", C.c_uint8), ("mapped", C.c_uint8),
+                ("n_cigar", C.c_uint16), ("flags", C.c_uint16), ("cigar_off", C.c_uint32), ("score", C.c_int32)]
+
+
+_hs = None
+
+
+def hostsim():
+    global _hs
+    if _hs is None:
+        subprocess.run(["make", "-C", os.path.join(HERE, "hostsim")], check=True, stdout=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+        L.hs_align.restype = C.c_int
+        L.hs_align.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.POINTER(Rec),
+                               C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int]
+        _hs = L
+    return _hs
+
+
+def records_to_results(recs, cig, n_reads, paired):
+    """-> list of dicts shaped like oracle.call_align_reads_direct output."""
+    def one(r):
+        if not r.mapped or not (r.flags & 4):
+            return dict(pos=2147483647 if True else 0, rs=0, re=0, qs=0, qe=0, mapq=0, rev=0, proper_frag=0, cigar=[])
+        return dict(pos=r.rs + 1, rs=r.rs, re=r.re, qs=r.qs, qe=r.qe, mapq=r.mapq, rev=r.rev, proper_frag=r.proper_frag,
+                    cigar=[int(x) for x in cig[r.cigar_off:r.cigar_off + r.n_cigar]])
+    out = []
+    if paired:
+        for i in range(n_reads // 2):
+            a, b = recs[2 * i], recs[2 * i + 1]
+            out.append(dict(mapped=int(a.mapped), r1=one(a), r2=one(b), flags=a.flags | b.flags))
+    else:
+        for i in range(n_reads):
+            out.append(dict(mapped=int(recs[i].mapped), r1=one(recs[i]), r2=None, flags=recs[i].flags))
+    return out
+
+
+def hostsim_align(reference: bytes, reads, paired, verbose=0):
+    n = len(reads)
+    arr = (C.c_char_p * n)(*reads)
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    recs = (Rec * max(n, 1))()
+    cap = max(64, sum(len(r) for r in reads))
+    cig = np.zeros(cap, np.uint32)
+    used = C.c_int64()
+    rc = hostsim().hs_align(reference, len(reference), n, arr, lens, int(paired), recs, cig.ctypes.data, cap, C.byref(used), verbose)
+    assert rc == 0, rc
+    return records_to_results(recs, cig, n, paired)
+
+
+def cigar_str(c):
+    return "".join("%d%s" % (x >> 4, "MIDNSHP=X"[x & 0xf]) for x in c)
+
+
+def compare_results(got, want, label="", max_report=5):
+    """Exact comparison of pos/rs/re/qs/qe/mapq/rev/proper_frag/CIGAR per read; unmapped -> only `mapped`."""
+    bad = []
+    for i, (g, w) in enumerate(zip(got, want)):
+        if g["mapped"] != w["mapped"]:
+            bad.append((i, "mapped", g["mapped"], w["mapped"]))
+            continue
+        if not w["mapped"]:
+            continue
+        for m in ("r1", "r2"):
+            if w[m] is None:
+                continue
+            for f in ("pos", "rs", "re", "qs", "qe", "mapq", "rev", "proper_frag"):
+                if g[m][f] != w[m][f]:
+                    bad.append((i, m + "." + f, g[m][f], w[m][f]))
+            if g[m]["cigar"] != w[m]["cigar"]:
+                bad.append((i, m + ".cigar", cigar_str(g[m]["cigar"]), cigar_str(w[m]["cigar"])))
+    return bad
+
+
+def smoke_align(ctx, pm, genome, reads):
+    """used by __graft_entry__.smoke(): a few hundred pairs through the HIP aligner vs the reference aligner."""
+    import panmap_amd as pmx
+    from oracle import oracle as orc
+    if not hasattr(pmx, "Aligner"):
+        return
+    sub = reads[:400]
+    sub_al = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(sub)]
+    al = pmx.Aligner(ctx, genome, int(np.mean([len(r) for r in sub])))
+    got = al.align_reads(sub_al, paired=True)
+    want = orc.ref_align_reads_direct(genome, sub_al, True)
+    bad = compare_results(got, want)
+    assert not bad, bad[:5]
+    print("smoke: align OK (%d pairs, %d mapped)" % (len(want), sum(w["mapped"] for w in want)))

@@ -1,0 +1,117 @@
+"""GPU parity tests for the ALIGN stage: HIP kernel (through the C ABI) vs the reference's own aligner
+compiled from its sources (oracle/_ref: src/mm_align.c + vendored minimap2).  Bit-exact on
+pos / rs / re / qs / qe / mapq / rev / proper_frag / CIGAR."""
+import os
+
+import numpy as np
+import pytest
+
+import align_checks as ac
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_genome():
+    return b"".join(l.strip() for l in open(os.path.join(GOLDEN, "isolate.ref.fa"), "rb") if not l.startswith(b">"))
+
+
+def _pairs(pmx, genome, n, seed, **kw):
+    concat, off = pmx.simulate_paired_reads(genome, n, seed=seed, **kw)
+    reads = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+    return [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(reads)]   # readFastqPaired orientation
+
+
+def test_synthetic_pairs_exact(pmx, oracle, ctx):
+    g = _ref_genome()
+    reads = _pairs(pmx, g, 2000, 21)
+    al = pmx.Aligner(ctx, g, 150)
+    got = al.align_reads(reads, paired=True)
+    want = oracle.ref_align_reads_direct(g, reads, True, 8)
+    assert not ac.compare_results(got, want)
+    assert all(x["flags"] & 3 == 0 for x in got)
+    assert sum(w["mapped"] for w in want) == len(want)
+
+
+def test_revcomp_on_device_equals_host_revcomp(pmx, oracle, ctx):
+    g = _ref_genome()
+    concat, off = pmx.simulate_paired_reads(g, 1000, seed=22)
+    raw = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]       # FASTQ orientation
+    host_rc = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(raw)]
+    al = pmx.Aligner(ctx, g, 150)
+    a = al.align_reads(raw, paired=True, revcomp_mate2=True)
+    b = al.align_reads(host_rc, paired=True, revcomp_mate2=False)
+    assert not ac.compare_results(a, b)
+
+
+def test_example_reads_exact(pmx, oracle, ctx):
+    """the README demo reads (real errors, indels, N, variable length) against the placed genome"""
+    g = _ref_genome()
+    seqs, _, _ = pmx.read_fastq_paired(os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz"))
+    reads = seqs[:30000]
+    mean_len = int(sum(len(r) for r in reads) / len(reads))
+    al = pmx.Aligner(ctx, g, mean_len)
+    got = al.align_reads(reads, paired=True)
+    want = oracle.ref_align_reads_direct(g, reads, True, 8)
+    bad = ac.compare_results(got, want)
+    assert not bad, bad[:10]
+    n_flag = sum(1 for x in got if x["flags"] & 3)
+    assert n_flag <= 5, n_flag      # capacity / unsupported-branch reports must stay exceptional
+
+
+def test_noisy_and_edge_pairs(pmx, oracle, ctx):
+    g = _ref_genome()
+    reads = _pairs(pmx, g, 600, 23, sub_rate=0.03)
+    rng = np.random.default_rng(5)
+    # indels, N runs, unrelated sequence, very short mates
+    for i in range(0, 400, 2):
+        r = bytearray(reads[i])
+        p = int(rng.integers(20, 120))
+        k = i % 8
+        if k == 0:
+            del r[p:p + int(rng.integers(1, 9))]
+        elif k == 2:
+            r[p:p] = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 9))).astype(np.uint8))
+        elif k == 4:
+            r[p:p + 5] = b"NNNNN"
+        elif k == 6:
+            r = bytearray(bytes(rng.choice(list(b"ACGT"), 150).astype(np.uint8)))
+        reads[i] = bytes(r)
+    reads[401] = reads[401][:40]
+    reads[403] = reads[403][:21]
+    reads[405] = b"A" * 150
+    al = pmx.Aligner(ctx, g, 150)
+    got = al.align_reads(reads, paired=True)
+    want = oracle.ref_align_reads_direct(g, reads, True, 8)
+    bad = ac.compare_results(got, want)
+    assert not bad, bad[:10]
+
+
+def test_align_reads_direct_dropin(pmx, oracle, ctx):
+    """same signature, same results as the reference boundary (src/mm_align.h:44-53)"""
+    g = _ref_genome()
+    reads = _pairs(pmx, g, 300, 24)
+    got = pmx.align_reads_direct(g, reads, True, 4)
+    want = oracle.ref_align_reads_direct(g, reads, True, 4)
+    assert not ac.compare_results(got, want)
+    odd = reads[:7]                                             # odd count in paired mode: last read ignored
+    assert not ac.compare_results(pmx.align_reads_direct(g, odd, True), oracle.ref_align_reads_direct(g, odd, True))
+
+
+def test_full_size_properties(pmx, ctx):
+    """BASELINE config 2 (1M reads): error-free pairs must come back as full-length matches at their
+    source coordinates with proper_frag set; mate order / strand consistent."""
+    g = _ref_genome()
+    n_pairs = 500000
+    concat, off = pmx.simulate_paired_reads(g, n_pairs, seed=42, sub_rate=0.0)
+    rs = pmx.ReadSet(ctx, concat=concat, offsets=off)
+    al = pmx.Aligner(ctx, g, 150)
+    al.align_readset(rs, paired=True, revcomp_mate2=True)
+    recs, cig = al.fetch()
+    assert len(recs) == 2 * n_pairs
+    assert np.all(recs["mapped"] == 1) and np.all(recs["flags"] & 3 == 0)
+    assert np.all(recs["n_cigar"] == 1) and np.all(recs["re"] - recs["rs"] == 150) and np.all(recs["qe"] - recs["qs"] == 150)
+    assert np.all(cig[recs["cigar_off"]] == (150 << 4))
+    assert np.all(recs["proper_frag"] == 1)
+    assert np.all(recs["rev"] == 0)                 # R2 was reverse-complemented into the forward strand
+    assert np.all(recs["rs"][1::2] >= recs["rs"][0::2])
