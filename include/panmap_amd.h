@@ -146,6 +146,9 @@ int pmx_place_add_reads(pmx_ctx *ctx, pmx_place *pl, const pmx_readset *rs, cons
 int64_t pmx_place_histogram_size(pmx_ctx *ctx, pmx_place *pl);
 int pmx_place_histogram_export(pmx_ctx *ctx, pmx_place *pl, uint64_t *hash, int64_t *count, int64_t cap);
 int pmx_place_histogram_merge(pmx_ctx *ctx, pmx_place *pl, const uint64_t *hash, const int64_t *count, int64_t n);
+/* same with caller-owned DEVICE buffers (e.g. torch tensors fed to an RCCL all-gather): no host bounce */
+int pmx_place_histogram_export_device(pmx_ctx *ctx, pmx_place *pl, void *d_hash, void *d_count, int64_t cap);
+int pmx_place_histogram_merge_device(pmx_ctx *ctx, pmx_place *pl, const void *d_hash, const void *d_count, int64_t n);
 
 /* read-side filters + magnitudes (src/placement.cpp:1703-1856), then [hot] per-node delta scoring
    down the tree (src/placement.cpp:242-345, 701-918) and the sequential best/tie rule (:355-401) */
@@ -213,6 +216,8 @@ int64_t pmx_align_num_records(const pmx_aligner *al);
 int64_t pmx_align_cigar_words(pmx_ctx *ctx, pmx_aligner *al);
 int pmx_align_fetch(pmx_ctx *ctx, pmx_aligner *al, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,
                     int64_t arena_cap);
+/* copy the fixed-size records into a caller-owned DEVICE buffer (for RCCL gathers) */
+int pmx_align_copy_records_device(pmx_ctx *ctx, pmx_aligner *al, void *d_records, int64_t n_records);
 /* device pointers of the last result (for RCCL gathers without a host bounce) */
 const void *pmx_align_device_records(const pmx_aligner *al);
 const void *pmx_align_device_cigars(const pmx_aligner *al);

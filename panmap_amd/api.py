@@ -368,6 +368,18 @@ class Placer:
         check(lib.pmx_place_histogram_merge(self.ctx._h, self._h, hashes.ctypes.data, counts.ctypes.data, len(hashes)),
               "pmx_place_histogram_merge")
 
+    def histogram_size(self) -> int:
+        n = lib.pmx_place_histogram_size(self.ctx._h, self._h)
+        if n < 0:
+            raise _lib.PmxError(n, "pmx_place_histogram_size")
+        return n
+
+    def export_device(self, d_hash_ptr: int, d_count_ptr: int, cap: int):
+        check(lib.pmx_place_histogram_export_device(self.ctx._h, self._h, d_hash_ptr, d_count_ptr, cap), "pmx_place_histogram_export_device")
+
+    def merge_device(self, d_hash_ptr: int, d_count_ptr: int, n: int):
+        check(lib.pmx_place_histogram_merge_device(self.ctx._h, self._h, d_hash_ptr, d_count_ptr, n), "pmx_place_histogram_merge_device")
+
     def score(self, params: TraversalParams = TraversalParams(), n_reads: int = 0) -> PlacementResult:
         cp, res = params.to_c(), _lib.PlaceResult()
         check(lib.pmx_place_score(self.ctx._h, self._h, C.byref(cp), n_reads, C.byref(res)), "pmx_place_score")
@@ -465,6 +477,13 @@ class Aligner:
         cig = np.zeros(max(words, 1), np.uint32)
         check(lib.pmx_align_fetch(self.ctx._h, self._h, recs.ctypes.data, len(recs), cig.ctypes.data, len(cig)), "pmx_align_fetch")
         return recs[:n], cig[:words]
+
+    def copy_records_device(self, d_ptr: int, n_records: int):
+        check(lib.pmx_align_copy_records_device(self.ctx._h, self._h, d_ptr, n_records), "pmx_align_copy_records_device")
+
+    @property
+    def n_records(self) -> int:
+        return lib.pmx_align_num_records(self._h)
 
     def align_reads(self, reads, paired: bool, revcomp_mate2: bool = False):
         """-> list of per-pair (or per-read) dicts shaped like align_pair_result_t."""

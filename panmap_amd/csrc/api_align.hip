@@ -167,6 +167,17 @@ int pmx_align_fetch(pmx_ctx* ctx, pmx_aligner* al, pmx_aln_record* records, int6
     PMX_CATCH
 }
 
+int pmx_align_copy_records_device(pmx_ctx* ctx, pmx_aligner* al, void* d_records, int64_t n_records) {
+    if (!ctx || !al || !d_records || n_records < al->n_records) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    if (al->n_records > 0)
+        PMX_HIP(hipMemcpyAsync(d_records, al->records.p, sizeof(AlnRecord) * (size_t)al->n_records, hipMemcpyDeviceToDevice, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
 const void* pmx_align_device_records(const pmx_aligner* al) { return al ? al->records.p : nullptr; }
 const void* pmx_align_device_cigars(const pmx_aligner* al) { return al ? al->cigars.p : nullptr; }
 

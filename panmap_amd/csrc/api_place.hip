@@ -432,6 +432,35 @@ int pmx_place_histogram_export(pmx_ctx* ctx, pmx_place* pl, uint64_t* hash, int6
     PMX_CATCH
 }
 
+int pmx_place_histogram_export_device(pmx_ctx* ctx, pmx_place* pl, void* d_hash, void* d_count, int64_t cap) {
+    if (!ctx || !pl || (cap > 0 && (!d_hash || !d_count))) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    finalize_histogram(ctx, pl);
+    if (cap < pl->n_hist) return fail(PMX_ERR_CAPACITY, "histogram export buffer too small");
+    if (pl->n_hist > 0) {
+        PMX_HIP(hipMemcpyAsync(d_hash, pl->hist_hash.p, sizeof(uint64_t) * pl->n_hist, hipMemcpyDeviceToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(d_count, pl->hist_count.p, sizeof(int64_t) * pl->n_hist, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_place_histogram_merge_device(pmx_ctx* ctx, pmx_place* pl, const void* d_hash, const void* d_count, int64_t n) {
+    if (!ctx || !pl || n < 0 || (n > 0 && (!d_hash || !d_count))) return PMX_ERR_ARG;
+    if (n == 0) return PMX_OK;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    table_reserve(ctx, pl, (uint64_t)n);
+    hipLaunchKernelGGL(k_table_merge, dim3(grid_for(n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, (const uint64_t*)d_hash,
+                       (const int64_t*)d_count, n, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    pl->hist_sorted = false;
+    return PMX_OK;
+    PMX_CATCH
+}
+
 int pmx_place_histogram_merge(pmx_ctx* ctx, pmx_place* pl, const uint64_t* hash, const int64_t* count, int64_t n) {
     if (!ctx || !pl || n < 0 || (n > 0 && (!hash || !count))) return PMX_ERR_ARG;
     if (n == 0) return PMX_OK;
