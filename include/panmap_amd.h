@@ -207,6 +207,8 @@ typedef struct pmx_aligner pmx_aligner;
 /* builds the minimizer index of one reference genome on the device; preset chosen from the mean
    read length exactly as setup_minimap2(for_scoring=1) does (src/mm_align.c:118-188) */
 int pmx_aligner_create(pmx_ctx *ctx, const char *reference, int64_t ref_len, int mean_read_len, pmx_aligner **out);
+/* re-target an existing aligner at another reference genome (keeps the work buffers) */
+int pmx_aligner_set_reference(pmx_ctx *ctx, pmx_aligner *al, const char *reference, int64_t ref_len, int mean_read_len);
 void pmx_aligner_free(pmx_ctx *ctx, pmx_aligner *al);
 /* [hot] map + align every read (pair) of a packed read set.  revcomp_mate2 != 0: odd-indexed reads
    are reverse-complemented on the fly (what readFastqPaired does on the host, src/seeding.cpp:251).

@@ -114,6 +114,7 @@ SIGNATURES = {
     "pmx_align_reads_direct": (None, [_cp, _cp, _i32, C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_cp),
                                       C.POINTER(C.c_int), C.POINTER(AlignPairResult), C.c_bool, _i32]),
     "pmx_aligner_create": (_i32, [_vp, _cp, _i64, _i32, _PP]),
+    "pmx_aligner_set_reference": (_i32, [_vp, _vp, _cp, _i64, _i32]),
     "pmx_aligner_free": (None, [_vp, _vp]),
     "pmx_align_readset": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "pmx_align_num_records": (_i64, [_vp]),

@@ -465,6 +465,10 @@ class Aligner:
         self._ref = bytes(reference)
         check(lib.pmx_aligner_create(ctx._h, self._ref, len(self._ref), int(mean_read_len), C.byref(self._h)), "pmx_aligner_create")
 
+    def set_reference(self, reference: bytes, mean_read_len: int):
+        self._ref = bytes(reference)
+        check(lib.pmx_aligner_set_reference(self.ctx._h, self._h, self._ref, len(self._ref), int(mean_read_len)), "pmx_aligner_set_reference")
+
     def align_readset(self, rs: ReadSet, paired: bool, revcomp_mate2: bool = False):
         check(lib.pmx_align_readset(self.ctx._h, self._h, rs._h, int(paired), int(revcomp_mate2)), "pmx_align_readset")
 

@@ -79,13 +79,13 @@ PMX_HD void align_pair(Work& W, const Opt& o, int qlen, const uint8_t* qseq, int
         ez_reset(ez);
         ez.zdropped = 1;
     } else {
-        ksw_extd2(W, qlen, qseq, tlen, tseq, o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2, (int8_t)o.e2, w, zdrop, end_bonus, flag, ez);
+        ksw_extd2_auto(W, qlen, qseq, tlen, tseq, o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2, (int8_t)o.e2, w, zdrop, end_bonus, flag, ez);
     }
 }
 
 // update_max_zdrop + mm_test_zdrop (align.c:32-89).  The inversion probe (ksw_ll_i16) is reported as
 // unsupported instead of evaluated; it only decides between return codes 1 and 2.
-PMX_HD int test_zdrop(Work& W, const Opt& o, const uint8_t* qseq, const uint8_t* tseq, int n_cigar, const uint32_t* cigar) {
+PMX_HDN int test_zdrop(Work& W, const Opt& o, const uint8_t* qseq, const uint8_t* tseq, int n_cigar, const uint32_t* cigar) {
     int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
     int pos[2][2] = {{-1, -1}, {-1, -1}};
     auto upd = [&](int32_t sc, int ii, int jj) {
@@ -123,7 +123,7 @@ PMX_HD int test_zdrop(Work& W, const Opt& o, const uint8_t* qseq, const uint8_t*
 }
 
 // mm_fix_cigar (align.c:91-167)
-PMX_HD void fix_cigar(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq, int* qshift, int* tshift) {
+PMX_HDN void fix_cigar(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq, int* qshift, int* tshift) {
     uint32_t* cg = reg_cigar(W, r);
     int32_t toff = 0, qoff = 0, to_shrink = 0;
     *qshift = *tshift = 0;
@@ -192,7 +192,7 @@ PMX_HD void fix_cigar(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq,
 }
 
 // mm_update_extra (align.c:240-289), log_gap = 1, is_eqx = 0
-PMX_HD void update_extra(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq, const int8_t* mat, int8_t q, int8_t e) {
+PMX_HDN void update_extra(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq, const int8_t* mat, int8_t q, int8_t e) {
     if (!r.has_p) return;
     int32_t qshift, tshift, toff = 0, qoff = 0;
     double s = 0.0, mx = 0.0;
@@ -267,7 +267,7 @@ PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, const A128* a, int min_
     return n;
 }
 
-PMX_HD void filter_bad_seeds(Work& W, int as1, int cnt1, A128* a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
+PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, A128* a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
     int32_t* K = (int32_t*)W.f;   // chain DP arrays are idle during alignment
     const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
     if (n == 0) return;
@@ -301,7 +301,7 @@ PMX_HD void filter_bad_seeds(Work& W, int as1, int cnt1, A128* a, int min_gap, i
 }
 
 // mm_filter_bad_seeds_alt (align.c:429-462)
-PMX_HD void filter_bad_seeds_alt(Work& W, int as1, int cnt1, A128* a, int min_gap, int max_ext) {
+PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, A128* a, int min_gap, int max_ext) {
     int32_t* K = (int32_t*)W.f;
     const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
     if (n == 0) return;
@@ -336,7 +336,7 @@ PMX_HD void filter_bad_seeds_alt(Work& W, int as1, int cnt1, A128* a, int min_ga
 }
 
 // mm_fix_bad_ends (align.c:464-502)
-PMX_HD void fix_bad_ends(const Reg& r, const A128* a, int bw, int min_match, int32_t* as, int32_t* cnt) {
+PMX_HDN void fix_bad_ends(const Reg& r, const A128* a, int bw, int min_match, int32_t* as, int32_t* cnt) {
     *as = r.as;
     *cnt = r.cnt;
     if (r.cnt < 3) return;
@@ -369,7 +369,7 @@ PMX_HD void fix_bad_ends(const Reg& r, const A128* a, int bw, int min_match, int
 }
 
 // mm_align1 (align.c:575-833)
-PMX_HD void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t* const qseq0[2], Reg& r, Reg& r2, int n_a, A128* a, Ez& ez) {
+PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t* const qseq0[2], Reg& r, Reg& r2, int n_a, A128* a, Ez& ez) {
     const int32_t rev = (int32_t)(a[r.as].x >> 63);
     int32_t as1, cnt1;
     uint8_t* tseq = W.tseq;
@@ -520,7 +520,7 @@ PMX_HD void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t*
 }
 
 // mm_event_identity / mm_recal_max_dp / mm_update_dp_max (align.c:918-965); only reached for qlen >= rank_min_len
-PMX_HD void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac, int a, int b) {
+PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac, int a, int b) {
     int32_t mx = -1, max2 = -1, max_i = -1;
     if (n_regs < 2) return;
     for (int i = 0; i < n_regs; ++i) {
@@ -566,7 +566,7 @@ PMX_HD void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac, 
 }
 
 // mm_align_skeleton (align.c:967-1027) for one segment; then the tail of align_regs (map.c:225-234)
-PMX_HD void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int* n_regs_, Reg* regs, A128* a) {
+PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int* n_regs_, Reg* regs, A128* a) {
     const int qlen = W.qlen[seg];
     int n_regs = *n_regs_;
     uint8_t* qseq0[2] = {W.qseq[seg][0], W.qseq[seg][1]};

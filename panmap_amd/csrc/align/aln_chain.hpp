@@ -66,7 +66,7 @@ PMX_HD int64_t chain_bk_end(int32_t max_drop, const A128* z, const int32_t* f, c
 // mg_lchain_dp (lchain.c:148-230) followed by mg_chain_backtrack (:27-76) and compact_a (:78-111).
 // In: W.a[0..n_a) sorted anchors.  Out: W.a holds the chained anchors grouped by chain, W.u[0..n_u)
 // = score<<32 | count, chains ordered by the target position of their first anchor.
-PMX_HD void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int n_seg) {
+PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int n_seg) {
     const int64_t n = W.n_a;
     const int bw = o.bw, max_skip = o.max_chain_skip, max_iter = o.max_chain_iter, min_cnt = o.min_cnt, min_sc = o.min_chain_score;
     const float chn_pen_gap = o.chn_pen_gap, chn_pen_skip = o.chn_pen_skip;

@@ -48,7 +48,7 @@ PMX_HD uint64_t hit_hash64(uint64_t key) {   // hit.c:42-52 (unmasked variant)
 PMX_HD void reg_clear(Reg& r) { memset(&r, 0, sizeof(Reg)); }
 
 // mm_gen_regs (hit.c:54-94): chains sorted by (score, hash) descending
-PMX_HD int gen_regs(Work& W, uint32_t hash, int qlen, int n_u, const uint64_t* u, const A128* a, Reg* r) {
+PMX_HDN int gen_regs(Work& W, uint32_t hash, int qlen, int n_u, const uint64_t* u, const A128* a, Reg* r) {
     if (n_u == 0) return 0;
     if (n_u > W.caps.max_reg) { W.status |= PMX_ST_OVERFLOW; n_u = W.caps.max_reg; }
     A128* z = W.aux128;
@@ -98,7 +98,7 @@ PMX_HD void split_reg(Reg& r, Reg& r2, int n, int qlen, const A128* a) {
 }
 
 // mm_set_parent (hit.c:132-191); hard_mask_level == 0, no ALT contigs
-PMX_HD void set_parent(Work& W, float mask_level, int mask_len, int n, Reg* r, int sub_diff) {
+PMX_HDN void set_parent(Work& W, float mask_level, int mask_len, int n, Reg* r, int sub_diff) {
     if (n <= 0) return;
     for (int i = 0; i < n; ++i) r[i].id = i;
     uint64_t* cov = W.aux64;
@@ -165,7 +165,7 @@ PMX_HD int set_sam_pri(int n, Reg* r) {
 }
 
 // mm_sync_regs (hit.c:239-262)
-PMX_HD void sync_regs(Work& W, int n_regs, Reg* regs) {
+PMX_HDN void sync_regs(Work& W, int n_regs, Reg* regs) {
     if (n_regs <= 0) return;
     int max_id = -1;
     for (int i = 0; i < n_regs; ++i) max_id = max_id > regs[i].id ? max_id : regs[i].id;
@@ -186,7 +186,7 @@ PMX_HD void sync_regs(Work& W, int n_regs, Reg* regs) {
 }
 
 // mm_select_sub (hit.c:264-285)
-PMX_HD void select_sub(Work& W, float pri_ratio, int min_diff, int best_n, int check_strand, int min_strand_sc, int* n_, Reg* r) {
+PMX_HDN void select_sub(Work& W, float pri_ratio, int min_diff, int best_n, int check_strand, int min_strand_sc, int* n_, Reg* r) {
     if (pri_ratio > 0.0f && *n_ > 0) {
         const int n = *n_;
         int k = 0, n_2nd = 0;
@@ -211,7 +211,7 @@ PMX_HD void select_sub(Work& W, float pri_ratio, int min_diff, int best_n, int c
 }
 
 // mm_select_sub_multi (pe.c:6-43)
-PMX_HD void select_sub_multi(Work& W, float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int n_segs,
+PMX_HDN void select_sub_multi(Work& W, float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int n_segs,
                              const int* qlens, int* n_, Reg* r) {
     if (pri_ratio > 0.0f && *n_ > 0) {
         const int n = *n_;
@@ -279,7 +279,7 @@ PMX_HD void filter_regs(const Opt& o, int qlen, int* n_regs, Reg* regs) {
 }
 
 // mm_hit_sort (hit.c:193-225): by (dp_max or score, hash) descending; cnt==0 regions squeezed out
-PMX_HD void hit_sort(Work& W, int* n_regs, Reg* r) {
+PMX_HDN void hit_sort(Work& W, int* n_regs, Reg* r) {
     const int n = *n_regs;
     if (n <= 1) return;
     A128* aux = W.aux128;
@@ -299,7 +299,7 @@ PMX_HD void hit_sort(Work& W, int* n_regs, Reg* r) {
 }
 
 // mm_squeeze_a (hit.c:324-343)
-PMX_HD int squeeze_a(Work& W, int n_regs, Reg* regs, A128* a) {
+PMX_HDN int squeeze_a(Work& W, int n_regs, Reg* regs, A128* a) {
     uint64_t* aux = W.aux64;
     int as = 0;
     for (int i = 0; i < n_regs; ++i) aux[i] = (uint64_t)(uint32_t)regs[i].as << 32 | (uint32_t)i;
@@ -316,7 +316,7 @@ PMX_HD int squeeze_a(Work& W, int n_regs, Reg* regs, A128* a) {
 }
 
 // mm_seg_gen (hit.c:345-400) for n_segs == 2: split fragment chains into per-mate chains
-PMX_HD void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, const Reg* regs0, const A128* a) {
+PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, const Reg* regs0, const A128* a) {
     const int n_segs = W.n_segs;
     int acc_qlen[3];
     acc_qlen[0] = 0;
@@ -358,7 +358,7 @@ PMX_HD void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, const
 }
 
 // mm_set_mapq (hit.c:421-466) without inversion hits; logf values come from host-computed tables
-PMX_HD void set_mapq(const RefIndex& ri, int n_regs, Reg* regs, int min_chain_sc, int match_sc, int rep_len, int is_sr, uint32_t* status) {
+PMX_HDN void set_mapq(const RefIndex& ri, int n_regs, Reg* regs, int min_chain_sc, int match_sc, int rep_len, int is_sr, uint32_t* status) {
     const float q_coef = 40.0f;
     int64_t sum_sc = 0;
     if (n_regs == 0) return;

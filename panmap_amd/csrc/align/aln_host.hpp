@@ -221,10 +221,10 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
     place(L.qseq, (size_t)4 * c.max_qlen, PMX_FAST);
     place(L.tseq, (size_t)c.max_tlen + 32, PMX_FAST);
     place(L.a, sizeof(A128) * c.max_anchor, PMX_FAST);
-    place(L.f, 4 * (size_t)c.max_anchor, PMX_FAST);
-    place(L.p, 4 * (size_t)c.max_anchor, PMX_FAST);
-    place(L.t, 4 * (size_t)c.max_anchor, PMX_FAST);
-    place(L.v, 4 * (size_t)c.max_anchor, PMX_FAST);
+    place(L.f, 16 * (size_t)c.max_anchor, PMX_FAST);   // f,p,t,v as ONE block (also the seed-position cache)
+    L.p = L.f; L.p.off += 4 * (size_t)c.max_anchor;
+    L.t = L.f; L.t.off += 8 * (size_t)c.max_anchor;
+    L.v = L.f; L.v.off += 12 * (size_t)c.max_anchor;
     place(L.regs0, sizeof(Reg) * c.max_reg, PMX_FAST);
     place(L.regs1, sizeof(Reg) * c.max_reg, PMX_FAST);
     place(L.regs2, sizeof(Reg) * c.max_reg, PMX_FAST);

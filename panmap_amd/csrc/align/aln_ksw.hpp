@@ -46,7 +46,7 @@ PMX_HD void push_cigar(uint32_t* cigar, int* n_cigar, int cap, uint32_t op, int 
 }
 
 // ksw_backtrack (ksw2.h:127-162) with is_rot = 1, min_intron_len = 0
-PMX_HD void ksw_backtrack(Work& W, int is_rev, const uint8_t* p, const int32_t* off, const int32_t* off_end, int n_col, int i0, int j0,
+PMX_HDN void ksw_backtrack(Work& W, int is_rev, const uint8_t* p, const int32_t* off, const int32_t* off_end, int n_col, int i0, int j0,
                           int* n_cigar_) {
     int n_cigar = 0, i = i0, j = j0, state = 0;
     uint32_t* cigar = W.cig_tmp;
@@ -86,7 +86,7 @@ inline int64_t wave_max_i64(int64_t v) { return v; }
 #endif
 
 // ksw_extd2_sse.  query/target hold nt4 codes; with_cigar always on.  Results in ez and W.cig_tmp.
-PMX_HD void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+PMX_HDN void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
                       int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     const int lane = lane_id();
     const int approx_max = !!(flag & PMX_EZ_APPROX_MAX);
@@ -319,6 +319,72 @@ PMX_HD void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const u
         ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, ez.max_t, ez.max_q, &ez.n_cigar);
     }
     wave_sync();
+}
+
+
+#if PMX_W > 1
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+#else
+inline int wave_sum_i32(int v) { return v; }
+#endif
+
+// Number of positions i < n where a[i] != b[i] or a base is ambiguous (code >= 4), saturating early is
+// not needed: n <= a few hundred.  Lane-parallel.
+PMX_HD int count_diff(const uint8_t* a, const uint8_t* b, int n) {
+    int d = 0;
+    for (int i = lane_id(); i < n; i += PMX_W) d += (a[i] != b[i] || a[i] > 3) ? 1 : 0;
+    return wave_sum_i32(d);
+}
+
+// ksw_extd2 with two shortcuts whose results are provably what the DP returns (DESIGN.md "DP shortcuts"):
+//  (1) extension (EXTZ_ONLY) of a query that equals the target prefix base for base (no ambiguous base),
+//      band and z-drop not binding: the main diagonal is the unique optimum -> max = qlen*a at
+//      (qlen-1,qlen-1), reach_end iff end_bonus > 0, CIGAR = qlen M;
+//  (2) global alignment in the approximate-max first pass of two equal-length sequences without
+//      ambiguous bases whose Hamming distance d satisfies d*(a+b) < a + 2*min(q+e,q2+e2): every gapped
+//      alignment scores strictly less than the gap-free one for every prefix pair on the main diagonal,
+//      so the traceback is all-diagonal -> score = len*a - d*(a+b), CIGAR = len M.
+// Everything else runs the DP.
+PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+                           int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+    const int a = mat[0], b = -mat[1];
+    const int g1 = q + e, g2 = q2 + e2;
+    const int gmin = g1 < g2 ? g1 : g2, gmax = g1 > g2 ? g1 : g2;
+    if (qlen > 0 && tlen > 0 && a > 0 && b > 0 && (w < 0 || (w >= qlen && w >= tlen)) && -mat[1] <= 2 * gmin) {
+        if ((flag & PMX_EZ_EXTZ_ONLY) && tlen >= qlen && zdrop >= 2 * gmax + a) {
+            if (count_diff(query, target, qlen) == 0) {
+                ez_reset(ez);
+                ez.max = (uint32_t)(qlen * a);
+                ez.max_t = ez.max_q = qlen - 1;
+                ez.mqe = qlen * a;
+                ez.mqe_t = qlen - 1;
+                if (tlen == qlen) { ez.mte = qlen * a; ez.mte_q = qlen - 1; }
+                ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
+                W.cig_tmp[0] = (uint32_t)qlen << 4;
+                ez.n_cigar = 1;
+                wave_sync();
+                return;
+            }
+        } else if (!(flag & PMX_EZ_EXTZ_ONLY) && (flag & PMX_EZ_APPROX_MAX) && !(flag & PMX_EZ_APPROX_DROP) && qlen == tlen) {
+            const int d = count_diff(query, target, qlen);
+            // count_diff also counts ambiguous bases; any such position forces the DP (d is then unreliable)
+            int amb = 0;
+            for (int i = lane_id(); i < qlen; i += PMX_W) amb += (query[i] > 3 || target[i] > 3) ? 1 : 0;
+            amb = wave_sum_i32(amb);
+            if (amb == 0 && d * (a + b) < a + 2 * gmin) {
+                ez_reset(ez);
+                ez.score = qlen * a - d * (a + b);
+                W.cig_tmp[0] = (uint32_t)qlen << 4;
+                ez.n_cigar = 1;
+                wave_sync();
+                return;
+            }
+        }
+    }
+    ksw_extd2(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
 }
 
 }  // namespace aln

@@ -38,7 +38,7 @@ PMX_HD void set_pe_thru(const int* qlens, const int* n_regs, Reg* const* regs) {
 }
 
 // mm_pair (pe.c:76-177)
-PMX_HD void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, const int* qlens, int* n_regs,
+PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, const int* qlens, int* n_regs,
                       Reg* const* regs) {
     // pair array (s, rev, key, reg index) kept as parallel arrays in the idle chaining scratch
     const int cap = W.caps.max_reg * 2;
@@ -138,7 +138,7 @@ PMX_HD void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonus
 }
 
 // mm_map_frag (map.c:236-390) for n_segs in {1,2}.  Regions end up in W.regs[s] / W.n_regs[s].
-PMX_HD void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
+PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     const int n_segs = W.n_segs;
     int qlen_sum = 0;
     for (int i = 0; i < n_segs; ++i) { qlen_sum += W.qlen[i]; W.n_regs[i] = 0; }

@@ -23,7 +23,7 @@ PMX_HD uint64_t mz_hash64(uint64_t key, uint64_t mask) {
 
 // (w,k)-minimizers of one segment, appended to W.mv (no HPC).  seq holds nt4 codes (>=4 ambiguous).
 // Output layout as the reference: x = hash<<8 | span, y = rid<<32 | lastPos<<1 | strand.
-PMX_HD void sketch_segment(Work& W, const uint8_t* seq, int len, int w, int k, uint32_t rid) {
+PMX_HDN void sketch_segment(Work& W, const uint8_t* seq, int len, int w, int k, uint32_t rid) {
     const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
     uint64_t kmer0 = 0, kmer1 = 0;
     int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
@@ -137,7 +137,7 @@ PMX_HD void heap_down_max_u64(uint64_t* l, int i, int n) {   // ks_heapdown_uint
 
 // mm_seed_select (seed.c:56-96): within a streak of high-occurrence minimizers keep the
 // max_high_occ least frequent ones.
-PMX_HD void seed_select(int n, Seed* a, int len, int max_occ, int max_max_occ, int dist) {
+PMX_HDN void seed_select(int n, Seed* a, int len, int max_occ, int max_max_occ, int dist) {
     if (n == 0 || n == 1) return;
     int m = 0;
     for (int i = 0; i < n; ++i)
@@ -174,13 +174,21 @@ PMX_HD void seed_select(int n, Seed* a, int len, int max_occ, int max_max_occ, i
     }
 }
 
-// mm_collect_matches (seed.c:98-131) + mm_seed_collect_all (:28-52)
-PMX_HD void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
+// mm_collect_matches (seed.c:98-131) + mm_seed_collect_all (:28-52).  The index probes of all
+// minimizers are issued lane-parallel first (one L2 round trip instead of n_mv dependent ones).
+PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
     int n_m0 = 0;
+    for (int i = lane_id(); i < W.n_mv; i += PMX_W) {
+        uint32_t off = 0;
+        const uint32_t t = index_lookup(ri, W.mv[i].x >> 8, &off);
+        W.heap[i].x = off;
+        W.heap[i].y = t;
+    }
+    wave_sync();
     for (int i = 0; i < W.n_mv; ++i) {
         const A128 p = W.mv[i];
-        uint32_t off = 0;
-        const uint32_t t = index_lookup(ri, p.x >> 8, &off);
+        const uint32_t off = (uint32_t)W.heap[i].x;
+        const uint32_t t = (uint32_t)W.heap[i].y;
         if (t == 0) continue;
         Seed q;
         q.q_pos = (uint32_t)p.y;
@@ -193,6 +201,7 @@ PMX_HD void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen,
         if (i < W.n_mv - 1 && p.x >> 8 == W.mv[i + 1].x >> 8) q.is_tandem = 1;
         W.seeds[n_m0++] = q;
     }
+    wave_sync();
     if (o.occ_dist > 0 && o.max_max_occ > max_occ) seed_select(n_m0, W.seeds, qlen, max_occ, o.max_max_occ, o.occ_dist);
     else
         for (int i = 0; i < n_m0; ++i)
@@ -223,7 +232,7 @@ PMX_HD void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen,
 
 // collect_seed_hits_heap (map.c:102-166): k-way merge of the occurrence lists by reference position;
 // forward-strand anchors first, then the reverse-strand ones, both ascending.
-PMX_HD void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
+PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
     collect_matches(W, o, ri, qlen, max_occ);
     if (W.n_a > W.caps.max_anchor) {
         W.status |= PMX_ST_OVERFLOW;
@@ -234,10 +243,23 @@ PMX_HD void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, in
     const int64_t n_a = W.n_a;
     A128* heap = W.heap;
     A128* a = W.a;
+    // stage every occurrence list in the (idle) chaining scratch so the merge never waits on HBM/L2:
+    // cache offsets are assigned in seed order, the copies run one seed per lane
+    uint64_t* pc = (uint64_t*)W.f;   // f,p,t,v are one contiguous block of 16*max_anchor bytes
+    {
+        uint32_t acc = 0;
+        for (int i = 0; i < n_m; ++i) { const uint32_t n = W.seeds[i].n; W.seeds[i].flt = acc; acc += n; }   // flt is free now: cache offset
+        wave_sync();
+        for (int i = lane_id(); i < n_m; i += PMX_W) {
+            const Seed q = W.seeds[i];
+            for (uint32_t j = 0; j < q.n; ++j) pc[q.flt + j] = ri.pos[q.off + j];
+        }
+        wave_sync();
+    }
     int heap_size = 0;
     for (int i = 0; i < n_m; ++i) {
         if (W.seeds[i].n > 0) {
-            heap[heap_size].x = ri.pos[W.seeds[i].off];
+            heap[heap_size].x = pc[W.seeds[i].flt];
             heap[heap_size].y = (uint64_t)i << 32;
             ++heap_size;
         }
@@ -264,7 +286,7 @@ PMX_HD void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, in
         }
         if ((uint32_t)heap[0].y < q.n - 1) {
             ++heap[0].y;
-            heap[0].x = ri.pos[W.seeds[heap[0].y >> 32].off + (uint32_t)heap[0].y];
+            heap[0].x = pc[W.seeds[heap[0].y >> 32].flt + (uint32_t)heap[0].y];
         } else {
             heap[0] = heap[heap_size - 1];
             --heap_size;

@@ -30,7 +30,7 @@ PMX_HD void rs_insertsort(T* beg, T* end) {
 // one level of the American-flag pass on byte `s/8`; iterative over an explicit stack of pending
 // sub-ranges (the reference recurses; the visiting order of disjoint buckets does not matter)
 template <class T, class K>
-PMX_HD void rs_sort_level(T* beg, T* end, int s, T** stk_b, T** stk_e, int* stk_s, int& sp, int stk_cap, uint32_t* overflow) {
+PMX_HDN void rs_sort_level(T* beg, T* end, int s, T** stk_b, T** stk_e, int* stk_s, int& sp, int stk_cap, uint32_t* overflow) {
     // bucket boundaries: 256 (begin,end) pairs kept as offsets
     int32_t bb[256], be[256];
     for (int k = 0; k < 256; ++k) bb[k] = be[k] = 0;
@@ -66,7 +66,7 @@ PMX_HD void rs_sort_level(T* beg, T* end, int s, T** stk_b, T** stk_e, int* stk_
 }
 
 template <class T, class K>
-PMX_HD void radix_sort(T* beg, T* end, uint32_t* status) {
+PMX_HDN void radix_sort(T* beg, T* end, uint32_t* status) {
     if (end - beg <= 64) {
         rs_insertsort<T, K>(beg, end);
         return;

@@ -30,6 +30,7 @@ struct AlignArgs {
 };
 
 __global__ void k_align_reads(AlignArgs A);
+__global__ void k_align_reads_w4(AlignArgs A);
 
 }  // namespace aln
 }  // namespace pmx

@@ -10,8 +10,8 @@
 namespace pmx {
 namespace aln {
 
-__global__ void __launch_bounds__(64)
-k_align_reads(AlignArgs A) {
+template <int WAVES_PER_SIMD>
+__device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     Work& W = *reinterpret_cast<Work*>(lds);
     uint8_t* fast = lds + PMX_ALIGN_WORK_BYTES;
@@ -89,6 +89,10 @@ k_align_reads(AlignArgs A) {
         }
     }
 }
+
+// two register budgets of the same body: 256 VGPRs (2 waves/SIMD) and 128 VGPRs (4 waves/SIMD)
+__global__ void __launch_bounds__(64, 2) k_align_reads(AlignArgs A) { align_reads_body<2>(A); }
+__global__ void __launch_bounds__(64, 4) k_align_reads_w4(AlignArgs A) { align_reads_body<4>(A); }
 
 }  // namespace aln
 }  // namespace pmx

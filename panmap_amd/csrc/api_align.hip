@@ -48,18 +48,18 @@ int fail(int code, const std::string& msg) {
 
 template <class T>
 void upload(DevBuf<T>& d, const std::vector<T>& h, hipStream_t st) {
-    d.alloc(h.size());
+    d.ensure(h.size());
     if (!h.empty()) PMX_HIP(hipMemcpyAsync(d.p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, st));
 }
 }  // namespace
 
 extern "C" {
 
-int pmx_aligner_create(pmx_ctx* ctx, const char* reference, int64_t ref_len, int mean_read_len, pmx_aligner** out) {
-    if (!ctx || !reference || ref_len <= 0 || !out) return PMX_ERR_ARG;
+int pmx_aligner_set_reference(pmx_ctx* ctx, pmx_aligner* al, const char* reference, int64_t ref_len, int mean_read_len) {
+    if (!ctx || !al || !reference || ref_len <= 0) return PMX_ERR_ARG;
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
-    std::unique_ptr<pmx_aligner> al(new pmx_aligner());
+    PMX_HIP(hipStreamSynchronize(ctx->stream));   // nothing may still read the old index
     al->mean_len = mean_read_len;
     al->opt = make_opt(mean_read_len);
     const int max_score = std::max(8192, (mean_read_len * 4 + 1024) * (al->opt.a + 1));
@@ -82,8 +82,19 @@ int pmx_aligner_create(pmx_ctx* ctx, const char* reference, int64_t ref_len, int
     r.logf_ratio = al->d_logf_ratio.p;
     r.logf_int = al->d_logf_int.p;
     r.n_logf = (int32_t)al->host.logf_int.size();
-    al->cigar_used.alloc(1);
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_aligner_create(pmx_ctx* ctx, const char* reference, int64_t ref_len, int mean_read_len, pmx_aligner** out) {
+    if (!ctx || !reference || ref_len <= 0 || !out) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<pmx_aligner> al(new pmx_aligner());
+    al->cigar_used.alloc(1);
+    const int rc = pmx_aligner_set_reference(ctx, al.get(), reference, ref_len, mean_read_len);
+    if (rc != PMX_OK) return rc;
     *out = al.release();
     return PMX_OK;
     PMX_CATCH
@@ -108,13 +119,18 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     PMX_HIP(hipMemsetAsync(al->cigar_used.p, 0, sizeof(unsigned long long), ctx->stream));
     if (n_items <= 0) return PMX_OK;
 
-    const size_t lds_budget = 20 * 1024;
+    // tuning knobs (defaults chosen from measurements): LDS arena per wave and register budget
+    size_t lds_budget = 20 * 1024;
+    int waves_per_simd = 4;
+    if (const char* e = getenv("PMX_ALIGN_LDS_KB")) lds_budget = (size_t)atoi(e) * 1024;
+    if (const char* e = getenv("PMX_ALIGN_WAVES")) waves_per_simd = atoi(e);
+    auto kern = waves_per_simd >= 4 ? k_align_reads_w4 : k_align_reads;
     AlignArgs A;
     A.layout = plan_layout((int)rs->max_len, paired ? 2 : 1, al->opt, lds_budget);
     const size_t lds_bytes = PMX_ALIGN_WORK_BYTES + A.layout.fast_bytes + 16;
     if (lds_bytes > 160 * 1024) return fail(PMX_ERR_UNSUPPORTED, "reads too long for the LDS work arena");
-    if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)k_align_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    int waves_per_cu = (int)std::min<size_t>(16, (size_t)(160 * 1024) / lds_bytes);
+    if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int waves_per_cu = (int)std::min<size_t>((size_t)(waves_per_simd >= 4 ? 16 : 8), (size_t)(160 * 1024) / lds_bytes);
     if (waves_per_cu < 1) waves_per_cu = 1;
     int64_t grid = (int64_t)ctx->n_cu * waves_per_cu;
     if (grid > n_items) grid = n_items;
@@ -132,7 +148,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.cigar_cap = al->cigar_cap;
     A.cigar_used = al->cigar_used.p;
     timer_begin(ctx, "align");
-    hipLaunchKernelGGL(k_align_reads, dim3((unsigned)grid), dim3(64), lds_bytes, ctx->stream, A);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, ctx->stream, A);
     timer_end(ctx, "align", 1);
     PMX_HIP(hipGetLastError());
     return PMX_OK;

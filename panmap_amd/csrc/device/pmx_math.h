@@ -5,8 +5,10 @@
 
 #if defined(__HIPCC__)
 #define PMX_HD __host__ __device__ __forceinline__
+#define PMX_HDN __host__ __device__ __attribute__((noinline)) inline   // big phase functions: own register allocation
 #else
 #define PMX_HD inline
+#define PMX_HDN inline
 #endif
 
 namespace pmx {
