@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define ORC_SUM_BLOCK 1024
+
 /* ------------------------------------------------------------------ hashes */
 
 static inline uint64_t rotl64(uint64_t h, unsigned r) { r &= 63u; return r ? (h << r) | (h >> (64u - r)) : h; }
@@ -337,19 +339,25 @@ int64_t orc_finalize_reads(const uint64_t *hash, const int64_t *count, int64_t n
         est_cov = cnt > 0 ? (double)sum / (double)cnt : 0.0;
         min_support = est_cov > 3.0 ? 2 : 1;
     }
-    /* computeReadSeedMagnitudes: src/placement.cpp:957-984, summed in ascending-hash order */
-    double mag2 = 0.0, lsum = 0.0;
+    /* computeReadSeedMagnitudes: src/placement.cpp:957-984.  The reference sums in hash-map iteration
+       order (unspecified); canonical order here and on the GPU: kept seeds in ascending-hash order, summed
+       sequentially inside consecutive blocks of ORC_SUM_BLOCK, then the block sums sequentially. */
     int64_t kept = 0, total = 0;
     for (int64_t i = 0; i < n; ++i) {
         if (dead[i]) continue;
         total += count[i];
         if (count[i] < min_support) continue;
-        double L = log1p((double)count[i]);
         kept_hash[kept] = hash[i];
-        kept_log[kept] = L;
-        mag2 += L * L;
-        lsum += L;
+        kept_log[kept] = log1p((double)count[i]);
         ++kept;
+    }
+    double mag2 = 0.0, lsum = 0.0;
+    for (int64_t b = 0; b < kept; b += ORC_SUM_BLOCK) {
+        double m2 = 0.0, ls = 0.0;
+        const int64_t e = b + ORC_SUM_BLOCK < kept ? b + ORC_SUM_BLOCK : kept;
+        for (int64_t i = b; i < e; ++i) { const double L = kept_log[i]; m2 += L * L; ls += L; }
+        mag2 += m2;
+        lsum += ls;
     }
     free(dead);
     st->min_support = min_support;

@@ -49,6 +49,7 @@ struct pmx_place {
     DevBuf<double> tvals;
     uint64_t tcap = 0;
     DevBuf<double> scalars;                // [0]=sum L^2 [1]=sum L [2]=wc_den
+    DevBuf<double> partial;                // block sums of the canonical-order reduction
     DevBuf<unsigned long long> stats;
     DevBuf<char> tmp;                      // rocprim temp storage
     // node outputs
@@ -90,7 +91,8 @@ void table_reserve(pmx_ctx* ctx, pmx_place* pl, uint64_t bound_new) {
     unsigned long long h_ctr[PMX_CTR_N];
     PMX_HIP(hipMemcpyAsync(h_ctr, pl->counters.p, sizeof(h_ctr), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t entries = h_ctr[PMX_CTR_ENTRIES];
+    uint64_t entries = 0;
+    for (int i = 0; i < PMX_CTR_NSHARD; ++i) entries += h_ctr[PMX_CTR_SHARD0 + i];
     uint64_t need = next_pow2((uint64_t)((double)(entries + bound_new) / 0.7) + 1024);
     if (need < (1u << 16)) need = 1u << 16;
     if (pl->cap >= need) return;
@@ -104,8 +106,7 @@ void table_reserve(pmx_ctx* ctx, pmx_place* pl, uint64_t bound_new) {
     ovals.swap(pl->vals);
     const uint64_t ocap = pl->cap;
     table_alloc(ctx, pl, need);
-    unsigned long long zero = 0;
-    PMX_HIP(hipMemcpyAsync(pl->counters.p + PMX_CTR_ENTRIES, &zero, sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemsetAsync(pl->counters.p + PMX_CTR_SHARD0, 0, sizeof(unsigned long long) * PMX_CTR_NSHARD, ctx->stream));
     hipLaunchKernelGGL(k_table_rehash, dim3(grid_for((int64_t)ocap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, okeys.p, ovals.p, ocap,
                        pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -118,7 +119,8 @@ void finalize_histogram(pmx_ctx* ctx, pmx_place* pl) {
     PMX_HIP(hipMemcpyAsync(h_ctr, pl->counters.p, sizeof(h_ctr), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     if (h_ctr[PMX_CTR_OVERFLOW]) throw std::runtime_error("seed table overflow (internal sizing error)");
-    const int64_t n = (int64_t)h_ctr[PMX_CTR_ENTRIES];
+    int64_t n = 0;
+    for (int i = 0; i < PMX_CTR_NSHARD; ++i) n += (int64_t)h_ctr[PMX_CTR_SHARD0 + i];
     pl->n_hist = n;
     pl->hist_hash.ensure(n);
     pl->hist_count.ensure(n);
@@ -547,7 +549,12 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     } else if (min_support < 0) min_support = 1;
     pl->n_kept = n_kept;
     // canonical-order sums (src/placement.cpp:957-984)
-    hipLaunchKernelGGL(k_sequential_sums, dim3(1), dim3(64), 0, st, pl->kept_log.p, n_kept, pl->scalars.p);
+    {
+        const int64_t nb = (n_kept + PMX_SUM_BLOCK - 1) / PMX_SUM_BLOCK;
+        pl->partial.ensure((size_t)(2 * nb + 2));
+        if (nb > 0) hipLaunchKernelGGL(k_block_sums, dim3(grid_for(nb, 64, G)), dim3(64), 0, st, pl->kept_log.p, n_kept, pl->partial.p);
+        hipLaunchKernelGGL(k_sequential_sums, dim3(1), dim3(64), 0, st, pl->partial.p, nb, pl->scalars.p);
+    }
     // probe table for the kept seeds
     pl->tcap = next_pow2((uint64_t)std::max<int64_t>(n_kept, 1) * 2 + 64);
     pl->tkeys.ensure(pl->tcap);

@@ -4,7 +4,9 @@
 
 #define PMX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
 #define PMX_SEED_BLOCK 128
-enum { PMX_CTR_ENTRIES = 0, PMX_CTR_OVERFLOW = 1, PMX_CTR_SEEDS = 2, PMX_CTR_COMPACT = 3, PMX_CTR_N = 8 };
+#define PMX_SUM_BLOCK 1024
+#define PMX_CTR_NSHARD 256
+enum { PMX_CTR_ENTRIES = 0, PMX_CTR_OVERFLOW = 1, PMX_CTR_SEEDS = 2, PMX_CTR_COMPACT = 3, PMX_CTR_SHARD0 = 8, PMX_CTR_N = 8 + PMX_CTR_NSHARD };
 
 namespace pmx {
 
@@ -30,7 +32,8 @@ __global__ void k_hist_stats(const int64_t* count, const uint8_t* dead, int64_t 
 __global__ void k_keep_flags(const int64_t* count, const uint8_t* dead, int64_t n, int64_t min_support, uint32_t* flag);
 __global__ void k_keep_scatter(const uint64_t* hash, const int64_t* count, const uint32_t* flag, const uint32_t* pos, int64_t n,
                                uint64_t* kept_hash, double* kept_log);
-__global__ void k_sequential_sums(const double* kept_log, int64_t n, double* out);
+__global__ void k_block_sums(const double* kept_log, int64_t n, double* partial);
+__global__ void k_sequential_sums(const double* partial, int64_t nb, double* out);
 __global__ void k_kept_table_build(const uint64_t* kept_hash, const double* kept_log, int64_t n, uint64_t* tkeys, double* tvals,
                                    uint64_t mask);
 __global__ void k_wc_denominator(const uint64_t* ch_hash, const int16_t* ch_child, uint64_t beg, uint64_t end, const uint64_t* tkeys,

@@ -58,7 +58,7 @@ __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long*
     uint64_t slot = mix64(key) & mask;
     for (uint64_t probes = 0; probes <= mask; ++probes) {
         unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)key);
-        if (prev == PMX_EMPTY_KEY) atomicAdd(&counters[PMX_CTR_ENTRIES], 1ULL);
+        if (prev == PMX_EMPTY_KEY) atomicAdd(&counters[PMX_CTR_SHARD0 + (slot & (PMX_CTR_NSHARD - 1))], 1ULL);   // sharded: one hot word would serialise
         if (prev == PMX_EMPTY_KEY || prev == key) {
             atomicAdd(&vals[slot], mult);
             return;
@@ -190,12 +190,24 @@ __global__ void k_table_rehash(const uint64_t* __restrict__ okeys, const unsigne
 
 __global__ void k_table_compact(const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ vals, uint64_t cap,
                                 uint64_t* out_hash, int64_t* out_count, unsigned long long* n_out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t k = keys[i];
-        if (k == PMX_EMPTY_KEY) continue;
-        const unsigned long long j = atomicAdd(n_out, 1ULL);
-        out_hash[j] = k;
-        out_count[j] = (int64_t)vals[i];
+    // uniform trip count so the whole wave reaches the ballot; one atomic per wave
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_iter = (cap + stride - 1) / stride;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        const uint64_t i = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const uint64_t k = i < cap ? keys[i] : PMX_EMPTY_KEY;
+        const bool have = k != PMX_EMPTY_KEY;
+        const unsigned long long m = __ballot(have);
+        if (m == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0);
+        if (have) {
+            const unsigned long long j = base + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
+            out_hash[j] = k;
+            out_count[j] = (int64_t)vals[i];
+        }
     }
 }
 
@@ -254,15 +266,29 @@ __global__ void k_keep_scatter(const uint64_t* __restrict__ hash, const int64_t*
     }
 }
 
-// Canonical-order FP sums (ascending hash, strictly sequential):
-// out[0] = sum L^2, out[1] = sum L.   One thread.
-__global__ void k_sequential_sums(const double* __restrict__ kept_log, int64_t n, double* out) {
+// Canonical-order FP sums (same order as oracle_place.c): kept seeds in ascending
+// hash order, sequential inside consecutive blocks of PMX_SUM_BLOCK (one thread per block), then the
+// block sums sequentially (one thread).  partial[2*b] = sum L^2, partial[2*b+1] = sum L.
+__global__ void k_block_sums(const double* __restrict__ kept_log, int64_t n, double* partial) {
+    const int64_t nb = (n + PMX_SUM_BLOCK - 1) / PMX_SUM_BLOCK;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t beg = b * PMX_SUM_BLOCK, end = beg + PMX_SUM_BLOCK < n ? beg + PMX_SUM_BLOCK : n;
+        double m2 = 0.0, s = 0.0;
+        for (int64_t i = beg; i < end; ++i) {
+            const double L = kept_log[i];
+            m2 += L * L;
+            s += L;
+        }
+        partial[2 * b] = m2;
+        partial[2 * b + 1] = s;
+    }
+}
+__global__ void k_sequential_sums(const double* __restrict__ partial, int64_t nb, double* out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     double m2 = 0.0, s = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
-        const double L = kept_log[i];
-        m2 += L * L;
-        s += L;
+    for (int64_t b = 0; b < nb; ++b) {
+        m2 += partial[2 * b];
+        s += partial[2 * b + 1];
     }
     out[0] = m2;
     out[1] = s;
