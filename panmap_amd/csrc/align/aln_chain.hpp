@@ -63,6 +63,96 @@ PMX_HD int64_t chain_bk_end(int32_t max_drop, const A128* z, const int32_t* f, c
     return max_i;
 }
 
+#if PMX_W > 1
+__device__ __forceinline__ int32_t rl32(int32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return (uint64_t)hi << 32 | lo;
+}
+
+// Fill phase of mg_lchain_dp for n <= 64 anchors, one anchor per lane: for anchor i every predecessor
+// lane evaluates comput_sc in parallel; the order-dependent part of the reference loop (strict-max
+// update, the t[]-mark / n_skip early exit, lchain.c:176-190) is replayed sequentially over the lanes'
+// values with scalar reads.  t[j]==i marks only ever compare against the current i, so they live in a
+// 64-bit mask that is reset per anchor.  Writes f/p/v exactly as the generic loop would.
+__device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int n_seg) {
+    const int n = (int)W.n_a;
+    const int lane = lane_id();
+    const int bw = o.bw, max_skip = o.max_chain_skip;
+    const float gp = o.chn_pen_gap, sp = o.chn_pen_skip;
+    A128 mine;
+    mine.x = lane < n ? W.a[lane].x : 0;
+    mine.y = lane < n ? W.a[lane].y : 0;
+    int32_t fj = 0, pj = -1, vj = 0;
+    int st = 0, max_ii = -1;
+    for (int i = 0; i < n; ++i) {
+        A128 ai;
+        ai.x = rl64(mine.x, i);
+        ai.y = rl64(mine.y, i);
+        // advance st (lchain.c:173): first lane >= st that is on the same strand/target and within max_dist_x
+        {
+            const bool far = (ai.x >> 32 != mine.x >> 32) || (ai.x > mine.x + (uint64_t)max_dist_x);
+            const unsigned long long ok = __ballot(!far && lane >= st && lane < i);
+            st = ok ? (int)__builtin_ctzll(ok) : i;
+        }
+        const bool in_rng = lane >= st && lane < i;
+        int32_t sc = INT32_MIN;
+        if (in_rng) sc = chain_score(ai, mine, max_dist_x, max_dist_y, bw, gp, sp, n_seg);
+        const unsigned long long valid = __ballot(in_rng && sc != INT32_MIN);
+        const int32_t val = sc != INT32_MIN ? sc + fj : INT32_MIN;
+        int32_t max_f = (int32_t)(ai.y >> 32 & 0xff), n_skip = 0;
+        int max_j = -1;
+        unsigned long long mark = 0;
+        int j;
+        for (j = i - 1; j >= st; --j) {
+            if (!(valid >> j & 1)) continue;
+            const int32_t s_ = rl32(val, j);
+            if (s_ > max_f) {
+                max_f = s_;
+                max_j = j;
+                if (n_skip > 0) --n_skip;
+            } else if (mark >> j & 1) {
+                if (++n_skip > max_skip) break;
+            }
+            const int32_t pp = rl32(pj, j);
+            if (pp >= 0) mark |= 1ULL << pp;
+        }
+        const int end_j = j;
+        if (max_ii < 0 || (int64_t)(ai.x - rl64(mine.x, max_ii < 0 ? 0 : max_ii)) > (int64_t)max_dist_x) {
+            // max f over [st, i-1]; equal values keep the largest j (scan runs downwards with strict <)
+            int64_t key = in_rng ? ((int64_t)fj << 32 | (uint32_t)lane) : INT64_MIN;
+            for (int ofs = 32; ofs > 0; ofs >>= 1) {
+                const int64_t other = __shfl_xor(key, ofs);
+                key = other > key ? other : key;
+            }
+            max_ii = key == INT64_MIN ? -1 : (int)(uint32_t)key;
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            // NB: max_ii may lie before st (e.g. the last forward-strand anchor when i is the first
+            // reverse-strand one: the unsigned difference wraps negative and skips the refresh above),
+            // so the score is evaluated here, not read from the lanes' in-range values
+            A128 am;
+            am.x = rl64(mine.x, max_ii);
+            am.y = rl64(mine.y, max_ii);
+            const int32_t tmp = chain_score(ai, am, max_dist_x, max_dist_y, bw, gp, sp, n_seg), fm = rl32(fj, max_ii);
+            if (tmp != INT32_MIN && max_f < tmp + fm) { max_f = tmp + fm; max_j = max_ii; }
+        }
+        const int32_t v_prev = max_j >= 0 ? rl32(vj, max_j) : 0;
+        const int32_t v_i = max_j >= 0 && v_prev > max_f ? v_prev : max_f;
+        if (lane == i) { fj = max_f; pj = max_j; vj = v_i; }
+        if (max_ii < 0) max_ii = i;
+        else {
+            const uint64_t xm = rl64(mine.x, max_ii);
+            const int32_t fm = rl32(fj, max_ii);
+            if ((int64_t)(ai.x - xm) <= (int64_t)max_dist_x && fm < max_f) max_ii = i;
+        }
+    }
+    if (lane < n) { W.f[lane] = fj; W.p[lane] = pj; W.v[lane] = vj; }
+    wave_sync();
+}
+#endif
+
 // mg_lchain_dp (lchain.c:148-230) followed by mg_chain_backtrack (:27-76) and compact_a (:78-111).
 // In: W.a[0..n_a) sorted anchors.  Out: W.a holds the chained anchors grouped by chain, W.u[0..n_u)
 // = score<<32 | count, chains ordered by the target position of their first anchor.
@@ -77,42 +167,50 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     const int32_t max_drop = bw;
     if (max_dist_x < bw) max_dist_x = bw;
     if (max_dist_y < bw) max_dist_y = bw;
+#if PMX_W > 1
+    const bool wave_fill = n <= 64;
+    if (wave_fill) chain_fill_wave(W, o, max_dist_x, max_dist_y, n_seg);
+#else
+    const bool wave_fill = false;
+#endif
+    if (!wave_fill) {
     for (int64_t i = 0; i < n; ++i) t[i] = 0;
-    int64_t st = 0, max_ii = -1;
-    for (int64_t i = 0; i < n; ++i) {
-        int64_t max_j = -1, end_j;
-        int32_t max_f = (int32_t)(a[i].y >> 32 & 0xff), n_skip = 0;
-        while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist_x)) ++st;
-        if (i - st > max_iter) st = i - max_iter;
-        int64_t j;
-        for (j = i - 1; j >= st; --j) {
-            int32_t sc = chain_score(a[i], a[j], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
-            if (sc == INT32_MIN) continue;
-            sc += f[j];
-            if (sc > max_f) {
-                max_f = sc;
-                max_j = j;
-                if (n_skip > 0) --n_skip;
-            } else if (t[j] == (int32_t)i) {
-                if (++n_skip > max_skip) break;
+        int64_t st = 0, max_ii = -1;
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t max_j = -1, end_j;
+            int32_t max_f = (int32_t)(a[i].y >> 32 & 0xff), n_skip = 0;
+            while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist_x)) ++st;
+            if (i - st > max_iter) st = i - max_iter;
+            int64_t j;
+            for (j = i - 1; j >= st; --j) {
+                int32_t sc = chain_score(a[i], a[j], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                if (sc == INT32_MIN) continue;
+                sc += f[j];
+                if (sc > max_f) {
+                    max_f = sc;
+                    max_j = j;
+                    if (n_skip > 0) --n_skip;
+                } else if (t[j] == (int32_t)i) {
+                    if (++n_skip > max_skip) break;
+                }
+                if (p[j] >= 0) t[p[j]] = (int32_t)i;
             }
-            if (p[j] >= 0) t[p[j]] = (int32_t)i;
+            end_j = j;
+            if (max_ii < 0 || (int64_t)(a[i].x - a[max_ii].x) > (int64_t)max_dist_x) {
+                int32_t mx = INT32_MIN;
+                max_ii = -1;
+                for (j = i - 1; j >= st; --j)
+                    if (mx < f[j]) { mx = f[j]; max_ii = j; }
+            }
+            if (max_ii >= 0 && max_ii < end_j) {
+                const int32_t tmp = chain_score(a[i], a[max_ii], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
+            }
+            f[i] = max_f;
+            p[i] = (int32_t)max_j;
+            v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
+            if (max_ii < 0 || ((int64_t)(a[i].x - a[max_ii].x) <= (int64_t)max_dist_x && f[max_ii] < f[i])) max_ii = i;
         }
-        end_j = j;
-        if (max_ii < 0 || (int64_t)(a[i].x - a[max_ii].x) > (int64_t)max_dist_x) {
-            int32_t mx = INT32_MIN;
-            max_ii = -1;
-            for (j = i - 1; j >= st; --j)
-                if (mx < f[j]) { mx = f[j]; max_ii = j; }
-        }
-        if (max_ii >= 0 && max_ii < end_j) {
-            const int32_t tmp = chain_score(a[i], a[max_ii], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
-            if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
-        }
-        f[i] = max_f;
-        p[i] = (int32_t)max_j;
-        v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
-        if (max_ii < 0 || ((int64_t)(a[i].x - a[max_ii].x) <= (int64_t)max_dist_x && f[max_ii] < f[i])) max_ii = i;
     }
 
     // ---- backtrack (lchain.c:27-76)

@@ -326,13 +326,16 @@ PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, cons
         for (int i = 0; i < n_regs0; ++i) W.seg_u[s][i] = (uint64_t)(uint32_t)regs0[i].score << 32;
         W.seg_n_a[s] = 0;
     }
+    int n_seg_anchors[2] = {0, 0};
     for (int i = 0; i < n_regs0; ++i) {
         const Reg& r = regs0[i];
         for (int j = 0; j < r.cnt; ++j) {
             const int sid = (int)((a[r.as + j].y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
             ++W.seg_u[sid][i];
+            ++n_seg_anchors[sid & 1];
         }
     }
+    W.seg_a[1] = W.seg_a[0] + n_seg_anchors[0];   // both mates' anchor lists share one max_anchor block
     for (int s = 0; s < n_segs; ++s) {
         int n_u = 0;
         for (int i = 0; i < n_regs0; ++i)

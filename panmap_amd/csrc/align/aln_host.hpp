@@ -244,13 +244,82 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
     place(L.z, sizeof(A128) * c.max_anchor, PMX_SLOW);
     place(L.reg_tmp, sizeof(Reg) * c.max_reg, PMX_SLOW);
     place(L.seg_a0, sizeof(A128) * c.max_anchor, PMX_SLOW);
-    place(L.seg_a1, sizeof(A128) * c.max_anchor, PMX_SLOW);
+    L.seg_a1 = L.seg_a0;                       // seg_gen splits the block dynamically
     place(L.seg_u0, 8 * (size_t)c.max_reg * 4, PMX_SLOW);
     place(L.seg_u1, 8 * (size_t)c.max_reg * 4, PMX_SLOW);
     place(L.cig_pool, 4 * (size_t)c.max_cigar * c.n_cig_slots, PMX_SLOW);
     place(L.tb, L.tb_cap + 64, PMX_SLOW);
     L.fast_bytes = used[PMX_FAST];
     L.slow_bytes = used[PMX_SLOW];
+    return L;
+}
+
+// Tier-1 layout for short read pairs: EVERYTHING except the traceback matrix lives in LDS, with small
+// typical-case capacities and phase overlays (seeding scratch | chaining scratch | DP arrays share one
+// region; they are never live together).  A pair that exceeds a capacity reports PMX_ST_OVERFLOW and is
+// re-run by the tier-2 launch with the general layout.
+inline Layout plan_layout_compact(int max_read_len, int n_segs, const Opt& o) {
+    Layout L;
+    Caps& c = L.caps;
+    c.max_qlen = (max_read_len + 15) / 16 * 16 + 16;
+    c.max_mini = 96;
+    c.max_anchor = 128;
+    c.max_reg = 8;
+    c.max_cigar = 32;
+    c.max_tlen = (c.max_qlen + o.max_gap + 15) / 16 * 16 + 16;
+    c.n_cig_slots = 20;
+    const int wband = (int)(std::max(o.bw, o.bw_long) * 1.5 + 1.);
+    const int n_col = ((std::min(std::min(c.max_tlen, c.max_qlen), wband + 1) + 15) / 16 + 1) * 16;
+    L.tb_cap = (size_t)(c.max_qlen + c.max_tlen) * n_col;
+    size_t top = 0;
+    auto put = [&](Layout::Ent& e, size_t bytes, size_t& cursor, int space = PMX_FAST) {
+        bytes = (bytes + 15) & ~(size_t)15;
+        e.space = (uint32_t)space;
+        e.off = cursor;
+        cursor += bytes;
+    };
+    // persistent
+    put(L.qseq, (size_t)4 * c.max_qlen, top);
+    put(L.mv, sizeof(A128) * c.max_mini, top);
+    put(L.a, sizeof(A128) * c.max_anchor, top);
+    put(L.regs0, sizeof(Reg) * c.max_reg, top);
+    put(L.regs1, sizeof(Reg) * c.max_reg, top);
+    put(L.regs2, sizeof(Reg) * c.max_reg, top);
+    put(L.reg_tmp, sizeof(Reg) * c.max_reg, top);
+    put(L.seg_a0, sizeof(A128) * c.max_anchor, top);
+    L.seg_a1 = L.seg_a0;                       // seg_gen splits the block dynamically
+    put(L.seg_u0, 8 * (size_t)c.max_reg * 4, top);
+    put(L.seg_u1, 8 * (size_t)c.max_reg * 4, top);
+    put(L.u, 8 * (size_t)c.max_reg * 4, top);
+    put(L.aux64, 8 * (size_t)c.max_reg * 8, top);
+    put(L.aux128, sizeof(A128) * c.max_reg * 4, top);
+    put(L.cig_pool, 4 * (size_t)c.max_cigar * c.n_cig_slots, top);
+    // overlay region
+    size_t ca = top, cb = top, cd = top;
+    put(L.sk_buf, sizeof(A128) * 32, ca);
+    put(L.seeds, sizeof(Seed) * c.max_mini, ca);
+    put(L.heap, sizeof(A128) * c.max_mini, ca);
+    put(L.f, 16 * (size_t)c.max_anchor, cb);
+    L.p = L.f; L.p.off += 4 * (size_t)c.max_anchor;
+    L.t = L.f; L.t.off += 8 * (size_t)c.max_anchor;
+    L.v = L.f; L.v.off += 12 * (size_t)c.max_anchor;
+    put(L.z, sizeof(A128) * c.max_anchor, cb);
+    put(L.a2, sizeof(A128) * c.max_anchor, cb);
+    put(L.u2, 8 * (size_t)c.max_reg * 4, cb);
+    put(L.du, (size_t)7 * (c.max_tlen + 32), cd);
+    put(L.sf, (size_t)c.max_tlen + 32, cd);
+    put(L.qr, (size_t)c.max_tlen + 64, cd);
+    put(L.tseq, (size_t)c.max_tlen + 32, cd);
+    put(L.H, 4 * (size_t)(c.max_tlen + 32), cd);
+    put(L.off_, 8 * (size_t)(c.max_qlen + c.max_tlen), cd);
+    put(L.cig_tmp, 4 * (size_t)c.max_cigar, cd);
+    // (the seed-position cache of the heap merge lives in the persistent seg_a block, so the seeding, chaining
+    //  and DP scratch regions may all overlay each other)
+    L.fast_bytes = std::max(ca, std::max(cb, cd));
+    size_t slow = 0;
+    put(L.mini_pos, 8 * (size_t)c.max_mini, slow, PMX_SLOW);
+    put(L.tb, L.tb_cap + 64, slow, PMX_SLOW);
+    L.slow_bytes = slow;
     return L;
 }
 

@@ -243,9 +243,9 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     const int64_t n_a = W.n_a;
     A128* heap = W.heap;
     A128* a = W.a;
-    // stage every occurrence list in the (idle) chaining scratch so the merge never waits on HBM/L2:
+    // stage every occurrence list in idle scratch so the merge never waits on HBM/L2:
     // cache offsets are assigned in seed order, the copies run one seed per lane
-    uint64_t* pc = (uint64_t*)W.f;   // f,p,t,v are one contiguous block of 16*max_anchor bytes
+    uint64_t* pc = (uint64_t*)W.seg_a[0];   // the per-mate anchor block (16*max_anchor bytes) is idle until seg_gen
     {
         uint32_t acc = 0;
         for (int i = 0; i < n_m; ++i) { const uint32_t n = W.seeds[i].n; W.seeds[i].flt = acc; acc += n; }   // flt is free now: cache offset

@@ -13,7 +13,10 @@ struct AlignArgs {
     const uint32_t* amb;
     const int64_t* woff;
     const int64_t* off;
-    int64_t n_items;        // pairs (paired) or reads
+    int64_t n_items;        // pairs (paired) or reads, or worklist length
+    const uint32_t* worklist;   // tier 2: item ids to (re)process; NULL = 0..n_items-1
+    uint32_t* retry_list;       // tier 1: items whose capacities overflowed (NULL in tier 2)
+    unsigned long long* retry_count;
     int paired;
     int revcomp_mate2;
     // reference + options

@@ -19,7 +19,8 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
     const int lane = (int)(threadIdx.x & 63u);
     const int n_segs = A.paired ? 2 : 1;
 
-    for (int64_t item = blockIdx.x; item < A.n_items; item += gridDim.x) {
+    for (int64_t it = blockIdx.x; it < A.n_items; it += gridDim.x) {
+        const int64_t item = A.worklist ? (int64_t)A.worklist[it] : it;
         __syncthreads();
         bind_work(W, A.layout, fast, slow);
         W.n_segs = n_segs;
@@ -55,6 +56,10 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
         } else {
             W.status |= PMX_ST_OVERFLOW;
             W.n_regs[0] = W.n_regs[1] = 0;
+        }
+        if (A.retry_list && (W.status & PMX_ST_OVERFLOW)) {   // tier 1: hand the pair to the general-capacity launch
+            if (lane == 0) A.retry_list[atomicAdd(A.retry_count, 1ULL)] = (uint32_t)item;
+            continue;
         }
         const bool mapped = !too_long && frag_is_mapped(W, A.paired);
         for (int s = 0; s < n_segs; ++s) {

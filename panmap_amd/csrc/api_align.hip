@@ -29,7 +29,10 @@ struct pmx_aligner {
     DevBuf<AlnRecord> records;
     DevBuf<uint32_t> cigars;
     DevBuf<unsigned long long> cigar_used;
-    DevBuf<uint8_t> slow;
+    DevBuf<uint8_t> slow, slow2;
+    DevBuf<uint32_t> retry_list;
+    DevBuf<unsigned long long> retry_count;
+    int64_t last_retry = 0;
     int64_t n_records = 0;
     uint64_t cigar_cap = 0;
     double last_occupancy = 0;
@@ -119,26 +122,18 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     PMX_HIP(hipMemsetAsync(al->cigar_used.p, 0, sizeof(unsigned long long), ctx->stream));
     if (n_items <= 0) return PMX_OK;
 
-    // tuning knobs (defaults chosen from measurements): LDS arena per wave and register budget
-    size_t lds_budget = 20 * 1024;
+    // Tier 1: compact all-LDS layout (typical short-read pairs); tier 2: general capacities for the pairs
+    // that overflowed tier 1 (and for everything when the compact layout does not fit LDS).
     int waves_per_simd = 4;
+    size_t lds_budget = 24 * 1024;
     if (const char* e = getenv("PMX_ALIGN_LDS_KB")) lds_budget = (size_t)atoi(e) * 1024;
     if (const char* e = getenv("PMX_ALIGN_WAVES")) waves_per_simd = atoi(e);
+    const bool use_tier1 = !getenv("PMX_ALIGN_NO_TIER1");
     auto kern = waves_per_simd >= 4 ? k_align_reads_w4 : k_align_reads;
+    const int n_segs = paired ? 2 : 1;
+
     AlignArgs A;
-    A.layout = plan_layout((int)rs->max_len, paired ? 2 : 1, al->opt, lds_budget);
-    const size_t lds_bytes = PMX_ALIGN_WORK_BYTES + A.layout.fast_bytes + 16;
-    if (lds_bytes > 160 * 1024) return fail(PMX_ERR_UNSUPPORTED, "reads too long for the LDS work arena");
-    if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    int waves_per_cu = (int)std::min<size_t>((size_t)(waves_per_simd >= 4 ? 16 : 8), (size_t)(160 * 1024) / lds_bytes);
-    if (waves_per_cu < 1) waves_per_cu = 1;
-    int64_t grid = (int64_t)ctx->n_cu * waves_per_cu;
-    if (grid > n_items) grid = n_items;
-    A.slow_stride = (A.layout.slow_bytes + 255) & ~(size_t)255;
-    al->slow.ensure(A.slow_stride * (size_t)grid);
-    A.slow_base = al->slow.p;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
-    A.n_items = n_items;
     A.paired = paired ? 1 : 0;
     A.revcomp_mate2 = revcomp_mate2 ? 1 : 0;
     A.opt = al->opt;
@@ -147,8 +142,45 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.cigars = al->cigars.p;
     A.cigar_cap = al->cigar_cap;
     A.cigar_used = al->cigar_used.p;
+
+    auto launch = [&](const Layout& L, int64_t n_work, const uint32_t* worklist, uint32_t* retry_list, DevBuf<uint8_t>& slab) {
+        const size_t lds_bytes = PMX_ALIGN_WORK_BYTES + L.fast_bytes + 16;
+        if (lds_bytes > 160 * 1024) throw std::runtime_error("reads too long for the LDS work arena");
+        if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        int waves_per_cu = (int)std::min<size_t>((size_t)(waves_per_simd >= 4 ? 16 : 8), (size_t)(160 * 1024) / lds_bytes);
+        if (waves_per_cu < 1) waves_per_cu = 1;
+        int64_t grid = (int64_t)ctx->n_cu * waves_per_cu;
+        if (grid > n_work) grid = n_work;
+        A.layout = L;
+        A.slow_stride = (L.slow_bytes + 255) & ~(size_t)255;
+        slab.ensure(A.slow_stride * (size_t)grid);
+        A.slow_base = slab.p;
+        A.n_items = n_work;
+        A.worklist = worklist;
+        A.retry_list = retry_list;
+        A.retry_count = al->retry_count.p;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, ctx->stream, A);
+        PMX_HIP(hipGetLastError());
+    };
+
+    al->retry_count.ensure(1);
+    PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, sizeof(unsigned long long), ctx->stream));
+    const Layout general = plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget);
+    const Layout compact = plan_layout_compact((int)rs->max_len, n_segs, al->opt);
+    const bool tier1_fits = use_tier1 && al->opt.is_sr_like && PMX_ALIGN_WORK_BYTES + compact.fast_bytes + 16 <= 40 * 1024;
     timer_begin(ctx, "align");
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, ctx->stream, A);
+    if (tier1_fits) {
+        al->retry_list.ensure((size_t)n_items);
+        launch(compact, n_items, nullptr, al->retry_list.p, al->slow);
+        unsigned long long n_retry = 0;
+        PMX_HIP(hipMemcpyAsync(&n_retry, al->retry_count.p, sizeof(n_retry), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        al->last_retry = (int64_t)n_retry;
+        if (n_retry > 0) launch(general, (int64_t)n_retry, al->retry_list.p, nullptr, al->slow2);
+    } else {
+        al->last_retry = 0;
+        launch(general, n_items, nullptr, nullptr, al->slow2);
+    }
     timer_end(ctx, "align", 1);
     PMX_HIP(hipGetLastError());
     return PMX_OK;
