@@ -26,6 +26,7 @@ PMX_HD void gen_simple_mat(int8_t* mat, int8_t a, int8_t b, int8_t sc_ambi) {   
 }
 
 PMX_HD void ref_getseq(const RefIndex& ri, int st, int en, uint8_t* out) {   // mm_idx_getseq (index.c:152-162)
+    PMX_LDS(out);
     if (en > ri.len) en = ri.len;
     const int lane = lane_id();
     for (int i = st + lane; i < en; i += PMX_W) out[i - st] = ri.seq[i];
@@ -33,6 +34,7 @@ PMX_HD void ref_getseq(const RefIndex& ri, int st, int en, uint8_t* out) {   // 
 }
 
 PMX_HD void seq_rev(int len, uint8_t* seq) {   // mm_seq_rev
+    PMX_LDS(seq);
     wave_sync();
     if (lane_id() == 0 || PMX_W == 1)
         for (int i = 0; i < len >> 1; ++i) { const uint8_t t = seq[i]; seq[i] = seq[len - 1 - i]; seq[len - 1 - i] = t; }
@@ -54,9 +56,10 @@ PMX_HD void reg_alloc_p(Work& W, Reg& r) {
 
 // mm_append_cigar (align.c:291-314)
 PMX_HD void append_cigar(Work& W, Reg& r, int n_cigar, const uint32_t* cigar) {
+    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(cigar);
     if (n_cigar == 0) return;
     reg_alloc_p(W, r);
-    uint32_t* c = reg_cigar(W, r);
+    uint32_t* c = reg_cigar(W, r); PMX_LDS(c);
     if ((int)r.n_cigar + n_cigar > W.caps.max_cigar) { W.status |= PMX_ST_OVERFLOW; return; }
     if (r.n_cigar > 0 && (c[r.n_cigar - 1] & 0xf) == (cigar[0] & 0xf)) {
         c[r.n_cigar - 1] += cigar[0] >> 4 << 4;
@@ -86,6 +89,7 @@ PMX_HD void align_pair(Work& W, const Opt& o, int qlen, const uint8_t* qseq, int
 // update_max_zdrop + mm_test_zdrop (align.c:32-89).  The inversion probe (ksw_ll_i16) is reported as
 // unsupported instead of evaluated; it only decides between return codes 1 and 2.
 PMX_HDN int test_zdrop(Work& W, const Opt& o, const uint8_t* qseq, const uint8_t* tseq, int n_cigar, const uint32_t* cigar) {
+    PMX_LDS(&W); PMX_LDS(qseq); PMX_LDS(tseq); PMX_LDS(cigar);
     int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
     int pos[2][2] = {{-1, -1}, {-1, -1}};
     auto upd = [&](int32_t sc, int ii, int jj) {
@@ -124,7 +128,8 @@ PMX_HDN int test_zdrop(Work& W, const Opt& o, const uint8_t* qseq, const uint8_t
 
 // mm_fix_cigar (align.c:91-167)
 PMX_HDN void fix_cigar(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq, int* qshift, int* tshift) {
-    uint32_t* cg = reg_cigar(W, r);
+    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq); PMX_LDS(tseq);
+    uint32_t* cg = reg_cigar(W, r); PMX_LDS(cg);
     int32_t toff = 0, qoff = 0, to_shrink = 0;
     *qshift = *tshift = 0;
     if (r.n_cigar <= 1) return;
@@ -193,13 +198,14 @@ PMX_HDN void fix_cigar(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq
 
 // mm_update_extra (align.c:240-289), log_gap = 1, is_eqx = 0
 PMX_HDN void update_extra(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq, const int8_t* mat, int8_t q, int8_t e) {
+    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq); PMX_LDS(tseq);
     if (!r.has_p) return;
     int32_t qshift, tshift, toff = 0, qoff = 0;
     double s = 0.0, mx = 0.0;
     fix_cigar(W, r, qseq, tseq, &qshift, &tshift);
     qseq += qshift;
     tseq += tshift;
-    const uint32_t* cg = reg_cigar(W, r);
+    const uint32_t* cg = reg_cigar(W, r); PMX_LDS(cg);
     r.blen = r.mlen = 0;
     for (uint32_t k = 0; k < r.n_cigar; ++k) {
         const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
@@ -252,6 +258,7 @@ PMX_HD int anchor_gap(const A128* a, int i) {   // query advance minus reference
 
 // collect_long_gaps + mm_filter_bad_seeds (align.c:374-427).  K[] lives in W.aux64 (as int32).
 PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, const A128* a, int min_gap, int32_t* K, int cap) {
+    PMX_LDS(&W); PMX_LDS(a); PMX_LDS(K);
     int n = 0;
     for (int i = 1; i < cnt1; ++i) {
         const int gap = anchor_gap(a + as1, i);
@@ -268,7 +275,8 @@ PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, const A128* a, int min_
 }
 
 PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, A128* a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
-    int32_t* K = (int32_t*)W.f;   // chain DP arrays are idle during alignment
+    PMX_LDS(&W); PMX_LDS(a);
+    int32_t* K = (int32_t*)W.f; PMX_LDS(K);   // chain DP arrays are idle during alignment
     const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
     if (n == 0) return;
     int mx = 0, max_st = -1, max_en = -1;
@@ -302,7 +310,8 @@ PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, A128* a, int min_gap, 
 
 // mm_filter_bad_seeds_alt (align.c:429-462)
 PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, A128* a, int min_gap, int max_ext) {
-    int32_t* K = (int32_t*)W.f;
+    PMX_LDS(&W); PMX_LDS(a);
+    int32_t* K = (int32_t*)W.f; PMX_LDS(K);
     const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
     if (n == 0) return;
     for (int k = 0; k < n;) {
@@ -337,6 +346,7 @@ PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, A128* a, int min_g
 
 // mm_fix_bad_ends (align.c:464-502)
 PMX_HDN void fix_bad_ends(const Reg& r, const A128* a, int bw, int min_match, int32_t* as, int32_t* cnt) {
+    PMX_LDS(&r); PMX_LDS(a);
     *as = r.as;
     *cnt = r.cnt;
     if (r.cnt < 3) return;
@@ -370,9 +380,11 @@ PMX_HDN void fix_bad_ends(const Reg& r, const A128* a, int bw, int min_match, in
 
 // mm_align1 (align.c:575-833)
 PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t* const qseq0[2], Reg& r, Reg& r2, int n_a, A128* a, Ez& ez) {
+    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(a);   // r2 and ez are caller-locals (private)
+    uint32_t* cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
     const int32_t rev = (int32_t)(a[r.as].x >> 63);
     int32_t as1, cnt1;
-    uint8_t* tseq = W.tseq;
+    uint8_t* tseq = W.tseq; PMX_LDS(tseq);
     int32_t l, dropped = 0, rs0, re0, qs0, qe0;
     int32_t rs, re, qs, qe;
     int32_t rs1, qs1, re1, qe1;
@@ -447,14 +459,14 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t
     if (re0 - rs0 > W.caps.max_tlen || re0 <= rs0) { W.status |= PMX_ST_OVERFLOW; return; }
 
     if (qs > 0 && rs > 0) {   // left extension (align.c:704-722)
-        uint8_t* qseq = &qseq0[rev][qs0];
+        uint8_t* qseq = &qseq0[rev][qs0]; PMX_LDS(qseq);
         ref_getseq(ri, rs0, rs, tseq);
         seq_rev(qs - qs0, qseq);
         seq_rev(rs - rs0, tseq);
         align_pair(W, o, qs - qs0, qseq, rs - rs0, tseq, bw, o.end_bonus, r.split_inv ? o.zdrop_inv : o.zdrop,
                    PMX_EZ_EXTZ_ONLY | PMX_EZ_RIGHT | PMX_EZ_REV_CIGAR, ez);
         if (ez.n_cigar > 0) {
-            append_cigar(W, r, ez.n_cigar, W.cig_tmp);
+            append_cigar(W, r, ez.n_cigar, cig_tmp);
             r.dp_score += (int32_t)ez.max;
         }
         rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
@@ -470,12 +482,12 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t
         if (i == cnt1 - 1 || (a[as1 + i].y & PMX_SEED_LONG_JOIN) || (qe - qs >= o.min_ksw_len && re - rs >= o.min_ksw_len)) {
             int bw1 = bw_long;
             if (a[as1 + i].y & PMX_SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
-            uint8_t* qseq = &qseq0[rev][qs];
+            uint8_t* qseq = &qseq0[rev][qs]; PMX_LDS(qseq);
             ref_getseq(ri, rs, re, tseq);
             align_pair(W, o, qe - qs, qseq, re - rs, tseq, bw1, -1, o.zdrop, PMX_EZ_APPROX_MAX, ez);   // first pass: approximate Z-drop
-            const int zdrop_code = test_zdrop(W, o, qseq, tseq, ez.n_cigar, W.cig_tmp);
+            const int zdrop_code = test_zdrop(W, o, qseq, tseq, ez.n_cigar, cig_tmp);
             if (zdrop_code != 0) align_pair(W, o, qe - qs, qseq, re - rs, tseq, bw1, -1, zdrop_code == 2 ? o.zdrop_inv : o.zdrop, 0, ez);
-            if (ez.n_cigar > 0) append_cigar(W, r, ez.n_cigar, W.cig_tmp);
+            if (ez.n_cigar > 0) append_cigar(W, r, ez.n_cigar, cig_tmp);
             if (ez.zdropped) {   // truncated by Z-drop
                 int32_t j;
                 reg_alloc_p(W, r);
@@ -497,11 +509,11 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t
     }
 
     if (!dropped && qe < qe0 && re < re0) {   // right extension (align.c:799-815)
-        uint8_t* qseq = &qseq0[rev][qe];
+        uint8_t* qseq = &qseq0[rev][qe]; PMX_LDS(qseq);
         ref_getseq(ri, re, re0, tseq);
         align_pair(W, o, qe0 - qe, qseq, re0 - re, tseq, bw, o.end_bonus, o.zdrop, PMX_EZ_EXTZ_ONLY, ez);
         if (ez.n_cigar > 0) {
-            append_cigar(W, r, ez.n_cigar, W.cig_tmp);
+            append_cigar(W, r, ez.n_cigar, cig_tmp);
             r.dp_score += (int32_t)ez.max;
         }
         re1 = re + (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
@@ -514,13 +526,14 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t
 
     if (r.has_p) {
         ref_getseq(ri, rs1, re1, tseq);
-        const uint8_t* qseq = &qseq0[r.rev][qs1];
+        const uint8_t* qseq = &qseq0[r.rev][qs1]; PMX_LDS(qseq);
         update_extra(W, r, qseq, tseq, o.mat, (int8_t)o.q, (int8_t)o.e);
     }
 }
 
 // mm_event_identity / mm_recal_max_dp / mm_update_dp_max (align.c:918-965); only reached for qlen >= rank_min_len
 PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac, int a, int b) {
+    PMX_LDS(&W); PMX_LDS(regs);
     int32_t mx = -1, max2 = -1, max_i = -1;
     if (n_regs < 2) return;
     for (int i = 0; i < n_regs; ++i) {
@@ -533,7 +546,7 @@ PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac,
     if (regs[max_i].qe - regs[max_i].qs < (double)qlen * frac) return;
     if (max2 < (double)mx * frac) return;
     auto count_gaps = [&](const Reg& r, int32_t* n_gap, int32_t* n_gapo) {
-        const uint32_t* cg = reg_cigar(W, r);
+        const uint32_t* cg = reg_cigar(W, r); PMX_LDS(cg);
         *n_gap = *n_gapo = 0;
         for (uint32_t i = 0; i < r.n_cigar; ++i) {
             const int32_t op = cg[i] & 0xf, len = cg[i] >> 4;
@@ -549,7 +562,7 @@ PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac,
     for (int i = 0; i < n_regs; ++i) {
         Reg& r = regs[i];
         if (!r.has_p) continue;
-        const uint32_t* cg = reg_cigar(W, r);
+        const uint32_t* cg = reg_cigar(W, r); PMX_LDS(cg);
         int32_t ng = 0, ngo = 0;
         double gap_cost = 0.0;
         for (uint32_t q = 0; q < r.n_cigar; ++q) {
@@ -567,6 +580,7 @@ PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac,
 
 // mm_align_skeleton (align.c:967-1027) for one segment; then the tail of align_regs (map.c:225-234)
 PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int* n_regs_, Reg* regs, A128* a) {
+    PMX_LDS(&W); PMX_LDS(n_regs_); PMX_LDS(regs); PMX_LDS(a);
     const int qlen = W.qlen[seg];
     int n_regs = *n_regs_;
     uint8_t* qseq0[2] = {W.qseq[seg][0], W.qseq[seg][1]};

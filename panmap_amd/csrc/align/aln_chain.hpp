@@ -49,6 +49,7 @@ PMX_HD int32_t chain_score(const A128 ai, const A128 aj, int32_t max_dist_x, int
 
 // mg_chain_bk_end (lchain.c:9-25)
 PMX_HD int64_t chain_bk_end(int32_t max_drop, const A128* z, const int32_t* f, const int32_t* p, int32_t* t, int64_t k) {
+    PMX_LDS(z); PMX_LDS(f); PMX_LDS(p); PMX_LDS(t);
     int64_t i = (int64_t)z[k].y, end_i = -1, max_i = i;
     int32_t max_s = 0;
     if (i < 0 || t[i] != 0) return i;
@@ -81,9 +82,11 @@ __device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_d
     const int lane = lane_id();
     const int bw = o.bw, max_skip = o.max_chain_skip;
     const float gp = o.chn_pen_gap, sp = o.chn_pen_skip;
+    PMX_LDS(&W);
+    A128* a_ = W.a; PMX_LDS(a_);
     A128 mine;
-    mine.x = lane < n ? W.a[lane].x : 0;
-    mine.y = lane < n ? W.a[lane].y : 0;
+    mine.x = lane < n ? a_[lane].x : 0;
+    mine.y = lane < n ? a_[lane].y : 0;
     int32_t fj = 0, pj = -1, vj = 0;
     int st = 0, max_ii = -1;
     for (int i = 0; i < n; ++i) {
@@ -148,7 +151,11 @@ __device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_d
             if ((int64_t)(ai.x - xm) <= (int64_t)max_dist_x && fm < max_f) max_ii = i;
         }
     }
-    if (lane < n) { W.f[lane] = fj; W.p[lane] = pj; W.v[lane] = vj; }
+    {
+        int32_t *f_ = W.f, *p_ = W.p, *v_ = W.v;
+        PMX_LDS(f_); PMX_LDS(p_); PMX_LDS(v_);
+        if (lane < n) { f_[lane] = fj; p_[lane] = pj; v_[lane] = vj; }
+    }
     wave_sync();
 }
 #endif
@@ -160,10 +167,12 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     const int64_t n = W.n_a;
     const int bw = o.bw, max_skip = o.max_chain_skip, max_iter = o.max_chain_iter, min_cnt = o.min_cnt, min_sc = o.min_chain_score;
     const float chn_pen_gap = o.chn_pen_gap, chn_pen_skip = o.chn_pen_skip;
+    PMX_LDS(&W);
     W.n_u = 0;
     if (n == 0) return;
-    A128* a = W.a;
+    A128* a = W.a; PMX_LDS(a);
     int32_t *f = W.f, *t = W.t, *v = W.v, *p = W.p;
+    PMX_LDS(f); PMX_LDS(t); PMX_LDS(v); PMX_LDS(p);
     const int32_t max_drop = bw;
     if (max_dist_x < bw) max_dist_x = bw;
     if (max_dist_y < bw) max_dist_y = bw;
@@ -214,7 +223,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     }
 
     // ---- backtrack (lchain.c:27-76)
-    A128* z = W.z;
+    A128* z = W.z; PMX_LDS(z);
     int64_t n_z = 0;
     for (int64_t i = 0; i < n; ++i)
         if (f[i] >= min_sc) { z[n_z].x = (uint64_t)(int64_t)f[i]; z[n_z].y = (uint64_t)i; ++n_z; }
@@ -223,7 +232,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     for (int64_t i = 0; i < n; ++i) t[i] = 0;
     int64_t n_v = 0;
     int32_t n_u = 0;
-    uint64_t* u = W.u;
+    uint64_t* u = W.u; PMX_LDS(u);
     // (the reference runs this loop twice, first only to size u[]; one pass gives the same u[] and v[])
     for (int64_t k = n_z - 1; k >= 0; --k) {
         if (t[z[k].y] == 0) {
@@ -241,14 +250,14 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     if (n_u == 0) { W.n_a = 0; W.n_u = 0; return; }
 
     // ---- compact (lchain.c:78-111): chains reversed into ascending order, then sorted by target position
-    A128* b = W.a2;
+    A128* b = W.a2; PMX_LDS(b);
     int64_t kk = 0;
     for (int32_t i = 0; i < n_u; ++i) {
         const int64_t k0 = kk;
         const int32_t ni = (int32_t)u[i];
         for (int32_t j = 0; j < ni; ++j) b[kk++] = a[v[k0 + (ni - j - 1)]];
     }
-    A128* wv = W.z;   // z[] is free again
+    A128* wv = W.z; PMX_LDS(wv);   // z[] is free again
     kk = 0;
     for (int32_t i = 0; i < n_u; ++i) {
         wv[i].x = b[kk].x;
@@ -256,7 +265,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
         kk += (int32_t)u[i];
     }
     radix_sort_128x(wv, wv + n_u, &W.status);
-    uint64_t* u2 = W.u2;
+    uint64_t* u2 = W.u2; PMX_LDS(u2);
     kk = 0;
     for (int32_t i = 0; i < n_u; ++i) {
         const int32_t j = (int32_t)wv[i].y, nn = (int32_t)u[j];

@@ -10,6 +10,7 @@ namespace aln {
 
 // mm_cal_fuzzy_len + mm_reg_set_coor (hit.c:8-40); is_qstrand == 0
 PMX_HD void reg_set_coor(Reg& r, int32_t qlen, const A128* a) {
+    PMX_LDS(a);
     const int32_t k = r.as, q_span = (int32_t)(a[k].y >> 32 & 0xff);
     r.rev = (uint8_t)(a[k].x >> 63);
     r.rid = (int32_t)(a[k].x << 1 >> 33);
@@ -49,9 +50,10 @@ PMX_HD void reg_clear(Reg& r) { memset(&r, 0, sizeof(Reg)); }
 
 // mm_gen_regs (hit.c:54-94): chains sorted by (score, hash) descending
 PMX_HDN int gen_regs(Work& W, uint32_t hash, int qlen, int n_u, const uint64_t* u, const A128* a, Reg* r) {
+    PMX_LDS(&W); PMX_LDS(u); PMX_LDS(a); PMX_LDS(r);
     if (n_u == 0) return 0;
     if (n_u > W.caps.max_reg) { W.status |= PMX_ST_OVERFLOW; n_u = W.caps.max_reg; }
-    A128* z = W.aux128;
+    A128* z = W.aux128; PMX_LDS(z);
     int k = 0;
     for (int i = 0; i < n_u; ++i) {
         const uint32_t h = (uint32_t)hit_hash64((hit_hash64(a[k].x) + hit_hash64(a[k].y)) ^ hash);
@@ -78,6 +80,7 @@ PMX_HDN int gen_regs(Work& W, uint32_t hash, int qlen, int n_u, const uint64_t* 
 
 // mm_split_reg (hit.c:112-130)
 PMX_HD void split_reg(Reg& r, Reg& r2, int n, int qlen, const A128* a) {
+    PMX_LDS(&r); PMX_LDS(a);   // r2 is a caller-local (private) object
     if (n <= 0 || n >= r.cnt) return;
     r2 = r;
     r2.id = -1;
@@ -99,9 +102,10 @@ PMX_HD void split_reg(Reg& r, Reg& r2, int n, int qlen, const A128* a) {
 
 // mm_set_parent (hit.c:132-191); hard_mask_level == 0, no ALT contigs
 PMX_HDN void set_parent(Work& W, float mask_level, int mask_len, int n, Reg* r, int sub_diff) {
+    PMX_LDS(&W); PMX_LDS(r);
     if (n <= 0) return;
     for (int i = 0; i < n; ++i) r[i].id = i;
-    uint64_t* cov = W.aux64;
+    uint64_t* cov = W.aux64; PMX_LDS(cov);
     int32_t* w = (int32_t*)(W.aux64 + W.caps.max_reg);
     w[0] = 0;
     r[0].parent = 0;
@@ -156,6 +160,7 @@ PMX_HDN void set_parent(Work& W, float mask_level, int mask_len, int n, Reg* r, 
 
 // mm_set_sam_pri (hit.c:227-237)
 PMX_HD int set_sam_pri(int n, Reg* r) {
+    PMX_LDS(r);
     int n_pri = 0;
     for (int i = 0; i < n; ++i) {
         if (r[i].id == r[i].parent) { ++n_pri; r[i].sam_pri = (n_pri == 1); }
@@ -166,11 +171,12 @@ PMX_HD int set_sam_pri(int n, Reg* r) {
 
 // mm_sync_regs (hit.c:239-262)
 PMX_HDN void sync_regs(Work& W, int n_regs, Reg* regs) {
+    PMX_LDS(&W); PMX_LDS(regs);
     if (n_regs <= 0) return;
     int max_id = -1;
     for (int i = 0; i < n_regs; ++i) max_id = max_id > regs[i].id ? max_id : regs[i].id;
     const int n_tmp = max_id + 1;
-    int32_t* tmp = (int32_t*)W.aux64;
+    int32_t* tmp = (int32_t*)W.aux64; PMX_LDS(tmp);
     if (n_tmp > W.caps.max_reg * 4) { W.status |= PMX_ST_OVERFLOW; return; }
     for (int i = 0; i < n_tmp; ++i) tmp[i] = -1;
     for (int i = 0; i < n_regs; ++i)
@@ -187,6 +193,7 @@ PMX_HDN void sync_regs(Work& W, int n_regs, Reg* regs) {
 
 // mm_select_sub (hit.c:264-285)
 PMX_HDN void select_sub(Work& W, float pri_ratio, int min_diff, int best_n, int check_strand, int min_strand_sc, int* n_, Reg* r) {
+    PMX_LDS(&W); PMX_LDS(r);
     if (pri_ratio > 0.0f && *n_ > 0) {
         const int n = *n_;
         int k = 0, n_2nd = 0;
@@ -213,6 +220,7 @@ PMX_HDN void select_sub(Work& W, float pri_ratio, int min_diff, int best_n, int 
 // mm_select_sub_multi (pe.c:6-43)
 PMX_HDN void select_sub_multi(Work& W, float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int n_segs,
                              const int* qlens, int* n_, Reg* r) {
+    PMX_LDS(&W); PMX_LDS(r); PMX_LDS(qlens); PMX_LDS(n_);
     if (pri_ratio > 0.0f && *n_ > 0) {
         const int n = *n_;
         int k = 0, n_2nd = 0;
@@ -247,6 +255,7 @@ PMX_HDN void select_sub_multi(Work& W, float pri_ratio, float pri1, float pri2, 
 
 // mm_filter_strand_retained (hit.c:287-299)
 PMX_HD int filter_strand_retained(int n_regs, Reg* r) {
+    PMX_LDS(r);
     int k = 0;
     for (int i = 0; i < n_regs; ++i) {
         const int p = r[i].parent;
@@ -260,6 +269,7 @@ PMX_HD int filter_strand_retained(int n_regs, Reg* r) {
 
 // mm_filter_regs (hit.c:301-322)
 PMX_HD void filter_regs(const Opt& o, int qlen, int* n_regs, Reg* regs) {
+    PMX_LDS(regs);
     int k = 0;
     for (int i = 0; i < *n_regs; ++i) {
         Reg& r = regs[i];
@@ -280,10 +290,11 @@ PMX_HD void filter_regs(const Opt& o, int qlen, int* n_regs, Reg* regs) {
 
 // mm_hit_sort (hit.c:193-225): by (dp_max or score, hash) descending; cnt==0 regions squeezed out
 PMX_HDN void hit_sort(Work& W, int* n_regs, Reg* r) {
+    PMX_LDS(&W); PMX_LDS(r);
     const int n = *n_regs;
     if (n <= 1) return;
-    A128* aux = W.aux128;
-    Reg* t = W.reg_tmp;
+    A128* aux = W.aux128; PMX_LDS(aux);
+    Reg* t = W.reg_tmp; PMX_LDS(t);
     int n_aux = 0;
     for (int i = 0; i < n; ++i) {
         if (r[i].inv || r[i].cnt > 0) {
@@ -300,7 +311,8 @@ PMX_HDN void hit_sort(Work& W, int* n_regs, Reg* r) {
 
 // mm_squeeze_a (hit.c:324-343)
 PMX_HDN int squeeze_a(Work& W, int n_regs, Reg* regs, A128* a) {
-    uint64_t* aux = W.aux64;
+    PMX_LDS(&W); PMX_LDS(regs); PMX_LDS(a);
+    uint64_t* aux = W.aux64; PMX_LDS(aux);
     int as = 0;
     for (int i = 0; i < n_regs; ++i) aux[i] = (uint64_t)(uint32_t)regs[i].as << 32 | (uint32_t)i;
     radix_sort_64(aux, aux + n_regs, &W.status);
@@ -317,13 +329,17 @@ PMX_HDN int squeeze_a(Work& W, int n_regs, Reg* regs, A128* a) {
 
 // mm_seg_gen (hit.c:345-400) for n_segs == 2: split fragment chains into per-mate chains
 PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, const Reg* regs0, const A128* a) {
+    PMX_LDS(&W); PMX_LDS(qlens); PMX_LDS(regs0); PMX_LDS(a);
+    uint64_t* su[2] = {W.seg_u[0], W.seg_u[1]};
+    PMX_LDS(su[0]); PMX_LDS(su[1]);
+    A128* sa0 = W.seg_a[0]; PMX_LDS(sa0);
     const int n_segs = W.n_segs;
     int acc_qlen[3];
     acc_qlen[0] = 0;
     for (int s = 1; s < n_segs; ++s) acc_qlen[s] = acc_qlen[s - 1] + qlens[s - 1];
     const int qlen_sum = acc_qlen[n_segs - 1] + qlens[n_segs - 1];
     for (int s = 0; s < n_segs; ++s) {
-        for (int i = 0; i < n_regs0; ++i) W.seg_u[s][i] = (uint64_t)(uint32_t)regs0[i].score << 32;
+        for (int i = 0; i < n_regs0; ++i) (s ? su[1] : su[0])[i] = (uint64_t)(uint32_t)regs0[i].score << 32;
         W.seg_n_a[s] = 0;
     }
     int n_seg_anchors[2] = {0, 0};
@@ -331,15 +347,16 @@ PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, cons
         const Reg& r = regs0[i];
         for (int j = 0; j < r.cnt; ++j) {
             const int sid = (int)((a[r.as + j].y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
-            ++W.seg_u[sid][i];
+            ++(sid ? su[1] : su[0])[i];
             ++n_seg_anchors[sid & 1];
         }
     }
-    W.seg_a[1] = W.seg_a[0] + n_seg_anchors[0];   // both mates' anchor lists share one max_anchor block
+    W.seg_a[1] = sa0 + n_seg_anchors[0];   // both mates' anchor lists share one max_anchor block
+    A128* sa1 = sa0 + n_seg_anchors[0];
     for (int s = 0; s < n_segs; ++s) {
         int n_u = 0;
         for (int i = 0; i < n_regs0; ++i)
-            if ((int32_t)W.seg_u[s][i] != 0) W.seg_u[s][n_u++] = W.seg_u[s][i];
+            if ((int32_t)(s ? su[1] : su[0])[i] != 0) { (s ? su[1] : su[0])[n_u] = (s ? su[1] : su[0])[i]; ++n_u; }
         W.seg_n_u[s] = n_u;
     }
     for (int i = 0; i < n_regs0; ++i) {
@@ -348,20 +365,22 @@ PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, cons
             A128 a1 = a[r.as + j];
             const int sid = (int)((a1.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
             a1.y -= (uint64_t)(int64_t)(a1.x >> 63 ? qlen_sum - (qlens[sid] + acc_qlen[sid]) : acc_qlen[sid]);
-            W.seg_a[sid][W.seg_n_a[sid]++] = a1;
+            (sid ? sa1 : sa0)[W.seg_n_a[sid]++] = a1;
         }
     }
     for (int s = 0; s < n_segs; ++s) {
-        W.n_regs[s] = gen_regs(W, hash, qlens[s], W.seg_n_u[s], W.seg_u[s], W.seg_a[s], W.regs[s]);
+        Reg* rs_ = W.regs[s]; PMX_LDS(rs_);
+        W.n_regs[s] = gen_regs(W, hash, qlens[s], W.seg_n_u[s], s ? su[1] : su[0], s ? sa1 : sa0, rs_);
         for (int i = 0; i < W.n_regs[s]; ++i) {
-            W.regs[s][i].seg_split = 1;
-            W.regs[s][i].seg_id = (uint8_t)s;
+            rs_[i].seg_split = 1;
+            rs_[i].seg_id = (uint8_t)s;
         }
     }
 }
 
 // mm_set_mapq (hit.c:421-466) without inversion hits; logf values come from host-computed tables
 PMX_HDN void set_mapq(const RefIndex& ri, int n_regs, Reg* regs, int min_chain_sc, int match_sc, int rep_len, int is_sr, uint32_t* status) {
+    PMX_LDS(regs); PMX_LDS(status);
     const float q_coef = 40.0f;
     int64_t sum_sc = 0;
     if (n_regs == 0) return;

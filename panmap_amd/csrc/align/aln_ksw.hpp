@@ -48,8 +48,9 @@ PMX_HD void push_cigar(uint32_t* cigar, int* n_cigar, int cap, uint32_t op, int 
 // ksw_backtrack (ksw2.h:127-162) with is_rot = 1, min_intron_len = 0
 PMX_HDN void ksw_backtrack(Work& W, int is_rev, const uint8_t* p, const int32_t* off, const int32_t* off_end, int n_col, int i0, int j0,
                           int* n_cigar_) {
+    PMX_LDS(&W); PMX_LDS(off); PMX_LDS(off_end);   // p = traceback matrix: global memory
     int n_cigar = 0, i = i0, j = j0, state = 0;
-    uint32_t* cigar = W.cig_tmp;
+    uint32_t* cigar = W.cig_tmp; PMX_LDS(cigar);
     const int cap = W.caps.max_cigar;
     while (i >= 0 && j >= 0) {
         int force_state = -1;
@@ -88,6 +89,7 @@ inline int64_t wave_max_i64(int64_t v) { return v; }
 // ksw_extd2_sse.  query/target hold nt4 codes; with_cigar always on.  Results in ez and W.cig_tmp.
 PMX_HDN void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
                       int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+    PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
     const int lane = lane_id();
     const int approx_max = !!(flag & PMX_EZ_APPROX_MAX);
     ez_reset(ez);
@@ -119,6 +121,8 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const 
     uint8_t *sf = W.sf, *qr = W.qr;
     int32_t* H = W.H;
     int32_t *off = W.off, *off_end = W.off_end;
+    PMX_LDS(u); PMX_LDS(v); PMX_LDS(x); PMX_LDS(y); PMX_LDS(x2); PMX_LDS(y2); PMX_LDS(s);
+    PMX_LDS(sf); PMX_LDS(qr); PMX_LDS(H); PMX_LDS(off); PMX_LDS(off_end);
     uint8_t* p = W.tb;
     const int T16 = tlen_ * 16;
     // initial fill (ksw2_extd2_sse.c:107-126): every lane takes a stride
@@ -334,6 +338,7 @@ inline int wave_sum_i32(int v) { return v; }
 // Number of positions i < n where a[i] != b[i] or a base is ambiguous (code >= 4), saturating early is
 // not needed: n <= a few hundred.  Lane-parallel.
 PMX_HD int count_diff(const uint8_t* a, const uint8_t* b, int n) {
+    PMX_LDS(a); PMX_LDS(b);
     int d = 0;
     for (int i = lane_id(); i < n; i += PMX_W) d += (a[i] != b[i] || a[i] > 3) ? 1 : 0;
     return wave_sum_i32(d);
@@ -350,6 +355,8 @@ PMX_HD int count_diff(const uint8_t* a, const uint8_t* b, int n) {
 // Everything else runs the DP.
 PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
                            int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+    PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
+    uint32_t* cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
     const int a = mat[0], b = -mat[1];
     const int g1 = q + e, g2 = q2 + e2;
     const int gmin = g1 < g2 ? g1 : g2, gmax = g1 > g2 ? g1 : g2;
@@ -363,7 +370,7 @@ PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, co
                 ez.mqe_t = qlen - 1;
                 if (tlen == qlen) { ez.mte = qlen * a; ez.mte_q = qlen - 1; }
                 ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
-                W.cig_tmp[0] = (uint32_t)qlen << 4;
+                cig_tmp[0] = (uint32_t)qlen << 4;
                 ez.n_cigar = 1;
                 wave_sync();
                 return;
@@ -377,7 +384,7 @@ PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, co
             if (amb == 0 && d * (a + b) < a + 2 * gmin) {
                 ez_reset(ez);
                 ez.score = qlen * a - d * (a + b);
-                W.cig_tmp[0] = (uint32_t)qlen << 4;
+                cig_tmp[0] = (uint32_t)qlen << 4;
                 ez.n_cigar = 1;
                 wave_sync();
                 return;

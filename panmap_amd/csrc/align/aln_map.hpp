@@ -23,13 +23,15 @@ PMX_HD uint32_t wang_hash(uint32_t key) {   // __ac_Wang_hash (khash.h)
 
 // mm_set_pe_thru (pe.c:45-64)
 PMX_HD void set_pe_thru(const int* qlens, const int* n_regs, Reg* const* regs) {
+    Reg* r0 = regs[0]; Reg* r1 = regs[1];
+    PMX_LDS(r0); PMX_LDS(r1); PMX_LDS(qlens); PMX_LDS(n_regs);
     int n_pri[2] = {0, 0}, pri[2] = {-1, -1};
     for (int s = 0; s < 2; ++s)
         for (int i = 0; i < n_regs[s]; ++i)
-            if (regs[s][i].id == regs[s][i].parent) { ++n_pri[s]; pri[s] = i; }
+            if ((s ? r1 : r0)[i].id == (s ? r1 : r0)[i].parent) { ++n_pri[s]; pri[s] = i; }
     if (n_pri[0] == 1 && n_pri[1] == 1) {
-        Reg& p = regs[0][pri[0]];
-        Reg& q = regs[1][pri[1]];
+        Reg& p = r0[pri[0]];
+        Reg& q = r1[pri[1]];
         const int d1 = p.rs - q.rs < 0 ? q.rs - p.rs : p.rs - q.rs, d2 = p.re - q.re < 0 ? q.re - p.re : p.re - q.re;
         if (p.rid == q.rid && p.rev == q.rev && d1 < 3 && d2 < 3 &&
             ((p.qs == 0 && qlens[1] - q.qe == 0) || (q.qs == 0 && qlens[0] - p.qe == 0)))
@@ -41,17 +43,21 @@ PMX_HD void set_pe_thru(const int* qlens, const int* n_regs, Reg* const* regs) {
 PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, const int* qlens, int* n_regs,
                       Reg* const* regs) {
     // pair array (s, rev, key, reg index) kept as parallel arrays in the idle chaining scratch
+    PMX_LDS(&W); PMX_LDS(qlens); PMX_LDS(n_regs);
+    Reg* r0_ = regs[0]; Reg* r1_ = regs[1];
+    PMX_LDS(r0_); PMX_LDS(r1_);
+#define PMX_REGS(s) ((s) ? r1_ : r0_)
     const int cap = W.caps.max_reg * 2;
-    uint64_t* key = W.aux64;                       // [cap]
+    uint64_t* key = W.aux64; PMX_LDS(key);         // [cap]
     int32_t* ps = (int32_t*)(W.aux64 + cap);       // [cap] segment
     int32_t* pi = ps + cap;                        // [cap] index in regs[s]
-    uint64_t* sc = (uint64_t*)W.z;                 // pair scores
+    uint64_t* sc = (uint64_t*)W.z; PMX_LDS(sc);    // pair scores
     const int sc_cap = W.caps.max_anchor * 2;      // z holds max_anchor A128
     int n = 0, segs = 0, dp_thres = 0;
     for (int s = 0; s < 2; ++s) {
         int mx = 0;
         for (int i = 0; i < n_regs[s]; ++i) {
-            const Reg& r = regs[s][i];
+            const Reg& r = PMX_REGS(s)[i];
             ps[n] = s;
             pi[n] = i;
             key[n] = (uint64_t)(uint32_t)r.rid << 32 | (uint32_t)(r.rs << 1) | (uint32_t)(s ^ r.rev);
@@ -78,14 +84,14 @@ PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonu
     int max_idx[2] = {-1, -1}, last[2] = {-1, -1};
     int n_sc = 0;
     for (int i = 0; i < n; ++i) {
-        const Reg& ri_ = regs[ps[i]][pi[i]];
+        const Reg& ri_ = PMX_REGS(ps[i])[pi[i]];
         const int rev_i = ri_.rev;
         if (key[i] & 1) {   // reverse first read or forward second read
             if (last[rev_i] < 0) continue;
-            const Reg* q = &regs[ps[last[rev_i]]][pi[last[rev_i]]];
+            const Reg* q = &PMX_REGS(ps[last[rev_i]])[pi[last[rev_i]]];
             if (ri_.rid != q->rid || ri_.rs - q->re > max_gap_ref) continue;
             for (int j = last[rev_i]; j >= 0; --j) {
-                q = &regs[ps[j]][pi[j]];
+                q = &PMX_REGS(ps[j])[pi[j]];
                 if (q->rev != rev_i || ps[j] == ps[i]) continue;
                 if (ri_.rid != q->rid || ri_.rs - q->re > max_gap_ref) break;
                 if (ri_.dp_max + q->dp_max < dp_thres) continue;
@@ -100,19 +106,19 @@ PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonu
     if (n_sc > 0 && mx > 0) {
         int n_sub = 0, mapq_pe;
         Reg* r[2];
-        r[0] = &regs[0][pi[max_idx[0]]];
-        r[1] = &regs[1][pi[max_idx[1]]];
+        r[0] = &r0_[pi[max_idx[0]]];
+        r[1] = &r1_[pi[max_idx[1]]];
         r[0]->proper_frag = r[1]->proper_frag = 1;
         for (int s = 0; s < 2; ++s) {
             if (r[s]->id != r[s]->parent) {   // lift to primary and update parent
-                Reg* p = &regs[s][r[s]->parent];
+                Reg* p = &PMX_REGS(s)[r[s]->parent];
                 const int pid = p->id;
                 for (int i = 0; i < n_regs[s]; ++i)
-                    if (regs[s][i].parent == pid) regs[s][i].parent = r[s]->id;
+                    if (PMX_REGS(s)[i].parent == pid) PMX_REGS(s)[i].parent = r[s]->id;
                 p->mapq = 0;
             }
             if (!r[s]->sam_pri) {
-                for (int i = 0; i < n_regs[s]; ++i) regs[s][i].sam_pri = 0;
+                for (int i = 0; i < n_regs[s]; ++i) PMX_REGS(s)[i].sam_pri = 0;
                 r[s]->sam_pri = 1;
             }
         }
@@ -135,10 +141,15 @@ PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonu
         }
     }
     set_pe_thru(qlens, n_regs, regs);
+#undef PMX_REGS
 }
 
 // mm_map_frag (map.c:236-390) for n_segs in {1,2}.  Regions end up in W.regs[s] / W.n_regs[s].
 PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
+    PMX_LDS(&W);
+    A128* a_ = W.a; PMX_LDS(a_);
+    uint64_t* u_ = W.u; PMX_LDS(u_);
+    Reg* regs0_ = W.regs0; PMX_LDS(regs0_);
     const int n_segs = W.n_segs;
     int qlen_sum = 0;
     for (int i = 0; i < n_segs; ++i) { qlen_sum += W.qlen[i]; W.n_regs[i] = 0; }
@@ -165,18 +176,18 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     chain_dp(W, o, max_chain_gap_ref, max_chain_gap_qry, n_segs);
 
     if (o.bw_long > o.bw && n_segs == 1 && W.n_u > 1) {   // long-join re-chaining (map.c:296-305): RMQ chaining not restated yet
-        const int32_t st = (int32_t)W.a[0].y, en = (int32_t)W.a[(int32_t)W.u[0] - 1].y;
+        const int32_t st = (int32_t)a_[0].y, en = (int32_t)a_[(int32_t)u_[0] - 1].y;
         if (qlen_sum - (en - st) > o.rmq_rescue_size || en - st > qlen_sum * o.rmq_rescue_ratio) W.status |= PMX_ST_UNSUPPORTED;
     } else if (o.max_occ > o.mid_occ && W.rep_len > 0) {   // re-chain with a higher occurrence cap (map.c:306-330)
         int rechain = 0;
         if (W.n_u > 0) {
             int n_chained_segs = 1, mx = 0, max_i = -1, max_off = -1, off = 0;
             for (int i = 0; i < W.n_u; ++i) {
-                if (mx < (int)(W.u[i] >> 32)) { mx = (int)(W.u[i] >> 32); max_i = i; max_off = off; }
-                off += (int32_t)W.u[i];
+                if (mx < (int)(u_[i] >> 32)) { mx = (int)(u_[i] >> 32); max_i = i; max_off = off; }
+                off += (int32_t)u_[i];
             }
-            for (int i = 1; i < (int32_t)W.u[max_i]; ++i)
-                if ((W.a[max_off + i].y & PMX_SEED_SEG_MASK) != (W.a[max_off + i - 1].y & PMX_SEED_SEG_MASK)) ++n_chained_segs;
+            for (int i = 1; i < (int32_t)u_[max_i]; ++i)
+                if ((a_[max_off + i].y & PMX_SEED_SEG_MASK) != (a_[max_off + i - 1].y & PMX_SEED_SEG_MASK)) ++n_chained_segs;
             if (n_chained_segs < n_segs) rechain = 1;
         } else rechain = 1;
         if (rechain) {
@@ -186,25 +197,26 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     }
     W.frag_gap = max_chain_gap_ref;
 
-    W.n_regs0 = gen_regs(W, hash, qlen_sum, W.n_u, W.u, W.a, W.regs0);
+    W.n_regs0 = gen_regs(W, hash, qlen_sum, W.n_u, u_, a_, regs0_);
 
     // chain_post (map.c:206-213)
-    set_parent(W, o.mask_level, o.mask_len, W.n_regs0, W.regs0, o.a * 2 + o.b);
-    if (n_segs <= 1) select_sub(W, o.pri_ratio, o.k * 2, o.best_n, 1, (int)(o.max_gap * 0.8), &W.n_regs0, W.regs0);
-    else select_sub_multi(W, o.pri_ratio, 0.2f, 0.7f, max_chain_gap_ref, o.k * 2, o.best_n, n_segs, W.qlen, &W.n_regs0, W.regs0);
+    set_parent(W, o.mask_level, o.mask_len, W.n_regs0, regs0_, o.a * 2 + o.b);
+    if (n_segs <= 1) select_sub(W, o.pri_ratio, o.k * 2, o.best_n, 1, (int)(o.max_gap * 0.8), &W.n_regs0, regs0_);
+    else select_sub_multi(W, o.pri_ratio, 0.2f, 0.7f, max_chain_gap_ref, o.k * 2, o.best_n, n_segs, W.qlen, &W.n_regs0, regs0_);
     // mm_est_err only feeds Reg::div, read by mm_filter_strand_retained for strand_retained hits
     // (single-segment mode only): not evaluated, flagged when it would matter
     if (n_segs == 1)
         for (int i = 0; i < W.n_regs0; ++i)
-            if (W.regs0[i].strand_retained) W.status |= PMX_ST_UNSUPPORTED;
+            if (regs0_[i].strand_retained) W.status |= PMX_ST_UNSUPPORTED;
 
     if (n_segs == 1) {
-        for (int i = 0; i < W.n_regs0; ++i) W.regs[0][i] = W.regs0[i];
+        Reg* rs0 = W.regs[0]; PMX_LDS(rs0);
+        for (int i = 0; i < W.n_regs0; ++i) rs0[i] = regs0_[i];
         W.n_regs[0] = W.n_regs0;
-        align_regs(W, o, ri, 0, &W.n_regs[0], W.regs[0], W.a);
-        set_mapq(ri, W.n_regs[0], W.regs[0], o.min_chain_score, o.a, W.rep_len, 0, &W.status);
+        align_regs(W, o, ri, 0, &W.n_regs[0], rs0, a_);
+        set_mapq(ri, W.n_regs[0], rs0, o.min_chain_score, o.a, W.rep_len, 0, &W.status);
     } else {
-        seg_gen(W, hash, W.qlen, W.n_regs0, W.regs0, W.a);
+        seg_gen(W, hash, W.qlen, W.n_regs0, regs0_, a_);
         for (int s = 0; s < n_segs; ++s) {
             set_parent(W, o.mask_level, o.mask_len, W.n_regs[s], W.regs[s], o.a * 2 + o.b);
             align_regs(W, o, ri, s, &W.n_regs[s], W.regs[s], W.seg_a[s]);

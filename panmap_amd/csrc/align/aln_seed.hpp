@@ -27,13 +27,15 @@ PMX_HDN void sketch_segment(Work& W, const uint8_t* seq, int len, int w, int k, 
     const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
     uint64_t kmer0 = 0, kmer1 = 0;
     int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
-    A128* buf = W.sk_buf;
+    PMX_LDS(&W); PMX_LDS(seq);
+    A128* buf = W.sk_buf; PMX_LDS(buf);
+    A128* mvp = W.mv; PMX_LDS(mvp);
     A128 mn;
     mn.x = mn.y = UINT64_MAX;
     for (int j = 0; j < w; ++j) buf[j].x = buf[j].y = UINT64_MAX;
 #define PMX_MV_PUSH(val)                                              \
     do {                                                              \
-        if (W.n_mv < W.caps.max_mini) W.mv[W.n_mv] = (val);           \
+        if (W.n_mv < W.caps.max_mini) mvp[W.n_mv] = (val);            \
         else W.status |= PMX_ST_OVERFLOW;                             \
         if (W.n_mv < W.caps.max_mini) ++W.n_mv;                       \
     } while (0)
@@ -90,12 +92,14 @@ PMX_HDN void sketch_segment(Work& W, const uint8_t* seq, int len, int w, int k, 
 // collect_minimizers (map.c:59-73): segment s gets rid = s and its positions shifted by the summed
 // lengths of the previous segments.  (sdust masking is off: options.c:23.)
 PMX_HD void collect_minimizers(Work& W, const Opt& o) {
+    PMX_LDS(&W);
+    A128* mvp = W.mv; PMX_LDS(mvp);
     W.n_mv = 0;
     int sum = 0;
     for (int s = 0; s < W.n_segs; ++s) {
         const int n0 = W.n_mv;
         sketch_segment(W, W.qseq[s][0], W.qlen[s], o.w, o.k, (uint32_t)s);
-        for (int j = n0; j < W.n_mv; ++j) W.mv[j].y += (uint64_t)sum << 1;
+        for (int j = n0; j < W.n_mv; ++j) mvp[j].y += (uint64_t)sum << 1;
         sum += W.qlen[s];
     }
 }
@@ -113,6 +117,7 @@ PMX_HD uint32_t index_lookup(const RefIndex& ri, uint64_t minier, uint32_t* off)
 
 // binary heaps exactly as ksort.h:43-59 builds them (ties must break the same way)
 PMX_HD void heap_down_min_x(A128* l, int i, int n) {   // "less" = a.x > b.x  -> min-heap on x (map.c:76)
+    PMX_LDS(l);
     int k = i;
     const A128 tmp = l[i];
     while ((k = (k << 1) + 1) < n) {
@@ -138,6 +143,7 @@ PMX_HD void heap_down_max_u64(uint64_t* l, int i, int n) {   // ks_heapdown_uint
 // mm_seed_select (seed.c:56-96): within a streak of high-occurrence minimizers keep the
 // max_high_occ least frequent ones.
 PMX_HDN void seed_select(int n, Seed* a, int len, int max_occ, int max_max_occ, int dist) {
+    PMX_LDS(a);
     if (n == 0 || n == 1) return;
     int m = 0;
     for (int i = 0; i < n; ++i)
@@ -177,18 +183,23 @@ PMX_HDN void seed_select(int n, Seed* a, int len, int max_occ, int max_max_occ, 
 // mm_collect_matches (seed.c:98-131) + mm_seed_collect_all (:28-52).  The index probes of all
 // minimizers are issued lane-parallel first (one L2 round trip instead of n_mv dependent ones).
 PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
+    PMX_LDS(&W);
+    A128* mv = W.mv; PMX_LDS(mv);
+    A128* hp = W.heap; PMX_LDS(hp);
+    Seed* seeds = W.seeds; PMX_LDS(seeds);
+    uint64_t* mini_pos = W.mini_pos;   // global scratch (only mm_est_err would read it)
     int n_m0 = 0;
     for (int i = lane_id(); i < W.n_mv; i += PMX_W) {
         uint32_t off = 0;
-        const uint32_t t = index_lookup(ri, W.mv[i].x >> 8, &off);
-        W.heap[i].x = off;
-        W.heap[i].y = t;
+        const uint32_t t = index_lookup(ri, mv[i].x >> 8, &off);
+        hp[i].x = off;
+        hp[i].y = t;
     }
     wave_sync();
     for (int i = 0; i < W.n_mv; ++i) {
-        const A128 p = W.mv[i];
-        const uint32_t off = (uint32_t)W.heap[i].x;
-        const uint32_t t = (uint32_t)W.heap[i].y;
+        const A128 p = mv[i];
+        const uint32_t off = (uint32_t)hp[i].x;
+        const uint32_t t = (uint32_t)hp[i].y;
         if (t == 0) continue;
         Seed q;
         q.q_pos = (uint32_t)p.y;
@@ -197,20 +208,20 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
         q.n = t;
         q.seg_id = (uint32_t)(p.y >> 32);
         q.is_tandem = q.flt = 0;
-        if (i > 0 && p.x >> 8 == W.mv[i - 1].x >> 8) q.is_tandem = 1;
-        if (i < W.n_mv - 1 && p.x >> 8 == W.mv[i + 1].x >> 8) q.is_tandem = 1;
-        W.seeds[n_m0++] = q;
+        if (i > 0 && p.x >> 8 == mv[i - 1].x >> 8) q.is_tandem = 1;
+        if (i < W.n_mv - 1 && p.x >> 8 == mv[i + 1].x >> 8) q.is_tandem = 1;
+        seeds[n_m0++] = q;
     }
     wave_sync();
-    if (o.occ_dist > 0 && o.max_max_occ > max_occ) seed_select(n_m0, W.seeds, qlen, max_occ, o.max_max_occ, o.occ_dist);
+    if (o.occ_dist > 0 && o.max_max_occ > max_occ) seed_select(n_m0, seeds, qlen, max_occ, o.max_max_occ, o.occ_dist);
     else
         for (int i = 0; i < n_m0; ++i)
-            if ((int)W.seeds[i].n > max_occ) W.seeds[i].flt = 1;
+            if ((int)seeds[i].n > max_occ) seeds[i].flt = 1;
     int rep_st = 0, rep_en = 0, n_m = 0, rep_len = 0;
     int64_t n_a = 0;
     W.n_mini_pos = 0;
     for (int i = 0; i < n_m0; ++i) {
-        const Seed q = W.seeds[i];
+        const Seed q = seeds[i];
         if (q.flt) {
             const int en = (int)(q.q_pos >> 1) + 1, st = en - (int)q.q_span;
             if (st > rep_en) {
@@ -220,8 +231,8 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
             } else rep_en = en;
         } else {
             n_a += q.n;
-            W.mini_pos[W.n_mini_pos++] = (uint64_t)q.q_span << 32 | q.q_pos >> 1;
-            W.seeds[n_m++] = q;
+            mini_pos[W.n_mini_pos++] = (uint64_t)q.q_span << 32 | q.q_pos >> 1;
+            seeds[n_m++] = q;
         }
     }
     rep_len += rep_en - rep_st;
@@ -239,27 +250,29 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
         W.n_a = 0;
         return;
     }
+    PMX_LDS(&W);
     const int n_m = W.n_seeds;
     const int64_t n_a = W.n_a;
-    A128* heap = W.heap;
-    A128* a = W.a;
+    A128* heap = W.heap; PMX_LDS(heap);
+    A128* a = W.a; PMX_LDS(a);
+    Seed* seeds = W.seeds; PMX_LDS(seeds);
     // stage every occurrence list in idle scratch so the merge never waits on HBM/L2:
     // cache offsets are assigned in seed order, the copies run one seed per lane
-    uint64_t* pc = (uint64_t*)W.seg_a[0];   // the per-mate anchor block (16*max_anchor bytes) is idle until seg_gen
+    uint64_t* pc = (uint64_t*)W.seg_a[0]; PMX_LDS(pc);   // the per-mate anchor block (16*max_anchor bytes) is idle until seg_gen
     {
         uint32_t acc = 0;
-        for (int i = 0; i < n_m; ++i) { const uint32_t n = W.seeds[i].n; W.seeds[i].flt = acc; acc += n; }   // flt is free now: cache offset
+        for (int i = 0; i < n_m; ++i) { const uint32_t n = seeds[i].n; seeds[i].flt = acc; acc += n; }   // flt is free now: cache offset
         wave_sync();
         for (int i = lane_id(); i < n_m; i += PMX_W) {
-            const Seed q = W.seeds[i];
+            const Seed q = seeds[i];
             for (uint32_t j = 0; j < q.n; ++j) pc[q.flt + j] = ri.pos[q.off + j];
         }
         wave_sync();
     }
     int heap_size = 0;
     for (int i = 0; i < n_m; ++i) {
-        if (W.seeds[i].n > 0) {
-            heap[heap_size].x = pc[W.seeds[i].flt];
+        if (seeds[i].n > 0) {
+            heap[heap_size].x = pc[seeds[i].flt];
             heap[heap_size].y = (uint64_t)i << 32;
             ++heap_size;
         }
@@ -267,7 +280,7 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     for (int q = (heap_size >> 1) - 1; q >= 0; --q) heap_down_min_x(heap, q, heap_size);
     int64_t n_for = 0, n_rev = 0;
     while (heap_size > 0) {
-        const Seed q = W.seeds[heap[0].y >> 32];
+        const Seed q = seeds[heap[0].y >> 32];
         const uint64_t r = heap[0].x;
         const int32_t rpos = (int32_t)((uint32_t)r >> 1);
         A128 p;
@@ -286,7 +299,7 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
         }
         if ((uint32_t)heap[0].y < q.n - 1) {
             ++heap[0].y;
-            heap[0].x = pc[W.seeds[heap[0].y >> 32].flt + (uint32_t)heap[0].y];
+            heap[0].x = pc[seeds[heap[0].y >> 32].flt + (uint32_t)heap[0].y];
         } else {
             heap[0] = heap[heap_size - 1];
             --heap_size;

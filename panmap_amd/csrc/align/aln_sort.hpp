@@ -18,6 +18,7 @@ struct KeyU64 {
 
 template <class T, class K>
 PMX_HD void rs_insertsort(T* beg, T* end) {
+
     for (T* i = beg + 1; i < end; ++i) {
         if (K::key(*i) < K::key(*(i - 1))) {
             T *j, tmp = *i;

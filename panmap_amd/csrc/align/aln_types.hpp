@@ -29,6 +29,15 @@ inline int lane_id() { return 0; }
 inline void wave_sync() {}
 #endif
 
+// Tier-1 translation unit (PMX_ALL_LDS): every work array except the traceback matrix is in LDS, and the
+// compiler is told so pointer by pointer -- otherwise generic pointers compile to flat_load/flat_store,
+// whose latency dominated the kernel (measured: ~9k flat ops per pair, 56% of wave cycles waiting).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PMX_ALL_LDS)
+#define PMX_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define PMX_LDS(p) ((void)0)
+#endif
+
 struct A128 {
     uint64_t x, y;
 };

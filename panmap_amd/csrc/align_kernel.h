@@ -34,6 +34,8 @@ struct AlignArgs {
 
 __global__ void k_align_reads(AlignArgs A);
 __global__ void k_align_reads_w4(AlignArgs A);
+__global__ void k_align_reads_t1(AlignArgs A);
+__global__ void k_align_reads_t1_w4(AlignArgs A);
 
 }  // namespace aln
 }  // namespace pmx

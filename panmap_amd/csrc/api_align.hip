@@ -143,10 +143,11 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.cigar_cap = al->cigar_cap;
     A.cigar_used = al->cigar_used.p;
 
-    auto launch = [&](const Layout& L, int64_t n_work, const uint32_t* worklist, uint32_t* retry_list, DevBuf<uint8_t>& slab) {
+    auto kern_t1 = waves_per_simd >= 4 ? k_align_reads_t1_w4 : k_align_reads_t1;
+    auto launch = [&](decltype(kern) kfn, const Layout& L, int64_t n_work, const uint32_t* worklist, uint32_t* retry_list, DevBuf<uint8_t>& slab) {
         const size_t lds_bytes = PMX_ALIGN_WORK_BYTES + L.fast_bytes + 16;
         if (lds_bytes > 160 * 1024) throw std::runtime_error("reads too long for the LDS work arena");
-        if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         int waves_per_cu = (int)std::min<size_t>((size_t)(waves_per_simd >= 4 ? 16 : 8), (size_t)(160 * 1024) / lds_bytes);
         if (waves_per_cu < 1) waves_per_cu = 1;
         int64_t grid = (int64_t)ctx->n_cu * waves_per_cu;
@@ -159,7 +160,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         A.worklist = worklist;
         A.retry_list = retry_list;
         A.retry_count = al->retry_count.p;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_bytes, ctx->stream, A);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64), lds_bytes, ctx->stream, A);
         PMX_HIP(hipGetLastError());
     };
 
@@ -171,15 +172,15 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     timer_begin(ctx, "align");
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
-        launch(compact, n_items, nullptr, al->retry_list.p, al->slow);
+        launch(kern_t1, compact, n_items, nullptr, al->retry_list.p, al->slow);
         unsigned long long n_retry = 0;
         PMX_HIP(hipMemcpyAsync(&n_retry, al->retry_count.p, sizeof(n_retry), hipMemcpyDeviceToHost, ctx->stream));
         PMX_HIP(hipStreamSynchronize(ctx->stream));
         al->last_retry = (int64_t)n_retry;
-        if (n_retry > 0) launch(general, (int64_t)n_retry, al->retry_list.p, nullptr, al->slow2);
+        if (n_retry > 0) launch(kern, general, (int64_t)n_retry, al->retry_list.p, nullptr, al->slow2);
     } else {
         al->last_retry = 0;
-        launch(general, n_items, nullptr, nullptr, al->slow2);
+        launch(kern, general, n_items, nullptr, nullptr, al->slow2);
     }
     timer_end(ctx, "align", 1);
     PMX_HIP(hipGetLastError());

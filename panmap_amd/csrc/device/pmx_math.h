@@ -5,7 +5,11 @@
 
 #if defined(__HIPCC__)
 #define PMX_HD __host__ __device__ __forceinline__
+#if defined(PMX_FULL_INLINE)
+#define PMX_HDN __host__ __device__ __forceinline__   // tier-1 kernel: one flat function so LDS address spaces can be inferred
+#else
 #define PMX_HDN __host__ __device__ __attribute__((noinline)) inline   // big phase functions: own register allocation
+#endif
 #else
 #define PMX_HD inline
 #define PMX_HDN inline
