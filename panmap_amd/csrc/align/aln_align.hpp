@@ -586,6 +586,7 @@ PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int*
     uint8_t* qseq0[2] = {W.qseq[seg][0], W.qseq[seg][1]};
     Ez ez;
     const int n_a = squeeze_a(W, n_regs, regs, a);
+    PMX_STAMP(W, 6);
     for (int i = 0; i < n_regs; ++i) {
         Reg r2;
         reg_clear(r2);
@@ -599,7 +600,9 @@ PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int*
             }
         }
         if (i > 0 && regs[i].split_inv) W.status |= PMX_ST_UNSUPPORTED;   // mm_align1_inv (inversion rescue)
+        if (W.status & PMX_ST_NEED_WAVE) return;   // thread-per-pair kernel: this pair is re-run by the wave kernel
     }
+    PMX_STAMP(W, 7);
     filter_regs(o, qlen, &n_regs, regs);
     if (qlen >= o.rank_min_len) {
         update_dp_max(W, qlen, n_regs, regs, o.rank_frac, o.a, o.b);
@@ -611,6 +614,7 @@ PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int*
     select_sub(W, o.pri_ratio, o.k * 2, o.best_n, 0, (int)(o.max_gap * 0.8), &n_regs, regs);
     set_sam_pri(n_regs, regs);
     *n_regs_ = n_regs;
+    PMX_STAMP(W, 8);
 }
 
 }  // namespace aln

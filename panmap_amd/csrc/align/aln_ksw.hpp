@@ -83,7 +83,7 @@ __device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
     return v;
 }
 #else
-inline int64_t wave_max_i64(int64_t v) { return v; }
+PMX_HD int64_t wave_max_i64(int64_t v) { return v; }
 #endif
 
 // ksw_extd2_sse.  query/target hold nt4 codes; with_cigar always on.  Results in ez and W.cig_tmp.
@@ -332,7 +332,7 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 #else
-inline int wave_sum_i32(int v) { return v; }
+PMX_HD int wave_sum_i32(int v) { return v; }
 #endif
 
 // Number of positions i < n where a[i] != b[i] or a base is ambiguous (code >= 4), saturating early is
@@ -353,7 +353,7 @@ PMX_HD int count_diff(const uint8_t* a, const uint8_t* b, int n) {
 //      alignment scores strictly less than the gap-free one for every prefix pair on the main diagonal,
 //      so the traceback is all-diagonal -> score = len*a - d*(a+b), CIGAR = len M.
 // Everything else runs the DP.
-PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+PMX_HD bool ksw_shortcut(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
                            int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
     uint32_t* cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
@@ -373,7 +373,7 @@ PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, co
                 cig_tmp[0] = (uint32_t)qlen << 4;
                 ez.n_cigar = 1;
                 wave_sync();
-                return;
+                return true;
             }
         } else if (!(flag & PMX_EZ_EXTZ_ONLY) && (flag & PMX_EZ_APPROX_MAX) && !(flag & PMX_EZ_APPROX_DROP) && qlen == tlen) {
             const int d = count_diff(query, target, qlen);
@@ -387,11 +387,24 @@ PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, co
                 cig_tmp[0] = (uint32_t)qlen << 4;
                 ez.n_cigar = 1;
                 wave_sync();
-                return;
+                return true;
             }
         }
     }
+    return false;
+}
+
+PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+                           int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+    if (ksw_shortcut(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) return;
+#if defined(PMX_THREAD_PER_PAIR) && defined(__HIP_DEVICE_COMPILE__)
+    // the thread-per-pair kernel never runs a DP: hand the pair to the wave-per-pair kernel
+    W.status |= PMX_ST_NEED_WAVE;
+    ez_reset(ez);
+    ez.zdropped = 1;
+#else
     ksw_extd2(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+#endif
 }
 
 }  // namespace aln

@@ -162,8 +162,10 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     hash = wang_hash(hash);
 
     collect_minimizers(W, o);
+    PMX_STAMP(W, 1);
     if (o.q_occ_frac > 0.0f && W.n_mv > o.mid_occ && o.mid_occ > 0) W.status |= PMX_ST_UNSUPPORTED;   // mm_seed_mz_flt (seed.c:5-26)
     collect_seed_hits_heap(W, o, ri, qlen_sum, o.mid_occ);
+    PMX_STAMP(W, 2);
 
     const int max_chain_gap_qry = o.max_gap;   // not MM_F_SR
     int max_chain_gap_ref;
@@ -174,6 +176,7 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     } else max_chain_gap_ref = o.max_gap;
 
     chain_dp(W, o, max_chain_gap_ref, max_chain_gap_qry, n_segs);
+    PMX_STAMP(W, 3);
 
     if (o.bw_long > o.bw && n_segs == 1 && W.n_u > 1) {   // long-join re-chaining (map.c:296-305): RMQ chaining not restated yet
         const int32_t st = (int32_t)a_[0].y, en = (int32_t)a_[(int32_t)u_[0] - 1].y;
@@ -214,17 +217,23 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
         for (int i = 0; i < W.n_regs0; ++i) rs0[i] = regs0_[i];
         W.n_regs[0] = W.n_regs0;
         align_regs(W, o, ri, 0, &W.n_regs[0], rs0, a_);
+        if (W.status & PMX_ST_NEED_WAVE) return;
         set_mapq(ri, W.n_regs[0], rs0, o.min_chain_score, o.a, W.rep_len, 0, &W.status);
     } else {
+        PMX_STAMP(W, 4);
         seg_gen(W, hash, W.qlen, W.n_regs0, regs0_, a_);
+        PMX_STAMP(W, 5);
         for (int s = 0; s < n_segs; ++s) {
             set_parent(W, o.mask_level, o.mask_len, W.n_regs[s], W.regs[s], o.a * 2 + o.b);
             align_regs(W, o, ri, s, &W.n_regs[s], W.regs[s], W.seg_a[s]);
+            if (W.status & PMX_ST_NEED_WAVE) return;
             set_mapq(ri, W.n_regs[s], W.regs[s], o.min_chain_score, o.a, W.rep_len, 0, &W.status);
+            PMX_STAMP(W, 9);
         }
         if (n_segs == 2 && o.pe_ori >= 0) {
             Reg* rr[2] = {W.regs[0], W.regs[1]};
             pair_hits(W, ri, max_chain_gap_ref, o.pe_bonus, o.a * 2 + o.b, o.a, W.qlen, W.n_regs, rr);
+            PMX_STAMP(W, 10);
         }
     }
 }

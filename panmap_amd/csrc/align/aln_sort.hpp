@@ -66,10 +66,37 @@ PMX_HDN void rs_sort_level(T* beg, T* end, int s, T** stk_b, T** stk_e, int* stk
     }
 }
 
+#if PMX_W > 1
+// n <= 64: one element per lane, rank = number of elements that precede it in a STABLE ascending order.
+// The reference's insertion sort is stable, so the result is identical; the n^2/4 dependent LDS moves of
+// the insertion sort become n scalar broadcasts.
+template <class T, class K>
+__device__ __forceinline__ void wave_rank_sort(T* beg, int n) {
+    const int lane = lane_id();
+    T val;
+    uint64_t key = 0;
+    if (lane < n) { val = beg[lane]; key = K::key(val); }
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)klo, j), jh = (uint32_t)__builtin_amdgcn_readlane((int)khi, j);
+        const uint64_t kj = (uint64_t)jh << 32 | jl;
+        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+    }
+    wave_sync();
+    if (lane < n) beg[rank] = val;
+    wave_sync();
+}
+#endif
+
 template <class T, class K>
 PMX_HDN void radix_sort(T* beg, T* end, uint32_t* status) {
     if (end - beg <= 64) {
+#if PMX_W > 1
+        if (end - beg > 1) wave_rank_sort<T, K>(beg, (int)(end - beg));
+#else
         rs_insertsort<T, K>(beg, end);
+#endif
         return;
     }
     T* stk_b[64];

@@ -12,7 +12,9 @@
 
 #include "../device/pmx_math.h"
 
-#if defined(__HIP_DEVICE_COMPILE__)
+// PMX_W = lanes that cooperate on ONE read pair: 64 in the wave-per-pair kernels, 1 on the host and in the
+// thread-per-pair kernel (PMX_THREAD_PER_PAIR: every lane runs the whole pipeline for its own pair).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PMX_THREAD_PER_PAIR)
 #define PMX_W 64
 #else
 #define PMX_W 1
@@ -21,12 +23,12 @@
 namespace pmx {
 namespace aln {
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if PMX_W > 1
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }   // one wave per workgroup
 #else
-inline int lane_id() { return 0; }
-inline void wave_sync() {}
+PMX_HD int lane_id() { return 0; }
+PMX_HD void wave_sync() {}
 #endif
 
 // Tier-1 translation unit (PMX_ALL_LDS): every work array except the traceback matrix is in LDS, and the
@@ -36,6 +38,19 @@ inline void wave_sync() {}
 #define PMX_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
 #else
 #define PMX_LDS(p) ((void)0)
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PMX_THREAD_PER_PAIR)
+#define PMX_STAMP(W, k)                                                              \
+    do {                                                                            \
+        if ((W).prof) {                                                             \
+            const unsigned long long t_ = (unsigned long long)clock64();            \
+            (W).prof_acc[k] += t_ - (W).prof_t;                                     \
+            (W).prof_t = t_;                                                        \
+        }                                                                           \
+    } while (0)
+#else
+#define PMX_STAMP(W, k) ((void)0)
 #endif
 
 struct A128 {
@@ -134,6 +149,7 @@ struct Ez {             // ksw_extz_t (ksw2.h:27-36)
 // status bits reported per record
 #define PMX_ST_OVERFLOW 0x1
 #define PMX_ST_UNSUPPORTED 0x2
+#define PMX_ST_NEED_WAVE 0x4   // thread-per-pair kernel: this pair needs a real DP -> wave-per-pair kernel
 
 // Capacities of the per-wave work memory (chosen by the host from the read-length regime).
 struct Caps {
@@ -197,6 +213,10 @@ struct Work {
     int rep_len;
     int frag_gap;
     uint64_t tmp64;        // lane-0 -> wave broadcast slot
+    // optional phase profile (diagnostic runs only: AlignArgs::prof != NULL)
+    unsigned long long* prof;
+    unsigned long long prof_t;
+    unsigned long long prof_acc[16];
 };
 
 }  // namespace aln

@@ -2,7 +2,7 @@
 #pragma once
 #include "align/aln_host.hpp"
 
-#define PMX_ALIGN_WORK_BYTES 1024   // LDS bytes reserved for the Work descriptor
+#define PMX_ALIGN_WORK_BYTES 1280   // LDS bytes reserved for the Work descriptor
 
 namespace pmx {
 namespace aln {
@@ -17,6 +17,7 @@ struct AlignArgs {
     const uint32_t* worklist;   // tier 2: item ids to (re)process; NULL = 0..n_items-1
     uint32_t* retry_list;       // tier 1: items whose capacities overflowed (NULL in tier 2)
     unsigned long long* retry_count;
+    unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
     int paired;
     int revcomp_mate2;
     // reference + options
@@ -36,6 +37,7 @@ __global__ void k_align_reads(AlignArgs A);
 __global__ void k_align_reads_w4(AlignArgs A);
 __global__ void k_align_reads_t1(AlignArgs A);
 __global__ void k_align_reads_t1_w4(AlignArgs A);
+__global__ void k_align_reads_tpp(AlignArgs A);
 
 }  // namespace aln
 }  // namespace pmx

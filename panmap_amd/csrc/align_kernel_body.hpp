@@ -26,6 +26,8 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
         __syncthreads();
         bind_work(W, A.layout, fast, slow);
         W.n_segs = n_segs;
+        W.prof = A.prof;
+        if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 16; ++k) W.prof_acc[k] = 0; }
         bool too_long = false;
         for (int s = 0; s < n_segs; ++s) {
             const int64_t r = A.paired ? 2 * item + s : item;
@@ -54,6 +56,7 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
                 }
             }
             __syncthreads();
+            PMX_STAMP(W, 0);
             map_frag(W, A.opt, A.ri);
             __syncthreads();
         } else {
@@ -95,6 +98,11 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
                 }
             }
             if (lane == 0) A.records[r] = rec;
+        }
+        if (A.prof) {
+            PMX_STAMP(W, 11);
+            __syncthreads();
+            if (lane < 16) atomicAdd(&A.prof[lane], W.prof_acc[lane]);
         }
     }
 }

@@ -1,0 +1,99 @@
+// ALIGN stage, tier-0 kernel for gfx950: THREAD per read pair.  The per-pair bookkeeping of minimap2
+// (sketch, seed lookup, chaining, region logic, CIGAR clean-up, mapq, pairing) is scalar, branchy code: run
+// redundantly on 64 lanes it wastes the machine (measured: ~130k wave-instructions and 1.6M cycles per
+// pair); run as 64 independent pairs per wave it is ordinary SIMT.  This kernel executes the very same
+// sources as the host unit-test build (PMX_W = 1) and never runs a DP: pairs whose extensions are not
+// covered by the proved shortcuts (ksw_shortcut) or that exceed a work-buffer capacity are appended to a
+// retry list and re-run by the wave-per-pair kernels.  Per-thread work arrays live in a private HBM slab.
+#define PMX_THREAD_PER_PAIR 1
+#include <hip/hip_runtime.h>
+
+#include "align/aln_host.hpp"
+#include "align_kernel.h"
+
+namespace pmx {
+namespace aln {
+
+__global__ void __launch_bounds__(64)
+k_align_reads_tpp(AlignArgs A) {
+    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t n_threads = (int64_t)gridDim.x * 64;
+    uint8_t* slab = A.slow_base + (size_t)tid * A.slow_stride;
+    const size_t fast_sz = (A.layout.fast_bytes + 63) & ~(size_t)63;
+    const int n_segs = A.paired ? 2 : 1;
+
+    for (int64_t it = tid; it < A.n_items; it += n_threads) {
+        const int64_t item = A.worklist ? (int64_t)A.worklist[it] : it;
+        Work W;
+        bind_work(W, A.layout, slab, slab + fast_sz);
+        W.n_segs = n_segs;
+        W.prof = nullptr;
+        bool too_long = false;
+        for (int s = 0; s < n_segs; ++s) {
+            const int64_t r = A.paired ? 2 * item + s : item;
+            const int64_t len = A.off[r + 1] - A.off[r];
+            if (len > A.layout.caps.max_qlen) too_long = true;
+            W.qlen[s] = (int)len;
+        }
+        if (!too_long) {
+            for (int s = 0; s < n_segs; ++s) {
+                const int64_t r = A.paired ? 2 * item + s : item;
+                const int len = W.qlen[s];
+                const uint64_t* rw = A.words + A.woff[r];
+                const uint32_t* ra = A.amb + A.woff[r];
+                uint8_t* fwd = W.qseq[s][0];
+                uint8_t* rev = W.qseq[s][1];
+                const bool rc = A.revcomp_mate2 && s == 1;
+                uint64_t cw = 0;
+                uint32_t ca = 0;
+                for (int i = 0; i < len; ++i) {
+                    if ((i & 31) == 0) { cw = rw[i >> 5]; ca = ra[i >> 5]; }
+                    const uint32_t code = (uint32_t)cw & 3u, am = ca & 1u;
+                    cw >>= 2; ca >>= 1;
+                    const uint8_t c = am ? (code == 3 ? 3 : 4) : (uint8_t)code;
+                    const uint8_t cc = c < 4 ? (uint8_t)(3 - c) : (uint8_t)4;
+                    if (!rc) { fwd[i] = c; rev[len - 1 - i] = cc; }
+                    else { fwd[len - 1 - i] = cc; rev[i] = c; }
+                }
+            }
+            map_frag(W, A.opt, A.ri);
+        } else {
+            W.status |= PMX_ST_OVERFLOW;
+        }
+        if (W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) {
+            A.retry_list[atomicAdd(A.retry_count, 1ULL)] = (uint32_t)item;
+            continue;
+        }
+        const bool mapped = frag_is_mapped(W, A.paired);
+        for (int s = 0; s < n_segs; ++s) {
+            const int64_t r = A.paired ? 2 * item + s : item;
+            AlnRecord rec;
+            memset(&rec, 0, sizeof(rec));
+            rec.flags = (uint16_t)(W.status & 3u);
+            if (mapped) {
+                rec.mapped = 1;
+                const Reg& g = W.regs[s][0];
+                if (g.has_p) {
+                    rec.flags |= PMX_REC_HAS_ALN;
+                    rec.rs = g.rs; rec.re = g.re; rec.qs = g.qs; rec.qe = g.qe;
+                    rec.mapq = g.mapq; rec.rev = g.rev; rec.proper_frag = g.proper_frag;
+                    rec.n_cigar = (uint16_t)g.n_cigar;
+                    rec.score = g.dp_max;
+                    const uint64_t coff = atomicAdd(A.cigar_used, (unsigned long long)g.n_cigar);
+                    rec.cigar_off = (uint32_t)coff;
+                    if (coff + g.n_cigar <= A.cigar_cap) {
+                        const uint32_t* cg = reg_cigar(W, g);
+                        for (uint32_t i = 0; i < g.n_cigar; ++i) A.cigars[coff + i] = cg[i];
+                    } else {
+                        rec.flags |= PMX_REC_OVERFLOW;
+                        rec.n_cigar = 0;
+                    }
+                }
+            }
+            A.records[r] = rec;
+        }
+    }
+}
+
+}  // namespace aln
+}  // namespace pmx

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -29,10 +30,12 @@ struct pmx_aligner {
     DevBuf<AlnRecord> records;
     DevBuf<uint32_t> cigars;
     DevBuf<unsigned long long> cigar_used;
-    DevBuf<uint8_t> slow, slow2;
+    DevBuf<uint8_t> slow, slow2, slab0;
+    DevBuf<uint32_t> retry_list2;
     DevBuf<uint32_t> retry_list;
     DevBuf<unsigned long long> retry_count;
-    int64_t last_retry = 0;
+    int64_t last_retry = 0, last_tpp_retry = 0;
+    DevBuf<unsigned long long> prof;
     int64_t n_records = 0;
     uint64_t cigar_cap = 0;
     double last_occupancy = 0;
@@ -142,6 +145,12 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.cigars = al->cigars.p;
     A.cigar_cap = al->cigar_cap;
     A.cigar_used = al->cigar_used.p;
+    A.prof = nullptr;
+    if (getenv("PMX_ALIGN_PROF")) {
+        al->prof.ensure(16);
+        PMX_HIP(hipMemsetAsync(al->prof.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        A.prof = al->prof.p;
+    }
 
     auto kern_t1 = waves_per_simd >= 4 ? k_align_reads_t1_w4 : k_align_reads_t1;
     auto launch = [&](decltype(kern) kfn, const Layout& L, int64_t n_work, const uint32_t* worklist, uint32_t* retry_list, DevBuf<uint8_t>& slab) {
@@ -169,20 +178,61 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     const Layout general = plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget);
     const Layout compact = plan_layout_compact((int)rs->max_len, n_segs, al->opt);
     const bool tier1_fits = use_tier1 && al->opt.is_sr_like && PMX_ALIGN_WORK_BYTES + compact.fast_bytes + 16 <= 40 * 1024;
-    timer_begin(ctx, "align");
-    if (tier1_fits) {
-        al->retry_list.ensure((size_t)n_items);
-        launch(kern_t1, compact, n_items, nullptr, al->retry_list.p, al->slow);
+    const bool use_tier0 = tier1_fits && !getenv("PMX_ALIGN_NO_TPP");
+    auto read_retry = [&]() -> int64_t {
         unsigned long long n_retry = 0;
         PMX_HIP(hipMemcpyAsync(&n_retry, al->retry_count.p, sizeof(n_retry), hipMemcpyDeviceToHost, ctx->stream));
         PMX_HIP(hipStreamSynchronize(ctx->stream));
-        al->last_retry = (int64_t)n_retry;
-        if (n_retry > 0) launch(kern, general, (int64_t)n_retry, al->retry_list.p, nullptr, al->slow2);
+        PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, sizeof(unsigned long long), ctx->stream));
+        return (int64_t)n_retry;
+    };
+    timer_begin(ctx, "align");
+    if (tier1_fits) {
+        al->retry_list.ensure((size_t)n_items);
+        al->retry_list2.ensure((size_t)n_items);
+        int64_t n_t1 = n_items;
+        const uint32_t* t1_list = nullptr;
+        al->last_tpp_retry = 0;
+        if (use_tier0) {   // tier 0: thread per pair, no DP
+            int tpp_waves = 8;
+            if (const char* e = getenv("PMX_ALIGN_TPP_WAVES")) tpp_waves = atoi(e);
+            int64_t grid = (int64_t)ctx->n_cu * tpp_waves;
+            if (grid * 64 > n_items) grid = (n_items + 63) / 64;
+            A.layout = compact;
+            A.slow_stride = ((compact.fast_bytes + 63) & ~(size_t)63) + ((compact.slow_bytes - compact.tb_cap + 255) & ~(size_t)255);
+            al->slab0.ensure(A.slow_stride * (size_t)grid * 64);
+            A.slow_base = al->slab0.p;
+            A.n_items = n_items;
+            A.worklist = nullptr;
+            A.retry_list = al->retry_list2.p;
+            A.retry_count = al->retry_count.p;
+            hipLaunchKernelGGL(k_align_reads_tpp, dim3((unsigned)grid), dim3(64), 0, ctx->stream, A);
+            PMX_HIP(hipGetLastError());
+            n_t1 = read_retry();
+            t1_list = al->retry_list2.p;
+            al->last_tpp_retry = n_t1;
+        }
+        int64_t n_retry = 0;
+        if (n_t1 > 0) {
+            launch(kern_t1, compact, n_t1, t1_list, al->retry_list.p, al->slow);
+            n_retry = read_retry();
+        }
+        al->last_retry = n_retry;
+        if (n_retry > 0) launch(kern, general, n_retry, al->retry_list.p, nullptr, al->slow2);
     } else {
         al->last_retry = 0;
         launch(kern, general, n_items, nullptr, nullptr, al->slow2);
     }
     timer_end(ctx, "align", 1);
+    if (A.prof) {
+        unsigned long long h[16];
+        PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        static const char* names[16] = {"decode", "sketch", "seed+heap", "chain", "gen_regs+post", "seg_gen", "squeeze", "align1(all regs)", "filter/sort/parent", "mapq", "pair", "output", "", "", "", ""};
+        fprintf(stderr, "[pmx align phase cycles per item]");
+        for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.0f", names[k], (double)h[k] / (double)n_items);
+        fprintf(stderr, " tpp_retry=%lld retry=%lld\n", (long long)al->last_tpp_retry, (long long)al->last_retry);
+    }
     PMX_HIP(hipGetLastError());
     return PMX_OK;
     PMX_CATCH
