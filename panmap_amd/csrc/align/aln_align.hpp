@@ -600,7 +600,7 @@ PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int*
             }
         }
         if (i > 0 && regs[i].split_inv) W.status |= PMX_ST_UNSUPPORTED;   // mm_align1_inv (inversion rescue)
-        if (W.status & PMX_ST_NEED_WAVE) return;   // thread-per-pair kernel: this pair is re-run by the wave kernel
+        if (W.status & PMX_ST_ABORT) return;   // thread-per-pair kernel: this pair is re-run by the wave kernel
     }
     PMX_STAMP(W, 7);
     filter_regs(o, qlen, &n_regs, regs);

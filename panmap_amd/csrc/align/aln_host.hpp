@@ -351,6 +351,8 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow) {
 #undef PMX_AT
     W.status = 0;
     W.cig_next = 0;
+    W.dp_req_base = nullptr; W.dp_res = nullptr; W.dp_slot_ctr = nullptr;
+    W.dp_slot = -1; W.dp_slot_cap = 0; W.dp_n_cached = 0; W.dp_calls = 0;
 }
 
 // fixed-size output record (== pmx_aln_record in include/panmap_amd.h)

@@ -397,9 +397,37 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, const uint8_t* query, int tlen, cons
 PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
                            int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     if (ksw_shortcut(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) return;
-#if defined(PMX_THREAD_PER_PAIR) && defined(__HIP_DEVICE_COMPILE__)
-    // the thread-per-pair kernel never runs a DP: hand the pair to the wave-per-pair kernel
-    W.status |= PMX_ST_NEED_WAVE;
+#if defined(PMX_THREAD_PER_PAIR) && (defined(__HIP_DEVICE_COMPILE__) || defined(PMX_HOSTSIM_TPP))
+    // the thread-per-pair kernel never runs a DP itself: serve it from the pair's result list, or post
+    // it as a request (first unserved call only) and abort this pass
+    const uint32_t key = (uint32_t)qlen | (uint32_t)tlen << 10 | (uint32_t)(flag & 0xff) << 20;
+    if (!(W.status & PMX_ST_ABORT)) {
+        const int c = W.dp_calls++;
+        if (c < W.dp_n_cached) {
+            const DpRes& R = W.dp_res[c];
+            if (R.key == key) {
+                ez = R.ez;
+                for (int i = 0; i < ez.n_cigar; ++i) W.cig_tmp[i] = R.cigar[i];
+                return;
+            }
+            W.status |= PMX_ST_NEED_WAVE;
+        } else if (W.dp_req_base && c < PMX_DP_MAX_CALLS && ((qlen + 15) & ~15) + tlen <= PMX_DP_SEQ_BYTES) {
+            if (W.dp_slot < 0 && W.dp_slot_ctr) {
+                const unsigned long long sl = atomicAdd(W.dp_slot_ctr, 1ULL);
+                if (sl < W.dp_slot_cap) W.dp_slot = (int64_t)sl;
+            }
+            if (W.dp_slot >= 0) {
+                DpReq* rq = reinterpret_cast<DpReq*>(W.dp_req_base + (size_t)W.dp_slot * sizeof(DpReq));
+                rq->qlen = qlen; rq->tlen = tlen; rq->w = w; rq->zdrop = zdrop; rq->end_bonus = end_bonus; rq->flag = flag;
+                rq->call = (uint32_t)c; rq->key = key;
+                uint8_t* sq = rq->seq;
+                for (int i = 0; i < qlen; ++i) sq[i] = query[i];
+                sq += (qlen + 15) & ~15;
+                for (int i = 0; i < tlen; ++i) sq[i] = target[i];
+                W.status |= PMX_ST_NEED_DP;
+            } else W.status |= PMX_ST_NEED_WAVE;
+        } else W.status |= PMX_ST_NEED_WAVE;
+    }
     ez_reset(ez);
     ez.zdropped = 1;
 #else

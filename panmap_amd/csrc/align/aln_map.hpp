@@ -217,7 +217,7 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
         for (int i = 0; i < W.n_regs0; ++i) rs0[i] = regs0_[i];
         W.n_regs[0] = W.n_regs0;
         align_regs(W, o, ri, 0, &W.n_regs[0], rs0, a_);
-        if (W.status & PMX_ST_NEED_WAVE) return;
+        if (W.status & PMX_ST_ABORT) return;
         set_mapq(ri, W.n_regs[0], rs0, o.min_chain_score, o.a, W.rep_len, 0, &W.status);
     } else {
         PMX_STAMP(W, 4);
@@ -226,7 +226,7 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
         for (int s = 0; s < n_segs; ++s) {
             set_parent(W, o.mask_level, o.mask_len, W.n_regs[s], W.regs[s], o.a * 2 + o.b);
             align_regs(W, o, ri, s, &W.n_regs[s], W.regs[s], W.seg_a[s]);
-            if (W.status & PMX_ST_NEED_WAVE) return;
+            if (W.status & PMX_ST_ABORT) return;
             set_mapq(ri, W.n_regs[s], W.regs[s], o.min_chain_score, o.a, W.rep_len, 0, &W.status);
             PMX_STAMP(W, 9);
         }

@@ -149,7 +149,28 @@ struct Ez {             // ksw_extz_t (ksw2.h:27-36)
 // status bits reported per record
 #define PMX_ST_OVERFLOW 0x1
 #define PMX_ST_UNSUPPORTED 0x2
-#define PMX_ST_NEED_WAVE 0x4   // thread-per-pair kernel: this pair needs a real DP -> wave-per-pair kernel
+#define PMX_ST_NEED_WAVE 0x4   // thread-per-pair kernel: hand this pair to the wave-per-pair kernels
+#define PMX_ST_NEED_DP 0x8     // thread-per-pair kernel: a DP request was posted; re-run once it is served
+#define PMX_ST_ABORT (PMX_ST_NEED_WAVE | PMX_ST_NEED_DP)
+
+// DP service of the thread-per-pair kernel (align_kernel_tpp.hip): a pair whose extension / gap fill is
+// not covered by ksw_shortcut posts the DP's inputs as a request, a wave-per-request kernel runs
+// ksw_extd2 on it, and the pair is replayed with the result served from its per-pair result list (the
+// pipeline is deterministic, so the c-th DP call of the replay is the c-th call of the first run).
+#define PMX_DP_SEQ_BYTES 480
+#define PMX_DP_MAX_CIGAR 20
+#define PMX_DP_MAX_CALLS 8
+struct DpRes {   // 128 bytes
+    Ez ez;
+    uint32_t key;                    // must equal the request's key; 0xffffffff = the DP overflowed
+    uint32_t cigar[PMX_DP_MAX_CIGAR];
+};
+
+struct DpReq {   // 512 bytes
+    int32_t qlen, tlen, w, zdrop, end_bonus, flag;
+    uint32_t call, key;
+    uint8_t seq[PMX_DP_SEQ_BYTES];   // query, then target at ((qlen + 15) & ~15)
+};
 
 // Capacities of the per-wave work memory (chosen by the host from the read-length regime).
 struct Caps {
@@ -213,6 +234,13 @@ struct Work {
     int rep_len;
     int frag_gap;
     uint64_t tmp64;        // lane-0 -> wave broadcast slot
+    // DP service (thread-per-pair kernel only; all NULL / 0 elsewhere)
+    uint8_t* dp_req_base;             // request slots, sizeof(DpReq) each
+    const struct DpRes* dp_res;       // this pair's served results (dp_n_cached of them)
+    unsigned long long* dp_slot_ctr;  // round 0: slot allocator
+    int64_t dp_slot;                  // this pair's slot, -1 = none yet
+    uint32_t dp_slot_cap;
+    int dp_n_cached, dp_calls;
     // optional phase profile (diagnostic runs only: AlignArgs::prof != NULL)
     unsigned long long* prof;
     unsigned long long prof_t;

@@ -15,8 +15,17 @@ struct AlignArgs {
     const int64_t* off;
     int64_t n_items;        // pairs (paired) or reads, or worklist length
     const uint32_t* worklist;   // tier 2: item ids to (re)process; NULL = 0..n_items-1
-    uint32_t* retry_list;       // tier 1: items whose capacities overflowed (NULL in tier 2)
+    uint32_t* retry_list;       // tier 1: items whose capacities overflowed (NULL in tier 2); tier 0: pairs for the wave tiers
     unsigned long long* retry_count;
+    // tier 0 DP service (NULL elsewhere): see DpReq / DpRes in align/aln_types.hpp
+    uint8_t* dp_req_base;       // slot_cap * sizeof(DpReq)
+    DpRes* dp_res_base;         // slot_cap * PMX_DP_MAX_CALLS
+    uint32_t* dp_ncached;       // served results per slot
+    uint32_t* dp_slot_pairs;    // slot -> pair id
+    uint32_t* dp_next_list;     // round >= 1: slots that posted another request
+    unsigned long long* dp_count;   // round 0: slot allocator; round >= 1: length of dp_next_list
+    uint32_t dp_slot_cap;
+    int dp_round;
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
     int paired;
     int revcomp_mate2;
@@ -38,6 +47,7 @@ __global__ void k_align_reads_w4(AlignArgs A);
 __global__ void k_align_reads_t1(AlignArgs A);
 __global__ void k_align_reads_t1_w4(AlignArgs A);
 __global__ void k_align_reads_tpp(AlignArgs A);
+__global__ void k_align_dp_serve(AlignArgs A);
 
 }  // namespace aln
 }  // namespace pmx

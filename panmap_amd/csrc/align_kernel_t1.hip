@@ -11,5 +11,46 @@ namespace aln {
 __global__ void __launch_bounds__(64, 2) k_align_reads_t1(AlignArgs A) { align_reads_body<2>(A); }
 __global__ void __launch_bounds__(64, 4) k_align_reads_t1_w4(AlignArgs A) { align_reads_body<4>(A); }
 
+// DP service of the thread-per-pair kernel: one wave per posted request runs the anti-diagonal-parallel
+// ksw_extd2 with its arrays in LDS (traceback matrix in the wave's HBM slab) and appends the result to the
+// slot's result list.
+__global__ void __launch_bounds__(64, 4) k_align_dp_serve(AlignArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    Work& W = *reinterpret_cast<Work*>(lds);
+    PMX_LDS(&W);
+    uint8_t* fast = lds + PMX_ALIGN_WORK_BYTES;
+    uint8_t* slow = A.slow_base + (size_t)blockIdx.x * A.slow_stride;
+    const int lane = (int)(threadIdx.x & 63u);
+    for (int64_t it = blockIdx.x; it < A.n_items; it += gridDim.x) {
+        const int64_t slot = A.worklist ? (int64_t)A.worklist[it] : it;
+        const DpReq* rq = reinterpret_cast<const DpReq*>(A.dp_req_base + (size_t)slot * sizeof(DpReq));
+        __syncthreads();
+        bind_work(W, A.layout, fast, slow);
+        W.prof = nullptr;
+        const int qlen = rq->qlen, tlen = rq->tlen;
+        const int t_off = (qlen + 15) & ~15;
+        uint8_t* sq = W.qseq[0][0]; PMX_LDS(sq);
+        __syncthreads();
+        for (int i = lane; i < t_off + tlen; i += 64) sq[i] = rq->seq[i];
+        __syncthreads();
+        Ez ez;
+        ksw_extd2(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, rq->w,
+                  rq->zdrop, rq->end_bonus, rq->flag, ez);
+        __syncthreads();
+        if (lane == 0) {
+            const uint32_t n = A.dp_ncached[slot];
+            if (n < PMX_DP_MAX_CALLS) {
+                DpRes& R = A.dp_res_base[(size_t)slot * PMX_DP_MAX_CALLS + n];
+                const bool bad = (W.status & PMX_ST_OVERFLOW) || ez.n_cigar > PMX_DP_MAX_CIGAR || n != rq->call;
+                R.ez = ez;
+                R.key = bad ? 0xffffffffu : rq->key;
+                const uint32_t* cg = W.cig_tmp; PMX_LDS(cg);
+                if (!bad) for (int i = 0; i < ez.n_cigar; ++i) R.cigar[i] = cg[i];
+                A.dp_ncached[slot] = n + 1;
+            }
+        }
+    }
+}
+
 }  // namespace aln
 }  // namespace pmx

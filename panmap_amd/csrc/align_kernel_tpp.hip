@@ -2,9 +2,12 @@
 // (sketch, seed lookup, chaining, region logic, CIGAR clean-up, mapq, pairing) is scalar, branchy code: run
 // redundantly on 64 lanes it wastes the machine (measured: ~130k wave-instructions and 1.6M cycles per
 // pair); run as 64 independent pairs per wave it is ordinary SIMT.  This kernel executes the very same
-// sources as the host unit-test build (PMX_W = 1) and never runs a DP: pairs whose extensions are not
-// covered by the proved shortcuts (ksw_shortcut) or that exceed a work-buffer capacity are appended to a
-// retry list and re-run by the wave-per-pair kernels.  Per-thread work arrays live in a private HBM slab.
+// sources as the host unit-test build (PMX_W = 1) and never runs a DP itself: a pair whose extension is not
+// covered by the proved shortcuts (ksw_shortcut) posts the DP inputs as a request and aborts; the
+// wave-per-request kernel k_align_dp_serve (align_kernel_t1.hip) computes it; the next round replays the
+// pair with the result served from its slot (rounds repeat until no pair posts a request).  Pairs that
+// exceed a work-buffer or DP-service capacity go to the wave-per-pair kernels through retry_list.
+// Per-thread work arrays live in a private HBM slab.
 #define PMX_THREAD_PER_PAIR 1
 #include <hip/hip_runtime.h>
 
@@ -23,11 +26,24 @@ k_align_reads_tpp(AlignArgs A) {
     const int n_segs = A.paired ? 2 : 1;
 
     for (int64_t it = tid; it < A.n_items; it += n_threads) {
-        const int64_t item = A.worklist ? (int64_t)A.worklist[it] : it;
+        int64_t item, slot = -1;
+        if (A.dp_round == 0) item = it;
+        else {
+            slot = A.worklist ? (int64_t)A.worklist[it] : it;
+            item = (int64_t)A.dp_slot_pairs[slot];
+            if (item == 0xffffffffLL) continue;
+        }
         Work W;
         bind_work(W, A.layout, slab, slab + fast_sz);
         W.n_segs = n_segs;
         W.prof = nullptr;
+        W.dp_req_base = A.dp_req_base;
+        W.dp_slot_cap = A.dp_slot_cap;
+        W.dp_slot = slot;
+        if (slot >= 0) {
+            W.dp_res = A.dp_res_base + (size_t)slot * PMX_DP_MAX_CALLS;
+            W.dp_n_cached = (int)A.dp_ncached[slot];
+        } else W.dp_slot_ctr = A.dp_count;
         bool too_long = false;
         for (int s = 0; s < n_segs; ++s) {
             const int64_t r = A.paired ? 2 * item + s : item;
@@ -62,6 +78,12 @@ k_align_reads_tpp(AlignArgs A) {
         }
         if (W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) {
             A.retry_list[atomicAdd(A.retry_count, 1ULL)] = (uint32_t)item;
+            if (A.dp_round == 0 && W.dp_slot >= 0) A.dp_slot_pairs[W.dp_slot] = 0xffffffffu;   // slot taken, pair gone
+            continue;
+        }
+        if (W.status & PMX_ST_NEED_DP) {
+            if (A.dp_round == 0) A.dp_slot_pairs[W.dp_slot] = (uint32_t)item;
+            else A.dp_next_list[atomicAdd(A.dp_count, 1ULL)] = (uint32_t)slot;
             continue;
         }
         const bool mapped = frag_is_mapped(W, A.paired);

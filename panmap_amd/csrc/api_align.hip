@@ -32,6 +32,11 @@ struct pmx_aligner {
     DevBuf<unsigned long long> cigar_used;
     DevBuf<uint8_t> slow, slow2, slab0;
     DevBuf<uint32_t> retry_list2;
+    DevBuf<uint8_t> dp_req;
+    DevBuf<DpRes> dp_res;
+    DevBuf<uint32_t> dp_ncached, dp_slot_pairs, dp_list_a, dp_list_b;
+    int64_t last_dp_requests = 0;
+    int last_dp_rounds = 0;
     DevBuf<uint32_t> retry_list;
     DevBuf<unsigned long long> retry_count;
     int64_t last_retry = 0, last_tpp_retry = 0;
@@ -173,19 +178,24 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         PMX_HIP(hipGetLastError());
     };
 
-    al->retry_count.ensure(1);
-    PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, sizeof(unsigned long long), ctx->stream));
+    al->retry_count.ensure(2);   // [0] pairs for the next (wave) tier, [1] DP requests of the current tier-0 round
+    PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     const Layout general = plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget);
     const Layout compact = plan_layout_compact((int)rs->max_len, n_segs, al->opt);
     const bool tier1_fits = use_tier1 && al->opt.is_sr_like && PMX_ALIGN_WORK_BYTES + compact.fast_bytes + 16 <= 40 * 1024;
     const bool use_tier0 = tier1_fits && !getenv("PMX_ALIGN_NO_TPP");
-    auto read_retry = [&]() -> int64_t {
-        unsigned long long n_retry = 0;
-        PMX_HIP(hipMemcpyAsync(&n_retry, al->retry_count.p, sizeof(n_retry), hipMemcpyDeviceToHost, ctx->stream));
+    const bool use_dp_service = !getenv("PMX_ALIGN_NO_DP_SERVICE");
+    // reads both counters; [1] is reset for the next round, [0] only when asked
+    auto read_counts = [&](int64_t& n_next_tier, int64_t& n_dp, bool reset_next_tier) {
+        unsigned long long h[2] = {0, 0};
+        PMX_HIP(hipMemcpyAsync(h, al->retry_count.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         PMX_HIP(hipStreamSynchronize(ctx->stream));
-        PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, sizeof(unsigned long long), ctx->stream));
-        return (int64_t)n_retry;
+        PMX_HIP(hipMemsetAsync(al->retry_count.p + (reset_next_tier ? 0 : 1), 0, sizeof(unsigned long long) * (reset_next_tier ? 2 : 1), ctx->stream));
+        n_next_tier = (int64_t)h[0];
+        n_dp = (int64_t)h[1];
     };
+    A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
+    A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
     timer_begin(ctx, "align");
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
@@ -193,29 +203,77 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         int64_t n_t1 = n_items;
         const uint32_t* t1_list = nullptr;
         al->last_tpp_retry = 0;
-        if (use_tier0) {   // tier 0: thread per pair, no DP
-            int tpp_waves = 8;
+        al->last_dp_requests = 0;
+        al->last_dp_rounds = 0;
+        if (use_tier0) {   // tier 0: thread per pair + DP service rounds
+            int tpp_waves = 4;
             if (const char* e = getenv("PMX_ALIGN_TPP_WAVES")) tpp_waves = atoi(e);
-            int64_t grid = (int64_t)ctx->n_cu * tpp_waves;
-            if (grid * 64 > n_items) grid = (n_items + 63) / 64;
-            A.layout = compact;
-            A.slow_stride = ((compact.fast_bytes + 63) & ~(size_t)63) + ((compact.slow_bytes - compact.tb_cap + 255) & ~(size_t)255);
-            al->slab0.ensure(A.slow_stride * (size_t)grid * 64);
-            A.slow_base = al->slab0.p;
-            A.n_items = n_items;
-            A.worklist = nullptr;
+            const int64_t max_grid = std::min<int64_t>((int64_t)ctx->n_cu * tpp_waves, (n_items + 63) / 64);
+            const size_t tpp_stride = ((compact.fast_bytes + 63) & ~(size_t)63) + ((compact.slow_bytes - compact.tb_cap + 255) & ~(size_t)255);
+            al->slab0.ensure(tpp_stride * (size_t)max_grid * 64);
+            const size_t dp_lds = PMX_ALIGN_WORK_BYTES + compact.fast_bytes + 16;
+            const size_t dp_stride = (compact.slow_bytes + 255) & ~(size_t)255;
+            const int64_t dp_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dp_lds);
+            if (use_dp_service) {
+                al->dp_req.ensure((size_t)n_items * sizeof(DpReq));
+                al->dp_res.ensure((size_t)n_items * PMX_DP_MAX_CALLS);
+                al->dp_ncached.ensure((size_t)n_items);
+                al->dp_slot_pairs.ensure((size_t)n_items);
+                al->dp_list_a.ensure((size_t)n_items);
+                al->dp_list_b.ensure((size_t)n_items);
+                al->slow.ensure(dp_stride * (size_t)dp_max_grid);
+                PMX_HIP(hipMemsetAsync(al->dp_ncached.p, 0, sizeof(uint32_t) * (size_t)n_items, ctx->stream));
+                A.dp_req_base = al->dp_req.p; A.dp_res_base = al->dp_res.p; A.dp_ncached = al->dp_ncached.p;
+                A.dp_slot_pairs = al->dp_slot_pairs.p;
+                A.dp_slot_cap = (uint32_t)std::min<int64_t>(n_items, UINT32_MAX - 1);
+            }
+            A.dp_count = al->retry_count.p + 1;
             A.retry_list = al->retry_list2.p;
             A.retry_count = al->retry_count.p;
-            hipLaunchKernelGGL(k_align_reads_tpp, dim3((unsigned)grid), dim3(64), 0, ctx->stream, A);
-            PMX_HIP(hipGetLastError());
-            n_t1 = read_retry();
+            A.layout = compact;
+            auto launch_tpp = [&](int round, int64_t n_work, const uint32_t* worklist, uint32_t* next_list) {
+                int64_t grid = std::min<int64_t>(max_grid, (n_work + 63) / 64);
+                A.slow_stride = tpp_stride;
+                A.slow_base = al->slab0.p;
+                A.n_items = n_work;
+                A.worklist = worklist;
+                A.dp_round = round;
+                A.dp_next_list = next_list;
+                hipLaunchKernelGGL(k_align_reads_tpp, dim3((unsigned)grid), dim3(64), 0, ctx->stream, A);
+                PMX_HIP(hipGetLastError());
+            };
+            launch_tpp(0, n_items, nullptr, nullptr);
+            int64_t n_dp = 0;
+            read_counts(n_t1, n_dp, false);
+            n_dp = std::min<int64_t>(n_dp, (int64_t)A.dp_slot_cap);
+            const uint32_t* cur = nullptr;   // round 1 serves slots 0..n_dp-1
+            uint32_t* lists[2] = {al->dp_list_a.p, al->dp_list_b.p};
+            int round = 1;
+            while (n_dp > 0) {   // ends by itself: a pair posts at most PMX_DP_MAX_CALLS requests, then goes to the wave tier
+                al->last_dp_requests += n_dp;
+                A.slow_stride = dp_stride;
+                A.slow_base = al->slow.p;
+                A.n_items = n_dp;
+                A.worklist = cur;
+                hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dp_max_grid, n_dp)), dim3(64), dp_lds, ctx->stream, A);
+                PMX_HIP(hipGetLastError());
+                uint32_t* next = lists[round & 1];
+                launch_tpp(round, n_dp, cur, next);
+                read_counts(n_t1, n_dp, false);
+                cur = next;
+                ++round;
+            }
+            al->last_dp_rounds = round - 1;
+            PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+            A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
+            A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
             t1_list = al->retry_list2.p;
             al->last_tpp_retry = n_t1;
         }
-        int64_t n_retry = 0;
+        int64_t n_retry = 0, unused = 0;
         if (n_t1 > 0) {
             launch(kern_t1, compact, n_t1, t1_list, al->retry_list.p, al->slow);
-            n_retry = read_retry();
+            read_counts(n_retry, unused, true);
         }
         al->last_retry = n_retry;
         if (n_retry > 0) launch(kern, general, n_retry, al->retry_list.p, nullptr, al->slow2);
@@ -231,7 +289,8 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         static const char* names[16] = {"decode", "sketch", "seed+heap", "chain", "gen_regs+post", "seg_gen", "squeeze", "align1(all regs)", "filter/sort/parent", "mapq", "pair", "output", "", "", "", ""};
         fprintf(stderr, "[pmx align phase cycles per item]");
         for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.0f", names[k], (double)h[k] / (double)n_items);
-        fprintf(stderr, " tpp_retry=%lld retry=%lld\n", (long long)al->last_tpp_retry, (long long)al->last_retry);
+        fprintf(stderr, " dp_requests=%lld dp_rounds=%d tpp_retry=%lld retry=%lld\n", (long long)al->last_dp_requests, al->last_dp_rounds,
+                (long long)al->last_tpp_retry, (long long)al->last_retry);
     }
     PMX_HIP(hipGetLastError());
     return PMX_OK;

@@ -15,19 +15,20 @@ class Rec(C.Structure):
                 ("n_cigar", C.c_uint16), ("flags", C.c_uint16), ("cigar_off", C.c_uint32), ("score", C.c_int32)]
 
 
-_hs = None
+_hs = {}
 
 
-def hostsim():
-    global _hs
-    if _hs is None:
+def hostsim(tpp=False):
+    """tpp=False: the pipeline as the wave-per-pair kernels run it (PMX_W = 1); tpp=True: the thread-per-pair
+    kernel's control flow, with its DP-request / replay rounds emulated on the host."""
+    if tpp not in _hs:
         subprocess.run(["make", "-C", os.path.join(HERE, "hostsim")], check=True, stdout=subprocess.DEVNULL)
-        L = C.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+        L = C.CDLL(os.path.join(HERE, "hostsim", "libhostsim_tpp.so" if tpp else "libhostsim.so"))
         L.hs_align.restype = C.c_int
         L.hs_align.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.POINTER(Rec),
                                C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int]
-        _hs = L
-    return _hs
+        _hs[tpp] = L
+    return _hs[tpp]
 
 
 def records_to_results(recs, cig, n_reads, paired):
@@ -48,7 +49,7 @@ def records_to_results(recs, cig, n_reads, paired):
     return out
 
 
-def hostsim_align(reference: bytes, reads, paired, verbose=0):
+def hostsim_align(reference: bytes, reads, paired, verbose=0, tpp=False):
     n = len(reads)
     arr = (C.c_char_p * n)(*reads)
     lens = (C.c_int * n)(*[len(r) for r in reads])
@@ -56,7 +57,7 @@ def hostsim_align(reference: bytes, reads, paired, verbose=0):
     cap = max(64, sum(len(r) for r in reads))
     cig = np.zeros(cap, np.uint32)
     used = C.c_int64()
-    rc = hostsim().hs_align(reference, len(reference), n, arr, lens, int(paired), recs, cig.ctypes.data, cap, C.byref(used), verbose)
+    rc = hostsim(tpp).hs_align(reference, len(reference), n, arr, lens, int(paired), recs, cig.ctypes.data, cap, C.byref(used), verbose)
     assert rc == 0, rc
     return records_to_results(recs, cig, n, paired)
 

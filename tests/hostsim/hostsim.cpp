@@ -6,6 +6,11 @@
 #include <cstdlib>
 #include <vector>
 
+#ifdef PMX_HOSTSIM_TPP
+// emulation of the thread-per-pair kernel's DP service (align_kernel_tpp.hip + k_align_dp_serve): the pipeline
+// posts a request instead of running a DP, the request is served by ksw_extd2, the pair is replayed.
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
+#endif
 #include "align/aln_host.hpp"
 
 using namespace pmx::aln;
@@ -21,7 +26,15 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
     build_ref_index(ref, ref_len, o, std::max(4096, max_len * (o.a + 1) * 2 + 64), hri);
     const RefIndex ri = hri.view();
     const int n_segs = paired ? 2 : 1;
+#ifdef PMX_HOSTSIM_TPP
+    Layout L = plan_layout_compact(max_len, n_segs, o);
+    L.slow_bytes += 64;
+    std::vector<uint8_t> dp_req(sizeof(DpReq));
+    std::vector<DpRes> dp_res(PMX_DP_MAX_CALLS);
+    int64_t n_requests = 0, n_wave = 0;
+#else
     Layout L = plan_layout(max_len, n_segs, o, (size_t)1 << 30);
+#endif
     std::vector<uint8_t> fast(L.fast_bytes + 64), slow(L.slow_bytes + 64);
     Work W;
     memset(&W, 0, sizeof(W));
@@ -45,7 +58,48 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
             }
         }
         if (too_long) return -1;
+#ifdef PMX_HOSTSIM_TPP
+        int n_cached = 0;
+        for (;;) {
+            const int ql[2] = {W.qlen[0], W.qlen[1]};
+            bind_work(W, L, fast.data(), slow.data());
+            W.qlen[0] = ql[0]; W.qlen[1] = ql[1];
+            W.dp_req_base = dp_req.data();
+            W.dp_res = dp_res.data();
+            W.dp_slot = 0;
+            W.dp_slot_cap = 1;
+            W.dp_n_cached = n_cached;
+            map_frag(W, o, ri);
+            if ((W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) || !(W.status & PMX_ST_NEED_DP)) break;
+            const DpReq* rq = reinterpret_cast<const DpReq*>(dp_req.data());
+            if ((int)rq->call != n_cached) return -4;
+            Work W2;
+            memset(&W2, 0, sizeof(W2));
+            bind_work(W2, L, fast.data(), slow.data());
+            std::vector<uint8_t> seq(rq->seq, rq->seq + PMX_DP_SEQ_BYTES);
+            Ez ez;
+            ksw_extd2(W2, rq->qlen, seq.data(), rq->tlen, seq.data() + ((rq->qlen + 15) & ~15), o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2,
+                      (int8_t)o.e2, rq->w, rq->zdrop, rq->end_bonus, rq->flag, ez);
+            DpRes& R = dp_res[n_cached];
+            const bool bad = (W2.status & PMX_ST_OVERFLOW) || ez.n_cigar > PMX_DP_MAX_CIGAR;
+            R.ez = ez;
+            R.key = bad ? 0xffffffffu : rq->key;
+            if (!bad) for (int i = 0; i < ez.n_cigar; ++i) R.cigar[i] = W2.cig_tmp[i];
+            ++n_cached;
+            ++n_requests;
+        }
+        if (W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) {   // this pair goes to the wave-per-pair tiers
+            ++n_wave;
+            for (int s = 0; s < n_segs; ++s) {
+                AlnRecord& rec = recs[paired ? 2 * it + s : it];
+                memset(&rec, 0, sizeof(rec));
+                rec.flags = 0x8000;
+            }
+            continue;
+        }
+#else
         map_frag(W, o, ri);
+#endif
         const bool mapped = frag_is_mapped(W, paired);
         for (int s = 0; s < n_segs; ++s) {
             AlnRecord& rec = recs[paired ? 2 * it + s : it];
@@ -68,5 +122,8 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
         }
     }
     *cig_used = used;
+#ifdef PMX_HOSTSIM_TPP
+    if (verbose) fprintf(stderr, "hostsim tpp: %lld DP requests, %lld pairs to the wave tier of %d\n", (long long)n_requests, (long long)n_wave, n_items);
+#endif
     return 0;
 }

@@ -1,0 +1,64 @@
+"""CPU tests of the ALIGN pipeline sources (panmap_amd/csrc/align/*.hpp compiled by g++ with PMX_W = 1,
+tests/hostsim) against the reference's own aligner compiled from its sources (oracle/_ref).  They check the
+host logic of the kernels -- sketch, seeding, chaining, region bookkeeping, ksw2 DP, mapq, pairing -- and
+the thread-per-pair kernel's DP-request / replay protocol without a GPU; the HIP kernels themselves are
+checked by tests/test_align_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+
+import align_checks as ac
+from conftest import GOLDEN
+
+
+def _ref_genome():
+    return b"".join(l.strip() for l in open(os.path.join(GOLDEN, "isolate.ref.fa"), "rb") if not l.startswith(b">"))
+
+
+@pytest.fixture(scope="module")
+def cases(pmx):
+    g = _ref_genome()
+    seqs, _, _ = pmx.read_fastq_paired(os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz"))
+    real = seqs[20000:26000]
+    concat, off = pmx.simulate_paired_reads(g, 1500, seed=31, sub_rate=0.02)
+    syn = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+    syn = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(syn)]
+    rng = np.random.default_rng(9)
+    for i in range(0, 600, 2):   # indels and N runs
+        r = bytearray(syn[i])
+        p = int(rng.integers(15, 130))
+        k = i % 6
+        if k == 0:
+            del r[p:p + int(rng.integers(1, 7))]
+        elif k == 2:
+            r[p:p] = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 7))).astype(np.uint8))
+        else:
+            r[p:p + 3] = b"NNN"
+        syn[i] = bytes(r)
+    return g, {"real": real, "synthetic": syn}
+
+
+@pytest.mark.parametrize("name", ["real", "synthetic"])
+def test_pipeline_sources_equal_reference(pmx, oracle, cases, name):
+    g, sets = cases
+    reads = sets[name]
+    want = oracle.ref_align_reads_direct(g, reads, True, 8)
+    got = ac.hostsim_align(g, reads, True)
+    bad = ac.compare_results(got, want)
+    assert not bad, bad[:10]
+    assert sum(1 for x in got if x["flags"] & 3) <= 2
+
+
+@pytest.mark.parametrize("name", ["real", "synthetic"])
+def test_thread_per_pair_dp_service_replay(pmx, oracle, cases, name):
+    """the tier-0 control flow: DP requests served out of line, pair replayed; pairs handed to the wave tiers
+    (flag 0x8000) are excluded and must stay a small minority"""
+    g, sets = cases
+    reads = sets[name]
+    want = oracle.ref_align_reads_direct(g, reads, True, 8)
+    got = ac.hostsim_align(g, reads, True, tpp=True)
+    keep = [i for i, x in enumerate(got) if not (x["flags"] & 0x8000)]
+    assert len(keep) >= 0.9 * len(got), (len(keep), len(got))
+    bad = ac.compare_results([got[i] for i in keep], [want[i] for i in keep])
+    assert not bad, bad[:10]
