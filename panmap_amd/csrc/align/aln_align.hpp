@@ -25,7 +25,7 @@ PMX_HD void gen_simple_mat(int8_t* mat, int8_t a, int8_t b, int8_t sc_ambi) {   
     for (int j = 0; j < 5; ++j) mat[4 * 5 + j] = sc_ambi;
 }
 
-PMX_HD void ref_getseq(const RefIndex& ri, int st, int en, uint8_t* out) {   // mm_idx_getseq (index.c:152-162)
+PMX_HD void ref_getseq(const RefIndex& ri, int st, int en, Ptr<uint8_t> out) {   // mm_idx_getseq (index.c:152-162)
     PMX_LDS(out);
     if (en > ri.len) en = ri.len;
     const int lane = lane_id();
@@ -33,7 +33,7 @@ PMX_HD void ref_getseq(const RefIndex& ri, int st, int en, uint8_t* out) {   // 
     wave_sync();
 }
 
-PMX_HD void seq_rev(int len, uint8_t* seq) {   // mm_seq_rev
+PMX_HD void seq_rev(int len, Ptr<uint8_t> seq) {   // mm_seq_rev
     PMX_LDS(seq);
     wave_sync();
     if (lane_id() == 0 || PMX_W == 1)
@@ -42,7 +42,7 @@ PMX_HD void seq_rev(int len, uint8_t* seq) {   // mm_seq_rev
 }
 
 // CIGAR storage of a region: a slot in the per-wave pool
-PMX_HD uint32_t* reg_cigar(Work& W, const Reg& r) { return W.cig_pool + (size_t)r.cig_slot * W.caps.max_cigar; }
+PMX_HD Ptr<uint32_t> reg_cigar(Work& W, const Reg& r) { return W.cig_pool + (size_t)r.cig_slot * W.caps.max_cigar; }
 
 PMX_HD void reg_alloc_p(Work& W, Reg& r) {
     if (r.has_p) return;
@@ -55,11 +55,11 @@ PMX_HD void reg_alloc_p(Work& W, Reg& r) {
 }
 
 // mm_append_cigar (align.c:291-314)
-PMX_HD void append_cigar(Work& W, Reg& r, int n_cigar, const uint32_t* cigar) {
+PMX_HD void append_cigar(Work& W, Reg& r, int n_cigar, Ptr<const uint32_t> cigar) {
     PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(cigar);
     if (n_cigar == 0) return;
     reg_alloc_p(W, r);
-    uint32_t* c = reg_cigar(W, r); PMX_LDS(c);
+    Ptr<uint32_t> c = reg_cigar(W, r); PMX_LDS(c);
     if ((int)r.n_cigar + n_cigar > W.caps.max_cigar) { W.status |= PMX_ST_OVERFLOW; return; }
     if (r.n_cigar > 0 && (c[r.n_cigar - 1] & 0xf) == (cigar[0] & 0xf)) {
         c[r.n_cigar - 1] += cigar[0] >> 4 << 4;
@@ -72,7 +72,7 @@ PMX_HD void append_cigar(Work& W, Reg& r, int n_cigar, const uint32_t* cigar) {
 }
 
 // mm_align_pair (align.c:316-343) without the splice / single-affine branches (q != q2 on this path)
-PMX_HD void align_pair(Work& W, const Opt& o, int qlen, const uint8_t* qseq, int tlen, const uint8_t* tseq, int w, int end_bonus, int zdrop,
+PMX_HD void align_pair(Work& W, const Opt& o, int qlen, Ptr<const uint8_t> qseq, int tlen, Ptr<const uint8_t> tseq, int w, int end_bonus, int zdrop,
                        int flag, Ez& ez) {
     if (o.max_sw_mat > 0 && (int64_t)tlen * qlen > o.max_sw_mat) {
         ez_reset(ez);
@@ -88,7 +88,7 @@ PMX_HD void align_pair(Work& W, const Opt& o, int qlen, const uint8_t* qseq, int
 
 // update_max_zdrop + mm_test_zdrop (align.c:32-89).  The inversion probe (ksw_ll_i16) is reported as
 // unsupported instead of evaluated; it only decides between return codes 1 and 2.
-PMX_HDN int test_zdrop(Work& W, const Opt& o, const uint8_t* qseq, const uint8_t* tseq, int n_cigar, const uint32_t* cigar) {
+PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int n_cigar, Ptr<const uint32_t> cigar) {
     PMX_LDS(&W); PMX_LDS(qseq); PMX_LDS(tseq); PMX_LDS(cigar);
     int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
     int pos[2][2] = {{-1, -1}, {-1, -1}};
@@ -127,9 +127,9 @@ PMX_HDN int test_zdrop(Work& W, const Opt& o, const uint8_t* qseq, const uint8_t
 }
 
 // mm_fix_cigar (align.c:91-167)
-PMX_HDN void fix_cigar(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq, int* qshift, int* tshift) {
+PMX_HDN void fix_cigar(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int* qshift, int* tshift) {
     PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq); PMX_LDS(tseq);
-    uint32_t* cg = reg_cigar(W, r); PMX_LDS(cg);
+    Ptr<uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
     int32_t toff = 0, qoff = 0, to_shrink = 0;
     *qshift = *tshift = 0;
     if (r.n_cigar <= 1) return;
@@ -197,7 +197,7 @@ PMX_HDN void fix_cigar(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq
 }
 
 // mm_update_extra (align.c:240-289), log_gap = 1, is_eqx = 0
-PMX_HDN void update_extra(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* tseq, const int8_t* mat, int8_t q, int8_t e) {
+PMX_HDN void update_extra(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, const int8_t* mat, int8_t q, int8_t e) {
     PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq); PMX_LDS(tseq);
     if (!r.has_p) return;
     int32_t qshift, tshift, toff = 0, qoff = 0;
@@ -205,7 +205,7 @@ PMX_HDN void update_extra(Work& W, Reg& r, const uint8_t* qseq, const uint8_t* t
     fix_cigar(W, r, qseq, tseq, &qshift, &tshift);
     qseq += qshift;
     tseq += tshift;
-    const uint32_t* cg = reg_cigar(W, r); PMX_LDS(cg);
+    Ptr<const uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
     r.blen = r.mlen = 0;
     for (uint32_t k = 0; k < r.n_cigar; ++k) {
         const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
@@ -252,12 +252,12 @@ PMX_HD void adjust_minier(const Opt& o, const A128& a, int32_t* r, int32_t* q) {
     *q = (int32_t)a.y - (o.k >> 1);
 }
 
-PMX_HD int anchor_gap(const A128* a, int i) {   // query advance minus reference advance between anchors i-1 and i
+PMX_HD int anchor_gap(Ptr<const A128> a, int i) {   // query advance minus reference advance between anchors i-1 and i
     return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - ((int32_t)a[i].x - (int32_t)a[i - 1].x);
 }
 
 // collect_long_gaps + mm_filter_bad_seeds (align.c:374-427).  K[] lives in W.aux64 (as int32).
-PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, const A128* a, int min_gap, int32_t* K, int cap) {
+PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, Ptr<const A128> a, int min_gap, Ptr<int32_t> K, int cap) {
     PMX_LDS(&W); PMX_LDS(a); PMX_LDS(K);
     int n = 0;
     for (int i = 1; i < cnt1; ++i) {
@@ -274,9 +274,9 @@ PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, const A128* a, int min_
     return n;
 }
 
-PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, A128* a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
+PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, Ptr<A128> a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
     PMX_LDS(&W); PMX_LDS(a);
-    int32_t* K = (int32_t*)W.f; PMX_LDS(K);   // chain DP arrays are idle during alignment
+    Ptr<int32_t> K = W.f; PMX_LDS(K);   // chain DP arrays are idle during alignment
     const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
     if (n == 0) return;
     int mx = 0, max_st = -1, max_en = -1;
@@ -309,9 +309,9 @@ PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, A128* a, int min_gap, 
 }
 
 // mm_filter_bad_seeds_alt (align.c:429-462)
-PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, A128* a, int min_gap, int max_ext) {
+PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, Ptr<A128> a, int min_gap, int max_ext) {
     PMX_LDS(&W); PMX_LDS(a);
-    int32_t* K = (int32_t*)W.f; PMX_LDS(K);
+    Ptr<int32_t> K = W.f; PMX_LDS(K);
     const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
     if (n == 0) return;
     for (int k = 0; k < n;) {
@@ -345,7 +345,7 @@ PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, A128* a, int min_g
 }
 
 // mm_fix_bad_ends (align.c:464-502)
-PMX_HDN void fix_bad_ends(const Reg& r, const A128* a, int bw, int min_match, int32_t* as, int32_t* cnt) {
+PMX_HDN void fix_bad_ends(const Reg& r, Ptr<const A128> a, int bw, int min_match, int32_t* as, int32_t* cnt) {
     PMX_LDS(&r); PMX_LDS(a);
     *as = r.as;
     *cnt = r.cnt;
@@ -379,12 +379,12 @@ PMX_HDN void fix_bad_ends(const Reg& r, const A128* a, int bw, int min_match, in
 }
 
 // mm_align1 (align.c:575-833)
-PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t* const qseq0[2], Reg& r, Reg& r2, int n_a, A128* a, Ez& ez) {
+PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const Ptr<uint8_t>* qseq0, Reg& r, Reg& r2, int n_a, Ptr<A128> a, Ez& ez) {
     PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(a);   // r2 and ez are caller-locals (private)
-    uint32_t* cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
+    Ptr<uint32_t> cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
     const int32_t rev = (int32_t)(a[r.as].x >> 63);
     int32_t as1, cnt1;
-    uint8_t* tseq = W.tseq; PMX_LDS(tseq);
+    Ptr<uint8_t> tseq = W.tseq; PMX_LDS(tseq);
     int32_t l, dropped = 0, rs0, re0, qs0, qe0;
     int32_t rs, re, qs, qe;
     int32_t rs1, qs1, re1, qe1;
@@ -459,7 +459,7 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t
     if (re0 - rs0 > W.caps.max_tlen || re0 <= rs0) { W.status |= PMX_ST_OVERFLOW; return; }
 
     if (qs > 0 && rs > 0) {   // left extension (align.c:704-722)
-        uint8_t* qseq = &qseq0[rev][qs0]; PMX_LDS(qseq);
+        Ptr<uint8_t> qseq = qseq0[rev] + qs0; PMX_LDS(qseq);
         ref_getseq(ri, rs0, rs, tseq);
         seq_rev(qs - qs0, qseq);
         seq_rev(rs - rs0, tseq);
@@ -482,7 +482,7 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t
         if (i == cnt1 - 1 || (a[as1 + i].y & PMX_SEED_LONG_JOIN) || (qe - qs >= o.min_ksw_len && re - rs >= o.min_ksw_len)) {
             int bw1 = bw_long;
             if (a[as1 + i].y & PMX_SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
-            uint8_t* qseq = &qseq0[rev][qs]; PMX_LDS(qseq);
+            Ptr<uint8_t> qseq = qseq0[rev] + qs; PMX_LDS(qseq);
             ref_getseq(ri, rs, re, tseq);
             align_pair(W, o, qe - qs, qseq, re - rs, tseq, bw1, -1, o.zdrop, PMX_EZ_APPROX_MAX, ez);   // first pass: approximate Z-drop
             const int zdrop_code = test_zdrop(W, o, qseq, tseq, ez.n_cigar, cig_tmp);
@@ -509,7 +509,7 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t
     }
 
     if (!dropped && qe < qe0 && re < re0) {   // right extension (align.c:799-815)
-        uint8_t* qseq = &qseq0[rev][qe]; PMX_LDS(qseq);
+        Ptr<uint8_t> qseq = qseq0[rev] + qe; PMX_LDS(qseq);
         ref_getseq(ri, re, re0, tseq);
         align_pair(W, o, qe0 - qe, qseq, re0 - re, tseq, bw, o.end_bonus, o.zdrop, PMX_EZ_EXTZ_ONLY, ez);
         if (ez.n_cigar > 0) {
@@ -526,7 +526,7 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, uint8_t
 
     if (r.has_p) {
         ref_getseq(ri, rs1, re1, tseq);
-        const uint8_t* qseq = &qseq0[r.rev][qs1]; PMX_LDS(qseq);
+        Ptr<const uint8_t> qseq = qseq0[r.rev] + qs1; PMX_LDS(qseq);
         update_extra(W, r, qseq, tseq, o.mat, (int8_t)o.q, (int8_t)o.e);
     }
 }
@@ -546,7 +546,7 @@ PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac,
     if (regs[max_i].qe - regs[max_i].qs < (double)qlen * frac) return;
     if (max2 < (double)mx * frac) return;
     auto count_gaps = [&](const Reg& r, int32_t* n_gap, int32_t* n_gapo) {
-        const uint32_t* cg = reg_cigar(W, r); PMX_LDS(cg);
+        Ptr<const uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
         *n_gap = *n_gapo = 0;
         for (uint32_t i = 0; i < r.n_cigar; ++i) {
             const int32_t op = cg[i] & 0xf, len = cg[i] >> 4;
@@ -562,7 +562,7 @@ PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac,
     for (int i = 0; i < n_regs; ++i) {
         Reg& r = regs[i];
         if (!r.has_p) continue;
-        const uint32_t* cg = reg_cigar(W, r); PMX_LDS(cg);
+        Ptr<const uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
         int32_t ng = 0, ngo = 0;
         double gap_cost = 0.0;
         for (uint32_t q = 0; q < r.n_cigar; ++q) {
@@ -579,11 +579,11 @@ PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac,
 }
 
 // mm_align_skeleton (align.c:967-1027) for one segment; then the tail of align_regs (map.c:225-234)
-PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int* n_regs_, Reg* regs, A128* a) {
+PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int* n_regs_, Reg* regs, Ptr<A128> a) {
     PMX_LDS(&W); PMX_LDS(n_regs_); PMX_LDS(regs); PMX_LDS(a);
     const int qlen = W.qlen[seg];
     int n_regs = *n_regs_;
-    uint8_t* qseq0[2] = {W.qseq[seg][0], W.qseq[seg][1]};
+    const Ptr<uint8_t> qseq0[2] = {W.qseq[seg][0], W.qseq[seg][1]};
     Ez ez;
     const int n_a = squeeze_a(W, n_regs, regs, a);
     PMX_STAMP(W, 6);

@@ -48,7 +48,7 @@ PMX_HD int32_t chain_score(const A128 ai, const A128 aj, int32_t max_dist_x, int
 }
 
 // mg_chain_bk_end (lchain.c:9-25)
-PMX_HD int64_t chain_bk_end(int32_t max_drop, const A128* z, const int32_t* f, const int32_t* p, int32_t* t, int64_t k) {
+PMX_HD int64_t chain_bk_end(int32_t max_drop, Ptr<const A128> z, Ptr<const int32_t> f, Ptr<const int32_t> p, Ptr<int32_t> t, int64_t k) {
     PMX_LDS(z); PMX_LDS(f); PMX_LDS(p); PMX_LDS(t);
     int64_t i = (int64_t)z[k].y, end_i = -1, max_i = i;
     int32_t max_s = 0;
@@ -170,8 +170,8 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     PMX_LDS(&W);
     W.n_u = 0;
     if (n == 0) return;
-    A128* a = W.a; PMX_LDS(a);
-    int32_t *f = W.f, *t = W.t, *v = W.v, *p = W.p;
+    Ptr<A128> a = W.a; PMX_LDS(a);
+    Ptr<int32_t> f = W.f, t = W.t, v = W.v, p = W.p;
     PMX_LDS(f); PMX_LDS(t); PMX_LDS(v); PMX_LDS(p);
     const int32_t max_drop = bw;
     if (max_dist_x < bw) max_dist_x = bw;
@@ -223,7 +223,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     }
 
     // ---- backtrack (lchain.c:27-76)
-    A128* z = W.z; PMX_LDS(z);
+    Ptr<A128> z = W.z; PMX_LDS(z);
     int64_t n_z = 0;
     for (int64_t i = 0; i < n; ++i)
         if (f[i] >= min_sc) { z[n_z].x = (uint64_t)(int64_t)f[i]; z[n_z].y = (uint64_t)i; ++n_z; }
@@ -232,7 +232,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     for (int64_t i = 0; i < n; ++i) t[i] = 0;
     int64_t n_v = 0;
     int32_t n_u = 0;
-    uint64_t* u = W.u; PMX_LDS(u);
+    Ptr<uint64_t> u = W.u; PMX_LDS(u);
     // (the reference runs this loop twice, first only to size u[]; one pass gives the same u[] and v[])
     for (int64_t k = n_z - 1; k >= 0; --k) {
         if (t[z[k].y] == 0) {
@@ -250,14 +250,14 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     if (n_u == 0) { W.n_a = 0; W.n_u = 0; return; }
 
     // ---- compact (lchain.c:78-111): chains reversed into ascending order, then sorted by target position
-    A128* b = W.a2; PMX_LDS(b);
+    Ptr<A128> b = W.a2; PMX_LDS(b);
     int64_t kk = 0;
     for (int32_t i = 0; i < n_u; ++i) {
         const int64_t k0 = kk;
         const int32_t ni = (int32_t)u[i];
         for (int32_t j = 0; j < ni; ++j) b[kk++] = a[v[k0 + (ni - j - 1)]];
     }
-    A128* wv = W.z; PMX_LDS(wv);   // z[] is free again
+    Ptr<A128> wv = W.z; PMX_LDS(wv);   // z[] is free again
     kk = 0;
     for (int32_t i = 0; i < n_u; ++i) {
         wv[i].x = b[kk].x;
@@ -265,7 +265,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
         kk += (int32_t)u[i];
     }
     radix_sort_128x(wv, wv + n_u, &W.status);
-    uint64_t* u2 = W.u2; PMX_LDS(u2);
+    Ptr<uint64_t> u2 = W.u2; PMX_LDS(u2);
     kk = 0;
     for (int32_t i = 0; i < n_u; ++i) {
         const int32_t j = (int32_t)wv[i].y, nn = (int32_t)u[j];

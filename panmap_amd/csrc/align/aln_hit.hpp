@@ -9,7 +9,7 @@ namespace pmx {
 namespace aln {
 
 // mm_cal_fuzzy_len + mm_reg_set_coor (hit.c:8-40); is_qstrand == 0
-PMX_HD void reg_set_coor(Reg& r, int32_t qlen, const A128* a) {
+PMX_HD void reg_set_coor(Reg& r, int32_t qlen, Ptr<const A128> a) {
     PMX_LDS(a);
     const int32_t k = r.as, q_span = (int32_t)(a[k].y >> 32 & 0xff);
     r.rev = (uint8_t)(a[k].x >> 63);
@@ -49,11 +49,11 @@ PMX_HD uint64_t hit_hash64(uint64_t key) {   // hit.c:42-52 (unmasked variant)
 PMX_HD void reg_clear(Reg& r) { memset(&r, 0, sizeof(Reg)); }
 
 // mm_gen_regs (hit.c:54-94): chains sorted by (score, hash) descending
-PMX_HDN int gen_regs(Work& W, uint32_t hash, int qlen, int n_u, const uint64_t* u, const A128* a, Reg* r) {
+PMX_HDN int gen_regs(Work& W, uint32_t hash, int qlen, int n_u, Ptr<const uint64_t> u, Ptr<const A128> a, Reg* r) {
     PMX_LDS(&W); PMX_LDS(u); PMX_LDS(a); PMX_LDS(r);
     if (n_u == 0) return 0;
     if (n_u > W.caps.max_reg) { W.status |= PMX_ST_OVERFLOW; n_u = W.caps.max_reg; }
-    A128* z = W.aux128; PMX_LDS(z);
+    Ptr<A128> z = W.aux128; PMX_LDS(z);
     int k = 0;
     for (int i = 0; i < n_u; ++i) {
         const uint32_t h = (uint32_t)hit_hash64((hit_hash64(a[k].x) + hit_hash64(a[k].y)) ^ hash);
@@ -79,7 +79,7 @@ PMX_HDN int gen_regs(Work& W, uint32_t hash, int qlen, int n_u, const uint64_t* 
 }
 
 // mm_split_reg (hit.c:112-130)
-PMX_HD void split_reg(Reg& r, Reg& r2, int n, int qlen, const A128* a) {
+PMX_HD void split_reg(Reg& r, Reg& r2, int n, int qlen, Ptr<const A128> a) {
     PMX_LDS(&r); PMX_LDS(a);   // r2 is a caller-local (private) object
     if (n <= 0 || n >= r.cnt) return;
     r2 = r;
@@ -105,8 +105,8 @@ PMX_HDN void set_parent(Work& W, float mask_level, int mask_len, int n, Reg* r, 
     PMX_LDS(&W); PMX_LDS(r);
     if (n <= 0) return;
     for (int i = 0; i < n; ++i) r[i].id = i;
-    uint64_t* cov = W.aux64; PMX_LDS(cov);
-    int32_t* w = (int32_t*)(W.aux64 + W.caps.max_reg);
+    Ptr<uint64_t> cov = W.aux64; PMX_LDS(cov);
+    Ptr<int32_t> w = ptr_cast<int32_t>(W.aux64 + W.caps.max_reg);
     w[0] = 0;
     r[0].parent = 0;
     int k = 1;
@@ -176,7 +176,7 @@ PMX_HDN void sync_regs(Work& W, int n_regs, Reg* regs) {
     int max_id = -1;
     for (int i = 0; i < n_regs; ++i) max_id = max_id > regs[i].id ? max_id : regs[i].id;
     const int n_tmp = max_id + 1;
-    int32_t* tmp = (int32_t*)W.aux64; PMX_LDS(tmp);
+    Ptr<int32_t> tmp = ptr_cast<int32_t>(W.aux64); PMX_LDS(tmp);
     if (n_tmp > W.caps.max_reg * 4) { W.status |= PMX_ST_OVERFLOW; return; }
     for (int i = 0; i < n_tmp; ++i) tmp[i] = -1;
     for (int i = 0; i < n_regs; ++i)
@@ -293,7 +293,7 @@ PMX_HDN void hit_sort(Work& W, int* n_regs, Reg* r) {
     PMX_LDS(&W); PMX_LDS(r);
     const int n = *n_regs;
     if (n <= 1) return;
-    A128* aux = W.aux128; PMX_LDS(aux);
+    Ptr<A128> aux = W.aux128; PMX_LDS(aux);
     Reg* t = W.reg_tmp; PMX_LDS(t);
     int n_aux = 0;
     for (int i = 0; i < n; ++i) {
@@ -310,9 +310,9 @@ PMX_HDN void hit_sort(Work& W, int* n_regs, Reg* r) {
 }
 
 // mm_squeeze_a (hit.c:324-343)
-PMX_HDN int squeeze_a(Work& W, int n_regs, Reg* regs, A128* a) {
+PMX_HDN int squeeze_a(Work& W, int n_regs, Reg* regs, Ptr<A128> a) {
     PMX_LDS(&W); PMX_LDS(regs); PMX_LDS(a);
-    uint64_t* aux = W.aux64; PMX_LDS(aux);
+    Ptr<uint64_t> aux = W.aux64; PMX_LDS(aux);
     int as = 0;
     for (int i = 0; i < n_regs; ++i) aux[i] = (uint64_t)(uint32_t)regs[i].as << 32 | (uint32_t)i;
     radix_sort_64(aux, aux + n_regs, &W.status);
@@ -328,11 +328,11 @@ PMX_HDN int squeeze_a(Work& W, int n_regs, Reg* regs, A128* a) {
 }
 
 // mm_seg_gen (hit.c:345-400) for n_segs == 2: split fragment chains into per-mate chains
-PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, const Reg* regs0, const A128* a) {
+PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, const Reg* regs0, Ptr<const A128> a) {
     PMX_LDS(&W); PMX_LDS(qlens); PMX_LDS(regs0); PMX_LDS(a);
-    uint64_t* su[2] = {W.seg_u[0], W.seg_u[1]};
+    Ptr<uint64_t> su[2] = {W.seg_u[0], W.seg_u[1]};
     PMX_LDS(su[0]); PMX_LDS(su[1]);
-    A128* sa0 = W.seg_a[0]; PMX_LDS(sa0);
+    Ptr<A128> sa0 = W.seg_a[0]; PMX_LDS(sa0);
     const int n_segs = W.n_segs;
     int acc_qlen[3];
     acc_qlen[0] = 0;
@@ -352,7 +352,7 @@ PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, cons
         }
     }
     W.seg_a[1] = sa0 + n_seg_anchors[0];   // both mates' anchor lists share one max_anchor block
-    A128* sa1 = sa0 + n_seg_anchors[0];
+    Ptr<A128> sa1 = sa0 + n_seg_anchors[0];
     for (int s = 0; s < n_segs; ++s) {
         int n_u = 0;
         for (int i = 0; i < n_regs0; ++i)

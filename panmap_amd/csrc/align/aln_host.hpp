@@ -105,6 +105,7 @@ inline uint8_t nt4_of_char(unsigned char c) {   // seq_nt4_table (sketch.c:9-26)
 }
 
 // mm_idx_str(w, k, 0, 14, 1, &ref) (index.c:408-451): sketch the reference, group occurrences by minimizer
+#ifndef PMX_INTERLEAVED   // host-only (raw pointers); the thread-per-pair device pass skips it
 inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp_score, HostRefIndex& out) {
     out = HostRefIndex();
     out.seq.resize((size_t)ref_len);
@@ -175,16 +176,18 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
     }
 }
 
+#endif
 // ------------------------------------------------------------------------------ work memory layout
-enum { PMX_FAST = 0, PMX_SLOW = 1 };
+enum { PMX_FAST = 0, PMX_SLOW = 1, PMX_RAW = 2 };   // RAW: thread-per-pair layout only (per-thread contiguous structs)
 
 struct Layout {
     Caps caps;
-    size_t fast_bytes = 0, slow_bytes = 0;
+    size_t fast_bytes = 0, slow_bytes = 0, raw_bytes = 0;
     size_t tb_cap = 0;
     struct Ent { uint32_t space; size_t off; };
     Ent qseq, mv, sk_buf, seeds, mini_pos, heap, a, a2, f, t, v, p, z, u, u2, regs0, regs1, regs2, reg_tmp, seg_a0, seg_a1, seg_u0,
-        seg_u1, aux64, aux128, du, sf, qr, H, off_, tseq, cig_tmp, cig_pool, tb;
+        seg_u1, aux64, aux128, du, sf, qr, H, off_, tseq, cig_tmp, cig_pool, tb, tb_fast;
+    size_t tb_fast_cap = 0;   // DP-service layout only: LDS traceback area for small DPs
 };
 
 // Capacities for a read-length regime; fast = LDS budget (bytes) per wave.
@@ -323,23 +326,92 @@ inline Layout plan_layout_compact(int max_read_len, int n_segs, const Opt& o) {
     return L;
 }
 
-PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow) {
-    uint8_t* base[2] = {fast, slow};
+// DP-service layout (k_align_dp_serve): only what ksw_extd2 touches; the request's sequences go to the qseq
+// block; DPs whose traceback matrix fits tb_fast_cap keep it in LDS (the serial traceback walk is
+// latency-bound), larger ones use the wave's HBM slab.  Capacities as in the compact layout.
+inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o) {
+    Layout L = plan_layout_compact(max_read_len, n_segs, o);
+    const Caps& c = L.caps;
+    size_t top = 0;
+    auto put = [&](Layout::Ent& e, size_t bytes) {
+        bytes = (bytes + 15) & ~(size_t)15;
+        e.space = PMX_FAST;
+        e.off = top;
+        top += bytes;
+    };
+    const Layout::Ent none{PMX_FAST, 0};   // unused arrays alias offset 0 (never dereferenced by ksw_extd2)
+    L.mv = L.a = L.regs0 = L.regs1 = L.regs2 = L.reg_tmp = L.seg_a0 = L.seg_a1 = L.seg_u0 = L.seg_u1 = L.u = L.aux64 = L.aux128 = none;
+    L.cig_pool = L.sk_buf = L.seeds = L.heap = L.f = L.p = L.t = L.v = L.z = L.a2 = L.u2 = L.tseq = L.mini_pos = none;
+    put(L.qseq, (size_t)std::max(4 * c.max_qlen, 512));
+    put(L.du, (size_t)7 * (c.max_tlen + 32));
+    put(L.sf, (size_t)c.max_tlen + 32);
+    put(L.qr, (size_t)c.max_tlen + 64);
+    put(L.H, 4 * (size_t)(c.max_tlen + 32));
+    put(L.off_, 8 * (size_t)(c.max_qlen + c.max_tlen));
+    put(L.cig_tmp, 4 * (size_t)c.max_cigar);
+    L.tb_fast_cap = 12 * 1024;
+    put(L.tb_fast, L.tb_fast_cap);
+    L.fast_bytes = top;
+    L.tb.space = PMX_SLOW;
+    L.tb.off = 0;
+    L.slow_bytes = L.tb_cap + 64;
+    return L;
+}
+
+// Thread-per-pair layout (k_align_reads_tpp): the compact layout's arrays, addressed through IPtr (logical
+// offsets: FAST region first, SLOW region behind it, interleaved across the wave by IPtr::phys), except the
+// Reg / Seed struct arrays, which live in a small per-thread contiguous RAW region behind plain pointers.
+// tb_bytes > 0 adds a per-thread traceback area (in-lane DPs; off by default).
+inline Layout plan_layout_tpp(int max_read_len, int n_segs, const Opt& o, size_t tb_bytes) {
+    Layout L = plan_layout_compact(max_read_len, n_segs, o);
+    const Caps& c = L.caps;
+    size_t raw = 0;
+    auto put_raw = [&](Layout::Ent& e, size_t bytes) {
+        e.space = PMX_RAW;
+        e.off = raw;
+        raw += (bytes + 15) & ~(size_t)15;
+    };
+    put_raw(L.regs0, sizeof(Reg) * c.max_reg);
+    put_raw(L.regs1, sizeof(Reg) * c.max_reg);
+    put_raw(L.regs2, sizeof(Reg) * c.max_reg);
+    put_raw(L.reg_tmp, sizeof(Reg) * c.max_reg);
+    put_raw(L.seeds, sizeof(Seed) * c.max_mini);
+    L.raw_bytes = raw;
+    // (the FAST offsets of the moved arrays stay reserved: simpler than re-packing, ~6 KB of address space)
+    L.tb_cap = tb_bytes;
+    L.slow_bytes = L.tb.off + tb_bytes;   // mini_pos, then the traceback area
+    return L;
+}
+
+// logical size of one thread's interleaved arena (FAST then SLOW), a multiple of the 16-byte granule
+inline size_t tpp_arena_bytes(const Layout& L) { return ((L.fast_bytes + 63) & ~(size_t)63) + ((L.slow_bytes + 15) & ~(size_t)15); }
+
+// Binds the Work pointers.  Wave-per-pair kernels / host: fast = LDS arena (or host buffer), slow = the wave's
+// HBM slab.  Thread-per-pair kernel: fast/slow are unused (IPtr offsets), raw = the thread's struct region.
+PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow, uint8_t* raw = nullptr) {
+    uint8_t* base[3] = {fast, slow, raw};
+#ifdef PMX_INTERLEAVED
+    const uint32_t lbase[2] = {0u, (uint32_t)((L.fast_bytes + 63) & ~(size_t)63)};
+#define PMX_AT(T, e) (IPtr<T>(lbase[L.e.space] + (uint32_t)L.e.off))
+#else
 #define PMX_AT(T, e) ((T*)(base[L.e.space] + L.e.off))
+#endif
+#define PMX_AT_RAW(T, e) ((T*)(base[L.e.space] + L.e.off))
     W.caps = L.caps;
     const int mq = L.caps.max_qlen;
-    uint8_t* qs = PMX_AT(uint8_t, qseq);
+    Ptr<uint8_t> qs = PMX_AT(uint8_t, qseq);
     W.qseq[0][0] = qs; W.qseq[0][1] = qs + mq; W.qseq[1][0] = qs + 2 * mq; W.qseq[1][1] = qs + 3 * mq;
-    W.mv = PMX_AT(A128, mv); W.sk_buf = PMX_AT(A128, sk_buf); W.seeds = PMX_AT(Seed, seeds);
+    W.mv = PMX_AT(A128, mv); W.sk_buf = PMX_AT(A128, sk_buf); W.seeds = PMX_AT_RAW(Seed, seeds);
     W.mini_pos = PMX_AT(uint64_t, mini_pos); W.heap = PMX_AT(A128, heap);
     W.a = PMX_AT(A128, a); W.a2 = PMX_AT(A128, a2);
     W.f = PMX_AT(int32_t, f); W.t = PMX_AT(int32_t, t); W.v = PMX_AT(int32_t, v); W.p = PMX_AT(int32_t, p);
     W.z = PMX_AT(A128, z); W.u = PMX_AT(uint64_t, u); W.u2 = PMX_AT(uint64_t, u2);
-    W.regs0 = PMX_AT(Reg, regs0); W.regs[0] = PMX_AT(Reg, regs1); W.regs[1] = PMX_AT(Reg, regs2); W.reg_tmp = PMX_AT(Reg, reg_tmp);
+    W.regs0 = PMX_AT_RAW(Reg, regs0); W.regs[0] = PMX_AT_RAW(Reg, regs1); W.regs[1] = PMX_AT_RAW(Reg, regs2);
+    W.reg_tmp = PMX_AT_RAW(Reg, reg_tmp);
     W.seg_a[0] = PMX_AT(A128, seg_a0); W.seg_a[1] = PMX_AT(A128, seg_a1);
     W.seg_u[0] = PMX_AT(uint64_t, seg_u0); W.seg_u[1] = PMX_AT(uint64_t, seg_u1);
     W.aux64 = PMX_AT(uint64_t, aux64); W.aux128 = PMX_AT(A128, aux128);
-    int8_t* d = PMX_AT(int8_t, du);
+    Ptr<int8_t> d = PMX_AT(int8_t, du);
     const int T = L.caps.max_tlen + 32;
     W.du = d; W.dv = d + T; W.dx = d + 2 * T; W.dy = d + 3 * T; W.dx2 = d + 4 * T; W.dy2 = d + 5 * T; W.ds = d + 6 * T;
     W.sf = PMX_AT(uint8_t, sf); W.qr = PMX_AT(uint8_t, qr);
@@ -349,6 +421,7 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow) {
     W.tseq = PMX_AT(uint8_t, tseq);
     W.cig_tmp = PMX_AT(uint32_t, cig_tmp); W.cig_pool = PMX_AT(uint32_t, cig_pool);
 #undef PMX_AT
+#undef PMX_AT_RAW
     W.status = 0;
     W.cig_next = 0;
     W.dp_req_base = nullptr; W.dp_res = nullptr; W.dp_slot_ctr = nullptr;

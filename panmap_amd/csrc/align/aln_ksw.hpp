@@ -38,7 +38,7 @@ PMX_HD int ez_apply_zdrop(Ez& ez, int32_t H, int r, int t, int zdrop, int8_t e) 
     return 0;
 }
 
-PMX_HD void push_cigar(uint32_t* cigar, int* n_cigar, int cap, uint32_t op, int len, uint32_t* status) {   // ksw_push_cigar
+PMX_HD void push_cigar(Ptr<uint32_t> cigar, int* n_cigar, int cap, uint32_t op, int len, uint32_t* status) {   // ksw_push_cigar
     if (*n_cigar == 0 || op != (cigar[*n_cigar - 1] & 0xf)) {
         if (*n_cigar < cap) cigar[(*n_cigar)++] = (uint32_t)len << 4 | op;
         else *status |= PMX_ST_OVERFLOW;
@@ -46,11 +46,11 @@ PMX_HD void push_cigar(uint32_t* cigar, int* n_cigar, int cap, uint32_t op, int 
 }
 
 // ksw_backtrack (ksw2.h:127-162) with is_rot = 1, min_intron_len = 0
-PMX_HDN void ksw_backtrack(Work& W, int is_rev, const uint8_t* p, const int32_t* off, const int32_t* off_end, int n_col, int i0, int j0,
+PMX_HDN void ksw_backtrack(Work& W, int is_rev, Ptr<const uint8_t> p, Ptr<const int32_t> off, Ptr<const int32_t> off_end, int n_col, int i0, int j0,
                           int* n_cigar_) {
     PMX_LDS(&W); PMX_LDS(off); PMX_LDS(off_end);   // p = traceback matrix: global memory
     int n_cigar = 0, i = i0, j = j0, state = 0;
-    uint32_t* cigar = W.cig_tmp; PMX_LDS(cigar);
+    Ptr<uint32_t> cigar = W.cig_tmp; PMX_LDS(cigar);
     const int cap = W.caps.max_cigar;
     while (i >= 0 && j >= 0) {
         int force_state = -1;
@@ -87,7 +87,8 @@ PMX_HD int64_t wave_max_i64(int64_t v) { return v; }
 #endif
 
 // ksw_extd2_sse.  query/target hold nt4 codes; with_cigar always on.  Results in ez and W.cig_tmp.
-PMX_HDN void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+template <class QP, class TP>
+PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const int8_t* mat, int8_t q, int8_t e,
                       int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
     const int lane = lane_id();
@@ -117,13 +118,13 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const 
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
     const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
 
-    int8_t *u = W.du, *v = W.dv, *x = W.dx, *y = W.dy, *x2 = W.dx2, *y2 = W.dy2, *s = W.ds;
-    uint8_t *sf = W.sf, *qr = W.qr;
-    int32_t* H = W.H;
-    int32_t *off = W.off, *off_end = W.off_end;
+    Ptr<int8_t> u = W.du, v = W.dv, x = W.dx, y = W.dy, x2 = W.dx2, y2 = W.dy2, s = W.ds;
+    Ptr<uint8_t> sf = W.sf, qr = W.qr;
+    Ptr<int32_t> H = W.H;
+    Ptr<int32_t> off = W.off, off_end = W.off_end;
     PMX_LDS(u); PMX_LDS(v); PMX_LDS(x); PMX_LDS(y); PMX_LDS(x2); PMX_LDS(y2); PMX_LDS(s);
     PMX_LDS(sf); PMX_LDS(qr); PMX_LDS(H); PMX_LDS(off); PMX_LDS(off_end);
-    uint8_t* p = W.tb;
+    Ptr<uint8_t> p = W.tb;
     const int T16 = tlen_ * 16;
     // initial fill (ksw2_extd2_sse.c:107-126): every lane takes a stride
     for (int t = lane; t < T16; t += PMX_W) {
@@ -168,7 +169,7 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const 
             u[r] = r == 0 ? (int8_t)(-q - e) : r < long_thres ? (int8_t)-e : r == long_thres ? (int8_t)long_diff : (int8_t)-e2;
         }
         // scores (loop fission, :168-189): 16-wide chunks starting at st0
-        const uint8_t* qrr = qr + (qlen - 1 - r);
+        Ptr<const uint8_t> qrr = qr + (qlen - 1 - r);
         const int s_end = st0 + ((en0 - st0) / 16 + 1) * 16;
         for (int t = st0 + lane; t < s_end; t += PMX_W) {
             const uint8_t sq = sf[t], sq2 = qrr[t];
@@ -181,7 +182,7 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, const uint8_t* query, int tlen, const 
         // diagonal in x[t-1], v[t-1], x2[t-1]
         off[r] = st;
         off_end[r] = en;
-        uint8_t* pr = p + (size_t)r * n_col - st;
+        Ptr<uint8_t> pr = p + ((size_t)r * n_col - st);
         const int n_chunk = (en - st + PMX_W) / PMX_W;
         for (int c = n_chunk - 1; c >= 0; --c) {
             const int t = st + c * PMX_W + lane;
@@ -337,7 +338,7 @@ PMX_HD int wave_sum_i32(int v) { return v; }
 
 // Number of positions i < n where a[i] != b[i] or a base is ambiguous (code >= 4), saturating early is
 // not needed: n <= a few hundred.  Lane-parallel.
-PMX_HD int count_diff(const uint8_t* a, const uint8_t* b, int n) {
+PMX_HD int count_diff(Ptr<const uint8_t> a, Ptr<const uint8_t> b, int n) {
     PMX_LDS(a); PMX_LDS(b);
     int d = 0;
     for (int i = lane_id(); i < n; i += PMX_W) d += (a[i] != b[i] || a[i] > 3) ? 1 : 0;
@@ -353,10 +354,10 @@ PMX_HD int count_diff(const uint8_t* a, const uint8_t* b, int n) {
 //      alignment scores strictly less than the gap-free one for every prefix pair on the main diagonal,
 //      so the traceback is all-diagonal -> score = len*a - d*(a+b), CIGAR = len M.
 // Everything else runs the DP.
-PMX_HD bool ksw_shortcut(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, Ptr<const uint8_t> target, const int8_t* mat, int8_t q, int8_t e,
                            int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
-    uint32_t* cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
+    Ptr<uint32_t> cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
     const int a = mat[0], b = -mat[1];
     const int g1 = q + e, g2 = q2 + e2;
     const int gmin = g1 < g2 ? g1 : g2, gmax = g1 > g2 ? g1 : g2;
@@ -394,12 +395,24 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, const uint8_t* query, int tlen, cons
     return false;
 }
 
-PMX_HD void ksw_extd2_auto(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+PMX_HD void ksw_extd2_auto(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, Ptr<const uint8_t> target, const int8_t* mat, int8_t q, int8_t e,
                            int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     if (ksw_shortcut(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) return;
 #if defined(PMX_THREAD_PER_PAIR) && (defined(__HIP_DEVICE_COMPILE__) || defined(PMX_HOSTSIM_TPP))
     // the thread-per-pair kernel never runs a DP itself: serve it from the pair's result list, or post
     // it as a request (first unserved call only) and abort this pass
+    // ... except a small one whose arrays fit the thread's own slab (the common case: an extension over a
+    // mismatch near a read end): a scalar DP in this lane is cheaper than a request + replay round
+    {
+        int wb = w < 0 ? (tlen > qlen ? tlen : qlen) : w;
+        int n_col = qlen < tlen ? qlen : tlen;
+        n_col = (((n_col < wb + 1 ? n_col : wb + 1) + 15) / 16 + 1) * 16;
+        if (!(W.status & PMX_ST_ABORT) && qlen > 0 && tlen > 0 && (tlen + 15) / 16 * 16 <= W.caps.max_tlen && qlen <= W.caps.max_tlen &&
+            (size_t)(qlen + tlen - 1) * (size_t)n_col <= W.tb_cap) {
+            ksw_extd2(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+            return;
+        }
+    }
     const uint32_t key = (uint32_t)qlen | (uint32_t)tlen << 10 | (uint32_t)(flag & 0xff) << 20;
     if (!(W.status & PMX_ST_ABORT)) {
         const int c = W.dp_calls++;

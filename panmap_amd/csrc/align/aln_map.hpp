@@ -48,10 +48,10 @@ PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonu
     PMX_LDS(r0_); PMX_LDS(r1_);
 #define PMX_REGS(s) ((s) ? r1_ : r0_)
     const int cap = W.caps.max_reg * 2;
-    uint64_t* key = W.aux64; PMX_LDS(key);         // [cap]
-    int32_t* ps = (int32_t*)(W.aux64 + cap);       // [cap] segment
-    int32_t* pi = ps + cap;                        // [cap] index in regs[s]
-    uint64_t* sc = (uint64_t*)W.z; PMX_LDS(sc);    // pair scores
+    Ptr<uint64_t> key = W.aux64; PMX_LDS(key);                 // [cap]
+    Ptr<int32_t> ps = ptr_cast<int32_t>(W.aux64 + cap);        // [cap] segment
+    Ptr<int32_t> pi = ps + cap;                                // [cap] index in regs[s]
+    Ptr<uint64_t> sc = ptr_cast<uint64_t>(W.z); PMX_LDS(sc);   // pair scores
     const int sc_cap = W.caps.max_anchor * 2;      // z holds max_anchor A128
     int n = 0, segs = 0, dp_thres = 0;
     for (int s = 0; s < 2; ++s) {
@@ -147,8 +147,8 @@ PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonu
 // mm_map_frag (map.c:236-390) for n_segs in {1,2}.  Regions end up in W.regs[s] / W.n_regs[s].
 PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     PMX_LDS(&W);
-    A128* a_ = W.a; PMX_LDS(a_);
-    uint64_t* u_ = W.u; PMX_LDS(u_);
+    Ptr<A128> a_ = W.a; PMX_LDS(a_);
+    Ptr<uint64_t> u_ = W.u; PMX_LDS(u_);
     Reg* regs0_ = W.regs0; PMX_LDS(regs0_);
     const int n_segs = W.n_segs;
     int qlen_sum = 0;

@@ -23,13 +23,13 @@ PMX_HD uint64_t mz_hash64(uint64_t key, uint64_t mask) {
 
 // (w,k)-minimizers of one segment, appended to W.mv (no HPC).  seq holds nt4 codes (>=4 ambiguous).
 // Output layout as the reference: x = hash<<8 | span, y = rid<<32 | lastPos<<1 | strand.
-PMX_HDN void sketch_segment(Work& W, const uint8_t* seq, int len, int w, int k, uint32_t rid) {
+PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
     const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
     uint64_t kmer0 = 0, kmer1 = 0;
     int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
     PMX_LDS(&W); PMX_LDS(seq);
-    A128* buf = W.sk_buf; PMX_LDS(buf);
-    A128* mvp = W.mv; PMX_LDS(mvp);
+    Ptr<A128> buf = W.sk_buf; PMX_LDS(buf);
+    Ptr<A128> mvp = W.mv; PMX_LDS(mvp);
     A128 mn;
     mn.x = mn.y = UINT64_MAX;
     for (int j = 0; j < w; ++j) buf[j].x = buf[j].y = UINT64_MAX;
@@ -93,7 +93,7 @@ PMX_HDN void sketch_segment(Work& W, const uint8_t* seq, int len, int w, int k, 
 // lengths of the previous segments.  (sdust masking is off: options.c:23.)
 PMX_HD void collect_minimizers(Work& W, const Opt& o) {
     PMX_LDS(&W);
-    A128* mvp = W.mv; PMX_LDS(mvp);
+    Ptr<A128> mvp = W.mv; PMX_LDS(mvp);
     W.n_mv = 0;
     int sum = 0;
     for (int s = 0; s < W.n_segs; ++s) {
@@ -116,7 +116,7 @@ PMX_HD uint32_t index_lookup(const RefIndex& ri, uint64_t minier, uint32_t* off)
 }
 
 // binary heaps exactly as ksort.h:43-59 builds them (ties must break the same way)
-PMX_HD void heap_down_min_x(A128* l, int i, int n) {   // "less" = a.x > b.x  -> min-heap on x (map.c:76)
+PMX_HD void heap_down_min_x(Ptr<A128> l, int i, int n) {   // "less" = a.x > b.x  -> min-heap on x (map.c:76)
     PMX_LDS(l);
     int k = i;
     const A128 tmp = l[i];
@@ -184,10 +184,10 @@ PMX_HDN void seed_select(int n, Seed* a, int len, int max_occ, int max_max_occ, 
 // minimizers are issued lane-parallel first (one L2 round trip instead of n_mv dependent ones).
 PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
     PMX_LDS(&W);
-    A128* mv = W.mv; PMX_LDS(mv);
-    A128* hp = W.heap; PMX_LDS(hp);
+    Ptr<A128> mv = W.mv; PMX_LDS(mv);
+    Ptr<A128> hp = W.heap; PMX_LDS(hp);
     Seed* seeds = W.seeds; PMX_LDS(seeds);
-    uint64_t* mini_pos = W.mini_pos;   // global scratch (only mm_est_err would read it)
+    Ptr<uint64_t> mini_pos = W.mini_pos;   // global scratch (only mm_est_err would read it)
     int n_m0 = 0;
     for (int i = lane_id(); i < W.n_mv; i += PMX_W) {
         uint32_t off = 0;
@@ -253,12 +253,12 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     PMX_LDS(&W);
     const int n_m = W.n_seeds;
     const int64_t n_a = W.n_a;
-    A128* heap = W.heap; PMX_LDS(heap);
-    A128* a = W.a; PMX_LDS(a);
+    Ptr<A128> heap = W.heap; PMX_LDS(heap);
+    Ptr<A128> a = W.a; PMX_LDS(a);
     Seed* seeds = W.seeds; PMX_LDS(seeds);
     // stage every occurrence list in idle scratch so the merge never waits on HBM/L2:
     // cache offsets are assigned in seed order, the copies run one seed per lane
-    uint64_t* pc = (uint64_t*)W.seg_a[0]; PMX_LDS(pc);   // the per-mate anchor block (16*max_anchor bytes) is idle until seg_gen
+    Ptr<uint64_t> pc = ptr_cast<uint64_t>(W.seg_a[0]); PMX_LDS(pc);   // the per-mate anchor block (16*max_anchor bytes) is idle until seg_gen
     {
         uint32_t acc = 0;
         for (int i = 0; i < n_m; ++i) { const uint32_t n = seeds[i].n; seeds[i].flt = acc; acc += n; }   // flt is free now: cache offset

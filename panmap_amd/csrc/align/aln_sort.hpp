@@ -17,12 +17,12 @@ struct KeyU64 {
 };
 
 template <class T, class K>
-PMX_HD void rs_insertsort(T* beg, T* end) {
-
-    for (T* i = beg + 1; i < end; ++i) {
+PMX_HD void rs_insertsort(Ptr<T> beg, Ptr<T> end) {
+    for (Ptr<T> i = beg + 1; i < end; ++i) {
         if (K::key(*i) < K::key(*(i - 1))) {
-            T *j, tmp = *i;
-            for (j = i; j > beg && K::key(tmp) < K::key(*(j - 1)); --j) *j = *(j - 1);
+            Ptr<T> j = i;
+            const T tmp = *i;
+            for (; j > beg && K::key(tmp) < K::key(*(j - 1)); --j) *j = *(j - 1);
             *j = tmp;
         }
     }
@@ -31,11 +31,11 @@ PMX_HD void rs_insertsort(T* beg, T* end) {
 // one level of the American-flag pass on byte `s/8`; iterative over an explicit stack of pending
 // sub-ranges (the reference recurses; the visiting order of disjoint buckets does not matter)
 template <class T, class K>
-PMX_HDN void rs_sort_level(T* beg, T* end, int s, T** stk_b, T** stk_e, int* stk_s, int& sp, int stk_cap, uint32_t* overflow) {
+PMX_HDN void rs_sort_level(Ptr<T> beg, Ptr<T> end, int s, Ptr<T>* stk_b, Ptr<T>* stk_e, int* stk_s, int& sp, int stk_cap, uint32_t* overflow) {
     // bucket boundaries: 256 (begin,end) pairs kept as offsets
     int32_t bb[256], be[256];
     for (int k = 0; k < 256; ++k) bb[k] = be[k] = 0;
-    for (T* i = beg; i != end; ++i) ++be[(K::key(*i) >> s) & 255];
+    for (Ptr<T> i = beg; i != end; ++i) ++be[(K::key(*i) >> s) & 255];
     for (int k = 1; k < 256; ++k) { be[k] += be[k - 1]; bb[k] = be[k - 1]; }
     for (int k = 0; k < 256;) {
         if (bb[k] != be[k]) {
@@ -90,7 +90,7 @@ __device__ __forceinline__ void wave_rank_sort(T* beg, int n) {
 #endif
 
 template <class T, class K>
-PMX_HDN void radix_sort(T* beg, T* end, uint32_t* status) {
+PMX_HDN void radix_sort(Ptr<T> beg, Ptr<T> end, uint32_t* status) {
     if (end - beg <= 64) {
 #if PMX_W > 1
         if (end - beg > 1) wave_rank_sort<T, K>(beg, (int)(end - beg));
@@ -99,22 +99,22 @@ PMX_HDN void radix_sort(T* beg, T* end, uint32_t* status) {
 #endif
         return;
     }
-    T* stk_b[64];
-    T* stk_e[64];
+    Ptr<T> stk_b[64];
+    Ptr<T> stk_e[64];
     int stk_s[64];
     int sp = 0;
     stk_b[0] = beg; stk_e[0] = end; stk_s[0] = 56; sp = 1;
     while (sp > 0) {
         --sp;
-        T* b = stk_b[sp];
-        T* e = stk_e[sp];
+        Ptr<T> b = stk_b[sp];
+        Ptr<T> e = stk_e[sp];
         const int s = stk_s[sp];
         rs_sort_level<T, K>(b, e, s, stk_b, stk_e, stk_s, sp, 64, status);
     }
 }
 
-PMX_HD void radix_sort_128x(A128* beg, A128* end, uint32_t* status) { radix_sort<A128, KeyX>(beg, end, status); }
-PMX_HD void radix_sort_64(uint64_t* beg, uint64_t* end, uint32_t* status) { radix_sort<uint64_t, KeyU64>(beg, end, status); }
+PMX_HD void radix_sort_128x(Ptr<A128> beg, Ptr<A128> end, uint32_t* status) { radix_sort<A128, KeyX>(beg, end, status); }
+PMX_HD void radix_sort_64(Ptr<uint64_t> beg, Ptr<uint64_t> end, uint32_t* status) { radix_sort<uint64_t, KeyU64>(beg, end, status); }
 
 }  // namespace aln
 }  // namespace pmx

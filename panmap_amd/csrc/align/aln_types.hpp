@@ -10,6 +10,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../device/pmx_math.h"
 
 // PMX_W = lanes that cooperate on ONE read pair: 64 in the wave-per-pair kernels, 1 on the host and in the
@@ -56,6 +58,62 @@ PMX_HD void wave_sync() {}
 struct A128 {
     uint64_t x, y;
 };
+
+// ---------------------------------------------------------------------------------------- work pointers
+// Ptr<T> is how every per-pair work array is addressed.  In the wave-per-pair kernels and on the host it is
+// a plain T*.  In the thread-per-pair kernel it is IPtr<T>: a 32-bit LOGICAL byte offset into the thread's
+// work arena, translated on access to a 16-byte-granule interleaved address in the wave's HBM slab
+//     physical = wave_base + (offset / 16) * (64 * 16) + lane * 16 + offset % 16
+// so the 64 lanes of a wave touching the same logical offset share cache lines instead of owning one line
+// each (measured with per-thread contiguous slabs: 4450 line fills per pair, ~4.2 TB/s of HBM traffic; the
+// kernel was bound by exactly that).  Objects of size 1/2/4/8/16 with natural alignment never straddle a
+// granule, so operator[] can hand out real references; larger structs (Reg, Seed) stay in a small
+// per-thread contiguous region behind plain pointers.
+#if defined(PMX_THREAD_PER_PAIR) && defined(__HIPCC__)
+struct TppArena {
+    uint8_t* base;          // first wave's slab
+    uint32_t wave_stride;   // bytes per wave slab = 64 * per-thread logical arena size
+    uint32_t pad;
+};
+__constant__ TppArena c_tpp_arena;
+#endif
+#if defined(PMX_THREAD_PER_PAIR) && defined(__HIP_DEVICE_COMPILE__)
+#define PMX_INTERLEAVED 1
+template <class T>
+struct IPtr {
+    uint32_t o;
+    IPtr() = default;
+    __device__ explicit IPtr(uint32_t off) : o(off) {}
+    template <class U, class = typename std::enable_if<std::is_convertible<U*, T*>::value>::type>
+    __device__ IPtr(const IPtr<U>& q) : o(q.o) {}
+    __device__ __forceinline__ static T* phys(uint32_t off) {
+        uint8_t* wave_base = c_tpp_arena.base + (size_t)blockIdx.x * c_tpp_arena.wave_stride;   // uniform
+        const uint32_t vo = ((threadIdx.x & 63u) << 4) + ((off >> 4) << 10) + (off & 15u);
+        return reinterpret_cast<T*>(wave_base + vo);
+    }
+    __device__ __forceinline__ T& operator*() const { return *phys(o); }
+    __device__ __forceinline__ T* operator->() const { return phys(o); }
+    template <class I> __device__ __forceinline__ T& operator[](I i) const { return *phys(o + (uint32_t)i * (uint32_t)sizeof(T)); }
+    template <class I> __device__ __forceinline__ IPtr operator+(I n) const { return IPtr(o + (uint32_t)n * (uint32_t)sizeof(T)); }
+    template <class I> __device__ __forceinline__ IPtr operator-(I n) const { return IPtr(o - (uint32_t)n * (uint32_t)sizeof(T)); }
+    __device__ __forceinline__ int64_t operator-(const IPtr& q) const { return (int64_t)((int32_t)(o - q.o) / (int32_t)sizeof(T)); }
+    template <class I> __device__ __forceinline__ IPtr& operator+=(I n) { o += (uint32_t)n * (uint32_t)sizeof(T); return *this; }
+    template <class I> __device__ __forceinline__ IPtr& operator-=(I n) { o -= (uint32_t)n * (uint32_t)sizeof(T); return *this; }
+    __device__ __forceinline__ IPtr& operator++() { o += (uint32_t)sizeof(T); return *this; }
+    __device__ __forceinline__ IPtr& operator--() { o -= (uint32_t)sizeof(T); return *this; }
+    __device__ __forceinline__ bool operator==(const IPtr& q) const { return o == q.o; }
+    __device__ __forceinline__ bool operator!=(const IPtr& q) const { return o != q.o; }
+    __device__ __forceinline__ bool operator<(const IPtr& q) const { return o < q.o; }
+    __device__ __forceinline__ bool operator>(const IPtr& q) const { return o > q.o; }
+    __device__ __forceinline__ bool operator<=(const IPtr& q) const { return o <= q.o; }
+    __device__ __forceinline__ bool operator>=(const IPtr& q) const { return o >= q.o; }
+};
+template <class T> using Ptr = IPtr<T>;
+template <class U, class T> __device__ __forceinline__ IPtr<U> ptr_cast(IPtr<T> q) { return IPtr<U>(q.o); }
+#else
+template <class T> using Ptr = T*;
+template <class U, class T> PMX_HD U* ptr_cast(T* q) { return reinterpret_cast<U*>(q); }
+#endif
 
 // anchor flag bits in A128::y (mmpriv.h:17-23)
 #define PMX_SEED_LONG_JOIN (1ULL << 40)
@@ -188,47 +246,47 @@ struct Caps {
 struct Work {
     Caps caps;
     // sequences
-    uint8_t* qseq[2][2];   // [segment][strand] nt4 codes; strand 1 = reverse complement
+    Ptr<uint8_t> qseq[2][2];   // [segment][strand] nt4 codes; strand 1 = reverse complement
     int qlen[2];
     int n_segs;
     // sketch / seeds
-    A128* mv;
+    Ptr<A128> mv;
     int n_mv;
-    A128* sk_buf;          // minimizer window ring (w entries)
+    Ptr<A128> sk_buf;      // minimizer window ring (w entries)
     Seed* seeds;
     int n_seeds;
-    uint64_t* mini_pos;
+    Ptr<uint64_t> mini_pos;
     int n_mini_pos;
-    A128* heap;
+    Ptr<A128> heap;
     // anchors + chaining
-    A128* a;
-    A128* a2;
+    Ptr<A128> a;
+    Ptr<A128> a2;
     int64_t n_a;
-    int32_t *f, *t, *v, *p;
-    A128* z;
-    uint64_t* u;
-    uint64_t* u2;
+    Ptr<int32_t> f, t, v, p;
+    Ptr<A128> z;
+    Ptr<uint64_t> u;
+    Ptr<uint64_t> u2;
     int n_u;
     // regions
     Reg* regs0;
     Reg* regs[2];
     Reg* reg_tmp;
     int n_regs0, n_regs[2];
-    A128* seg_a[2];
-    uint64_t* seg_u[2];
+    Ptr<A128> seg_a[2];
+    Ptr<uint64_t> seg_u[2];
     int seg_n_a[2], seg_n_u[2];
-    uint64_t* aux64;       // small sort scratch (max_reg * 2)
-    A128* aux128;
+    Ptr<uint64_t> aux64;   // small sort scratch (max_reg * 2)
+    Ptr<A128> aux128;
     // DP
-    int8_t *du, *dv, *dx, *dy, *dx2, *dy2, *ds;
-    uint8_t *sf, *qr;
-    int32_t* H;
-    int32_t *off, *off_end;
-    uint8_t* tb;           // traceback matrix (global)
+    Ptr<int8_t> du, dv, dx, dy, dx2, dy2, ds;
+    Ptr<uint8_t> sf, qr;
+    Ptr<int32_t> H;
+    Ptr<int32_t> off, off_end;
+    Ptr<uint8_t> tb;       // traceback matrix (global)
     size_t tb_cap;
-    uint8_t* tseq;
-    uint32_t* cig_tmp;     // ez->cigar
-    uint32_t* cig_pool;    // n_cig_slots * max_cigar
+    Ptr<uint8_t> tseq;
+    Ptr<uint32_t> cig_tmp;   // ez->cigar
+    Ptr<uint32_t> cig_pool;  // n_cig_slots * max_cigar
     int cig_next;
     uint32_t status;
     int rep_len;

@@ -26,6 +26,7 @@ struct AlignArgs {
     unsigned long long* dp_count;   // round 0: slot allocator; round >= 1: length of dp_next_list
     uint32_t dp_slot_cap;
     int dp_round;
+
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
     int paired;
     int revcomp_mate2;
@@ -48,6 +49,28 @@ __global__ void k_align_reads_t1(AlignArgs A);
 __global__ void k_align_reads_t1_w4(AlignArgs A);
 __global__ void k_align_reads_tpp(AlignArgs A);
 __global__ void k_align_dp_serve(AlignArgs A);
+void tpp_set_arena(uint8_t* base, size_t wave_stride, hipStream_t stream);
+
+// bytes of the traceback matrix ksw_extd2 needs for a request (same n_col as ksw2_extd2_sse.c:95-98)
+PMX_HD size_t dp_request_tb_bytes(int qlen, int tlen, int w) {
+    if (qlen <= 0 || tlen <= 0) return 0;
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    int n_col = qlen < tlen ? qlen : tlen;
+    n_col = (((n_col < w + 1 ? n_col : w + 1) + 15) / 16 + 1) * 16;
+    return (size_t)(qlen + tlen - 1) * (size_t)n_col;
+}
+
+// append a served DP to its slot's result list
+PMX_HD void dp_store_result(const AlignArgs& A, int64_t slot, const DpReq* rq, const Ez& ez, const uint32_t* cigar, uint32_t status) {
+    const uint32_t n = A.dp_ncached[slot];
+    if (n >= PMX_DP_MAX_CALLS) return;
+    DpRes& R = A.dp_res_base[(size_t)slot * PMX_DP_MAX_CALLS + n];
+    const bool bad = (status & PMX_ST_OVERFLOW) || ez.n_cigar > PMX_DP_MAX_CIGAR || n != rq->call;
+    R.ez = ez;
+    R.key = bad ? 0xffffffffu : rq->key;
+    if (!bad) for (int i = 0; i < ez.n_cigar; ++i) R.cigar[i] = cigar[i];
+    A.dp_ncached[slot] = n + 1;
+}
 
 }  // namespace aln
 }  // namespace pmx

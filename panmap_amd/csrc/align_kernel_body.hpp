@@ -22,7 +22,11 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
     const int n_segs = A.paired ? 2 : 1;
 
     for (int64_t it = blockIdx.x; it < A.n_items; it += gridDim.x) {
-        const int64_t item = A.worklist ? (int64_t)A.worklist[it] : it;
+        int64_t item = A.worklist ? (int64_t)A.worklist[it] : it;
+        if (A.dp_slot_pairs) {   // worklist holds DP-service slots
+            item = (int64_t)A.dp_slot_pairs[item];
+            if (item == 0xffffffffLL) continue;   // slot whose pair already went to the retry list
+        }
         __syncthreads();
         bind_work(W, A.layout, fast, slow);
         W.n_segs = n_segs;

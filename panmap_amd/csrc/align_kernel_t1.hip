@@ -29,6 +29,8 @@ __global__ void __launch_bounds__(64, 4) k_align_dp_serve(AlignArgs A) {
         W.prof = nullptr;
         const int qlen = rq->qlen, tlen = rq->tlen;
         const int t_off = (qlen + 15) & ~15;
+        const size_t tb_need = dp_request_tb_bytes(qlen, tlen, rq->w);
+        if (tb_need <= A.layout.tb_fast_cap) W.tb = fast + A.layout.tb_fast.off;   // traceback matrix in LDS when it fits
         uint8_t* sq = W.qseq[0][0]; PMX_LDS(sq);
         __syncthreads();
         for (int i = lane; i < t_off + tlen; i += 64) sq[i] = rq->seq[i];
@@ -38,16 +40,8 @@ __global__ void __launch_bounds__(64, 4) k_align_dp_serve(AlignArgs A) {
                   rq->zdrop, rq->end_bonus, rq->flag, ez);
         __syncthreads();
         if (lane == 0) {
-            const uint32_t n = A.dp_ncached[slot];
-            if (n < PMX_DP_MAX_CALLS) {
-                DpRes& R = A.dp_res_base[(size_t)slot * PMX_DP_MAX_CALLS + n];
-                const bool bad = (W.status & PMX_ST_OVERFLOW) || ez.n_cigar > PMX_DP_MAX_CIGAR || n != rq->call;
-                R.ez = ez;
-                R.key = bad ? 0xffffffffu : rq->key;
-                const uint32_t* cg = W.cig_tmp; PMX_LDS(cg);
-                if (!bad) for (int i = 0; i < ez.n_cigar; ++i) R.cigar[i] = cg[i];
-                A.dp_ncached[slot] = n + 1;
-            }
+            const uint32_t* cg = W.cig_tmp; PMX_LDS(cg);
+            dp_store_result(A, slot, rq, ez, cg, W.status);
         }
     }
 }

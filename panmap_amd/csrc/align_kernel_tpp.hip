@@ -13,16 +13,21 @@
 
 #include "align/aln_host.hpp"
 #include "align_kernel.h"
+#include "device/dev_util.hpp"
 
 namespace pmx {
 namespace aln {
 
-__global__ void __launch_bounds__(64)
+// Per-thread memory: the interleaved arena is addressed through IPtr (aln_types.hpp) relative to the wave's
+// slab in c_tpp_arena; `raw` is the thread's contiguous region for the Reg / Seed arrays.
+#ifndef PMX_TPP_OCC
+#define PMX_TPP_OCC 4   // waves per SIMD the register allocation targets (latency-bound kernel: occupancy hides L2 round trips)
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PMX_TPP_OCC)))
 k_align_reads_tpp(AlignArgs A) {
     const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t n_threads = (int64_t)gridDim.x * 64;
-    uint8_t* slab = A.slow_base + (size_t)tid * A.slow_stride;
-    const size_t fast_sz = (A.layout.fast_bytes + 63) & ~(size_t)63;
+    uint8_t* raw = A.slow_base + (size_t)tid * A.slow_stride;
     const int n_segs = A.paired ? 2 : 1;
 
     for (int64_t it = tid; it < A.n_items; it += n_threads) {
@@ -34,7 +39,7 @@ k_align_reads_tpp(AlignArgs A) {
             if (item == 0xffffffffLL) continue;
         }
         Work W;
-        bind_work(W, A.layout, slab, slab + fast_sz);
+        bind_work(W, A.layout, nullptr, nullptr, raw);
         W.n_segs = n_segs;
         W.prof = nullptr;
         W.dp_req_base = A.dp_req_base;
@@ -57,8 +62,8 @@ k_align_reads_tpp(AlignArgs A) {
                 const int len = W.qlen[s];
                 const uint64_t* rw = A.words + A.woff[r];
                 const uint32_t* ra = A.amb + A.woff[r];
-                uint8_t* fwd = W.qseq[s][0];
-                uint8_t* rev = W.qseq[s][1];
+                Ptr<uint8_t> fwd = W.qseq[s][0];
+                Ptr<uint8_t> rev = W.qseq[s][1];
                 const bool rc = A.revcomp_mate2 && s == 1;
                 uint64_t cw = 0;
                 uint32_t ca = 0;
@@ -104,7 +109,7 @@ k_align_reads_tpp(AlignArgs A) {
                     const uint64_t coff = atomicAdd(A.cigar_used, (unsigned long long)g.n_cigar);
                     rec.cigar_off = (uint32_t)coff;
                     if (coff + g.n_cigar <= A.cigar_cap) {
-                        const uint32_t* cg = reg_cigar(W, g);
+                        Ptr<const uint32_t> cg = reg_cigar(W, g);
                         for (uint32_t i = 0; i < g.n_cigar; ++i) A.cigars[coff + i] = cg[i];
                     } else {
                         rec.flags |= PMX_REC_OVERFLOW;
@@ -115,6 +120,16 @@ k_align_reads_tpp(AlignArgs A) {
             A.records[r] = rec;
         }
     }
+}
+
+// host side of c_tpp_arena (the symbol lives in this translation unit)
+void tpp_set_arena(uint8_t* base, size_t wave_stride, hipStream_t stream) {
+    TppArena h;
+    h.base = base;
+    h.wave_stride = (uint32_t)wave_stride;
+    h.pad = 0;
+    PMX_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tpp_arena), &h, sizeof(h), 0, hipMemcpyHostToDevice, stream));
+    PMX_HIP(hipStreamSynchronize(stream));   // h is a stack object
 }
 
 }  // namespace aln

@@ -30,7 +30,7 @@ struct pmx_aligner {
     DevBuf<AlnRecord> records;
     DevBuf<uint32_t> cigars;
     DevBuf<unsigned long long> cigar_used;
-    DevBuf<uint8_t> slow, slow2, slab0;
+    DevBuf<uint8_t> slow, slow2, slab0, slab_raw;
     DevBuf<uint32_t> retry_list2;
     DevBuf<uint8_t> dp_req;
     DevBuf<DpRes> dp_res;
@@ -206,13 +206,23 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         al->last_dp_requests = 0;
         al->last_dp_rounds = 0;
         if (use_tier0) {   // tier 0: thread per pair + DP service rounds
-            int tpp_waves = 4;
+            int tpp_waves = 16;   // 4 per SIMD: what k_align_reads_tpp's register allocation targets (PMX_TPP_OCC)
             if (const char* e = getenv("PMX_ALIGN_TPP_WAVES")) tpp_waves = atoi(e);
             const int64_t max_grid = std::min<int64_t>((int64_t)ctx->n_cu * tpp_waves, (n_items + 63) / 64);
-            const size_t tpp_stride = ((compact.fast_bytes + 63) & ~(size_t)63) + ((compact.slow_bytes - compact.tb_cap + 255) & ~(size_t)255);
-            al->slab0.ensure(tpp_stride * (size_t)max_grid * 64);
-            const size_t dp_lds = PMX_ALIGN_WORK_BYTES + compact.fast_bytes + 16;
-            const size_t dp_stride = (compact.slow_bytes + 255) & ~(size_t)255;
+            // thread-per-pair layout: interleaved arena per wave + a small contiguous struct region per thread
+            size_t tpp_tb = 0;   // in-lane DPs measured slower than request + replay (divergence): off
+            if (const char* e = getenv("PMX_ALIGN_TPP_TB")) tpp_tb = (size_t)atoll(e);
+            const Layout tpp_layout = plan_layout_tpp((int)rs->max_len, n_segs, al->opt, tpp_tb);
+            const size_t tpp_wave_stride = tpp_arena_bytes(tpp_layout) * 64;
+            const size_t tpp_raw_stride = (tpp_layout.raw_bytes + 255) & ~(size_t)255;
+            al->slab0.ensure(tpp_wave_stride * (size_t)max_grid);
+            al->slab_raw.ensure(tpp_raw_stride * (size_t)max_grid * 64);
+            tpp_set_arena(al->slab0.p, tpp_wave_stride, ctx->stream);
+            const Layout dp_layout = plan_layout_dp((int)rs->max_len, n_segs, al->opt);
+            const size_t dp_lds = PMX_ALIGN_WORK_BYTES + dp_layout.fast_bytes + 16;
+            const size_t dp_stride = (dp_layout.slow_bytes + 255) & ~(size_t)255;
+            int64_t small_rounds = 2048;   // fewer pairs than this cannot fill the chip thread-per-pair: wave tier
+            if (const char* e = getenv("PMX_ALIGN_TPP_MIN")) small_rounds = atoll(e);
             const int64_t dp_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dp_lds);
             if (use_dp_service) {
                 al->dp_req.ensure((size_t)n_items * sizeof(DpReq));
@@ -230,11 +240,11 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             A.dp_count = al->retry_count.p + 1;
             A.retry_list = al->retry_list2.p;
             A.retry_count = al->retry_count.p;
-            A.layout = compact;
+            A.layout = tpp_layout;
             auto launch_tpp = [&](int round, int64_t n_work, const uint32_t* worklist, uint32_t* next_list) {
                 int64_t grid = std::min<int64_t>(max_grid, (n_work + 63) / 64);
-                A.slow_stride = tpp_stride;
-                A.slow_base = al->slab0.p;
+                A.slow_stride = tpp_raw_stride;
+                A.slow_base = al->slab_raw.p;
                 A.n_items = n_work;
                 A.worklist = worklist;
                 A.dp_round = round;
@@ -249,8 +259,14 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             const uint32_t* cur = nullptr;   // round 1 serves slots 0..n_dp-1
             uint32_t* lists[2] = {al->dp_list_a.p, al->dp_list_b.p};
             int round = 1;
+            int64_t n_small = 0;
             while (n_dp > 0) {   // ends by itself: a pair posts at most PMX_DP_MAX_CALLS requests, then goes to the wave tier
+                if (n_dp < small_rounds) {   // remainder: wave-per-pair kernel over the slots (dp_slot_pairs maps them to pairs)
+                    n_small = n_dp;
+                    break;
+                }
                 al->last_dp_requests += n_dp;
+                A.layout = dp_layout;
                 A.slow_stride = dp_stride;
                 A.slow_base = al->slow.p;
                 A.n_items = n_dp;
@@ -258,15 +274,29 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dp_max_grid, n_dp)), dim3(64), dp_lds, ctx->stream, A);
                 PMX_HIP(hipGetLastError());
                 uint32_t* next = lists[round & 1];
+                A.layout = tpp_layout;
                 launch_tpp(round, n_dp, cur, next);
                 read_counts(n_t1, n_dp, false);
                 cur = next;
                 ++round;
             }
             al->last_dp_rounds = round - 1;
-            PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-            A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
+            A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr;
             A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
+            if (n_small > 0) {   // their capacity overflows (rare) join the tier-1 retry list through counter [0]
+                if (!cur) {      // round-1 remainder: slots are 0..n-1
+                    std::vector<uint32_t> iota((size_t)n_small);
+                    for (int64_t i = 0; i < n_small; ++i) iota[(size_t)i] = (uint32_t)i;
+                    PMX_HIP(hipMemcpyAsync(lists[0], iota.data(), sizeof(uint32_t) * (size_t)n_small, hipMemcpyHostToDevice, ctx->stream));
+                    PMX_HIP(hipStreamSynchronize(ctx->stream));
+                    cur = lists[0];
+                }
+                launch(kern_t1, compact, n_small, cur, al->retry_list2.p, al->slow);   // A.dp_slot_pairs still set
+                int64_t unused2 = 0;
+                read_counts(n_t1, unused2, false);
+            }
+            A.dp_slot_pairs = nullptr;
+            PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
             t1_list = al->retry_list2.p;
             al->last_tpp_retry = n_t1;
         }

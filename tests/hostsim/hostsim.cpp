@@ -29,6 +29,8 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
 #ifdef PMX_HOSTSIM_TPP
     Layout L = plan_layout_compact(max_len, n_segs, o);
     L.slow_bytes += 64;
+    const Layout Lserve = L;
+    L.tb_cap = 8 * 1024;   // the thread-per-pair kernel's in-lane DP limit (api_align.hip: tpp_layout)
     std::vector<uint8_t> dp_req(sizeof(DpReq));
     std::vector<DpRes> dp_res(PMX_DP_MAX_CALLS);
     int64_t n_requests = 0, n_wave = 0;
@@ -75,7 +77,7 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
             if ((int)rq->call != n_cached) return -4;
             Work W2;
             memset(&W2, 0, sizeof(W2));
-            bind_work(W2, L, fast.data(), slow.data());
+            bind_work(W2, Lserve, fast.data(), slow.data());
             std::vector<uint8_t> seq(rq->seq, rq->seq + PMX_DP_SEQ_BYTES);
             Ez ez;
             ksw_extd2(W2, rq->qlen, seq.data(), rq->tlen, seq.data() + ((rq->qlen + 15) & ~15), o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2,
