@@ -256,7 +256,7 @@ PMX_HD int anchor_gap(Ptr<const A128> a, int i) {   // query advance minus refer
     return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - ((int32_t)a[i].x - (int32_t)a[i - 1].x);
 }
 
-// collect_long_gaps + mm_filter_bad_seeds (align.c:374-427).  K[] lives in W.aux64 (as int32).
+// collect_long_gaps + mm_filter_bad_seeds (align.c:374-427).  K[] lives in the idle chain-DP array W.f.
 PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, Ptr<const A128> a, int min_gap, Ptr<int32_t> K, int cap) {
     PMX_LDS(&W); PMX_LDS(a); PMX_LDS(K);
     int n = 0;

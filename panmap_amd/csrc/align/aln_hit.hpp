@@ -106,7 +106,7 @@ PMX_HDN void set_parent(Work& W, float mask_level, int mask_len, int n, Reg* r, 
     if (n <= 0) return;
     for (int i = 0; i < n; ++i) r[i].id = i;
     Ptr<uint64_t> cov = W.aux64; PMX_LDS(cov);
-    Ptr<int32_t> w = ptr_cast<int32_t>(W.aux64 + W.caps.max_reg);
+    Ptr<int32_t> w = W.aux32; PMX_LDS(w);
     w[0] = 0;
     r[0].parent = 0;
     int k = 1;
@@ -176,7 +176,7 @@ PMX_HDN void sync_regs(Work& W, int n_regs, Reg* regs) {
     int max_id = -1;
     for (int i = 0; i < n_regs; ++i) max_id = max_id > regs[i].id ? max_id : regs[i].id;
     const int n_tmp = max_id + 1;
-    Ptr<int32_t> tmp = ptr_cast<int32_t>(W.aux64); PMX_LDS(tmp);
+    Ptr<int32_t> tmp = W.aux32; PMX_LDS(tmp);
     if (n_tmp > W.caps.max_reg * 4) { W.status |= PMX_ST_OVERFLOW; return; }
     for (int i = 0; i < n_tmp; ++i) tmp[i] = -1;
     for (int i = 0; i < n_regs; ++i)

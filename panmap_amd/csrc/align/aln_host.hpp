@@ -186,7 +186,7 @@ struct Layout {
     size_t tb_cap = 0;
     struct Ent { uint32_t space; size_t off; };
     Ent qseq, mv, sk_buf, seeds, mini_pos, heap, a, a2, f, t, v, p, z, u, u2, regs0, regs1, regs2, reg_tmp, seg_a0, seg_a1, seg_u0,
-        seg_u1, aux64, aux128, du, sf, qr, H, off_, tseq, cig_tmp, cig_pool, tb, tb_fast;
+        seg_u1, aux64, aux32, aux128, du, sf, qr, H, off_, tseq, cig_tmp, cig_pool, tb, tb_fast;
     size_t tb_fast_cap = 0;   // DP-service layout only: LDS traceback area for small DPs
 };
 
@@ -238,6 +238,7 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
     place(L.off_, 8 * (size_t)(c.max_qlen + c.max_tlen), PMX_FAST);
     place(L.cig_tmp, 4 * (size_t)c.max_cigar, PMX_FAST);
     place(L.aux64, 8 * (size_t)c.max_reg * 8, PMX_FAST);
+    place(L.aux32, 4 * (size_t)c.max_reg * 4, PMX_FAST);
     place(L.aux128, sizeof(A128) * c.max_reg * 4, PMX_FAST);
     place(L.u, 8 * (size_t)c.max_reg * 4, PMX_FAST);
     place(L.u2, 8 * (size_t)c.max_reg * 4, PMX_FAST);
@@ -295,6 +296,7 @@ inline Layout plan_layout_compact(int max_read_len, int n_segs, const Opt& o) {
     put(L.seg_u1, 8 * (size_t)c.max_reg * 4, top);
     put(L.u, 8 * (size_t)c.max_reg * 4, top);
     put(L.aux64, 8 * (size_t)c.max_reg * 8, top);
+    put(L.aux32, 4 * (size_t)c.max_reg * 4, top);
     put(L.aux128, sizeof(A128) * c.max_reg * 4, top);
     put(L.cig_pool, 4 * (size_t)c.max_cigar * c.n_cig_slots, top);
     // overlay region
@@ -329,9 +331,17 @@ inline Layout plan_layout_compact(int max_read_len, int n_segs, const Opt& o) {
 // DP-service layout (k_align_dp_serve): only what ksw_extd2 touches; the request's sequences go to the qseq
 // block; DPs whose traceback matrix fits tb_fast_cap keep it in LDS (the serial traceback walk is
 // latency-bound), larger ones use the wave's HBM slab.  Capacities as in the compact layout.
-inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o) {
+// small_qlen > 0 selects the SMALL class (extensions over a few dozen bases: nearly all requests), served by
+// the register-resident ksw_extd2_reg: only the request's sequences, off[]/off_end[], the CIGAR buffer and an
+// 8 KB traceback area live in LDS.
+inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o, int small_qlen = 0, int small_tlen = 0) {
     Layout L = plan_layout_compact(max_read_len, n_segs, o);
-    const Caps& c = L.caps;
+    Caps& c = L.caps;
+    if (small_qlen > 0) {
+        c.max_qlen = small_qlen;
+        c.max_tlen = small_tlen + 16;
+        L.tb_cap = 0;
+    }
     size_t top = 0;
     auto put = [&](Layout::Ent& e, size_t bytes) {
         bytes = (bytes + 15) & ~(size_t)15;
@@ -340,16 +350,19 @@ inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o) {
         top += bytes;
     };
     const Layout::Ent none{PMX_FAST, 0};   // unused arrays alias offset 0 (never dereferenced by ksw_extd2)
-    L.mv = L.a = L.regs0 = L.regs1 = L.regs2 = L.reg_tmp = L.seg_a0 = L.seg_a1 = L.seg_u0 = L.seg_u1 = L.u = L.aux64 = L.aux128 = none;
+    L.mv = L.a = L.regs0 = L.regs1 = L.regs2 = L.reg_tmp = L.seg_a0 = L.seg_a1 = L.seg_u0 = L.seg_u1 = L.u = L.aux64 = L.aux32 = L.aux128 = none;
     L.cig_pool = L.sk_buf = L.seeds = L.heap = L.f = L.p = L.t = L.v = L.z = L.a2 = L.u2 = L.tseq = L.mini_pos = none;
-    put(L.qseq, (size_t)std::max(4 * c.max_qlen, 512));
-    put(L.du, (size_t)7 * (c.max_tlen + 32));
-    put(L.sf, (size_t)c.max_tlen + 32);
-    put(L.qr, (size_t)c.max_tlen + 64);
-    put(L.H, 4 * (size_t)(c.max_tlen + 32));
+    put(L.qseq, small_qlen > 0 ? (size_t)(((small_qlen + 15) & ~15) + small_tlen) : (size_t)std::max(4 * c.max_qlen, 512));
+    if (small_qlen > 0) L.du = L.sf = L.qr = L.H = none;   // register-resident DP
+    else {
+        put(L.du, (size_t)7 * (c.max_tlen + 32));
+        put(L.sf, (size_t)c.max_tlen + 32);
+        put(L.qr, (size_t)c.max_tlen + 64);
+        put(L.H, 4 * (size_t)(c.max_tlen + 32));
+    }
     put(L.off_, 8 * (size_t)(c.max_qlen + c.max_tlen));
     put(L.cig_tmp, 4 * (size_t)c.max_cigar);
-    L.tb_fast_cap = 12 * 1024;
+    L.tb_fast_cap = small_qlen > 0 ? 8 * 1024 : 12 * 1024;
     put(L.tb_fast, L.tb_fast_cap);
     L.fast_bytes = top;
     L.tb.space = PMX_SLOW;
@@ -363,13 +376,18 @@ inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o) {
 // Reg / Seed struct arrays, which live in a small per-thread contiguous RAW region behind plain pointers.
 // tb_bytes > 0 adds a per-thread traceback area (in-lane DPs; off by default).
 inline Layout plan_layout_tpp(int max_read_len, int n_segs, const Opt& o, size_t tb_bytes) {
-    Layout L = plan_layout_compact(max_read_len, n_segs, o);
+    Layout L = plan_layout_compact(max_read_len, n_segs, o);   // capacities
     const Caps& c = L.caps;
-    size_t raw = 0;
+    size_t raw = 0, top = 0;
     auto put_raw = [&](Layout::Ent& e, size_t bytes) {
         e.space = PMX_RAW;
         e.off = raw;
         raw += (bytes + 15) & ~(size_t)15;
+    };
+    auto put = [&](Layout::Ent& e, size_t bytes) {   // one region each, no overlays (see IPtr)
+        e.space = PMX_FAST;
+        e.off = top;
+        top += (bytes + 15) & ~(size_t)15;
     };
     put_raw(L.regs0, sizeof(Reg) * c.max_reg);
     put_raw(L.regs1, sizeof(Reg) * c.max_reg);
@@ -377,9 +395,40 @@ inline Layout plan_layout_tpp(int max_read_len, int n_segs, const Opt& o, size_t
     put_raw(L.reg_tmp, sizeof(Reg) * c.max_reg);
     put_raw(L.seeds, sizeof(Seed) * c.max_mini);
     L.raw_bytes = raw;
-    // (the FAST offsets of the moved arrays stay reserved: simpler than re-packing, ~6 KB of address space)
+    put(L.qseq, (size_t)4 * c.max_qlen);
+    put(L.tseq, (size_t)c.max_tlen + 32);
+    put(L.mv, sizeof(A128) * c.max_mini);
+    put(L.sk_buf, sizeof(A128) * 32);
+    put(L.heap, sizeof(A128) * c.max_mini);
+    put(L.mini_pos, 8 * (size_t)c.max_mini);
+    put(L.a, sizeof(A128) * c.max_anchor);
+    put(L.a2, sizeof(A128) * c.max_anchor);
+    put(L.z, sizeof(A128) * c.max_anchor);
+    put(L.f, 16 * (size_t)c.max_anchor);
+    L.p = L.f; L.p.off += 4 * (size_t)c.max_anchor;
+    L.t = L.f; L.t.off += 8 * (size_t)c.max_anchor;
+    L.v = L.f; L.v.off += 12 * (size_t)c.max_anchor;
+    put(L.u, 8 * (size_t)c.max_reg * 4);
+    put(L.u2, 8 * (size_t)c.max_reg * 4);
+    put(L.seg_a0, sizeof(A128) * c.max_anchor);
+    L.seg_a1 = L.seg_a0;
+    put(L.seg_u0, 8 * (size_t)c.max_reg * 4);
+    put(L.seg_u1, 8 * (size_t)c.max_reg * 4);
+    put(L.aux64, 8 * (size_t)c.max_reg * 8);
+    put(L.aux32, 4 * (size_t)c.max_reg * 4);
+    put(L.aux128, sizeof(A128) * c.max_reg * 4);
+    put(L.cig_tmp, 4 * (size_t)c.max_cigar);
+    put(L.cig_pool, 4 * (size_t)c.max_cigar * c.n_cig_slots);
+    // DP arrays: only touched by in-lane DPs (tb_bytes > 0)
+    put(L.du, (size_t)7 * (c.max_tlen + 32));
+    put(L.sf, (size_t)c.max_tlen + 32);
+    put(L.qr, (size_t)c.max_tlen + 64);
+    put(L.H, 4 * (size_t)(c.max_tlen + 32));
+    put(L.off_, 8 * (size_t)(c.max_qlen + c.max_tlen));
+    put(L.tb, tb_bytes + 16);
     L.tb_cap = tb_bytes;
-    L.slow_bytes = L.tb.off + tb_bytes;   // mini_pos, then the traceback area
+    L.fast_bytes = top;
+    L.slow_bytes = 0;
     return L;
 }
 
@@ -410,7 +459,7 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow, ui
     W.reg_tmp = PMX_AT_RAW(Reg, reg_tmp);
     W.seg_a[0] = PMX_AT(A128, seg_a0); W.seg_a[1] = PMX_AT(A128, seg_a1);
     W.seg_u[0] = PMX_AT(uint64_t, seg_u0); W.seg_u[1] = PMX_AT(uint64_t, seg_u1);
-    W.aux64 = PMX_AT(uint64_t, aux64); W.aux128 = PMX_AT(A128, aux128);
+    W.aux64 = PMX_AT(uint64_t, aux64); W.aux32 = PMX_AT(int32_t, aux32); W.aux128 = PMX_AT(A128, aux128);
     Ptr<int8_t> d = PMX_AT(int8_t, du);
     const int T = L.caps.max_tlen + 32;
     W.du = d; W.dv = d + T; W.dx = d + 2 * T; W.dy = d + 3 * T; W.dx2 = d + 4 * T; W.dy2 = d + 5 * T; W.ds = d + 6 * T;

@@ -327,13 +327,279 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
 }
 
 
+#if PMX_W == 64
+// ------------------------------------------------------------------------------------------------------
+// ksw_extd2 for short targets, REGISTER-resident: lane L of the wave owns target columns t = L + 64*c
+// (c < NC), so the seven int8 difference arrays and H[] of ksw2_extd2_sse.c are per-lane registers, the
+// t-1 neighbours of the recurrence are one lane away (shuffle of the previous diagonal's values) and the
+// scalar reads the reference makes on its arrays (x[st-1], H[en0-1], u[en0], v[last_H0_t], ...) are
+// v_readlane at a uniform index.  No LDS round trips or barriers inside the anti-diagonal loop except the
+// traceback byte each active lane stores.  Semantics are those of ksw_extd2 above, statement for statement
+// (same 16-cell rounding of [st,en], same stale s[] cells, same candidate order of the exact max).
+// Requires ((tlen + 15) / 16) * 16 <= 64 * NC.
+__device__ __forceinline__ int rl_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+template <int NC>
+__device__ __forceinline__ int rd_col(const int (&a)[NC], int idx) {   // a[] indexed by target column, uniform idx
+    if (NC == 1) return rl_i32(a[0], idx);
+    return idx < 64 ? rl_i32(a[0], idx) : rl_i32(a[NC - 1], idx - 64);
+}
+
+template <int NC>
+__device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+                              int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+    static_assert(NC == 1 || NC == 2, "one or two target columns per lane");
+    PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
+    const int lane = lane_id();
+    const int approx_max = !!(flag & PMX_EZ_APPROX_MAX);
+    ez_reset(ez);
+    if (qlen <= 0 || tlen <= 0) return;
+    if (q2 + e2 < q + e) { int8_t t_ = q; q = q2; q2 = t_; t_ = e; e = e2; e2 = t_; }
+    const int qe = q + e;
+    const int8_t sc_mch = mat[0], sc_mis = mat[1], sc_N = mat[24] == 0 ? (int8_t)-e2 : mat[24];
+    if (w < 0) w = tlen > qlen ? tlen : qlen;
+    const int wl = w, wr = w;
+    const int tlen_ = (tlen + 15) / 16;
+    int n_col_ = qlen < tlen ? qlen : tlen;
+    n_col_ = ((n_col_ < w + 1 ? n_col_ : w + 1) + 15) / 16 + 1;
+    const int n_col = n_col_ * 16;
+    {
+        int min_sc = mat[1];
+        for (int t = 1; t < 25; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
+        if (-min_sc > 2 * (q + e)) return;
+    }
+    if (tlen_ * 16 > 64 * NC || qlen + tlen > W.caps.max_qlen + W.caps.max_tlen || (size_t)(qlen + tlen - 1) * (size_t)n_col > W.tb_cap) {
+        W.status |= PMX_ST_OVERFLOW;
+        ez.zdropped = 1;
+        return;
+    }
+    int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+    if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+    const int long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+    int32_t *off = W.off, *off_end = W.off_end;
+    PMX_LDS(off); PMX_LDS(off_end);
+    uint8_t* p = W.tb;
+
+    // per-column state (int8 values of the reference kept sign-extended in 32-bit registers)
+    int u[NC], v[NC], x[NC], y[NC], x2[NC], y2[NC], s[NC], H[NC], sf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int t = c * 64 + lane;
+        u[c] = v[c] = x[c] = y[c] = (int8_t)(-q - e);
+        x2[c] = y2[c] = (int8_t)(-q2 - e2);
+        H[c] = PMX_KSW_NEG_INF;
+        s[c] = 0;
+        sf[c] = t < tlen ? target[t] : 0;
+    }
+    const int8_t init_ue = (int8_t)(-q - e), init_ue2 = (int8_t)(-q2 - e2);
+
+    int last_st = -1, last_en = -1;
+    int32_t H0 = 0, last_H0_t = 0;
+    for (int r = 0; r < qlen + tlen - 1; ++r) {
+        int st = 0, en = tlen - 1;
+        if (st < r - qlen + 1) st = r - qlen + 1;
+        if (en > r) en = r;
+        if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
+        if (en > (r + wl) >> 1) en = (r + wl) >> 1;
+        if (st > en) { ez.zdropped = 1; break; }
+        const int st0 = st, en0 = en;
+        st = st / 16 * 16;
+        en = (en + 16) / 16 * 16 - 1;
+        // boundary conditions (ksw2_extd2_sse.c:150-166)
+        const int8_t gap_head = r == 0 ? init_ue : r < long_thres ? (int8_t)-e : r == long_thres ? (int8_t)long_diff : (int8_t)-e2;
+        int8_t x1, x21, v1;
+        if (st > 0) {
+            if (st - 1 >= last_st && st - 1 <= last_en) {
+                x1 = (int8_t)rd_col<NC>(x, st - 1); x21 = (int8_t)rd_col<NC>(x2, st - 1); v1 = (int8_t)rd_col<NC>(v, st - 1);
+            } else { x1 = init_ue; x21 = init_ue2; v1 = init_ue; }
+        } else { x1 = init_ue; x21 = init_ue2; v1 = gap_head; }
+        if (en >= r) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c * 64 + lane == r) { y[c] = init_ue; y2[c] = init_ue2; u[c] = gap_head; }
+        }
+        // scores of [st0, s_end); cells of [st, st0) keep whatever s[] held (as the SSE code does)
+        const int s_end = st0 + ((en0 - st0) / 16 + 1) * 16;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int t = c * 64 + lane;
+            if (t >= st0 && t < s_end) {
+                const int sq = sf[c];
+                const int sq2 = t <= r ? (int)query[r - t] : 0;   // qr[] padding is 0 beyond the query
+                int8_t val = sq == sq2 ? sc_mch : sc_mis;
+                if (sq == 4 || sq2 == 4) val = sc_N;
+                s[c] = val;
+            }
+        }
+        // the t-1 neighbours, read from the previous diagonal's state before anything is updated
+        int xs[NC], vs[NC], x2s[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            xs[c] = __shfl_up(x[c], 1);
+            vs[c] = __shfl_up(v[c], 1);
+            x2s[c] = __shfl_up(x2[c], 1);
+        }
+        if (NC == 2) {
+            const int bx = rl_i32(x[0], 63), bv = rl_i32(v[0], 63), bx2 = rl_i32(x2[0], 63);
+            if (lane == 0) { xs[NC - 1] = bx; vs[NC - 1] = bv; x2s[NC - 1] = bx2; }
+        }
+        // core recurrence on [st, en]
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int t = c * 64 + lane;
+            if (t >= st && t <= en) {
+                int8_t z = (int8_t)s[c];
+                const int8_t xt1 = t == st ? x1 : (int8_t)xs[c];
+                const int8_t vt1 = t == st ? v1 : (int8_t)vs[c];
+                const int8_t x2t1 = t == st ? x21 : (int8_t)x2s[c];
+                const int8_t ut = (int8_t)u[c];
+                int8_t a = (int8_t)(xt1 + vt1);
+                int8_t b = (int8_t)((int8_t)y[c] + ut);
+                int8_t a2 = (int8_t)(x2t1 + vt1);
+                int8_t b2 = (int8_t)((int8_t)y2[c] + ut);
+                uint8_t d;
+                if (!(flag & PMX_EZ_RIGHT)) {
+                    d = a > z ? 1 : 0;
+                    z = z > a ? z : a;
+                    d = b > z ? 2 : d;
+                    z = z > b ? z : b;
+                    d = a2 > z ? 3 : d;
+                    z = z > a2 ? z : a2;
+                    d = b2 > z ? 4 : d;
+                    z = z > b2 ? z : b2;
+                    z = z < sc_mch ? z : sc_mch;
+                } else {
+                    d = z > a ? 0 : 1;
+                    z = z > a ? z : a;
+                    d = z > b ? d : 2;
+                    z = z > b ? z : b;
+                    d = z > a2 ? d : 3;
+                    z = z > a2 ? z : a2;
+                    d = z > b2 ? d : 4;
+                    z = z > b2 ? z : b2;
+                    z = z < sc_mch ? z : sc_mch;
+                }
+                u[c] = (int8_t)(z - vt1);
+                v[c] = (int8_t)(z - ut);
+                int8_t tmp = (int8_t)(z - q);
+                a = (int8_t)(a - tmp);
+                b = (int8_t)(b - tmp);
+                tmp = (int8_t)(z - q2);
+                a2 = (int8_t)(a2 - tmp);
+                b2 = (int8_t)(b2 - tmp);
+                if (!(flag & PMX_EZ_RIGHT)) {
+                    x[c] = (int8_t)((a > 0 ? a : 0) - qe);
+                    d |= a > 0 ? 0x08 : 0;
+                    y[c] = (int8_t)((b > 0 ? b : 0) - qe);
+                    d |= b > 0 ? 0x10 : 0;
+                    x2[c] = (int8_t)((a2 > 0 ? a2 : 0) - (q2 + e2));
+                    d |= a2 > 0 ? 0x20 : 0;
+                    y2[c] = (int8_t)((b2 > 0 ? b2 : 0) - (q2 + e2));
+                    d |= b2 > 0 ? 0x40 : 0;
+                } else {
+                    x[c] = (int8_t)((0 > a ? 0 : a) - qe);
+                    d |= 0 > a ? 0 : 0x08;
+                    y[c] = (int8_t)((0 > b ? 0 : b) - qe);
+                    d |= 0 > b ? 0 : 0x10;
+                    x2[c] = (int8_t)((0 > a2 ? 0 : a2) - (q2 + e2));
+                    d |= 0 > a2 ? 0 : 0x20;
+                    y2[c] = (int8_t)((0 > b2 ? 0 : b2) - (q2 + e2));
+                    d |= 0 > b2 ? 0 : 0x40;
+                }
+                p[(size_t)r * n_col + (t - st)] = d;
+            }
+        }
+        if (lane == 0) { off[r] = st; off_end[r] = en; }
+        if (!approx_max) {   // exact max through H[] (:323-366)
+            int32_t max_H, max_t;
+            if (r > 0) {
+                const int32_t h_en0 = en0 > 0 ? rd_col<NC>(H, en0 - 1) + (int8_t)rd_col<NC>(u, en0) : rd_col<NC>(H, en0) + (int8_t)rd_col<NC>(v, en0);
+                const int en1 = st0 + (en0 - st0) / 4 * 4;
+                int64_t best = (int64_t)((uint64_t)(uint32_t)h_en0 << 32 | 0x7fffffffu);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int t = c * 64 + lane;
+                    if (t >= st0 && t < en0) {
+                        const int32_t h = H[c] + (int32_t)(int8_t)v[c];
+                        H[c] = h;
+                        uint32_t prio;
+                        if (t < en1) prio = 0x7ffffffeu - ((uint32_t)((t - st0) & 3) << 24) - (uint32_t)((t - st0) >> 2);
+                        else prio = 0x7ffffffeu - (5u << 24) - (uint32_t)(t - st0);
+                        const int64_t key = (int64_t)((uint64_t)(uint32_t)h << 32 | prio);
+                        best = key > best ? key : best;
+                    }
+                    if (t == en0) H[c] = h_en0;
+                }
+                best = wave_max_i64(best);
+                max_H = (int32_t)(best >> 32);
+                const uint32_t prio = (uint32_t)best;
+                if (prio == 0x7fffffffu) max_t = en0;
+                else {
+                    const uint32_t dd = 0x7ffffffeu - prio;
+                    const uint32_t cls = dd >> 24, idx = dd & 0xffffffu;
+                    max_t = cls >= 5 ? st0 + (int)idx : st0 + (int)(idx * 4 + cls);
+                }
+            } else {
+                if (lane == 0) H[0] = (int8_t)v[0] - qe;
+                max_H = rl_i32(H[0], 0);
+                max_t = 0;
+            }
+            const int32_t H_en0 = rd_col<NC>(H, en0), H_st0 = rd_col<NC>(H, st0);
+            if (en0 == tlen - 1 && H_en0 > ez.mte) { ez.mte = H_en0; ez.mte_q = r - en0; }
+            if (r - st0 == qlen - 1 && H_st0 > ez.mqe) { ez.mqe = H_st0; ez.mqe_t = st0; }
+            if (ez_apply_zdrop(ez, max_H, r, max_t, zdrop, e2)) break;
+            if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = rd_col<NC>(H, tlen - 1);
+        } else {             // approximate max along one path (:367-383)
+            if (r > 0) {
+                if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+                    const int32_t d0 = (int8_t)rd_col<NC>(v, last_H0_t), d1 = (int8_t)rd_col<NC>(u, last_H0_t + 1);
+                    if (d0 > d1) H0 += d0;
+                    else { H0 += d1; ++last_H0_t; }
+                } else if (last_H0_t >= st0 && last_H0_t <= en0) {
+                    H0 += (int8_t)rd_col<NC>(v, last_H0_t);
+                } else {
+                    ++last_H0_t;
+                    H0 += (int8_t)rd_col<NC>(u, last_H0_t);
+                }
+            } else { H0 = (int8_t)rd_col<NC>(v, 0) - qe; last_H0_t = 0; }
+            if ((flag & PMX_EZ_APPROX_DROP) && ez_apply_zdrop(ez, H0, r, last_H0_t, zdrop, e2)) break;
+            if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
+        }
+        last_st = st;
+        last_en = en;
+    }
+    wave_sync();
+    const int rev_cigar = !!(flag & PMX_EZ_REV_CIGAR);
+    if (!ez.zdropped && !(flag & PMX_EZ_EXTZ_ONLY)) {
+        ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, tlen - 1, qlen - 1, &ez.n_cigar);
+    } else if (!ez.zdropped && (flag & PMX_EZ_EXTZ_ONLY) && ez.mqe + end_bonus > (int)ez.max) {
+        ez.reach_end = 1;
+        ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, ez.mqe_t, qlen - 1, &ez.n_cigar);
+    } else if (ez.max_t >= 0 && ez.max_q >= 0) {
+        ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, ez.max_t, ez.max_q, &ez.n_cigar);
+    }
+    wave_sync();
+}
+#elif defined(__HIPCC__)
+// (device-only; declared so the host pass of the kernels parses)
+template <int NC>
+__device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e, int8_t q2,
+                   int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez);
+#endif
+
+
 #if PMX_W > 1
 __device__ __forceinline__ int wave_sum_i32(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ int wave_max_i32(int v) {
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(v, o); v = other > v ? other : v; }
+    return v;
+}
 #else
 PMX_HD int wave_sum_i32(int v) { return v; }
+PMX_HD int wave_max_i32(int v) { return v; }
 #endif
 
 // Number of positions i < n where a[i] != b[i] or a base is ambiguous (code >= 4), saturating early is
@@ -345,10 +611,16 @@ PMX_HD int count_diff(Ptr<const uint8_t> a, Ptr<const uint8_t> b, int n) {
     return wave_sum_i32(d);
 }
 
-// ksw_extd2 with two shortcuts whose results are provably what the DP returns (DESIGN.md "DP shortcuts"):
+// ksw_extd2 with shortcuts whose results are provably what the DP returns (DESIGN.md "DP shortcuts"):
 //  (1) extension (EXTZ_ONLY) of a query that equals the target prefix base for base (no ambiguous base),
 //      band and z-drop not binding: the main diagonal is the unique optimum -> max = qlen*a at
 //      (qlen-1,qlen-1), reach_end iff end_bonus > 0, CIGAR = qlen M;
+//  (1b) the same with exactly ONE mismatch (at query position p) and (a+b) < min(q+e,q2+e2): any path that
+//      ends off the main diagonal pays a gap (>= gmin) and aligns at most min(i,j)+1 pairs, so it scores
+//      < a*(m+1) - (a+b) <= H(m,m); any gapped path back onto the diagonal pays two gaps.  Hence every
+//      maximum the DP tracks sits on the diagonal with H(m,m) = a*(m+1) - (m >= p ? a+b : 0): the running
+//      max is the first of { a*p at (p-1,p-1), a*qlen-(a+b) at the end } to reach the larger value (strict
+//      '>' keeps the earlier on ties), mqe = a*qlen-(a+b) at t = qlen-1, the traceback is all-diagonal;
 //  (2) global alignment in the approximate-max first pass of two equal-length sequences without
 //      ambiguous bases whose Hamming distance d satisfies d*(a+b) < a + 2*min(q+e,q2+e2): every gapped
 //      alignment scores strictly less than the gap-free one for every prefix pair on the main diagonal,
@@ -362,8 +634,15 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
     const int g1 = q + e, g2 = q2 + e2;
     const int gmin = g1 < g2 ? g1 : g2, gmax = g1 > g2 ? g1 : g2;
     if (qlen > 0 && tlen > 0 && a > 0 && b > 0 && (w < 0 || (w >= qlen && w >= tlen)) && -mat[1] <= 2 * gmin) {
-        if ((flag & PMX_EZ_EXTZ_ONLY) && tlen >= qlen && zdrop >= 2 * gmax + a) {
-            if (count_diff(query, target, qlen) == 0) {
+        if ((flag & PMX_EZ_EXTZ_ONLY) && tlen >= qlen && zdrop >= 2 * gmax + a + (a + b)) {
+            // d = differing or ambiguous positions among the first qlen; pm = the largest such position
+            int d = 0, pm = -1;
+            for (int i = lane_id(); i < qlen; i += PMX_W) {
+                const bool bad = query[i] != target[i] || query[i] > 3 || target[i] > 3;
+                if (bad) { ++d; pm = i; }
+            }
+            d = wave_sum_i32(d);
+            if (d == 0) {
                 ez_reset(ez);
                 ez.max = (uint32_t)(qlen * a);
                 ez.max_t = ez.max_q = qlen - 1;
@@ -375,6 +654,23 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
                 ez.n_cigar = 1;
                 wave_sync();
                 return true;
+            }
+            if (d == 1 && a + b < gmin) {
+                const int pos = wave_max_i32(pm);
+                if (query[pos] <= 3 && target[pos] <= 3) {   // a real mismatch, not an ambiguous base
+                    ez_reset(ez);
+                    const int hend = qlen * a - (a + b);
+                    if (pos >= 1) { ez.max = (uint32_t)(pos * a); ez.max_t = ez.max_q = pos - 1; }
+                    if (hend > (int)ez.max) { ez.max = (uint32_t)hend; ez.max_t = ez.max_q = qlen - 1; }
+                    ez.mqe = hend;
+                    ez.mqe_t = qlen - 1;
+                    if (tlen == qlen) { ez.mte = hend; ez.mte_q = qlen - 1; }
+                    ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
+                    const int len = ez.reach_end ? qlen : ez.max_q + 1;
+                    if (len > 0) { cig_tmp[0] = (uint32_t)len << 4; ez.n_cigar = 1; }
+                    wave_sync();
+                    return true;
+                }
             }
         } else if (!(flag & PMX_EZ_EXTZ_ONLY) && (flag & PMX_EZ_APPROX_MAX) && !(flag & PMX_EZ_APPROX_DROP) && qlen == tlen) {
             const int d = count_diff(query, target, qlen);

@@ -49,7 +49,7 @@ PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonu
 #define PMX_REGS(s) ((s) ? r1_ : r0_)
     const int cap = W.caps.max_reg * 2;
     Ptr<uint64_t> key = W.aux64; PMX_LDS(key);                 // [cap]
-    Ptr<int32_t> ps = ptr_cast<int32_t>(W.aux64 + cap);        // [cap] segment
+    Ptr<int32_t> ps = W.aux32; PMX_LDS(ps);                    // [cap] segment
     Ptr<int32_t> pi = ps + cap;                                // [cap] index in regs[s]
     Ptr<uint64_t> sc = ptr_cast<uint64_t>(W.z); PMX_LDS(sc);   // pair scores
     const int sc_cap = W.caps.max_anchor * 2;      // z holds max_anchor A128

@@ -62,13 +62,18 @@ struct A128 {
 // ---------------------------------------------------------------------------------------- work pointers
 // Ptr<T> is how every per-pair work array is addressed.  In the wave-per-pair kernels and on the host it is
 // a plain T*.  In the thread-per-pair kernel it is IPtr<T>: a 32-bit LOGICAL byte offset into the thread's
-// work arena, translated on access to a 16-byte-granule interleaved address in the wave's HBM slab
-//     physical = wave_base + (offset / 16) * (64 * 16) + lane * 16 + offset % 16
+// work arena, translated on access to a granule-interleaved address in the wave's HBM slab
+//     physical = wave_base + (offset / G) * (64 * G) + lane * G + offset % G
 // so the 64 lanes of a wave touching the same logical offset share cache lines instead of owning one line
 // each (measured with per-thread contiguous slabs: 4450 line fills per pair, ~4.2 TB/s of HBM traffic; the
-// kernel was bound by exactly that).  Objects of size 1/2/4/8/16 with natural alignment never straddle a
-// granule, so operator[] can hand out real references; larger structs (Reg, Seed) stay in a small
-// per-thread contiguous region behind plain pointers.
+// kernel was bound by exactly that).  The granule G follows the element type: 16 bytes for 8/16-byte
+// elements (A128, uint64), 4 bytes for byte / 32-bit arrays (a wave-wide byte access then spans 256 B
+// instead of 1 KB).  Either way a 16-byte-aligned logical block maps into the same 1 KB physical block,
+// so regions of different granule never collide as long as every region is 16-byte aligned and sized and
+// is always accessed through one granule -- the thread-per-pair layout therefore has NO overlaid regions,
+// and ptr_cast only converts between types of equal granule.  Objects with natural alignment never
+// straddle a granule, so operator[] can hand out real references; larger structs (Reg, Seed) stay in a
+// small per-thread contiguous region behind plain pointers.
 #if defined(PMX_THREAD_PER_PAIR) && defined(__HIPCC__)
 struct TppArena {
     uint8_t* base;          // first wave's slab
@@ -86,9 +91,10 @@ struct IPtr {
     __device__ explicit IPtr(uint32_t off) : o(off) {}
     template <class U, class = typename std::enable_if<std::is_convertible<U*, T*>::value>::type>
     __device__ IPtr(const IPtr<U>& q) : o(q.o) {}
+    static constexpr uint32_t LG = sizeof(T) >= 8 ? 4u : 2u;   // log2 of the granule
     __device__ __forceinline__ static T* phys(uint32_t off) {
         uint8_t* wave_base = c_tpp_arena.base + (size_t)blockIdx.x * c_tpp_arena.wave_stride;   // uniform
-        const uint32_t vo = ((threadIdx.x & 63u) << 4) + ((off >> 4) << 10) + (off & 15u);
+        const uint32_t vo = ((threadIdx.x & 63u) << LG) + ((off >> LG) << (LG + 6)) + (off & ((1u << LG) - 1u));
         return reinterpret_cast<T*>(wave_base + vo);
     }
     __device__ __forceinline__ T& operator*() const { return *phys(o); }
@@ -109,7 +115,10 @@ struct IPtr {
     __device__ __forceinline__ bool operator>=(const IPtr& q) const { return o >= q.o; }
 };
 template <class T> using Ptr = IPtr<T>;
-template <class U, class T> __device__ __forceinline__ IPtr<U> ptr_cast(IPtr<T> q) { return IPtr<U>(q.o); }
+template <class U, class T> __device__ __forceinline__ IPtr<U> ptr_cast(IPtr<T> q) {
+    static_assert(IPtr<U>::LG == IPtr<T>::LG, "ptr_cast between element types of different interleave granule");
+    return IPtr<U>(q.o);
+}
 #else
 template <class T> using Ptr = T*;
 template <class U, class T> PMX_HD U* ptr_cast(T* q) { return reinterpret_cast<U*>(q); }
@@ -275,7 +284,8 @@ struct Work {
     Ptr<A128> seg_a[2];
     Ptr<uint64_t> seg_u[2];
     int seg_n_a[2], seg_n_u[2];
-    Ptr<uint64_t> aux64;   // small sort scratch (max_reg * 2)
+    Ptr<uint64_t> aux64;   // small sort scratch (max_reg * 8)
+    Ptr<int32_t> aux32;    // small index scratch (max_reg * 4)
     Ptr<A128> aux128;
     // DP
     Ptr<int8_t> du, dv, dx, dy, dx2, dy2, ds;

@@ -11,9 +11,10 @@ namespace aln {
 __global__ void __launch_bounds__(64, 2) k_align_reads_t1(AlignArgs A) { align_reads_body<2>(A); }
 __global__ void __launch_bounds__(64, 4) k_align_reads_t1_w4(AlignArgs A) { align_reads_body<4>(A); }
 
-// DP service of the thread-per-pair kernel: one wave per posted request runs the anti-diagonal-parallel
-// ksw_extd2 with its arrays in LDS (traceback matrix in the wave's HBM slab) and appends the result to the
-// slot's result list.
+// DP service of the thread-per-pair kernel: one wave per posted request.  Class 1 (short targets: nearly all
+// requests) runs the register-resident ksw_extd2_reg; the rest run the anti-diagonal-parallel ksw_extd2 with
+// its arrays in LDS (traceback matrix in LDS when it fits, else in the wave's HBM slab).  The result is
+// appended to the slot's result list.
 __global__ void __launch_bounds__(64, 4) k_align_dp_serve(AlignArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     Work& W = *reinterpret_cast<Work*>(lds);
@@ -25,23 +26,46 @@ __global__ void __launch_bounds__(64, 4) k_align_dp_serve(AlignArgs A) {
         const int64_t slot = A.worklist ? (int64_t)A.worklist[it] : it;
         const DpReq* rq = reinterpret_cast<const DpReq*>(A.dp_req_base + (size_t)slot * sizeof(DpReq));
         __syncthreads();
+        const unsigned long long tp0 = A.prof ? (unsigned long long)clock64() : 0ULL;
         bind_work(W, A.layout, fast, slow);
         W.prof = nullptr;
         const int qlen = rq->qlen, tlen = rq->tlen;
         const int t_off = (qlen + 15) & ~15;
         const size_t tb_need = dp_request_tb_bytes(qlen, tlen, rq->w);
-        if (tb_need <= A.layout.tb_fast_cap) W.tb = fast + A.layout.tb_fast.off;   // traceback matrix in LDS when it fits
+        if (A.dp_class != 0) {
+            const bool small = qlen <= A.dp_small_qlen && tlen <= A.dp_small_tlen && tb_need <= (size_t)8192;
+            if (small != (A.dp_class == 1)) continue;   // the other launch serves it
+        }
+        if (tb_need <= A.layout.tb_fast_cap) {   // traceback matrix in LDS when it fits
+            W.tb = fast + A.layout.tb_fast.off;
+            if (W.tb_cap < A.layout.tb_fast_cap) W.tb_cap = A.layout.tb_fast_cap;
+        }
         uint8_t* sq = W.qseq[0][0]; PMX_LDS(sq);
         __syncthreads();
         for (int i = lane; i < t_off + tlen; i += 64) sq[i] = rq->seq[i];
         __syncthreads();
+        const unsigned long long tp1 = A.prof ? (unsigned long long)clock64() : 0ULL;
         Ez ez;
-        ksw_extd2(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, rq->w,
-                  rq->zdrop, rq->end_bonus, rq->flag, ez);
+        if (A.dp_class == 1 && tlen <= 64)
+            ksw_extd2_reg<1>(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, rq->w,
+                             rq->zdrop, rq->end_bonus, rq->flag, ez);
+        else if (A.dp_class == 1)
+            ksw_extd2_reg<2>(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, rq->w,
+                             rq->zdrop, rq->end_bonus, rq->flag, ez);
+        else
+            ksw_extd2(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, rq->w,
+                      rq->zdrop, rq->end_bonus, rq->flag, ez);
         __syncthreads();
+        const unsigned long long tp2 = A.prof ? (unsigned long long)clock64() : 0ULL;
         if (lane == 0) {
             const uint32_t* cg = W.cig_tmp; PMX_LDS(cg);
             dp_store_result(A, slot, rq, ez, cg, W.status);
+        }
+        if (A.prof && lane == 0) {
+            atomicAdd(&A.prof[12], tp1 - tp0);
+            atomicAdd(&A.prof[13], tp2 - tp1);
+            atomicAdd(&A.prof[14], (unsigned long long)clock64() - tp2);
+            atomicAdd(&A.prof[15], (unsigned long long)(qlen + tlen - 1));
         }
     }
 }

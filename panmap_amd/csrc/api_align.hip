@@ -196,6 +196,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     };
     A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
     A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
+    A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0;
     timer_begin(ctx, "align");
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
@@ -224,6 +225,11 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             int64_t small_rounds = 2048;   // fewer pairs than this cannot fill the chip thread-per-pair: wave tier
             if (const char* e = getenv("PMX_ALIGN_TPP_MIN")) small_rounds = atoll(e);
             const int64_t dp_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dp_lds);
+            const int small_qlen = 128, small_tlen = 128;   // ksw_extd2_reg<2>: two target columns per lane
+            const Layout dps_layout = plan_layout_dp((int)rs->max_len, n_segs, al->opt, small_qlen, small_tlen);
+            const size_t dps_lds = PMX_ALIGN_WORK_BYTES + dps_layout.fast_bytes + 16;
+            const int64_t dps_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dps_lds);
+            const bool dp_two_class = !getenv("PMX_ALIGN_DP_ONE_CLASS");
             if (use_dp_service) {
                 al->dp_req.ensure((size_t)n_items * sizeof(DpReq));
                 al->dp_res.ensure((size_t)n_items * PMX_DP_MAX_CALLS);
@@ -271,7 +277,15 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 A.slow_base = al->slow.p;
                 A.n_items = n_dp;
                 A.worklist = cur;
+                A.dp_small_qlen = small_qlen;
+                A.dp_small_tlen = small_tlen;
+                A.dp_class = dp_two_class ? 2 : 0;
                 hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dp_max_grid, n_dp)), dim3(64), dp_lds, ctx->stream, A);
+                if (dp_two_class) {
+                    A.layout = dps_layout;
+                    A.dp_class = 1;
+                    hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dps_max_grid, n_dp)), dim3(64), dps_lds, ctx->stream, A);
+                }
                 PMX_HIP(hipGetLastError());
                 uint32_t* next = lists[round & 1];
                 A.layout = tpp_layout;
@@ -319,6 +333,9 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         static const char* names[16] = {"decode", "sketch", "seed+heap", "chain", "gen_regs+post", "seg_gen", "squeeze", "align1(all regs)", "filter/sort/parent", "mapq", "pair", "output", "", "", "", ""};
         fprintf(stderr, "[pmx align phase cycles per item]");
         for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.0f", names[k], (double)h[k] / (double)n_items);
+        fprintf(stderr, " [dp serve: cycles load=%.0f ksw=%.0f store=%.0f per request, diagonals=%.1f]", (double)h[12] / std::max<double>(1, (double)al->last_dp_requests),
+                (double)h[13] / std::max<double>(1, (double)al->last_dp_requests), (double)h[14] / std::max<double>(1, (double)al->last_dp_requests),
+                (double)h[15] / std::max<double>(1, (double)al->last_dp_requests));
         fprintf(stderr, " dp_requests=%lld dp_rounds=%d tpp_retry=%lld retry=%lld\n", (long long)al->last_dp_requests, al->last_dp_rounds,
                 (long long)al->last_tpp_retry, (long long)al->last_retry);
     }

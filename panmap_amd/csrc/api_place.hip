@@ -53,7 +53,8 @@ struct pmx_place {
     DevBuf<unsigned long long> stats;
     DevBuf<char> tmp;                      // rocprim temp storage
     // node outputs
-    DevBuf<double> metrics5, scores5;
+    DevBuf<double> metrics5, scores5, terms;
+    DevBuf<uint8_t> term_meta;
     DevBuf<int64_t> counts2;
     std::vector<double> h_scores;
     std::vector<std::vector<uint32_t>> tied;
@@ -388,7 +389,6 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
     if (pp->dedup_reads) return fail(PMX_ERR_UNSUPPORTED, "--dedup is not implemented on the device yet");
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
-    table_reserve(ctx, pl, (uint64_t)rs->total);
     SeedParams sp;
     sp.k = pl->params.k; sp.s = pl->params.s; sp.t = pl->params.t; sp.l = pl->params.l; sp.open = pl->params.open ? 1 : 0;
     sp.trim_start = pp->trim_start; sp.trim_end = pp->trim_end;
@@ -398,11 +398,21 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
     if (lds > 64 * 1024)
         PMX_HIP(hipFuncSetAttribute((const void*)k_seed_histogram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (rs->n > 0) {
+        // Reads go in chunks of <= ~16M bases.  Before each chunk the table is grown (rehash) if the distinct
+        // keys seen so far plus one new key per base of the chunk would push the load factor past 0.7, so an
+        // insert can never fail, yet the table is sized by what the reads actually contain (a few million
+        // distinct seeds for a 1M-read sample) instead of by the one-key-per-base bound of the whole batch:
+        // a 16x smaller table to clear, probe and compact.
+        const int64_t chunk_reads = std::max<int64_t>(1, ((int64_t)16 << 20) / std::max<int64_t>(rs->max_len, 1));
         timer_begin(ctx, "seed");
-        hipLaunchKernelGGL(k_seed_histogram, dim3(grid_for(rs->n, PMX_SEED_BLOCK, ctx->n_cu * 16)), dim3(PMX_SEED_BLOCK), lds, ctx->stream,
-                           rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, rs->n, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
+        for (int64_t r0 = 0; r0 < rs->n; r0 += chunk_reads) {
+            const int64_t r1 = std::min<int64_t>(rs->n, r0 + chunk_reads);
+            table_reserve(ctx, pl, (uint64_t)((r1 - r0) * rs->max_len));
+            hipLaunchKernelGGL(k_seed_histogram, dim3(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), dim3(PMX_SEED_BLOCK), lds, ctx->stream,
+                               rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
+            PMX_HIP(hipGetLastError());
+        }
         timer_end(ctx, "seed", 1);
-        PMX_HIP(hipGetLastError());
     }
     pl->n_reads_added += rs->n;
     pl->hist_sorted = false;
@@ -573,12 +583,19 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     // ---- node scoring, one launch per BFS level (src/placement.cpp:701-918)
     const int n_levels = (int)pl->level_off.size() - 1;
     timer_begin(ctx, "score");
+    const int64_t n_ch = pl->n_changes;
+    pl->terms.ensure((size_t)std::max<int64_t>(n_ch, 1) * 5);
+    pl->term_meta.ensure((size_t)std::max<int64_t>(n_ch, 1));
+    double* t_mag = pl->terms.p;
+    double *t_raw = t_mag + n_ch, *t_cos = t_mag + 2 * n_ch, *t_wc = t_mag + 3 * n_ch, *t_lc = t_mag + 4 * n_ch;
+    if (n_ch > 0)
+        hipLaunchKernelGGL(k_score_terms, dim3(grid_for(n_ch, 256, G)), dim3(256), 0, st, pl->ch_hash.p, pl->ch_par.p, pl->ch_child.p, n_ch,
+                           pl->tkeys.p, pl->tvals.p, pl->tcap - 1, n_kept > 0 ? 1 : 0, t_mag, t_raw, t_cos, t_wc, t_lc, pl->term_meta.p);
     for (int lv = 0; lv < n_levels; ++lv) {
         const int64_t beg = pl->level_off[lv], cnt = pl->level_off[lv + 1] - beg;
         if (cnt <= 0) continue;
         hipLaunchKernelGGL(k_score_level, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, pl->level_nodes.p + beg, cnt, pl->parent.p, pl->offsets.p,
-                           pl->ch_hash.p, pl->ch_par.p, pl->ch_child.p, pl->tkeys.p, pl->tvals.p, pl->tcap - 1, n_kept > 0 ? 1 : 0, pl->metrics5.p,
-                           pl->counts2.p);
+                           t_mag, t_raw, t_cos, t_wc, t_lc, pl->term_meta.p, pl->metrics5.p, pl->counts2.p);
     }
     timer_end(ctx, "score", 1);
     hipLaunchKernelGGL(k_score_getters, dim3(grid_for(pl->n_nodes, 256, G)), dim3(256), 0, st, pl->metrics5.p, pl->counts2.p, pl->n_nodes, log_mag,

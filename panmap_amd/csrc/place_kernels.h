@@ -17,7 +17,7 @@ struct SeedParams {
 
 __global__ void k_pack_reads(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int64_t n_reads, int64_t n_words,
                              uint64_t* words, uint32_t* amb);
-__global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t n_reads,
+__global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin, int64_t n_reads,
                                  SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters);
 __global__ void k_table_merge(const uint64_t* hash, const int64_t* count, int64_t n, uint64_t* keys, unsigned long long* vals,
                               uint64_t mask, unsigned long long* counters);
@@ -38,9 +38,12 @@ __global__ void k_kept_table_build(const uint64_t* kept_hash, const double* kept
                                    uint64_t mask);
 __global__ void k_wc_denominator(const uint64_t* ch_hash, const int16_t* ch_child, uint64_t beg, uint64_t end, const uint64_t* tkeys,
                                  const double* tvals, uint64_t mask, int has_kept, double* out);
+__global__ void k_score_terms(const uint64_t* ch_hash, const int16_t* ch_par, const int16_t* ch_child, int64_t n_changes,
+                              const uint64_t* tkeys, const double* tvals, uint64_t mask, int has_kept, double* t_mag, double* t_raw,
+                              double* t_cos, double* t_wc, double* t_lc, uint8_t* t_meta);
 __global__ void k_score_level(const uint32_t* level_nodes, int64_t n_level, const uint32_t* parent, const uint64_t* offsets,
-                              const uint64_t* ch_hash, const int16_t* ch_par, const int16_t* ch_child, const uint64_t* tkeys,
-                              const double* tvals, uint64_t mask, int has_kept, double* metrics5, int64_t* counts2);
+                              const double* t_mag, const double* t_raw, const double* t_cos, const double* t_wc, const double* t_lc,
+                              const uint8_t* t_meta, double* metrics5, int64_t* counts2);
 __global__ void k_score_getters(const double* metrics5, const int64_t* counts2, int64_t n_nodes, double log_mag, double log_cont_den,
                                 double wc_den, int64_t n_kept, double* scores5);
 __global__ void k_fill_u64(uint64_t* p, uint64_t v, uint64_t n);

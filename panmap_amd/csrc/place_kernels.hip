@@ -72,8 +72,8 @@ __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long*
 // l-deep syncmer ring of every thread in LDS, laid out [slot][thread] (conflict-free ds_read_b64).
 __global__ void __launch_bounds__(PMX_SEED_BLOCK)
 k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
-                 const int64_t* __restrict__ off, int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals,
-                 uint64_t mask, unsigned long long* counters) {
+                 const int64_t* __restrict__ off, int64_t r_begin, int64_t n_reads, SeedParams sp, uint64_t* keys,
+                 unsigned long long* vals, uint64_t mask, unsigned long long* counters) {
     extern __shared__ uint64_t lds[];
     const int w = sp.k - sp.s + 1;
     const int l = sp.l < 1 ? 1 : sp.l;
@@ -84,7 +84,7 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
     const uint64_t HB[4] = {0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x20323ed082572324ULL, 0x295549f54be24456ULL};
     unsigned long long n_seeds = 0;
 
-    for (int64_t r = (int64_t)blockIdx.x * PMX_SEED_BLOCK + tid; r < n_reads; r += (int64_t)gridDim.x * PMX_SEED_BLOCK) {
+    for (int64_t r = r_begin + (int64_t)blockIdx.x * PMX_SEED_BLOCK + tid; r < n_reads; r += (int64_t)gridDim.x * PMX_SEED_BLOCK) {
         const int64_t len = off[r + 1] - off[r];
         if (len < sp.k) continue;
         const uint64_t* rw = words + woff[r];
@@ -190,23 +190,42 @@ __global__ void k_table_rehash(const uint64_t* __restrict__ okeys, const unsigne
 
 __global__ void k_table_compact(const uint64_t* __restrict__ keys, const unsigned long long* __restrict__ vals, uint64_t cap,
                                 uint64_t* out_hash, int64_t* out_count, unsigned long long* n_out) {
-    // uniform trip count so the whole wave reaches the ballot; one atomic per wave
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t n_iter = (cap + stride - 1) / stride;
+    // One wave compacts a tile of 64 x 16 slots per step: coalesced loads, a wave prefix sum of the per-lane
+    // occupancy and ONE atomic per tile on the output cursor (a single-address atomic per 64 slots was the
+    // whole cost of this kernel: ~88 atomics/us on one address).  Output order is arbitrary (sorted next).
+    constexpr int K = 16;
     const int lane = threadIdx.x & 63;
-    for (uint64_t it = 0; it < n_iter; ++it) {
-        const uint64_t i = it * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const uint64_t k = i < cap ? keys[i] : PMX_EMPTY_KEY;
-        const bool have = k != PMX_EMPTY_KEY;
-        const unsigned long long m = __ballot(have);
-        if (m == 0) continue;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n_tiles = (cap + 64 * K - 1) / (64 * K);
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        uint64_t kk[K];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const uint64_t i = tile * (64 * K) + (uint64_t)j * 64 + lane;
+            kk[j] = i < cap ? keys[i] : PMX_EMPTY_KEY;
+            cnt += kk[j] != PMX_EMPTY_KEY ? 1 : 0;
+        }
+        int incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const int total = __shfl(incl, 63);
+        if (total == 0) continue;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
+        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)total);
         base = __shfl(base, 0);
-        if (have) {
-            const unsigned long long j = base + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
-            out_hash[j] = k;
-            out_count[j] = (int64_t)vals[i];
+        unsigned long long pos = base + (unsigned long long)(incl - cnt);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (kk[j] != PMX_EMPTY_KEY) {
+                const uint64_t i = tile * (64 * K) + (uint64_t)j * 64 + lane;
+                out_hash[pos] = kk[j];
+                out_count[pos] = (int64_t)vals[i];
+                ++pos;
+            }
         }
     }
 }
@@ -320,93 +339,165 @@ __device__ __forceinline__ bool kept_lookup(const uint64_t* __restrict__ tkeys, 
 
 // weighted-containment denominator: root changes in stored order (src/placement.cpp:1863-1876).  One wave:
 // lanes probe 64 changes at a time, then the additions run in stored order.
-__global__ void k_wc_denominator(const uint64_t* __restrict__ ch_hash, const int16_t* __restrict__ ch_child, uint64_t beg, uint64_t end,
-                                 const uint64_t* __restrict__ tkeys, const double* __restrict__ tvals, uint64_t mask, int has_kept,
-                                 double* out) {
+__global__ void __launch_bounds__(1024)
+k_wc_denominator(const uint64_t* __restrict__ ch_hash, const int16_t* __restrict__ ch_child, uint64_t beg, uint64_t end,
+                 const uint64_t* __restrict__ tkeys, const double* __restrict__ tvals, uint64_t mask, int has_kept, double* out) {
+    // one block: every thread probes its changes in parallel into an LDS tile, then thread 0 adds the tile in
+    // stored order (a no-hit change contributes +0.0, which is exact; see k_score_level)
+    __shared__ double tile[1024];
     if (blockIdx.x != 0) return;
-    const int lane = threadIdx.x & 63;
     double acc = 0.0;
-    for (uint64_t base = beg; base < end; base += 64) {
-        const uint64_t i = base + lane;
+    for (uint64_t base = beg; base < end; base += blockDim.x) {
+        const uint64_t i = base + threadIdx.x;
         double inv = 0.0;
-        int hit = 0;
         if (i < end) {
             const int16_t cc = ch_child[i];
             double L;
-            if (cc > 0 && has_kept && kept_lookup(tkeys, tvals, mask, ch_hash[i], &L)) { inv = 1.0 / (double)cc; hit = 1; }
+            if (cc > 0 && has_kept && kept_lookup(tkeys, tvals, mask, ch_hash[i], &L)) inv = 1.0 / (double)cc;
         }
-        const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
-        for (int j = 0; j < cnt; ++j) {
-            const int hj = __shfl(hit, j);
-            const double ij = __shfl(inv, j);
-            if (hj) acc += ij;
+        tile[threadIdx.x] = inv;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = (int)((end - base) < blockDim.x ? (end - base) : blockDim.x);
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+                const double v0 = tile[j], v1 = tile[j + 1], v2 = tile[j + 2], v3 = tile[j + 3], v4 = tile[j + 4], v5 = tile[j + 5],
+                             v6 = tile[j + 6], v7 = tile[j + 7];
+                acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+            }
+            for (; j < cnt; ++j) acc += tile[j];
         }
+        __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = acc;
 }
 
 // --------------------------------------------------------------------------- node scoring
-// One wave per node of one BFS level.  Child state = parent state + own deltas applied in stored order
-// (src/placement.cpp:242-345, :772-774).  Lanes fetch/probe/evaluate 64 changes in parallel; the
-// additions are replayed strictly in order so every accumulator sees the reference's operation sequence.
+// Child state = parent state + own deltas applied in stored order (src/placement.cpp:242-345, :772-774).
+// The floating-point additions are replayed strictly in stored order so every accumulator sees the
+// reference's operation sequence (the integer counters are order-free and are wave-reduced).  A BFS level
+// lasts as long as its largest node, so the per-change critical path is what matters: everything that does
+// not depend on the order (log1p, table probe, the terms) is computed for all changes at once in pass 1;
+// pass 2 streams the terms (two 64-change chunks in flight), broadcasts them with v_readlane (no LDS round
+// trip) and visits only the changes that hit the kept-seed table for the four hit-only accumulators
+// (skipping a no-hit change is what the reference's control flow does).
+__device__ __forceinline__ double readlane_f64(double v, int j) {
+    const long long b = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, j);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)b >> 32), j);
+    return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
+
+// Pass 1 (one launch, every seed change of the index in parallel): the order-independent part -- log1p,
+// kept-seed table probe, the five per-change terms -- written as SoA so pass 2 streams them coalesced.
+// meta: bit 0 = hit, bits 1-2 = d_pres + 1, bits 3-4 = d_uniq + 1.
+__global__ void __launch_bounds__(256)
+k_score_terms(const uint64_t* __restrict__ ch_hash, const int16_t* __restrict__ ch_par, const int16_t* __restrict__ ch_child,
+              int64_t n_changes, const uint64_t* __restrict__ tkeys, const double* __restrict__ tvals, uint64_t mask, int has_kept,
+              double* __restrict__ t_mag, double* __restrict__ t_raw, double* __restrict__ t_cos, double* __restrict__ t_wc,
+              double* __restrict__ t_lc, uint8_t* __restrict__ t_meta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_changes; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pc = ch_par[i], cc = ch_child[i];
+        const double logC = cc > 0 ? log1p_count(cc) : 0.0;
+        const double logP = pc > 0 ? log1p_count(pc) : 0.0;
+        t_mag[i] = logC * logC - logP * logP;
+        const int d_uniq = (cc > 0) - (pc > 0);
+        int d_pres = 0, hit = 0;
+        double L, d_raw = 0.0, d_cos = 0.0, d_wc = 0.0, d_lc = 0.0;
+        if (cc != pc && has_kept && kept_lookup(tkeys, tvals, mask, ch_hash[i], &L)) {
+            hit = 1;
+            d_pres = (int)((pc == 0) & (cc != 0)) - (int)((cc == 0) & (pc != 0));
+            const double o1 = pc > 0 ? L / (double)pc : 0.0, n1 = cc > 0 ? L / (double)cc : 0.0;
+            d_raw = n1 - o1;
+            d_cos = L * (logC - logP);
+            const double o2 = pc > 0 ? 1.0 / (double)pc : 0.0, n2 = cc > 0 ? 1.0 / (double)cc : 0.0;
+            d_wc = n2 - o2;
+            d_lc = (double)d_pres * L;
+        }
+        t_raw[i] = d_raw; t_cos[i] = d_cos; t_wc[i] = d_wc; t_lc[i] = d_lc;
+        t_meta[i] = (uint8_t)(hit | (d_pres + 1) << 1 | (d_uniq + 1) << 3);
+    }
+}
+
+struct ScoreTerms {
+    double d_raw, d_cos, d_wc, d_lc, d_mag;
+    int d_pres, d_uniq, hit;
+};
+
+__device__ __forceinline__ ScoreTerms load_terms(uint64_t i, uint64_t end, const double* __restrict__ t_mag, const double* __restrict__ t_raw,
+                                                 const double* __restrict__ t_cos, const double* __restrict__ t_wc,
+                                                 const double* __restrict__ t_lc, const uint8_t* __restrict__ t_meta) {
+    ScoreTerms t;
+    t.d_raw = t.d_cos = t.d_wc = t.d_lc = t.d_mag = 0.0;
+    t.d_pres = t.d_uniq = t.hit = 0;
+    if (i < end) {   // all six loads are independent: nothing waits until the terms are used two chunks later
+        const int m = t_meta[i];
+        t.d_mag = t_mag[i];
+        t.d_raw = t_raw[i]; t.d_cos = t_cos[i]; t.d_wc = t_wc[i]; t.d_lc = t_lc[i];
+        t.hit = m & 1;
+        t.d_pres = (m & 1) ? ((m >> 1) & 3) - 1 : 0;
+        t.d_uniq = ((m >> 3) & 3) - 1;
+    }
+    return t;
+}
+
+__device__ __forceinline__ int wave_sum_int(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Pass 2, one launch per BFS level, one wave per node: parent state + the node's terms added in stored order.
+// The five accumulators are five independent serial chains, so they run in five LANES: each 64-change chunk
+// is staged in LDS as [change][accumulator] and lanes 0..4 walk it with one ds_read + one v_add_f64 per
+// change (a no-hit change carries +0.0 for the four hit-only terms: adding +0.0 is exact, and no accumulator
+// can be -0.0).  The critical path per change is one FP64 add instead of a dozen broadcast instructions.
 __global__ void __launch_bounds__(256)
 k_score_level(const uint32_t* __restrict__ level_nodes, int64_t n_level, const uint32_t* __restrict__ parent,
-              const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ ch_hash, const int16_t* __restrict__ ch_par,
-              const int16_t* __restrict__ ch_child, const uint64_t* __restrict__ tkeys, const double* __restrict__ tvals,
-              uint64_t mask, int has_kept, double* metrics5, int64_t* counts2) {
+              const uint64_t* __restrict__ offsets, const double* __restrict__ t_mag, const double* __restrict__ t_raw,
+              const double* __restrict__ t_cos, const double* __restrict__ t_wc, const double* __restrict__ t_lc,
+              const uint8_t* __restrict__ t_meta, double* metrics5, int64_t* counts2) {
+    __shared__ double stage[4][64 * 5];
     const int lane = threadIdx.x & 63;
-    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int wib = threadIdx.x >> 6;
+    const int64_t wv = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib;
     if (wv >= n_level) return;
     const uint32_t nd = level_nodes[wv];
-    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+    double* sh = stage[wib];
+    double acc = 0.0;              // lane k < 5: accumulator k (raw, cos, wc, lc, mag)
     int64_t c0 = 0, c1 = 0;
+    const uint64_t beg = offsets[nd], end = offsets[nd + 1];
+    ScoreTerms cur = load_terms(beg + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+    ScoreTerms nx1 = load_terms(beg + 64 + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
     if (nd != 0) {
         const uint32_t pa = parent[nd];
-        m0 = metrics5[5 * (size_t)pa + 0]; m1 = metrics5[5 * (size_t)pa + 1]; m2 = metrics5[5 * (size_t)pa + 2];
-        m3 = metrics5[5 * (size_t)pa + 3]; m4 = metrics5[5 * (size_t)pa + 4];
+        if (lane < 5) acc = metrics5[5 * (size_t)pa + lane];
         c0 = counts2[2 * (size_t)pa + 0]; c1 = counts2[2 * (size_t)pa + 1];
     }
-    const uint64_t beg = offsets[nd], end = offsets[nd + 1];
     for (uint64_t base = beg; base < end; base += 64) {
-        const uint64_t i = base + lane;
-        double d_raw = 0, d_cos = 0, d_wc = 0, d_lc = 0, d_mag = 0;
-        int d_pres = 0, d_uniq = 0, hit = 0;
-        if (i < end) {
-            const int64_t pc = ch_par[i], cc = ch_child[i];
-            const double logC = cc > 0 ? log1p_count(cc) : 0.0;
-            const double logP = pc > 0 ? log1p_count(pc) : 0.0;
-            d_mag = logC * logC - logP * logP;
-            d_uniq = (cc > 0) - (pc > 0);
-            double L;
-            if (cc != pc && has_kept && kept_lookup(tkeys, tvals, mask, ch_hash[i], &L)) {
-                hit = 1;
-                d_pres = (int)((pc == 0) & (cc != 0)) - (int)((cc == 0) & (pc != 0));
-                const double o1 = pc > 0 ? L / (double)pc : 0.0, n1 = cc > 0 ? L / (double)cc : 0.0;
-                d_raw = n1 - o1;
-                d_cos = L * (logC - logP);
-                const double o2 = pc > 0 ? 1.0 / (double)pc : 0.0, n2 = cc > 0 ? 1.0 / (double)cc : 0.0;
-                d_wc = n2 - o2;
-                d_lc = (double)d_pres * L;
-            }
-        }
+        // two chunks of terms are in flight while this one is added up
+        const ScoreTerms nx2 = load_terms(base + 128 + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
         const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
-        for (int j = 0; j < cnt; ++j) {
-            m4 += __shfl(d_mag, j);
-            c1 += __shfl(d_uniq, j);
-            if (__shfl(hit, j)) {
-                c0 += __shfl(d_pres, j);
-                m0 += __shfl(d_raw, j);
-                m1 += __shfl(d_cos, j);
-                m2 += __shfl(d_wc, j);
-                m3 += __shfl(d_lc, j);
+        c1 += wave_sum_int(cur.d_uniq);
+        c0 += wave_sum_int(cur.d_pres);          // d_pres is 0 unless hit
+        sh[lane * 5 + 0] = cur.d_raw; sh[lane * 5 + 1] = cur.d_cos; sh[lane * 5 + 2] = cur.d_wc; sh[lane * 5 + 3] = cur.d_lc;
+        sh[lane * 5 + 4] = cur.d_mag;
+        __builtin_amdgcn_wave_barrier();          // same-wave LDS traffic is ordered; this only pins the compiler
+        if (lane < 5) {
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+                const double v0 = sh[(j + 0) * 5 + lane], v1 = sh[(j + 1) * 5 + lane], v2 = sh[(j + 2) * 5 + lane],
+                             v3 = sh[(j + 3) * 5 + lane], v4 = sh[(j + 4) * 5 + lane], v5 = sh[(j + 5) * 5 + lane],
+                             v6 = sh[(j + 6) * 5 + lane], v7 = sh[(j + 7) * 5 + lane];
+                acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
             }
+            for (; j < cnt; ++j) acc += sh[j * 5 + lane];
         }
+        __builtin_amdgcn_wave_barrier();
+        cur = nx1;
+        nx1 = nx2;
     }
-    if (lane == 0) {
-        metrics5[5 * (size_t)nd + 0] = m0; metrics5[5 * (size_t)nd + 1] = m1; metrics5[5 * (size_t)nd + 2] = m2;
-        metrics5[5 * (size_t)nd + 3] = m3; metrics5[5 * (size_t)nd + 4] = m4;
-        counts2[2 * (size_t)nd + 0] = c0; counts2[2 * (size_t)nd + 1] = c1;
-    }
+    if (lane < 5) metrics5[5 * (size_t)nd + lane] = acc;
+    if (lane == 0) { counts2[2 * (size_t)nd + 0] = c0; counts2[2 * (size_t)nd + 1] = c1; }
 }
 
 // score getters (src/placement.hpp:120-149); TSV order log_raw, log_cosine, containment,

@@ -30,7 +30,7 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
     Layout L = plan_layout_compact(max_len, n_segs, o);
     L.slow_bytes += 64;
     const Layout Lserve = L;
-    L.tb_cap = 8 * 1024;   // the thread-per-pair kernel's in-lane DP limit (api_align.hip: tpp_layout)
+    L.tb_cap = 0;   // like api_align.hip: no in-lane DPs, every DP is a request
     std::vector<uint8_t> dp_req(sizeof(DpReq));
     std::vector<DpRes> dp_res(PMX_DP_MAX_CALLS);
     int64_t n_requests = 0, n_wave = 0;
@@ -75,6 +75,7 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
             if ((W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) || !(W.status & PMX_ST_NEED_DP)) break;
             const DpReq* rq = reinterpret_cast<const DpReq*>(dp_req.data());
             if ((int)rq->call != n_cached) return -4;
+            if (getenv("PMX_HS_DUMP")) fprintf(stderr, "REQ %d %d %d %d\n", rq->qlen, rq->tlen, rq->w, rq->flag);
             Work W2;
             memset(&W2, 0, sizeof(W2));
             bind_work(W2, Lserve, fast.data(), slow.data());
