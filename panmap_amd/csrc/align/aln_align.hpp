@@ -28,8 +28,20 @@ PMX_HD void gen_simple_mat(int8_t* mat, int8_t a, int8_t b, int8_t sc_ambi) {   
 PMX_HD void ref_getseq(const RefIndex& ri, int st, int en, Ptr<uint8_t> out) {   // mm_idx_getseq (index.c:152-162)
     PMX_LDS(out);
     if (en > ri.len) en = ri.len;
+#if PMX_W == 1
+    // scalar copy: aligned 32-bit loads from the reference, 32-bit stores while four bases are available
+    GlobalByteReader src(ri.seq);
+    Ptr<uint32_t> out4 = ptr_cast<uint32_t>(out);
+    int i = st;
+    for (; i + 4 <= en; i += 4) {
+        const uint32_t wd = src[i] | src[i + 1] << 8 | src[i + 2] << 16 | src[i + 3] << 24;
+        out4[(i - st) >> 2] = wd;
+    }
+    for (; i < en; ++i) out[i - st] = (uint8_t)src[i];
+#else
     const int lane = lane_id();
     for (int i = st + lane; i < en; i += PMX_W) out[i - st] = ri.seq[i];
+#endif
     wave_sync();
 }
 
@@ -104,11 +116,12 @@ PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const
             }
         } else { mx = sc; max_i = ii; max_j = jj; }
     };
+    ByteReader q_r(qseq), t_r(tseq);
     for (int k = 0; k < n_cigar; ++k) {
         const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
         if (op == 0) {
             for (uint32_t l = 0; l < len; ++l) {
-                score += o.mat[tseq[i + l] * 5 + qseq[j + l]];
+                score += o.mat[t_r[i + (int)l] * 5 + q_r[j + (int)l]];
                 upd(score, i + (int)l, j + (int)l);
             }
             i += len; j += len;
@@ -206,13 +219,14 @@ PMX_HDN void update_extra(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const ui
     qseq += qshift;
     tseq += tshift;
     Ptr<const uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
+    ByteReader q_r(qseq), t_r(tseq);
     r.blen = r.mlen = 0;
     for (uint32_t k = 0; k < r.n_cigar; ++k) {
         const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
         if (op == 0) {
             int n_ambi = 0, n_diff = 0;
             for (uint32_t l = 0; l < len; ++l) {
-                const int cq = qseq[qoff + l], ct = tseq[toff + l];
+                const int cq = (int)q_r[qoff + (int)l], ct = (int)t_r[toff + (int)l];
                 if (ct > 3 || cq > 3) ++n_ambi;
                 else if (ct != cq) ++n_diff;
                 s += mat[ct * 5 + cq];
@@ -226,7 +240,7 @@ PMX_HDN void update_extra(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const ui
         } else if (op == 1) {
             int n_ambi = 0;
             for (uint32_t l = 0; l < len; ++l)
-                if (qseq[qoff + l] > 3) ++n_ambi;
+                if (q_r[qoff + (int)l] > 3) ++n_ambi;
             r.blen += len - n_ambi;
             r.n_ambi += n_ambi;
             s -= q + (double)e * mg_log2f((float)(1.0 + len));
@@ -235,7 +249,7 @@ PMX_HDN void update_extra(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const ui
         } else if (op == 2) {
             int n_ambi = 0;
             for (uint32_t l = 0; l < len; ++l)
-                if (tseq[toff + l] > 3) ++n_ambi;
+                if (t_r[toff + (int)l] > 3) ++n_ambi;
             r.blen += len - n_ambi;
             r.n_ambi += n_ambi;
             s -= q + (double)e * mg_log2f((float)(1.0 + len));

@@ -81,7 +81,7 @@ struct HostRefIndex {
     RefIndex view() const {
         RefIndex r;
         r.seq = seq.data();
-        r.len = (int32_t)seq.size();
+        r.len = (int32_t)seq.size() - 8;   // seq carries 8 bytes of padding
         r.ht_mask = (uint32_t)ht_key.size() - 1;
         r.ht_key = ht_key.data();
         r.ht_off = ht_off.data();
@@ -108,7 +108,7 @@ inline uint8_t nt4_of_char(unsigned char c) {   // seq_nt4_table (sketch.c:9-26)
 #ifndef PMX_INTERLEAVED   // host-only (raw pointers); the thread-per-pair device pass skips it
 inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp_score, HostRefIndex& out) {
     out = HostRefIndex();
-    out.seq.resize((size_t)ref_len);
+    out.seq.assign((size_t)ref_len + 8, 0);   // padded: readers fetch aligned 32-bit words
     for (int64_t i = 0; i < ref_len; ++i) out.seq[i] = nt4_of_char((unsigned char)ref[i]);
     o.ref_len = (int)ref_len;
     Work W;

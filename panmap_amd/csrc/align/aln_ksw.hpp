@@ -637,9 +637,12 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
         if ((flag & PMX_EZ_EXTZ_ONLY) && tlen >= qlen && zdrop >= 2 * gmax + a + (a + b)) {
             // d = differing or ambiguous positions among the first qlen; pm = the largest such position
             int d = 0, pm = -1;
-            for (int i = lane_id(); i < qlen; i += PMX_W) {
-                const bool bad = query[i] != target[i] || query[i] > 3 || target[i] > 3;
-                if (bad) { ++d; pm = i; }
+            {
+                ByteReader qr_(query), tr_(target);
+                for (int i = lane_id(); i < qlen; i += PMX_W) {
+                    const uint32_t cq = qr_[i], ct = tr_[i];
+                    if (cq != ct || cq > 3 || ct > 3) { ++d; pm = i; }
+                }
             }
             d = wave_sum_i32(d);
             if (d == 0) {
@@ -673,10 +676,17 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
                 }
             }
         } else if (!(flag & PMX_EZ_EXTZ_ONLY) && (flag & PMX_EZ_APPROX_MAX) && !(flag & PMX_EZ_APPROX_DROP) && qlen == tlen) {
-            const int d = count_diff(query, target, qlen);
-            // count_diff also counts ambiguous bases; any such position forces the DP (d is then unreliable)
-            int amb = 0;
-            for (int i = lane_id(); i < qlen; i += PMX_W) amb += (query[i] > 3 || target[i] > 3) ? 1 : 0;
+            // differing positions, and ambiguous bases (any of those forces the DP)
+            int d = 0, amb = 0;
+            {
+                ByteReader qr_(query), tr_(target);
+                for (int i = lane_id(); i < qlen; i += PMX_W) {
+                    const uint32_t cq = qr_[i], ct = tr_[i];
+                    d += (cq != ct || cq > 3) ? 1 : 0;
+                    amb += (cq > 3 || ct > 3) ? 1 : 0;
+                }
+            }
+            d = wave_sum_i32(d);
             amb = wave_sum_i32(amb);
             if (amb == 0 && d * (a + b) < a + 2 * gmin) {
                 ez_reset(ez);

@@ -39,8 +39,9 @@ PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int
         else W.status |= PMX_ST_OVERFLOW;                             \
         if (W.n_mv < W.caps.max_mini) ++W.n_mv;                       \
     } while (0)
+    ByteReader seq_r(seq);
     for (int i = 0; i < len; ++i) {
-        const int c = seq[i];
+        const int c = (int)seq_r[i];
         A128 info;
         info.x = info.y = UINT64_MAX;
         if (c < 4) {

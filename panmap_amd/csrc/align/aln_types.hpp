@@ -42,7 +42,7 @@ PMX_HD void wave_sync() {}
 #define PMX_LDS(p) ((void)0)
 #endif
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PMX_THREAD_PER_PAIR)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define PMX_STAMP(W, k)                                                              \
     do {                                                                            \
         if ((W).prof) {                                                             \
@@ -122,6 +122,41 @@ template <class U, class T> __device__ __forceinline__ IPtr<U> ptr_cast(IPtr<T> 
 #else
 template <class T> using Ptr = T*;
 template <class U, class T> PMX_HD U* ptr_cast(T* q) { return reinterpret_cast<U*>(q); }
+#endif
+
+// Sequential byte reads through ALIGNED 32-bit loads: the per-base loops of the pipeline (sketch, mismatch
+// scans, z-drop test, alignment statistics, reference copies) issue one memory access per four bases instead
+// of one per base.  Works on either pointer flavour: the aligned word that contains byte i is loaded once
+// and kept until the scan leaves it (arrays are padded, so the word never leaves the allocation).
+#ifdef PMX_INTERLEAVED
+struct ByteReader {
+    uint32_t base, tag, w;
+    __device__ __forceinline__ explicit ByteReader(IPtr<const uint8_t> q) : base(q.o), tag(0xffffffffu), w(0) {}
+    __device__ __forceinline__ uint32_t operator[](int i) {
+        const uint32_t o = base + (uint32_t)i;
+        if ((o >> 2) != tag) { tag = o >> 2; w = *IPtr<const uint32_t>::phys(o & ~3u); }
+        return (w >> ((o & 3u) * 8u)) & 0xffu;
+    }
+};
+#endif
+struct RawByteReader {   // wave-per-pair kernels / host: plain byte reads (lanes stride the loops, LDS pointers stay LDS)
+    const uint8_t* base;
+    PMX_HD explicit RawByteReader(const uint8_t* q) : base(q) {}
+    PMX_HD uint32_t operator[](int i) const { return base[i]; }
+};
+struct GlobalByteReader {   // reference sequence in global memory, any mode
+    const uint8_t* base;
+    uintptr_t tag;
+    uint32_t w;
+    PMX_HD explicit GlobalByteReader(const uint8_t* q) : base(q), tag(~(uintptr_t)0), w(0) {}
+    PMX_HD uint32_t operator[](int i) {
+        const uintptr_t a = (uintptr_t)(base + i);
+        if ((a >> 2) != tag) { tag = a >> 2; w = *reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3); }
+        return (w >> ((a & 3u) * 8u)) & 0xffu;
+    }
+};
+#ifndef PMX_INTERLEAVED
+typedef RawByteReader ByteReader;
 #endif
 
 // anchor flag bits in A128::y (mmpriv.h:17-23)

@@ -41,7 +41,8 @@ k_align_reads_tpp(AlignArgs A) {
         Work W;
         bind_work(W, A.layout, nullptr, nullptr, raw);
         W.n_segs = n_segs;
-        W.prof = nullptr;
+        W.prof = A.prof;   // diagnostic runs: lane 0's stamps are the wave's phase timeline
+        if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 16; ++k) W.prof_acc[k] = 0; }
         W.dp_req_base = A.dp_req_base;
         W.dp_slot_cap = A.dp_slot_cap;
         W.dp_slot = slot;
@@ -62,21 +63,34 @@ k_align_reads_tpp(AlignArgs A) {
                 const int len = W.qlen[s];
                 const uint64_t* rw = A.words + A.woff[r];
                 const uint32_t* ra = A.amb + A.woff[r];
-                Ptr<uint8_t> fwd = W.qseq[s][0];
-                Ptr<uint8_t> rev = W.qseq[s][1];
+                // X = the read as stored (forward strand, or the reverse-strand array when the mate is
+                // reverse-complemented on the fly); Y = complement of X read backwards.  Four bases per store.
                 const bool rc = A.revcomp_mate2 && s == 1;
+                Ptr<uint8_t> X = rc ? W.qseq[s][1] : W.qseq[s][0];
+                Ptr<uint8_t> Y = rc ? W.qseq[s][0] : W.qseq[s][1];
+                Ptr<uint32_t> X4 = ptr_cast<uint32_t>(X), Y4 = ptr_cast<uint32_t>(Y);
                 uint64_t cw = 0;
-                uint32_t ca = 0;
+                uint32_t ca = 0, wd = 0;
                 for (int i = 0; i < len; ++i) {
                     if ((i & 31) == 0) { cw = rw[i >> 5]; ca = ra[i >> 5]; }
                     const uint32_t code = (uint32_t)cw & 3u, am = ca & 1u;
                     cw >>= 2; ca >>= 1;
-                    const uint8_t c = am ? (code == 3 ? 3 : 4) : (uint8_t)code;
-                    const uint8_t cc = c < 4 ? (uint8_t)(3 - c) : (uint8_t)4;
-                    if (!rc) { fwd[i] = c; rev[len - 1 - i] = cc; }
-                    else { fwd[len - 1 - i] = cc; rev[i] = c; }
+                    const uint32_t c = am ? (code == 3 ? 3u : 4u) : code;
+                    wd |= c << ((i & 3) * 8);
+                    if ((i & 3) == 3) { X4[i >> 2] = wd; wd = 0; }
                 }
+                for (int i = len & ~3; i < len; ++i) X[i] = (uint8_t)(wd >> ((i & 3) * 8));
+                ByteReader xr(X);
+                wd = 0;
+                for (int j = 0; j < len; ++j) {
+                    const uint32_t c = xr[len - 1 - j];
+                    const uint32_t cc = c < 4 ? 3u - c : 4u;
+                    wd |= cc << ((j & 3) * 8);
+                    if ((j & 3) == 3) { Y4[j >> 2] = wd; wd = 0; }
+                }
+                for (int j = len & ~3; j < len; ++j) Y[j] = (uint8_t)(wd >> ((j & 3) * 8));
             }
+            PMX_STAMP(W, 0);
             map_frag(W, A.opt, A.ri);
         } else {
             W.status |= PMX_ST_OVERFLOW;
@@ -118,6 +132,11 @@ k_align_reads_tpp(AlignArgs A) {
                 }
             }
             A.records[r] = rec;
+        }
+        if (A.prof) {
+            PMX_STAMP(W, 11);
+            if ((threadIdx.x & 63) == 0)
+                for (int k = 0; k < 12; ++k) atomicAdd(&A.prof[k], W.prof_acc[k]);
         }
     }
 }

@@ -222,7 +222,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             const Layout dp_layout = plan_layout_dp((int)rs->max_len, n_segs, al->opt);
             const size_t dp_lds = PMX_ALIGN_WORK_BYTES + dp_layout.fast_bytes + 16;
             const size_t dp_stride = (dp_layout.slow_bytes + 255) & ~(size_t)255;
-            int64_t small_rounds = 2048;   // fewer pairs than this cannot fill the chip thread-per-pair: wave tier
+            int64_t small_rounds = 16384;   // fewer pairs than this cannot fill the chip thread-per-pair: wave tier
             if (const char* e = getenv("PMX_ALIGN_TPP_MIN")) small_rounds = atoll(e);
             const int64_t dp_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dp_lds);
             const int small_qlen = 128, small_tlen = 128;   // ksw_extd2_reg<2>: two target columns per lane
