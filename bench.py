@@ -166,7 +166,7 @@ def main():
         step()
     sync_all()
     t0 = time.perf_counter()
-    kernel_ms = {"align": [], "seed": [], "score": []}
+    kernel_ms = {"align": [], "align_tpp0": [], "seed": [], "score": []}
     for _ in range(args.steps):
         step()
         for k in kernel_ms:
@@ -190,12 +190,26 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_reads * args.steps / elapsed
         align_ms = float(np.mean(kernel_ms["align"]))
+        tpp0_ms = float(np.mean(kernel_ms["align_tpp0"]))
         seed_ms = float(np.mean(kernel_ms["seed"]))
         score_ms = float(np.mean(kernel_ms["score"]))
-        # dominant kernel = k_align_reads.  Algorithmic HBM bytes per read: 38 B packed
-        # bases + 19 B ambiguity words in, 32 B record + 4 B per CIGAR op out ~= 80 B + 13 B = 93 B
+        # Dominant kernel = k_align_reads_tpp, round 0 (every pair of the batch, one launch per step); its duration
+        # is measured with HIP events recorded on the launch stream (pmx_last_kernel_ms).  Algorithmic HBM bytes
+        # per read: 38 B packed bases + 19 B ambiguity words in, 32 B record + 4 B per
+        # CIGAR op out ~= 93 B; times the reads of one launch.
         alg_bytes = n_reads * (38 + 19 + 32 + 4.0 * float(np.mean(recs["n_cigar"])))
-        achieved = alg_bytes / (align_ms * 1e-3) / 1e9
+        dom_ms = tpp0_ms if tpp0_ms > 0 else align_ms
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of that kernel per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, see profiles/r01/README.md); only valid for the workload it was collected on.
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")) as fh:
+                pt = json.load(fh)
+            if pt.get("reads_per_gpu") == n_reads and pt.get("read_len") == args.read_len and world == 1:
+                traffic = float(pt["k_align_reads_tpp_round0"]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "reads placed+aligned/sec, 10M×150bp vs 20k-genome PanMAN, 1/2/4/8 MI355X",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -205,11 +219,13 @@ def main():
                                    % (args.reads_per_gpu // 1000000, args.read_len, "" if world == 1 else "; read-sharded, seed index replicated, RCCL histogram all-gather + record gather"),
                        "reads_per_gpu": n_reads, "read_len": args.read_len, "index": "k=19,s=8,l=3,closed syncmers,flank-mask 250",
                        "aligner_preset": "k=21,w=11,a=2,b=8,q=12,e=2,q2=24,e2=1 (src/mm_align.c:140-166)"},
-            "roofline": {"bound": "hbm", "kernel": "k_align_reads", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "kernel_ms": align_ms, "note": "integer DP kernel: VALU/LDS-bound by construction, HBM fraction is low; see DESIGN.md",
-                         "dp_gcups": n_reads * 1.3e4 / (align_ms * 1e-3) / 1e9},
-            "kernels_ms": {"k_seed_histogram": seed_ms, "k_score_level(all levels)": score_ms, "k_align_reads": align_ms},
+            "roofline": {"bound": "hbm", "kernel": "k_align_reads_tpp (round 0: all pairs)", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": dom_ms,
+                         "note": "thread-per-pair mapping kernel: per-pair work state (~10 KB touched) lives in an interleaved "
+                                 "HBM arena, so its traffic, not the 93 B/read of input+output, is what the kernel moves; "
+                                 "it is bound by dependent L1/L2 round trips (DESIGN.md 4.1)"},
+            "kernels_ms": {"seed stage (k_seed_histogram, chunked)": seed_ms, "score stage (k_score_terms + k_score_level x levels)": score_ms,
+                           "align stage (all tiers)": align_ms, "k_align_reads_tpp round 0": tpp0_ms},
             "checks": {"placed_node": placed_id, "mapped_fraction": mapped_frac, "records_flagged": flagged,
                        "unique_seeds": int(res.n_unique_seeds), "kept_seeds": int(res.readUniqueSeedCount)},
         }

@@ -62,6 +62,29 @@ def hostsim_align(reference: bytes, reads, paired, verbose=0, tpp=False):
     return records_to_results(recs, cig, n, paired)
 
 
+def golden_cases(pmx):
+    """(genome, {name: (reads, expected results)}) of tests/golden/align_golden.json.gz; the inputs are regenerated
+    exactly as tests/golden/make_align_golden.py made them"""
+    import gzip
+    import json
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_align_golden", os.path.join(HERE, "golden", "make_align_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    genome, sets = mod.inputs(pmx)
+    exp = json.loads(gzip.open(os.path.join(HERE, "golden", "align_golden.json.gz")).read())
+    out = {}
+    for name, reads in sets.items():
+        want = []
+        for row in exp[name]:
+            d = {"mapped": row[0]}
+            for m, r in (("r1", row[1]), ("r2", row[2])):
+                d[m] = dict(pos=r[0], rs=r[1], re=r[2], qs=r[3], qe=r[4], mapq=r[5], rev=r[6], proper_frag=r[7], cigar=r[8])
+            want.append(d)
+        out[name] = (reads, want)
+    return genome, out
+
+
 def cigar_str(c):
     return "".join("%d%s" % (x >> 4, "MIDNSHP=X"[x & 0xf]) for x in c)
 

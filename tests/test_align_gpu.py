@@ -130,3 +130,15 @@ def test_full_size_properties(pmx, ctx):
         if i & 1:
             read = comp[read[::-1]]
         assert np.array_equal(read[r["qs"]:r["qe"]], ga[r["rs"]:r["re"]])
+
+
+def test_golden_fixture_gpu(pmx, ctx):
+    """HIP path vs the committed outputs of the reference aligner (tests/golden/align_golden.json.gz)"""
+    g, cases_ = ac.golden_cases(pmx)
+    for name, (reads, want) in cases_.items():
+        mean_len = int(sum(len(r) for r in reads) / len(reads))
+        al = pmx.Aligner(ctx, g, mean_len)
+        got = al.align_reads(reads, paired=True)
+        bad = ac.compare_results(got, want)
+        assert not bad, (name, bad[:10])
+        assert sum(1 for x in got if x["flags"] & 3) <= 2

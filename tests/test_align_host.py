@@ -62,3 +62,15 @@ def test_thread_per_pair_dp_service_replay(pmx, oracle, cases, name):
     assert len(keep) >= 0.9 * len(got), (len(keep), len(got))
     bad = ac.compare_results([got[i] for i in keep], [want[i] for i in keep])
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("tpp", [False, True])
+def test_golden_fixture(pmx, tpp):
+    """committed outputs of the reference aligner (tests/golden/align_golden.json.gz): no oracle/_ref needed"""
+    g, cases_ = ac.golden_cases(pmx)
+    for name, (reads, want) in cases_.items():
+        got = ac.hostsim_align(g, reads, True, tpp=tpp)
+        keep = [i for i, x in enumerate(got) if not (x["flags"] & 0x8000)]
+        assert len(keep) >= 0.95 * len(got)
+        bad = ac.compare_results([got[i] for i in keep], [want[i] for i in keep])
+        assert not bad, (name, bad[:10])
