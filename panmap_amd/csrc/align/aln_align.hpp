@@ -270,7 +270,7 @@ PMX_HD int anchor_gap(Ptr<const A128> a, int i) {   // query advance minus refer
     return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - ((int32_t)a[i].x - (int32_t)a[i - 1].x);
 }
 
-// collect_long_gaps + mm_filter_bad_seeds (align.c:374-427).  K[] lives in the idle chain-DP array W.f.
+// collect_long_gaps + mm_filter_bad_seeds (align.c:374-427).  K[] lives in W.kidx.
 PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, Ptr<const A128> a, int min_gap, Ptr<int32_t> K, int cap) {
     PMX_LDS(&W); PMX_LDS(a); PMX_LDS(K);
     int n = 0;
@@ -290,7 +290,7 @@ PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, Ptr<const A128> a, int 
 
 PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, Ptr<A128> a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
     PMX_LDS(&W); PMX_LDS(a);
-    Ptr<int32_t> K = W.f; PMX_LDS(K);   // chain DP arrays are idle during alignment
+    Ptr<int32_t> K = W.kidx; PMX_LDS(K);
     const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
     if (n == 0) return;
     int mx = 0, max_st = -1, max_en = -1;
@@ -325,7 +325,7 @@ PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, Ptr<A128> a, int min_g
 // mm_filter_bad_seeds_alt (align.c:429-462)
 PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, Ptr<A128> a, int min_gap, int max_ext) {
     PMX_LDS(&W); PMX_LDS(a);
-    Ptr<int32_t> K = W.f; PMX_LDS(K);
+    Ptr<int32_t> K = W.kidx; PMX_LDS(K);
     const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
     if (n == 0) return;
     for (int k = 0; k < n;) {

@@ -48,19 +48,19 @@ PMX_HD int32_t chain_score(const A128 ai, const A128 aj, int32_t max_dist_x, int
 }
 
 // mg_chain_bk_end (lchain.c:9-25)
-PMX_HD int64_t chain_bk_end(int32_t max_drop, Ptr<const A128> z, Ptr<const int32_t> f, Ptr<const int32_t> p, Ptr<int32_t> t, int64_t k) {
-    PMX_LDS(z); PMX_LDS(f); PMX_LDS(p); PMX_LDS(t);
+PMX_HD int64_t chain_bk_end(int32_t max_drop, Ptr<const A128> z, Ptr<ChainCell> c, int64_t k) {
+    PMX_LDS(z); PMX_LDS(c);
     int64_t i = (int64_t)z[k].y, end_i = -1, max_i = i;
     int32_t max_s = 0;
-    if (i < 0 || t[i] != 0) return i;
+    if (i < 0 || c[i].t != 0) return i;
     do {
-        t[i] = 2;
-        end_i = i = p[i];
-        const int32_t s = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
+        c[i].t = 2;
+        end_i = i = c[i].p;
+        const int32_t s = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - c[i].f;
         if (s > max_s) { max_s = s; max_i = i; }
         else if (max_s - s > max_drop) break;
-    } while (i >= 0 && t[i] == 0);
-    for (i = (int64_t)z[k].y; i >= 0 && i != end_i; i = p[i]) t[i] = 0;
+    } while (i >= 0 && c[i].t == 0);
+    for (i = (int64_t)z[k].y; i >= 0 && i != end_i; i = c[i].p) c[i].t = 0;
     return max_i;
 }
 
@@ -152,9 +152,8 @@ __device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_d
         }
     }
     {
-        int32_t *f_ = W.f, *p_ = W.p, *v_ = W.v;
-        PMX_LDS(f_); PMX_LDS(p_); PMX_LDS(v_);
-        if (lane < n) { f_[lane] = fj; p_[lane] = pj; v_[lane] = vj; }
+        ChainCell* c_ = W.cc; PMX_LDS(c_);
+        if (lane < n) { c_[lane].f = fj; c_[lane].p = pj; c_[lane].v = vj; }
     }
     wave_sync();
 }
@@ -171,8 +170,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     W.n_u = 0;
     if (n == 0) return;
     Ptr<A128> a = W.a; PMX_LDS(a);
-    Ptr<int32_t> f = W.f, t = W.t, v = W.v, p = W.p;
-    PMX_LDS(f); PMX_LDS(t); PMX_LDS(v); PMX_LDS(p);
+    Ptr<ChainCell> c = W.cc; PMX_LDS(c);
     const int32_t max_drop = bw;
     if (max_dist_x < bw) max_dist_x = bw;
     if (max_dist_y < bw) max_dist_y = bw;
@@ -183,42 +181,52 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     const bool wave_fill = false;
 #endif
     if (!wave_fill) {
-    for (int64_t i = 0; i < n; ++i) t[i] = 0;
+        for (int64_t i = 0; i < n; ++i) c[i].t = 0;
         int64_t st = 0, max_ii = -1;
         for (int64_t i = 0; i < n; ++i) {
             int64_t max_j = -1, end_j;
-            int32_t max_f = (int32_t)(a[i].y >> 32 & 0xff), n_skip = 0;
-            while (st < i && (a[i].x >> 32 != a[st].x >> 32 || a[i].x > a[st].x + (uint64_t)max_dist_x)) ++st;
+            const A128 ai = a[i];
+            int32_t max_f = (int32_t)(ai.y >> 32 & 0xff), n_skip = 0;
+            while (st < i && (ai.x >> 32 != a[st].x >> 32 || ai.x > a[st].x + (uint64_t)max_dist_x)) ++st;
             if (i - st > max_iter) st = i - max_iter;
             int64_t j;
             for (j = i - 1; j >= st; --j) {
-                int32_t sc = chain_score(a[i], a[j], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                int32_t sc = chain_score(ai, a[j], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
                 if (sc == INT32_MIN) continue;
-                sc += f[j];
+                const ChainCell cj = c[j];
+                sc += cj.f;
                 if (sc > max_f) {
                     max_f = sc;
                     max_j = j;
                     if (n_skip > 0) --n_skip;
-                } else if (t[j] == (int32_t)i) {
+                } else if (cj.t == (int32_t)i) {
                     if (++n_skip > max_skip) break;
                 }
-                if (p[j] >= 0) t[p[j]] = (int32_t)i;
+                if (cj.p >= 0) c[cj.p].t = (int32_t)i;
             }
             end_j = j;
-            if (max_ii < 0 || (int64_t)(a[i].x - a[max_ii].x) > (int64_t)max_dist_x) {
+            if (max_ii < 0 || (int64_t)(ai.x - a[max_ii].x) > (int64_t)max_dist_x) {
                 int32_t mx = INT32_MIN;
                 max_ii = -1;
-                for (j = i - 1; j >= st; --j)
-                    if (mx < f[j]) { mx = f[j]; max_ii = j; }
+                for (j = i - 1; j >= st; --j) {
+                    const int32_t fj = c[j].f;
+                    if (mx < fj) { mx = fj; max_ii = j; }
+                }
             }
             if (max_ii >= 0 && max_ii < end_j) {
-                const int32_t tmp = chain_score(a[i], a[max_ii], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
-                if (tmp != INT32_MIN && max_f < tmp + f[max_ii]) { max_f = tmp + f[max_ii]; max_j = max_ii; }
+                const int32_t tmp = chain_score(ai, a[max_ii], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                const int32_t fm = c[max_ii].f;
+                if (tmp != INT32_MIN && max_f < tmp + fm) { max_f = tmp + fm; max_j = max_ii; }
             }
-            f[i] = max_f;
-            p[i] = (int32_t)max_j;
-            v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
-            if (max_ii < 0 || ((int64_t)(a[i].x - a[max_ii].x) <= (int64_t)max_dist_x && f[max_ii] < f[i])) max_ii = i;
+            {
+                const int32_t vm = max_j >= 0 ? c[max_j].v : 0;
+                ChainCell ci = c[i];
+                ci.f = max_f;
+                ci.p = (int32_t)max_j;
+                ci.v = max_j >= 0 && vm > max_f ? vm : max_f;
+                c[i] = ci;
+            }
+            if (max_ii < 0 || ((int64_t)(ai.x - a[max_ii].x) <= (int64_t)max_dist_x && c[max_ii].f < max_f)) max_ii = i;
         }
     }
 
@@ -226,21 +234,21 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     Ptr<A128> z = W.z; PMX_LDS(z);
     int64_t n_z = 0;
     for (int64_t i = 0; i < n; ++i)
-        if (f[i] >= min_sc) { z[n_z].x = (uint64_t)(int64_t)f[i]; z[n_z].y = (uint64_t)i; ++n_z; }
+        if (c[i].f >= min_sc) { z[n_z].x = (uint64_t)(int64_t)c[i].f; z[n_z].y = (uint64_t)i; ++n_z; }
     if (n_z == 0) { W.n_a = 0; return; }
     radix_sort_128x(z, z + n_z, &W.status);
-    for (int64_t i = 0; i < n; ++i) t[i] = 0;
+    for (int64_t i = 0; i < n; ++i) c[i].t = 0;
     int64_t n_v = 0;
     int32_t n_u = 0;
     Ptr<uint64_t> u = W.u; PMX_LDS(u);
     // (the reference runs this loop twice, first only to size u[]; one pass gives the same u[] and v[])
     for (int64_t k = n_z - 1; k >= 0; --k) {
-        if (t[z[k].y] == 0) {
+        if (c[z[k].y].t == 0) {
             const int64_t n_v0 = n_v;
-            const int64_t end_i = chain_bk_end(max_drop, z, f, p, t, k);
+            const int64_t end_i = chain_bk_end(max_drop, z, c, k);
             int64_t i;
-            for (i = (int64_t)z[k].y; i != end_i; i = p[i]) { v[n_v++] = (int32_t)i; t[i] = 1; }
-            const int32_t sc = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - f[i];
+            for (i = (int64_t)z[k].y; i != end_i; i = c[i].p) { c[n_v++].v = (int32_t)i; c[i].t = 1; }
+            const int32_t sc = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - c[i].f;
             if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
                 if (n_u < W.caps.max_reg * 4) u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(n_v - n_v0);
                 else { W.status |= PMX_ST_OVERFLOW; n_v = n_v0; }
@@ -255,7 +263,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     for (int32_t i = 0; i < n_u; ++i) {
         const int64_t k0 = kk;
         const int32_t ni = (int32_t)u[i];
-        for (int32_t j = 0; j < ni; ++j) b[kk++] = a[v[k0 + (ni - j - 1)]];
+        for (int32_t j = 0; j < ni; ++j) b[kk++] = a[c[k0 + (ni - j - 1)].v];
     }
     Ptr<A128> wv = W.z; PMX_LDS(wv);   // z[] is free again
     kk = 0;

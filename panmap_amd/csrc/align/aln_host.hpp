@@ -185,7 +185,7 @@ struct Layout {
     size_t fast_bytes = 0, slow_bytes = 0, raw_bytes = 0;
     size_t tb_cap = 0;
     struct Ent { uint32_t space; size_t off; };
-    Ent qseq, mv, sk_buf, seeds, mini_pos, heap, a, a2, f, t, v, p, z, u, u2, regs0, regs1, regs2, reg_tmp, seg_a0, seg_a1, seg_u0,
+    Ent qseq, mv, sk_buf, seeds, seeds_b, mini_pos, heap, a, a2, cc, kidx, z, u, u2, regs0, regs1, regs2, reg_tmp, seg_a0, seg_a1, seg_u0,
         seg_u1, aux64, aux32, aux128, du, sf, qr, H, off_, tseq, cig_tmp, cig_pool, tb, tb_fast;
     size_t tb_fast_cap = 0;   // DP-service layout only: LDS traceback area for small DPs
 };
@@ -224,16 +224,15 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
     place(L.qseq, (size_t)4 * c.max_qlen, PMX_FAST);
     place(L.tseq, (size_t)c.max_tlen + 32, PMX_FAST);
     place(L.a, sizeof(A128) * c.max_anchor, PMX_FAST);
-    place(L.f, 16 * (size_t)c.max_anchor, PMX_FAST);   // f,p,t,v as ONE block (also the seed-position cache)
-    L.p = L.f; L.p.off += 4 * (size_t)c.max_anchor;
-    L.t = L.f; L.t.off += 8 * (size_t)c.max_anchor;
-    L.v = L.f; L.v.off += 12 * (size_t)c.max_anchor;
+    place(L.cc, sizeof(ChainCell) * (size_t)c.max_anchor, PMX_FAST);
+    L.kidx = L.cc;   // the chain cells are idle while regions are aligned
     place(L.regs0, sizeof(Reg) * c.max_reg, PMX_FAST);
     place(L.regs1, sizeof(Reg) * c.max_reg, PMX_FAST);
     place(L.regs2, sizeof(Reg) * c.max_reg, PMX_FAST);
     place(L.mv, sizeof(A128) * c.max_mini, PMX_FAST);
     place(L.sk_buf, sizeof(A128) * 256, PMX_SLOW);
-    place(L.seeds, sizeof(Seed) * c.max_mini, PMX_FAST);
+    place(L.seeds, sizeof(SeedA) * c.max_mini, PMX_FAST);
+    place(L.seeds_b, sizeof(SeedB) * c.max_mini, PMX_FAST);
     place(L.H, 4 * (size_t)(c.max_tlen + 32), PMX_FAST);
     place(L.off_, 8 * (size_t)(c.max_qlen + c.max_tlen), PMX_FAST);
     place(L.cig_tmp, 4 * (size_t)c.max_cigar, PMX_FAST);
@@ -302,12 +301,11 @@ inline Layout plan_layout_compact(int max_read_len, int n_segs, const Opt& o) {
     // overlay region
     size_t ca = top, cb = top, cd = top;
     put(L.sk_buf, sizeof(A128) * 32, ca);
-    put(L.seeds, sizeof(Seed) * c.max_mini, ca);
+    put(L.seeds, sizeof(SeedA) * c.max_mini, ca);
+    put(L.seeds_b, sizeof(SeedB) * c.max_mini, ca);
     put(L.heap, sizeof(A128) * c.max_mini, ca);
-    put(L.f, 16 * (size_t)c.max_anchor, cb);
-    L.p = L.f; L.p.off += 4 * (size_t)c.max_anchor;
-    L.t = L.f; L.t.off += 8 * (size_t)c.max_anchor;
-    L.v = L.f; L.v.off += 12 * (size_t)c.max_anchor;
+    put(L.cc, sizeof(ChainCell) * (size_t)c.max_anchor, cb);
+    L.kidx = L.cc;   // the chain cells are idle while regions are aligned
     put(L.z, sizeof(A128) * c.max_anchor, cb);
     put(L.a2, sizeof(A128) * c.max_anchor, cb);
     put(L.u2, 8 * (size_t)c.max_reg * 4, cb);
@@ -351,7 +349,7 @@ inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o, int sma
     };
     const Layout::Ent none{PMX_FAST, 0};   // unused arrays alias offset 0 (never dereferenced by ksw_extd2)
     L.mv = L.a = L.regs0 = L.regs1 = L.regs2 = L.reg_tmp = L.seg_a0 = L.seg_a1 = L.seg_u0 = L.seg_u1 = L.u = L.aux64 = L.aux32 = L.aux128 = none;
-    L.cig_pool = L.sk_buf = L.seeds = L.heap = L.f = L.p = L.t = L.v = L.z = L.a2 = L.u2 = L.tseq = L.mini_pos = none;
+    L.cig_pool = L.sk_buf = L.seeds = L.seeds_b = L.heap = L.cc = L.kidx = L.z = L.a2 = L.u2 = L.tseq = L.mini_pos = none;
     put(L.qseq, small_qlen > 0 ? (size_t)(((small_qlen + 15) & ~15) + small_tlen) : (size_t)std::max(4 * c.max_qlen, 512));
     if (small_qlen > 0) L.du = L.sf = L.qr = L.H = none;   // register-resident DP
     else {
@@ -373,7 +371,7 @@ inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o, int sma
 
 // Thread-per-pair layout (k_align_reads_tpp): the compact layout's arrays, addressed through IPtr (logical
 // offsets: FAST region first, SLOW region behind it, interleaved across the wave by IPtr::phys), except the
-// Reg / Seed struct arrays, which live in a small per-thread contiguous RAW region behind plain pointers.
+// Reg struct arrays, which live in a small per-thread contiguous RAW region behind plain pointers.
 // tb_bytes > 0 adds a per-thread traceback area (in-lane DPs; off by default).
 inline Layout plan_layout_tpp(int max_read_len, int n_segs, const Opt& o, size_t tb_bytes) {
     Layout L = plan_layout_compact(max_read_len, n_segs, o);   // capacities
@@ -393,21 +391,20 @@ inline Layout plan_layout_tpp(int max_read_len, int n_segs, const Opt& o, size_t
     put_raw(L.regs1, sizeof(Reg) * c.max_reg);
     put_raw(L.regs2, sizeof(Reg) * c.max_reg);
     put_raw(L.reg_tmp, sizeof(Reg) * c.max_reg);
-    put_raw(L.seeds, sizeof(Seed) * c.max_mini);
     L.raw_bytes = raw;
     put(L.qseq, (size_t)4 * c.max_qlen);
     put(L.tseq, (size_t)c.max_tlen + 32);
     put(L.mv, sizeof(A128) * c.max_mini);
+    put(L.seeds, sizeof(SeedA) * c.max_mini);
+    put(L.seeds_b, sizeof(SeedB) * c.max_mini);
     put(L.sk_buf, sizeof(A128) * 32);
     put(L.heap, sizeof(A128) * c.max_mini);
     put(L.mini_pos, 8 * (size_t)c.max_mini);
     put(L.a, sizeof(A128) * c.max_anchor);
     put(L.a2, sizeof(A128) * c.max_anchor);
     put(L.z, sizeof(A128) * c.max_anchor);
-    put(L.f, 16 * (size_t)c.max_anchor);
-    L.p = L.f; L.p.off += 4 * (size_t)c.max_anchor;
-    L.t = L.f; L.t.off += 8 * (size_t)c.max_anchor;
-    L.v = L.f; L.v.off += 12 * (size_t)c.max_anchor;
+    put(L.cc, sizeof(ChainCell) * (size_t)c.max_anchor);
+    put(L.kidx, 4 * (size_t)c.max_anchor);   // own region: a different interleave granule than the cells
     put(L.u, 8 * (size_t)c.max_reg * 4);
     put(L.u2, 8 * (size_t)c.max_reg * 4);
     put(L.seg_a0, sizeof(A128) * c.max_anchor);
@@ -450,10 +447,10 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow, ui
     const int mq = L.caps.max_qlen;
     Ptr<uint8_t> qs = PMX_AT(uint8_t, qseq);
     W.qseq[0][0] = qs; W.qseq[0][1] = qs + mq; W.qseq[1][0] = qs + 2 * mq; W.qseq[1][1] = qs + 3 * mq;
-    W.mv = PMX_AT(A128, mv); W.sk_buf = PMX_AT(A128, sk_buf); W.seeds = PMX_AT_RAW(Seed, seeds);
+    W.mv = PMX_AT(A128, mv); W.sk_buf = PMX_AT(A128, sk_buf); W.seeds = PMX_AT(SeedA, seeds); W.seeds_b = PMX_AT(SeedB, seeds_b);
     W.mini_pos = PMX_AT(uint64_t, mini_pos); W.heap = PMX_AT(A128, heap);
     W.a = PMX_AT(A128, a); W.a2 = PMX_AT(A128, a2);
-    W.f = PMX_AT(int32_t, f); W.t = PMX_AT(int32_t, t); W.v = PMX_AT(int32_t, v); W.p = PMX_AT(int32_t, p);
+    W.cc = PMX_AT(ChainCell, cc); W.kidx = PMX_AT(int32_t, kidx);
     W.z = PMX_AT(A128, z); W.u = PMX_AT(uint64_t, u); W.u2 = PMX_AT(uint64_t, u2);
     W.regs0 = PMX_AT_RAW(Reg, regs0); W.regs[0] = PMX_AT_RAW(Reg, regs1); W.regs[1] = PMX_AT_RAW(Reg, regs2);
     W.reg_tmp = PMX_AT_RAW(Reg, reg_tmp);

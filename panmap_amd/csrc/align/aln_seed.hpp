@@ -143,7 +143,7 @@ PMX_HD void heap_down_max_u64(uint64_t* l, int i, int n) {   // ks_heapdown_uint
 
 // mm_seed_select (seed.c:56-96): within a streak of high-occurrence minimizers keep the
 // max_high_occ least frequent ones.
-PMX_HDN void seed_select(int n, Seed* a, int len, int max_occ, int max_max_occ, int dist) {
+PMX_HDN void seed_select(int n, Ptr<SeedA> a, int len, int max_occ, int max_max_occ, int dist) {
     PMX_LDS(a);
     if (n == 0 || n == 1) return;
     int m = 0;
@@ -187,7 +187,8 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
     PMX_LDS(&W);
     Ptr<A128> mv = W.mv; PMX_LDS(mv);
     Ptr<A128> hp = W.heap; PMX_LDS(hp);
-    Seed* seeds = W.seeds; PMX_LDS(seeds);
+    Ptr<SeedA> seeds = W.seeds; PMX_LDS(seeds);
+    Ptr<SeedB> seeds_b = W.seeds_b; PMX_LDS(seeds_b);
     Ptr<uint64_t> mini_pos = W.mini_pos;   // global scratch (only mm_est_err would read it)
     int n_m0 = 0;
     for (int i = lane_id(); i < W.n_mv; i += PMX_W) {
@@ -202,16 +203,20 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
         const uint32_t off = (uint32_t)hp[i].x;
         const uint32_t t = (uint32_t)hp[i].y;
         if (t == 0) continue;
-        Seed q;
+        SeedA q;
+        SeedB qb;
         q.q_pos = (uint32_t)p.y;
-        q.q_span = (uint32_t)(p.x & 0xff);
+        qb.q_span = (uint32_t)(p.x & 0xff);
         q.off = off;
         q.n = t;
-        q.seg_id = (uint32_t)(p.y >> 32);
-        q.is_tandem = q.flt = 0;
-        if (i > 0 && p.x >> 8 == mv[i - 1].x >> 8) q.is_tandem = 1;
-        if (i < W.n_mv - 1 && p.x >> 8 == mv[i + 1].x >> 8) q.is_tandem = 1;
-        seeds[n_m0++] = q;
+        qb.seg_id = (uint32_t)(p.y >> 32);
+        qb.is_tandem = q.flt = 0;
+        qb.pad = 0;
+        if (i > 0 && p.x >> 8 == mv[i - 1].x >> 8) qb.is_tandem = 1;
+        if (i < W.n_mv - 1 && p.x >> 8 == mv[i + 1].x >> 8) qb.is_tandem = 1;
+        seeds[n_m0] = q;
+        seeds_b[n_m0] = qb;
+        ++n_m0;
     }
     wave_sync();
     if (o.occ_dist > 0 && o.max_max_occ > max_occ) seed_select(n_m0, seeds, qlen, max_occ, o.max_max_occ, o.occ_dist);
@@ -222,9 +227,10 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
     int64_t n_a = 0;
     W.n_mini_pos = 0;
     for (int i = 0; i < n_m0; ++i) {
-        const Seed q = seeds[i];
+        const SeedA q = seeds[i];
+        const SeedB qb = seeds_b[i];
         if (q.flt) {
-            const int en = (int)(q.q_pos >> 1) + 1, st = en - (int)q.q_span;
+            const int en = (int)(q.q_pos >> 1) + 1, st = en - (int)qb.q_span;
             if (st > rep_en) {
                 rep_len += rep_en - rep_st;
                 rep_st = st;
@@ -232,8 +238,10 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
             } else rep_en = en;
         } else {
             n_a += q.n;
-            mini_pos[W.n_mini_pos++] = (uint64_t)q.q_span << 32 | q.q_pos >> 1;
-            seeds[n_m++] = q;
+            mini_pos[W.n_mini_pos++] = (uint64_t)qb.q_span << 32 | q.q_pos >> 1;
+            seeds[n_m] = q;
+            seeds_b[n_m] = qb;
+            ++n_m;
         }
     }
     rep_len += rep_en - rep_st;
@@ -256,7 +264,8 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     const int64_t n_a = W.n_a;
     Ptr<A128> heap = W.heap; PMX_LDS(heap);
     Ptr<A128> a = W.a; PMX_LDS(a);
-    Seed* seeds = W.seeds; PMX_LDS(seeds);
+    Ptr<SeedA> seeds = W.seeds; PMX_LDS(seeds);
+    Ptr<SeedB> seeds_b = W.seeds_b; PMX_LDS(seeds_b);
     // stage every occurrence list in idle scratch so the merge never waits on HBM/L2:
     // cache offsets are assigned in seed order, the copies run one seed per lane
     Ptr<uint64_t> pc = ptr_cast<uint64_t>(W.seg_a[0]); PMX_LDS(pc);   // the per-mate anchor block (16*max_anchor bytes) is idle until seg_gen
@@ -265,7 +274,7 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
         for (int i = 0; i < n_m; ++i) { const uint32_t n = seeds[i].n; seeds[i].flt = acc; acc += n; }   // flt is free now: cache offset
         wave_sync();
         for (int i = lane_id(); i < n_m; i += PMX_W) {
-            const Seed q = seeds[i];
+            const SeedA q = seeds[i];
             for (uint32_t j = 0; j < q.n; ++j) pc[q.flt + j] = ri.pos[q.off + j];
         }
         wave_sync();
@@ -281,21 +290,22 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     for (int q = (heap_size >> 1) - 1; q >= 0; --q) heap_down_min_x(heap, q, heap_size);
     int64_t n_for = 0, n_rev = 0;
     while (heap_size > 0) {
-        const Seed q = seeds[heap[0].y >> 32];
+        const SeedA q = seeds[heap[0].y >> 32];
+        const SeedB qb = seeds_b[heap[0].y >> 32];
         const uint64_t r = heap[0].x;
         const int32_t rpos = (int32_t)((uint32_t)r >> 1);
         A128 p;
         if ((r & 1) == (q.q_pos & 1)) {   // forward strand
             p.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
-            p.y = (uint64_t)q.q_span << 32 | q.q_pos >> 1;
-            p.y |= (uint64_t)q.seg_id << PMX_SEED_SEG_SHIFT;
-            if (q.is_tandem) p.y |= PMX_SEED_TANDEM;
+            p.y = (uint64_t)qb.q_span << 32 | q.q_pos >> 1;
+            p.y |= (uint64_t)qb.seg_id << PMX_SEED_SEG_SHIFT;
+            if (qb.is_tandem) p.y |= PMX_SEED_TANDEM;
             a[n_for++] = p;
         } else {                          // reverse strand: query position mirrored
             p.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
-            p.y = (uint64_t)q.q_span << 32 | (uint32_t)(qlen - ((int)(q.q_pos >> 1) + 1 - (int)q.q_span) - 1);
-            p.y |= (uint64_t)q.seg_id << PMX_SEED_SEG_SHIFT;
-            if (q.is_tandem) p.y |= PMX_SEED_TANDEM;
+            p.y = (uint64_t)qb.q_span << 32 | (uint32_t)(qlen - ((int)(q.q_pos >> 1) + 1 - (int)qb.q_span) - 1);
+            p.y |= (uint64_t)qb.seg_id << PMX_SEED_SEG_SHIFT;
+            if (qb.is_tandem) p.y |= PMX_SEED_TANDEM;
             a[n_a - (++n_rev)] = p;
         }
         if ((uint32_t)heap[0].y < q.n - 1) {

@@ -225,8 +225,19 @@ struct RefIndex {
     int32_t n_logf;
 };
 
-struct Seed {           // mm_seed_t (mmpriv.h:42-49)
-    uint32_t n, q_pos, q_span, flt, seg_id, is_tandem, off;
+// chain-DP state of one anchor (f, p, t, v of mg_lchain_dp, lchain.c:148-230) as ONE 16-byte cell: the inner
+// loop needs f, p and t of anchor j together -- one load instead of three
+struct ChainCell {
+    int32_t f, p, t, v;
+};
+
+// mm_seed_t (mmpriv.h:42-49) as two 16-byte halves kept in parallel arrays (one interleave granule each in the
+// thread-per-pair arena): the merge loop reads both, the occurrence filter and the list staging only the first
+struct SeedA {
+    uint32_t n, q_pos, off, flt;
+};
+struct SeedB {
+    uint32_t q_span, seg_id, is_tandem, pad;
 };
 
 struct Reg {            // mm_reg1_t + mm_extra_t (minimap.h:98-128)
@@ -297,7 +308,8 @@ struct Work {
     Ptr<A128> mv;
     int n_mv;
     Ptr<A128> sk_buf;      // minimizer window ring (w entries)
-    Seed* seeds;
+    Ptr<SeedA> seeds;
+    Ptr<SeedB> seeds_b;
     int n_seeds;
     Ptr<uint64_t> mini_pos;
     int n_mini_pos;
@@ -306,7 +318,8 @@ struct Work {
     Ptr<A128> a;
     Ptr<A128> a2;
     int64_t n_a;
-    Ptr<int32_t> f, t, v, p;
+    Ptr<ChainCell> cc;     // chain-DP cells (max_anchor)
+    Ptr<int32_t> kidx;     // filter_bad_seeds: indices of long gaps (max_anchor)
     Ptr<A128> z;
     Ptr<uint64_t> u;
     Ptr<uint64_t> u2;

@@ -54,6 +54,9 @@ struct pmx_place {
     DevBuf<char> tmp;                      // rocprim temp storage
     // node outputs
     DevBuf<double> metrics5, scores5, terms;
+    DevBuf<uint64_t> dd_h1, dd_h2, dd_h1s, dd_key;   // --dedup scratch
+    DevBuf<uint32_t> dd_idx, dd_idx2;
+    DevBuf<uint8_t> dd_keep;
     DevBuf<uint8_t> term_meta;
     DevBuf<int64_t> counts2;
     std::vector<double> h_scores;
@@ -386,7 +389,6 @@ int pmx_place_reset(pmx_ctx* ctx, pmx_place* pl) {
 int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, const pmx_place_params* pp) {
     if (!ctx || !pl || !rs || !pp) return PMX_ERR_ARG;
     if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack first)");
-    if (pp->dedup_reads) return fail(PMX_ERR_UNSUPPORTED, "--dedup is not implemented on the device yet");
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     SeedParams sp;
@@ -403,13 +405,35 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         // insert can never fail, yet the table is sized by what the reads actually contain (a few million
         // distinct seeds for a 1M-read sample) instead of by the one-key-per-base bound of the whole batch:
         // a 16x smaller table to clear, probe and compact.
+        const uint8_t* keep = nullptr;
+        if (pp->dedup_reads) {   // --dedup: every distinct read sequence of this read set counts once
+            const int64_t n = rs->n;
+            const int G = ctx->n_cu * 8;
+            pl->dd_h1.ensure((size_t)n); pl->dd_h2.ensure((size_t)n); pl->dd_h1s.ensure((size_t)n); pl->dd_key.ensure((size_t)n);
+            pl->dd_idx.ensure((size_t)n); pl->dd_idx2.ensure((size_t)n); pl->dd_keep.ensure((size_t)n);
+            hipLaunchKernelGGL(k_read_hashes, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p, n, pl->dd_h1.p,
+                               pl->dd_h2.p, pl->dd_idx.p);
+            // stable LSD order: by h2 first, then by h1
+            size_t bytes = 0;
+            PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->dd_h2.p, pl->dd_key.p, pl->dd_idx.p, pl->dd_idx2.p, (size_t)n, 0, 64, ctx->stream));
+            pl->tmp.ensure(bytes);
+            PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->dd_h2.p, pl->dd_key.p, pl->dd_idx.p, pl->dd_idx2.p, (size_t)n, 0, 64, ctx->stream));
+            hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, pl->dd_h1.p, pl->dd_idx2.p, n, pl->dd_key.p);
+            PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->dd_key.p, pl->dd_h1s.p, pl->dd_idx2.p, pl->dd_idx.p, (size_t)n, 0, 64, ctx->stream));
+            pl->tmp.ensure(bytes);
+            PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->dd_key.p, pl->dd_h1s.p, pl->dd_idx2.p, pl->dd_idx.p, (size_t)n, 0, 64, ctx->stream));
+            hipLaunchKernelGGL(k_mark_first_of_run, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p, pl->dd_h1s.p,
+                               pl->dd_h2.p, pl->dd_idx.p, n, pl->dd_keep.p);
+            PMX_HIP(hipGetLastError());
+            keep = pl->dd_keep.p;
+        }
         const int64_t chunk_reads = std::max<int64_t>(1, ((int64_t)16 << 20) / std::max<int64_t>(rs->max_len, 1));
         timer_begin(ctx, "seed");
         for (int64_t r0 = 0; r0 < rs->n; r0 += chunk_reads) {
             const int64_t r1 = std::min<int64_t>(rs->n, r0 + chunk_reads);
             table_reserve(ctx, pl, (uint64_t)((r1 - r0) * rs->max_len));
             hipLaunchKernelGGL(k_seed_histogram, dim3(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), dim3(PMX_SEED_BLOCK), lds, ctx->stream,
-                               rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
+                               rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep);
             PMX_HIP(hipGetLastError());
         }
         timer_end(ctx, "seed", 1);

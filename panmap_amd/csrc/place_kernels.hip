@@ -52,6 +52,49 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* _
     }
 }
 
+// --------------------------------------------------------------------------------- read dedup (--dedup)
+// The reference sorts the read strings and counts every distinct sequence once (src/placement.cpp:1550-1620).
+// Here: two independent 64-bit hashes of the raw ASCII of each read, a stable radix sort on the 128-bit key,
+// and an exact byte comparison with the predecessor in sorted order; the first read of every run is kept.
+__global__ void k_read_hashes(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ off, int64_t n_reads, uint64_t* h1,
+                              uint64_t* h2, uint32_t* idx) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = off[r], e = off[r + 1];
+        uint64_t a = 0xcbf29ce484222325ULL, c = 0x9e3779b97f4a7c15ULL ^ (uint64_t)(e - b);
+        for (int64_t i = b; i < e; ++i) {
+            const uint64_t ch = ascii[i];
+            a = (a ^ ch) * 0x100000001b3ULL;                   // FNV-1a
+            c = mix64(c + ch + 0x632be59bd9b4e019ULL);         // chained avalanche
+        }
+        h1[r] = a;
+        h2[r] = c;
+        idx[r] = (uint32_t)r;
+    }
+}
+
+__global__ void k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, int64_t n, uint64_t* dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
+// sorted by (h1, h2): keep[read] = 1 for the first read of every run of byte-identical reads
+__global__ void k_mark_first_of_run(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ off, const uint64_t* __restrict__ h1s,
+                                    const uint64_t* __restrict__ h2, const uint32_t* __restrict__ perm, int64_t n, uint8_t* keep) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = perm[j];
+        bool first = true;
+        if (j > 0) {
+            const uint32_t q = perm[j - 1];
+            const int64_t lr = off[r + 1] - off[r], lq = off[q + 1] - off[q];
+            if (h1s[j] == h1s[j - 1] && h2[r] == h2[q] && lr == lq) {
+                bool same = true;
+                for (int64_t i = 0; i < lr && same; ++i) same = ascii[off[r] + i] == ascii[off[q] + i];
+                first = !same;
+            }
+        }
+        keep[r] = first ? 1 : 0;
+    }
+}
+
 // --------------------------------------------------------------------------------- seeding
 __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long* vals, uint64_t mask, uint64_t key,
                                              unsigned long long mult, unsigned long long* counters) {
@@ -73,7 +116,7 @@ __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long*
 __global__ void __launch_bounds__(PMX_SEED_BLOCK)
 k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
                  const int64_t* __restrict__ off, int64_t r_begin, int64_t n_reads, SeedParams sp, uint64_t* keys,
-                 unsigned long long* vals, uint64_t mask, unsigned long long* counters) {
+                 unsigned long long* vals, uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep) {
     extern __shared__ uint64_t lds[];
     const int w = sp.k - sp.s + 1;
     const int l = sp.l < 1 ? 1 : sp.l;
@@ -87,6 +130,7 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
     for (int64_t r = r_begin + (int64_t)blockIdx.x * PMX_SEED_BLOCK + tid; r < n_reads; r += (int64_t)gridDim.x * PMX_SEED_BLOCK) {
         const int64_t len = off[r + 1] - off[r];
         if (len < sp.k) continue;
+        if (keep && !keep[r]) continue;   // --dedup: a later copy of an identical read
         const uint64_t* rw = words + woff[r];
         const uint32_t* ra = amb + woff[r];
         const int64_t valid_start = sp.trim_start, valid_end = len - sp.trim_end - sp.k;

@@ -22,7 +22,7 @@ def _check_place(pmx, oracle, ctx, index, reads, params=None, k=19, s=8, l=3, op
         placer.add_reads(rs, params)
     res = placer.score(params, len(reads))
     want = oracle.place(reads, index.arrays(), k, s, l, open_syncmer, t, params.trimStart, params.trimEnd, params.seedMaskFraction,
-                        params.minReadSupport, params.forceLeaf)
+                        params.minReadSupport, params.forceLeaf, params.dedupReads)
     hh, hc = placer.histogram()
     assert np.array_equal(hh, want["hist_hash"]), "seed set differs"
     assert np.array_equal(hc, want["hist_count"]), "seed counts differ"
@@ -90,6 +90,22 @@ def test_place_edge_cases(pmx, oracle, ctx, sars, sars_index):
     _check_place(pmx, oracle, ctx, sars_index, reads, pmx.TraversalParams(trimStart=10, trimEnd=25, minReadSupport=1))
     _check_place(pmx, oracle, ctx, sars_index, [])                                  # no reads at all
     _check_place(pmx, oracle, ctx, sars_index, reads, pmx.TraversalParams(forceLeaf=True, seedMaskFraction=0.01))
+
+
+def test_place_dedup(pmx, oracle, ctx, sars, sars_index):
+    """--dedup (src/placement.cpp:1550-1620): every distinct read string counts once"""
+    g = sars.genome("node_7618")
+    concat, off = pmx.simulate_paired_reads(g, 1500, seed=5)
+    reads = _as_reads(concat, off)
+    rng = np.random.default_rng(8)
+    dup = [reads[int(i)] for i in rng.integers(0, len(reads), 2000)]          # exact copies, some several times
+    near = [r[:-1] + (b"A" if r[-1:] != b"A" else b"C") for r in reads[:200]]   # differ in the last base only
+    case = [reads[0].lower(), reads[1][:100], reads[1][:100], b"", b""]         # case matters; prefixes; empties
+    allr = reads + dup + near + case
+    order = rng.permutation(len(allr))
+    allr = [allr[int(i)] for i in order]
+    _check_place(pmx, oracle, ctx, sars_index, allr, pmx.TraversalParams(dedupReads=True))
+    _check_place(pmx, oracle, ctx, sars_index, allr, pmx.TraversalParams(dedupReads=False))
 
 
 @pytest.mark.parametrize("k,s,l,open_syncmer,t", [(15, 8, 1, False, 0), (31, 6, 3, False, 0), (19, 8, 2, True, 3), (21, 10, 4, False, 2)])
