@@ -64,6 +64,11 @@ typedef struct {
 
 int pmx_index_build(const pmx_panman *pm, int k, int s, int t, int l, int open_syncmer, int flank_mask,
                     pmx_index **out);
+/* mode 0 = automatic (incremental DFS; from-scratch re-seeding of every node when the PanMAN has inverted
+ * blocks), 1 = from scratch, 2 = incremental; max_nodes >= 0 stops after that many nodes in DFS order
+ * (the remaining nodes carry no changes) -- both exist for the cross-check tests of the producer */
+int pmx_index_build_ex(const pmx_panman *pm, int k, int s, int t, int l, int open_syncmer, int flank_mask,
+                       int mode, int64_t max_nodes, pmx_index **out);
 /* adopt caller-provided SoA arrays (copied): parent[n], offsets[n+1], hash/pc/cc[offsets[n]] */
 int pmx_index_from_arrays(const pmx_index_info *info, const uint32_t *parent, const uint64_t *offsets,
                           const uint64_t *hash, const int16_t *parent_count, const int16_t *child_count,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "pmx_panman_find_node": (_i64, [_vp, _cp]),
     "pmx_panman_node_genome": (_i64, [_vp, _i64, _vp, _i64]),
     "pmx_index_build": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _PP]),
+    "pmx_index_build_ex": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _PP]),
     "pmx_index_from_arrays": (_i32, [C.POINTER(IndexInfo), _vp, _vp, _vp, _vp, _vp, _PP]),
     "pmx_index_close": (None, [_vp]),
     "pmx_index_get_info": (_i32, [_vp, C.POINTER(IndexInfo)]),

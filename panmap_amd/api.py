@@ -79,9 +79,10 @@ class Index:
         check(lib.pmx_index_get_info(self._h, C.byref(self.info)), "pmx_index_get_info")
 
     @classmethod
-    def build(cls, pm: Panman, k=19, s=8, t=0, l=3, open_syncmer=False, flank_mask=250) -> "Index":
+    def build(cls, pm: Panman, k=19, s=8, t=0, l=3, open_syncmer=False, flank_mask=250, mode=0, max_nodes=-1) -> "Index":
+        """mode 0 = automatic, 1 = from-scratch re-seeding of every node, 2 = incremental DFS (see pmx_index_build_ex)"""
         h = C.c_void_p()
-        check(lib.pmx_index_build(pm._h, k, s, t, l, int(open_syncmer), flank_mask, C.byref(h)), "pmx_index_build")
+        check(lib.pmx_index_build_ex(pm._h, k, s, t, l, int(open_syncmer), flank_mask, mode, max_nodes, C.byref(h)), "pmx_index_build_ex")
         return cls(h)
 
     @classmethod

@@ -65,7 +65,12 @@ int64_t pmx_panman_node_genome(const pmx_panman* pm, int64_t i, char* buf, int64
 }
 
 int pmx_index_build(const pmx_panman* pm, int k, int s, int t, int l, int open_syncmer, int flank_mask, pmx_index** out) {
-    if (!pm || !out) return PMX_ERR_ARG;
+    return pmx_index_build_ex(pm, k, s, t, l, open_syncmer, flank_mask, 0, -1, out);
+}
+
+int pmx_index_build_ex(const pmx_panman* pm, int k, int s, int t, int l, int open_syncmer, int flank_mask, int mode, int64_t max_nodes,
+                       pmx_index** out) {
+    if (!pm || !out || mode < 0 || mode > 2) return PMX_ERR_ARG;
     // same validation as the CLI (src/main.cpp:2221-2235)
     if (k <= 0 || s <= 0 || s > k || t < 0 || t > k - s || l < 0 || k > 64) {
         pmx::set_error("invalid seeding parameters");
@@ -75,7 +80,7 @@ int pmx_index_build(const pmx_panman* pm, int k, int s, int t, int l, int open_s
         pmx_index* ix = new pmx_index();
         pmx::SyncmerParams p;
         p.k = k; p.s = s; p.t = t; p.l = l; p.open = open_syncmer != 0;
-        pmx::build_lite_index(pm->pm, p, flank_mask, ix->ix);
+        pmx::build_lite_index(pm->pm, p, flank_mask, ix->ix, mode, max_nodes < 0 ? (size_t)-1 : (size_t)max_nodes);
         *out = ix;
         return PMX_OK;
     } catch (const std::exception& e) {

@@ -248,7 +248,63 @@ struct Builder {
 
 }  // namespace
 
-void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, LiteIndex& out) {
+namespace {
+bool has_inverted_blocks(const Panman& pm) {
+    for (const auto& nd : pm.nodes)
+        for (const auto& bm : nd.block_muts)
+            if (bm.inversion) return true;
+    return false;
+}
+
+// From-scratch producer: every node's genome is materialised (incremental column state, undone on the way
+// back up), its seed multiset extracted as the reference's test helpers do (src/test/helpers/
+// seed_helpers.cpp: extractSeeds + k-min-mers) and diffed against the parent's.  O(genome) per node instead
+// of O(mutated columns); used for PanMANs with inverted blocks, which the incremental builder does not track,
+// and by tests/test_host_stage.py as an independent check of the incremental builder.
+void build_from_scratch(const Panman& pm, const SyncmerParams& p, int flank_mask, size_t max_nodes, LiteIndex& out) {
+    typedef std::vector<std::pair<uint64_t, int32_t>> Counts;
+    const size_t n = std::min(pm.nodes.size(), max_nodes);
+    PanmanState st;
+    st.init(pm);
+    std::vector<int32_t> stack;
+    std::vector<UndoLog> undos;
+    std::vector<Counts> counts;
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t par = pm.nodes[i].parent;
+        while (!stack.empty() && stack.back() != par) {
+            undo_node(st, undos.back());
+            undos.pop_back();
+            counts.pop_back();
+            stack.pop_back();
+        }
+        undos.emplace_back();
+        stack.push_back((int32_t)i);
+        apply_node(pm, (int32_t)i, st, &undos.back(), nullptr);
+        counts.emplace_back();
+        genome_seed_counts(genome_of_state(pm, st), p, flank_mask, counts.back());
+        static const Counts empty;
+        const Counts& pc = counts.size() >= 2 ? counts[counts.size() - 2] : empty;
+        const Counts& cc = counts.back();
+        size_t a = 0, b = 0;
+        auto emit = [&](uint64_t h, int32_t x, int32_t y) {
+            if (x == y) return;
+            if (x > INT16_MAX || y > INT16_MAX) throw std::runtime_error("index build: seed count exceeds int16");
+            out.hash.push_back(h);
+            out.parent_count.push_back((int16_t)x);
+            out.child_count.push_back((int16_t)y);
+        };
+        while (a < pc.size() || b < cc.size()) {
+            if (b == cc.size() || (a < pc.size() && pc[a].first < cc[b].first)) { emit(pc[a].first, pc[a].second, 0); ++a; }
+            else if (a == pc.size() || cc[b].first < pc[a].first) { emit(cc[b].first, 0, cc[b].second); ++b; }
+            else { emit(pc[a].first, pc[a].second, cc[b].second); ++a; ++b; }
+        }
+        out.offsets[i + 1] = out.hash.size();
+    }
+    for (size_t i = n; i < pm.nodes.size(); ++i) out.offsets[i + 1] = out.hash.size();
+}
+}  // namespace
+
+void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, LiteIndex& out, int mode, size_t max_nodes) {
     if (p.l > 32) throw std::runtime_error("index build: l > 32 unsupported");
     out = LiteIndex();
     out.params = p;
@@ -262,12 +318,17 @@ void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, 
         out.parent[i] = pm.nodes[i].parent < 0 ? 0u : (uint32_t)pm.nodes[i].parent;
     }
     if (n == 0) return;
+    if (mode == 1 || (mode == 0 && has_inverted_blocks(pm))) {
+        build_from_scratch(pm, p, flank_mask, max_nodes, out);
+        return;
+    }
     Builder b(pm, p, flank_mask);
     // Pre-order numbering == node index, so visiting nodes in index order with an explicit
     // ancestor stack is the DFS; undo when leaving a subtree.
     std::vector<int32_t> stack;
     std::vector<NodeUndo> undos;
-    for (size_t i = 0; i < n; ++i) {
+    const size_t n_do = std::min(n, max_nodes);
+    for (size_t i = 0; i < n_do; ++i) {
         int32_t par = pm.nodes[i].parent;
         while (!stack.empty() && stack.back() != par) {
             b.undo(undos.back());
@@ -279,6 +340,7 @@ void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, 
         b.process((int32_t)i, undos.back(), out.hash, out.parent_count, out.child_count);
         out.offsets[i + 1] = out.hash.size();
     }
+    for (size_t i = n_do; i < n; ++i) out.offsets[i + 1] = out.hash.size();
 }
 
 void genome_seed_counts(const std::string& genome, const SyncmerParams& p, int flank_mask,

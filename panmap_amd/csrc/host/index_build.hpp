@@ -24,9 +24,13 @@ struct LiteIndex {
     size_t n_nodes() const { return parent.size(); }
 };
 
-// Builds the index over the whole tree (incremental DFS; state undone on exit).
-// Throws std::runtime_error for PanMANs with inverted blocks (not yet supported) or count overflow.
-void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, LiteIndex& out);
+// Builds the index over the whole tree (state undone on exit).  mode 0 = automatic: incremental DFS (work
+// proportional to the mutated columns of every node), or the from-scratch producer (every node's genome
+// re-seeded and diffed against its parent) when the PanMAN has inverted blocks; 1 = from scratch, 2 =
+// incremental.  max_nodes < n_nodes stops after that many nodes in DFS order (tests).
+// Throws std::runtime_error on count overflow.
+void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, LiteIndex& out, int mode = 0,
+                      size_t max_nodes = (size_t)-1);
 
 // From-scratch seed multiset of a genome string with the hard flank mask applied (test helper
 // mirroring src/test/helpers/seed_helpers.cpp:12 extractSeeds + k-min-mers).

