@@ -25,6 +25,15 @@ PMX_HD void gen_simple_mat(int8_t* mat, int8_t a, int8_t b, int8_t sc_ambi) {   
     for (int j = 0; j < 5; ++j) mat[4 * 5 + j] = sc_ambi;
 }
 
+// o.mat is always ksw_gen_simple_mat(a, b, sc_ambi) (make_opt): the per-base loops evaluate it arithmetically
+// instead of loading a table entry per base
+PMX_HD int simple_score(const Opt& o, uint32_t t, uint32_t q) {
+    const int amb = o.sc_ambi > 0 ? -o.sc_ambi : o.sc_ambi;
+    const int mis = o.b > 0 ? -o.b : o.b;
+    const int mch = o.a < 0 ? -o.a : o.a;
+    return (t > 3 || q > 3) ? amb : (t == q ? mch : mis);
+}
+
 PMX_HD void ref_getseq(const RefIndex& ri, int st, int en, Ptr<uint8_t> out) {   // mm_idx_getseq (index.c:152-162)
     PMX_LDS(out);
     if (en > ri.len) en = ri.len;
@@ -98,6 +107,19 @@ PMX_HD void align_pair(Work& W, const Opt& o, int qlen, Ptr<const uint8_t> qseq,
     }
 }
 
+// Scalar execution models only (thread per pair, host): try the DP shortcuts with the target bases read straight
+// from the reference (no copy into W.tseq, no in-place reversal for a left extension).  Same pre-checks as
+// align_pair; false = nothing decided, take the regular path.
+template <class QF, class TF>
+PMX_HD bool try_shortcut_direct(Work& W, const Opt& o, int qlen, QF& qf, int tlen, TF& tf, int w, int end_bonus, int zdrop, int flag, Ez& ez) {
+    if (o.max_sw_mat > 0 && (int64_t)tlen * qlen > o.max_sw_mat) return false;
+    if (o.q == o.q2 && o.e == o.e2) return false;
+    W.last_dp_shortcut = 0;
+    if (!ksw_shortcut_f(W, qlen, qf, tlen, tf, o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2, (int8_t)o.e2, w, zdrop, end_bonus, flag, ez)) return false;
+    W.last_dp_shortcut = 1;
+    return true;
+}
+
 // update_max_zdrop + mm_test_zdrop (align.c:32-89).  The inversion probe (ksw_ll_i16) is reported as
 // unsupported instead of evaluated; it only decides between return codes 1 and 2.
 PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int n_cigar, Ptr<const uint32_t> cigar) {
@@ -121,7 +143,7 @@ PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const
         const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
         if (op == 0) {
             for (uint32_t l = 0; l < len; ++l) {
-                score += o.mat[t_r[i + (int)l] * 5 + q_r[j + (int)l]];
+                score += simple_score(o, t_r[i + (int)l], q_r[j + (int)l]);
                 upd(score, i + (int)l, j + (int)l);
             }
             i += len; j += len;
@@ -210,16 +232,13 @@ PMX_HDN void fix_cigar(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const uint8
 }
 
 // mm_update_extra (align.c:240-289), log_gap = 1, is_eqx = 0
-PMX_HDN void update_extra(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, const int8_t* mat, int8_t q, int8_t e) {
-    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq); PMX_LDS(tseq);
-    if (!r.has_p) return;
-    int32_t qshift, tshift, toff = 0, qoff = 0;
+template <class TR>
+PMX_HD void update_extra_core(Work& W, const Opt& o, Reg& r, Ptr<const uint8_t> qseq, TR& t_r, int8_t q, int8_t e) {
+    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq);
+    int32_t toff = 0, qoff = 0;
     double s = 0.0, mx = 0.0;
-    fix_cigar(W, r, qseq, tseq, &qshift, &tshift);
-    qseq += qshift;
-    tseq += tshift;
     Ptr<const uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
-    ByteReader q_r(qseq), t_r(tseq);
+    ByteReader q_r(qseq);
     r.blen = r.mlen = 0;
     for (uint32_t k = 0; k < r.n_cigar; ++k) {
         const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
@@ -229,7 +248,7 @@ PMX_HDN void update_extra(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const ui
                 const int cq = (int)q_r[qoff + (int)l], ct = (int)t_r[toff + (int)l];
                 if (ct > 3 || cq > 3) ++n_ambi;
                 else if (ct != cq) ++n_diff;
-                s += mat[ct * 5 + cq];
+                s += simple_score(o, (uint32_t)ct, (uint32_t)cq);
                 if (s < 0) s = 0;
                 else mx = mx > s ? mx : s;
             }
@@ -258,6 +277,17 @@ PMX_HDN void update_extra(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const ui
         } else if (op == 3) toff += len;
     }
     r.dp_max = (int32_t)(mx + .499);
+}
+
+PMX_HDN void update_extra(Work& W, const Opt& o, Reg& r, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int8_t q, int8_t e) {
+    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq); PMX_LDS(tseq);
+    if (!r.has_p) return;
+    int32_t qshift, tshift;
+    fix_cigar(W, r, qseq, tseq, &qshift, &tshift);
+    qseq += qshift;
+    tseq += tshift;
+    ByteReader t_r(tseq);
+    update_extra_core(W, o, r, qseq, t_r, q, e);
 }
 
 // mm_adjust_minier (align.c:355-372), non-HPC
@@ -474,18 +504,31 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
 
     if (qs > 0 && rs > 0) {   // left extension (align.c:704-722)
         Ptr<uint8_t> qseq = qseq0[rev] + qs0; PMX_LDS(qseq);
-        ref_getseq(ri, rs0, rs, tseq);
-        seq_rev(qs - qs0, qseq);
-        seq_rev(rs - rs0, tseq);
-        align_pair(W, o, qs - qs0, qseq, rs - rs0, tseq, bw, o.end_bonus, r.split_inv ? o.zdrop_inv : o.zdrop,
-                   PMX_EZ_EXTZ_ONLY | PMX_EZ_RIGHT | PMX_EZ_REV_CIGAR, ez);
+        bool decided = false;
+#if PMX_W == 1
+        {
+            RevBases<ByteReader> qf(ByteReader(Ptr<const uint8_t>(qseq)), qs - qs0);
+            RevBases<GlobalByteReader> tf(GlobalByteReader(ri.seq + rs0), rs - rs0);
+            decided = try_shortcut_direct(W, o, qs - qs0, qf, rs - rs0, tf, bw, o.end_bonus, r.split_inv ? o.zdrop_inv : o.zdrop,
+                                          PMX_EZ_EXTZ_ONLY | PMX_EZ_RIGHT | PMX_EZ_REV_CIGAR, ez);
+        }
+#endif
+        if (!decided) {
+            ref_getseq(ri, rs0, rs, tseq);
+            seq_rev(qs - qs0, qseq);
+            seq_rev(rs - rs0, tseq);
+            W.skip_shortcut = PMX_W == 1;
+            align_pair(W, o, qs - qs0, qseq, rs - rs0, tseq, bw, o.end_bonus, r.split_inv ? o.zdrop_inv : o.zdrop,
+                       PMX_EZ_EXTZ_ONLY | PMX_EZ_RIGHT | PMX_EZ_REV_CIGAR, ez);
+            W.skip_shortcut = 0;
+        }
         if (ez.n_cigar > 0) {
             append_cigar(W, r, ez.n_cigar, cig_tmp);
             r.dp_score += (int32_t)ez.max;
         }
         rs1 = rs - (ez.reach_end ? ez.mqe_t + 1 : ez.max_t + 1);
         qs1 = qs - (ez.reach_end ? qs - qs0 : ez.max_q + 1);
-        seq_rev(qs - qs0, qseq);
+        if (!decided) seq_rev(qs - qs0, qseq);
     } else { rs1 = rs; qs1 = qs; }
     re1 = rs; qe1 = qs;
 
@@ -497,9 +540,25 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
             int bw1 = bw_long;
             if (a[as1 + i].y & PMX_SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
             Ptr<uint8_t> qseq = qseq0[rev] + qs; PMX_LDS(qseq);
-            ref_getseq(ri, rs, re, tseq);
-            align_pair(W, o, qe - qs, qseq, re - rs, tseq, bw1, -1, o.zdrop, PMX_EZ_APPROX_MAX, ez);   // first pass: approximate Z-drop
-            const int zdrop_code = test_zdrop(W, o, qseq, tseq, ez.n_cigar, cig_tmp);
+            bool decided = false;
+#if PMX_W == 1
+            {
+                FwdBases<ByteReader> qf{ByteReader(Ptr<const uint8_t>(qseq))};
+                FwdBases<GlobalByteReader> tf{GlobalByteReader(ri.seq + rs)};
+                decided = try_shortcut_direct(W, o, qe - qs, qf, re - rs, tf, bw1, -1, o.zdrop, PMX_EZ_APPROX_MAX, ez);
+            }
+#endif
+            if (!decided) {
+                ref_getseq(ri, rs, re, tseq);
+                W.skip_shortcut = PMX_W == 1;
+                align_pair(W, o, qe - qs, qseq, re - rs, tseq, bw1, -1, o.zdrop, PMX_EZ_APPROX_MAX, ez);   // first pass: approximate Z-drop
+                W.skip_shortcut = 0;
+            }
+            // a gap fill answered by shortcut (2) is gap-free with at most two mismatches: its largest score drop is
+            // 2(a+b) <= zdrop, so mm_test_zdrop returns 0 without looking
+            const bool tz_skip = W.last_dp_shortcut && 2 * (o.a + o.b) <= o.zdrop && 2 * (o.a + o.b) <= o.zdrop_inv;
+            if (!tz_skip && decided) ref_getseq(ri, rs, re, tseq);   // the shortcut read the reference directly
+            const int zdrop_code = tz_skip ? 0 : test_zdrop(W, o, qseq, tseq, ez.n_cigar, cig_tmp);
             if (zdrop_code != 0) align_pair(W, o, qe - qs, qseq, re - rs, tseq, bw1, -1, zdrop_code == 2 ? o.zdrop_inv : o.zdrop, 0, ez);
             if (ez.n_cigar > 0) append_cigar(W, r, ez.n_cigar, cig_tmp);
             if (ez.zdropped) {   // truncated by Z-drop
@@ -524,8 +583,20 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
 
     if (!dropped && qe < qe0 && re < re0) {   // right extension (align.c:799-815)
         Ptr<uint8_t> qseq = qseq0[rev] + qe; PMX_LDS(qseq);
-        ref_getseq(ri, re, re0, tseq);
-        align_pair(W, o, qe0 - qe, qseq, re0 - re, tseq, bw, o.end_bonus, o.zdrop, PMX_EZ_EXTZ_ONLY, ez);
+        bool decided = false;
+#if PMX_W == 1
+        {
+            FwdBases<ByteReader> qf{ByteReader(Ptr<const uint8_t>(qseq))};
+            FwdBases<GlobalByteReader> tf{GlobalByteReader(ri.seq + re)};
+            decided = try_shortcut_direct(W, o, qe0 - qe, qf, re0 - re, tf, bw, o.end_bonus, o.zdrop, PMX_EZ_EXTZ_ONLY, ez);
+        }
+#endif
+        if (!decided) {
+            ref_getseq(ri, re, re0, tseq);
+            W.skip_shortcut = PMX_W == 1;
+            align_pair(W, o, qe0 - qe, qseq, re0 - re, tseq, bw, o.end_bonus, o.zdrop, PMX_EZ_EXTZ_ONLY, ez);
+            W.skip_shortcut = 0;
+        }
         if (ez.n_cigar > 0) {
             append_cigar(W, r, ez.n_cigar, cig_tmp);
             r.dp_score += (int32_t)ez.max;
@@ -539,9 +610,17 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
     else { r.qs = qlen - qe1; r.qe = qlen - qs1; }
 
     if (r.has_p) {
-        ref_getseq(ri, rs1, re1, tseq);
         Ptr<const uint8_t> qseq = qseq0[r.rev] + qs1; PMX_LDS(qseq);
-        update_extra(W, r, qseq, tseq, o.mat, (int8_t)o.q, (int8_t)o.e);
+#if PMX_W == 1
+        if (r.n_cigar <= 1) {   // mm_fix_cigar is a no-op then: the statistics can scan the reference directly
+            GlobalByteReader t_r(ri.seq + rs1);
+            update_extra_core(W, o, r, qseq, t_r, (int8_t)o.q, (int8_t)o.e);
+        } else
+#endif
+        {
+            ref_getseq(ri, rs1, re1, tseq);
+            update_extra(W, o, r, qseq, tseq, (int8_t)o.q, (int8_t)o.e);
+        }
     }
 }
 

@@ -472,6 +472,7 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow, ui
     W.cig_next = 0;
     W.dp_req_base = nullptr; W.dp_res = nullptr; W.dp_slot_ctr = nullptr;
     W.dp_slot = -1; W.dp_slot_cap = 0; W.dp_n_cached = 0; W.dp_calls = 0;
+    W.last_dp_shortcut = 0; W.skip_shortcut = 0;
 }
 
 // fixed-size output record (== pmx_aln_record in include/panmap_amd.h)

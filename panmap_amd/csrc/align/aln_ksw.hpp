@@ -626,9 +626,12 @@ PMX_HD int count_diff(Ptr<const uint8_t> a, Ptr<const uint8_t> b, int n) {
 //      alignment scores strictly less than the gap-free one for every prefix pair on the main diagonal,
 //      so the traceback is all-diagonal -> score = len*a - d*(a+b), CIGAR = len M.
 // Everything else runs the DP.
-PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, Ptr<const uint8_t> target, const int8_t* mat, int8_t q, int8_t e,
-                           int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
-    PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
+// QF / TF: callables returning the query / target base at position i (so the bases can come from the work
+// arena, straight from the reference in global memory, or be read back to front for a left extension)
+template <class QF, class TF>
+PMX_HD bool ksw_shortcut_f(Work& W, int qlen, QF& qf, int tlen, TF& tf, const int8_t* mat, int8_t q, int8_t e, int8_t q2, int8_t e2, int w,
+                           int zdrop, int end_bonus, int flag, Ez& ez) {
+    PMX_LDS(&W);
     Ptr<uint32_t> cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
     const int a = mat[0], b = -mat[1];
     const int g1 = q + e, g2 = q2 + e2;
@@ -637,12 +640,9 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
         if ((flag & PMX_EZ_EXTZ_ONLY) && tlen >= qlen && zdrop >= 2 * gmax + a + (a + b)) {
             // d = differing or ambiguous positions among the first qlen; pm = the largest such position
             int d = 0, pm = -1;
-            {
-                ByteReader qr_(query), tr_(target);
-                for (int i = lane_id(); i < qlen; i += PMX_W) {
-                    const uint32_t cq = qr_[i], ct = tr_[i];
-                    if (cq != ct || cq > 3 || ct > 3) { ++d; pm = i; }
-                }
+            for (int i = lane_id(); i < qlen; i += PMX_W) {
+                const uint32_t cq = qf(i), ct = tf(i);
+                if (cq != ct || cq > 3 || ct > 3) { ++d; pm = i; }
             }
             d = wave_sum_i32(d);
             if (d == 0) {
@@ -660,7 +660,7 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
             }
             if (d == 1 && a + b < gmin) {
                 const int pos = wave_max_i32(pm);
-                if (query[pos] <= 3 && target[pos] <= 3) {   // a real mismatch, not an ambiguous base
+                if (qf(pos) <= 3 && tf(pos) <= 3) {   // a real mismatch, not an ambiguous base
                     ez_reset(ez);
                     const int hend = qlen * a - (a + b);
                     if (pos >= 1) { ez.max = (uint32_t)(pos * a); ez.max_t = ez.max_q = pos - 1; }
@@ -678,13 +678,10 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
         } else if (!(flag & PMX_EZ_EXTZ_ONLY) && (flag & PMX_EZ_APPROX_MAX) && !(flag & PMX_EZ_APPROX_DROP) && qlen == tlen) {
             // differing positions, and ambiguous bases (any of those forces the DP)
             int d = 0, amb = 0;
-            {
-                ByteReader qr_(query), tr_(target);
-                for (int i = lane_id(); i < qlen; i += PMX_W) {
-                    const uint32_t cq = qr_[i], ct = tr_[i];
-                    d += (cq != ct || cq > 3) ? 1 : 0;
-                    amb += (cq > 3 || ct > 3) ? 1 : 0;
-                }
+            for (int i = lane_id(); i < qlen; i += PMX_W) {
+                const uint32_t cq = qf(i), ct = tf(i);
+                d += (cq != ct || cq > 3) ? 1 : 0;
+                amb += (cq > 3 || ct > 3) ? 1 : 0;
             }
             d = wave_sum_i32(d);
             amb = wave_sum_i32(amb);
@@ -701,9 +698,35 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
     return false;
 }
 
+// base readers for ksw_shortcut_f
+template <class R>
+struct FwdBases {
+    R r;
+    PMX_HD explicit FwdBases(R r_) : r(r_) {}
+    PMX_HD uint32_t operator()(int i) { return r[i]; }
+};
+template <class R>
+struct RevBases {   // position i of the reversed sequence of length n
+    R r;
+    int n;
+    PMX_HD RevBases(R r_, int n_) : r(r_), n(n_) {}
+    PMX_HD uint32_t operator()(int i) { return r[n - 1 - i]; }
+};
+
+PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, Ptr<const uint8_t> target, const int8_t* mat, int8_t q, int8_t e,
+                         int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+    PMX_LDS(query); PMX_LDS(target);
+    FwdBases<ByteReader> qf{ByteReader(query)}, tf{ByteReader(target)};
+    return ksw_shortcut_f(W, qlen, qf, tlen, tf, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+}
+
 PMX_HD void ksw_extd2_auto(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, Ptr<const uint8_t> target, const int8_t* mat, int8_t q, int8_t e,
                            int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
-    if (ksw_shortcut(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) return;
+    W.last_dp_shortcut = 0;
+    if (!W.skip_shortcut && ksw_shortcut(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) {
+        W.last_dp_shortcut = 1;
+        return;
+    }
 #if defined(PMX_THREAD_PER_PAIR) && (defined(__HIP_DEVICE_COMPILE__) || defined(PMX_HOSTSIM_TPP))
     // the thread-per-pair kernel never runs a DP itself: serve it from the pair's result list, or post
     // it as a request (first unserved call only) and abort this pass

@@ -357,6 +357,8 @@ struct Work {
     int64_t dp_slot;                  // this pair's slot, -1 = none yet
     uint32_t dp_slot_cap;
     int dp_n_cached, dp_calls;
+    int last_dp_shortcut;   // the last align_pair call was answered by ksw_shortcut
+    int skip_shortcut;      // align1 already tried the shortcut on the reference bases directly
     // optional phase profile (diagnostic runs only: AlignArgs::prof != NULL)
     unsigned long long* prof;
     unsigned long long prof_t;
