@@ -681,7 +681,11 @@ PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int*
     const int n_a = squeeze_a(W, n_regs, regs, a);
     PMX_STAMP(W, 6);
     for (int i = 0; i < n_regs; ++i) {
+#ifdef PMX_INTERLEAVED
+        Reg& r2 = W.reg_tmp[0];   // (strided struct: lives in the arena, not on the stack; hit_sort uses reg_tmp later)
+#else
         Reg r2;
+#endif
         reg_clear(r2);
         align1(W, o, ri, qlen, qseq0, regs[i], r2, n_a, a, ez);
         if (r2.cnt > 0) {   // mm_insert_reg

@@ -46,7 +46,12 @@ PMX_HD uint64_t hit_hash64(uint64_t key) {   // hit.c:42-52 (unmasked variant)
     return key;
 }
 
-PMX_HD void reg_clear(Reg& r) { memset(&r, 0, sizeof(Reg)); }
+PMX_HD void reg_clear(Reg& r) {
+#define PMX_X(f) r.f = 0;
+    PMX_REG_FIELDS(PMX_X)
+#undef PMX_X
+    r.pad_b[0] = r.pad_b[1] = r.pad_b[2] = 0;
+}
 
 // mm_gen_regs (hit.c:54-94): chains sorted by (score, hash) descending
 PMX_HDN int gen_regs(Work& W, uint32_t hash, int qlen, int n_u, Ptr<const uint64_t> u, Ptr<const A128> a, Reg* r) {

@@ -371,26 +371,26 @@ inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o, int sma
 
 // Thread-per-pair layout (k_align_reads_tpp): the compact layout's arrays, addressed through IPtr (logical
 // offsets: FAST region first, SLOW region behind it, interleaved across the wave by IPtr::phys), except the
-// Reg struct arrays, which live in a small per-thread contiguous RAW region behind plain pointers.
+// Reg struct arrays: strided structs in a per-wave RAW region (base pointer = region + lane * 4).
 // tb_bytes > 0 adds a per-thread traceback area (in-lane DPs; off by default).
 inline Layout plan_layout_tpp(int max_read_len, int n_segs, const Opt& o, size_t tb_bytes) {
     Layout L = plan_layout_compact(max_read_len, n_segs, o);   // capacities
     const Caps& c = L.caps;
     size_t raw = 0, top = 0;
-    auto put_raw = [&](Layout::Ent& e, size_t bytes) {
+    auto put_raw = [&](Layout::Ent& e, size_t n_regs) {   // strided Reg arrays: bytes per WAVE (see struct Reg)
         e.space = PMX_RAW;
         e.off = raw;
-        raw += (bytes + 15) & ~(size_t)15;
+        raw += n_regs * (size_t)PMX_REG_STRIDED_BYTES;
     };
     auto put = [&](Layout::Ent& e, size_t bytes) {   // one region each, no overlays (see IPtr)
         e.space = PMX_FAST;
         e.off = top;
         top += (bytes + 15) & ~(size_t)15;
     };
-    put_raw(L.regs0, sizeof(Reg) * c.max_reg);
-    put_raw(L.regs1, sizeof(Reg) * c.max_reg);
-    put_raw(L.regs2, sizeof(Reg) * c.max_reg);
-    put_raw(L.reg_tmp, sizeof(Reg) * c.max_reg);
+    put_raw(L.regs0, (size_t)c.max_reg);
+    put_raw(L.regs1, (size_t)c.max_reg);
+    put_raw(L.regs2, (size_t)c.max_reg);
+    put_raw(L.reg_tmp, (size_t)c.max_reg);
     L.raw_bytes = raw;
     put(L.qseq, (size_t)4 * c.max_qlen);
     put(L.tseq, (size_t)c.max_tlen + 32);
@@ -473,6 +473,7 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow, ui
     W.dp_req_base = nullptr; W.dp_res = nullptr; W.dp_slot_ctr = nullptr;
     W.dp_slot = -1; W.dp_slot_cap = 0; W.dp_n_cached = 0; W.dp_calls = 0;
     W.last_dp_shortcut = 0; W.skip_shortcut = 0;
+    W.sk_lds_x = nullptr; W.sk_lds_y = nullptr;
 }
 
 // fixed-size output record (== pmx_aln_record in include/panmap_amd.h)

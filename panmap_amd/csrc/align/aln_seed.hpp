@@ -23,16 +23,43 @@ PMX_HD uint64_t mz_hash64(uint64_t key, uint64_t mask) {
 
 // (w,k)-minimizers of one segment, appended to W.mv (no HPC).  seq holds nt4 codes (>=4 ambiguous).
 // Output layout as the reference: x = hash<<8 | span, y = rid<<32 | lastPos<<1 | strand.
-PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
+// the window ring of sketch_segment: w entries of (x, y)
+struct RingMem {            // in the work arena (or LDS / host memory through plain pointers)
+    Ptr<A128> buf;
+    PMX_HD A128 get(int j) const { return buf[j]; }
+    PMX_HD uint64_t getx(int j) const { return buf[j].x; }
+    PMX_HD void set(int j, const A128& v) const { buf[j] = v; }
+};
+#ifdef PMX_INTERLEAVED
+struct RingLds {            // thread-per-pair kernel: [slot][lane] in LDS, y stored as its low 32 bits
+    uint64_t* x;
+    uint32_t* y;
+    uint64_t y_hi;
+    __device__ __forceinline__ A128 get(int j) const {
+        A128 v;
+        v.x = x[j * 64];
+        v.y = v.x == UINT64_MAX ? UINT64_MAX : (y_hi | y[j * 64]);
+        return v;
+    }
+    __device__ __forceinline__ uint64_t getx(int j) const { return x[j * 64]; }
+    __device__ __forceinline__ void set(int j, const A128& v) const { x[j * 64] = v.x; y[j * 64] = (uint32_t)v.y; }
+};
+#endif
+
+template <class Ring>
+PMX_HD void sketch_segment_t(Work& W, const Ring& buf, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
     const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
     uint64_t kmer0 = 0, kmer1 = 0;
     int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
     PMX_LDS(&W); PMX_LDS(seq);
-    Ptr<A128> buf = W.sk_buf; PMX_LDS(buf);
     Ptr<A128> mvp = W.mv; PMX_LDS(mvp);
     A128 mn;
     mn.x = mn.y = UINT64_MAX;
-    for (int j = 0; j < w; ++j) buf[j].x = buf[j].y = UINT64_MAX;
+    {
+        A128 inv;
+        inv.x = inv.y = UINT64_MAX;
+        for (int j = 0; j < w; ++j) buf.set(j, inv);
+    }
 #define PMX_MV_PUSH(val)                                              \
     do {                                                              \
         if (W.n_mv < W.caps.max_mini) mvp[W.n_mv] = (val);            \
@@ -59,12 +86,12 @@ PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int
             l = 0;
             kmer_span = 0;
         }
-        buf[buf_pos] = info;
+        buf.set(buf_pos, info);
         if (l == w + k - 1 && mn.x != UINT64_MAX) {   // first full window: emit earlier identical k-mers
             for (int j = buf_pos + 1; j < w; ++j)
-                if (mn.x == buf[j].x && buf[j].y != mn.y) PMX_MV_PUSH(buf[j]);
+                { const A128 bj = buf.get(j); if (mn.x == bj.x && bj.y != mn.y) PMX_MV_PUSH(bj); }
             for (int j = 0; j < buf_pos; ++j)
-                if (mn.x == buf[j].x && buf[j].y != mn.y) PMX_MV_PUSH(buf[j]);
+                { const A128 bj = buf.get(j); if (mn.x == bj.x && bj.y != mn.y) PMX_MV_PUSH(bj); }
         }
         if (info.x <= mn.x) {                          // new minimum: flush the old one
             if (l >= w + k && mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
@@ -74,20 +101,33 @@ PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int
             if (l >= w + k - 1 && mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
             mn.x = UINT64_MAX;
             for (int j = buf_pos + 1; j < w; ++j)
-                if (mn.x >= buf[j].x) { mn = buf[j]; min_pos = j; }   // >= keeps the right-most
+                if (mn.x >= buf.getx(j)) { mn = buf.get(j); min_pos = j; }   // >= keeps the right-most
             for (int j = 0; j <= buf_pos; ++j)
-                if (mn.x >= buf[j].x) { mn = buf[j]; min_pos = j; }
+                if (mn.x >= buf.getx(j)) { mn = buf.get(j); min_pos = j; }
             if (l >= w + k - 1 && mn.x != UINT64_MAX) {
                 for (int j = buf_pos + 1; j < w; ++j)
-                    if (mn.x == buf[j].x && mn.y != buf[j].y) PMX_MV_PUSH(buf[j]);
+                    { const A128 bj = buf.get(j); if (mn.x == bj.x && mn.y != bj.y) PMX_MV_PUSH(bj); }
                 for (int j = 0; j <= buf_pos; ++j)
-                    if (mn.x == buf[j].x && mn.y != buf[j].y) PMX_MV_PUSH(buf[j]);
+                    { const A128 bj = buf.get(j); if (mn.x == bj.x && mn.y != bj.y) PMX_MV_PUSH(bj); }
             }
         }
         if (++buf_pos == w) buf_pos = 0;
     }
     if (mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
 #undef PMX_MV_PUSH
+}
+
+PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
+#ifdef PMX_INTERLEAVED
+    if (W.sk_lds_x) {
+        RingLds ring{W.sk_lds_x, W.sk_lds_y, (uint64_t)rid << 32};
+        sketch_segment_t(W, ring, seq, len, w, k, rid);
+        return;
+    }
+#endif
+    RingMem ring{W.sk_buf};
+    PMX_LDS(ring.buf);
+    sketch_segment_t(W, ring, seq, len, w, k, rid);
 }
 
 // collect_minimizers (map.c:59-73): segment s gets rid = s and its positions shifted by the summed

@@ -240,18 +240,50 @@ struct SeedB {
     uint32_t q_span, seg_id, is_tandem, pad;
 };
 
-struct Reg {            // mm_reg1_t + mm_extra_t (minimap.h:98-128)
-    int32_t id, cnt, rid, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
-    uint32_t hash;
-    float div;
-    uint8_t mapq, split, rev, inv, sam_pri, proper_frag, pe_thru, seg_split, seg_id, split_inv, is_alt, strand_retained;
+// mm_reg1_t + mm_extra_t (minimap.h:98-128).  In the thread-per-pair kernel the struct is STRIDED: every 4-byte
+// slot is followed by 252 bytes of padding, so that with a base pointer of `wave region + lane * 4` the fields of
+// the 64 lanes' regions interleave dword by dword exactly like the IPtr arrays (a wave touching the same field of
+// its 64 regions touches 256 contiguous bytes instead of 64 separate lines), while the code keeps plain struct
+// syntax.  Copies and clears are field-wise (the padding belongs to the other lanes).
+#define PMX_REG_SLOTS 27
+#define PMX_REG_STRIDED_BYTES (PMX_REG_SLOTS * 256)
+#ifdef PMX_INTERLEAVED
+#define PMX_RP(n) char pad_##n[252];
+#else
+#define PMX_RP(n)
+#endif
+#define PMX_REG_FIELDS(X)                                                                                              \
+    X(id) X(cnt) X(rid) X(score) X(qs) X(qe) X(rs) X(re) X(parent) X(subsc) X(as) X(mlen) X(blen) X(n_sub) X(score0)   \
+    X(hash) X(div) X(mapq) X(split) X(rev) X(inv) X(sam_pri) X(proper_frag) X(pe_thru) X(seg_split) X(seg_id)          \
+    X(split_inv) X(is_alt) X(strand_retained) X(has_p) X(dp_score) X(dp_max) X(dp_max2) X(n_ambi) X(n_cigar) X(cig_slot)
+struct Reg {
+    int32_t id; PMX_RP(0) int32_t cnt; PMX_RP(1) int32_t rid; PMX_RP(2) int32_t score; PMX_RP(3) int32_t qs; PMX_RP(4)
+    int32_t qe; PMX_RP(5) int32_t rs; PMX_RP(6) int32_t re; PMX_RP(7) int32_t parent; PMX_RP(8) int32_t subsc; PMX_RP(9)
+    int32_t as; PMX_RP(10) int32_t mlen; PMX_RP(11) int32_t blen; PMX_RP(12) int32_t n_sub; PMX_RP(13) int32_t score0; PMX_RP(14)
+    uint32_t hash; PMX_RP(15)
+    float div; PMX_RP(16)
+    uint8_t mapq, split, rev, inv; PMX_RP(17)
+    uint8_t sam_pri, proper_frag, pe_thru, seg_split; PMX_RP(18)
+    uint8_t seg_id, split_inv, is_alt, strand_retained; PMX_RP(19)
     // extra
-    uint8_t has_p;
-    int32_t dp_score, dp_max, dp_max2;
-    uint32_t n_ambi;
-    uint32_t n_cigar;
-    uint32_t cig_slot;   // index of this region's CIGAR buffer in the per-wave CIGAR pool
+    uint8_t has_p, pad_b[3]; PMX_RP(20)
+    int32_t dp_score; PMX_RP(21) int32_t dp_max; PMX_RP(22) int32_t dp_max2; PMX_RP(23)
+    uint32_t n_ambi; PMX_RP(24)
+    uint32_t n_cigar; PMX_RP(25)
+    uint32_t cig_slot; PMX_RP(26)   // index of this region's CIGAR buffer in the per-wave CIGAR pool
+#ifdef PMX_INTERLEAVED
+    Reg() = default;
+#define PMX_X(f) f = o.f;
+    __device__ __forceinline__ Reg(const Reg& o) { PMX_REG_FIELDS(PMX_X) }
+    __device__ __forceinline__ Reg& operator=(const Reg& o) { PMX_REG_FIELDS(PMX_X) return *this; }
+#undef PMX_X
+#endif
 };
+#ifdef PMX_INTERLEAVED
+static_assert(sizeof(Reg) == PMX_REG_STRIDED_BYTES, "strided Reg layout");
+#else
+static_assert(sizeof(Reg) == 4 * PMX_REG_SLOTS, "Reg has 27 four-byte slots");
+#endif
 
 struct Ez {             // ksw_extz_t (ksw2.h:27-36)
     uint32_t max;
@@ -308,6 +340,10 @@ struct Work {
     Ptr<A128> mv;
     int n_mv;
     Ptr<A128> sk_buf;      // minimizer window ring (w entries)
+    // thread-per-pair kernel: the ring lives in LDS instead, [slot][lane], 8-byte x and 4-byte low half of y
+    // (the high half of y is the segment id); NULL elsewhere
+    uint64_t* sk_lds_x;
+    uint32_t* sk_lds_y;
     Ptr<SeedA> seeds;
     Ptr<SeedB> seeds_b;
     int n_seeds;

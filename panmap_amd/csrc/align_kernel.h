@@ -26,6 +26,7 @@ struct AlignArgs {
     unsigned long long* dp_count;   // round 0: slot allocator; round >= 1: length of dp_next_list
     uint32_t dp_slot_cap;
     int dp_round;
+    int tpp_ring_w;             // k_align_reads_tpp: minimizer window length when the ring lives in LDS, else 0
     int dp_class;               // k_align_dp_serve: 0 = every request, 1 = only small ones, 2 = only the others
     int dp_small_qlen, dp_small_tlen;   // small class: qlen <= , tlen <= (multiple of 16), traceback <= layout.tb_fast_cap
 

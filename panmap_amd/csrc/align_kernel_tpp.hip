@@ -19,7 +19,7 @@ namespace pmx {
 namespace aln {
 
 // Per-thread memory: the interleaved arena is addressed through IPtr (aln_types.hpp) relative to the wave's
-// slab in c_tpp_arena; `raw` is the thread's contiguous region for the Reg / Seed arrays.
+// slab in c_tpp_arena; `raw` is this lane's base into the wave's strided Reg region (struct Reg).
 #ifndef PMX_TPP_OCC
 #define PMX_TPP_OCC 4   // waves per SIMD the register allocation targets (latency-bound kernel: occupancy hides L2 round trips)
 #endif
@@ -27,8 +27,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PMX_TPP
 k_align_reads_tpp(AlignArgs A) {
     const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t n_threads = (int64_t)gridDim.x * 64;
-    uint8_t* raw = A.slow_base + (size_t)tid * A.slow_stride;
+    uint8_t* raw = A.slow_base + (size_t)blockIdx.x * A.slow_stride + ((threadIdx.x & 63u) << 2);   // strided Reg region of this lane
     const int n_segs = A.paired ? 2 : 1;
+    // minimizer window ring of this lane in LDS (dynamic LDS = 12 bytes x w x 64 lanes; 0 -> ring in the arena)
+    extern __shared__ __attribute__((aligned(16))) uint8_t tpp_lds[];
+    uint64_t* ring_x = nullptr;
+    uint32_t* ring_y = nullptr;
+    if (A.tpp_ring_w > 0) {
+        ring_x = reinterpret_cast<uint64_t*>(tpp_lds) + (threadIdx.x & 63u);
+        ring_y = reinterpret_cast<uint32_t*>(tpp_lds + (size_t)A.tpp_ring_w * 64 * 8) + (threadIdx.x & 63u);
+    }
 
     for (int64_t it = tid; it < A.n_items; it += n_threads) {
         int64_t item, slot = -1;
@@ -41,6 +49,8 @@ k_align_reads_tpp(AlignArgs A) {
         Work W;
         bind_work(W, A.layout, nullptr, nullptr, raw);
         W.n_segs = n_segs;
+        W.sk_lds_x = ring_x;
+        W.sk_lds_y = ring_y;
         W.prof = A.prof;   // diagnostic runs: lane 0's stamps are the wave's phase timeline
         if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 16; ++k) W.prof_acc[k] = 0; }
         W.dp_req_base = A.dp_req_base;

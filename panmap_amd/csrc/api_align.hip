@@ -196,7 +196,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     };
     A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
     A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
-    A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0;
+    A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.tpp_ring_w = 0;
     timer_begin(ctx, "align");
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
@@ -217,7 +217,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             const size_t tpp_wave_stride = tpp_arena_bytes(tpp_layout) * 64;
             const size_t tpp_raw_stride = (tpp_layout.raw_bytes + 255) & ~(size_t)255;
             al->slab0.ensure(tpp_wave_stride * (size_t)max_grid);
-            al->slab_raw.ensure(tpp_raw_stride * (size_t)max_grid * 64);
+            al->slab_raw.ensure(tpp_raw_stride * (size_t)max_grid);   // per wave
             tpp_set_arena(al->slab0.p, tpp_wave_stride, ctx->stream);
             const Layout dp_layout = plan_layout_dp((int)rs->max_len, n_segs, al->opt);
             const size_t dp_lds = PMX_ALIGN_WORK_BYTES + dp_layout.fast_bytes + 16;
@@ -243,6 +243,10 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 A.dp_slot_pairs = al->dp_slot_pairs.p;
                 A.dp_slot_cap = (uint32_t)std::min<int64_t>(n_items, UINT32_MAX - 1);
             }
+            // minimizer window ring in LDS when 16 waves per CU still fit (12 B x w x 64 lanes per wave)
+            size_t tpp_lds_bytes = (size_t)al->opt.w * 64 * 12;
+            if (tpp_lds_bytes * (size_t)tpp_waves > (size_t)150 * 1024 || getenv("PMX_ALIGN_NO_LDS_RING")) tpp_lds_bytes = 0;
+            A.tpp_ring_w = tpp_lds_bytes ? al->opt.w : 0;
             A.dp_count = al->retry_count.p + 1;
             A.retry_list = al->retry_list2.p;
             A.retry_count = al->retry_count.p;
@@ -255,7 +259,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 A.worklist = worklist;
                 A.dp_round = round;
                 A.dp_next_list = next_list;
-                hipLaunchKernelGGL(k_align_reads_tpp, dim3((unsigned)grid), dim3(64), 0, ctx->stream, A);
+                hipLaunchKernelGGL(k_align_reads_tpp, dim3((unsigned)grid), dim3(64), tpp_lds_bytes, ctx->stream, A);
                 PMX_HIP(hipGetLastError());
             };
             timer_begin(ctx, "align_tpp0");   // the dominant kernel on its own (bench.py roofline)
