@@ -98,13 +98,24 @@ __global__ void k_mark_first_of_run(const uint8_t* __restrict__ ascii, const int
 // --------------------------------------------------------------------------------- seeding
 __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long* vals, uint64_t mask, uint64_t key,
                                              unsigned long long mult, unsigned long long* counters) {
+    // A slot's key goes EMPTY -> key once and never changes again, so the common case (the seed is already in
+    // the table: the ~10^4 true seeds of a sample are hit millions of times) needs no compare-and-swap: a plain
+    // device-scope load finds the slot and the count is bumped with a fire-and-forget atomic add.  A returning
+    // CAS on those hot lines cost microseconds each and the 37 inserts of a read are serial.
     uint64_t slot = mix64(key) & mask;
     for (uint64_t probes = 0; probes <= mask; ++probes) {
-        unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)key);
-        if (prev == PMX_EMPTY_KEY) atomicAdd(&counters[PMX_CTR_SHARD0 + (slot & (PMX_CTR_NSHARD - 1))], 1ULL);   // sharded: one hot word would serialise
-        if (prev == PMX_EMPTY_KEY || prev == key) {
+        const unsigned long long cur = __hip_atomic_load((unsigned long long*)&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) {
             atomicAdd(&vals[slot], mult);
             return;
+        }
+        if (cur == PMX_EMPTY_KEY) {
+            const unsigned long long prev = atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)key);
+            if (prev == PMX_EMPTY_KEY) atomicAdd(&counters[PMX_CTR_SHARD0 + (slot & (PMX_CTR_NSHARD - 1))], 1ULL);   // sharded: one hot word would serialise
+            if (prev == PMX_EMPTY_KEY || prev == key) {
+                atomicAdd(&vals[slot], mult);
+                return;
+            }
         }
         slot = (slot + 1) & mask;
     }
@@ -124,8 +135,15 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
     uint64_t* ringR = lds + (size_t)w * PMX_SEED_BLOCK;      // [w][B]
     uint64_t* ringS = lds + (size_t)2 * w * PMX_SEED_BLOCK;  // [l][B]
     const int tid = threadIdx.x;
-    const uint64_t HB[4] = {0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x20323ed082572324ULL, 0x295549f54be24456ULL};
+    // base hashes A, C, G, T (src/seeding.hpp:100-112) picked with selects, not a table in memory
+    auto HB = [](uint32_t c) -> uint64_t {
+        const uint64_t lo = (c & 1u) ? 0x3193c18562a02b4cULL : 0x3c8bfbb395c60474ULL;
+        const uint64_t hi = (c & 1u) ? 0x295549f54be24456ULL : 0x20323ed082572324ULL;
+        return (c & 2u) ? hi : lo;
+    };
     unsigned long long n_seeds = 0;
+    // ring slots advance by one per base: kept as wrapping counters (a 64-bit '%' per base costs hundreds of instructions)
+    const int first0 = sp.t % w, last0 = (sp.k - sp.s - sp.t) % w;
 
     for (int64_t r = r_begin + (int64_t)blockIdx.x * PMX_SEED_BLOCK + tid; r < n_reads; r += (int64_t)gridDim.x * PMX_SEED_BLOCK) {
         const int64_t len = off[r + 1] - off[r];
@@ -142,52 +160,60 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
         uint32_t ca = 0;
         uint64_t F = 0, R = 0;  // k-min-mer rolling hashes
         int64_t n_sync = 0;
-        for (int64_t i = 0; i < len; ++i) {
+        int slot_w = 0;                        // (i - s + 1) mod w
+        int s_first = first0, s_last = last0;  // (ks + t) mod w, (ks + k - s - t) mod w
+        int slot_l = 0;                        // (n_sync - 1) mod l
+        const int ilen = (int)len;
+        for (int i = 0; i < ilen; ++i) {
             if ((i & 31) == 0) { cw = rw[i >> 5]; ca = ra[i >> 5]; }
             const uint32_t code = (uint32_t)(cw & 3u);
             const uint32_t am = ca & 1u;
             cw >>= 2; ca >>= 1;
-            const uint64_t hb = am ? 0 : HB[code], hc = am ? 0 : HB[3 - code];
+            const uint64_t hb = am ? 0 : HB(code), hc = am ? 0 : HB(3 - code);
             if (am) last_amb = i;
             // outgoing bases (distance s and k behind)
             if (i < sp.s) { fS ^= rotl64(hb, (unsigned)(sp.s - 1 - i)); rS ^= rotl64(hc, (unsigned)i); }
             else {
                 const uint32_t oc = (uint32_t)(hist2 >> (2 * (sp.s - 1))) & 3u, oa = (hista >> (sp.s - 1)) & 1u;
-                const uint64_t ob = oa ? 0 : HB[oc], ocm = oa ? 0 : HB[3 - oc];
+                const uint64_t ob = oa ? 0 : HB(oc), ocm = oa ? 0 : HB(3 - oc);
                 fS = rotl64(fS, 1) ^ rotl64(ob, (unsigned)sp.s) ^ hb;
                 rS = rotr64(rS, 1) ^ rotr64(ocm, 1) ^ rotl64(hc, (unsigned)(sp.s - 1));
             }
             if (i < sp.k) { fK ^= rotl64(hb, (unsigned)(sp.k - 1 - i)); rK ^= rotl64(hc, (unsigned)i); }
             else {
                 const uint32_t oc = (uint32_t)(hist2 >> (2 * (sp.k - 1))) & 3u, oa = (hista >> (sp.k - 1)) & 1u;
-                const uint64_t ob = oa ? 0 : HB[oc], ocm = oa ? 0 : HB[3 - oc];
+                const uint64_t ob = oa ? 0 : HB(oc), ocm = oa ? 0 : HB(3 - oc);
                 fK = rotl64(fK, 1) ^ rotl64(ob, (unsigned)sp.k) ^ hb;
                 rK = rotr64(rK, 1) ^ rotr64(ocm, 1) ^ rotl64(hc, (unsigned)(sp.k - 1));
             }
             hist2 = (hist2 << 2) | code;
             hista = (hista << 1) | am;
             if (i >= sp.s - 1) {
-                const int slot = (int)((i - sp.s + 1) % w);
-                ringF[(size_t)slot * PMX_SEED_BLOCK + tid] = fS;
-                ringR[(size_t)slot * PMX_SEED_BLOCK + tid] = rS;
+                ringF[(size_t)slot_w * PMX_SEED_BLOCK + tid] = fS;
+                ringR[(size_t)slot_w * PMX_SEED_BLOCK + tid] = rS;
+                slot_w = slot_w + 1 == w ? 0 : slot_w + 1;
             }
             if (i < sp.k - 1) continue;
             const int64_t ks = i - sp.k + 1;
+            const int cur_first = s_first, cur_last = s_last;   // this k-mer's slots; advance for the next one
+            s_first = s_first + 1 == w ? 0 : s_first + 1;
+            s_last = s_last + 1 == w ? 0 : s_last + 1;
             if (last_amb >= ks || fK == rK) continue;
+            // window minima (all w slots: a data-dependent rescan diverges across the wave and was measured slower)
             uint64_t fmin = UINT64_MAX, rmin = UINT64_MAX;
+#pragma unroll 4
             for (int j = 0; j < w; ++j) {
                 const uint64_t a = ringF[(size_t)j * PMX_SEED_BLOCK + tid], b = ringR[(size_t)j * PMX_SEED_BLOCK + tid];
                 fmin = a < fmin ? a : fmin;
                 rmin = b < rmin ? b : rmin;
             }
-            const int s_first = (int)((ks + sp.t) % w), s_last = (int)((ks + sp.k - sp.s - sp.t) % w);
             bool fs, rs;
             if (sp.open) {
-                fs = ringF[(size_t)s_first * PMX_SEED_BLOCK + tid] == fmin;
-                rs = ringR[(size_t)s_last * PMX_SEED_BLOCK + tid] == rmin;
+                fs = ringF[(size_t)cur_first * PMX_SEED_BLOCK + tid] == fmin;
+                rs = ringR[(size_t)cur_last * PMX_SEED_BLOCK + tid] == rmin;
             } else {
-                fs = ringF[(size_t)s_first * PMX_SEED_BLOCK + tid] == fmin || ringF[(size_t)s_last * PMX_SEED_BLOCK + tid] == fmin;
-                rs = ringR[(size_t)s_last * PMX_SEED_BLOCK + tid] == rmin || ringR[(size_t)s_first * PMX_SEED_BLOCK + tid] == rmin;
+                fs = ringF[(size_t)cur_first * PMX_SEED_BLOCK + tid] == fmin || ringF[(size_t)cur_last * PMX_SEED_BLOCK + tid] == fmin;
+                rs = ringR[(size_t)cur_last * PMX_SEED_BLOCK + tid] == rmin || ringR[(size_t)cur_first * PMX_SEED_BLOCK + tid] == rmin;
             }
             if (!(fs || rs)) continue;
             if (ks < valid_start || ks > valid_end) continue;   // primer trim (src/placement.cpp:1629-1648)
@@ -204,19 +230,23 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
                 R ^= rotl64(h, (unsigned)(sp.k * (int)(n_sync - 1)));
                 have = n_sync == l;
             } else {
-                const uint64_t prev = ringS[(size_t)((n_sync - 1) % l) * PMX_SEED_BLOCK + tid];
+                const uint64_t prev = ringS[(size_t)slot_l * PMX_SEED_BLOCK + tid];
                 F = rotl64(F, (unsigned)sp.k) ^ rotl64(prev, (unsigned)(sp.k * l)) ^ h;
                 R = rotr64(R, (unsigned)sp.k) ^ rotr64(prev, (unsigned)sp.k) ^ rotl64(h, (unsigned)(sp.k * (l - 1)));
                 have = true;
             }
-            ringS[(size_t)((n_sync - 1) % l) * PMX_SEED_BLOCK + tid] = h;
+            ringS[(size_t)slot_l * PMX_SEED_BLOCK + tid] = h;
+            slot_l = slot_l + 1 == l ? 0 : slot_l + 1;
             if (have && F != R) {
                 table_insert(keys, vals, mask, F < R ? F : R, 1ULL, counters);
                 ++n_seeds;
             }
         }
     }
-    if (n_seeds) atomicAdd(&counters[PMX_CTR_SEEDS], n_seeds);
+    // one atomic per wave: a per-thread atomic on this single word was the whole cost of the kernel
+    // (same-address atomics retire at a few hundred per microsecond)
+    for (int o = 32; o > 0; o >>= 1) n_seeds += __shfl_xor(n_seeds, o);
+    if ((tid & 63) == 0 && n_seeds) atomicAdd(&counters[PMX_CTR_SEEDS], n_seeds);
 }
 
 // merge externally supplied (hash,count) pairs into the table (multi-GPU histogram exchange)
