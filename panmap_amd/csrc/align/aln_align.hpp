@@ -656,13 +656,13 @@ PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac,
         Reg& r = regs[i];
         if (!r.has_p) continue;
         Ptr<const uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
-        int32_t ng = 0, ngo = 0;
+        int32_t ng = 0;
         double gap_cost = 0.0;
         for (uint32_t q = 0; q < r.n_cigar; ++q) {
             const int32_t op = cg[q] & 0xf, len = cg[q] >> 4;
             if (op == 1 || op == 2) {
                 gap_cost += b2 + (double)mg_log2f((float)(1.0 + len));
-                ++ngo; ng += len;
+                ng += len;
             }
         }
         const int32_t n_mis = r.blen + (int32_t)r.n_ambi - r.mlen - ng;

@@ -25,7 +25,6 @@ namespace aln {
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PMX_TPP_OCC)))
 k_align_reads_tpp(AlignArgs A) {
-    const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t n_threads = (int64_t)gridDim.x * 64;
     uint8_t* raw = A.slow_base + (size_t)blockIdx.x * A.slow_stride + ((threadIdx.x & 63u) << 2);   // strided Reg region of this lane
     const int n_segs = A.paired ? 2 : 1;
@@ -38,15 +37,20 @@ k_align_reads_tpp(AlignArgs A) {
         ring_y = reinterpret_cast<uint32_t*>(tpp_lds + (size_t)A.tpp_ring_w * 64 * 8) + (threadIdx.x & 63u);
     }
 
-    for (int64_t it = tid; it < A.n_items; it += n_threads) {
-        int64_t item, slot = -1;
+    const int lane = (int)(threadIdx.x & 63u);
+    // every lane of the wave runs the same number of iterations (the CIGAR arena is claimed once per wave)
+    for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < A.n_items; it0 += n_threads) {
+        const int64_t it = it0 + lane;
+        int64_t item = -1, slot = -1;
+        bool emit = false;
+        Work W;
+        if (it < A.n_items) do {   // `break` = this lane emits no record in this pass
         if (A.dp_round == 0) item = it;
         else {
             slot = A.worklist ? (int64_t)A.worklist[it] : it;
             item = (int64_t)A.dp_slot_pairs[slot];
-            if (item == 0xffffffffLL) continue;
+            if (item == 0xffffffffLL) break;
         }
-        Work W;
         bind_work(W, A.layout, nullptr, nullptr, raw);
         W.n_segs = n_segs;
         W.sk_lds_x = ring_x;
@@ -108,14 +112,37 @@ k_align_reads_tpp(AlignArgs A) {
         if (W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) {
             A.retry_list[atomicAdd(A.retry_count, 1ULL)] = (uint32_t)item;
             if (A.dp_round == 0 && W.dp_slot >= 0) A.dp_slot_pairs[W.dp_slot] = 0xffffffffu;   // slot taken, pair gone
-            continue;
+            break;
         }
         if (W.status & PMX_ST_NEED_DP) {
             if (A.dp_round == 0) A.dp_slot_pairs[W.dp_slot] = (uint32_t)item;
             else A.dp_next_list[atomicAdd(A.dp_count, 1ULL)] = (uint32_t)slot;
-            continue;
+            break;
         }
-        const bool mapped = frag_is_mapped(W, A.paired);
+        emit = true;
+        } while (0);
+        // CIGAR arena: one atomic per wave (a returning atomic per mate on this single word serialised the lanes)
+        bool mapped = false;
+        uint32_t need[2] = {0, 0};
+        if (emit) {
+            mapped = frag_is_mapped(W, A.paired);
+            for (int s = 0; s < n_segs; ++s)
+                if (mapped && W.regs[s][0].has_p) need[s] = W.regs[s][0].n_cigar;
+        }
+        const uint32_t mine = need[0] + need[1];
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const uint32_t wave_total = __shfl(incl, 63);
+        unsigned long long wave_base = 0;
+        if (wave_total) {
+            if (lane == 0) wave_base = atomicAdd(A.cigar_used, (unsigned long long)wave_total);
+            wave_base = __shfl(wave_base, 0);
+        }
+        uint64_t coff = wave_base + (incl - mine);
+        if (emit)
         for (int s = 0; s < n_segs; ++s) {
             const int64_t r = A.paired ? 2 * item + s : item;
             AlnRecord rec;
@@ -130,7 +157,6 @@ k_align_reads_tpp(AlignArgs A) {
                     rec.mapq = g.mapq; rec.rev = g.rev; rec.proper_frag = g.proper_frag;
                     rec.n_cigar = (uint16_t)g.n_cigar;
                     rec.score = g.dp_max;
-                    const uint64_t coff = atomicAdd(A.cigar_used, (unsigned long long)g.n_cigar);
                     rec.cigar_off = (uint32_t)coff;
                     if (coff + g.n_cigar <= A.cigar_cap) {
                         Ptr<const uint32_t> cg = reg_cigar(W, g);
@@ -139,11 +165,12 @@ k_align_reads_tpp(AlignArgs A) {
                         rec.flags |= PMX_REC_OVERFLOW;
                         rec.n_cigar = 0;
                     }
+                    coff += g.n_cigar;
                 }
             }
             A.records[r] = rec;
         }
-        if (A.prof) {
+        if (A.prof && emit) {
             PMX_STAMP(W, 11);
             if ((threadIdx.x & 63) == 0)
                 for (int k = 0; k < 12; ++k) atomicAdd(&A.prof[k], W.prof_acc[k]);

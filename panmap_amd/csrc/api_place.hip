@@ -427,7 +427,9 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             PMX_HIP(hipGetLastError());
             keep = pl->dd_keep.p;
         }
-        const int64_t chunk_reads = std::max<int64_t>(1, ((int64_t)16 << 20) / std::max<int64_t>(rs->max_len, 1));
+        int64_t chunk_mb = 16;
+        if (const char* e = getenv("PMX_SEED_CHUNK_MB")) chunk_mb = std::max<int64_t>(1, atoll(e));
+        const int64_t chunk_reads = std::max<int64_t>(1, (chunk_mb << 20) / std::max<int64_t>(rs->max_len, 1));
         timer_begin(ctx, "seed");
         for (int64_t r0 = 0; r0 < rs->n; r0 += chunk_reads) {
             const int64_t r1 = std::min<int64_t>(rs->n, r0 + chunk_reads);
@@ -542,7 +544,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
         if (pp->seed_mask_fraction > 0.0) {
             // unique seeds after homopolymer erase
             PMX_HIP(hipMemsetAsync(pl->stats.p, 0, 4 * sizeof(unsigned long long), st));
-            hipLaunchKernelGGL(k_hist_stats, dim3(grid_for(n, 256, G)), dim3(256), 0, st, pl->hist_count.p, pl->dead.p, n, pl->stats.p);
+            hipLaunchKernelGGL(k_hist_stats, dim3(grid_for(n, 256, ctx->n_cu)), dim3(256), 0, st, pl->hist_count.p, pl->dead.p, n, pl->stats.p);
             PMX_HIP(hipMemcpyAsync(h_stats, pl->stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
             PMX_HIP(hipStreamSynchronize(st));
             const int64_t n_mask = (int64_t)(pp->seed_mask_fraction * (double)h_stats[3]);   // :1775
@@ -561,7 +563,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
             }
         }
         PMX_HIP(hipMemsetAsync(pl->stats.p, 0, 4 * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_hist_stats, dim3(grid_for(n, 256, G)), dim3(256), 0, st, pl->hist_count.p, pl->dead.p, n, pl->stats.p);
+        hipLaunchKernelGGL(k_hist_stats, dim3(grid_for(n, 256, ctx->n_cu)), dim3(256), 0, st, pl->hist_count.p, pl->dead.p, n, pl->stats.p);
         PMX_HIP(hipMemcpyAsync(h_stats, pl->stats.p, sizeof(h_stats), hipMemcpyDeviceToHost, st));
         PMX_HIP(hipStreamSynchronize(st));
         if (min_support < 0) {   // resolveMinReadSupport, src/placement.cpp:931-955
