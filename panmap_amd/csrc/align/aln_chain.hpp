@@ -159,6 +159,28 @@ __device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_d
 }
 #endif
 
+#if PMX_W == 1
+// Scalar execution models (thread per pair, host): everything the inner loop of the fill needs from anchor j --
+// reference position, query position, span, segment, f, p, the t mark -- packed into ONE 16-byte cell, so an
+// inner iteration is one load (and one 2-byte store for the mark) instead of an anchor load plus a cell load.
+// Valid while positions in the query fit 16 bits and there are fewer than 65,535 anchors.
+struct PackedCell {
+    uint32_t x_lo;       // low 32 bits of anchor x (comput_sc only uses the 32-bit difference)
+    uint16_t y_lo;       // query position
+    uint8_t span, seg;
+    int32_t f;
+    uint16_t p1;         // p + 1 (0 = none)
+    uint16_t t;
+};
+static_assert(sizeof(PackedCell) == 16, "one interleave granule");
+PMX_HD A128 packed_anchor(const PackedCell& c) {
+    A128 r;
+    r.x = c.x_lo;
+    r.y = (uint64_t)c.seg << PMX_SEED_SEG_SHIFT | (uint64_t)c.span << 32 | c.y_lo;
+    return r;
+}
+#endif
+
 // mg_lchain_dp (lchain.c:148-230) followed by mg_chain_backtrack (:27-76) and compact_a (:78-111).
 // In: W.a[0..n_a) sorted anchors.  Out: W.a holds the chained anchors grouped by chain, W.u[0..n_u)
 // = score<<32 | count, chains ordered by the target position of their first anchor.
@@ -180,7 +202,75 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
 #else
     const bool wave_fill = false;
 #endif
-    if (!wave_fill) {
+    bool packed_fill = false;
+#if PMX_W == 1
+    {
+        int qsum = 0;
+        for (int sg = 0; sg < W.n_segs; ++sg) qsum += W.qlen[sg];
+        packed_fill = n < 65535 && qsum < 65536;
+    }
+    if (packed_fill) {
+        Ptr<PackedCell> pk = ptr_cast<PackedCell>(W.z);   // z[] is idle until the backtrack
+        int64_t st = 0, max_ii = -1;
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t max_j = -1, end_j;
+            const A128 ai = a[i];
+            PackedCell ci;
+            ci.x_lo = (uint32_t)ai.x;
+            ci.y_lo = (uint16_t)(uint32_t)ai.y;
+            ci.span = (uint8_t)(ai.y >> 32 & 0xff);
+            ci.seg = (uint8_t)((ai.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
+            ci.f = 0; ci.p1 = 0; ci.t = 0;
+            const A128 ri = packed_anchor(ci);
+            int32_t max_f = (int32_t)ci.span, n_skip = 0;
+            while (st < i && (ai.x >> 32 != a[st].x >> 32 || ai.x > a[st].x + (uint64_t)max_dist_x)) ++st;
+            if (i - st > max_iter) st = i - max_iter;
+            int64_t j;
+            for (j = i - 1; j >= st; --j) {
+                const PackedCell cj = pk[j];
+                int32_t sc = chain_score(ri, packed_anchor(cj), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                if (sc == INT32_MIN) continue;
+                sc += cj.f;
+                if (sc > max_f) {
+                    max_f = sc;
+                    max_j = j;
+                    if (n_skip > 0) --n_skip;
+                } else if (cj.t == (uint16_t)i) {
+                    if (++n_skip > max_skip) break;
+                }
+                if (cj.p1) pk[cj.p1 - 1].t = (uint16_t)i;
+            }
+            end_j = j;
+            if (max_ii < 0 || (int64_t)(ai.x - a[max_ii].x) > (int64_t)max_dist_x) {
+                int32_t mx = INT32_MIN;
+                max_ii = -1;
+                for (j = i - 1; j >= st; --j) {
+                    const int32_t fj = pk[j].f;
+                    if (mx < fj) { mx = fj; max_ii = j; }
+                }
+            }
+            if (max_ii >= 0 && max_ii < end_j) {
+                const PackedCell cm = pk[max_ii];
+                const int32_t tmp = chain_score(ri, packed_anchor(cm), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                if (tmp != INT32_MIN && max_f < tmp + cm.f) { max_f = tmp + cm.f; max_j = max_ii; }
+            }
+            {
+                const int32_t vm = max_j >= 0 ? c[max_j].v : 0;
+                ChainCell co;
+                co.f = max_f;
+                co.p = (int32_t)max_j;
+                co.t = 0;
+                co.v = max_j >= 0 && vm > max_f ? vm : max_f;
+                c[i] = co;
+                ci.f = max_f;
+                ci.p1 = (uint16_t)(max_j + 1);
+                pk[i] = ci;
+            }
+            if (max_ii < 0 || ((int64_t)(ai.x - a[max_ii].x) <= (int64_t)max_dist_x && pk[max_ii].f < max_f)) max_ii = i;
+        }
+    }
+#endif
+    if (!wave_fill && !packed_fill) {
         for (int64_t i = 0; i < n; ++i) c[i].t = 0;
         int64_t st = 0, max_ii = -1;
         for (int64_t i = 0; i < n; ++i) {
