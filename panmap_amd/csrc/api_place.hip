@@ -53,6 +53,8 @@ struct pmx_place {
     DevBuf<unsigned long long> stats;
     DevBuf<char> tmp;                      // rocprim temp storage
     // node outputs
+    hipGraphExec_t level_graph_exec = nullptr;   // captured k_score_level chain
+    const void* level_graph_sig[3] = {nullptr, nullptr, nullptr};
     DevBuf<double> metrics5, scores5, terms;
     DevBuf<uint64_t> dd_h1, dd_h2, dd_h1s, dd_key;   // --dedup scratch
     DevBuf<uint32_t> dd_idx, dd_idx2;
@@ -366,6 +368,7 @@ int pmx_place_create(pmx_ctx* ctx, const pmx_index* idx, pmx_place** out) {
 
 void pmx_place_free(pmx_ctx* ctx, pmx_place* pl) {
     if (ctx) (void)hipSetDevice(ctx->device);
+    if (pl && pl->level_graph_exec) (void)hipGraphExecDestroy(pl->level_graph_exec);
     delete pl;
 }
 
@@ -617,11 +620,30 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     if (n_ch > 0)
         hipLaunchKernelGGL(k_score_terms, dim3(grid_for(n_ch, 256, G)), dim3(256), 0, st, pl->ch_hash.p, pl->ch_par.p, pl->ch_child.p, n_ch,
                            pl->tkeys.p, pl->tvals.p, pl->tcap - 1, n_kept > 0 ? 1 : 0, t_mag, t_raw, t_cos, t_wc, t_lc, pl->term_meta.p);
-    for (int lv = 0; lv < n_levels; ++lv) {
-        const int64_t beg = pl->level_off[lv], cnt = pl->level_off[lv + 1] - beg;
-        if (cnt <= 0) continue;
-        hipLaunchKernelGGL(k_score_level, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, pl->level_nodes.p + beg, cnt, pl->parent.p, pl->offsets.p,
-                           t_mag, t_raw, t_cos, t_wc, t_lc, pl->term_meta.p, pl->metrics5.p, pl->counts2.p);
+    // The level launches are a fixed, launch-bound chain (122 dependent launches for the SARS tree, none of
+    // whose arguments change between calls): captured once into a HIP graph and replayed.
+    auto launch_levels = [&]() {
+        for (int lv = 0; lv < n_levels; ++lv) {
+            const int64_t beg = pl->level_off[lv], cnt = pl->level_off[lv + 1] - beg;
+            if (cnt <= 0) continue;
+            hipLaunchKernelGGL(k_score_level, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, pl->level_nodes.p + beg, cnt, pl->parent.p,
+                               pl->offsets.p, t_mag, t_raw, t_cos, t_wc, t_lc, pl->term_meta.p, pl->metrics5.p, pl->counts2.p);
+        }
+    };
+    const void* sig[3] = {(const void*)t_mag, (const void*)pl->metrics5.p, (const void*)pl->term_meta.p};
+    if (getenv("PMX_PLACE_NO_GRAPH")) launch_levels();
+    else {
+        if (!pl->level_graph_exec || pl->level_graph_sig[0] != sig[0] || pl->level_graph_sig[1] != sig[1] || pl->level_graph_sig[2] != sig[2]) {
+            if (pl->level_graph_exec) { (void)hipGraphExecDestroy(pl->level_graph_exec); pl->level_graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            PMX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            launch_levels();
+            PMX_HIP(hipStreamEndCapture(st, &graph));
+            PMX_HIP(hipGraphInstantiate(&pl->level_graph_exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            for (int q = 0; q < 3; ++q) pl->level_graph_sig[q] = sig[q];
+        }
+        PMX_HIP(hipGraphLaunch(pl->level_graph_exec, st));
     }
     timer_end(ctx, "score", 1);
     hipLaunchKernelGGL(k_score_getters, dim3(grid_for(pl->n_nodes, 256, G)), dim3(256), 0, st, pl->metrics5.p, pl->counts2.p, pl->n_nodes, log_mag,
