@@ -338,7 +338,9 @@ inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o, int sma
     if (small_qlen > 0) {
         c.max_qlen = small_qlen;
         c.max_tlen = small_tlen + 16;
-        L.tb_cap = 0;
+        const int wband = (int)(std::max(o.bw, o.bw_long) * 1.5 + 1.);
+        const int n_col = ((std::min(std::min(small_tlen, small_qlen), wband + 1) + 15) / 16 + 1) * 16;
+        L.tb_cap = (size_t)(small_qlen + small_tlen) * n_col;   // HBM traceback area for the requests that do not fit LDS
     }
     size_t top = 0;
     auto put = [&](Layout::Ent& e, size_t bytes) {

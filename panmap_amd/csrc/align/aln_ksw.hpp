@@ -338,17 +338,24 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
 // (same 16-cell rounding of [st,en], same stale s[] cells, same candidate order of the exact max).
 // Requires ((tlen + 15) / 16) * 16 <= 64 * NC.
 __device__ __forceinline__ int rl_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// lane L receives lane L-1's value (lane 0: 0): DPP wave_shr:1, one VALU op, no LDS crossbar round trip
+__device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_max_i32x(int v) {
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(v, o); v = other > v ? other : v; }
+    return v;
+}
 
 template <int NC>
 __device__ __forceinline__ int rd_col(const int (&a)[NC], int idx) {   // a[] indexed by target column, uniform idx
     if (NC == 1) return rl_i32(a[0], idx);
-    return idx < 64 ? rl_i32(a[0], idx) : rl_i32(a[NC - 1], idx - 64);
+    if (NC == 2) return idx < 64 ? rl_i32(a[0], idx) : rl_i32(a[NC - 1], idx - 64);
+    return idx < 64 ? rl_i32(a[0], idx) : idx < 128 ? rl_i32(a[NC > 1 ? 1 : 0], idx - 64) : rl_i32(a[NC - 1], idx - 128);
 }
 
-template <int NC>
+template <int NC, bool TB_IN_LDS>
 __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
                               int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
-    static_assert(NC == 1 || NC == 2, "one or two target columns per lane");
+    static_assert(NC >= 1 && NC <= 3, "one to three target columns per lane");
     PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
     const int lane = lane_id();
     const int approx_max = !!(flag & PMX_EZ_APPROX_MAX);
@@ -379,6 +386,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
     int32_t *off = W.off, *off_end = W.off_end;
     PMX_LDS(off); PMX_LDS(off_end);
     uint8_t* p = W.tb;
+    if (TB_IN_LDS) PMX_LDS(p);   // ds_write_b8 instead of a flat store
 
     // per-column state (int8 values of the reference kept sign-extended in 32-bit registers)
     int u[NC], v[NC], x[NC], y[NC], x2[NC], y2[NC], s[NC], H[NC], sf[NC];
@@ -405,6 +413,13 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
         const int st0 = st, en0 = en;
         st = st / 16 * 16;
         en = (en + 16) / 16 * 16 - 1;
+        // this diagonal's query bases, issued first so the LDS latency hides behind the boundary work
+        int sq2v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int t = c * 64 + lane;
+            sq2v[c] = (t <= r && r - t < qlen) ? (int)query[r - t] : 0;
+        }
         // boundary conditions (ksw2_extd2_sse.c:150-166)
         const int8_t gap_head = r == 0 ? init_ue : r < long_thres ? (int8_t)-e : r == long_thres ? (int8_t)long_diff : (int8_t)-e2;
         int8_t x1, x21, v1;
@@ -425,7 +440,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
             const int t = c * 64 + lane;
             if (t >= st0 && t < s_end) {
                 const int sq = sf[c];
-                const int sq2 = t <= r ? (int)query[r - t] : 0;   // qr[] padding is 0 beyond the query
+                const int sq2 = t <= r ? sq2v[c] : 0;   // qr[] padding is 0 beyond the query
                 int8_t val = sq == sq2 ? sc_mch : sc_mis;
                 if (sq == 4 || sq2 == 4) val = sc_N;
                 s[c] = val;
@@ -435,17 +450,19 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
         int xs[NC], vs[NC], x2s[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            xs[c] = __shfl_up(x[c], 1);
-            vs[c] = __shfl_up(v[c], 1);
-            x2s[c] = __shfl_up(x2[c], 1);
+            xs[c] = wave_shr1(x[c]);
+            vs[c] = wave_shr1(v[c]);
+            x2s[c] = wave_shr1(x2[c]);
         }
-        if (NC == 2) {
-            const int bx = rl_i32(x[0], 63), bv = rl_i32(v[0], 63), bx2 = rl_i32(x2[0], 63);
-            if (lane == 0) { xs[NC - 1] = bx; vs[NC - 1] = bv; x2s[NC - 1] = bx2; }
+#pragma unroll
+        for (int c = 1; c < NC; ++c) {   // column c's lane 0 continues after column c-1's lane 63
+            const int bx = rl_i32(x[c - 1], 63), bv = rl_i32(v[c - 1], 63), bx2 = rl_i32(x2[c - 1], 63);
+            if (lane == 0) { xs[c] = bx; vs[c] = bv; x2s[c] = bx2; }
         }
-        // core recurrence on [st, en]
+        // core recurrence on [st, en] (columns entirely outside the range are skipped with a uniform branch)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            if (NC > 1 && (c * 64 + 63 < st || c * 64 > en)) continue;
             const int t = c * 64 + lane;
             if (t >= st && t <= en) {
                 int8_t z = (int8_t)s[c];
@@ -515,29 +532,38 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
             if (r > 0) {
                 const int32_t h_en0 = en0 > 0 ? rd_col<NC>(H, en0 - 1) + (int8_t)rd_col<NC>(u, en0) : rd_col<NC>(H, en0) + (int8_t)rd_col<NC>(v, en0);
                 const int en1 = st0 + (en0 - st0) / 4 * 4;
-                int64_t best = (int64_t)((uint64_t)(uint32_t)h_en0 << 32 | 0x7fffffffu);
+                // H[] update, then the maximum with the SSE loop's candidate order: en0 first, then the four
+                // t-classes (t - st0) mod 4 of the vector part [st0, en1) in class order, each by ascending t,
+                // then the scalar tail [en1, en0) by ascending t.  Value by a 32-bit wave max, position from
+                // ballots of the lanes that hold it.
+                int hv[NC], lmax = INT32_MIN;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     const int t = c * 64 + lane;
+                    hv[c] = INT32_MIN;
                     if (t >= st0 && t < en0) {
                         const int32_t h = H[c] + (int32_t)(int8_t)v[c];
                         H[c] = h;
-                        uint32_t prio;
-                        if (t < en1) prio = 0x7ffffffeu - ((uint32_t)((t - st0) & 3) << 24) - (uint32_t)((t - st0) >> 2);
-                        else prio = 0x7ffffffeu - (5u << 24) - (uint32_t)(t - st0);
-                        const int64_t key = (int64_t)((uint64_t)(uint32_t)h << 32 | prio);
-                        best = key > best ? key : best;
+                        hv[c] = h;
+                        lmax = h > lmax ? h : lmax;
                     }
                     if (t == en0) H[c] = h_en0;
                 }
-                best = wave_max_i64(best);
-                max_H = (int32_t)(best >> 32);
-                const uint32_t prio = (uint32_t)best;
-                if (prio == 0x7fffffffu) max_t = en0;
+                const int wmax = wave_max_i32x(lmax);
+                if (h_en0 >= wmax) { max_H = h_en0; max_t = en0; }
                 else {
-                    const uint32_t dd = 0x7ffffffeu - prio;
-                    const uint32_t cls = dd >> 24, idx = dd & 0xffffffu;
-                    max_t = cls >= 5 ? st0 + (int)idx : st0 + (int)(idx * 4 + cls);
+                    max_H = wmax;
+                    max_t = -1;
+#pragma unroll
+                    for (int cls = 0; cls < 5; ++cls) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const int t = c * 64 + lane;
+                            const bool in_cls = cls < 4 ? (t < en1 && ((t - st0) & 3) == cls) : t >= en1;
+                            const unsigned long long m = __ballot(hv[c] == wmax && t >= st0 && t < en0 && in_cls);
+                            if (max_t < 0 && m) max_t = c * 64 + (int)__builtin_ctzll(m);
+                        }
+                    }
                 }
             } else {
                 if (lane == 0) H[0] = (int8_t)v[0] - qe;
@@ -582,7 +608,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
 }
 #elif defined(__HIPCC__)
 // (device-only; declared so the host pass of the kernels parses)
-template <int NC>
+template <int NC, bool TB_IN_LDS>
 __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e, int8_t q2,
                    int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez);
 #endif

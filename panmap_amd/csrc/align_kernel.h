@@ -28,7 +28,8 @@ struct AlignArgs {
     int dp_round;
     int tpp_ring_w;             // k_align_reads_tpp: minimizer window length when the ring lives in LDS, else 0
     int dp_class;               // k_align_dp_serve: 0 = every request, 1 = only small ones, 2 = only the others
-    int dp_small_qlen, dp_small_tlen;   // small class: qlen <= , tlen <= (multiple of 16), traceback <= layout.tb_fast_cap
+    int dp_small_qlen, dp_small_tlen;   // register-DP class: qlen <=, tlen <=, traceback bytes <= dp_small_tb
+    uint32_t dp_small_tb;
 
 
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)

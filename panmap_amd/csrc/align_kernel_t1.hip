@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(64, 4) k_align_dp_serve(AlignArgs A) {
         const int t_off = (qlen + 15) & ~15;
         const size_t tb_need = dp_request_tb_bytes(qlen, tlen, rq->w);
         if (A.dp_class != 0) {
-            const bool small = qlen <= A.dp_small_qlen && tlen <= A.dp_small_tlen && tb_need <= (size_t)8192;
+            const bool small = qlen <= A.dp_small_qlen && tlen <= A.dp_small_tlen && tb_need <= (size_t)A.dp_small_tb;
             if (small != (A.dp_class == 1)) continue;   // the other launch serves it
         }
         if (tb_need <= A.layout.tb_fast_cap) {   // traceback matrix in LDS when it fits
@@ -46,12 +46,16 @@ __global__ void __launch_bounds__(64, 4) k_align_dp_serve(AlignArgs A) {
         __syncthreads();
         const unsigned long long tp1 = A.prof ? (unsigned long long)clock64() : 0ULL;
         Ez ez;
-        if (A.dp_class == 1 && tlen <= 64)
-            ksw_extd2_reg<1>(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, rq->w,
-                             rq->zdrop, rq->end_bonus, rq->flag, ez);
-        else if (A.dp_class == 1)
-            ksw_extd2_reg<2>(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, rq->w,
-                             rq->zdrop, rq->end_bonus, rq->flag, ez);
+#define PMX_REG_DP(NC, TBL)                                                                                                            \
+    ksw_extd2_reg<NC, TBL>(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, \
+                           rq->w, rq->zdrop, rq->end_bonus, rq->flag, ez)
+        if (A.dp_class == 1) {
+            const bool tbl = tb_need <= A.layout.tb_fast_cap;
+            if (tlen <= 64) { if (tbl) PMX_REG_DP(1, true); else PMX_REG_DP(1, false); }
+            else if (tlen <= 128) { if (tbl) PMX_REG_DP(2, true); else PMX_REG_DP(2, false); }
+            else { if (tbl) PMX_REG_DP(3, true); else PMX_REG_DP(3, false); }
+        }
+#undef PMX_REG_DP
         else
             ksw_extd2(W, qlen, sq, tlen, sq + t_off, A.opt.mat, (int8_t)A.opt.q, (int8_t)A.opt.e, (int8_t)A.opt.q2, (int8_t)A.opt.e2, rq->w,
                       rq->zdrop, rq->end_bonus, rq->flag, ez);

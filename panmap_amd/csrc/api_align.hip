@@ -196,7 +196,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     };
     A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
     A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
-    A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.tpp_ring_w = 0;
+    A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.dp_small_tb = 0; A.tpp_ring_w = 0;
     timer_begin(ctx, "align");
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
@@ -225,10 +225,11 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             int64_t small_rounds = 16384;   // fewer pairs than this cannot fill the chip thread-per-pair: wave tier
             if (const char* e = getenv("PMX_ALIGN_TPP_MIN")) small_rounds = atoll(e);
             const int64_t dp_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dp_lds);
-            const int small_qlen = 128, small_tlen = 128;   // ksw_extd2_reg<2>: two target columns per lane
+            const int small_qlen = 192, small_tlen = 192;   // ksw_extd2_reg<3>: up to three target columns per lane
             const Layout dps_layout = plan_layout_dp((int)rs->max_len, n_segs, al->opt, small_qlen, small_tlen);
             const size_t dps_lds = PMX_ALIGN_WORK_BYTES + dps_layout.fast_bytes + 16;
             const int64_t dps_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dps_lds);
+            const size_t dps_stride = (dps_layout.slow_bytes + 255) & ~(size_t)255;
             const bool dp_two_class = !getenv("PMX_ALIGN_DP_ONE_CLASS");
             if (use_dp_service) {
                 al->dp_req.ensure((size_t)n_items * sizeof(DpReq));
@@ -238,6 +239,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 al->dp_list_a.ensure((size_t)n_items);
                 al->dp_list_b.ensure((size_t)n_items);
                 al->slow.ensure(dp_stride * (size_t)dp_max_grid);
+                al->slow2.ensure(dps_stride * (size_t)dps_max_grid);
                 PMX_HIP(hipMemsetAsync(al->dp_ncached.p, 0, sizeof(uint32_t) * (size_t)n_items, ctx->stream));
                 A.dp_req_base = al->dp_req.p; A.dp_res_base = al->dp_res.p; A.dp_ncached = al->dp_ncached.p;
                 A.dp_slot_pairs = al->dp_slot_pairs.p;
@@ -285,10 +287,13 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 A.worklist = cur;
                 A.dp_small_qlen = small_qlen;
                 A.dp_small_tlen = small_tlen;
+                A.dp_small_tb = (uint32_t)dps_layout.tb_cap;
                 A.dp_class = dp_two_class ? 2 : 0;
                 hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dp_max_grid, n_dp)), dim3(64), dp_lds, ctx->stream, A);
                 if (dp_two_class) {
                     A.layout = dps_layout;
+                    A.slow_stride = dps_stride;
+                    A.slow_base = al->slow2.p;
                     A.dp_class = 1;
                     hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dps_max_grid, n_dp)), dim3(64), dps_lds, ctx->stream, A);
                 }
