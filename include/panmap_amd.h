@@ -195,6 +195,14 @@ void pmx_align_reads_direct(const char *reference, const char *refName, int n_re
                             const char **quality, const char **read_names, const int *r_lens,
                             align_pair_result_t *results, bool pairedEndReads, int n_threads);
 
+/* ---- BAM egress (host): what alignAndWriteBam does with the results of align_reads_direct
+ * (src/conversion.cpp:288-538: build_bam_from_result, compute_sam_flags, compute_tlen, sort by pos, BAM + .bai).
+ * reads / quality / read_names / r_lens are the arrays that were handed to the aligner (R2 already reverse-
+ * complemented and its qualities reversed).  Writes `bam_path` and `bam_path`.bai.  Returns PMX_OK or PMX_ERR_IO. */
+int pmx_write_bam(const char *bam_path, const char *ref_name, int64_t ref_len, int n_reads, const char **reads,
+                  const char **quality, const char **read_names, const int *r_lens,
+                  const align_pair_result_t *results, bool pairedEndReads);
+
 /* Device-resident form used by the pipeline / benchmark: fixed 32-byte records + CIGAR arena. */
 typedef struct {
     int32_t rs, re, qs, qe;

@@ -4,7 +4,7 @@ All compute is in libpanmap_amd.so (hand-written HIP for gfx950 behind the C ABI
 include/panmap_amd.h); this package is the thin host-side mirror of the reference's interfaces.
 """
 from ._lib import LIB_PATH, PmxError, lib  # noqa: F401  (import fails loudly if the .so is missing)
-from .api import (METRICS, Aligner, align_reads_direct, records_to_results, REC_DTYPE, Context, Index, Panman, PlacementResult, Placer, ReadSet, TraversalParams,  # noqa: F401
+from .api import (METRICS, Aligner, align_reads_direct, write_bam, records_to_results, REC_DTYPE, Context, Index, Panman, PlacementResult, Placer, ReadSet, TraversalParams,  # noqa: F401
                   concat_reads, extract_read_sequences, format_placement_tsv, place_lite, read_fastq_paired,
                   read_fastx, reverse_complement)
 from .synth import simulate_paired_reads, simulate_long_reads  # noqa: F401

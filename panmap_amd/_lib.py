@@ -112,6 +112,8 @@ SIGNATURES = {
     "pmx_place_tied": (_i32, [_vp, _i32, _vp, _i64]),
     "pmx_place_node_outputs": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "pmx_place_kept_seeds": (_i64, [_vp, _vp, _vp, _vp, _i64]),
+    "pmx_write_bam": (_i32, [_cp, _cp, _i64, _i32, C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_cp), C.POINTER(C.c_int),
+                             C.POINTER(AlignPairResult), C.c_bool]),
     "pmx_align_reads_direct": (None, [_cp, _cp, _i32, C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_cp),
                                       C.POINTER(C.c_int), C.POINTER(AlignPairResult), C.c_bool, _i32]),
     "pmx_aligner_create": (_i32, [_vp, _cp, _i64, _i32, _PP]),

@@ -549,3 +549,32 @@ def align_reads_direct(reference: bytes, reads, paired: bool, n_threads: int = 1
             libc.free(C.cast(ra.cigar, C.c_void_p))
         return dict(pos=ra.pos, rs=ra.rs, re=ra.re, qs=ra.qs, qe=ra.qe, mapq=ra.mapq, rev=ra.rev, proper_frag=ra.proper_frag, cigar=cg)
     return [dict(mapped=res[i].mapped, r1=unpack(res[i].r1), r2=unpack(res[i].r2) if paired else None) for i in range(n_res)]
+
+
+def write_bam(bam_path: str, ref_name: str, ref_len: int, seqs, quals, names, results, paired: bool):
+    """BAM + .bai egress of alignment results (alignAndWriteBam, src/conversion.cpp:426-538).  seqs / quals / names are
+    what the aligner was given (R2 reverse-complemented, its qualities reversed); results as returned by
+    align_reads_direct / Aligner.align_reads."""
+    n = len(seqs)
+    arr = (C.c_char_p * n)(*seqs)
+    qarr = (C.c_char_p * n)(*quals)
+    narr = (C.c_char_p * n)(*names)
+    lens = (C.c_int * n)(*[len(r) for r in seqs])
+    n_res = n // 2 if paired else n
+    res = (_lib.AlignPairResult * max(n_res, 1))()
+    keep = []
+
+    def fill(dst, d):
+        if d is None:
+            return
+        for f in ("pos", "rs", "re", "qs", "qe", "mapq", "rev", "proper_frag"):
+            setattr(dst, f, int(d[f]))
+        cg = (C.c_uint32 * max(len(d["cigar"]), 1))(*[int(x) for x in d["cigar"]])
+        keep.append(cg)
+        dst.n_cigar = len(d["cigar"])
+        dst.cigar = C.cast(cg, C.POINTER(C.c_uint32))
+    for i in range(n_res):
+        res[i].mapped = int(results[i]["mapped"])
+        fill(res[i].r1, results[i]["r1"])
+        fill(res[i].r2, results[i].get("r2"))
+    check(lib.pmx_write_bam(bam_path.encode(), ref_name.encode(), ref_len, n, arr, qarr, narr, lens, res, paired), "pmx_write_bam")

@@ -3,6 +3,7 @@
 #include <string>
 
 #include "api_internal.hpp"
+#include "host/bam_writer.hpp"
 #include "host/index_build.hpp"
 #include "host/panman.hpp"
 
@@ -133,3 +134,24 @@ const int16_t* pmx_index_child_counts(const pmx_index* idx) { return idx ? idx->
 }  // extern "C"
 
 const pmx::LiteIndex* pmx_index_internal(const pmx_index* idx) { return idx ? &idx->ix : nullptr; }
+
+extern "C" int pmx_write_bam(const char* bam_path, const char* ref_name, int64_t ref_len, int n_reads, const char** reads, const char** quality,
+                             const char** read_names, const int* r_lens, const align_pair_result_t* results, bool pairedEndReads) {
+    if (!bam_path || !ref_name || n_reads < 0 || (n_reads > 0 && (!reads || !quality || !read_names || !r_lens || !results))) return PMX_ERR_ARG;
+    try {
+        std::vector<std::string> seqs((size_t)n_reads), quals((size_t)n_reads), names((size_t)n_reads);
+        for (int i = 0; i < n_reads; ++i) {
+            seqs[(size_t)i].assign(reads[i], (size_t)r_lens[i]);
+            quals[(size_t)i] = quality[i] ? std::string(quality[i]) : std::string();
+            if ((int)quals[(size_t)i].size() < r_lens[i]) quals[(size_t)i].resize((size_t)r_lens[i], 'I');   // missing qualities -> 'I' (src/seeding.cpp:231-269)
+            names[(size_t)i] = read_names[i] ? read_names[i] : "";
+        }
+        const int64_t n_results = pairedEndReads ? n_reads / 2 : n_reads;
+        const int rc = pmx::write_bam(bam_path, ref_name, ref_len, seqs, quals, names, results, n_results, pairedEndReads, true);
+        if (rc != 0) { pmx::set_error("failed to write BAM / BAI"); return PMX_ERR_IO; }
+        return PMX_OK;
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return PMX_ERR_IO;
+    }
+}
