@@ -602,7 +602,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     if (n_kept > 0)
         hipLaunchKernelGGL(k_kept_table_build, dim3(grid_for(n_kept, 256, G)), dim3(256), 0, st, pl->kept_hash.p, pl->kept_log.p, n_kept, pl->tkeys.p,
                            pl->tvals.p, pl->tcap - 1);
-    hipLaunchKernelGGL(k_wc_denominator, dim3(1), dim3(64), 0, st, pl->ch_hash.p, pl->ch_child.p, pl->root_beg, pl->root_end, pl->tkeys.p, pl->tvals.p,
+    hipLaunchKernelGGL(k_wc_denominator, dim3(1), dim3(1024), 0, st, pl->ch_hash.p, pl->ch_child.p, pl->root_beg, pl->root_end, pl->tkeys.p, pl->tvals.p,
                        pl->tcap - 1, n_kept > 0 ? 1 : 0, pl->scalars.p + 2);
     double h_scal[3];
     PMX_HIP(hipMemcpyAsync(h_scal, pl->scalars.p, sizeof(h_scal), hipMemcpyDeviceToHost, st));
