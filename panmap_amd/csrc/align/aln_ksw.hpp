@@ -523,7 +523,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
                     y2[c] = (int8_t)((0 > b2 ? 0 : b2) - (q2 + e2));
                     d |= 0 > b2 ? 0 : 0x40;
                 }
-                p[(size_t)r * n_col + (t - st)] = d;
+                p[(uint32_t)(r * n_col + (t - st))] = d;
             }
         }
         if (lane == 0) { off[r] = st; off_end[r] = en; }
@@ -552,18 +552,23 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
                 const int wmax = wave_max_i32x(lmax);
                 if (h_en0 >= wmax) { max_H = h_en0; max_t = en0; }
                 else {
-                    max_H = wmax;
-                    max_t = -1;
+                    // position: every lane that holds the maximum offers its candidate priority (larger = earlier
+                    // in the SSE loop's order); one more wave max picks the winner
+                    uint32_t lp = 0;
 #pragma unroll
-                    for (int cls = 0; cls < 5; ++cls) {
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            const int t = c * 64 + lane;
-                            const bool in_cls = cls < 4 ? (t < en1 && ((t - st0) & 3) == cls) : t >= en1;
-                            const unsigned long long m = __ballot(hv[c] == wmax && t >= st0 && t < en0 && in_cls);
-                            if (max_t < 0 && m) max_t = c * 64 + (int)__builtin_ctzll(m);
+                    for (int c = 0; c < NC; ++c) {
+                        const int t = c * 64 + lane;
+                        if (hv[c] == wmax && t >= st0 && t < en0) {
+                            const uint32_t pr = t < en1 ? 0x7ffffffeu - ((uint32_t)((t - st0) & 3) << 24) - (uint32_t)((t - st0) >> 2)
+                                                        : 0x7ffffffeu - (5u << 24) - (uint32_t)(t - st0);
+                            lp = pr > lp ? pr : lp;
                         }
                     }
+                    const uint32_t wp = (uint32_t)wave_max_i32x((int)lp);
+                    const uint32_t dd = 0x7ffffffeu - wp;
+                    const uint32_t cls = dd >> 24, idx = dd & 0xffffffu;
+                    max_H = wmax;
+                    max_t = cls >= 5 ? st0 + (int)idx : st0 + (int)(idx * 4 + cls);
                 }
             } else {
                 if (lane == 0) H[0] = (int8_t)v[0] - qe;

@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(64, 4) k_align_reads_t1_w4(AlignArgs A) { alig
 // requests) runs the register-resident ksw_extd2_reg; the rest run the anti-diagonal-parallel ksw_extd2 with
 // its arrays in LDS (traceback matrix in LDS when it fits, else in the wave's HBM slab).  The result is
 // appended to the slot's result list.
-__global__ void __launch_bounds__(64, 4) k_align_dp_serve(AlignArgs A) {
+__global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     Work& W = *reinterpret_cast<Work*>(lds);
     PMX_LDS(&W);
