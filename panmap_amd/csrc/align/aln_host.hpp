@@ -78,6 +78,7 @@ struct HostRefIndex {
     std::vector<uint64_t> pos;
     std::vector<float> logf_ratio, logf_int;
     std::vector<uint32_t> occ;   // occurrences per distinct minimizer
+    int logf_a = 0;              // match score the logf tables were built for
     RefIndex view() const {
         RefIndex r;
         r.seq = seq.data();
@@ -107,6 +108,11 @@ inline uint8_t nt4_of_char(unsigned char c) {   // seq_nt4_table (sketch.c:9-26)
 // mm_idx_str(w, k, 0, 14, 1, &ref) (index.c:408-451): sketch the reference, group occurrences by minimizer
 #ifndef PMX_INTERLEAVED   // host-only (raw pointers); the thread-per-pair device pass skips it
 inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp_score, HostRefIndex& out) {
+    // the logf tables only depend on (a, size): keep them across references
+    std::vector<float> keep_ratio, keep_int;
+    const int keep_a = out.logf_a;
+    keep_ratio.swap(out.logf_ratio);
+    keep_int.swap(out.logf_int);
     out = HostRefIndex();
     out.seq.assign((size_t)ref_len + 8, 0);   // padded: readers fetch aligned 32-bit words
     for (int64_t i = 0; i < ref_len; ++i) out.seq[i] = nt4_of_char((unsigned char)ref[i]);
@@ -120,7 +126,8 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
     W.n_mv = 0;
     if (ref_len > 0) sketch_segment(W, out.seq.data(), (int)ref_len, o.w, o.k, 0);
     mv.resize(W.n_mv);
-    std::stable_sort(mv.begin(), mv.end(), [](const A128& a, const A128& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    // by minimizer value (span byte excluded), then by position: the occurrence list of a key is ascending in y
+    std::sort(mv.begin(), mv.end(), [](const A128& a, const A128& b) { return (a.x >> 8) != (b.x >> 8) ? (a.x >> 8) < (b.x >> 8) : a.y < b.y; });
     size_t n_keys = 0;
     for (size_t i = 0; i < mv.size(); ++i)
         if (i == 0 || mv[i].x >> 8 != mv[i - 1].x >> 8) ++n_keys;
@@ -133,10 +140,7 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
     for (size_t i = 0; i < mv.size();) {
         size_t j = i;
         while (j < mv.size() && mv[j].x >> 8 == mv[i].x >> 8) ++j;
-        std::vector<uint64_t> ys;
-        for (size_t q = i; q < j; ++q) ys.push_back(mv[q].y);
-        std::sort(ys.begin(), ys.end());
-        for (size_t q = i; q < j; ++q) out.pos[q] = ys[q - i];
+        for (size_t q = i; q < j; ++q) out.pos[q] = mv[q].y;
         const uint64_t key = mv[i].x >> 8;
         uint32_t slot = (uint32_t)mix64(key) & (uint32_t)(cap - 1);
         while (out.ht_key[slot] != UINT64_MAX) slot = (slot + 1) & (uint32_t)(cap - 1);
@@ -168,12 +172,18 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
     gen_simple_mat(o.mat, (int8_t)o.a, (int8_t)o.b, (int8_t)o.sc_ambi);
     // logf tables from the host libm (hit.c:440-457, pe.c:160)
     const int n = max_dp_score + 2;
-    out.logf_ratio.resize(n);
-    out.logf_int.resize(n);
-    for (int i = 0; i < n; ++i) {
-        out.logf_ratio[i] = logf((float)i / o.a);
-        out.logf_int[i] = logf((float)i);
+    if (keep_a == o.a && (int)keep_ratio.size() == n) {
+        out.logf_ratio.swap(keep_ratio);
+        out.logf_int.swap(keep_int);
+    } else {
+        out.logf_ratio.resize(n);
+        out.logf_int.resize(n);
+        for (int i = 0; i < n; ++i) {
+            out.logf_ratio[i] = logf((float)i / o.a);
+            out.logf_int[i] = logf((float)i);
+        }
     }
+    out.logf_a = o.a;
 }
 
 #endif
