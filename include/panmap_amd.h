@@ -104,6 +104,9 @@ int pmx_readset_upload(pmx_ctx *ctx, const char *concat, const int64_t *offsets,
 int pmx_readset_wrap_device(pmx_ctx *ctx, const void *d_concat, const void *d_offsets, int64_t n_reads,
                             int64_t total_bytes, int64_t max_read_len, pmx_readset **out);
 int pmx_readset_pack(pmx_ctx *ctx, pmx_readset *rs);
+/* FASTQ quality strings of the same reads (same offsets; one Phred+33 byte per base): only needed for
+ * pmx_place_params.min_seed_quality > 0 (allReadQualities, src/placement.cpp:1386) */
+int pmx_readset_set_qualities(pmx_ctx *ctx, pmx_readset *rs, const char *qual_concat);
 void pmx_readset_free(pmx_ctx *ctx, pmx_readset *rs);
 int64_t pmx_readset_num_reads(const pmx_readset *rs);
 
@@ -119,7 +122,9 @@ typedef struct {
     int32_t trim_start, trim_end;
     int32_t dedup_reads;       /* --dedup: each distinct sequence counted once */
     int32_t force_leaf;
-    int32_t reserved[3];
+    int32_t min_seed_quality;  /* --min-seed-quality: > 0 with qualities attached selects the quality-filtered
+                                  seeding branch (src/placement.cpp:1386-1527; it ignores dedup_reads) */
+    int32_t reserved[2];
 } pmx_place_params;
 
 typedef struct {

@@ -44,6 +44,7 @@ def olib():
         L.orc_hist_free.argtypes = [vp]
         L.orc_hist_add.argtypes = [vp, C.c_uint64, i64]
         L.orc_hist_add_read.argtypes = [vp, C.c_char_p, i64, i32, i32, i32, i32, i32, i32, i32, i64]
+        L.orc_hist_add_read_q.argtypes = [vp, C.c_char_p, C.c_char_p, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32]
         L.orc_hist_size.restype = i64
         L.orc_hist_size.argtypes = [vp]
         L.orc_hist_export_sorted.argtypes = [vp, vp, vp]
@@ -86,12 +87,18 @@ def read_seeds(seq: bytes, k, s, l, open_syncmer=False, t=0, trim_start=0, trim_
     return out[:n].copy()
 
 
-def histogram(reads, k, s, l, open_syncmer=False, t=0, trim_start=0, trim_end=0, dedup=False):
+def histogram(reads, k, s, l, open_syncmer=False, t=0, trim_start=0, trim_end=0, dedup=False, quals=None, min_q=0):
     """(hash asc, count) of all read seeds.  dedup: each distinct sequence counted once
-    (src/placement.cpp:1619-1620); otherwise counts are additive per read."""
+    (src/placement.cpp:1619-1620); otherwise counts are additive per read.  quals + min_q > 0: the
+    quality-filtered branch (src/placement.cpp:1386-1527; no dedup there)."""
     L = olib()
     h = C.c_void_p(L.orc_hist_new())
-    it = set(reads) if dedup else reads
+    if quals is not None and min_q > 0:
+        for r, q in zip(reads, quals):
+            L.orc_hist_add_read_q(h, r, q, len(r), len(q), k, s, l, int(open_syncmer), t, trim_start, trim_end, min_q)
+        it = []
+    else:
+        it = set(reads) if dedup else reads
     for r in it:
         L.orc_hist_add_read(h, r, len(r), k, s, l, int(open_syncmer), t, trim_start, trim_end, 1)
     n = L.orc_hist_size(h)
@@ -134,9 +141,9 @@ def best_ties(parent, scores, force_leaf=False, cap=1 << 16):
 
 
 def place(reads, idx_arrays, k, s, l, open_syncmer=False, t=0, trim_start=0, trim_end=0, mask_fraction=0.0, min_support=-1,
-          force_leaf=False, dedup=False):
+          force_leaf=False, dedup=False, quals=None, min_q=0):
     """Whole place stage on the CPU oracle.  Returns dict with everything the GPU path reports."""
-    hs, cn = histogram(reads, k, s, l, open_syncmer, t, trim_start, trim_end, dedup)
+    hs, cn = histogram(reads, k, s, l, open_syncmer, t, trim_start, trim_end, dedup, quals, min_q)
     kh, kl, st = finalize_reads(hs, cn, k, mask_fraction, min_support)
     sc, met, cts, wc = score_nodes(idx_arrays["parent"], idx_arrays["offsets"], idx_arrays["hash"], idx_arrays["parent_count"],
                                    idx_arrays["child_count"], kh, kl, st)

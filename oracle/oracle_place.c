@@ -188,6 +188,57 @@ int64_t orc_read_seeds(const char *seq, int64_t len, int k, int s, int l, int op
     return n;
 }
 
+/*
+ * Quality-filtered seeds of one read (src/placement.cpp:1386-1527, the `minSeedQuality > 0` branch; no read
+ * dedup there).  avgPhredQuality (:79-88) = sum(qual - 33) / k over the k-mer, 0 when the quality string does not
+ * cover it; a syncmer passes when its start is inside the trim window AND avg >= min_q.  l == 1: passing
+ * syncmers are the seeds.  l > 1: windows run over the ORIGINAL syncmer list (trimmed / low-quality syncmers are
+ * not removed first, unlike the unfiltered path) and a window yields a seed only if all its l syncmers pass.
+ */
+int64_t orc_read_seeds_q(const char *seq, const char *qual, int64_t len, int64_t qual_len, int k, int s, int l,
+                         int open, int t, int trim_start, int trim_end, int min_q, uint64_t *out)
+{
+    if (len < k) return 0;
+    const int64_t nk = len - k + 1;
+    uint64_t *h = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nk);
+    int64_t *p = (int64_t *)malloc(sizeof(int64_t) * (size_t)nk);
+    uint8_t *pass = (uint8_t *)malloc((size_t)nk);
+    int64_t m = orc_rolling_syncmers(seq, len, k, s, open, t, 0, h, NULL, NULL, p);
+    int64_t n = 0;
+    const int valid_start = trim_start, valid_end = (int)len - trim_end - k;
+    if (l < 1) l = 1;
+    if (m >= l) {
+        for (int64_t j = 0; j < m; ++j) {
+            double avg = 0.0;
+            if (qual_len > 0 && p[j] >= 0 && p[j] + k <= qual_len) {
+                int64_t sum = 0;
+                for (int i = 0; i < k; ++i) sum += (int)qual[p[j] + i] - 33;
+                avg = (double)sum / k;
+            }
+            const int in_range = (int)p[j] >= valid_start && (int)p[j] <= valid_end;
+            pass[j] = in_range && avg >= (double)min_q;
+        }
+        if (l == 1) {
+            for (int64_t j = 0; j < m; ++j)
+                if (pass[j]) out[n++] = h[j];
+        } else {
+            for (int64_t j = 0; j + l <= m; ++j) {
+                int ok = 1;
+                for (int q = 0; q < l; ++q) ok &= pass[j + q];
+                if (!ok) continue;
+                uint64_t F = 0, R = 0;
+                for (int q = 0; q < l; ++q) {
+                    F = rotl64(F, (unsigned)k) ^ h[j + q];
+                    R = rotl64(R, (unsigned)k) ^ h[j + l - q - 1];
+                }
+                if (F != R) out[n++] = F < R ? F : R;
+            }
+        }
+    }
+    free(h); free(p); free(pass);
+    return n;
+}
+
 /* --------------------------------------------------------------- histogram */
 
 struct orc_hist {
@@ -260,6 +311,18 @@ void orc_hist_add_read(orc_hist *h, const char *seq, int64_t len, int k, int s, 
     }
     int64_t n = orc_read_seeds(seq, len, k, s, l, open, t, trim_start, trim_end, h->tmp);
     for (int64_t i = 0; i < n; ++i) orc_hist_add(h, h->tmp[i], multiplicity);
+}
+
+void orc_hist_add_read_q(orc_hist *h, const char *seq, const char *qual, int64_t len, int64_t qual_len, int k, int s, int l,
+                         int open, int t, int trim_start, int trim_end, int min_q)
+{
+    if (h->tmp_cap < len + 1) {
+        free(h->tmp);
+        h->tmp_cap = len * 2 + 64;
+        h->tmp = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)h->tmp_cap);
+    }
+    int64_t n = orc_read_seeds_q(seq, qual, len, qual_len, k, s, l, open, t, trim_start, trim_end, min_q, h->tmp);
+    for (int64_t i = 0; i < n; ++i) orc_hist_add(h, h->tmp[i], 1);
 }
 
 int64_t orc_hist_size(const orc_hist *h) { return (int64_t)h->n; }

@@ -45,6 +45,11 @@ typedef struct orc_hist orc_hist;
 orc_hist *orc_hist_new(void);
 void orc_hist_free(orc_hist *h);
 void orc_hist_add(orc_hist *h, uint64_t key, int64_t mult);
+/* quality-filtered variant (src/placement.cpp:1386-1527); multiplicity is always 1 there */
+int64_t orc_read_seeds_q(const char *seq, const char *qual, int64_t len, int64_t qual_len, int k, int s, int l,
+                         int open, int t, int trim_start, int trim_end, int min_q, uint64_t *out);
+void orc_hist_add_read_q(orc_hist *h, const char *seq, const char *qual, int64_t len, int64_t qual_len, int k, int s, int l,
+                         int open, int t, int trim_start, int trim_end, int min_q);
 void orc_hist_add_read(orc_hist *h, const char *seq, int64_t len, int k, int s, int l, int open, int t,
                        int trim_start, int trim_end, int64_t multiplicity);
 int64_t orc_hist_size(const orc_hist *h);

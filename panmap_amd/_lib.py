@@ -36,7 +36,7 @@ class IndexInfo(C.Structure):
 class PlaceParams(C.Structure):
     _fields_ = [("seed_mask_fraction", C.c_double), ("min_read_support", C.c_int32),
                 ("trim_start", C.c_int32), ("trim_end", C.c_int32), ("dedup_reads", C.c_int32),
-                ("force_leaf", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("force_leaf", C.c_int32), ("min_seed_quality", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class PlaceResult(C.Structure):
@@ -95,6 +95,7 @@ SIGNATURES = {
     "pmx_ctx_stream": (_vp, [_vp]),
     "pmx_readset_upload": (_i32, [_vp, _vp, _vp, _i64, _PP]),
     "pmx_readset_wrap_device": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _PP]),
+    "pmx_readset_set_qualities": (_i32, [_vp, _vp, _vp]),
     "pmx_readset_pack": (_i32, [_vp, _vp]),
     "pmx_readset_free": (None, [_vp, _vp]),
     "pmx_readset_num_reads": (_i64, [_vp]),

@@ -282,6 +282,14 @@ class ReadSet:
     def pack(self):
         check(lib.pmx_readset_pack(self.ctx._h, self._h), "pmx_readset_pack")
 
+    def set_qualities(self, quals):
+        """attach the FASTQ quality strings (list of bytes, same lengths as the reads) for --min-seed-quality"""
+        qc = b"".join(quals)
+        if len(qc) != self.total_bases:
+            raise ValueError("quality strings must have the lengths of the reads")
+        buf = (C.c_char * max(len(qc), 1)).from_buffer_copy(qc if qc else b"\0")
+        check(lib.pmx_readset_set_qualities(self.ctx._h, self._h, C.addressof(buf)), "pmx_readset_set_qualities")
+
     def close(self):
         if self._h:
             lib.pmx_readset_free(self.ctx._h, self._h)
@@ -308,9 +316,8 @@ class TraversalParams:
     forceLeaf: bool = False
 
     def to_c(self) -> _lib.PlaceParams:
-        if self.minSeedQuality > 0:
-            raise NotImplementedError("--min-seed-quality is not implemented on the device yet")
         p = _lib.PlaceParams()
+        p.min_seed_quality = int(self.minSeedQuality)
         p.seed_mask_fraction = self.seedMaskFraction
         p.min_read_support = self.minReadSupport
         p.trim_start, p.trim_end = self.trimStart, self.trimEnd

@@ -289,6 +289,18 @@ int pmx_readset_wrap_device(pmx_ctx* ctx, const void* d_concat, const void* d_of
     PMX_CATCH
 }
 
+int pmx_readset_set_qualities(pmx_ctx* ctx, pmx_readset* rs, const char* qual_concat) {
+    if (!ctx || !rs || (rs->total > 0 && !qual_concat)) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    rs->qual.ensure((size_t)rs->total + 32);
+    if (rs->total > 0) PMX_HIP(hipMemcpyAsync(rs->qual.p, qual_concat, (size_t)rs->total, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    rs->has_qual = true;
+    return PMX_OK;
+    PMX_CATCH
+}
+
 int pmx_readset_pack(pmx_ctx* ctx, pmx_readset* rs) {
     if (!ctx || !rs) return PMX_ERR_ARG;
     PMX_TRY
@@ -408,8 +420,9 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         // insert can never fail, yet the table is sized by what the reads actually contain (a few million
         // distinct seeds for a 1M-read sample) instead of by the one-key-per-base bound of the whole batch:
         // a 16x smaller table to clear, probe and compact.
+        const bool quality_mode = pp->min_seed_quality > 0 && rs->has_qual;   // src/placement.cpp:1386: no dedup in this branch
         const uint8_t* keep = nullptr;
-        if (pp->dedup_reads) {   // --dedup: every distinct read sequence of this read set counts once
+        if (pp->dedup_reads && !quality_mode) {   // --dedup: every distinct read sequence of this read set counts once
             const int64_t n = rs->n;
             const int G = ctx->n_cu * 8;
             pl->dd_h1.ensure((size_t)n); pl->dd_h2.ensure((size_t)n); pl->dd_h1s.ensure((size_t)n); pl->dd_key.ensure((size_t)n);
@@ -438,7 +451,8 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             const int64_t r1 = std::min<int64_t>(rs->n, r0 + chunk_reads);
             table_reserve(ctx, pl, (uint64_t)((r1 - r0) * rs->max_len));
             hipLaunchKernelGGL(k_seed_histogram, dim3(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), dim3(PMX_SEED_BLOCK), lds, ctx->stream,
-                               rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep);
+                               rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep,
+                               quality_mode ? rs->qual.p : nullptr, quality_mode ? pp->min_seed_quality : 0);
             PMX_HIP(hipGetLastError());
         }
         timer_end(ctx, "seed", 1);

@@ -127,7 +127,8 @@ __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long*
 __global__ void __launch_bounds__(PMX_SEED_BLOCK)
 k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
                  const int64_t* __restrict__ off, int64_t r_begin, int64_t n_reads, SeedParams sp, uint64_t* keys,
-                 unsigned long long* vals, uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep) {
+                 unsigned long long* vals, uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep,
+                 const uint8_t* __restrict__ qual, int min_q) {
     extern __shared__ uint64_t lds[];
     const int w = sp.k - sp.s + 1;
     const int l = sp.l < 1 ? 1 : sp.l;
@@ -163,6 +164,10 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
         int slot_w = 0;                        // (i - s + 1) mod w
         int s_first = first0, s_last = last0;  // (ks + t) mod w, (ks + k - s - t) mod w
         int slot_l = 0;                        // (n_sync - 1) mod l
+        // --min-seed-quality (src/placement.cpp:1386-1527): rolling sum of (qual - 33) over the k-mer, and the number
+        // of consecutive syncmers (of the read's FULL syncmer list) that passed the trim + quality test
+        const uint8_t* rq = qual ? qual + off[r] : nullptr;
+        int qsum = 0, pass_run = 0;
         const int ilen = (int)len;
         for (int i = 0; i < ilen; ++i) {
             if ((i & 31) == 0) { cw = rw[i >> 5]; ca = ra[i >> 5]; }
@@ -193,6 +198,10 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
                 ringR[(size_t)slot_w * PMX_SEED_BLOCK + tid] = rS;
                 slot_w = slot_w + 1 == w ? 0 : slot_w + 1;
             }
+            if (rq) {
+                qsum += (int)rq[i] - 33;
+                if (i >= sp.k) qsum -= (int)rq[i - sp.k] - 33;
+            }
             if (i < sp.k - 1) continue;
             const int64_t ks = i - sp.k + 1;
             const int cur_first = s_first, cur_last = s_last;   // this k-mer's slots; advance for the next one
@@ -216,8 +225,31 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
                 rs = ringR[(size_t)cur_last * PMX_SEED_BLOCK + tid] == rmin || ringR[(size_t)cur_first * PMX_SEED_BLOCK + tid] == rmin;
             }
             if (!(fs || rs)) continue;
-            if (ks < valid_start || ks > valid_end) continue;   // primer trim (src/placement.cpp:1629-1648)
             const uint64_t h = fK < rK ? fK : rK;
+            if (rq) {   // quality-filtered branch: windows over all syncmers, valid only if every member passes
+                const bool pass = ks >= valid_start && ks <= valid_end && qsum >= min_q * sp.k;   // avg >= min_q, exactly
+                ++n_sync;
+                if (sp.l <= 1) {
+                    if (pass) { table_insert(keys, vals, mask, h, 1ULL, counters); ++n_seeds; }
+                    continue;
+                }
+                ringS[(size_t)slot_l * PMX_SEED_BLOCK + tid] = h;
+                slot_l = slot_l + 1 == l ? 0 : slot_l + 1;   // now the slot of the OLDEST of the last l syncmers
+                pass_run = pass ? pass_run + 1 : 0;
+                if (n_sync >= l && pass_run >= l) {
+                    uint64_t Fq = 0, Rq = 0;
+                    int sl = slot_l;
+                    for (int q2 = 0; q2 < l; ++q2) {   // oldest -> newest
+                        const uint64_t hq = ringS[(size_t)sl * PMX_SEED_BLOCK + tid];
+                        Fq = rotl64(Fq, (unsigned)sp.k) ^ hq;
+                        Rq ^= rotl64(hq, (unsigned)(sp.k * q2));
+                        sl = sl + 1 == l ? 0 : sl + 1;
+                    }
+                    if (Fq != Rq) { table_insert(keys, vals, mask, Fq < Rq ? Fq : Rq, 1ULL, counters); ++n_seeds; }
+                }
+                continue;
+            }
+            if (ks < valid_start || ks > valid_end) continue;   // primer trim (src/placement.cpp:1629-1648)
             ++n_sync;
             if (sp.l <= 1) {
                 table_insert(keys, vals, mask, h, 1ULL, counters);

@@ -13,4 +13,6 @@ struct pmx_readset {
     pmx::DevBuf<int64_t> woff;     // n+1 word offsets into words/amb
     pmx::DevBuf<uint64_t> words;   // 2 bits per base
     pmx::DevBuf<uint32_t> amb;     // 1 bit per base: not A/C/G/T
+    pmx::DevBuf<uint8_t> qual;     // optional: Phred+33 per base, same offsets as ascii (--min-seed-quality)
+    bool has_qual = false;
 };

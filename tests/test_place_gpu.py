@@ -13,16 +13,18 @@ def _as_reads(concat, off):
     return [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
 
 
-def _check_place(pmx, oracle, ctx, index, reads, params=None, k=19, s=8, l=3, open_syncmer=False, t=0):
+def _check_place(pmx, oracle, ctx, index, reads, params=None, k=19, s=8, l=3, open_syncmer=False, t=0, quals=None):
     params = params or pmx.TraversalParams()
     placer = pmx.Placer(ctx, index)
     placer.reset()
     if reads:
         rs = pmx.ReadSet(ctx, reads)
+        if quals is not None:
+            rs.set_qualities(quals)
         placer.add_reads(rs, params)
     res = placer.score(params, len(reads))
     want = oracle.place(reads, index.arrays(), k, s, l, open_syncmer, t, params.trimStart, params.trimEnd, params.seedMaskFraction,
-                        params.minReadSupport, params.forceLeaf, params.dedupReads)
+                        params.minReadSupport, params.forceLeaf, params.dedupReads, quals, params.minSeedQuality)
     hh, hc = placer.histogram()
     assert np.array_equal(hh, want["hist_hash"]), "seed set differs"
     assert np.array_equal(hc, want["hist_count"]), "seed counts differ"
@@ -124,6 +126,35 @@ def test_place_other_parameters(pmx, oracle, ctx, sars, k, s, l, open_syncmer, t
     index = pmx.Index.from_arrays(k, s, t, l, open_syncmer, parent, offsets, hash_, pc, cc)
     concat, off = pmx.simulate_paired_reads(g, 1500, seed=3)
     _check_place(pmx, oracle, ctx, index, _as_reads(concat, off), None, k, s, l, open_syncmer, t)
+
+
+def test_place_min_seed_quality(pmx, oracle, ctx, sars, sars_index):
+    """--min-seed-quality (src/placement.cpp:1386-1527): seeds whose k-mer averages below the Phred threshold are
+    dropped, windows over the full syncmer list; restated in the oracle (no reference fixture exists for it)"""
+    g = sars.genome("node_7618")
+    concat, off = pmx.simulate_paired_reads(g, 1500, seed=6)
+    reads = _as_reads(concat, off)
+    rng = np.random.default_rng(12)
+    quals = []
+    for r in reads:
+        q = rng.integers(2, 41, len(r)).astype(np.uint8) + 33
+        if rng.random() < 0.5:
+            q[:] = 73                                   # clean read
+        lo = int(rng.integers(0, max(1, len(r) - 30)))
+        q[lo:lo + int(rng.integers(5, 40))] = 35        # a low-quality stretch
+        quals.append(q.tobytes())
+    reads += [b"ACGT" * 10, b""]
+    quals += [b"I" * 40, b""]
+    for mq, ts, te in ((20, 0, 0), (30, 10, 20), (2, 0, 0)):
+        _check_place(pmx, oracle, ctx, sars_index, reads, pmx.TraversalParams(minSeedQuality=mq, trimStart=ts, trimEnd=te, dedupReads=True),
+                     quals=quals)
+    # l = 1 index
+    hs, cn = oracle.histogram([g], 15, 8, 1)
+    keep = cn < 30000
+    hs, cn = hs[keep], cn[keep]
+    index = pmx.Index.from_arrays(15, 8, 0, 1, False, np.array([0], np.uint32), np.array([0, len(hs)], np.uint64), hs,
+                                  np.zeros(len(hs), np.int16), cn.astype(np.int16))
+    _check_place(pmx, oracle, ctx, index, reads, pmx.TraversalParams(minSeedQuality=25), 15, 8, 1, quals=quals)
 
 
 def test_reference_e2e_fixtures_on_rsv_4k(pmx, oracle, ctx):
