@@ -89,14 +89,41 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # PMX_BENCH_TEST_BACKEND=gloo: functional check of the multi-rank logic on a box with fewer GPUs than ranks
+    # (ranks share devices, collectives go through host memory).  Never used for a reported number.
+    test_gloo = os.environ.get("PMX_BENCH_TEST_BACKEND") == "gloo"
+    if test_gloo:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if test_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    def all_reduce_(t):
+        if test_gloo:
+            c = t.cpu(); dist.all_reduce(c); t.copy_(c)
+        else:
+            dist.all_reduce(t)
+
+    def all_gather_into_(out, t):
+        if test_gloo:
+            co = out.cpu().view(-1); dist.all_gather_into_tensor(co, t.cpu().view(-1)); out.copy_(co.view(out.shape))
+        else:
+            dist.all_gather_into_tensor(out, t)
+
+    def gather_(t, lst):
+        if test_gloo:
+            cl = [x.cpu() for x in lst] if lst is not None else None
+            dist.gather(t.cpu(), cl, dst=0)
+        else:
+            dist.gather(t, lst, dst=0)
 
     import panmap_amd as pmx
     golden = os.path.join(ROOT, "tests", "golden")
@@ -127,16 +154,16 @@ def main():
             n_loc = placer.histogram_size()
             sizes = torch.zeros(world, dtype=torch.int64, device=dev)
             sizes[rank] = n_loc
-            dist.all_reduce(sizes)
-            mx = int(sizes.max().item())
-            mine = torch.zeros((2, mx), dtype=torch.int64, device=dev)
+            all_reduce_(sizes)
+            h_sizes = sizes.cpu().numpy()                 # one host round trip for all ranks' sizes
+            mx = int(h_sizes.max())
+            mine = torch.empty((2, mx), dtype=torch.int64, device=dev)
             placer.export_device(mine[0].data_ptr(), mine[1].data_ptr(), mx)
             allh = torch.empty((world, 2, mx), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allh, mine)
+            all_gather_into_(allh, mine)
             torch.cuda.synchronize()
-            for r in range(world):
-                if r != rank:
-                    placer.merge_device(allh[r, 0].data_ptr(), allh[r, 1].data_ptr(), int(sizes[r].item()))
+            # rank p's run sits 2*mx elements after rank p-1's in both the hash and the count plane
+            placer.merge_device_parts(allh[0, 0].data_ptr(), allh[0, 1].data_ptr(), 2 * mx, h_sizes, rank)
         res = placer.score(params, n_reads * world)
         node = res.best_index[4]                      # bestLogContainmentNodeId (src/main.cpp:1771)
         ref = pm.genome(int(node))                    # getStringFromReference, every step (nothing cached)
@@ -150,7 +177,7 @@ def main():
             recs = torch.empty((n_reads, 32), dtype=torch.uint8, device=dev)
             aligner.copy_records_device(recs.data_ptr(), n_reads)
             gl = [torch.empty_like(recs) for _ in range(world)] if rank == 0 else None
-            dist.gather(recs, gl, dst=0)
+            gather_(recs, gl)
         ctx.synchronize()
         state["res"], state["ref"] = res, ref
         return res
@@ -174,7 +201,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if test_gloo else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -215,8 +242,8 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i8 DP + u64 hash + f64 score", "data": "synthetic",
-            "config": {"workload": "%dM x %dbp synthetic paired reads per GPU vs SARS-CoV-2 20k PanMAN (39,999 nodes), place+align (configs[1]%s)"
-                                   % (args.reads_per_gpu // 1000000, args.read_len, "" if world == 1 else "; read-sharded, seed index replicated, RCCL histogram all-gather + record gather"),
+            "config": {"workload": "%gM x %dbp synthetic paired reads per GPU vs SARS-CoV-2 20k PanMAN (39,999 nodes), place+align (configs[1]%s)"
+                                   % (args.reads_per_gpu / 1e6, args.read_len, "" if world == 1 else "; read-sharded, seed index replicated, RCCL histogram all-gather + record gather"),
                        "reads_per_gpu": n_reads, "read_len": args.read_len, "index": "k=19,s=8,l=3,closed syncmers,flank-mask 250",
                        "aligner_preset": "k=21,w=11,a=2,b=8,q=12,e=2,q2=24,e2=1 (src/mm_align.c:140-166)"},
             "roofline": {"bound": "hbm", "kernel": "k_align_reads_tpp (round 0: all pairs)", "achieved": achieved, "peak": 8000.0,

@@ -158,6 +158,10 @@ int pmx_place_histogram_export(pmx_ctx *ctx, pmx_place *pl, uint64_t *hash, int6
 int pmx_place_histogram_merge(pmx_ctx *ctx, pmx_place *pl, const uint64_t *hash, const int64_t *count, int64_t n);
 /* same with caller-owned DEVICE buffers (e.g. torch tensors fed to an RCCL all-gather): no host bounce */
 int pmx_place_histogram_export_device(pmx_ctx *ctx, pmx_place *pl, void *d_hash, void *d_count, int64_t cap);
+/* n_parts (hash,count) runs laid out `part_stride` elements apart (the all-gather buffer of the multi-GPU
+ * exchange: rank p's run at d_hash + p * part_stride, sizes[p] valid entries); skip_part = this rank's own run */
+int pmx_place_histogram_merge_device_parts(pmx_ctx *ctx, pmx_place *pl, const void *d_hash, const void *d_count,
+                                           int64_t part_stride, const int64_t *sizes, int n_parts, int skip_part);
 int pmx_place_histogram_merge_device(pmx_ctx *ctx, pmx_place *pl, const void *d_hash, const void *d_count, int64_t n);
 
 /* read-side filters + magnitudes (src/placement.cpp:1703-1856), then [hot] per-node delta scoring

@@ -385,6 +385,11 @@ class Placer:
     def export_device(self, d_hash_ptr: int, d_count_ptr: int, cap: int):
         check(lib.pmx_place_histogram_export_device(self.ctx._h, self._h, d_hash_ptr, d_count_ptr, cap), "pmx_place_histogram_export_device")
 
+    def merge_device_parts(self, d_hash_ptr: int, d_count_ptr: int, part_stride: int, sizes, skip_part: int):
+        sz = np.ascontiguousarray(sizes, np.int64)
+        check(lib.pmx_place_histogram_merge_device_parts(self.ctx._h, self._h, d_hash_ptr, d_count_ptr, part_stride, sz.ctypes.data, len(sz), skip_part),
+              "pmx_place_histogram_merge_device_parts")
+
     def merge_device(self, d_hash_ptr: int, d_count_ptr: int, n: int):
         check(lib.pmx_place_histogram_merge_device(self.ctx._h, self._h, d_hash_ptr, d_count_ptr, n), "pmx_place_histogram_merge_device")
 

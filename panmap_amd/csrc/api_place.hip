@@ -516,6 +516,32 @@ int pmx_place_histogram_merge_device(pmx_ctx* ctx, pmx_place* pl, const void* d_
     PMX_CATCH
 }
 
+int pmx_place_histogram_merge_device_parts(pmx_ctx* ctx, pmx_place* pl, const void* d_hash, const void* d_count, int64_t part_stride,
+                                           const int64_t* sizes, int n_parts, int skip_part) {
+    if (!ctx || !pl || !sizes || n_parts < 0 || part_stride < 0) return PMX_ERR_ARG;
+    int64_t total = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        if (sizes[p] < 0 || sizes[p] > part_stride) return PMX_ERR_ARG;
+        if (p != skip_part) total += sizes[p];
+    }
+    if (total == 0) return PMX_OK;
+    if (!d_hash || !d_count) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    table_reserve(ctx, pl, (uint64_t)total);   // one capacity check for every part, then the merges run back to back
+    for (int p = 0; p < n_parts; ++p) {
+        if (p == skip_part || sizes[p] == 0) continue;
+        hipLaunchKernelGGL(k_table_merge, dim3(grid_for(sizes[p], 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                           (const uint64_t*)d_hash + (size_t)p * (size_t)part_stride, (const int64_t*)d_count + (size_t)p * (size_t)part_stride, sizes[p],
+                           pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
+    }
+    PMX_HIP(hipGetLastError());
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    pl->hist_sorted = false;
+    return PMX_OK;
+    PMX_CATCH
+}
+
 int pmx_place_histogram_merge(pmx_ctx* ctx, pmx_place* pl, const uint64_t* hash, const int64_t* count, int64_t n) {
     if (!ctx || !pl || n < 0 || (n > 0 && (!hash || !count))) return PMX_ERR_ARG;
     if (n == 0) return PMX_OK;

@@ -201,6 +201,31 @@ def test_histogram_shard_merge_equals_single_pass(pmx, ctx, sars, sars_index):
     assert ra.best_score == rc.best_score and ra.best_index == rc.best_index
 
 
+def test_histogram_parts_merge_on_device(pmx, ctx, sars, sars_index):
+    """the exchange as bench.py runs it: the ranks' runs in one padded [world, 2, max] device buffer, merged in one call"""
+    import torch
+    g = sars.genome("node_7618")
+    concat, off = pmx.simulate_paired_reads(g, 3000, seed=15)
+    reads = _as_reads(concat, off)
+    full = pmx.Placer(ctx, sars_index); full.reset(); full.add_reads(pmx.ReadSet(ctx, reads))
+    h_all, c_all = full.histogram()
+    shards = [reads[:1000], reads[1000:4400], reads[4400:]]
+    placers, sizes = [], []
+    for sh in shards:
+        pl = pmx.Placer(ctx, sars_index); pl.reset(); pl.add_reads(pmx.ReadSet(ctx, sh))
+        placers.append(pl); sizes.append(pl.histogram_size())
+    mx = max(sizes)
+    buf = torch.full((3, 2, mx), -1, dtype=torch.int64, device="cuda:0")
+    for r, pl in enumerate(placers):
+        pl.export_device(buf[r, 0].data_ptr(), buf[r, 1].data_ptr(), mx)
+    torch.cuda.synchronize()
+    for me in range(3):
+        pl = pmx.Placer(ctx, sars_index); pl.reset(); pl.add_reads(pmx.ReadSet(ctx, shards[me]))
+        pl.merge_device_parts(buf[0, 0].data_ptr(), buf[0, 1].data_ptr(), 2 * mx, sizes, me)
+        h, c = pl.histogram()
+        assert np.array_equal(h, h_all) and np.array_equal(c, c_all), me
+
+
 def test_full_size_properties(pmx, ctx, sars, sars_index):
     """BASELINE config 2 size (1M reads): size-independent checks -- total seed frequency equals the number
     of emitted seeds, and doubling the read set doubles every count (linearity of the histogram)."""
