@@ -554,9 +554,9 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
                 align_pair(W, o, qe - qs, qseq, re - rs, tseq, bw1, -1, o.zdrop, PMX_EZ_APPROX_MAX, ez);   // first pass: approximate Z-drop
                 W.skip_shortcut = 0;
             }
-            // a gap fill answered by shortcut (2) is gap-free with at most two mismatches: its largest score drop is
-            // 2(a+b) <= zdrop, so mm_test_zdrop returns 0 without looking
-            const bool tz_skip = W.last_dp_shortcut && 2 * (o.a + o.b) <= o.zdrop && 2 * (o.a + o.b) <= o.zdrop_inv;
+            // a gap fill answered by shortcut (2) is gap-free with at most three mismatches (d(a+b) <= a + 2*gmin): its
+            // largest score drop is below 4(a+b) <= zdrop, so mm_test_zdrop returns 0 without looking
+            const bool tz_skip = W.last_dp_shortcut && 4 * (o.a + o.b) <= o.zdrop && 4 * (o.a + o.b) <= o.zdrop_inv;
             if (!tz_skip && decided) ref_getseq(ri, rs, re, tseq);   // the shortcut read the reference directly
             const int zdrop_code = tz_skip ? 0 : test_zdrop(W, o, qseq, tseq, ez.n_cigar, cig_tmp);
             if (zdrop_code != 0) align_pair(W, o, qe - qs, qseq, re - rs, tseq, bw1, -1, zdrop_code == 2 ? o.zdrop_inv : o.zdrop, 0, ez);

@@ -130,3 +130,70 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
 #endif
     return 0;
 }
+
+#ifndef PMX_HOSTSIM_TPP
+// Property check of the DP shortcuts: random extension / gap-fill problems (small alphabets provoke repeats, which
+// is where a gapped path can rival the gap-free one); whenever ksw_shortcut answers, the full DP must give the
+// same consumed fields (max, max_t, max_q, mqe_t when reach_end, reach_end, score, zdropped, CIGAR).
+static uint64_t fz_state;
+static inline uint32_t fz_rand() {
+    fz_state ^= fz_state << 13; fz_state ^= fz_state >> 7; fz_state ^= fz_state << 17;
+    return (uint32_t)(fz_state >> 11);
+}
+extern "C" int hs_shortcut_fuzz(uint64_t seed, int64_t n_cases, int64_t* counts /* declined, agreed, mismatched */, int verbose) {
+    fz_state = seed * 0x9E3779B97F4A7C15ULL + 1;
+    Opt o = make_opt(150);
+    gen_simple_mat(o.mat, (int8_t)o.a, (int8_t)o.b, (int8_t)o.sc_ambi);
+    Layout L = plan_layout(256, 2, o, (size_t)1 << 30);
+    std::vector<uint8_t> fast(L.fast_bytes + 64), slow(L.slow_bytes + 64);
+    Work W;
+    memset(&W, 0, sizeof(W));
+    bind_work(W, L, fast.data(), slow.data());
+    std::vector<uint32_t> cig1(64);
+    counts[0] = counts[1] = counts[2] = 0;
+    uint8_t q[256], t[256];
+    for (int64_t it = 0; it < n_cases; ++it) {
+        const int mode = (int)(fz_rand() % 3);            // 0 right extension, 1 left extension, 2 gap fill (first pass)
+        const int alpha = 2 + (int)(fz_rand() % 3);       // 2..4 letters
+        const int qlen = 3 + (int)(fz_rand() % 70);
+        const int period = (fz_rand() & 3) == 0 ? 1 + (int)(fz_rand() % 6) : 0;   // sometimes a tandem repeat
+        int tlen = mode == 2 ? qlen : qlen + (int)(fz_rand() % 40);
+        for (int i = 0; i < tlen; ++i) t[i] = (uint8_t)(period && i >= period ? t[i - period] : fz_rand() % alpha);
+        for (int i = 0; i < qlen; ++i) q[i] = t[i];
+        const int n_mut = (int)(fz_rand() % 4);
+        for (int m = 0; m < n_mut; ++m) {
+            const int p = (int)(fz_rand() % qlen);
+            q[p] = (uint8_t)((q[p] + 1 + fz_rand() % 3) % 4);
+        }
+        if ((fz_rand() & 63) == 0) q[fz_rand() % qlen] = 4;   // an ambiguous base now and then
+        if ((fz_rand() & 63) == 0) t[fz_rand() % tlen] = 4;
+        const int flag = mode == 0 ? PMX_EZ_EXTZ_ONLY : mode == 1 ? (PMX_EZ_EXTZ_ONLY | PMX_EZ_RIGHT | PMX_EZ_REV_CIGAR) : PMX_EZ_APPROX_MAX;
+        const int end_bonus = mode == 2 ? -1 : o.end_bonus, w = (int)(o.bw * 1.5 + 1.);
+        Ez e1, e2;
+        W.status = 0;
+        const bool took = ksw_shortcut(W, qlen, q, tlen, t, o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2, (int8_t)o.e2, w, o.zdrop, end_bonus, flag, e1);
+        if (!took) { ++counts[0]; continue; }
+        for (int i = 0; i < e1.n_cigar; ++i) cig1[(size_t)i] = W.cig_tmp[i];
+        ksw_extd2(W, qlen, q, tlen, t, o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2, (int8_t)o.e2, w, o.zdrop, end_bonus, flag, e2);
+        bool same = e1.zdropped == e2.zdropped && e1.n_cigar == e2.n_cigar;
+        if (mode == 2) same = same && e1.score == e2.score;
+        else same = same && e1.max == e2.max && e1.max_t == e2.max_t && e1.max_q == e2.max_q && e1.reach_end == e2.reach_end &&
+                    (!e1.reach_end || e1.mqe_t == e2.mqe_t);
+        for (int i = 0; same && i < e1.n_cigar; ++i) same = cig1[(size_t)i] == W.cig_tmp[i];
+        if (same) ++counts[1];
+        else {
+            if (verbose && counts[2] < 5) {
+                fprintf(stderr, "shortcut mismatch mode=%d qlen=%d tlen=%d: max %u/%u max_t %d/%d max_q %d/%d reach %d/%d mqe_t %d/%d score %d/%d ncig %d/%d\n  q=", mode, qlen,
+                        tlen, e1.max, e2.max, e1.max_t, e2.max_t, e1.max_q, e2.max_q, e1.reach_end, e2.reach_end, e1.mqe_t, e2.mqe_t, e1.score, e2.score,
+                        e1.n_cigar, e2.n_cigar);
+                for (int i = 0; i < qlen; ++i) fputc("ACGTN"[q[i]], stderr);
+                fprintf(stderr, "\n  t=");
+                for (int i = 0; i < tlen; ++i) fputc("ACGTN"[t[i]], stderr);
+                fputc('\n', stderr);
+            }
+            ++counts[2];
+        }
+    }
+    return 0;
+}
+#endif

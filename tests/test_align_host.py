@@ -74,3 +74,17 @@ def test_golden_fixture(pmx, tpp):
         assert len(keep) >= 0.95 * len(got)
         bad = ac.compare_results([got[i] for i in keep], [want[i] for i in keep])
         assert not bad, (name, bad[:10])
+
+
+def test_dp_shortcuts_against_the_dp_fuzz():
+    """every answer ksw_shortcut gives on random extension / gap-fill problems (small alphabets, tandem repeats,
+    0-3 substitutions, the odd N) must be what ksw_extd2 computes"""
+    import ctypes as C
+    L = ac.hostsim(False)
+    L.hs_shortcut_fuzz.restype = C.c_int
+    L.hs_shortcut_fuzz.argtypes = [C.c_uint64, C.c_int64, C.POINTER(C.c_int64), C.c_int]
+    counts = (C.c_int64 * 3)()
+    L.hs_shortcut_fuzz(12345, 400000, counts, 1)
+    declined, agreed, bad = counts[0], counts[1], counts[2]
+    assert bad == 0, (declined, agreed, bad)
+    assert agreed > 50000, (declined, agreed)
