@@ -125,6 +125,8 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
     PMX_LDS(u); PMX_LDS(v); PMX_LDS(x); PMX_LDS(y); PMX_LDS(x2); PMX_LDS(y2); PMX_LDS(s);
     PMX_LDS(sf); PMX_LDS(qr); PMX_LDS(H); PMX_LDS(off); PMX_LDS(off_end);
     Ptr<uint8_t> p = W.tb;
+    const bool tb_lds = PMX_TB_IS_LDS(p);   // uniform
+    (void)tb_lds;
     const int T16 = tlen_ * 16;
     // initial fill (ksw2_extd2_sse.c:107-126): every lane takes a stride
     for (int t = lane; t < T16; t += PMX_W) {
@@ -182,7 +184,7 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
         // diagonal in x[t-1], v[t-1], x2[t-1]
         off[r] = st;
         off_end[r] = en;
-        Ptr<uint8_t> pr = p + ((size_t)r * n_col - st);
+        const uint32_t pr_off = (uint32_t)(r * n_col - st);
         const int n_chunk = (en - st + PMX_W) / PMX_W;
         for (int c = n_chunk - 1; c >= 0; --c) {
             const int t = st + c * PMX_W + lane;
@@ -250,7 +252,7 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
                     y2[t] = (int8_t)((0 > b2 ? 0 : b2) - (q2 + e2));
                     d |= 0 > b2 ? 0 : 0x40;
                 }
-                pr[t] = d;
+                PMX_TB_STORE(p, tb_lds, pr_off + (uint32_t)t, d);
             }
             wave_sync();
         }
@@ -340,9 +342,23 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
 __device__ __forceinline__ int rl_i32(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 // lane L receives lane L-1's value (lane 0: 0): DPP wave_shr:1, one VALU op, no LDS crossbar round trip
 __device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+// wave-wide signed max through DPP (row_shr 1/2/4/8 scan inside each row of 16, row_bcast:15 / :31 across rows;
+// the total lands in lane 63): six VALU ops instead of six ds_bpermute round trips through the LDS crossbar
 __device__ __forceinline__ int wave_max_i32x(int v) {
-    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(v, o); v = other > v ? other : v; }
-    return v;
+    const int lo = INT32_MIN;
+#define PMX_DPP_MAX(ctrl, rmask)                                                        \
+    do {                                                                                \
+        const int o_ = __builtin_amdgcn_update_dpp(lo, v, (ctrl), (rmask), 0xf, false); \
+        v = o_ > v ? o_ : v;                                                            \
+    } while (0)
+    PMX_DPP_MAX(0x111, 0xf);
+    PMX_DPP_MAX(0x112, 0xf);
+    PMX_DPP_MAX(0x114, 0xf);
+    PMX_DPP_MAX(0x118, 0xf);
+    PMX_DPP_MAX(0x142, 0xa);
+    PMX_DPP_MAX(0x143, 0xc);
+#undef PMX_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 template <int NC>
@@ -386,7 +402,6 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
     int32_t *off = W.off, *off_end = W.off_end;
     PMX_LDS(off); PMX_LDS(off_end);
     uint8_t* p = W.tb;
-    if (TB_IN_LDS) PMX_LDS(p);   // ds_write_b8 instead of a flat store
 
     // per-column state (int8 values of the reference kept sign-extended in 32-bit registers)
     int u[NC], v[NC], x[NC], y[NC], x2[NC], y2[NC], s[NC], H[NC], sf[NC];
@@ -414,9 +429,14 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
         st = st / 16 * 16;
         en = (en + 16) / 16 * 16 - 1;
         // this diagonal's query bases, issued first so the LDS latency hides behind the boundary work
+        // (for NC > 1 every per-column section skips the columns that lie outside its range with a uniform branch:
+        //  a diagonal of a 150 x 150 problem touches one or two of the three columns)
+        const int s_end = st0 + ((en0 - st0) / 16 + 1) * 16;
         int sq2v[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            sq2v[c] = 0;
+            if (NC > 1 && (c * 64 + 63 < st0 || c * 64 >= s_end)) continue;
             const int t = c * 64 + lane;
             sq2v[c] = (t <= r && r - t < qlen) ? (int)query[r - t] : 0;
         }
@@ -434,9 +454,9 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
                 if (c * 64 + lane == r) { y[c] = init_ue; y2[c] = init_ue2; u[c] = gap_head; }
         }
         // scores of [st0, s_end); cells of [st, st0) keep whatever s[] held (as the SSE code does)
-        const int s_end = st0 + ((en0 - st0) / 16 + 1) * 16;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            if (NC > 1 && (c * 64 + 63 < st0 || c * 64 >= s_end)) continue;
             const int t = c * 64 + lane;
             if (t >= st0 && t < s_end) {
                 const int sq = sf[c];
@@ -450,14 +470,15 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
         int xs[NC], vs[NC], x2s[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            xs[c] = vs[c] = x2s[c] = 0;
+            if (NC > 1 && (c * 64 + 63 < st || c * 64 > en)) continue;
             xs[c] = wave_shr1(x[c]);
             vs[c] = wave_shr1(v[c]);
             x2s[c] = wave_shr1(x2[c]);
-        }
-#pragma unroll
-        for (int c = 1; c < NC; ++c) {   // column c's lane 0 continues after column c-1's lane 63
-            const int bx = rl_i32(x[c - 1], 63), bv = rl_i32(v[c - 1], 63), bx2 = rl_i32(x2[c - 1], 63);
-            if (lane == 0) { xs[c] = bx; vs[c] = bv; x2s[c] = bx2; }
+            if (c > 0) {   // column c's lane 0 continues after column c-1's lane 63
+                const int bx = rl_i32(x[c - 1], 63), bv = rl_i32(v[c - 1], 63), bx2 = rl_i32(x2[c - 1], 63);
+                if (lane == 0) { xs[c] = bx; vs[c] = bv; x2s[c] = bx2; }
+            }
         }
         // core recurrence on [st, en] (columns entirely outside the range are skipped with a uniform branch)
 #pragma unroll
@@ -523,7 +544,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
                     y2[c] = (int8_t)((0 > b2 ? 0 : b2) - (q2 + e2));
                     d |= 0 > b2 ? 0 : 0x40;
                 }
-                p[(uint32_t)(r * n_col + (t - st))] = d;
+                PMX_TB_STORE(p, TB_IN_LDS, (uint32_t)(r * n_col + (t - st)), d);
             }
         }
         if (lane == 0) { off[r] = st; off_end[r] = en; }
@@ -539,8 +560,9 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
                 int hv[NC], lmax = INT32_MIN;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const int t = c * 64 + lane;
                     hv[c] = INT32_MIN;
+                    if (NC > 1 && (c * 64 + 63 < st0 || c * 64 > en0)) continue;
+                    const int t = c * 64 + lane;
                     if (t >= st0 && t < en0) {
                         const int32_t h = H[c] + (int32_t)(int8_t)v[c];
                         H[c] = h;
@@ -600,6 +622,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
         last_en = en;
     }
     wave_sync();
+    if (W.prof) W.prof_t = (unsigned long long)clock64();   // diagnostic: the serve kernel reports fill vs traceback
     const int rev_cigar = !!(flag & PMX_EZ_REV_CIGAR);
     if (!ez.zdropped && !(flag & PMX_EZ_EXTZ_ONLY)) {
         ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, tlen - 1, qlen - 1, &ez.n_cigar);

@@ -42,6 +42,24 @@ PMX_HD void wave_sync() {}
 #define PMX_LDS(p) ((void)0)
 #endif
 
+// Traceback bytes of the DP kernels.  A store through a generic pointer compiles to flat_store, which counts on
+// lgkmcnt as well as vmcnt: the next LDS access of the anti-diagonal loop then waits for the HBM round trip of
+// the previous diagonal's store (measured: ~5k cycles per diagonal in every DP kernel).  The wave-per-pair DP
+// kernels therefore pick the address space explicitly (uniform branch): ds_write_b8 or global_store_byte.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PMX_THREAD_PER_PAIR)
+typedef __attribute__((address_space(1))) uint8_t pmx_gbyte;
+typedef __attribute__((address_space(3))) uint8_t pmx_lbyte;
+#define PMX_TB_STORE(p, is_lds, idx, val)                         \
+    do {                                                         \
+        if (is_lds) ((pmx_lbyte*)(p))[(idx)] = (val);            \
+        else ((pmx_gbyte*)(p))[(idx)] = (val);                   \
+    } while (0)
+#define PMX_TB_IS_LDS(p) __builtin_amdgcn_is_shared((const void*)(p))
+#else
+#define PMX_TB_STORE(p, is_lds, idx, val) ((p)[(idx)] = (val))
+#define PMX_TB_IS_LDS(p) false
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PMX_STAMP(W, k)                                                              \
     do {                                                                            \

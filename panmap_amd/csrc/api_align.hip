@@ -344,7 +344,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         static const char* names[16] = {"decode", "sketch", "seed+heap", "chain", "gen_regs+post", "seg_gen", "squeeze", "align1(all regs)", "filter/sort/parent", "mapq", "pair", "output", "", "", "", ""};
         fprintf(stderr, "[pmx align phase cycles per item]");
         for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.0f", names[k], (double)h[k] / (double)n_items);
-        fprintf(stderr, " [dp serve: cycles load=%.0f ksw=%.0f store=%.0f per request, diagonals=%.1f]", (double)h[12] / std::max<double>(1, (double)al->last_dp_requests),
+        fprintf(stderr, " [dp serve: cycles traceback=%.0f ksw=%.0f store=%.0f per request, diagonals=%.1f]", (double)h[12] / std::max<double>(1, (double)al->last_dp_requests),
                 (double)h[13] / std::max<double>(1, (double)al->last_dp_requests), (double)h[14] / std::max<double>(1, (double)al->last_dp_requests),
                 (double)h[15] / std::max<double>(1, (double)al->last_dp_requests));
         fprintf(stderr, " dp_requests=%lld dp_rounds=%d tpp_retry=%lld retry=%lld\n", (long long)al->last_dp_requests, al->last_dp_rounds,
