@@ -145,10 +145,23 @@ def main():
     params = pmx.TraversalParams()
     state = {}
 
+    host_times = {} if os.environ.get("PMX_BENCH_HOST_TIMES") else None   # diagnostic: serialised per-phase wall times
+
+    def tick(name, t_prev):
+        if host_times is None:
+            return t_prev
+        ctx.synchronize()
+        t = time.perf_counter()
+        host_times[name] = host_times.get(name, 0.0) + (t - t_prev) * 1e3
+        return t
+
     def step():
+        tk = tick("", time.perf_counter()) if host_times is not None else 0.0
         rs.pack()
+        tk = tick("pack", tk)
         placer.reset()
         placer.add_reads(rs, params)
+        tk = tick("seed", tk)
         if world > 1:
             # exchange step: all-gather the per-rank (hash,count) histograms, merge the other ranks' parts
             n_loc = placer.histogram_size()
@@ -165,14 +178,18 @@ def main():
             # rank p's run sits 2*mx elements after rank p-1's in both the hash and the count plane
             placer.merge_device_parts(allh[0, 0].data_ptr(), allh[0, 1].data_ptr(), 2 * mx, h_sizes, rank)
         res = placer.score(params, n_reads * world)
+        tk = tick("score", tk)
         node = res.best_index[4]                      # bestLogContainmentNodeId (src/main.cpp:1771)
         ref = pm.genome(int(node))                    # getStringFromReference, every step (nothing cached)
+        tk = tick("genome", tk)
         if "aligner" not in state:
             state["aligner"] = pmx.Aligner(ctx, ref, args.read_len)
         else:
             state["aligner"].set_reference(ref, args.read_len)   # mm_idx_str of the placed genome, every step
         aligner = state["aligner"]
+        tk = tick("ref_index", tk)
         aligner.align_readset(rs, paired=True, revcomp_mate2=True)
+        tk = tick("align", tk)
         if world > 1:
             recs = torch.empty((n_reads, 32), dtype=torch.uint8, device=dev)
             aligner.copy_records_device(recs.data_ptr(), n_reads)
@@ -200,6 +217,9 @@ def main():
             kernel_ms[k].append(ctx.kernel_ms(k))
     sync_all()
     elapsed = time.perf_counter() - t0
+    if host_times is not None and rank == 0:
+        n_st = args.steps + args.warmup
+        print("[bench host times, ms/step, serialised] " + " ".join(f"{k}={v / n_st:.3f}" for k, v in host_times.items() if k), file=sys.stderr)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if test_gloo else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

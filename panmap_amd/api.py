@@ -62,11 +62,15 @@ class Panman:
         i = node if isinstance(node, int) else self.find_node(node)
         if i < 0:
             raise KeyError(node)
-        n = lib.pmx_panman_node_genome(self._h, i, None, 0)
+        # one reconstruction per call: the buffer of the previous call is tried first (genomes of one tree are
+        # about the same length) and grown when the answer does not fit
+        buf = getattr(self, "_gbuf", None)
+        n = lib.pmx_panman_node_genome(self._h, i, buf, len(buf) if buf is not None else 0)
         if n < 0:
             raise _lib.PmxError(-3, "pmx_panman_node_genome")
-        buf = C.create_string_buffer(max(n, 1))
-        lib.pmx_panman_node_genome(self._h, i, buf, n)
+        if buf is None or n > len(buf):
+            buf = self._gbuf = C.create_string_buffer(max(n + n // 8, 1))
+            lib.pmx_panman_node_genome(self._h, i, buf, len(buf))
         return buf.raw[:n]
 
 

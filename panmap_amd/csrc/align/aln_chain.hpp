@@ -162,9 +162,14 @@ __device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_d
 #if PMX_W == 1
 // Scalar execution models (thread per pair, host): everything the inner loop of the fill needs from anchor j --
 // reference position, query position, span, segment, f, p, the t mark -- packed into ONE 16-byte cell, so an
-// inner iteration is one load (and one 2-byte store for the mark) instead of an anchor load plus a cell load.
+// inner iteration needs one 16-byte cell instead of an anchor load plus a cell load.  Four cells form one 64-byte
+// block (Cell4: its own interleave granule in the thread-per-pair arena, so a lane's block is ONE contiguous line):
+// the inner loop walks the predecessors block by block -- four cells per line fetched, four loads in flight -- and
+// the "t" marks of the reference (t[p[j]] = i; tested as t[j] == i, i.e. only ever against the CURRENT i) live in
+// a 64-bit register mask relative to st whenever the window [st, i) has at most 64 anchors, so the fill does no
+// scattered read-modify-write at all (those 2-byte stores were ~40 % of the kernel's HBM traffic).
 // Valid while positions in the query fit 16 bits and there are fewer than 65,535 anchors.
-struct PackedCell {
+struct alignas(16) PackedCell {
     uint32_t x_lo;       // low 32 bits of anchor x (comput_sc only uses the 32-bit difference)
     uint16_t y_lo;       // query position
     uint8_t span, seg;
@@ -173,6 +178,12 @@ struct PackedCell {
     uint16_t t;
 };
 static_assert(sizeof(PackedCell) == 16, "one interleave granule");
+struct alignas(16) Cell4 {
+    static constexpr bool kWide64 = true;   // 64-byte interleave granule (aln_types.hpp IGranule)
+    PackedCell c[4];
+};
+static_assert(sizeof(Cell4) == 64, "four cells per block");
+PMX_HD PackedCell& packed_cell(Ptr<Cell4> pk4, int64_t j) { return pk4[j >> 2].c[j & 3]; }
 PMX_HD A128 packed_anchor(const PackedCell& c) {
     A128 r;
     r.x = c.x_lo;
@@ -210,10 +221,12 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
         packed_fill = n < 65535 && qsum < 65536;
     }
     if (packed_fill) {
-        Ptr<PackedCell> pk = ptr_cast<PackedCell>(W.z);   // z[] is idle until the backtrack
+        Ptr<Cell4> pk4 = ptr_region_cast<Cell4>(W.z);   // z[] is idle until the backtrack
         int64_t st = 0, max_ii = -1;
+        uint64_t x_st = a[0].x, x_mi = 0;   // a[st].x and a[max_ii].x, kept in registers
+        int32_t f_mi = 0;                   // f[max_ii]
         for (int64_t i = 0; i < n; ++i) {
-            int64_t max_j = -1, end_j;
+            int64_t max_j = -1;
             const A128 ai = a[i];
             PackedCell ci;
             ci.x_lo = (uint32_t)ai.x;
@@ -223,34 +236,50 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
             ci.f = 0; ci.p1 = 0; ci.t = 0;
             const A128 ri = packed_anchor(ci);
             int32_t max_f = (int32_t)ci.span, n_skip = 0;
-            while (st < i && (ai.x >> 32 != a[st].x >> 32 || ai.x > a[st].x + (uint64_t)max_dist_x)) ++st;
-            if (i - st > max_iter) st = i - max_iter;
-            int64_t j;
-            for (j = i - 1; j >= st; --j) {
-                const PackedCell cj = pk[j];
-                int32_t sc = chain_score(ri, packed_anchor(cj), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
-                if (sc == INT32_MIN) continue;
-                sc += cj.f;
-                if (sc > max_f) {
-                    max_f = sc;
-                    max_j = j;
-                    if (n_skip > 0) --n_skip;
-                } else if (cj.t == (uint16_t)i) {
-                    if (++n_skip > max_skip) break;
-                }
-                if (cj.p1) pk[cj.p1 - 1].t = (uint16_t)i;
+            while (st < i && (ai.x >> 32 != x_st >> 32 || ai.x > x_st + (uint64_t)max_dist_x)) {
+                ++st;
+                x_st = st < i ? a[st].x : ai.x;
             }
-            end_j = j;
-            if (max_ii < 0 || (int64_t)(ai.x - a[max_ii].x) > (int64_t)max_dist_x) {
+            if (i - st > max_iter) { st = i - max_iter; x_st = a[st].x; }
+            const bool use_mask = i - st <= 64;
+            uint64_t mark = 0;   // bit (k - st): anchor k is the predecessor of an anchor already visited for this i
+            int64_t end_j = st - 1;
+            bool stop = false;
+            for (int64_t g = (i - 1) >> 2; i > st && !stop && g >= (st >> 2); --g) {
+                const Cell4 G = pk4[g];
+#pragma unroll
+                for (int s_ = 3; s_ >= 0; --s_) {
+                    const int64_t j = g * 4 + s_;
+                    if (stop || j >= i || j < st) continue;
+                    const PackedCell cj = G.c[s_];
+                    int32_t sc = chain_score(ri, packed_anchor(cj), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                    if (sc == INT32_MIN) continue;
+                    sc += cj.f;
+                    if (sc > max_f) {
+                        max_f = sc;
+                        max_j = j;
+                        if (n_skip > 0) --n_skip;
+                    } else if (use_mask ? (mark >> (j - st) & 1) != 0 : packed_cell(pk4, j).t == (uint16_t)i) {
+                        if (++n_skip > max_skip) { stop = true; end_j = j; continue; }
+                    }
+                    if (cj.p1) {
+                        const int64_t k = (int64_t)cj.p1 - 1;
+                        if (!use_mask) packed_cell(pk4, k).t = (uint16_t)i;
+                        else if (k >= st) mark |= 1ULL << (k - st);
+                    }
+                }
+            }
+            if (max_ii < 0 || (int64_t)(ai.x - x_mi) > (int64_t)max_dist_x) {
                 int32_t mx = INT32_MIN;
                 max_ii = -1;
-                for (j = i - 1; j >= st; --j) {
-                    const int32_t fj = pk[j].f;
+                for (int64_t j = i - 1; j >= st; --j) {
+                    const int32_t fj = packed_cell(pk4, j).f;
                     if (mx < fj) { mx = fj; max_ii = j; }
                 }
+                if (max_ii >= 0) { x_mi = a[max_ii].x; f_mi = mx; }
             }
             if (max_ii >= 0 && max_ii < end_j) {
-                const PackedCell cm = pk[max_ii];
+                const PackedCell cm = packed_cell(pk4, max_ii);
                 const int32_t tmp = chain_score(ri, packed_anchor(cm), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
                 if (tmp != INT32_MIN && max_f < tmp + cm.f) { max_f = tmp + cm.f; max_j = max_ii; }
             }
@@ -264,9 +293,9 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
                 c[i] = co;
                 ci.f = max_f;
                 ci.p1 = (uint16_t)(max_j + 1);
-                pk[i] = ci;
+                packed_cell(pk4, i) = ci;
             }
-            if (max_ii < 0 || ((int64_t)(ai.x - a[max_ii].x) <= (int64_t)max_dist_x && pk[max_ii].f < max_f)) max_ii = i;
+            if (max_ii < 0 || ((int64_t)(ai.x - x_mi) <= (int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = ai.x; f_mi = max_f; }
         }
     }
 #endif
@@ -320,6 +349,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
         }
     }
 
+    PMX_STAMP(W, 18);
     // ---- backtrack (lchain.c:27-76)
     Ptr<A128> z = W.z; PMX_LDS(z);
     int64_t n_z = 0;
@@ -347,6 +377,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     }
     if (n_u == 0) { W.n_a = 0; W.n_u = 0; return; }
 
+    PMX_STAMP(W, 19);
     // ---- compact (lchain.c:78-111): chains reversed into ascending order, then sorted by target position
     Ptr<A128> b = W.a2; PMX_LDS(b);
     int64_t kk = 0;

@@ -397,7 +397,7 @@ inline Layout plan_layout_tpp(int max_read_len, int n_segs, const Opt& o, size_t
     auto put = [&](Layout::Ent& e, size_t bytes) {   // one region each, no overlays (see IPtr)
         e.space = PMX_FAST;
         e.off = top;
-        top += (bytes + 15) & ~(size_t)15;
+        top += (bytes + 63) & ~(size_t)63;   // 64-byte aligned: a region may be viewed through any granule (ptr_region_cast)
     };
     put_raw(L.regs0, (size_t)c.max_reg);
     put_raw(L.regs1, (size_t)c.max_reg);

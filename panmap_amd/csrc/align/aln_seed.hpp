@@ -294,6 +294,7 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
 // forward-strand anchors first, then the reverse-strand ones, both ascending.
 PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
     collect_matches(W, o, ri, qlen, max_occ);
+    PMX_STAMP(W, 16);
     if (W.n_a > W.caps.max_anchor) {
         W.status |= PMX_ST_OVERFLOW;
         W.n_a = 0;
@@ -329,6 +330,7 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     }
     for (int q = (heap_size >> 1) - 1; q >= 0; --q) heap_down_min_x(heap, q, heap_size);
     int64_t n_for = 0, n_rev = 0;
+    PMX_STAMP(W, 17);
     while (heap_size > 0) {
         const SeedA q = seeds[heap[0].y >> 32];
         const SeedB qb = seeds_b[heap[0].y >> 32];

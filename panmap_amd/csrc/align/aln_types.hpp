@@ -102,6 +102,9 @@ __constant__ TppArena c_tpp_arena;
 #endif
 #if defined(PMX_THREAD_PER_PAIR) && defined(__HIP_DEVICE_COMPILE__)
 #define PMX_INTERLEAVED 1
+// interleave granule of an element type (log2 bytes); a type may opt into a 64-byte granule (Wide64)
+template <class T, class = void> struct IGranule { static constexpr uint32_t LG = sizeof(T) >= 8 ? 4u : 2u; };
+template <class T> struct IGranule<T, typename std::enable_if<std::remove_cv<T>::type::kWide64>::type> { static constexpr uint32_t LG = 6u; };
 template <class T>
 struct IPtr {
     uint32_t o;
@@ -109,7 +112,7 @@ struct IPtr {
     __device__ explicit IPtr(uint32_t off) : o(off) {}
     template <class U, class = typename std::enable_if<std::is_convertible<U*, T*>::value>::type>
     __device__ IPtr(const IPtr<U>& q) : o(q.o) {}
-    static constexpr uint32_t LG = sizeof(T) >= 8 ? 4u : 2u;   // log2 of the granule
+    static constexpr uint32_t LG = IGranule<T>::LG;   // log2 of the granule
     __device__ __forceinline__ static T* phys(uint32_t off) {
         uint8_t* wave_base = c_tpp_arena.base + (size_t)blockIdx.x * c_tpp_arena.wave_stride;   // uniform
         const uint32_t vo = ((threadIdx.x & 63u) << LG) + ((off >> LG) << (LG + 6)) + (off & ((1u << LG) - 1u));
@@ -137,9 +140,16 @@ template <class U, class T> __device__ __forceinline__ IPtr<U> ptr_cast(IPtr<T> 
     static_assert(IPtr<U>::LG == IPtr<T>::LG, "ptr_cast between element types of different interleave granule");
     return IPtr<U>(q.o);
 }
+// A whole region viewed through another granule (e.g. 64-byte blocks of four chain cells: one lane's block is
+// one contiguous 64 bytes, so a batch of four cells costs one line instead of four).  Every 64-byte aligned
+// logical block maps into the same 4 KB of the wave slab under any granule, so this is safe as long as the region
+// starts 64-byte aligned (plan_layout_tpp aligns every region) and is accessed ONLY through the new view until
+// it is handed back (nothing cached is carried across).
+template <class U, class T> __device__ __forceinline__ IPtr<U> ptr_region_cast(IPtr<T> q) { return IPtr<U>(q.o); }
 #else
 template <class T> using Ptr = T*;
 template <class U, class T> PMX_HD U* ptr_cast(T* q) { return reinterpret_cast<U*>(q); }
+template <class U, class T> PMX_HD U* ptr_region_cast(T* q) { return reinterpret_cast<U*>(q); }
 #endif
 
 // Sequential byte reads through ALIGNED 32-bit loads: the per-base loops of the pipeline (sketch, mismatch
@@ -416,7 +426,7 @@ struct Work {
     // optional phase profile (diagnostic runs only: AlignArgs::prof != NULL)
     unsigned long long* prof;
     unsigned long long prof_t;
-    unsigned long long prof_acc[16];
+    unsigned long long prof_acc[20];   // [0..11] phases, [16..19] sub-phases of seeding / chaining (PMX_ALIGN_PROF)
 };
 
 }  // namespace aln

@@ -152,8 +152,8 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.cigar_used = al->cigar_used.p;
     A.prof = nullptr;
     if (getenv("PMX_ALIGN_PROF")) {
-        al->prof.ensure(16);
-        PMX_HIP(hipMemsetAsync(al->prof.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        al->prof.ensure(20);
+        PMX_HIP(hipMemsetAsync(al->prof.p, 0, 20 * sizeof(unsigned long long), ctx->stream));
         A.prof = al->prof.p;
     }
 
@@ -338,12 +338,15 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     }
     timer_end(ctx, "align", 1);
     if (A.prof) {
-        unsigned long long h[16];
+        unsigned long long h[20];
         PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         PMX_HIP(hipStreamSynchronize(ctx->stream));
         static const char* names[16] = {"decode", "sketch", "seed+heap", "chain", "gen_regs+post", "seg_gen", "squeeze", "align1(all regs)", "filter/sort/parent", "mapq", "pair", "output", "", "", "", ""};
         fprintf(stderr, "[pmx align phase cycles per item]");
         for (int k = 0; k < 12; ++k) fprintf(stderr, " %s=%.0f", names[k], (double)h[k] / (double)n_items);
+        // sub-phases (thread-per-pair kernel): "seed+heap" then holds only the heap merge, "chain" only the compaction
+        fprintf(stderr, " [of which index lookups=%.0f stage+heapify=%.0f chain fill=%.0f backtrack=%.0f]", (double)h[16] / (double)n_items,
+                (double)h[17] / (double)n_items, (double)h[18] / (double)n_items, (double)h[19] / (double)n_items);
         fprintf(stderr, " [dp serve: cycles traceback=%.0f ksw=%.0f store=%.0f per request, diagonals=%.1f]", (double)h[12] / std::max<double>(1, (double)al->last_dp_requests),
                 (double)h[13] / std::max<double>(1, (double)al->last_dp_requests), (double)h[14] / std::max<double>(1, (double)al->last_dp_requests),
                 (double)h[15] / std::max<double>(1, (double)al->last_dp_requests));

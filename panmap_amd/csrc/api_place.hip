@@ -56,6 +56,11 @@ struct pmx_place {
     hipGraphExec_t level_graph_exec = nullptr;   // captured k_score_level chain
     const void* level_graph_sig[3] = {nullptr, nullptr, nullptr};
     DevBuf<double> metrics5, scores5, terms;
+    DevBuf<uint32_t> chain_off, chain_nodes;   // heavy-path chains (k_score_chains), heads in BFS order
+    DevBuf<uint64_t> chain_beg, chain_end;
+    int64_t n_chains = 0;
+    DevBuf<uint32_t> tree_done;            // k_score_tree: epoch of the call that last finished each node; [n_nodes] = status word
+    uint32_t tree_epoch = 0;
     DevBuf<uint64_t> dd_h1, dd_h2, dd_h1s, dd_key;   // --dedup scratch
     DevBuf<uint32_t> dd_idx, dd_idx2;
     DevBuf<uint8_t> dd_keep;
@@ -364,6 +369,40 @@ int pmx_place_create(pmx_ctx* ctx, const pmx_index* idx, pmx_place** out) {
     }
     pl->level_nodes.alloc(n);
     PMX_HIP(hipMemcpyAsync(pl->level_nodes.p, pl->h_order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    // heavy-path chains for k_score_chains: weight of a node = its change count (the serial adds it costs) plus a
+    // constant; a chain = head (the root or a non-heaviest child), then heaviest child after heaviest child
+    std::vector<uint32_t> h_chain_off, h_chain_nodes;
+    std::vector<uint64_t> h_chain_beg, h_chain_end;
+    {
+        std::vector<uint64_t> sw((size_t)n);
+        std::vector<uint32_t> heavy((size_t)n, UINT32_MAX), n_child((size_t)n, 0);
+        for (int64_t i = 0; i < n; ++i) sw[i] = (L->offsets[i + 1] - L->offsets[i]) + 64;
+        for (int64_t i = n - 1; i > 0; --i) sw[L->parent[i]] += sw[i];   // parents precede their children
+        for (int64_t i = 1; i < n; ++i) {
+            const uint32_t p = L->parent[i];
+            ++n_child[p];
+            if (heavy[p] == UINT32_MAX || sw[i] > sw[heavy[p]]) heavy[p] = (uint32_t)i;
+        }
+        h_chain_nodes.reserve((size_t)n); h_chain_beg.reserve((size_t)n); h_chain_end.reserve((size_t)n);
+        for (int64_t j = 0; j < n; ++j) {
+            const uint32_t hd = pl->h_order[j];
+            if (hd != 0 && heavy[L->parent[hd]] == hd) continue;   // inside its parent's chain
+            h_chain_off.push_back((uint32_t)h_chain_nodes.size());
+            for (uint32_t v = hd; v != UINT32_MAX; v = heavy[v]) {
+                h_chain_nodes.push_back(v | (n_child[v] >= 2 ? 0x80000000u : 0u));
+                h_chain_beg.push_back(L->offsets[v]);
+                h_chain_end.push_back(L->offsets[v + 1]);
+            }
+        }
+        h_chain_off.push_back((uint32_t)h_chain_nodes.size());
+        if ((int64_t)h_chain_nodes.size() != n) throw std::runtime_error("chain decomposition does not cover the tree");
+    }
+    pl->n_chains = (int64_t)h_chain_off.size() - 1;
+    pl->chain_off.alloc(h_chain_off.size()); pl->chain_nodes.alloc((size_t)n); pl->chain_beg.alloc((size_t)n); pl->chain_end.alloc((size_t)n);
+    PMX_HIP(hipMemcpyAsync(pl->chain_off.p, h_chain_off.data(), sizeof(uint32_t) * h_chain_off.size(), hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(pl->chain_nodes.p, h_chain_nodes.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(pl->chain_beg.p, h_chain_beg.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(pl->chain_end.p, h_chain_end.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     pl->counters.alloc(PMX_CTR_N);
     PMX_HIP(hipMemsetAsync(pl->counters.p, 0, sizeof(unsigned long long) * PMX_CTR_N, ctx->stream));
     pl->scalars.alloc(8);
@@ -671,7 +710,32 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
         }
     };
     const void* sig[3] = {(const void*)t_mag, (const void*)pl->metrics5.p, (const void*)pl->term_meta.p};
-    if (getenv("PMX_PLACE_NO_GRAPH")) launch_levels();
+    bool tree_kernel = false;
+    if (!getenv("PMX_PLACE_LEVEL_KERNELS")) {
+        // one persistent launch, parent -> child through per-node flags (k_score_tree); one workgroup per CU so that
+        // every wave is resident
+        if (!pl->tree_done.p) {
+            pl->tree_done.alloc((size_t)pl->n_nodes + 1);
+            PMX_HIP(hipMemsetAsync(pl->tree_done.p, 0, sizeof(uint32_t) * ((size_t)pl->n_nodes + 1), st));
+            pl->tree_epoch = 0;
+        }
+        if (++pl->tree_epoch == 0) {   // wrapped: start over
+            PMX_HIP(hipMemsetAsync(pl->tree_done.p, 0, sizeof(uint32_t) * ((size_t)pl->n_nodes + 1), st));
+            pl->tree_epoch = 1;
+        }
+        if (getenv("PMX_PLACE_TREE_KERNEL")) {   // per-node flags in BFS order (kept for comparison)
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ctx->n_cu, (pl->n_nodes + 3) / 4));
+            hipLaunchKernelGGL(k_score_tree, dim3(grid), dim3(256), 0, st, pl->level_nodes.p, pl->n_nodes, pl->parent.p, pl->offsets.p, t_mag, t_raw,
+                               t_cos, t_wc, t_lc, pl->term_meta.p, pl->metrics5.p, pl->counts2.p, pl->tree_done.p, pl->tree_epoch,
+                               pl->tree_done.p + pl->n_nodes);
+        } else {
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ctx->n_cu, (pl->n_chains + 3) / 4));
+            hipLaunchKernelGGL(k_score_chains, dim3(grid), dim3(256), 0, st, pl->chain_off.p, pl->n_chains, pl->chain_nodes.p, pl->chain_beg.p,
+                               pl->chain_end.p, pl->parent.p, t_mag, t_raw, t_cos, t_wc, t_lc, pl->term_meta.p, pl->metrics5.p, pl->counts2.p,
+                               pl->tree_done.p, pl->tree_epoch, pl->tree_done.p + pl->n_nodes);
+        }
+        tree_kernel = true;
+    } else if (getenv("PMX_PLACE_NO_GRAPH")) launch_levels();
     else {
         if (!pl->level_graph_exec || pl->level_graph_sig[0] != sig[0] || pl->level_graph_sig[1] != sig[1] || pl->level_graph_sig[2] != sig[2]) {
             if (pl->level_graph_exec) { (void)hipGraphExecDestroy(pl->level_graph_exec); pl->level_graph_exec = nullptr; }
@@ -691,7 +755,13 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     PMX_HIP(hipGetLastError());
     pl->h_scores.resize(5 * (size_t)pl->n_nodes);
     PMX_HIP(hipMemcpyAsync(pl->h_scores.data(), pl->scores5.p, sizeof(double) * 5 * (size_t)pl->n_nodes, hipMemcpyDeviceToHost, st));
+    uint32_t tree_status = 0;
+    if (tree_kernel) PMX_HIP(hipMemcpyAsync(&tree_status, pl->tree_done.p + pl->n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PMX_HIP(hipStreamSynchronize(st));
+    if (tree_status != 0) {
+        PMX_HIP(hipMemsetAsync(pl->tree_done.p + pl->n_nodes, 0, sizeof(uint32_t), st));
+        throw std::runtime_error("k_score_tree: a wave timed out waiting for its parent node");
+    }
 
     // ---- sequential best/tie rule in BFS visit order (src/placement.cpp:355-401)
     Best best[5];

@@ -606,6 +606,167 @@ k_score_level(const uint32_t* __restrict__ level_nodes, int64_t n_level, const u
     if (lane == 0) { counts2[2 * (size_t)nd + 0] = c0; counts2[2 * (size_t)nd + 1] = c1; }
 }
 
+// Pass 2 as ONE persistent launch: wave w takes the BFS positions w, w + W, w + 2W, ... (W = resident waves) and
+// waits for its node's parent through a per-node flag instead of a kernel boundary per level.  A parent always
+// sits at an earlier BFS position, and every wave works through its positions in ascending order, so the wave that
+// owns the earliest unfinished position never waits on anything unfinished: no deadlock as long as all W waves are
+// resident (the host launches at most one workgroup per CU).  The arithmetic per node is k_score_level's, bit for bit.
+// done[] holds the epoch of the call that last finished the node (no clearing between calls); a wave that polls
+// longer than any sane run sets *status and every wave leaves.
+__global__ void __launch_bounds__(256)
+k_score_tree(const uint32_t* __restrict__ order, int64_t n_nodes, const uint32_t* __restrict__ parent, const uint64_t* __restrict__ offsets,
+             const double* __restrict__ t_mag, const double* __restrict__ t_raw, const double* __restrict__ t_cos,
+             const double* __restrict__ t_wc, const double* __restrict__ t_lc, const uint8_t* __restrict__ t_meta, double* metrics5,
+             int64_t* counts2, uint32_t* done, uint32_t epoch, uint32_t* status) {
+    __shared__ double stage[4][64 * 5];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    double* sh = stage[wib];
+    for (int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib; p < n_nodes; p += n_waves) {
+        const uint32_t nd = order[p];
+        double acc = 0.0;              // lane k < 5: accumulator k (raw, cos, wc, lc, mag)
+        int64_t c0 = 0, c1 = 0;
+        const uint64_t beg = offsets[nd], end = offsets[nd + 1];
+        // the node's own terms do not depend on the parent: in flight while the wave waits for it
+        ScoreTerms cur = load_terms(beg + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+        ScoreTerms nx1 = load_terms(beg + 64 + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+        if (nd != 0) {
+            const uint32_t pa = parent[nd];
+            uint32_t polls = 0;
+            bool ok = true;
+            while (__hip_atomic_load(&done[pa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++polls > (1u << 24) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+            }
+            if (!ok) {   // uniform: every lane polls the same flag
+                if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane < 5) acc = metrics5[5 * (size_t)pa + lane];
+            c0 = counts2[2 * (size_t)pa + 0]; c1 = counts2[2 * (size_t)pa + 1];
+        }
+        for (uint64_t base = beg; base < end; base += 64) {
+            const ScoreTerms nx2 = load_terms(base + 128 + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+            const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+            c1 += wave_sum_int(cur.d_uniq);
+            c0 += wave_sum_int(cur.d_pres);
+            sh[lane * 5 + 0] = cur.d_raw; sh[lane * 5 + 1] = cur.d_cos; sh[lane * 5 + 2] = cur.d_wc; sh[lane * 5 + 3] = cur.d_lc;
+            sh[lane * 5 + 4] = cur.d_mag;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 5) {
+                int j = 0;
+                for (; j + 8 <= cnt; j += 8) {
+                    const double v0 = sh[(j + 0) * 5 + lane], v1 = sh[(j + 1) * 5 + lane], v2 = sh[(j + 2) * 5 + lane],
+                                 v3 = sh[(j + 3) * 5 + lane], v4 = sh[(j + 4) * 5 + lane], v5 = sh[(j + 5) * 5 + lane],
+                                 v6 = sh[(j + 6) * 5 + lane], v7 = sh[(j + 7) * 5 + lane];
+                    acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+                }
+                for (; j < cnt; ++j) acc += sh[j * 5 + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            cur = nx1;
+            nx1 = nx2;
+        }
+        if (lane < 5) metrics5[5 * (size_t)nd + lane] = acc;
+        if (lane == 0) { counts2[2 * (size_t)nd + 0] = c0; counts2[2 * (size_t)nd + 1] = c1; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the wave's stores are visible before the flag
+        if (lane == 0) __hip_atomic_store(&done[nd], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Pass 2, heavy-path form: the host cuts the tree into chains (a node followed by its heaviest child, and so on
+// down to a leaf) and one wave walks one chain with the five accumulators staying in registers from node to node.
+// Only the HEAD of a chain waits on a flag (its parent lies in a chain that started earlier), and only nodes with
+// two or more children publish one: a root-to-leaf path crosses O(log n) chain boundaries instead of one kernel
+// boundary (or flag) per level.  chain_nodes[k] = node id | publish << 31; chain_beg/end[k] = the node's change
+// range, gathered in chain order so that the next node's terms are requested while this one is being added up.
+// Chains are sorted by the BFS position of their head and wave w takes chains w, w + W, ...: the chain that holds
+// a head's parent starts earlier, so the earliest unfinished chain never waits on an unfinished one (all W waves
+// are resident: at most one workgroup per CU).  Per node the arithmetic is k_score_level's, bit for bit.
+__global__ void __launch_bounds__(256)
+k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const uint32_t* __restrict__ chain_nodes,
+               const uint64_t* __restrict__ chain_beg, const uint64_t* __restrict__ chain_end, const uint32_t* __restrict__ parent,
+               const double* __restrict__ t_mag, const double* __restrict__ t_raw, const double* __restrict__ t_cos,
+               const double* __restrict__ t_wc, const double* __restrict__ t_lc, const uint8_t* __restrict__ t_meta, double* metrics5,
+               int64_t* counts2, uint32_t* done, uint32_t epoch, uint32_t* status) {
+    __shared__ double stage[4][64 * 5];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    double* sh = stage[wib];
+    for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib; c < n_chains; c += n_waves) {
+        const uint32_t cb = chain_off[c], ce = chain_off[c + 1];
+        uint32_t ent = chain_nodes[cb];
+        uint64_t beg = chain_beg[cb], end = chain_end[cb];
+        // lookahead: the ranges of the next node, whose terms are requested one node ahead
+        uint32_t ent2 = cb + 1 < ce ? chain_nodes[cb + 1] : 0u;
+        uint64_t beg2 = cb + 1 < ce ? chain_beg[cb + 1] : 0, end2 = cb + 1 < ce ? chain_end[cb + 1] : 0;
+        ScoreTerms cur = load_terms(beg + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+        ScoreTerms nx1 = load_terms(beg + 64 + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+        double acc = 0.0;              // lane k < 5: accumulator k (raw, cos, wc, lc, mag)
+        int64_t c0 = 0, c1 = 0;
+        const uint32_t head = ent & 0x7fffffffu;
+        if (head != 0) {
+            const uint32_t pa = parent[head];
+            uint32_t polls = 0;
+            bool ok = true;
+            while (__hip_atomic_load(&done[pa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > (1u << 24) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+            }
+            if (!ok) {   // uniform: every lane polls the same flag
+                if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (lane < 5) acc = metrics5[5 * (size_t)pa + lane];
+            c0 = counts2[2 * (size_t)pa + 0]; c1 = counts2[2 * (size_t)pa + 1];
+        }
+        for (uint32_t k = cb; k < ce; ++k) {
+            const uint32_t nd = ent & 0x7fffffffu;
+            const bool publish = (ent >> 31) != 0;
+            // request the next node's first two chunks and the ranges of the node after it
+            const ScoreTerms f_cur = load_terms(beg2 + lane, end2, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+            const ScoreTerms f_nx1 = load_terms(beg2 + 64 + lane, end2, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+            const uint32_t ent3 = k + 2 < ce ? chain_nodes[k + 2] : 0u;
+            const uint64_t beg3 = k + 2 < ce ? chain_beg[k + 2] : 0, end3 = k + 2 < ce ? chain_end[k + 2] : 0;
+            for (uint64_t base = beg; base < end; base += 64) {
+                const ScoreTerms nx2 = load_terms(base + 128 + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+                const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+                c1 += wave_sum_int(cur.d_uniq);
+                c0 += wave_sum_int(cur.d_pres);
+                sh[lane * 5 + 0] = cur.d_raw; sh[lane * 5 + 1] = cur.d_cos; sh[lane * 5 + 2] = cur.d_wc; sh[lane * 5 + 3] = cur.d_lc;
+                sh[lane * 5 + 4] = cur.d_mag;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 5) {
+                    int j = 0;
+                    for (; j + 8 <= cnt; j += 8) {
+                        const double v0 = sh[(j + 0) * 5 + lane], v1 = sh[(j + 1) * 5 + lane], v2 = sh[(j + 2) * 5 + lane],
+                                     v3 = sh[(j + 3) * 5 + lane], v4 = sh[(j + 4) * 5 + lane], v5 = sh[(j + 5) * 5 + lane],
+                                     v6 = sh[(j + 6) * 5 + lane], v7 = sh[(j + 7) * 5 + lane];
+                        acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+                    }
+                    for (; j < cnt; ++j) acc += sh[j * 5 + lane];
+                }
+                __builtin_amdgcn_wave_barrier();
+                cur = nx1;
+                nx1 = nx2;
+            }
+            if (lane < 5) metrics5[5 * (size_t)nd + lane] = acc;
+            if (lane == 0) { counts2[2 * (size_t)nd + 0] = c0; counts2[2 * (size_t)nd + 1] = c1; }
+            if (publish) {   // children in other chains wait for this node
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_store(&done[nd], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ent = ent2; beg = beg2; end = end2;
+            ent2 = ent3; beg2 = beg3; end2 = end3;
+            cur = f_cur; nx1 = f_nx1;
+        }
+    }
+}
+
 // score getters (src/placement.hpp:120-149); TSV order log_raw, log_cosine, containment,
 // weighted_containment, log_containment
 __global__ void k_score_getters(const double* __restrict__ metrics5, const int64_t* __restrict__ counts2, int64_t n_nodes,
