@@ -117,7 +117,130 @@ PMX_HD void sketch_segment_t(Work& W, const Ring& buf, Ptr<const uint8_t> seq, i
 #undef PMX_MV_PUSH
 }
 
+#if PMX_W == 1
+// The same sketch for the scalar execution models (thread per pair, host) with the window ring in REGISTERS
+// (w <= WMAX): sketch_segment_t re-scans the ring entry by entry whenever the minimum slides out of the window, and in
+// a wave of 64 reads some lane needs that at nearly every base, so every base paid ~2w dependent ring reads.  Here
+// the ring is an unrolled array (static indices; the dynamic slot is written by compare-select), the re-scan is a
+// min / arg-max-age reduction over registers, and the "identical minimizer in the window" loops only run when a
+// compare mask says there is one.  Entry order, tie rules and the emitted minimizers are exactly sketch_segment_t's:
+//  * re-scan order is j = buf_pos+1 .. w-1, 0 .. buf_pos with '>=': among equal x the LAST in that order wins, i.e.
+//    the largest age rank (j - buf_pos - 1) mod w;
+//  * an entry is "another occurrence" iff its x equals the minimum's and it is not the minimum's slot (y holds the
+//    position, unique per slot; invalid entries are excluded by mn.x != UINT64_MAX).
+template <int WMAX>
+PMX_HD void sketch_segment_reg(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
+    const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
+    const uint64_t y_hi = (uint64_t)rid << 32;
+    uint64_t kmer0 = 0, kmer1 = 0;
+    int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
+    PMX_LDS(&W); PMX_LDS(seq);
+    Ptr<A128> mvp = W.mv; PMX_LDS(mvp);
+    // the output cursor and its bound live in registers for the whole segment (W is memory to the compiler)
+    int n_mv = W.n_mv;
+    const int max_mini = W.caps.max_mini;
+    bool overflow = false;
+    A128 mn;
+    mn.x = mn.y = UINT64_MAX;
+    uint64_t xs[WMAX];
+    uint32_t ys[WMAX];   // low 32 bits of y (the high half is rid; an invalid entry has x == UINT64_MAX)
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j) { xs[j] = UINT64_MAX; ys[j] = 0xffffffffu; }   // slots >= w stay invalid forever
+    auto ring_get = [&](int j) {
+        A128 v;
+        v.x = UINT64_MAX;
+        uint32_t yl = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < WMAX; ++q)
+            if (q == j) { v.x = xs[q]; yl = ys[q]; }
+        v.y = v.x == UINT64_MAX ? UINT64_MAX : (y_hi | yl);
+        return v;
+    };
+#define PMX_MV_PUSH(val)                             \
+    do {                                             \
+        if (n_mv < max_mini) mvp[n_mv++] = (val);    \
+        else overflow = true;                        \
+    } while (0)
+    ByteReader seq_r(seq);
+    for (int i = 0; i < len; ++i) {
+        const int c = (int)seq_r[i];
+        A128 info;
+        info.x = info.y = UINT64_MAX;
+        if (c < 4) {
+            kmer_span = l + 1 < k ? l + 1 : k;
+            kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+            kmer1 = (kmer1 >> 2) | (uint64_t)(3 ^ c) << shift1;
+            if (kmer0 == kmer1) continue;   // strand-symmetric k-mer: skipped without advancing the window
+            const int z = kmer0 < kmer1 ? 0 : 1;
+            ++l;
+            if (l >= k && kmer_span < 256) {
+                info.x = mz_hash64(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
+                info.y = y_hi | (uint32_t)i << 1 | (uint32_t)z;
+            }
+        } else {
+            l = 0;
+            kmer_span = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j)
+            if (j == buf_pos) { xs[j] = info.x; ys[j] = (uint32_t)info.y; }
+        if (l == w + k - 1 && mn.x != UINT64_MAX) {   // first full window: emit earlier identical k-mers
+            for (int j = buf_pos + 1; j < w; ++j)
+                { const A128 bj = ring_get(j); if (mn.x == bj.x && bj.y != mn.y) PMX_MV_PUSH(bj); }
+            for (int j = 0; j < buf_pos; ++j)
+                { const A128 bj = ring_get(j); if (mn.x == bj.x && bj.y != mn.y) PMX_MV_PUSH(bj); }
+        }
+        // the three outcomes of sketch_segment_t's if / else-if, with ONE push site and a branch-free re-scan (in a
+        // wave of 64 reads some lane needs the re-scan at almost every base, so it is computed unconditionally)
+        const bool new_min = info.x <= mn.x;
+        const bool slid = !new_min && buf_pos == min_pos;
+        if (mn.x != UINT64_MAX && ((new_min && l >= w + k) || (slid && l >= w + k - 1))) PMX_MV_PUSH(mn);
+        uint64_t m = UINT64_MAX;
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j) m = xs[j] < m ? xs[j] : m;
+        uint32_t eq = 0;   // slots that hold the minimum (never empty; slots >= w only when everything is invalid)
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j) eq |= xs[j] == m ? 1u << j : 0u;
+        // last in scan order (j = buf_pos+1 .. w-1, 0 .. buf_pos, '>=') = the largest slot <= buf_pos if there is
+        // one, else the largest slot
+        const uint32_t lo = eq & ((2u << buf_pos) - 1u);
+        const int best_j = 31 - __builtin_clz(lo ? lo : eq);
+        uint32_t best_y = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < WMAX; ++j)
+            if (j == best_j) best_y = ys[j];
+        if (new_min) {
+            mn = info;
+            min_pos = buf_pos;
+        } else if (slid) {
+            mn.x = m;
+            mn.y = m == UINT64_MAX ? UINT64_MAX : (y_hi | best_y);
+            min_pos = best_j;
+            if (l >= w + k - 1 && mn.x != UINT64_MAX && (eq & ~(1u << min_pos)) != 0u) {   // other occurrences of the minimum
+                for (int j = buf_pos + 1; j < w; ++j)
+                    if ((eq >> j & 1u) && j != min_pos) PMX_MV_PUSH(ring_get(j));
+                for (int j = 0; j <= buf_pos; ++j)
+                    if ((eq >> j & 1u) && j != min_pos) PMX_MV_PUSH(ring_get(j));
+            }
+        }
+        if (++buf_pos == w) buf_pos = 0;
+    }
+    if (mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
+#undef PMX_MV_PUSH
+    W.n_mv = n_mv;
+    if (overflow) W.status |= PMX_ST_OVERFLOW;
+}
+#endif
+
 PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
+#if PMX_W == 1
+    if (w >= 1 && w <= 16) {   // the ring is unrolled to the next size class (sr preset: w = 11)
+        if (w <= 8) sketch_segment_reg<8>(W, seq, len, w, k, rid);
+        else if (w <= 12) sketch_segment_reg<12>(W, seq, len, w, k, rid);
+        else sketch_segment_reg<16>(W, seq, len, w, k, rid);
+        return;
+    }
+#endif
 #ifdef PMX_INTERLEAVED
     if (W.sk_lds_x) {
         RingLds ring{W.sk_lds_x, W.sk_lds_y, (uint64_t)rid << 32};
