@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpanmap_amd.so")
+# PMX_LIB_PATH: load another build of the same library (A/B runs of two builds on one GPU box)
+LIB_PATH = os.environ.get("PMX_LIB_PATH") or os.path.join(_HERE, "libpanmap_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -47,6 +47,34 @@ PMX_HD int32_t chain_score(const A128 ai, const A128 aj, int32_t max_dist_x, int
     return sc;
 }
 
+// The same function on the fields of two packed cells, written without early returns (selects instead of
+// branches: in the thread-per-pair kernel 64 lanes evaluate different anchor pairs at once, and every early return
+// of chain_score costs the wave a divergent branch).  Same integer and float expressions in the same order; the
+// values computed for a pair that chain_score would have rejected early are discarded.
+PMX_HD int32_t chain_score_sel(uint32_t xi, int32_t yi, int32_t sidi, uint32_t xj, int32_t yj, int32_t sidj, int32_t q_span, int32_t max_dist_x,
+                               int32_t max_dist_y, int32_t bw, float chn_pen_gap, float chn_pen_skip, int n_seg) {
+    const int32_t dq = yi - yj;
+    const int32_t dr = (int32_t)(xi - xj);
+    const bool same = sidi == sidj;
+    const int32_t dd = dr > dq ? dr - dq : dq - dr;
+    bool bad = dq <= 0 || dq > max_dist_x;
+    bad = bad || (same && (dr == 0 || dq > max_dist_y));
+    bad = bad || (same && dd > bw);
+    bad = bad || (n_seg > 1 && same && dr > max_dist_y);
+    const int32_t dg = dr < dq ? dr : dq;
+    int32_t sc = q_span < dg ? q_span : dg;
+    const bool pen = dd != 0 || dg > q_span;
+    const float lin_pen = chn_pen_gap * (float)dd + chn_pen_skip * (float)dg;
+    const float log_pen = dd >= 1 ? mg_log2f((float)((uint32_t)dd + 1u)) : 0.0f;
+    const float pen_same = lin_pen + .5f * log_pen, pen_diff = lin_pen < log_pen ? lin_pen : log_pen;
+    // (int) of a float: only meaningful (and only used) for pairs that are not rejected; clamp keeps the cast defined
+    const float pf = same ? pen_same : pen_diff;
+    const float pc = pf < -1.0e9f ? -1.0e9f : (pf > 1.0e9f ? 1.0e9f : pf);
+    const int32_t sc_pen = (!same && dr == 0) ? sc + 1 : sc - (int)pc;
+    sc = pen ? sc_pen : sc;
+    return bad ? INT32_MIN : sc;
+}
+
 // mg_chain_bk_end (lchain.c:9-25)
 PMX_HD int64_t chain_bk_end(int32_t max_drop, Ptr<const A128> z, Ptr<ChainCell> c, int64_t k) {
     PMX_LDS(z); PMX_LDS(c);
@@ -250,19 +278,23 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
 #pragma unroll
                 for (int s_ = 3; s_ >= 0; --s_) {
                     const int64_t j = g * 4 + s_;
-                    if (stop || j >= i || j < st) continue;
                     const PackedCell cj = G.c[s_];
-                    int32_t sc = chain_score(ri, packed_anchor(cj), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
-                    if (sc == INT32_MIN) continue;
-                    sc += cj.f;
-                    if (sc > max_f) {
-                        max_f = sc;
-                        max_j = j;
-                        if (n_skip > 0) --n_skip;
-                    } else if (use_mask ? (mark >> (j - st) & 1) != 0 : packed_cell(pk4, j).t == (uint16_t)i) {
-                        if (++n_skip > max_skip) { stop = true; end_j = j; continue; }
-                    }
-                    if (cj.p1) {
+                    const int32_t sc0 = chain_score_sel(ci.x_lo, (int32_t)ci.y_lo, (int32_t)ci.seg, cj.x_lo, (int32_t)cj.y_lo, (int32_t)cj.seg,
+                                                        (int32_t)cj.span, max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                    const bool valid = !stop && j < i && j >= st && sc0 != INT32_MIN;
+                    const int32_t sc = sc0 + cj.f;
+                    const bool better = valid && sc > max_f;
+                    bool marked = false;
+                    if (use_mask) marked = valid && !better && (mark >> ((j - st) & 63) & 1) != 0;
+                    else if (valid && !better) marked = packed_cell(pk4, j).t == (uint16_t)i;
+                    max_f = better ? sc : max_f;
+                    max_j = better ? j : max_j;
+                    n_skip += (better && n_skip > 0) ? -1 : 0;
+                    n_skip += marked ? 1 : 0;
+                    const bool brk = marked && n_skip > max_skip;   // the reference breaks before marking p[j]
+                    end_j = brk ? j : end_j;
+                    stop = stop || brk;
+                    if (valid && !brk && cj.p1) {
                         const int64_t k = (int64_t)cj.p1 - 1;
                         if (!use_mask) packed_cell(pk4, k).t = (uint16_t)i;
                         else if (k >= st) mark |= 1ULL << (k - st);
