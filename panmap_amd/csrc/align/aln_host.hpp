@@ -73,8 +73,7 @@ inline Opt make_opt(int mean_read_len) {
 
 struct HostRefIndex {
     std::vector<uint8_t> seq;
-    std::vector<uint64_t> ht_key;
-    std::vector<uint32_t> ht_off, ht_cnt;
+    std::vector<HtEnt> ht;
     std::vector<uint64_t> pos;
     std::vector<float> logf_ratio, logf_int;
     std::vector<uint32_t> occ;   // occurrences per distinct minimizer
@@ -83,10 +82,8 @@ struct HostRefIndex {
         RefIndex r;
         r.seq = seq.data();
         r.len = (int32_t)seq.size() - 8;   // seq carries 8 bytes of padding
-        r.ht_mask = (uint32_t)ht_key.size() - 1;
-        r.ht_key = ht_key.data();
-        r.ht_off = ht_off.data();
-        r.ht_cnt = ht_cnt.data();
+        r.ht_mask = (uint32_t)ht.size() - 1;
+        r.ht = ht.data();
         r.pos = pos.data();
         r.logf_ratio = logf_ratio.data();
         r.logf_int = logf_int.data();
@@ -133,9 +130,7 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
         if (i == 0 || mv[i].x >> 8 != mv[i - 1].x >> 8) ++n_keys;
     size_t cap = 16;
     while (cap < n_keys * 2 + 2) cap <<= 1;
-    out.ht_key.assign(cap, UINT64_MAX);
-    out.ht_off.assign(cap, 0);
-    out.ht_cnt.assign(cap, 0);
+    out.ht.assign(cap, HtEnt{UINT64_MAX, 0u, 0u});
     out.pos.resize(mv.size());
     for (size_t i = 0; i < mv.size();) {
         size_t j = i;
@@ -143,10 +138,8 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
         for (size_t q = i; q < j; ++q) out.pos[q] = mv[q].y;
         const uint64_t key = mv[i].x >> 8;
         uint32_t slot = (uint32_t)mix64(key) & (uint32_t)(cap - 1);
-        while (out.ht_key[slot] != UINT64_MAX) slot = (slot + 1) & (uint32_t)(cap - 1);
-        out.ht_key[slot] = key;
-        out.ht_off[slot] = (uint32_t)i;
-        out.ht_cnt[slot] = (uint32_t)(j - i);
+        while (out.ht[slot].key != UINT64_MAX) slot = (slot + 1) & (uint32_t)(cap - 1);
+        out.ht[slot] = HtEnt{key, (uint32_t)i, (uint32_t)(j - i)};
         out.occ.push_back((uint32_t)(j - i));
         i = j;
     }

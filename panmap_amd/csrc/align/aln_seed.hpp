@@ -272,9 +272,9 @@ PMX_HD void collect_minimizers(Work& W, const Opt& o) {
 PMX_HD uint32_t index_lookup(const RefIndex& ri, uint64_t minier, uint32_t* off) {
     uint32_t slot = (uint32_t)mix64(minier) & ri.ht_mask;
     while (true) {
-        const uint64_t key = ri.ht_key[slot];
-        if (key == minier) { *off = ri.ht_off[slot]; return ri.ht_cnt[slot]; }
-        if (key == UINT64_MAX) return 0;
+        const HtEnt e = ri.ht[slot];
+        if (e.key == minier) { *off = e.off; return e.cnt; }
+        if (e.key == UINT64_MAX) return 0;
         slot = (slot + 1) & ri.ht_mask;
     }
 }
@@ -291,6 +291,27 @@ PMX_HD void heap_down_min_x(Ptr<A128> l, int i, int n) {   // "less" = a.x > b.x
         i = k;
     }
     l[i] = tmp;
+}
+// heap_down_min_x(l, 0, n) for a root that is about to be overwritten with tmp: sifts tmp down from the root
+// without first storing it, reads both children of a node with independent loads, and returns the new root so the
+// caller does not have to load it back (same comparisons in the same order as ks_heapdown)
+PMX_HD A128 heap_replace_root_min_x(Ptr<A128> l, int n, const A128 tmp) {
+    PMX_LDS(l);
+    int i = 0, k;
+    A128 root = tmp;
+    while ((k = (i << 1) + 1) < n) {
+        A128 ck = l[k];
+        if (k != n - 1) {
+            const A128 ck1 = l[k + 1];
+            if (ck.x > ck1.x) { ++k; ck = ck1; }
+        }
+        if (ck.x > tmp.x) break;
+        l[i] = ck;
+        if (i == 0) root = ck;
+        i = k;
+    }
+    l[i] = tmp;
+    return root;
 }
 PMX_HD void heap_down_max_u64(uint64_t* l, int i, int n) {   // ks_heapdown_uint64_t: max-heap
     int k = i;
@@ -354,6 +375,58 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
     Ptr<SeedB> seeds_b = W.seeds_b; PMX_LDS(seeds_b);
     Ptr<uint64_t> mini_pos = W.mini_pos;   // global scratch (only mm_est_err would read it)
     int n_m0 = 0;
+#if PMX_W == 1
+    // scalar models: four probes in flight at a time (their first loads do not depend on each other), and the seed
+    // records are built straight from the probe results (no pass through heap[] scratch)
+    {
+        const int n_mv = W.n_mv;
+        uint64_t prev_key = 0;          // mv[i - 1].x >> 8
+        for (int i0 = 0; i0 < n_mv; i0 += 4) {
+            A128 m[5];
+            HtEnt e[4];
+            uint32_t slot[4];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                m[b].x = m[b].y = 0;
+                if (i0 + b < n_mv) m[b] = mv[i0 + b];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                slot[b] = (uint32_t)mix64(m[b].x >> 8) & ri.ht_mask;
+                e[b] = HtEnt{UINT64_MAX, 0u, 0u};
+                if (i0 + b < n_mv) e[b] = ri.ht[slot[b]];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (i0 + b >= n_mv) break;
+                const uint64_t key = m[b].x >> 8;
+                while (e[b].key != key && e[b].key != UINT64_MAX) {   // collision: keep probing
+                    slot[b] = (slot[b] + 1) & ri.ht_mask;
+                    e[b] = ri.ht[slot[b]];
+                }
+                const uint32_t t = e[b].key == key ? e[b].cnt : 0u;
+                if (t != 0) {
+                    const int i = i0 + b;
+                    SeedA q;
+                    SeedB qb;
+                    q.q_pos = (uint32_t)m[b].y;
+                    qb.q_span = (uint32_t)(m[b].x & 0xff);
+                    q.off = e[b].off;
+                    q.n = t;
+                    qb.seg_id = (uint32_t)(m[b].y >> 32);
+                    qb.is_tandem = q.flt = 0;
+                    qb.pad = 0;
+                    if (i > 0 && key == prev_key) qb.is_tandem = 1;
+                    if (i < n_mv - 1 && key == m[b + 1].x >> 8) qb.is_tandem = 1;
+                    seeds[n_m0] = q;
+                    seeds_b[n_m0] = qb;
+                    ++n_m0;
+                }
+                prev_key = key;
+            }
+        }
+    }
+#else
     for (int i = lane_id(); i < W.n_mv; i += PMX_W) {
         uint32_t off = 0;
         const uint32_t t = index_lookup(ri, mv[i].x >> 8, &off);
@@ -381,6 +454,7 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
         seeds_b[n_m0] = qb;
         ++n_m0;
     }
+#endif
     wave_sync();
     if (o.occ_dist > 0 && o.max_max_occ > max_occ) seed_select(n_m0, seeds, qlen, max_occ, o.max_max_occ, o.occ_dist);
     else
@@ -454,10 +528,14 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     for (int q = (heap_size >> 1) - 1; q >= 0; --q) heap_down_min_x(heap, q, heap_size);
     int64_t n_for = 0, n_rev = 0;
     PMX_STAMP(W, 17);
-    while (heap_size > 0) {
-        const SeedA q = seeds[heap[0].y >> 32];
-        const SeedB qb = seeds_b[heap[0].y >> 32];
-        const uint64_t r = heap[0].x;
+    A128 top;
+    top.x = top.y = 0;
+    if (heap_size > 0) top = heap[0];
+    while (heap_size > 0) {   // top == heap[0], kept in registers from pop to pop
+        const uint32_t si = (uint32_t)(top.y >> 32);
+        const SeedA q = seeds[si];
+        const SeedB qb = seeds_b[si];
+        const uint64_t r = top.x;
         const int32_t rpos = (int32_t)((uint32_t)r >> 1);
         A128 p;
         if ((r & 1) == (q.q_pos & 1)) {   // forward strand
@@ -473,14 +551,15 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
             if (qb.is_tandem) p.y |= PMX_SEED_TANDEM;
             a[n_a - (++n_rev)] = p;
         }
-        if ((uint32_t)heap[0].y < q.n - 1) {
-            ++heap[0].y;
-            heap[0].x = pc[seeds[heap[0].y >> 32].flt + (uint32_t)heap[0].y];
-        } else {
-            heap[0] = heap[heap_size - 1];
+        A128 nt;
+        if ((uint32_t)top.y < q.n - 1) {   // next occurrence of the same seed
+            nt.y = top.y + 1;
+            nt.x = pc[q.flt + (uint32_t)nt.y];
+        } else {                            // list exhausted: the last heap element takes the root
+            nt = heap[heap_size - 1];
             --heap_size;
         }
-        heap_down_min_x(heap, 0, heap_size);
+        top = heap_replace_root_min_x(heap, heap_size, nt);
     }
     // the reverse-strand block was filled back to front
     for (int64_t j = 0; j < n_rev >> 1; ++j) {

@@ -238,13 +238,15 @@ struct Opt {
 // Device-resident minimizer index of ONE reference sequence (replaces mm_idx_str / mm_idx_get,
 // index.c:81-99, 408-451): open-addressing table keyed by the minimizer value, occurrence lists sorted
 // ascending (index.c:252 sorts by position).
+struct HtEnt {              // one probe = one 16-byte load
+    uint64_t key;           // minimizer (x >> 8); UINT64_MAX = empty
+    uint32_t off, cnt;      // first occurrence in pos[], number of occurrences
+};
 struct RefIndex {
     const uint8_t* seq;     // nt4 codes 0..4, ref_len bytes
     int32_t len;
     uint32_t ht_mask;       // table size - 1
-    const uint64_t* ht_key; // minimizer (x >> 8); UINT64_MAX = empty
-    const uint32_t* ht_off; // first occurrence in pos[]
-    const uint32_t* ht_cnt; // number of occurrences
+    const HtEnt* ht;
     const uint64_t* pos;    // y values: rid<<32 | lastPos<<1 | strand
     // logf tables computed by the host libm (hit.c:440-457, pe.c:160): bit-identical mapq without
     // relying on a device logf.   logf_ratio[d] = logf((float)d / a) ; logf_int[n] = logf((float)n)

@@ -21,8 +21,8 @@ struct pmx_aligner {
     Opt opt;
     HostRefIndex host;
     DevBuf<uint8_t> d_seq;
-    DevBuf<uint64_t> d_key, d_pos;
-    DevBuf<uint32_t> d_off, d_cnt;
+    DevBuf<uint64_t> d_pos;
+    DevBuf<HtEnt> d_ht;
     DevBuf<float> d_logf_ratio, d_logf_int;
     RefIndex ri;
     int mean_len = 150;
@@ -76,19 +76,15 @@ int pmx_aligner_set_reference(pmx_ctx* ctx, pmx_aligner* al, const char* referen
     const int max_score = std::max(8192, (mean_read_len * 4 + 1024) * (al->opt.a + 1));
     build_ref_index(reference, ref_len, al->opt, max_score, al->host);
     upload(al->d_seq, al->host.seq, ctx->stream);
-    upload(al->d_key, al->host.ht_key, ctx->stream);
-    upload(al->d_off, al->host.ht_off, ctx->stream);
-    upload(al->d_cnt, al->host.ht_cnt, ctx->stream);
+    upload(al->d_ht, al->host.ht, ctx->stream);
     upload(al->d_pos, al->host.pos, ctx->stream);
     upload(al->d_logf_ratio, al->host.logf_ratio, ctx->stream);
     upload(al->d_logf_int, al->host.logf_int, ctx->stream);
     RefIndex& r = al->ri;
     r.seq = al->d_seq.p;
     r.len = (int32_t)ref_len;
-    r.ht_mask = (uint32_t)al->host.ht_key.size() - 1;
-    r.ht_key = al->d_key.p;
-    r.ht_off = al->d_off.p;
-    r.ht_cnt = al->d_cnt.p;
+    r.ht_mask = (uint32_t)al->host.ht.size() - 1;
+    r.ht = al->d_ht.p;
     r.pos = al->d_pos.p;
     r.logf_ratio = al->d_logf_ratio.p;
     r.logf_int = al->d_logf_int.p;
