@@ -502,6 +502,7 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
     } else { re0 = re; qe0 = qe; }
     if (re0 - rs0 > W.caps.max_tlen || re0 <= rs0) { W.status |= PMX_ST_OVERFLOW; return; }
 
+    PMX_STAMP(W, 20);
     if (qs > 0 && rs > 0) {   // left extension (align.c:704-722)
         Ptr<uint8_t> qseq = qseq0[rev] + qs0; PMX_LDS(qseq);
         bool decided = false;
@@ -531,14 +532,27 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
         if (!decided) seq_rev(qs - qs0, qseq);
     } else { rs1 = rs; qs1 = qs; }
     re1 = rs; qe1 = qs;
+    PMX_STAMP(W, 21);
 
-    for (int32_t i = 1; i < cnt1; ++i) {   // gap filling (align.c:727-797)
-        if ((a[as1 + i].y & (PMX_SEED_IGNORE | PMX_SEED_TANDEM)) && i != cnt1 - 1) continue;
-        adjust_minier(o, a[as1 + i], &re, &qe);
-        re1 = re; qe1 = qe;
-        if (i == cnt1 - 1 || (a[as1 + i].y & PMX_SEED_LONG_JOIN) || (qe - qs >= o.min_ksw_len && re - rs >= o.min_ksw_len)) {
+    // gap filling (align.c:727-797).  The reference walks the anchors one by one and fills whenever the stretch
+    // since the last fill is long enough; here the walk is split into a cheap scan to the next anchor that closes a
+    // fill and the fill itself, so that in the thread-per-pair kernel the lanes of a wave meet at the fill (with one
+    // flat loop a wave would run the fill branch at nearly every anchor, for whichever lanes happen to fill there).
+    for (int32_t i = 1; i < cnt1; ++i) {
+        bool fill = false;
+        uint64_t ay = 0;
+        for (; i < cnt1; ++i) {
+            const A128 ai = a[as1 + i];
+            ay = ai.y;
+            if ((ay & (PMX_SEED_IGNORE | PMX_SEED_TANDEM)) && i != cnt1 - 1) continue;
+            adjust_minier(o, ai, &re, &qe);
+            re1 = re; qe1 = qe;
+            if (i == cnt1 - 1 || (ay & PMX_SEED_LONG_JOIN) || (qe - qs >= o.min_ksw_len && re - rs >= o.min_ksw_len)) { fill = true; break; }
+        }
+        if (!fill) break;
+        {
             int bw1 = bw_long;
-            if (a[as1 + i].y & PMX_SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
+            if (ay & PMX_SEED_LONG_JOIN) bw1 = qe - qs > re - rs ? qe - qs : re - rs;
             Ptr<uint8_t> qseq = qseq0[rev] + qs; PMX_LDS(qseq);
             bool decided = false;
 #if PMX_W == 1
@@ -581,6 +595,7 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
         }
     }
 
+    PMX_STAMP(W, 22);
     if (!dropped && qe < qe0 && re < re0) {   // right extension (align.c:799-815)
         Ptr<uint8_t> qseq = qseq0[rev] + qe; PMX_LDS(qseq);
         bool decided = false;
@@ -605,6 +620,7 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
         qe1 = qe + (ez.reach_end ? qe0 - qe : ez.max_q + 1);
     }
 
+    PMX_STAMP(W, 23);
     r.rs = rs1; r.re = re1;
     if (!rev) { r.qs = qs1; r.qe = qe1; }
     else { r.qs = qlen - qe1; r.qe = qlen - qs1; }

@@ -428,7 +428,7 @@ struct Work {
     // optional phase profile (diagnostic runs only: AlignArgs::prof != NULL)
     unsigned long long* prof;
     unsigned long long prof_t;
-    unsigned long long prof_acc[20];   // [0..11] phases, [16..19] sub-phases of seeding / chaining (PMX_ALIGN_PROF)
+    unsigned long long prof_acc[24];   // [0..11] phases, [16..23] sub-phases of seeding / chaining / align1 (PMX_ALIGN_PROF)
 };
 
 }  // namespace aln

@@ -31,7 +31,7 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
         bind_work(W, A.layout, fast, slow);
         W.n_segs = n_segs;
         W.prof = A.prof;
-        if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 20; ++k) W.prof_acc[k] = 0; }
+        if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 24; ++k) W.prof_acc[k] = 0; }
         bool too_long = false;
         for (int s = 0; s < n_segs; ++s) {
             const int64_t r = A.paired ? 2 * item + s : item;

@@ -56,7 +56,7 @@ k_align_reads_tpp(AlignArgs A) {
         W.sk_lds_x = ring_x;
         W.sk_lds_y = ring_y;
         W.prof = A.prof;   // diagnostic runs: lane 0's stamps are the wave's phase timeline
-        if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 20; ++k) W.prof_acc[k] = 0; }
+        if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 24; ++k) W.prof_acc[k] = 0; }
         W.dp_req_base = A.dp_req_base;
         W.dp_slot_cap = A.dp_slot_cap;
         W.dp_slot = slot;
@@ -173,7 +173,7 @@ k_align_reads_tpp(AlignArgs A) {
         if (A.prof && emit) {
             PMX_STAMP(W, 11);
             if ((threadIdx.x & 63) == 0)
-                for (int k = 0; k < 20; ++k)
+                for (int k = 0; k < 24; ++k)
                     if (k < 12 || k >= 16) atomicAdd(&A.prof[k], W.prof_acc[k]);
         }
     }

@@ -148,8 +148,8 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.cigar_used = al->cigar_used.p;
     A.prof = nullptr;
     if (getenv("PMX_ALIGN_PROF")) {
-        al->prof.ensure(20);
-        PMX_HIP(hipMemsetAsync(al->prof.p, 0, 20 * sizeof(unsigned long long), ctx->stream));
+        al->prof.ensure(24);
+        PMX_HIP(hipMemsetAsync(al->prof.p, 0, 24 * sizeof(unsigned long long), ctx->stream));
         A.prof = al->prof.p;
     }
 
@@ -334,7 +334,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     }
     timer_end(ctx, "align", 1);
     if (A.prof) {
-        unsigned long long h[20];
+        unsigned long long h[24];
         PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         PMX_HIP(hipStreamSynchronize(ctx->stream));
         static const char* names[16] = {"decode", "sketch", "seed+heap", "chain", "gen_regs+post", "seg_gen", "squeeze", "align1(all regs)", "filter/sort/parent", "mapq", "pair", "output", "", "", "", ""};
@@ -343,6 +343,9 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         // sub-phases (thread-per-pair kernel): "seed+heap" then holds only the heap merge, "chain" only the compaction
         fprintf(stderr, " [of which index lookups=%.0f stage+heapify=%.0f chain fill=%.0f backtrack=%.0f]", (double)h[16] / (double)n_items,
                 (double)h[17] / (double)n_items, (double)h[18] / (double)n_items, (double)h[19] / (double)n_items);
+        // align1 (thread-per-pair kernel): "align1(all regs)" then holds only what follows the right extension
+        fprintf(stderr, " [align1: prologue+filters=%.0f left ext=%.0f gap fills=%.0f right ext=%.0f]", (double)h[20] / (double)n_items,
+                (double)h[21] / (double)n_items, (double)h[22] / (double)n_items, (double)h[23] / (double)n_items);
         fprintf(stderr, " [dp serve: cycles traceback=%.0f ksw=%.0f store=%.0f per request, diagonals=%.1f]", (double)h[12] / std::max<double>(1, (double)al->last_dp_requests),
                 (double)h[13] / std::max<double>(1, (double)al->last_dp_requests), (double)h[14] / std::max<double>(1, (double)al->last_dp_requests),
                 (double)h[15] / std::max<double>(1, (double)al->last_dp_requests));
