@@ -389,13 +389,55 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
         if (c[i].f >= min_sc) { z[n_z].x = (uint64_t)(int64_t)c[i].f; z[n_z].y = (uint64_t)i; ++n_z; }
     if (n_z == 0) { W.n_a = 0; return; }
     radix_sort_128x(z, z + n_z, &W.status);
-    for (int64_t i = 0; i < n; ++i) c[i].t = 0;
     int64_t n_v = 0;
     int32_t n_u = 0;
     Ptr<uint64_t> u = W.u; PMX_LDS(u);
+    if (n <= 64) {
+        // Up to 64 anchors: the t[] marks of mg_chain_backtrack / mg_chain_bk_end (0 unused, 1 in an emitted trace,
+        // 2 on the walk in progress) are one bit mask in a register, and the three passes over a chain (walk to the
+        // drop point, un-mark, trace up to the best prefix) collapse into one walk: every visited anchor is written
+        // to v[] as it is met, and the prefix that ends at the best-scoring cut is kept.
+        //  * the walk stops at an anchor already used, at the chain start, or max_drop below the best cut;
+        //  * the score of the kept prefix is the best cut's s = f[end] - f[cut] (the value mg_chain_bk_end maximised);
+        //  * the reference marks the kept prefix as used even when the chain is then rejected: same here.
+        uint64_t used = 0;
+        for (int64_t k = n_z - 1; k >= 0; --k) {
+            A128 zk;
+            for (; k >= 0; --k) {   // scan to the next unused chain end: the lanes of a wave meet at the walk
+                zk = z[k];
+                if (!(used >> zk.y & 1)) break;
+            }
+            if (k < 0) break;
+            const int32_t zx = (int32_t)zk.x;
+            const int64_t n_v0 = n_v;
+            int64_t i = (int64_t)zk.y;
+            int32_t max_s = 0;
+            uint64_t walk = 0, keep = 0;   // anchors visited so far / visited before the best cut
+            do {
+                walk |= 1ULL << i;
+                c[n_v0 + (int64_t)__builtin_popcountll(walk) - 1].v = (int32_t)i;
+                i = c[i].p;
+                const int32_t s = i < 0 ? zx : zx - c[i].f;
+                if (s > max_s) { max_s = s; keep = walk; }
+                else if (max_s - s > max_drop) break;
+            } while (i >= 0 && !(used >> i & 1));
+            const int64_t cnt = (int64_t)__builtin_popcountll(keep);
+            used |= keep;
+            n_v = n_v0 + cnt;
+            if (max_s >= min_sc && cnt > 0 && cnt >= min_cnt) {
+                if (n_u < W.caps.max_reg * 4) u[n_u++] = (uint64_t)(uint32_t)max_s << 32 | (uint64_t)cnt;
+                else { W.status |= PMX_ST_OVERFLOW; n_v = n_v0; }
+            } else n_v = n_v0;
+        }
+    } else {
+    for (int64_t i = 0; i < n; ++i) c[i].t = 0;
     // (the reference runs this loop twice, first only to size u[]; one pass gives the same u[] and v[])
+    // (scan to the next unused chain end, then trace it: the lanes of a wave meet at the trace)
     for (int64_t k = n_z - 1; k >= 0; --k) {
-        if (c[z[k].y].t == 0) {
+        for (; k >= 0; --k)
+            if (c[z[k].y].t == 0) break;
+        if (k < 0) break;
+        {
             const int64_t n_v0 = n_v;
             const int64_t end_i = chain_bk_end(max_drop, z, c, k);
             int64_t i;
@@ -406,6 +448,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
                 else { W.status |= PMX_ST_OVERFLOW; n_v = n_v0; }
             } else n_v = n_v0;
         }
+    }
     }
     if (n_u == 0) { W.n_a = 0; W.n_u = 0; return; }
 

@@ -343,18 +343,22 @@ PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, cons
     acc_qlen[0] = 0;
     for (int s = 1; s < n_segs; ++s) acc_qlen[s] = acc_qlen[s - 1] + qlens[s - 1];
     const int qlen_sum = acc_qlen[n_segs - 1] + qlens[n_segs - 1];
-    for (int s = 0; s < n_segs; ++s) {
-        for (int i = 0; i < n_regs0; ++i) (s ? su[1] : su[0])[i] = (uint64_t)(uint32_t)regs0[i].score << 32;
-        W.seg_n_a[s] = 0;
-    }
+    // u[s][i] = score << 32 | anchors of segment s in chain i (counted in registers, one store per entry)
     int n_seg_anchors[2] = {0, 0};
     for (int i = 0; i < n_regs0; ++i) {
         const Reg& r = regs0[i];
-        for (int j = 0; j < r.cnt; ++j) {
-            const int sid = (int)((a[r.as + j].y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
-            ++(sid ? su[1] : su[0])[i];
-            ++n_seg_anchors[sid & 1];
+        const int r_as = r.as, r_cnt = r.cnt;
+        const uint64_t sc_hi = (uint64_t)(uint32_t)r.score << 32;
+        uint32_t c0 = 0, c1 = 0;
+        for (int j = 0; j < r_cnt; ++j) {
+            const int sid = (int)((a[r_as + j].y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
+            c0 += sid ? 0u : 1u;
+            c1 += sid ? 1u : 0u;
         }
+        su[0][i] = sc_hi + c0;
+        if (n_segs > 1) su[1][i] = sc_hi + c1;
+        n_seg_anchors[0] += (int)c0;
+        n_seg_anchors[1] += (int)c1;
     }
     W.seg_a[1] = sa0 + n_seg_anchors[0];   // both mates' anchor lists share one max_anchor block
     Ptr<A128> sa1 = sa0 + n_seg_anchors[0];
@@ -364,14 +368,23 @@ PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, cons
             if ((int32_t)(s ? su[1] : su[0])[i] != 0) { (s ? su[1] : su[0])[n_u] = (s ? su[1] : su[0])[i]; ++n_u; }
         W.seg_n_u[s] = n_u;
     }
-    for (int i = 0; i < n_regs0; ++i) {
-        const Reg& r = regs0[i];
-        for (int j = 0; j < r.cnt; ++j) {
-            A128 a1 = a[r.as + j];
-            const int sid = (int)((a1.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
-            a1.y -= (uint64_t)(int64_t)(a1.x >> 63 ? qlen_sum - (qlens[sid] + acc_qlen[sid]) : acc_qlen[sid]);
-            (sid ? sa1 : sa0)[W.seg_n_a[sid]++] = a1;
+    {
+        int na0 = 0, na1 = 0;   // output cursors of the two mates
+        const int ql0 = qlens[0], ql1 = n_segs > 1 ? qlens[1] : 0;
+        for (int i = 0; i < n_regs0; ++i) {
+            const Reg& r = regs0[i];
+            const int r_as = r.as, r_cnt = r.cnt;
+            for (int j = 0; j < r_cnt; ++j) {
+                A128 a1 = a[r_as + j];
+                const int sid = (int)((a1.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
+                const int ql = sid ? ql1 : ql0, acc = sid ? acc_qlen[1] : acc_qlen[0];
+                a1.y -= (uint64_t)(int64_t)(a1.x >> 63 ? qlen_sum - (ql + acc) : acc);
+                if (sid) sa1[na1++] = a1;
+                else sa0[na0++] = a1;
+            }
         }
+        W.seg_n_a[0] = na0;
+        if (n_segs > 1) W.seg_n_a[1] = na1;
     }
     for (int s = 0; s < n_segs; ++s) {
         Reg* rs_ = W.regs[s]; PMX_LDS(rs_);
