@@ -212,6 +212,20 @@ struct alignas(16) Cell4 {
 };
 static_assert(sizeof(Cell4) == 64, "four cells per block");
 PMX_HD PackedCell& packed_cell(Ptr<Cell4> pk4, int64_t j) { return pk4[j >> 2].c[j & 3]; }
+// one cell as four 32-bit words, fetched with ONE 16-byte load (a struct copy is split into per-field loads)
+struct CellWords { uint32_t w0, w1, w2, w3; };   // x_lo | y_lo, span, seg | f | p1, t
+PMX_HD CellWords packed_cell_words(Ptr<Cell4> pk4, int64_t g, int s_) {
+    const PackedCell& c = pk4[g].c[s_];
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t pmx_u32x4 __attribute__((ext_vector_type(4)));
+    const pmx_u32x4 v = *reinterpret_cast<const pmx_u32x4*>(&c);
+    return CellWords{v.x, v.y, v.z, v.w};
+#else
+    CellWords r;
+    memcpy(&r, &c, 16);
+    return r;
+#endif
+}
 PMX_HD A128 packed_anchor(const PackedCell& c) {
     A128 r;
     r.x = c.x_lo;
@@ -273,32 +287,57 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
             uint64_t mark = 0;   // bit (k - st): anchor k is the predecessor of an anchor already visited for this i
             int64_t end_j = st - 1;
             bool stop = false;
-            for (int64_t g = (i - 1) >> 2; i > st && !stop && g >= (st >> 2); --g) {
+            if (use_mask) {
+                // window of at most 64 anchors: marks in the register mask, the whole body is selects
+                const int32_t i32 = (int32_t)i, st32 = (int32_t)st;
+                int32_t mj = -1, ej = st32 - 1;
+                for (int32_t g = (i32 - 1) >> 2; i32 > st32 && !stop && g >= (st32 >> 2); --g) {
+                    CellWords cw[4];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) cw[s_] = packed_cell_words(pk4, g, s_);
+#pragma unroll
+                    for (int s_ = 3; s_ >= 0; --s_) {
+                        const int32_t j = g * 4 + s_;
+                        const CellWords q = cw[s_];
+                        const int32_t sc0 = chain_score_sel(ci.x_lo, (int32_t)ci.y_lo, (int32_t)ci.seg, q.w0, (int32_t)(q.w1 & 0xffffu),
+                                                            (int32_t)(q.w1 >> 24), (int32_t)(q.w1 >> 16 & 0xffu), max_dist_x, max_dist_y, bw,
+                                                            chn_pen_gap, chn_pen_skip, n_seg);
+                        const bool valid = !stop && j < i32 && j >= st32 && sc0 != INT32_MIN;
+                        const int32_t sc = sc0 + (int32_t)q.w2;
+                        const bool better = valid && sc > max_f;
+                        const bool marked = valid && !better && (mark >> ((j - st32) & 63) & 1) != 0;
+                        max_f = better ? sc : max_f;
+                        mj = better ? j : mj;
+                        n_skip += (better && n_skip > 0) ? -1 : 0;
+                        n_skip += marked ? 1 : 0;
+                        const bool brk = marked && n_skip > max_skip;   // the reference breaks before marking p[j]
+                        ej = brk ? j : ej;
+                        stop = stop || brk;
+                        const int32_t kk = (int32_t)(q.w3 & 0xffffu) - 1 - st32;   // p[j] relative to st (p1 == 0: none)
+                        mark |= (valid && !brk && (q.w3 & 0xffffu) != 0u && kk >= 0) ? 1ULL << (kk & 63) : 0ULL;
+                    }
+                }
+                max_j = mj;
+                end_j = ej;
+            } else
+            for (int64_t g = (i - 1) >> 2; i > st && !stop && g >= (st >> 2); --g) {   // wide window: marks in the cells' t field
                 const Cell4 G = pk4[g];
 #pragma unroll
                 for (int s_ = 3; s_ >= 0; --s_) {
                     const int64_t j = g * 4 + s_;
+                    if (stop || j >= i || j < st) continue;
                     const PackedCell cj = G.c[s_];
-                    const int32_t sc0 = chain_score_sel(ci.x_lo, (int32_t)ci.y_lo, (int32_t)ci.seg, cj.x_lo, (int32_t)cj.y_lo, (int32_t)cj.seg,
-                                                        (int32_t)cj.span, max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
-                    const bool valid = !stop && j < i && j >= st && sc0 != INT32_MIN;
-                    const int32_t sc = sc0 + cj.f;
-                    const bool better = valid && sc > max_f;
-                    bool marked = false;
-                    if (use_mask) marked = valid && !better && (mark >> ((j - st) & 63) & 1) != 0;
-                    else if (valid && !better) marked = packed_cell(pk4, j).t == (uint16_t)i;
-                    max_f = better ? sc : max_f;
-                    max_j = better ? j : max_j;
-                    n_skip += (better && n_skip > 0) ? -1 : 0;
-                    n_skip += marked ? 1 : 0;
-                    const bool brk = marked && n_skip > max_skip;   // the reference breaks before marking p[j]
-                    end_j = brk ? j : end_j;
-                    stop = stop || brk;
-                    if (valid && !brk && cj.p1) {
-                        const int64_t k = (int64_t)cj.p1 - 1;
-                        if (!use_mask) packed_cell(pk4, k).t = (uint16_t)i;
-                        else if (k >= st) mark |= 1ULL << (k - st);
+                    int32_t sc = chain_score(ri, packed_anchor(cj), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                    if (sc == INT32_MIN) continue;
+                    sc += cj.f;
+                    if (sc > max_f) {
+                        max_f = sc;
+                        max_j = j;
+                        if (n_skip > 0) --n_skip;
+                    } else if (packed_cell(pk4, j).t == (uint16_t)i) {
+                        if (++n_skip > max_skip) { stop = true; end_j = j; continue; }
                     }
+                    if (cj.p1) packed_cell(pk4, (int64_t)cj.p1 - 1).t = (uint16_t)i;
                 }
             }
             if (max_ii < 0 || (int64_t)(ai.x - x_mi) > (int64_t)max_dist_x) {
