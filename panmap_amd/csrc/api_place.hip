@@ -449,7 +449,8 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
     sp.k = pl->params.k; sp.s = pl->params.s; sp.t = pl->params.t; sp.l = pl->params.l; sp.open = pl->params.open ? 1 : 0;
     sp.trim_start = pp->trim_start; sp.trim_end = pp->trim_end;
     const int w = sp.k - sp.s + 1, l = sp.l < 1 ? 1 : sp.l;
-    const size_t lds = (size_t)(2 * w + l) * PMX_SEED_BLOCK * sizeof(uint64_t);
+    const size_t lds = (size_t)(2 * w + l) * PMX_SEED_BLOCK * sizeof(uint64_t) +
+                       (size_t)(PMX_SEED_BLOCK / 64) * (PMX_SEED_QCAP * sizeof(uint64_t) + 8);   // + the waves' seed queues and their counters
     if (lds > 160 * 1024) return fail(PMX_ERR_UNSUPPORTED, "k-s+1 too large for the LDS ring");
     if (lds > 64 * 1024)
         PMX_HIP(hipFuncSetAttribute((const void*)k_seed_histogram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -4,6 +4,7 @@
 
 #define PMX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
 #define PMX_SEED_BLOCK 128
+#define PMX_SEED_QCAP 256   // seeds a wave queues in LDS before it inserts them 64 at a time (k_seed_histogram)
 #define PMX_SUM_BLOCK 1024
 #define PMX_CTR_NSHARD 256
 enum { PMX_CTR_ENTRIES = 0, PMX_CTR_OVERFLOW = 1, PMX_CTR_SEEDS = 2, PMX_CTR_COMPACT = 3, PMX_CTR_SHARD0 = 8, PMX_CTR_N = 8 + PMX_CTR_NSHARD };

@@ -136,6 +136,21 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
     uint64_t* ringR = lds + (size_t)w * PMX_SEED_BLOCK;      // [w][B]
     uint64_t* ringS = lds + (size_t)2 * w * PMX_SEED_BLOCK;  // [l][B]
     const int tid = threadIdx.x;
+    // Seeds are not inserted where they are found: a thread finds one at ~1 base in 6, so with an insert in the base
+    // loop a wave would wait for a table probe (an L2 round trip) at nearly every base with a handful of lanes
+    // active.  Each wave queues its seeds in LDS and, when the queue is nearly full (and once at the end), all of
+    // its lanes insert one queued seed each.  Counts are sums, so the insertion order does not matter.
+    uint64_t* queue = lds + (size_t)(2 * w + l) * PMX_SEED_BLOCK + (size_t)(tid >> 6) * PMX_SEED_QCAP;
+    uint32_t* qcnt = reinterpret_cast<uint32_t*>(lds + (size_t)(2 * w + l) * PMX_SEED_BLOCK + (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP) + (tid >> 6);
+    if ((tid & 63) == 0) *qcnt = 0;
+    auto enqueue = [&](uint64_t h) { queue[atomicAdd(qcnt, 1u)] = h; };
+    auto drain = [&]() {   // called with the wave's in-loop lanes converged; strides over the ACTIVE lanes
+        const unsigned long long act = __ballot(1);
+        const int rank = (int)__popcll(act & ((1ULL << (tid & 63)) - 1ULL)), n_act = (int)__popcll(act);
+        const int n_q = (int)__hip_atomic_load(qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int q = rank; q < n_q; q += n_act) table_insert(keys, vals, mask, queue[q], 1ULL, counters);
+        if (rank == 0) *qcnt = 0;
+    };
     // base hashes A, C, G, T (src/seeding.hpp:100-112) picked with selects, not a table in memory
     auto HB = [](uint32_t c) -> uint64_t {
         const uint64_t lo = (c & 1u) ? 0x3193c18562a02b4cULL : 0x3c8bfbb395c60474ULL;
@@ -170,6 +185,7 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
         int qsum = 0, pass_run = 0;
         const int ilen = (int)len;
         for (int i = 0; i < ilen; ++i) {
+            if (__hip_atomic_load(qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (uint32_t)(PMX_SEED_QCAP - 64)) drain();   // uniform: every in-loop lane reads the same word
             if ((i & 31) == 0) { cw = rw[i >> 5]; ca = ra[i >> 5]; }
             const uint32_t code = (uint32_t)(cw & 3u);
             const uint32_t am = ca & 1u;
@@ -230,7 +246,7 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
                 const bool pass = ks >= valid_start && ks <= valid_end && qsum >= min_q * sp.k;   // avg >= min_q, exactly
                 ++n_sync;
                 if (sp.l <= 1) {
-                    if (pass) { table_insert(keys, vals, mask, h, 1ULL, counters); ++n_seeds; }
+                    if (pass) { enqueue(h); ++n_seeds; }
                     continue;
                 }
                 ringS[(size_t)slot_l * PMX_SEED_BLOCK + tid] = h;
@@ -245,14 +261,14 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
                         Rq ^= rotl64(hq, (unsigned)(sp.k * q2));
                         sl = sl + 1 == l ? 0 : sl + 1;
                     }
-                    if (Fq != Rq) { table_insert(keys, vals, mask, Fq < Rq ? Fq : Rq, 1ULL, counters); ++n_seeds; }
+                    if (Fq != Rq) { enqueue(Fq < Rq ? Fq : Rq); ++n_seeds; }
                 }
                 continue;
             }
             if (ks < valid_start || ks > valid_end) continue;   // primer trim (src/placement.cpp:1629-1648)
             ++n_sync;
             if (sp.l <= 1) {
-                table_insert(keys, vals, mask, h, 1ULL, counters);
+                enqueue(h);
                 ++n_seeds;
                 continue;
             }
@@ -270,11 +286,12 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
             ringS[(size_t)slot_l * PMX_SEED_BLOCK + tid] = h;
             slot_l = slot_l + 1 == l ? 0 : slot_l + 1;
             if (have && F != R) {
-                table_insert(keys, vals, mask, F < R ? F : R, 1ULL, counters);
+                enqueue(F < R ? F : R);
                 ++n_seeds;
             }
         }
     }
+    drain();   // every lane of the wave is here
     // one atomic per wave: a per-thread atomic on this single word was the whole cost of the kernel
     // (same-address atomics retire at a few hundred per microsecond)
     for (int o = 32; o > 0; o >>= 1) n_seeds += __shfl_xor(n_seeds, o);
