@@ -490,9 +490,15 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         for (int64_t r0 = 0; r0 < rs->n; r0 += chunk_reads) {
             const int64_t r1 = std::min<int64_t>(rs->n, r0 + chunk_reads);
             table_reserve(ctx, pl, (uint64_t)((r1 - r0) * rs->max_len));
-            hipLaunchKernelGGL(k_seed_histogram, dim3(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), dim3(PMX_SEED_BLOCK), lds, ctx->stream,
-                               rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep,
-                               quality_mode ? rs->qual.p : nullptr, quality_mode ? pp->min_seed_quality : 0);
+            const dim3 grid(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
+            // the default seeding parameters run the kernel specialised for them (same results, ~3x fewer instructions)
+            if (sp.k == 19 && sp.s == 8 && sp.t == 0 && !quality_mode && !getenv("PMX_SEED_GENERIC"))
+                hipLaunchKernelGGL((k_seed_histogram_ks<19, 8>), grid, block, lds, ctx->stream, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp,
+                                   pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep);
+            else
+                hipLaunchKernelGGL(k_seed_histogram, grid, block, lds, ctx->stream, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p,
+                                   pl->vals.p, pl->cap - 1, pl->counters.p, keep, quality_mode ? rs->qual.p : nullptr,
+                                   quality_mode ? pp->min_seed_quality : 0);
             PMX_HIP(hipGetLastError());
         }
         timer_end(ctx, "seed", 1);

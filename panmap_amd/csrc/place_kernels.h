@@ -21,6 +21,10 @@ __global__ void k_pack_reads(const uint8_t* ascii, const int64_t* off, const int
 __global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin, int64_t n_reads,
                                  SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters,
                                  const uint8_t* keep, const uint8_t* qual, int min_q);
+template <int K, int S>
+__global__ void k_seed_histogram_ks(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin,
+                                    int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask,
+                                    unsigned long long* counters, const uint8_t* keep);
 __global__ void k_read_hashes(const uint8_t* ascii, const int64_t* off, int64_t n_reads, uint64_t* h1, uint64_t* h2, uint32_t* idx);
 __global__ void k_gather_u64(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst);
 __global__ void k_mark_first_of_run(const uint8_t* ascii, const int64_t* off, const uint64_t* h1s, const uint64_t* h2, const uint32_t* perm,

@@ -122,6 +122,33 @@ __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long*
     atomicAdd(&counters[PMX_CTR_OVERFLOW], 1ULL);
 }
 
+// Insert a wave's queued seeds: every active lane takes up to four queue entries at a time and issues their first
+// probes together (independent loads in flight), so a drain costs about one table round trip per four entries per
+// lane instead of one per entry.  A first probe that neither hits nor finds an empty slot continues in table_insert.
+__device__ __forceinline__ void drain_seed_queue(const uint64_t* queue, int n_q, int rank, int n_act, uint64_t* keys, unsigned long long* vals,
+                                                 uint64_t mask, unsigned long long* counters) {
+    for (int q0 = rank; q0 < n_q; q0 += 4 * n_act) {
+        uint64_t h[4], slot[4];
+        unsigned long long cur[4];
+        bool ok[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int q = q0 + b * n_act;
+            ok[b] = q < n_q;
+            h[b] = ok[b] ? queue[q] : 0;
+            slot[b] = mix64(h[b]) & mask;
+            cur[b] = 0;
+            if (ok[b]) cur[b] = __hip_atomic_load((unsigned long long*)&keys[slot[b]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (!ok[b]) continue;
+            if (cur[b] == h[b]) atomicAdd(&vals[slot[b]], 1ULL);
+            else table_insert(keys, vals, mask, h[b], 1ULL, counters);   // empty slot or collision: the full probe sequence
+        }
+    }
+}
+
 // One thread per read; rolling k-mer / s-mer hashes in registers, the (k-s+1)-deep s-mer ring and the
 // l-deep syncmer ring of every thread in LDS, laid out [slot][thread] (conflict-free ds_read_b64).
 __global__ void __launch_bounds__(PMX_SEED_BLOCK)
@@ -148,7 +175,7 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
         const unsigned long long act = __ballot(1);
         const int rank = (int)__popcll(act & ((1ULL << (tid & 63)) - 1ULL)), n_act = (int)__popcll(act);
         const int n_q = (int)__hip_atomic_load(qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int q = rank; q < n_q; q += n_act) table_insert(keys, vals, mask, queue[q], 1ULL, counters);
+        drain_seed_queue(queue, n_q, rank, n_act, keys, vals, mask, counters);
         if (rank == 0) *qcnt = 0;
     };
     // base hashes A, C, G, T (src/seeding.hpp:100-112) picked with selects, not a table in memory
@@ -297,6 +324,189 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
     for (int o = 32; o > 0; o >>= 1) n_seeds += __shfl_xor(n_seeds, o);
     if ((tid & 63) == 0 && n_seeds) atomicAdd(&counters[PMX_CTR_SEEDS], n_seeds);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// k_seed_histogram for compile-time (K, S), t == 0 and no quality filter (the default parameters k=19 s=8): the
+// generic kernel is bound by instruction issue (~770 instructions per base, half of them branch bookkeeping).
+// Here
+//  * every rotation amount is a constant, and "rotate the hash of the outgoing base" is a select among four
+//    pre-rotated constants;
+//  * the minimum of the last W = K-S+1 s-mer hashes comes from the block prefix/suffix scheme (van Herk /
+//    Gil-Werman): s-mers are grouped in blocks of W; a running prefix minimum of the current block lives in a
+//    register, and when a block completes one backward pass turns its W ring slots into suffix minima IN PLACE.
+//    The window ending at s-mer p is the tail [p-W+1, block end] of the previous block plus the head of the current
+//    one, so min = min(suffix[(p+1) mod W], prefix): ~3 ring operations per base instead of 2W reads.  With t == 0
+//    the closed-syncmer test needs "oldest s-mer == min" and "newest s-mer == min": the newest is in a register,
+//    and the oldest equals the minimum iff it was its own suffix minimum (one bit per slot, kept in a register mask
+//    by the backward pass) and that suffix minimum is <= the prefix;
+//  * the syncmer / k-min-mer bookkeeping is predicated instead of branched wherever that is cheap.
+// Results are identical to k_seed_histogram (same hashes, same syncmers, same counts).
+__device__ __forceinline__ constexpr uint64_t c_rotl64(uint64_t x, unsigned r) { return (r & 63u) ? (x << (r & 63u)) | (x >> (64u - (r & 63u))) : x; }
+__device__ __forceinline__ constexpr uint64_t c_hb(uint32_t c) {
+    return c == 0 ? 0x3c8bfbb395c60474ULL : c == 1 ? 0x3193c18562a02b4cULL : c == 2 ? 0x20323ed082572324ULL : 0x295549f54be24456ULL;
+}
+// hash of base c rotated left by R, or of its complement (3 - c); 0 when the position is ambiguous
+template <unsigned R, bool COMP>
+__device__ __forceinline__ uint64_t hb_rot(uint32_t c, uint32_t am) {
+    constexpr uint64_t v0 = c_rotl64(c_hb(COMP ? 3 : 0), R), v1 = c_rotl64(c_hb(COMP ? 2 : 1), R), v2 = c_rotl64(c_hb(COMP ? 1 : 2), R),
+                       v3 = c_rotl64(c_hb(COMP ? 0 : 3), R);
+    const uint64_t lo = (c & 1u) ? v1 : v0, hi = (c & 1u) ? v3 : v2;
+    const uint64_t v = (c & 2u) ? hi : lo;
+    return am ? 0ULL : v;
+}
+
+template <int K, int S>
+__global__ void __launch_bounds__(PMX_SEED_BLOCK)
+k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
+                    const int64_t* __restrict__ off, int64_t r_begin, int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals,
+                    uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep) {
+    constexpr int W = K - S + 1;
+    static_assert(K <= 32 && S >= 1 && W >= 2 && W <= 32, "window of 2..32 s-mers");
+    extern __shared__ uint64_t lds[];
+    const int l = sp.l < 1 ? 1 : sp.l;
+    const int tid = threadIdx.x;
+    uint64_t* ringF = lds + tid;                                      // [W][B] forward s-mer hashes / suffix minima
+    uint64_t* ringR = lds + (size_t)W * PMX_SEED_BLOCK + tid;         // [W][B]
+    uint64_t* ringS = lds + (size_t)2 * W * PMX_SEED_BLOCK + tid;     // [l][B] last l syncmer hashes
+    uint64_t* queue = lds + (size_t)(2 * W + l) * PMX_SEED_BLOCK + (size_t)(tid >> 6) * PMX_SEED_QCAP;
+    uint32_t* qcnt = reinterpret_cast<uint32_t*>(lds + (size_t)(2 * W + l) * PMX_SEED_BLOCK + (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP) + (tid >> 6);
+    if ((tid & 63) == 0) *qcnt = 0;
+    auto drain = [&]() {   // called with the wave's in-loop lanes converged; strides over the ACTIVE lanes
+        const unsigned long long act = __ballot(1);
+        const int rank = (int)__popcll(act & ((1ULL << (tid & 63)) - 1ULL)), n_act = (int)__popcll(act);
+        const int n_q = (int)__hip_atomic_load(qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        drain_seed_queue(queue, n_q, rank, n_act, keys, vals, mask, counters);
+        if (rank == 0) *qcnt = 0;
+    };
+    unsigned long long n_seeds = 0;
+    const unsigned rot_k = (unsigned)K, rot_kl = (unsigned)(K * l) & 63u, rot_kl1 = (unsigned)(K * (l - 1)) & 63u;
+
+    for (int64_t r = r_begin + (int64_t)blockIdx.x * PMX_SEED_BLOCK + tid; r < n_reads; r += (int64_t)gridDim.x * PMX_SEED_BLOCK) {
+        const int64_t len = off[r + 1] - off[r];
+        if (len < K) continue;
+        if (keep && !keep[r]) continue;   // --dedup: a later copy of an identical read
+        const uint64_t* rw = words + woff[r];
+        const uint32_t* ra = amb + woff[r];
+        const int valid_start = sp.trim_start, valid_end = (int)len - sp.trim_end - K;
+        uint64_t fS = 0, rS = 0, fK = 0, rK = 0;
+        uint64_t hist2 = 0;   // last 32 base codes, newest in bits 1:0
+        uint32_t hista = 0;   // last 32 ambiguity bits, newest in bit 0
+        int last_amb = -1;
+        uint64_t cw = 0, cw_next = rw[0];   // the next 32 bases are requested while these are processed
+        uint32_t ca = 0, ca_next = ra[0];
+        const int n_words = ((int)len + 31) >> 5;
+        uint64_t F = 0, R = 0;  // k-min-mer rolling hashes
+        int n_sync = 0, slot_l = 0;
+        int slot_w = 0;                                  // ring slot of the s-mer that ends at this base
+        uint64_t pfF = 0, pfR = 0, pf0F = 0, pf0R = 0;   // prefix minima of the current block, and the block's first s-mers
+        uint32_t selfF = 0, selfR = 0;                   // previous block: bit j = s-mer j was its own suffix minimum
+        const int ilen = (int)len;
+        for (int i = 0; i < ilen; ++i) {
+            if (__hip_atomic_load(qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (uint32_t)(PMX_SEED_QCAP - 64)) drain();
+            if ((i & 31) == 0) {
+                cw = cw_next; ca = ca_next;
+                if ((i >> 5) + 1 < n_words) { cw_next = rw[(i >> 5) + 1]; ca_next = ra[(i >> 5) + 1]; }
+            }
+            const uint32_t code = (uint32_t)(cw & 3u);
+            const uint32_t am = ca & 1u;
+            cw >>= 2; ca >>= 1;
+            last_amb = am ? i : last_amb;
+            const uint64_t hb = hb_rot<0, false>(code, am);
+            // s-mer and k-mer hashes (src/seeding.hpp rolling ntHash); i is uniform across the wave
+            if (i < S) {
+                fS ^= c_rotl64(hb, (unsigned)(S - 1 - i));
+                rS ^= c_rotl64(hb_rot<0, true>(code, am), (unsigned)i);
+            } else {
+                const uint32_t oc = (uint32_t)(hist2 >> (2 * (S - 1))) & 3u, oa = (hista >> (S - 1)) & 1u;
+                fS = c_rotl64(fS, 1) ^ hb_rot<S, false>(oc, oa) ^ hb;
+                rS = c_rotl64(rS, 63) ^ hb_rot<63, true>(oc, oa) ^ hb_rot<S - 1, true>(code, am);
+            }
+            if (i < K) {
+                fK ^= c_rotl64(hb, (unsigned)(K - 1 - i));
+                rK ^= c_rotl64(hb_rot<0, true>(code, am), (unsigned)i);
+            } else {
+                const uint32_t oc = (uint32_t)(hist2 >> (2 * (K - 1))) & 3u, oa = (hista >> (K - 1)) & 1u;
+                fK = c_rotl64(fK, 1) ^ hb_rot<K, false>(oc, oa) ^ hb;
+                rK = c_rotl64(rK, 63) ^ hb_rot<63, true>(oc, oa) ^ hb_rot<K - 1, true>(code, am);
+            }
+            hist2 = (hist2 << 2) | code;
+            hista = (hista << 1) | am;
+            if (i < S - 1) continue;
+            // ---- window minimum of the last W s-mers
+            uint64_t fmin, rmin;
+            bool f_old_min, r_old_min;   // the OLDEST s-mer of the window equals the minimum
+            pfF = slot_w == 0 ? fS : (fS < pfF ? fS : pfF);
+            pfR = slot_w == 0 ? rS : (rS < pfR ? rS : pfR);
+            pf0F = slot_w == 0 ? fS : pf0F;
+            pf0R = slot_w == 0 ? rS : pf0R;
+            if (slot_w == W - 1) {   // the window is exactly the current block; then turn the block into suffix minima
+                fmin = pfF; rmin = pfR;
+                f_old_min = pf0F == pfF;
+                r_old_min = pf0R == pfR;
+                uint64_t sF = fS, sR = rS;
+                selfF = selfR = 1u << (W - 1);
+                ringF[(size_t)(W - 1) * PMX_SEED_BLOCK] = sF;
+                ringR[(size_t)(W - 1) * PMX_SEED_BLOCK] = sR;
+#pragma unroll
+                for (int j = W - 2; j >= 0; --j) {
+                    const uint64_t xF = ringF[(size_t)j * PMX_SEED_BLOCK], xR = ringR[(size_t)j * PMX_SEED_BLOCK];
+                    selfF |= xF <= sF ? 1u << j : 0u;
+                    selfR |= xR <= sR ? 1u << j : 0u;
+                    sF = xF < sF ? xF : sF;
+                    sR = xR < sR ? xR : sR;
+                    ringF[(size_t)j * PMX_SEED_BLOCK] = sF;
+                    ringR[(size_t)j * PMX_SEED_BLOCK] = sR;
+                }
+            } else {
+                const uint64_t sufF = ringF[(size_t)(slot_w + 1) * PMX_SEED_BLOCK], sufR = ringR[(size_t)(slot_w + 1) * PMX_SEED_BLOCK];
+                fmin = sufF < pfF ? sufF : pfF;
+                rmin = sufR < pfR ? sufR : pfR;
+                f_old_min = (selfF >> (slot_w + 1) & 1u) != 0u && sufF <= pfF;
+                r_old_min = (selfR >> (slot_w + 1) & 1u) != 0u && sufR <= pfR;
+                ringF[(size_t)slot_w * PMX_SEED_BLOCK] = fS;   // (slot_w < W-1: the block is still open, raw values)
+                ringR[(size_t)slot_w * PMX_SEED_BLOCK] = rS;
+            }
+            slot_w = slot_w + 1 == W ? 0 : slot_w + 1;
+            if (i < K - 1) continue;
+            const int ks = i - K + 1;
+            // closed syncmer: the minimum sits at the first or the last s-mer; open: at the first (forward strand) /
+            // the last (reverse strand).  t == 0: first = oldest, last = newest of the window.
+            const bool f_new_min = fS == fmin, r_new_min = rS == rmin;
+            const bool fs = sp.open ? f_old_min : (f_old_min || f_new_min);
+            const bool rs = sp.open ? r_new_min : (r_new_min || r_old_min);
+            const bool sync = !(last_amb >= ks || fK == rK) && (fs || rs) && ks >= valid_start && ks <= valid_end;
+            if (!sync) continue;
+            const uint64_t h = fK < rK ? fK : rK;
+            ++n_sync;
+            uint64_t out = h;
+            bool have = true;
+            if (l > 1) {
+                if (n_sync <= l) {
+                    F = rotl64(F, rot_k) ^ h;
+                    R ^= rotl64(h, (unsigned)(K * (n_sync - 1)) & 63u);
+                    have = n_sync == l;
+                } else {
+                    const uint64_t prev = ringS[(size_t)slot_l * PMX_SEED_BLOCK];
+                    F = rotl64(F, rot_k) ^ rotl64(prev, rot_kl) ^ h;
+                    R = rotr64(R, rot_k) ^ rotr64(prev, rot_k) ^ rotl64(h, rot_kl1);
+                }
+                ringS[(size_t)slot_l * PMX_SEED_BLOCK] = h;
+                slot_l = slot_l + 1 == l ? 0 : slot_l + 1;
+                have = have && F != R;
+                out = F < R ? F : R;
+            }
+            if (have) {
+                queue[atomicAdd(qcnt, 1u)] = out;
+                ++n_seeds;
+            }
+        }
+    }
+    drain();   // every lane of the wave is here
+    for (int o = 32; o > 0; o >>= 1) n_seeds += __shfl_xor(n_seeds, o);
+    if ((tid & 63) == 0 && n_seeds) atomicAdd(&counters[PMX_CTR_SEEDS], n_seeds);
+}
+template __global__ void k_seed_histogram_ks<19, 8>(const uint64_t*, const uint32_t*, const int64_t*, const int64_t*, int64_t, int64_t, SeedParams,
+                                                    uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*);
 
 // merge externally supplied (hash,count) pairs into the table (multi-GPU histogram exchange)
 __global__ void k_table_merge(const uint64_t* __restrict__ hash, const int64_t* __restrict__ count, int64_t n, uint64_t* keys,
