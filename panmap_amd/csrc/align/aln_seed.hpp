@@ -380,6 +380,8 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
     // records are built straight from the probe results (no pass through heap[] scratch)
     {
         const int n_mv = W.n_mv;
+        bool any_high = false;          // some seed occurs more than max_occ times
+        int64_t sum_n = 0;
         uint64_t prev_key = 0;          // mv[i - 1].x >> 8
         for (int i0 = 0; i0 < n_mv; i0 += 4) {
             A128 m[5];
@@ -421,9 +423,20 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
                     seeds[n_m0] = q;
                     seeds_b[n_m0] = qb;
                     ++n_m0;
+                    any_high = any_high || (int)t > max_occ;
+                    sum_n += t;
                 }
                 prev_key = key;
             }
+        }
+        if (!any_high) {
+            // no seed above the occurrence cap (the usual case): mm_seed_select / the flt pass mark nothing and the
+            // compaction below is the identity, so its results are known here (mini_pos[] has no reader on this path)
+            W.n_mini_pos = n_m0;
+            W.n_seeds = n_m0;
+            W.n_a = sum_n;
+            W.rep_len = 0;
+            return;
         }
     }
 #else
@@ -507,6 +520,40 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     // stage every occurrence list in idle scratch so the merge never waits on HBM/L2:
     // cache offsets are assigned in seed order, the copies run one seed per lane
     Ptr<uint64_t> pc = ptr_cast<uint64_t>(W.seg_a[0]); PMX_LDS(pc);   // the per-mate anchor block (16*max_anchor bytes) is idle until seg_gen
+    int heap_size = 0;
+#if PMX_W == 1
+    {   // scalar models: one pass, four seeds at a time (their records and first positions are independent loads)
+        uint32_t acc = 0;
+        for (int i0 = 0; i0 < n_m; i0 += 4) {
+            SeedA q[4];
+            uint64_t p0[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                q[b].q_pos = q[b].off = q[b].n = q[b].flt = 0;
+                if (i0 + b < n_m) q[b] = seeds[i0 + b];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                p0[b] = 0;
+                if (i0 + b < n_m && q[b].n > 0) p0[b] = ri.pos[q[b].off];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (i0 + b >= n_m) break;
+                seeds[i0 + b].flt = acc;   // flt is free now: cache offset
+                if (q[b].n > 0) {
+                    pc[acc] = p0[b];
+                    for (uint32_t j = 1; j < q[b].n; ++j) pc[acc + j] = ri.pos[q[b].off + j];
+                    A128 h;
+                    h.x = p0[b];
+                    h.y = (uint64_t)(i0 + b) << 32;
+                    heap[heap_size++] = h;
+                }
+                acc += q[b].n;
+            }
+        }
+    }
+#else
     {
         uint32_t acc = 0;
         for (int i = 0; i < n_m; ++i) { const uint32_t n = seeds[i].n; seeds[i].flt = acc; acc += n; }   // flt is free now: cache offset
@@ -517,7 +564,6 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
         }
         wave_sync();
     }
-    int heap_size = 0;
     for (int i = 0; i < n_m; ++i) {
         if (seeds[i].n > 0) {
             heap[heap_size].x = pc[seeds[i].flt];
@@ -525,6 +571,7 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
             ++heap_size;
         }
     }
+#endif
     for (int q = (heap_size >> 1) - 1; q >= 0; --q) heap_down_min_x(heap, q, heap_size);
     int64_t n_for = 0, n_rev = 0;
     PMX_STAMP(W, 17);
