@@ -29,7 +29,7 @@ def main():
     fetch_dir, write_dir, reads, read_len, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     res = {"reads_per_gpu": reads, "read_len": read_len, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)"}
     for name, sub in (("k_align_reads_tpp_round0", "k_align_reads_tpp"), ("k_seed_histogram", "k_seed_histogram"),
-                      ("k_score_level", "k_score_level")):
+                      ("k_score_chains", "k_score_chains")):
         f = per_launch(fetch_dir, "FETCH_SIZE", sub)
         w = per_launch(write_dir, "WRITE_SIZE", sub)
         if not f or not w:
