@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <memory>
 #include <vector>
 
 #include "aln_map.hpp"
@@ -116,15 +117,40 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
     o.ref_len = (int)ref_len;
     Work W;
     memset(&W, 0, sizeof(W));
-    std::vector<A128> mv((size_t)ref_len + 16), buf(256);
-    W.mv = mv.data();
+    const size_t mv_cap = (size_t)ref_len + 16;
+    std::unique_ptr<A128[]> mv_buf(new A128[mv_cap]);   // uninitialised: the sketch writes what it uses
+    std::vector<A128> buf(256);
+    W.mv = mv_buf.get();
     W.sk_buf = buf.data();
-    W.caps.max_mini = (int)mv.size();
+    W.caps.max_mini = (int)mv_cap;
     W.n_mv = 0;
-    if (ref_len > 0) sketch_segment(W, out.seq.data(), (int)ref_len, o.w, o.k, 0);
-    mv.resize(W.n_mv);
+    if (ref_len > 0) {   // on a CPU the branchy ring walk is ~4x faster than the branch-free register form the kernels use
+        RingMem ring{W.sk_buf};
+        sketch_segment_t(W, ring, (Ptr<const uint8_t>)out.seq.data(), (int)ref_len, o.w, o.k, 0);
+    }
     // by minimizer value (span byte excluded), then by position: the occurrence list of a key is ascending in y
-    std::sort(mv.begin(), mv.end(), [](const A128& a, const A128& b) { return (a.x >> 8) != (b.x >> 8) ? (a.x >> 8) < (b.x >> 8) : a.y < b.y; });
+    std::vector<A128> mv((size_t)W.n_mv);
+    {
+        const A128* src = mv_buf.get();
+        const size_t n = (size_t)W.n_mv;
+        const auto by_key_pos = [](const A128& a, const A128& b) { return (a.x >> 8) != (b.x >> 8) ? (a.x >> 8) < (b.x >> 8) : a.y < b.y; };
+        if (2 * o.k <= 42 && n < ((size_t)1 << 21)) {
+            // one 64-bit key per minimizer (value << 21 | emission index), then the rare equal-value runs by position
+            std::vector<uint64_t> key(n);
+            for (size_t i = 0; i < n; ++i) key[i] = (src[i].x >> 8) << 21 | (uint64_t)i;
+            std::sort(key.begin(), key.end());
+            for (size_t i = 0; i < n; ++i) mv[i] = src[key[i] & (((uint64_t)1 << 21) - 1)];
+            for (size_t i = 0; i < n;) {
+                size_t j = i + 1;
+                while (j < n && mv[j].x >> 8 == mv[i].x >> 8) ++j;
+                if (j - i > 1) std::sort(mv.begin() + (ptrdiff_t)i, mv.begin() + (ptrdiff_t)j, by_key_pos);
+                i = j;
+            }
+        } else {
+            std::copy(src, src + n, mv.begin());
+            std::sort(mv.begin(), mv.end(), by_key_pos);
+        }
+    }
     size_t n_keys = 0;
     for (size_t i = 0; i < mv.size(); ++i)
         if (i == 0 || mv[i].x >> 8 != mv[i - 1].x >> 8) ++n_keys;

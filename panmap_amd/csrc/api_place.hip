@@ -55,7 +55,7 @@ struct pmx_place {
     // node outputs
     hipGraphExec_t level_graph_exec = nullptr;   // captured k_score_level chain
     const void* level_graph_sig[3] = {nullptr, nullptr, nullptr};
-    DevBuf<double> metrics5, scores5, terms;
+    DevBuf<double> metrics5, scores5, scores_bfs, terms;
     DevBuf<uint32_t> chain_off, chain_nodes;   // heavy-path chains (k_score_chains), heads in BFS order
     DevBuf<uint64_t> chain_beg, chain_end;
     int64_t n_chains = 0;
@@ -409,6 +409,7 @@ int pmx_place_create(pmx_ctx* ctx, const pmx_index* idx, pmx_place** out) {
     pl->stats.alloc(8);
     pl->metrics5.alloc(5 * (size_t)n);
     pl->scores5.alloc(5 * (size_t)n);
+    pl->scores_bfs.alloc(5 * (size_t)n);
     pl->counts2.alloc(2 * (size_t)n);
     pl->tied.assign(5, {});
     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -613,7 +614,18 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     PMX_HIP(hipSetDevice(ctx->device));
     std::memset(res, 0, sizeof(*res));
     for (int m = 0; m < 5; ++m) res->best_index[m] = UINT32_MAX;
+    // PMX_PLACE_PROF=1: host wall time of the sections of this call (each mark synchronises the stream first)
+    const bool prof = getenv("PMX_PLACE_PROF") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!prof) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pmx place score] %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     finalize_histogram(ctx, pl);
+    mark("finalize_histogram (compact + sort)");
     const int64_t n = pl->n_hist;
     const int G = ctx->n_cu * 8;
     hipStream_t st = ctx->stream;
@@ -673,6 +685,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
                            pl->kept_hash.p, pl->kept_log.p);
     } else if (min_support < 0) min_support = 1;
     pl->n_kept = n_kept;
+    mark("read-side filters (homopolymer, stats, keep scan/scatter)");
     // canonical-order sums (src/placement.cpp:957-984)
     {
         const int64_t nb = (n_kept + PMX_SUM_BLOCK - 1) / PMX_SUM_BLOCK;
@@ -694,6 +707,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     PMX_HIP(hipMemcpyAsync(h_scal, pl->scalars.p, sizeof(h_scal), hipMemcpyDeviceToHost, st));
     PMX_HIP(hipStreamSynchronize(st));
     const double log_mag = std::sqrt(h_scal[0]), log_cont_den = h_scal[1], wc_den = h_scal[2];
+    mark("sums, probe table, denominators");
 
     // ---- node scoring, one launch per BFS level (src/placement.cpp:701-918)
     const int n_levels = (int)pl->level_off.size() - 1;
@@ -758,24 +772,65 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     }
     timer_end(ctx, "score", 1);
     hipLaunchKernelGGL(k_score_getters, dim3(grid_for(pl->n_nodes, 256, G)), dim3(256), 0, st, pl->metrics5.p, pl->counts2.p, pl->n_nodes, log_mag,
-                       log_cont_den, wc_den, n_kept, pl->scores5.p);
+                       log_cont_den, wc_den, n_kept, pl->scores5.p, pl->level_nodes.p, pl->scores_bfs.p);
     PMX_HIP(hipGetLastError());
     pl->h_scores.resize(5 * (size_t)pl->n_nodes);
-    PMX_HIP(hipMemcpyAsync(pl->h_scores.data(), pl->scores5.p, sizeof(double) * 5 * (size_t)pl->n_nodes, hipMemcpyDeviceToHost, st));
+    PMX_HIP(hipMemcpyAsync(pl->h_scores.data(), pl->scores_bfs.p, sizeof(double) * 5 * (size_t)pl->n_nodes, hipMemcpyDeviceToHost, st));
     uint32_t tree_status = 0;
     if (tree_kernel) PMX_HIP(hipMemcpyAsync(&tree_status, pl->tree_done.p + pl->n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PMX_HIP(hipStreamSynchronize(st));
+    mark("terms + tree scoring + getters + D2H of the scores");
     if (tree_status != 0) {
         PMX_HIP(hipMemsetAsync(pl->tree_done.p + pl->n_nodes, 0, sizeof(uint32_t), st));
         throw std::runtime_error("k_score_tree: a wave timed out waiting for its parent node");
     }
 
     // ---- sequential best/tie rule in BFS visit order (src/placement.cpp:355-401)
+    // Every improvement of `best` resets the tie list to the improving node, so only the visit positions after the
+    // LAST improvement can contribute ties: pass 1 replays just the scalar part of the rule (best, idx, position of
+    // the last improvement), pass 2 runs the full rule from that position on.  Same result as one pass with the
+    // vectors, without pushing and clearing tens of thousands of transient ties.
     Best best[5];
-    for (int64_t j = 0; j < pl->n_nodes; ++j) {
-        const uint32_t nd = pl->h_order[j];
-        if (pp->force_leaf && pl->h_has_child[nd]) continue;
-        for (int m = 0; m < 5; ++m) best[m].update(nd, pl->h_scores[5 * (size_t)nd + m]);
+    {
+        const int64_t nn = pl->n_nodes;
+        std::vector<uint8_t> flag((size_t)nn);
+        for (int m = 0; m < 5; ++m) {
+            const double* sc = pl->h_scores.data() + (size_t)m * (size_t)nn;   // this metric, in visit order
+            double b = 0.0, thr = 0.0 + std::max(0.0 * 0.0001, 1e-9);   // thr = best + tol, recomputed only when best moves
+            int64_t last = -1;
+            if (pp->force_leaf) {
+                for (int64_t j = 0; j < nn; ++j) {
+                    if (pl->h_has_child[pl->h_order[j]]) continue;
+                    if (sc[j] > thr) { b = sc[j]; thr = b + std::max(b * 0.0001, 1e-9); last = j; }
+                }
+            } else {
+                for (int64_t j = 0; j < nn; ++j)
+                    if (sc[j] > thr) { b = sc[j]; thr = b + std::max(b * 0.0001, 1e-9); last = j; }
+            }
+            if (last < 0) {   // never improved (all scores ~0): the plain rule, start to end
+                for (int64_t j = 0; j < nn; ++j) {
+                    const uint32_t nd = pl->h_order[j];
+                    if (pp->force_leaf && pl->h_has_child[nd]) continue;
+                    best[m].update(nd, sc[j]);
+                }
+                continue;
+            }
+            // after the last improvement `best` is fixed, so a later node ties iff score >= best - tol (and > 0); the
+            // rule's list, once sorted and de-duplicated, is {idx} + those nodes: flagged and read back in id order
+            best[m].best = b;
+            best[m].idx = pl->h_order[last];
+            const double tol = std::max(b * 0.0001, 1e-9);
+            std::fill(flag.begin(), flag.end(), (uint8_t)0);
+            flag[best[m].idx] = 1;
+            for (int64_t j = last + 1; j < nn; ++j) {
+                if (!(sc[j] >= b - tol && sc[j] > 0)) continue;
+                const uint32_t nd = pl->h_order[j];
+                if (pp->force_leaf && pl->h_has_child[nd]) continue;
+                flag[nd] = 1;
+            }
+            for (int64_t nd = 0; nd < nn; ++nd)
+                if (flag[(size_t)nd]) best[m].tied.push_back((uint32_t)nd);
+        }
     }
     for (int m = 0; m < 5; ++m) {
         std::vector<uint32_t>& t = best[m].tied;
@@ -789,6 +844,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
         res->best_index[m] = best[m].idx;
         res->n_tied[m] = (int64_t)t.size();
     }
+    mark("best / tie rule on the host");
     res->n_unique_seeds = (int64_t)h_stats[3];
     res->n_kept_seeds = n_kept;
     res->total_seed_freq = (int64_t)h_stats[2];

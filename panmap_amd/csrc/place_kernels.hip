@@ -996,9 +996,13 @@ k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const u
 
 // score getters (src/placement.hpp:120-149); TSV order log_raw, log_cosine, containment,
 // weighted_containment, log_containment
+// scores5[node][metric] for the node outputs, and scores_bfs[metric][visit position] for the host's sequential
+// best/tie rule (one contiguous array per metric, in the order the rule visits the nodes)
 __global__ void k_score_getters(const double* __restrict__ metrics5, const int64_t* __restrict__ counts2, int64_t n_nodes,
-                                double log_mag, double log_cont_den, double wc_den, int64_t n_kept, double* scores5) {
-    for (int64_t nd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; nd < n_nodes; nd += (int64_t)gridDim.x * blockDim.x) {
+                                double log_mag, double log_cont_den, double wc_den, int64_t n_kept, double* scores5,
+                                const uint32_t* __restrict__ order, double* scores_bfs) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_nodes; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nd = (int64_t)order[j];
         const double* m = metrics5 + 5 * nd;
         double* sc = scores5 + 5 * nd;
         sc[0] = log_mag <= 0.0 ? 0.0 : m[0] / log_mag;
@@ -1011,6 +1015,7 @@ __global__ void k_score_getters(const double* __restrict__ metrics5, const int64
         sc[2] = n_kept > 0 ? (double)(uint64_t)counts2[2 * nd] / (double)(uint64_t)n_kept : 0.0;
         sc[3] = wc_den > 0.0 ? m[2] / wc_den : 0.0;
         sc[4] = log_cont_den > 0.0 ? m[3] / log_cont_den : 0.0;
+        for (int q = 0; q < 5; ++q) scores_bfs[(size_t)q * (size_t)n_nodes + (size_t)j] = sc[q];
     }
 }
 
