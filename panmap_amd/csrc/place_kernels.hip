@@ -912,6 +912,8 @@ k_score_tree(const uint32_t* __restrict__ order, int64_t n_nodes, const uint32_t
 // Chains are sorted by the BFS position of their head and wave w takes chains w, w + W, ...: the chain that holds
 // a head's parent starts earlier, so the earliest unfinished chain never waits on an unfinished one (all W waves
 // are resident: at most one workgroup per CU).  Per node the arithmetic is k_score_level's, bit for bit.
+#define PMX_CHAIN_FLUSH 8u
+#define PMX_CHAIN_AHEAD 3
 __global__ void __launch_bounds__(256)
 k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const uint32_t* __restrict__ chain_nodes,
                const uint64_t* __restrict__ chain_beg, const uint64_t* __restrict__ chain_end, const uint32_t* __restrict__ parent,
@@ -925,13 +927,26 @@ k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const u
     double* sh = stage[wib];
     for (int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + wib; c < n_chains; c += n_waves) {
         const uint32_t cb = chain_off[c], ce = chain_off[c + 1];
-        uint32_t ent = chain_nodes[cb];
-        uint64_t beg = chain_beg[cb], end = chain_end[cb];
-        // lookahead: the ranges of the next node, whose terms are requested one node ahead
-        uint32_t ent2 = cb + 1 < ce ? chain_nodes[cb + 1] : 0u;
-        uint64_t beg2 = cb + 1 < ce ? chain_beg[cb + 1] : 0, end2 = cb + 1 < ce ? chain_end[cb + 1] : 0;
-        ScoreTerms cur = load_terms(beg + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
-        ScoreTerms nx1 = load_terms(beg + 64 + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+        // Software pipeline over the chain: the first two 64-change chunks of the nodes k+1 .. k+PMX_CHAIN_AHEAD are
+        // in flight while node k is added up (a node's own arithmetic is a fraction of a microsecond, a load from
+        // HBM two), and the (node, range) records run one node further ahead still.
+        constexpr int AH = PMX_CHAIN_AHEAD;
+        uint32_t m_ent[AH + 2];
+        uint64_t m_beg[AH + 2], m_end[AH + 2];
+#pragma unroll
+        for (int a_ = 0; a_ < AH + 2; ++a_) {
+            const bool in = cb + (uint32_t)a_ < ce;
+            m_ent[a_] = in ? chain_nodes[cb + a_] : 0u;
+            m_beg[a_] = in ? chain_beg[cb + a_] : 0;
+            m_end[a_] = in ? chain_end[cb + a_] : 0;
+        }
+        ScoreTerms q_cur[AH + 1], q_nx1[AH + 1];
+#pragma unroll
+        for (int a_ = 0; a_ < AH + 1; ++a_) {
+            q_cur[a_] = load_terms(m_beg[a_] + lane, m_end[a_], t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+            q_nx1[a_] = load_terms(m_beg[a_] + 64 + lane, m_end[a_], t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+        }
+        uint32_t ent = m_ent[0];
         double acc = 0.0;              // lane k < 5: accumulator k (raw, cos, wc, lc, mag)
         int64_t c0 = 0, c1 = 0;
         const uint32_t head = ent & 0x7fffffffu;
@@ -951,14 +966,23 @@ k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const u
             if (lane < 5) acc = metrics5[5 * (size_t)pa + lane];
             c0 = counts2[2 * (size_t)pa + 0]; c1 = counts2[2 * (size_t)pa + 1];
         }
+        // Flags are published in batches: the release fence (an L2 write-back plus a wait, ~2-6 us) would otherwise sit
+        // on the chain's critical path at every node that has a second child -- on a caterpillar-shaped tree that is
+        // every node of the spine.  One fence per PMX_CHAIN_FLUSH publishing nodes (and one at the chain's end)
+        // covers all their stores; the lanes then set the flags of chain positions [k_from, k] in one instruction.
+        uint32_t k_from = cb, n_pend = 0;
         for (uint32_t k = cb; k < ce; ++k) {
+            ent = m_ent[0];
             const uint32_t nd = ent & 0x7fffffffu;
             const bool publish = (ent >> 31) != 0;
-            // request the next node's first two chunks and the ranges of the node after it
-            const ScoreTerms f_cur = load_terms(beg2 + lane, end2, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
-            const ScoreTerms f_nx1 = load_terms(beg2 + 64 + lane, end2, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
-            const uint32_t ent3 = k + 2 < ce ? chain_nodes[k + 2] : 0u;
-            const uint64_t beg3 = k + 2 < ce ? chain_beg[k + 2] : 0, end3 = k + 2 < ce ? chain_end[k + 2] : 0;
+            const uint64_t beg = m_beg[0], end = m_end[0];
+            ScoreTerms cur = q_cur[0], nx1 = q_nx1[0];
+            // request the chunks of node k + AH + 1 (its record arrived an iteration ago) and the record after that
+            const ScoreTerms f_cur = load_terms(m_beg[AH + 1] + lane, m_end[AH + 1], t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+            const ScoreTerms f_nx1 = load_terms(m_beg[AH + 1] + 64 + lane, m_end[AH + 1], t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
+            const bool in_f = k + (uint32_t)(AH + 2) < ce;
+            const uint32_t f_ent = in_f ? chain_nodes[k + AH + 2] : 0u;
+            const uint64_t f_beg = in_f ? chain_beg[k + AH + 2] : 0, f_end = in_f ? chain_end[k + AH + 2] : 0;
             for (uint64_t base = beg; base < end; base += 64) {
                 const ScoreTerms nx2 = load_terms(base + 128 + lane, end, t_mag, t_raw, t_cos, t_wc, t_lc, t_meta);
                 const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
@@ -983,13 +1007,22 @@ k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const u
             }
             if (lane < 5) metrics5[5 * (size_t)nd + lane] = acc;
             if (lane == 0) { counts2[2 * (size_t)nd + 0] = c0; counts2[2 * (size_t)nd + 1] = c1; }
-            if (publish) {   // children in other chains wait for this node
+            n_pend += publish ? 1u : 0u;   // children in other chains wait for this node
+            if (n_pend >= PMX_CHAIN_FLUSH || (k + 1 == ce && n_pend > 0)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (lane == 0) __hip_atomic_store(&done[nd], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (uint32_t q = k_from + (uint32_t)lane; q <= k; q += 64u) {
+                    const uint32_t e = chain_nodes[q];
+                    if (e >> 31) __hip_atomic_store(&done[e & 0x7fffffffu], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                k_from = k + 1;
+                n_pend = 0;
             }
-            ent = ent2; beg = beg2; end = end2;
-            ent2 = ent3; beg2 = beg3; end2 = end3;
-            cur = f_cur; nx1 = f_nx1;
+#pragma unroll
+            for (int a_ = 0; a_ < AH; ++a_) { q_cur[a_] = q_cur[a_ + 1]; q_nx1[a_] = q_nx1[a_ + 1]; }
+            q_cur[AH] = f_cur; q_nx1[AH] = f_nx1;
+#pragma unroll
+            for (int a_ = 0; a_ < AH + 1; ++a_) { m_ent[a_] = m_ent[a_ + 1]; m_beg[a_] = m_beg[a_ + 1]; m_end[a_] = m_end[a_ + 1]; }
+            m_ent[AH + 1] = f_ent; m_beg[AH + 1] = f_beg; m_end[AH + 1] = f_end;
         }
     }
 }
