@@ -218,7 +218,11 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             const Layout dp_layout = plan_layout_dp((int)rs->max_len, n_segs, al->opt);
             const size_t dp_lds = PMX_ALIGN_WORK_BYTES + dp_layout.fast_bytes + 16;
             const size_t dp_stride = (dp_layout.slow_bytes + 255) & ~(size_t)255;
-            int64_t small_rounds = 16384;   // fewer pairs than this cannot fill the chip thread-per-pair: wave tier
+            // A replay round costs a fixed ~4-5 ms (one pair's pass through the thread-per-pair kernel) plus the DPs, the
+            // wave tier ~0.2 us per easy pair and ~0.9 us per hard one.  First round (pairs asking for their first DP: mostly
+            // easy ones): the wave tier below 16,384 pairs.  Later rounds hold the pairs that needed a DP before, i.e.
+            // hard ones: another service round pays down to a quarter of that (real 150 bp reads: 53.8 -> 50.3 ms).
+            int64_t small_rounds = 16384;
             if (const char* e = getenv("PMX_ALIGN_TPP_MIN")) small_rounds = atoll(e);
             const int64_t dp_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dp_lds);
             const int small_qlen = 192, small_tlen = 192;   // ksw_extd2_reg<3>: up to three target columns per lane
@@ -271,7 +275,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             int round = 1;
             int64_t n_small = 0;
             while (n_dp > 0) {   // ends by itself: a pair posts at most PMX_DP_MAX_CALLS requests, then goes to the wave tier
-                if (n_dp < small_rounds) {   // remainder: wave-per-pair kernel over the slots (dp_slot_pairs maps them to pairs)
+                if (n_dp < (round == 1 ? small_rounds : small_rounds / 4)) {   // remainder: wave-per-pair kernel over the slots (dp_slot_pairs maps them to pairs)
                     n_small = n_dp;
                     break;
                 }
