@@ -20,11 +20,27 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* _
                              const int64_t* __restrict__ woff, int64_t n_reads, int64_t n_words,
                              uint64_t* __restrict__ words, uint32_t* __restrict__ amb) {
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
-        // read r with woff[r] <= w < woff[r+1]
-        int64_t lo = 0, hi = n_reads;
-        while (hi - lo > 1) {
-            int64_t mid = (lo + hi) >> 1;
-            if (woff[mid] <= w) lo = mid; else hi = mid;
+        // read r with woff[r] <= w < woff[r+1]: start from the proportional guess (exact for reads of one length: two
+        // loads instead of log2(n) dependent ones), gallop to a bracket, then bisect
+        int64_t lo, hi;
+        {
+            int64_t g = (int64_t)((double)w * (double)n_reads / (double)n_words);
+            g = g < 0 ? 0 : (g > n_reads - 1 ? n_reads - 1 : g);
+            if (woff[g] <= w) {
+                lo = g;
+                int64_t step = 1;
+                hi = g + 1;
+                while (hi < n_reads && woff[hi] <= w) { lo = hi; step <<= 1; hi = hi + step < n_reads ? hi + step : n_reads; }
+            } else {
+                hi = g;
+                int64_t step = 1;
+                lo = g - 1;
+                while (lo > 0 && woff[lo] > w) { hi = lo; step <<= 1; lo = lo - step > 0 ? lo - step : 0; }
+            }
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (woff[mid] <= w) lo = mid; else hi = mid;
+            }
         }
         const int64_t r = lo;
         const int64_t base0 = (w - woff[r]) * 32;
@@ -34,16 +50,13 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* _
         uint64_t v = 0;
         uint32_t a = 0;
         for (int j = 0; j < nb; ++j) {
-            uint8_t ch = p[j];
-            uint32_t code, am = 0;
-            switch (ch) {
-                case 'A': case 'a': code = 0; break;
-                case 'C': case 'c': code = 1; break;
-                case 'G': case 'g': code = 2; break;
-                case 'T': case 't': code = 3; break;
-                case 'U': case 'u': code = 3; am = 1; break;
-                default: code = 0; am = 1; break;
-            }
+            // A C G T (either case) -> 0 1 2 3 without a branch: with c = ch & 0xDF, ((c >> 1) ^ (c >> 2)) & 3 maps
+            // 0x41 0x43 0x47 0x54 to 0 1 2 3 (and U = 0x55 to 3); anything else is ambiguous with code 0
+            const uint32_t c = (uint32_t)p[j] & 0xDFu;
+            const uint32_t tr = ((c >> 1) ^ (c >> 2)) & 3u;
+            const bool acgt = c == 0x41u || c == 0x43u || c == 0x47u || c == 0x54u;
+            const bool is_u = c == 0x55u;
+            const uint32_t code = (acgt || is_u) ? tr : 0u, am = acgt ? 0u : 1u;
             v |= (uint64_t)code << (2 * j);
             a |= am << j;
         }
