@@ -110,7 +110,9 @@ def test_place_dedup(pmx, oracle, ctx, sars, sars_index):
     _check_place(pmx, oracle, ctx, sars_index, allr, pmx.TraversalParams(dedupReads=False))
 
 
-@pytest.mark.parametrize("k,s,l,open_syncmer,t", [(15, 8, 1, False, 0), (31, 6, 3, False, 0), (19, 8, 2, True, 3), (21, 10, 4, False, 2)])
+# (the three k=19, s=8, t=0 rows run the kernel specialised for the default k/s with the other l / open settings)
+@pytest.mark.parametrize("k,s,l,open_syncmer,t", [(15, 8, 1, False, 0), (31, 6, 3, False, 0), (19, 8, 2, True, 3), (21, 10, 4, False, 2),
+                                                  (19, 8, 1, False, 0), (19, 8, 3, True, 0), (19, 8, 5, False, 0)])
 def test_place_other_parameters(pmx, oracle, ctx, sars, k, s, l, open_syncmer, t):
     # a small hand-made index over the real hashes keeps this fast: root = seeds of one genome
     g = sars.genome("node_5")
