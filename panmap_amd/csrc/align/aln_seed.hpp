@@ -370,7 +370,8 @@ PMX_HDN void seed_select(int n, Ptr<SeedA> a, int len, int max_occ, int max_max_
 PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
     PMX_LDS(&W);
     Ptr<A128> mv = W.mv; PMX_LDS(mv);
-    Ptr<A128> hp = W.heap; PMX_LDS(hp);
+    Ptr<A128> hp = W.heap; PMX_LDS(hp);   // (wave models: scratch for the lane-parallel probes)
+    (void)hp;
     Ptr<SeedA> seeds = W.seeds; PMX_LDS(seeds);
     Ptr<SeedB> seeds_b = W.seeds_b; PMX_LDS(seeds_b);
     Ptr<uint64_t> mini_pos = W.mini_pos;   // global scratch (only mm_est_err would read it)
