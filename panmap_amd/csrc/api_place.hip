@@ -35,6 +35,7 @@ struct pmx_place {
     uint64_t cap = 0;
     DevBuf<unsigned long long> counters;   // PMX_CTR_N
     int64_t n_reads_added = 0;
+    bool table_dirty = false;              // something was inserted since the last reset
     // finalised histogram
     DevBuf<uint64_t> hist_hash, hist_hash_tmp;
     DevBuf<int64_t> hist_count, hist_count_tmp;
@@ -437,6 +438,7 @@ int pmx_place_reset(pmx_ctx* ctx, pmx_place* pl) {
     pl->n_reads_added = 0;
     pl->hist_sorted = false;
     pl->n_hist = 0;
+    pl->table_dirty = false;
     return PMX_OK;
     PMX_CATCH
 }
@@ -487,10 +489,21 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         int64_t chunk_mb = 16;
         if (const char* e = getenv("PMX_SEED_CHUNK_MB")) chunk_mb = std::max<int64_t>(1, atoll(e));
         const int64_t chunk_reads = std::max<int64_t>(1, (chunk_mb << 20) / std::max<int64_t>(rs->max_len, 1));
+        // Table sizing.  The safe bound on the distinct keys a chunk can add is one per base; real reads add one seed per
+        // 5-6 bases and most of those repeat.  When the table is empty at the start of the call the chunks are first run
+        // with a third of the safe bound (a 4x smaller table to clear, probe and compact); an insert that finds no slot is
+        // counted (probe sequences are capped), and in that case the table is cleared and the call is redone with the safe
+        // bound.  Same histogram either way.
+        int64_t bound_div = 1;
+        if (!pl->table_dirty && !getenv("PMX_SEED_SAFE_BOUND")) {
+            bound_div = 3;
+            if (const char* e = getenv("PMX_SEED_BOUND_DIV")) bound_div = std::max<int64_t>(1, atoll(e));   // (tests force the redo with a large value)
+        }
         timer_begin(ctx, "seed");
+        for (int attempt = 0; attempt < 2; ++attempt) {
         for (int64_t r0 = 0; r0 < rs->n; r0 += chunk_reads) {
             const int64_t r1 = std::min<int64_t>(rs->n, r0 + chunk_reads);
-            table_reserve(ctx, pl, (uint64_t)((r1 - r0) * rs->max_len));
+            table_reserve(ctx, pl, (uint64_t)((r1 - r0) * rs->max_len / bound_div) + 1);
             const dim3 grid(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
             // the default seeding parameters run the kernel specialised for them (same results, ~3x fewer instructions)
             if (sp.k == 19 && sp.s == 8 && sp.t == 0 && !quality_mode && !getenv("PMX_SEED_GENERIC"))
@@ -502,10 +515,23 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
                                    quality_mode ? pp->min_seed_quality : 0);
             PMX_HIP(hipGetLastError());
         }
+        if (bound_div == 1) break;
+        unsigned long long h_ovf = 0;
+        PMX_HIP(hipMemcpyAsync(&h_ovf, pl->counters.p + PMX_CTR_OVERFLOW, sizeof(h_ovf), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        if (getenv("PMX_PLACE_PROF")) fprintf(stderr, "[pmx place] seeding with bound 1/%lld: table %llu slots, %llu failed inserts\n", (long long)bound_div, (unsigned long long)pl->cap, h_ovf);
+        if (h_ovf == 0) break;
+        // the optimistic table overflowed: start over with the safe bound
+        PMX_HIP(hipMemsetAsync(pl->counters.p, 0, sizeof(unsigned long long) * PMX_CTR_N, ctx->stream));
+        hipLaunchKernelGGL(k_fill_u64, dim3(grid_for((int64_t)pl->cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p, PMX_EMPTY_KEY, pl->cap);
+        PMX_HIP(hipMemsetAsync(pl->vals.p, 0, pl->cap * sizeof(unsigned long long), ctx->stream));
+        bound_div = 1;
+        }
         timer_end(ctx, "seed", 1);
     }
     pl->n_reads_added += rs->n;
     pl->hist_sorted = false;
+    pl->table_dirty = true;
     return PMX_OK;
     PMX_CATCH
 }
@@ -559,6 +585,7 @@ int pmx_place_histogram_merge_device(pmx_ctx* ctx, pmx_place* pl, const void* d_
                        (const int64_t*)d_count, n, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     pl->hist_sorted = false;
+    pl->table_dirty = true;
     return PMX_OK;
     PMX_CATCH
 }
@@ -585,6 +612,7 @@ int pmx_place_histogram_merge_device_parts(pmx_ctx* ctx, pmx_place* pl, const vo
     PMX_HIP(hipGetLastError());
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     pl->hist_sorted = false;
+    pl->table_dirty = true;
     return PMX_OK;
     PMX_CATCH
 }
@@ -604,6 +632,7 @@ int pmx_place_histogram_merge(pmx_ctx* ctx, pmx_place* pl, const uint64_t* hash,
                        pl->cap - 1, pl->counters.p);
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     pl->hist_sorted = false;
+    pl->table_dirty = true;
     return PMX_OK;
     PMX_CATCH
 }

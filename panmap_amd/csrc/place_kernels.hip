@@ -115,8 +115,15 @@ __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long*
     // the table: the ~10^4 true seeds of a sample are hit millions of times) needs no compare-and-swap: a plain
     // device-scope load finds the slot and the count is bumped with a fire-and-forget atomic add.  A returning
     // CAS on those hot lines cost microseconds each and the 37 inserts of a read are serial.
+    // (probe sequences are capped: at the load factors the host keeps, a run of 4096 occupied slots means the table was
+    //  sized too small; the insert is counted as an overflow and the host starts over with a larger table)
     uint64_t slot = mix64(key) & mask;
-    for (uint64_t probes = 0; probes <= mask; ++probes) {
+    const uint64_t max_probes = mask < 4096 ? mask : 4096;
+    for (uint64_t probes = 0; probes <= max_probes; ++probes) {
+        // a long probe sequence: if some insert has already failed the host will redo the call with a larger table, so
+        // stop walking a full one.  (Checked only here: every wave polling one word at every drain costs +190 us per
+        // launch -- reads of a single address are served one after the other.)
+        if ((probes & 63) == 63 && __hip_atomic_load(&counters[PMX_CTR_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ULL) return;
         const unsigned long long cur = __hip_atomic_load((unsigned long long*)&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == key) {
             atomicAdd(&vals[slot], mult);
