@@ -884,7 +884,8 @@ k_score_tree(const uint32_t* __restrict__ order, int64_t n_nodes, const uint32_t
             bool ok = true;
             while (__hip_atomic_load(&done[pa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++polls > (1u << 24) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                // (the shared status word is looked at every 1024 polls only: one word read by every waiting wave is a hot spot)
+                if (++polls > (1u << 24) || ((polls & 1023u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = false; break; }
             }
             if (!ok) {   // uniform: every lane polls the same flag
                 if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -976,7 +977,8 @@ k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const u
             bool ok = true;
             while (__hip_atomic_load(&done[pa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++polls > (1u << 24) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                // (the shared status word is looked at every 1024 polls only: one word read by every waiting wave is a hot spot)
+                if (++polls > (1u << 24) || ((polls & 1023u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = false; break; }
             }
             if (!ok) {   // uniform: every lane polls the same flag
                 if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
