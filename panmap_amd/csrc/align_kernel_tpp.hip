@@ -83,26 +83,61 @@ k_align_reads_tpp(AlignArgs A) {
                 Ptr<uint8_t> X = rc ? W.qseq[s][1] : W.qseq[s][0];
                 Ptr<uint8_t> Y = rc ? W.qseq[s][0] : W.qseq[s][1];
                 Ptr<uint32_t> X4 = ptr_cast<uint32_t>(X), Y4 = ptr_cast<uint32_t>(Y);
+                // four bases at a time: one byte of the packed word expands to one 32-bit word of base codes (the
+                // ambiguity nibble is almost always zero), and the reverse complement is produced from the packed
+                // words as well (not by reading X back from the arena): byte-reversed, 3 - code
+                auto expand4 = [](uint32_t b) { return (b & 3u) | (b & 0xcu) << 6 | (b & 0x30u) << 12 | (b & 0xc0u) << 18; };
+                auto code_of = [](uint32_t code, uint32_t am) { return am ? (code == 3u ? 3u : 4u) : code; };
                 uint64_t cw = 0;
-                uint32_t ca = 0, wd = 0;
-                for (int i = 0; i < len; ++i) {
-                    if ((i & 31) == 0) { cw = rw[i >> 5]; ca = ra[i >> 5]; }
-                    const uint32_t code = (uint32_t)cw & 3u, am = ca & 1u;
-                    cw >>= 2; ca >>= 1;
-                    const uint32_t c = am ? (code == 3 ? 3u : 4u) : code;
-                    wd |= c << ((i & 3) * 8);
-                    if ((i & 3) == 3) { X4[i >> 2] = wd; wd = 0; }
+                uint32_t ca = 0;
+                const int n4 = len >> 2;
+                for (int g = 0; g < n4; ++g) {
+                    if ((g & 7) == 0) { cw = rw[g >> 3]; ca = ra[g >> 3]; }
+                    const uint32_t b = (uint32_t)cw & 0xffu, am4 = ca & 0xfu;
+                    cw >>= 8; ca >>= 4;
+                    uint32_t wd = expand4(b);
+                    if (am4) {
+                        wd = 0;
+                        for (int k = 0; k < 4; ++k) wd |= code_of(b >> (2 * k) & 3u, am4 >> k & 1u) << (8 * k);
+                    }
+                    X4[g] = wd;
                 }
-                for (int i = len & ~3; i < len; ++i) X[i] = (uint8_t)(wd >> ((i & 3) * 8));
-                ByteReader xr(X);
-                wd = 0;
-                for (int j = 0; j < len; ++j) {
-                    const uint32_t c = xr[len - 1 - j];
-                    const uint32_t cc = c < 4 ? 3u - c : 4u;
-                    wd |= cc << ((j & 3) * 8);
-                    if ((j & 3) == 3) { Y4[j >> 2] = wd; wd = 0; }
+                for (int i = n4 << 2; i < len; ++i) {
+                    const uint32_t code = (uint32_t)(rw[i >> 5] >> (2 * (i & 31))) & 3u, am = ra[i >> 5] >> (i & 31) & 1u;
+                    X[i] = (uint8_t)code_of(code, am);
                 }
-                for (int j = len & ~3; j < len; ++j) Y[j] = (uint8_t)(wd >> ((j & 3) * 8));
+                int cur = -1;
+                uint64_t w64 = 0;
+                uint32_t a32 = 0;
+                for (int g = 0; g < n4; ++g) {   // Y[4g .. 4g+3] = complement of X[len-1-4g .. len-4-4g]
+                    const int hi = len - 1 - 4 * g, lo = hi - 3;
+                    uint32_t wd;
+                    if ((lo >> 5) == (hi >> 5)) {
+                        if ((hi >> 5) != cur) { cur = hi >> 5; w64 = rw[cur]; a32 = ra[cur]; }
+                        const uint32_t b = (uint32_t)(w64 >> (2 * (lo & 31))) & 0xffu, am4 = a32 >> (lo & 31) & 0xfu;
+                        if (!am4) wd = 0x03030303u - __builtin_bswap32(expand4(b));
+                        else {
+                            wd = 0;
+                            for (int k = 0; k < 4; ++k) {   // byte k of Y = position hi - k = bit pair (3 - k) of b
+                                const uint32_t c = code_of(b >> (2 * (3 - k)) & 3u, am4 >> (3 - k) & 1u);
+                                wd |= (c < 4u ? 3u - c : 4u) << (8 * k);
+                            }
+                        }
+                    } else {   // the four bases straddle two packed words
+                        wd = 0;
+                        for (int k = 0; k < 4; ++k) {
+                            const int pp = hi - k;
+                            const uint32_t c = code_of((uint32_t)(rw[pp >> 5] >> (2 * (pp & 31))) & 3u, ra[pp >> 5] >> (pp & 31) & 1u);
+                            wd |= (c < 4u ? 3u - c : 4u) << (8 * k);
+                        }
+                    }
+                    Y4[g] = wd;
+                }
+                for (int j = n4 << 2; j < len; ++j) {
+                    const int pp = len - 1 - j;
+                    const uint32_t c = code_of((uint32_t)(rw[pp >> 5] >> (2 * (pp & 31))) & 3u, ra[pp >> 5] >> (pp & 31) & 1u);
+                    Y[j] = (uint8_t)(c < 4u ? 3u - c : 4u);
+                }
             }
             PMX_STAMP(W, 0);
             map_frag(W, A.opt, A.ri);
