@@ -232,7 +232,115 @@ PMX_HD void sketch_segment_reg(Work& W, Ptr<const uint8_t> seq, int len, int w, 
 }
 #endif
 
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+// Wave-per-pair kernels: the same sketch with the window ring held ACROSS THE LANES (lane j = slot j, w <= 64).  All
+// scalar state is wave-uniform (the base is broadcast with readfirstlane, so the k-mer arithmetic runs on the scalar
+// unit); the ring write is one predicated move, the re-scan a wave-wide 64-bit minimum plus a ballot, and reading a
+// slot a readlane -- no LDS round trips in the per-base loop (the ring-in-LDS form spends ~1200 cycles per base,
+// more than half of a tier-1 pair).  Scan order, tie rules and the emitted minimizers are sketch_segment_t's (see
+// sketch_segment_reg for the argument).
+__device__ __forceinline__ uint64_t sk_rl64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return (uint64_t)hi << 32 | lo;
+}
+__device__ void sketch_segment_wave(Work& W, const uint8_t* seq, int len, int w, int k, uint32_t rid) {
+    const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
+    const uint64_t y_hi = (uint64_t)rid << 32;
+    const int lane = lane_id();
+    uint64_t kmer0 = 0, kmer1 = 0;
+    int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
+    PMX_LDS(&W); PMX_LDS(seq);
+    A128* mvp = W.mv; PMX_LDS(mvp);
+    int n_mv = W.n_mv;
+    const int max_mini = W.caps.max_mini;
+    bool overflow = false;
+    A128 mn;
+    mn.x = mn.y = UINT64_MAX;
+    uint64_t rx = UINT64_MAX;     // this lane's ring slot (lanes >= w stay invalid)
+    uint32_t ry = 0xffffffffu;
+    auto ring_get = [&](int j) {
+        A128 v;
+        v.x = sk_rl64(rx, j);
+        const uint32_t yl = (uint32_t)__builtin_amdgcn_readlane((int)ry, j);
+        v.y = v.x == UINT64_MAX ? UINT64_MAX : (y_hi | yl);
+        return v;
+    };
+#define PMX_MV_PUSH(val)                                      \
+    do {                                                      \
+        if (n_mv < max_mini) { if (lane == 0) mvp[n_mv] = (val); ++n_mv; } \
+        else overflow = true;                                 \
+    } while (0)
+    for (int i = 0; i < len; ++i) {
+        const int c = __builtin_amdgcn_readfirstlane((int)seq[i]);
+        A128 info;
+        info.x = info.y = UINT64_MAX;
+        if (c < 4) {
+            kmer_span = l + 1 < k ? l + 1 : k;
+            kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+            kmer1 = (kmer1 >> 2) | (uint64_t)(3 ^ c) << shift1;
+            if (kmer0 == kmer1) continue;   // strand-symmetric k-mer: skipped without advancing the window
+            const int z = kmer0 < kmer1 ? 0 : 1;
+            ++l;
+            if (l >= k && kmer_span < 256) {
+                info.x = mz_hash64(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)kmer_span;
+                info.y = y_hi | (uint32_t)i << 1 | (uint32_t)z;
+            }
+        } else {
+            l = 0;
+            kmer_span = 0;
+        }
+        if (lane == buf_pos) { rx = info.x; ry = (uint32_t)info.y; }
+        if (l == w + k - 1 && mn.x != UINT64_MAX) {   // first full window: emit earlier identical k-mers
+            for (int j = buf_pos + 1; j < w; ++j)
+                { const A128 bj = ring_get(j); if (mn.x == bj.x && bj.y != mn.y) PMX_MV_PUSH(bj); }
+            for (int j = 0; j < buf_pos; ++j)
+                { const A128 bj = ring_get(j); if (mn.x == bj.x && bj.y != mn.y) PMX_MV_PUSH(bj); }
+        }
+        if (info.x <= mn.x) {                          // new minimum: flush the old one
+            if (l >= w + k && mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
+            mn = info;
+            min_pos = buf_pos;
+        } else if (buf_pos == min_pos) {               // the minimum slid out of the window
+            if (l >= w + k - 1 && mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
+            uint64_t m = rx;                           // wave-wide minimum of the slots
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t other = __shfl_xor(m, o);
+                m = other < m ? other : m;
+            }
+            m = sk_rl64(m, 0);                         // (every lane holds it; make it a scalar)
+            const unsigned long long eq = __ballot(lane < w && rx == m);   // slots that hold it (never empty)
+            // last in scan order (j = buf_pos+1 .. w-1, 0 .. buf_pos, '>=') = the largest slot <= buf_pos if there is
+            // one, else the largest slot
+            const unsigned long long lo = eq & ((2ULL << buf_pos) - 1ULL);
+            const int best_j = 63 - __builtin_clzll(lo ? lo : eq);
+            const uint32_t best_y = (uint32_t)__builtin_amdgcn_readlane((int)ry, best_j);
+            mn.x = m;
+            mn.y = m == UINT64_MAX ? UINT64_MAX : (y_hi | best_y);
+            min_pos = best_j;
+            if (l >= w + k - 1 && mn.x != UINT64_MAX && (eq & ~(1ULL << min_pos)) != 0ULL) {   // other occurrences of the minimum
+                for (int j = buf_pos + 1; j < w; ++j)
+                    if ((eq >> j & 1ULL) && j != min_pos) PMX_MV_PUSH(ring_get(j));
+                for (int j = 0; j <= buf_pos; ++j)
+                    if ((eq >> j & 1ULL) && j != min_pos) PMX_MV_PUSH(ring_get(j));
+            }
+        }
+        if (++buf_pos == w) buf_pos = 0;
+    }
+    if (mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
+#undef PMX_MV_PUSH
+    wave_sync();
+    W.n_mv = n_mv;
+    if (overflow) W.status |= PMX_ST_OVERFLOW;
+}
+#endif
+
 PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+    if (w >= 1 && w <= 64 && !W.sk_no_lane_ring) {
+        sketch_segment_wave(W, seq, len, w, k, rid);
+        return;
+    }
+#endif
 #if PMX_W == 1
     if (w >= 1 && w <= 16) {   // the ring is unrolled to the next size class (sr preset: w = 11)
         if (w <= 8) sketch_segment_reg<8>(W, seq, len, w, k, rid);

@@ -428,7 +428,8 @@ struct Work {
     // optional phase profile (diagnostic runs only: AlignArgs::prof != NULL)
     unsigned long long* prof;
     unsigned long long prof_t;
-    unsigned long long prof_acc[24];   // [0..11] phases, [16..23] sub-phases of seeding / chaining / align1 (PMX_ALIGN_PROF)
+    unsigned long long prof_acc[24];
+    int sk_no_lane_ring;   // wave models: 1 = sketch with the ring in LDS (comparison / fallback switch)   // [0..11] phases, [16..23] sub-phases of seeding / chaining / align1 (PMX_ALIGN_PROF)
 };
 
 }  // namespace aln

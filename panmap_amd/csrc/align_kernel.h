@@ -27,6 +27,7 @@ struct AlignArgs {
     uint32_t dp_slot_cap;
     int dp_round;
     int tpp_ring_w;             // k_align_reads_tpp: minimizer window length when the ring lives in LDS, else 0
+    int sk_no_lane_ring;        // wave-per-pair kernels: 1 = sketch with the window ring in LDS instead of across the lanes
     int dp_class;               // k_align_dp_serve: 0 = every request, 1 = only small ones, 2 = only the others
     int dp_small_qlen, dp_small_tlen;   // register-DP class: qlen <=, tlen <=, traceback bytes <= dp_small_tb
     uint32_t dp_small_tb;

@@ -31,6 +31,7 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
         bind_work(W, A.layout, fast, slow);
         W.n_segs = n_segs;
         W.prof = A.prof;
+        W.sk_no_lane_ring = A.sk_no_lane_ring;
         if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 24; ++k) W.prof_acc[k] = 0; }
         bool too_long = false;
         for (int s = 0; s < n_segs; ++s) {

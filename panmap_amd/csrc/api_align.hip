@@ -193,6 +193,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
     A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
     A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.dp_small_tb = 0; A.tpp_ring_w = 0;
+    A.sk_no_lane_ring = getenv("PMX_ALIGN_NO_LANE_RING") ? 1 : 0;
     timer_begin(ctx, "align");
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
