@@ -36,6 +36,8 @@ struct pmx_place {
     DevBuf<unsigned long long> counters;   // PMX_CTR_N
     int64_t n_reads_added = 0;
     bool table_dirty = false;              // something was inserted since the last reset
+    hipStream_t seed_streams[3] = {nullptr, nullptr, nullptr};   // side streams: seeding launches of one group run concurrently
+    hipEvent_t seed_go = nullptr, seed_done[3] = {nullptr, nullptr, nullptr};
     // finalised histogram
     DevBuf<uint64_t> hist_hash, hist_hash_tmp;
     DevBuf<int64_t> hist_count, hist_count_tmp;
@@ -422,6 +424,13 @@ int pmx_place_create(pmx_ctx* ctx, const pmx_index* idx, pmx_place** out) {
 void pmx_place_free(pmx_ctx* ctx, pmx_place* pl) {
     if (ctx) (void)hipSetDevice(ctx->device);
     if (pl && pl->level_graph_exec) (void)hipGraphExecDestroy(pl->level_graph_exec);
+    if (pl) {
+        for (int j = 0; j < 3; ++j) {
+            if (pl->seed_streams[j]) (void)hipStreamDestroy(pl->seed_streams[j]);
+            if (pl->seed_done[j]) (void)hipEventDestroy(pl->seed_done[j]);
+        }
+        if (pl->seed_go) (void)hipEventDestroy(pl->seed_go);
+    }
     delete pl;
 }
 
@@ -491,29 +500,51 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         const int64_t chunk_reads = std::max<int64_t>(1, (chunk_mb << 20) / std::max<int64_t>(rs->max_len, 1));
         // Table sizing.  The safe bound on the distinct keys a chunk can add is one per base; real reads add one seed per
         // 5-6 bases and most of those repeat.  When the table is empty at the start of the call the chunks are first run
-        // with a third of the safe bound (a 4x smaller table to clear, probe and compact); an insert that finds no slot is
+        // with an eighth of the safe bound (a smaller table to clear, probe and compact); an insert that finds no slot is
         // counted (probe sequences are capped), and in that case the table is cleared and the call is redone with the safe
         // bound.  Same histogram either way.
         int64_t bound_div = 1;
         if (!pl->table_dirty && !getenv("PMX_SEED_SAFE_BOUND")) {
-            bound_div = 3;
+            bound_div = 8;
             if (const char* e = getenv("PMX_SEED_BOUND_DIV")) bound_div = std::max<int64_t>(1, atoll(e));   // (tests force the redo with a large value)
         }
         timer_begin(ctx, "seed");
         for (int attempt = 0; attempt < 2; ++attempt) {
-        for (int64_t r0 = 0; r0 < rs->n; r0 += chunk_reads) {
-            const int64_t r1 = std::min<int64_t>(rs->n, r0 + chunk_reads);
-            table_reserve(ctx, pl, (uint64_t)((r1 - r0) * rs->max_len / bound_div) + 1);
+        // A launch of one chunk is latency-bound (every wave walks its 150 bases one after the other, a few waves per
+        // SIMD): the chunks of a group run concurrently on side streams, sharing the table (all they do is atomics).
+        int n_par = 3;
+        if (const char* e = getenv("PMX_SEED_PAR")) n_par = std::max(1, std::min(4, atoi(e)));
+        if (n_par > 1 && !pl->seed_go) {
+            PMX_HIP(hipEventCreateWithFlags(&pl->seed_go, hipEventDisableTiming));
+            for (int j = 0; j < 3; ++j) {
+                PMX_HIP(hipStreamCreateWithFlags(&pl->seed_streams[j], hipStreamNonBlocking));
+                PMX_HIP(hipEventCreateWithFlags(&pl->seed_done[j], hipEventDisableTiming));
+            }
+        }
+        for (int64_t g0 = 0; g0 < rs->n; g0 += chunk_reads * n_par) {
+            const int64_t g1 = std::min<int64_t>(rs->n, g0 + chunk_reads * n_par);
+            table_reserve(ctx, pl, (uint64_t)((g1 - g0) * rs->max_len / bound_div) + 1);
+            if (n_par > 1) PMX_HIP(hipEventRecord(pl->seed_go, ctx->stream));
+            int j = 0;
+            for (int64_t r0 = g0; r0 < g1; r0 += chunk_reads, ++j) {
+            const int64_t r1 = std::min<int64_t>(g1, r0 + chunk_reads);
+            hipStream_t st = j == 0 ? ctx->stream : pl->seed_streams[j - 1];
+            if (j > 0) PMX_HIP(hipStreamWaitEvent(st, pl->seed_go, 0));
             const dim3 grid(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
             // the default seeding parameters run the kernel specialised for them (same results, ~3x fewer instructions)
             if (sp.k == 19 && sp.s == 8 && sp.t == 0 && !quality_mode && !getenv("PMX_SEED_GENERIC"))
-                hipLaunchKernelGGL((k_seed_histogram_ks<19, 8>), grid, block, lds, ctx->stream, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp,
+                hipLaunchKernelGGL((k_seed_histogram_ks<19, 8>), grid, block, lds, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp,
                                    pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep);
             else
-                hipLaunchKernelGGL(k_seed_histogram, grid, block, lds, ctx->stream, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p,
+                hipLaunchKernelGGL(k_seed_histogram, grid, block, lds, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p,
                                    pl->vals.p, pl->cap - 1, pl->counters.p, keep, quality_mode ? rs->qual.p : nullptr,
                                    quality_mode ? pp->min_seed_quality : 0);
             PMX_HIP(hipGetLastError());
+            if (j > 0) {
+                PMX_HIP(hipEventRecord(pl->seed_done[j - 1], st));
+                PMX_HIP(hipStreamWaitEvent(ctx->stream, pl->seed_done[j - 1], 0));
+            }
+            }
         }
         if (bound_div == 1) break;
         unsigned long long h_ovf = 0;
