@@ -12,6 +12,19 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["default_tiers", "dp_service_forced", "wave_per_pair_only"])
+def _tier_mode(request, monkeypatch):
+    """Every test of this module runs three times: with the library's own tier choice (thread-per-pair kernel, its
+    DP leftovers to the wave-per-pair tier when they are few), with the DP service + replay rounds forced for any number
+    of leftovers (PMX_ALIGN_TPP_MIN=0), and with every pair on the wave-per-pair kernels (PMX_ALIGN_NO_TPP=1): the
+    exact-parity cases cover all execution models and both DP kernels on the GPU."""
+    if request.param == "dp_service_forced":
+        monkeypatch.setenv("PMX_ALIGN_TPP_MIN", "0")
+    elif request.param == "wave_per_pair_only":
+        monkeypatch.setenv("PMX_ALIGN_NO_TPP", "1")
+    yield
+
+
 def _ref_genome():
     return b"".join(l.strip() for l in open(os.path.join(GOLDEN, "isolate.ref.fa"), "rb") if not l.startswith(b">"))
 
