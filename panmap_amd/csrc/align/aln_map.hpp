@@ -161,7 +161,7 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     hash ^= wang_hash((uint32_t)qlen_sum) + wang_hash((uint32_t)o.seed);
     hash = wang_hash(hash);
 
-    collect_minimizers(W, o);
+    if (!W.mv_ready) collect_minimizers(W, o);
     PMX_STAMP(W, 1);
     if (o.q_occ_frac > 0.0f && W.n_mv > o.mid_occ && o.mid_occ > 0) W.status |= PMX_ST_UNSUPPORTED;   // mm_seed_mz_flt (seed.c:5-26)
     collect_seed_hits_heap(W, o, ri, qlen_sum, o.mid_occ);

@@ -429,7 +429,8 @@ struct Work {
     unsigned long long* prof;
     unsigned long long prof_t;
     unsigned long long prof_acc[24];
-    int sk_no_lane_ring;   // wave models: 1 = sketch with the ring in LDS (comparison / fallback switch)   // [0..11] phases, [16..23] sub-phases of seeding / chaining / align1 (PMX_ALIGN_PROF)
+    int sk_no_lane_ring;   // wave models: 1 = sketch with the ring in LDS (comparison / fallback switch)
+    int mv_ready;          // mv[] / n_mv already hold this pair's minimizers (handed over by the thread-per-pair kernel)   // [0..11] phases, [16..23] sub-phases of seeding / chaining / align1 (PMX_ALIGN_PROF)
 };
 
 }  // namespace aln

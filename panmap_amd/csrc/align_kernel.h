@@ -28,6 +28,12 @@ struct AlignArgs {
     int dp_round;
     int tpp_ring_w;             // k_align_reads_tpp: minimizer window length when the ring lives in LDS, else 0
     int sk_no_lane_ring;        // wave-per-pair kernels: 1 = sketch with the window ring in LDS instead of across the lanes
+    // Minimizer hand-over: a pair that posts a DP request in the thread-per-pair kernel leaves its minimizer list here
+    // (slot s: entry [s * mv_stride] holds the count in .x, the list follows), so the wave-per-pair tier does not have to
+    // sketch the reads again when it takes the pair over (the sketch is ~40 % of a pair's time there).  Slots >= mv_slots
+    // have no entry.
+    A128* mv_handover;
+    uint32_t mv_stride, mv_slots, mv_epoch;   // epoch: stamps the entries of this call (a slot may hold one of an earlier call)
     int dp_class;               // k_align_dp_serve: 0 = every request, 1 = only small ones, 2 = only the others
     int dp_small_qlen, dp_small_tlen;   // register-DP class: qlen <=, tlen <=, traceback bytes <= dp_small_tb
     uint32_t dp_small_tb;

@@ -23,7 +23,9 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
 
     for (int64_t it = blockIdx.x; it < A.n_items; it += gridDim.x) {
         int64_t item = A.worklist ? (int64_t)A.worklist[it] : it;
+        int64_t ho_slot = -1;
         if (A.dp_slot_pairs) {   // worklist holds DP-service slots
+            ho_slot = item;
             item = (int64_t)A.dp_slot_pairs[item];
             if (item == 0xffffffffLL) continue;   // slot whose pair already went to the retry list
         }
@@ -32,6 +34,17 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
         W.n_segs = n_segs;
         W.prof = A.prof;
         W.sk_no_lane_ring = A.sk_no_lane_ring;
+        W.mv_ready = 0;
+        if (A.mv_handover && ho_slot >= 0 && ho_slot < (int64_t)A.mv_slots) {   // minimizers left by the thread-per-pair kernel
+            const A128* src = A.mv_handover + (size_t)ho_slot * A.mv_stride;
+            const A128 hd = src[0];
+            if (hd.y == ((uint64_t)A.mv_epoch << 32 | (uint32_t)item) && (int)hd.x <= W.caps.max_mini) {
+                A128* mvp = W.mv; PMX_LDS(mvp);
+                for (int j = lane; j < (int)hd.x; j += 64) mvp[j] = src[1 + j];
+                W.n_mv = (int)hd.x;
+                W.mv_ready = 1;
+            }
+        }
         if (A.prof) { W.prof_t = (unsigned long long)clock64(); for (int k = 0; k < 24; ++k) W.prof_acc[k] = 0; }
         bool too_long = false;
         for (int s = 0; s < n_segs; ++s) {

@@ -53,6 +53,7 @@ k_align_reads_tpp(AlignArgs A) {
         }
         bind_work(W, A.layout, nullptr, nullptr, raw);
         W.n_segs = n_segs;
+        W.mv_ready = 0;
         W.sk_lds_x = ring_x;
         W.sk_lds_y = ring_y;
         W.prof = A.prof;   // diagnostic runs: lane 0's stamps are the wave's phase timeline
@@ -150,8 +151,17 @@ k_align_reads_tpp(AlignArgs A) {
             break;
         }
         if (W.status & PMX_ST_NEED_DP) {
-            if (A.dp_round == 0) A.dp_slot_pairs[W.dp_slot] = (uint32_t)item;
-            else A.dp_next_list[atomicAdd(A.dp_count, 1ULL)] = (uint32_t)slot;
+            if (A.dp_round == 0) {
+                A.dp_slot_pairs[W.dp_slot] = (uint32_t)item;
+                if (A.mv_handover && (uint64_t)W.dp_slot < (uint64_t)A.mv_slots && W.n_mv < (int)A.mv_stride) {   // see AlignArgs
+                    A128* dst = A.mv_handover + (size_t)W.dp_slot * A.mv_stride;
+                    A128 hd;
+                    hd.x = (uint64_t)W.n_mv; hd.y = (uint64_t)A.mv_epoch << 32 | (uint32_t)item;
+                    dst[0] = hd;
+                    Ptr<A128> mvp = W.mv;
+                    for (int j = 0; j < W.n_mv; ++j) dst[1 + j] = mvp[j];
+                }
+            } else A.dp_next_list[atomicAdd(A.dp_count, 1ULL)] = (uint32_t)slot;
             break;
         }
         emit = true;

@@ -31,6 +31,8 @@ struct pmx_aligner {
     DevBuf<uint32_t> cigars;
     DevBuf<unsigned long long> cigar_used;
     DevBuf<uint8_t> slow, slow2, slab0, slab_raw;
+    DevBuf<A128> mv_handover;
+    uint32_t mv_epoch = 0;
     DevBuf<uint32_t> retry_list2;
     DevBuf<uint8_t> dp_req;
     DevBuf<DpRes> dp_res;
@@ -194,6 +196,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
     A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.dp_small_tb = 0; A.tpp_ring_w = 0;
     A.sk_no_lane_ring = getenv("PMX_ALIGN_NO_LANE_RING") ? 1 : 0;
+    A.mv_handover = nullptr; A.mv_stride = 0; A.mv_slots = 0; A.mv_epoch = ++al->mv_epoch;
     timer_begin(ctx, "align");
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
@@ -245,6 +248,12 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 A.dp_req_base = al->dp_req.p; A.dp_res_base = al->dp_res.p; A.dp_ncached = al->dp_ncached.p;
                 A.dp_slot_pairs = al->dp_slot_pairs.p;
                 A.dp_slot_cap = (uint32_t)std::min<int64_t>(n_items, UINT32_MAX - 1);
+                if (!getenv("PMX_ALIGN_NO_MV_HANDOVER")) {
+                    A.mv_stride = (uint32_t)tpp_layout.caps.max_mini + 1u;
+                    A.mv_slots = (uint32_t)std::min<int64_t>(A.dp_slot_cap, 131072);
+                    al->mv_handover.ensure((size_t)A.mv_slots * A.mv_stride);
+                    A.mv_handover = al->mv_handover.p;
+                }
             }
             // minimizer window ring in LDS when 16 waves per CU still fit (12 B x w x 64 lanes per wave)
             size_t tpp_lds_bytes = (size_t)al->opt.w * 64 * 12;
