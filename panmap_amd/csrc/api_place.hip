@@ -763,10 +763,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
                            pl->tvals.p, pl->tcap - 1);
     hipLaunchKernelGGL(k_wc_denominator, dim3(1), dim3(1024), 0, st, pl->ch_hash.p, pl->ch_child.p, pl->root_beg, pl->root_end, pl->tkeys.p, pl->tvals.p,
                        pl->tcap - 1, n_kept > 0 ? 1 : 0, pl->scalars.p + 2);
-    double h_scal[3];
-    PMX_HIP(hipMemcpyAsync(h_scal, pl->scalars.p, sizeof(h_scal), hipMemcpyDeviceToHost, st));
-    PMX_HIP(hipStreamSynchronize(st));
-    const double log_mag = std::sqrt(h_scal[0]), log_cont_den = h_scal[1], wc_den = h_scal[2];
+    double h_scal[3] = {0, 0, 0};   // fetched with the scores below (the device reads the scalars itself)
     mark("sums, probe table, denominators");
 
     // ---- node scoring, one launch per BFS level (src/placement.cpp:701-918)
@@ -831,11 +828,12 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
         PMX_HIP(hipGraphLaunch(pl->level_graph_exec, st));
     }
     timer_end(ctx, "score", 1);
-    hipLaunchKernelGGL(k_score_getters, dim3(grid_for(pl->n_nodes, 256, G)), dim3(256), 0, st, pl->metrics5.p, pl->counts2.p, pl->n_nodes, log_mag,
-                       log_cont_den, wc_den, n_kept, pl->scores5.p, pl->level_nodes.p, pl->scores_bfs.p);
+    hipLaunchKernelGGL(k_score_getters, dim3(grid_for(pl->n_nodes, 256, G)), dim3(256), 0, st, pl->metrics5.p, pl->counts2.p, pl->n_nodes, pl->scalars.p,
+                       n_kept, pl->scores5.p, pl->level_nodes.p, pl->scores_bfs.p);
     PMX_HIP(hipGetLastError());
     pl->h_scores.resize(5 * (size_t)pl->n_nodes);
     PMX_HIP(hipMemcpyAsync(pl->h_scores.data(), pl->scores_bfs.p, sizeof(double) * 5 * (size_t)pl->n_nodes, hipMemcpyDeviceToHost, st));
+    PMX_HIP(hipMemcpyAsync(h_scal, pl->scalars.p, sizeof(h_scal), hipMemcpyDeviceToHost, st));
     uint32_t tree_status = 0;
     if (tree_kernel) PMX_HIP(hipMemcpyAsync(&tree_status, pl->tree_done.p + pl->n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     PMX_HIP(hipStreamSynchronize(st));
@@ -909,9 +907,9 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     res->n_kept_seeds = n_kept;
     res->total_seed_freq = (int64_t)h_stats[2];
     res->min_support = min_support;
-    res->log_read_magnitude = log_mag;
-    res->log_containment_den = log_cont_den;
-    res->weighted_containment_den = wc_den;
+    res->log_read_magnitude = std::sqrt(h_scal[0]);
+    res->log_containment_den = h_scal[1];
+    res->weighted_containment_den = h_scal[2];
     return PMX_OK;
     PMX_CATCH
 }

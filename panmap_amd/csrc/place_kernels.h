@@ -61,8 +61,8 @@ __global__ void k_score_chains(const uint32_t* chain_off, int64_t n_chains, cons
                                const uint64_t* chain_end, const uint32_t* parent, const double* t_mag, const double* t_raw, const double* t_cos,
                                const double* t_wc, const double* t_lc, const uint8_t* t_meta, double* metrics5, int64_t* counts2,
                                uint32_t* done, uint32_t epoch, uint32_t* status);
-__global__ void k_score_getters(const double* metrics5, const int64_t* counts2, int64_t n_nodes, double log_mag, double log_cont_den,
-                                double wc_den, int64_t n_kept, double* scores5, const uint32_t* order, double* scores_bfs);
+__global__ void k_score_getters(const double* metrics5, const int64_t* counts2, int64_t n_nodes, const double* scalars, int64_t n_kept,
+                                double* scores5, const uint32_t* order, double* scores_bfs);
 __global__ void k_fill_u64(uint64_t* p, uint64_t v, uint64_t n);
 
 }  // namespace pmx

@@ -1053,9 +1053,11 @@ k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const u
 // weighted_containment, log_containment
 // scores5[node][metric] for the node outputs, and scores_bfs[metric][visit position] for the host's sequential
 // best/tie rule (one contiguous array per metric, in the order the rule visits the nodes)
+// (the three denominators are read from the device scalars [sum L^2, sum L, wc_den]: no host round trip before this launch)
 __global__ void k_score_getters(const double* __restrict__ metrics5, const int64_t* __restrict__ counts2, int64_t n_nodes,
-                                double log_mag, double log_cont_den, double wc_den, int64_t n_kept, double* scores5,
+                                const double* __restrict__ scalars, int64_t n_kept, double* scores5,
                                 const uint32_t* __restrict__ order, double* scores_bfs) {
+    const double log_mag = sqrt(scalars[0]), log_cont_den = scalars[1], wc_den = scalars[2];
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_nodes; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t nd = (int64_t)order[j];
         const double* m = metrics5 + 5 * nd;
