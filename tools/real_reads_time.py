@@ -1,3 +1,5 @@
+"""Align-stage throughput on the repository's real example reads (tests/golden/isolate_R*.fastq.gz, the list repeated 8x ~ 0.8 M
+reads): a harder workload than bench.py's synthetic reads (20 % of the pairs need a DP).  Run from the repo root on a GPU box."""
 import sys, time, os, numpy as np
 sys.path.insert(0,'.')
 import panmap_amd as pmx
