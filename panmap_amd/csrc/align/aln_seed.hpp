@@ -421,6 +421,33 @@ PMX_HD A128 heap_replace_root_min_x(Ptr<A128> l, int n, const A128 tmp) {
     l[i] = tmp;
     return root;
 }
+// the same with the root's two children cached in registers (c1 = l[1], c2 = l[2], kept in step with memory): the first
+// level of the sift needs no load, i.e. one dependent round trip less per pop
+PMX_HD A128 heap_replace_root_min_x_c(Ptr<A128> l, int n, const A128 tmp, A128& c1, A128& c2) {
+    PMX_LDS(l);
+    if (n <= 1) { l[0] = tmp; return tmp; }
+    int k = 1;
+    A128 ck = c1;
+    if (n > 2 && c1.x > c2.x) { k = 2; ck = c2; }
+    if (ck.x > tmp.x) { l[0] = tmp; return tmp; }
+    l[0] = ck;
+    int i = k, kk;
+    A128 at_k = tmp;   // what ends up at position k
+    while ((kk = (i << 1) + 1) < n) {
+        A128 ch = l[kk];
+        if (kk != n - 1) {
+            const A128 ch1 = l[kk + 1];
+            if (ch.x > ch1.x) { ++kk; ch = ch1; }
+        }
+        if (ch.x > tmp.x) break;
+        l[i] = ch;
+        if (i == k) at_k = ch;
+        i = kk;
+    }
+    l[i] = tmp;
+    if (k == 1) c1 = at_k; else c2 = at_k;
+    return ck;
+}
 PMX_HD void heap_down_max_u64(uint64_t* l, int i, int n) {   // ks_heapdown_uint64_t: max-heap
     int k = i;
     const uint64_t tmp = l[i];
@@ -684,10 +711,12 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     for (int q = (heap_size >> 1) - 1; q >= 0; --q) heap_down_min_x(heap, q, heap_size);
     int64_t n_for = 0, n_rev = 0;
     PMX_STAMP(W, 17);
-    A128 top;
-    top.x = top.y = 0;
+    A128 top, hc1, hc2;   // heap[0], heap[1], heap[2] kept in registers from pop to pop
+    top.x = top.y = hc1.x = hc1.y = hc2.x = hc2.y = 0;
     if (heap_size > 0) top = heap[0];
-    while (heap_size > 0) {   // top == heap[0], kept in registers from pop to pop
+    if (heap_size > 1) hc1 = heap[1];
+    if (heap_size > 2) hc2 = heap[2];
+    while (heap_size > 0) {
         const uint32_t si = (uint32_t)(top.y >> 32);
         const SeedA q = seeds[si];
         const SeedB qb = seeds_b[si];
@@ -715,7 +744,7 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
             nt = heap[heap_size - 1];
             --heap_size;
         }
-        top = heap_replace_root_min_x(heap, heap_size, nt);
+        top = heap_replace_root_min_x_c(heap, heap_size, nt, hc1, hc2);
     }
     // the reverse-strand block was filled back to front
     for (int64_t j = 0; j < n_rev >> 1; ++j) {
