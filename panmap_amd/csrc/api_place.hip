@@ -36,6 +36,7 @@ struct pmx_place {
     DevBuf<unsigned long long> counters;   // PMX_CTR_N
     int64_t n_reads_added = 0;
     bool table_dirty = false;              // something was inserted since the last reset
+    DevBuf<uint32_t> sk_key, sk_key2, sk_idx, sk_idx2;   // seeding order: reads sorted by their first 16 bases
     hipStream_t seed_streams[3] = {nullptr, nullptr, nullptr};   // side streams: seeding launches of one group run concurrently
     hipEvent_t seed_go = nullptr, seed_done[3] = {nullptr, nullptr, nullptr};
     // finalised histogram
@@ -509,6 +510,22 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             if (const char* e = getenv("PMX_SEED_BOUND_DIV")) bound_div = std::max<int64_t>(1, atoll(e));   // (tests force the redo with a large value)
         }
         timer_begin(ctx, "seed");
+        // seeding order (default-parameter kernel): reads that start with the same 16 bases next to each other, so that a
+        // block's (seed, count) cache sees its seeds many times (k_seed_histogram_ks)
+        const bool ks_path = sp.k == 19 && sp.s == 8 && sp.t == 0 && !quality_mode && !getenv("PMX_SEED_GENERIC");
+        const uint32_t* perm = nullptr;
+        if (ks_path && rs->n >= 4096 && rs->n < (int64_t)UINT32_MAX && !getenv("PMX_SEED_NO_SORT")) {
+            const int64_t n = rs->n;
+            pl->sk_key.ensure((size_t)n); pl->sk_key2.ensure((size_t)n); pl->sk_idx.ensure((size_t)n); pl->sk_idx2.ensure((size_t)n);
+            hipLaunchKernelGGL(k_read_prefix_keys, dim3(grid_for(n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rs->words.p, rs->woff.p, n,
+                               pl->sk_key.p, pl->sk_idx.p);
+            size_t bytes = 0;
+            PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, 32, ctx->stream));
+            pl->tmp.ensure(bytes);
+            PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, 32, ctx->stream));
+            perm = pl->sk_idx2.p;
+        }
+        const size_t lds_ks = lds + 16 + (size_t)PMX_SEED_CACHE * 12;
         for (int attempt = 0; attempt < 2; ++attempt) {
         // A launch of one chunk is latency-bound (every wave walks its 150 bases one after the other, a few waves per
         // SIMD): the chunks of a group run concurrently on side streams, sharing the table (all they do is atomics).
@@ -532,9 +549,9 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             if (j > 0) PMX_HIP(hipStreamWaitEvent(st, pl->seed_go, 0));
             const dim3 grid(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
             // the default seeding parameters run the kernel specialised for them (same results, ~3x fewer instructions)
-            if (sp.k == 19 && sp.s == 8 && sp.t == 0 && !quality_mode && !getenv("PMX_SEED_GENERIC"))
-                hipLaunchKernelGGL((k_seed_histogram_ks<19, 8>), grid, block, lds, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp,
-                                   pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep);
+            if (ks_path)
+                hipLaunchKernelGGL((k_seed_histogram_ks<19, 8>), grid, block, lds_ks, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp,
+                                   pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep, perm);
             else
                 hipLaunchKernelGGL(k_seed_histogram, grid, block, lds, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p,
                                    pl->vals.p, pl->cap - 1, pl->counters.p, keep, quality_mode ? rs->qual.p : nullptr,

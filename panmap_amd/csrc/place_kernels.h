@@ -4,6 +4,7 @@
 
 #define PMX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
 #define PMX_SEED_BLOCK 128
+#define PMX_SEED_CACHE 512   // entries of a block's (seed, count) cache in LDS (k_seed_histogram_ks)
 #define PMX_SEED_QCAP 256   // seeds a wave queues in LDS before it inserts them 64 at a time (k_seed_histogram)
 #define PMX_SUM_BLOCK 1024
 #define PMX_CTR_NSHARD 256
@@ -24,7 +25,8 @@ __global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, con
 template <int K, int S>
 __global__ void k_seed_histogram_ks(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin,
                                     int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask,
-                                    unsigned long long* counters, const uint8_t* keep);
+                                    unsigned long long* counters, const uint8_t* keep, const uint32_t* perm);
+__global__ void k_read_prefix_keys(const uint64_t* words, const int64_t* woff, int64_t n_reads, uint32_t* key, uint32_t* idx);
 __global__ void k_read_hashes(const uint8_t* ascii, const int64_t* off, int64_t n_reads, uint64_t* h1, uint64_t* h2, uint32_t* idx);
 __global__ void k_gather_u64(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst);
 __global__ void k_mark_first_of_run(const uint8_t* ascii, const int64_t* off, const uint64_t* h1s, const uint64_t* h2, const uint32_t* perm,
