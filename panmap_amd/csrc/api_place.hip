@@ -767,7 +767,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     {
         const int64_t nb = (n_kept + PMX_SUM_BLOCK - 1) / PMX_SUM_BLOCK;
         pl->partial.ensure((size_t)(2 * nb + 2));
-        if (nb > 0) hipLaunchKernelGGL(k_block_sums, dim3(grid_for(nb, 64, G)), dim3(64), 0, st, pl->kept_log.p, n_kept, pl->partial.p);
+        if (nb > 0) hipLaunchKernelGGL(k_block_sums, dim3((unsigned)std::min<int64_t>(nb, (int64_t)G * 4)), dim3(64), 0, st, pl->kept_log.p, n_kept, pl->partial.p);
         hipLaunchKernelGGL(k_sequential_sums, dim3(1), dim3(64), 0, st, pl->partial.p, nb, pl->scalars.p);
     }
     // probe table for the kept seeds

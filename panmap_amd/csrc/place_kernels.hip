@@ -677,29 +677,61 @@ __global__ void k_keep_scatter(const uint64_t* __restrict__ hash, const int64_t*
 // Canonical-order FP sums (same order as oracle_place.c): kept seeds in ascending
 // hash order, sequential inside consecutive blocks of PMX_SUM_BLOCK (one thread per block), then the
 // block sums sequentially (one thread).  partial[2*b] = sum L^2, partial[2*b+1] = sum L.
-__global__ void k_block_sums(const double* __restrict__ kept_log, int64_t n, double* partial) {
+// (one wave per block: the lanes fetch 64 values at a time, coalesced, into LDS; lane 0 walks them for sum L^2, lane 1
+//  for sum L -- the same sequential additions in the same order, without 1024 strided dependent loads per thread)
+__global__ void __launch_bounds__(64) k_block_sums(const double* __restrict__ kept_log, int64_t n, double* partial) {
+    __shared__ double sh[2][64];
+    const int lane = threadIdx.x;
     const int64_t nb = (n + PMX_SUM_BLOCK - 1) / PMX_SUM_BLOCK;
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const int64_t beg = b * PMX_SUM_BLOCK, end = beg + PMX_SUM_BLOCK < n ? beg + PMX_SUM_BLOCK : n;
-        double m2 = 0.0, s = 0.0;
-        for (int64_t i = beg; i < end; ++i) {
-            const double L = kept_log[i];
-            m2 += L * L;
-            s += L;
+        double acc = 0.0;   // lane 0: sum L^2, lane 1: sum L
+        double nxt = beg + lane < end ? kept_log[beg + lane] : 0.0;
+        int buf = 0;
+        for (int64_t base = beg; base < end; base += 64, buf ^= 1) {
+            const double cur = nxt;
+            if (base + 64 + lane < end) nxt = kept_log[base + 64 + lane];
+            sh[buf][lane] = cur;
+            __builtin_amdgcn_wave_barrier();
+            const int cnt = (int)(end - base < 64 ? end - base : 64);
+            if (lane < 2) {   // eight LDS reads in flight, then the eight dependent additions in order
+                const double* v = sh[buf];
+                int j = 0;
+                for (; j + 8 <= cnt; j += 8) {
+                    double a0 = v[j], a1 = v[j + 1], a2 = v[j + 2], a3 = v[j + 3], a4 = v[j + 4], a5 = v[j + 5], a6 = v[j + 6], a7 = v[j + 7];
+                    if (lane == 0) { a0 *= a0; a1 *= a1; a2 *= a2; a3 *= a3; a4 *= a4; a5 *= a5; a6 *= a6; a7 *= a7; }
+                    acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+                }
+                for (; j < cnt; ++j) { const double L = v[j]; acc += lane == 0 ? L * L : L; }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        partial[2 * b] = m2;
-        partial[2 * b + 1] = s;
+        if (lane < 2) partial[2 * b + lane] = acc;
     }
 }
-__global__ void k_sequential_sums(const double* __restrict__ partial, int64_t nb, double* out) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    double m2 = 0.0, s = 0.0;
-    for (int64_t b = 0; b < nb; ++b) {
-        m2 += partial[2 * b];
-        s += partial[2 * b + 1];
+__global__ void __launch_bounds__(64) k_sequential_sums(const double* __restrict__ partial, int64_t nb, double* out) {
+    __shared__ double sh[2][128];
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    double acc = 0.0;   // lane 0: sum of partial[2b], lane 1: sum of partial[2b+1], b ascending
+    int buf = 0;
+    for (int64_t base = 0; base < 2 * nb; base += 128, buf ^= 1) {
+        if (base + lane < 2 * nb) sh[buf][lane] = partial[base + lane];
+        if (base + 64 + lane < 2 * nb) sh[buf][64 + lane] = partial[base + 64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        const int cnt = (int)(2 * nb - base < 128 ? 2 * nb - base : 128);
+        if (lane < 2) {
+            const double* v = sh[buf];
+            int j = lane;
+            for (; j + 14 < cnt; j += 16) {
+                const double a0 = v[j], a1 = v[j + 2], a2 = v[j + 4], a3 = v[j + 6], a4 = v[j + 8], a5 = v[j + 10], a6 = v[j + 12], a7 = v[j + 14];
+                acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+            }
+            for (; j < cnt; j += 2) acc += v[j];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    out[0] = m2;
-    out[1] = s;
+    if (lane < 2) out[lane] = acc;
 }
 
 __global__ void k_kept_table_build(const uint64_t* __restrict__ kept_hash, const double* __restrict__ kept_log, int64_t n,
