@@ -204,6 +204,22 @@ void pmx_align_reads_direct(const char *reference, const char *refName, int n_re
                             const char **quality, const char **read_names, const int *r_lens,
                             align_pair_result_t *results, bool pairedEndReads, int n_threads);
 
+/* ---- FASTA / FASTQ ingest (host): what seeding::readFastqPaired (src/seeding.cpp:231-269) and extractReadSequences
+ * (src/placement.cpp:164-197) do with kseq.h, as flat arrays that upload to the device as they are.
+ * kseq conventions: name = header up to the first white space; multi-line sequence / quality; CR stripped; a record
+ * whose quality length differs from its sequence length ends the file.
+ * pmx_fastx_read_paired: mate 2 reverse-complemented (upper-case ACGT only) with its qualities reversed, mates
+ * interleaved (r1_0, r2_0, r1_1, ...), missing qualities 'I' x length; path2 NULL or "" = single-end; a mate-count
+ * mismatch is PMX_ERR_ARG (the reference exits).  pmx_fastx_read: one file, records in file order, FASTA qualities
+ * are zero bytes.  Views stay valid until pmx_fastx_free. */
+typedef struct pmx_fastx pmx_fastx;
+int pmx_fastx_read_paired(const char *path1, const char *path2, pmx_fastx **out);
+int pmx_fastx_read(const char *path, pmx_fastx **out);
+int64_t pmx_fastx_num_reads(const pmx_fastx *fx);
+int pmx_fastx_views(const pmx_fastx *fx, const char **seq_concat, const char **qual_concat, const int64_t **offsets,
+                    const char **names_concat, const int64_t **name_offsets);
+void pmx_fastx_free(pmx_fastx *fx);
+
 /* ---- BAM egress (host): what alignAndWriteBam does with the results of align_reads_direct
  * (src/conversion.cpp:288-538: build_bam_from_result, compute_sam_flags, compute_tlen, sort by pos, BAM + .bai).
  * reads / quality / read_names / r_lens are the arrays that were handed to the aligner (R2 already reverse-

@@ -6,5 +6,5 @@ include/panmap_amd.h); this package is the thin host-side mirror of the referenc
 from ._lib import LIB_PATH, PmxError, lib  # noqa: F401  (import fails loudly if the .so is missing)
 from .api import (METRICS, Aligner, align_reads_direct, write_bam, records_to_results, REC_DTYPE, Context, Index, Panman, PlacementResult, Placer, ReadSet, TraversalParams,  # noqa: F401
                   concat_reads, extract_read_sequences, format_placement_tsv, place_lite, read_fastq_paired,
-                  read_fastx, reverse_complement)
+                  read_fastx, reverse_complement, FastxReads, read_fastq_paired_native, read_fastx_native)
 from .synth import simulate_paired_reads, simulate_long_reads  # noqa: F401

@@ -115,6 +115,12 @@ SIGNATURES = {
     "pmx_place_tied": (_i32, [_vp, _i32, _vp, _i64]),
     "pmx_place_node_outputs": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "pmx_place_kept_seeds": (_i64, [_vp, _vp, _vp, _vp, _i64]),
+    "pmx_fastx_read_paired": (_i32, [_cp, _cp, _PP]),
+    "pmx_fastx_read": (_i32, [_cp, _PP]),
+    "pmx_fastx_num_reads": (_i64, [_vp]),
+    "pmx_fastx_views": (_i32, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_void_p)]),
+    "pmx_fastx_free": (None, [_vp]),
     "pmx_write_bam": (_i32, [_cp, _cp, _i64, _i32, C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_cp), C.POINTER(C.c_int),
                              C.POINTER(AlignPairResult), C.c_bool]),
     "pmx_align_reads_direct": (None, [_cp, _cp, _i32, C.POINTER(_cp), C.POINTER(_cp), C.POINTER(_cp),

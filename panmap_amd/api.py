@@ -217,6 +217,62 @@ def read_fastq_paired(reads1: str, reads2: str = ""):
     return seqs, quals, names
 
 
+class FastxReads:
+    """Reads parsed by the native (C++) FASTA/FASTQ reader: flat numpy views of the library's buffers
+    (`seq`, `qual`: uint8; `off`, `name_off`: int64 offsets) that upload to the device without a Python list in between."""
+
+    def __init__(self, handle):
+        self._h = handle
+        n = lib.pmx_fastx_num_reads(self._h)
+        ptrs = [C.c_void_p() for _ in range(5)]
+        check(lib.pmx_fastx_views(self._h, *[C.byref(p) for p in ptrs]), "pmx_fastx_views")
+        self.n = int(n)
+
+        def view(ptr, count, ctype, dtype):
+            if count == 0 or not ptr.value:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).view(dtype)
+
+        self.off = view(ptrs[2], self.n + 1, C.c_int64, np.int64)
+        self.name_off = view(ptrs[4], self.n + 1, C.c_int64, np.int64)
+        total = int(self.off[-1]) if self.n >= 0 and len(self.off) else 0
+        self.seq = view(ptrs[0], total, C.c_uint8, np.uint8)
+        self.qual = view(ptrs[1], total, C.c_uint8, np.uint8)
+        self.names_concat = view(ptrs[3], int(self.name_off[-1]) if len(self.name_off) else 0, C.c_uint8, np.uint8)
+
+    def lists(self):
+        """(seqs, quals, names) as Python lists of bytes: the shape read_fastq_paired returns"""
+        sb, qb, nb = self.seq.tobytes(), self.qual.tobytes(), self.names_concat.tobytes()
+        o, no = self.off, self.name_off
+        return ([sb[o[i]:o[i + 1]] for i in range(self.n)], [qb[o[i]:o[i + 1]] for i in range(self.n)],
+                [nb[no[i]:no[i + 1]] for i in range(self.n)])
+
+    def close(self):
+        if self._h:
+            lib.pmx_fastx_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_fastq_paired_native(reads1: str, reads2: str = "") -> FastxReads:
+    """seeding::readFastqPaired (src/seeding.cpp:231-269) by the library's C++ reader (pmx_fastx_read_paired)."""
+    h = C.c_void_p()
+    check(lib.pmx_fastx_read_paired(reads1.encode(), reads2.encode() if reads2 else None, C.byref(h)), "pmx_fastx_read_paired")
+    return FastxReads(h)
+
+
+def read_fastx_native(path: str) -> FastxReads:
+    """one FASTA/FASTQ(.gz) file in file order (kseq conventions); FASTA records have zero bytes as qualities"""
+    h = C.c_void_p()
+    check(lib.pmx_fastx_read(path.encode(), C.byref(h)), "pmx_fastx_read")
+    return FastxReads(h)
+
+
 def concat_reads(reads: Sequence[bytes]):
     lens = np.fromiter((len(r) for r in reads), np.int64, len(reads))
     off = np.zeros(len(reads) + 1, np.int64)
@@ -270,6 +326,18 @@ class ReadSet:
         self.total_bases = int(offsets[-1] - offsets[0])
         if pack:
             self.pack()
+
+    @classmethod
+    def from_fastx(cls, ctx: Context, fx: "FastxReads", with_qualities: bool = False, pack: bool = True) -> "ReadSet":
+        """upload the reads of the native FASTA/FASTQ reader (flat buffers, no Python list in between)"""
+        self = cls(ctx, concat=fx.seq, offsets=fx.off, pack=pack)
+        self._keep = (fx,)
+        if with_qualities:
+            if len(fx.qual) != self.total_bases:
+                raise ValueError("quality strings must have the lengths of the reads")
+            q = np.ascontiguousarray(fx.qual) if len(fx.qual) else np.zeros(1, np.uint8)
+            check(lib.pmx_readset_set_qualities(ctx._h, self._h, q.ctypes.data), "pmx_readset_set_qualities")
+        return self
 
     @classmethod
     def wrap_device(cls, ctx: Context, d_concat_ptr: int, d_offsets_ptr: int, n_reads: int, total_bytes: int, max_len: int, keepalive=None):

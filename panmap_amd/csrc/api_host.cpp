@@ -4,6 +4,7 @@
 
 #include "api_internal.hpp"
 #include "host/bam_writer.hpp"
+#include "host/fastx_reader.hpp"
 #include "host/index_build.hpp"
 #include "host/panman.hpp"
 
@@ -155,3 +156,48 @@ extern "C" int pmx_write_bam(const char* bam_path, const char* ref_name, int64_t
         return PMX_ERR_IO;
     }
 }
+
+// ---------------------------------------------------------------------------------- FASTA / FASTQ ingest
+struct pmx_fastx {
+    pmx::FastxReads r;
+};
+
+extern "C" int pmx_fastx_read_paired(const char* path1, const char* path2, pmx_fastx** out) {
+    if (!path1 || !out) return PMX_ERR_ARG;
+    pmx_fastx* fx = new pmx_fastx();
+    try {
+        pmx::read_fastq_paired(path1, path2 ? path2 : "", fx->r);
+    } catch (const std::exception& e) {
+        const std::string what = e.what();
+        delete fx;
+        pmx::set_error(what);
+        return what.rfind("Error:", 0) == 0 ? PMX_ERR_ARG : PMX_ERR_IO;   // mate-count mismatch vs unreadable file
+    }
+    *out = fx;
+    return PMX_OK;
+}
+extern "C" int pmx_fastx_read(const char* path, pmx_fastx** out) {
+    if (!path || !out) return PMX_ERR_ARG;
+    pmx_fastx* fx = new pmx_fastx();
+    try {
+        pmx::read_fastx(path, fx->r);
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        delete fx;
+        return PMX_ERR_IO;
+    }
+    *out = fx;
+    return PMX_OK;
+}
+extern "C" int64_t pmx_fastx_num_reads(const pmx_fastx* fx) { return fx ? fx->r.n() : -1; }
+extern "C" int pmx_fastx_views(const pmx_fastx* fx, const char** seq_concat, const char** qual_concat, const int64_t** offsets,
+                               const char** names_concat, const int64_t** name_offsets) {
+    if (!fx) return PMX_ERR_ARG;
+    if (seq_concat) *seq_concat = fx->r.seq.data();
+    if (qual_concat) *qual_concat = fx->r.qual.data();
+    if (offsets) *offsets = fx->r.off.data();
+    if (names_concat) *names_concat = fx->r.names.data();
+    if (name_offsets) *name_offsets = fx->r.name_off.data();
+    return PMX_OK;
+}
+extern "C" void pmx_fastx_free(pmx_fastx* fx) { delete fx; }

@@ -158,6 +158,44 @@ def test_fastq_readers(pmx, tmp_path):
     assert s == [b"ACGTACGT", b"TT"] and n == [b"s1", b"s2"]
 
 
+def test_native_fastx_reader_matches_python_reader(pmx, tmp_path):
+    """pmx_fastx_read / pmx_fastx_read_paired (C++, kseq conventions of src/seeding.cpp:231-269) against the Python
+    mirror on the repository's real FASTQ pair and on hand-made edge cases"""
+    import gzip
+    from conftest import GOLDEN
+    r1, r2 = os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz")
+    fx = pmx.read_fastq_paired_native(r1, r2)
+    seqs, quals, names = pmx.read_fastq_paired(r1, r2)
+    assert fx.n == len(seqs) and fx.lists() == (seqs, quals, names)
+    assert int(fx.off[-1]) == sum(len(x) for x in seqs)
+    # edge cases: CRLF, multi-line records, lower case, tab in the header, gzip / plain, FASTA mates (no qualities -> 'I')
+    a = tmp_path / "e_R1.fastq"
+    b = tmp_path / "e_R2.fastq.gz"
+    a.write_bytes(b"@r1 x y\r\nACGTN\r\n+\r\nIIIII\r\n@r2\tz\nGG\nGTT\n+\nII\nIII\n@r3\nacgT\n+r3\n!!!!\n")
+    with gzip.open(b, "wb") as f:
+        f.write(b"@r1\nAACCg\n+\nABCDE\n@r2\nTTTTT\n+\nIIIII\n@r3\nNNAC\n+\n1234\n")
+    fx = pmx.read_fastq_paired_native(str(a), str(b))
+    assert fx.lists() == pmx.read_fastq_paired(str(a), str(b))
+    assert fx.lists()[0] == [b"ACGTN", b"gGGTT", b"GGGTT", b"AAAAA", b"acgT", b"GTNN"]
+    assert fx.lists()[1][5] == b"4321" and fx.lists()[2] == [b"r1", b"r1", b"r2", b"r2", b"r3", b"r3"]
+    fa = tmp_path / "m.fa"
+    fa.write_text(">s1 desc\nACGT\nACGT\n>s2\nTT\n\n>s3\n")
+    one = pmx.read_fastx_native(str(fa))
+    assert one.lists()[0] == [b"ACGTACGT", b"TT", b""] and one.lists()[2] == [b"s1", b"s2", b"s3"]
+    assert pmx.read_fastq_paired_native(str(fa)).lists()[1] == [b"IIIIIIII", b"II", b""]     # single-end FASTA: 'I' qualities
+    # a record whose quality is shorter than its sequence ends the file (kseq_read returns -2 there)
+    t = tmp_path / "t.fastq"
+    t.write_text("@ok\nACGT\n+\nIIII\n@bad\nACGTACGT\n+\nIII\n")
+    assert pmx.read_fastx_native(str(t)).lists()[0] == [b"ACGT"]
+    # mate-count mismatch and unreadable file are errors
+    c = tmp_path / "c_R2.fastq"
+    c.write_text("@r1\nAACCG\n+\nABCDE\n")
+    with pytest.raises(pmx.PmxError):
+        pmx.read_fastq_paired_native(str(a), str(c))
+    with pytest.raises(pmx.PmxError):
+        pmx.read_fastx_native(str(tmp_path / "missing.fq"))
+
+
 def test_synthetic_reads_are_deterministic_and_fr(pmx, sars):
     g = sars.genome("node_7618")
     c1, o1 = pmx.simulate_paired_reads(g, 500, seed=42)
