@@ -186,6 +186,23 @@ def test_golden_placement_tsv_on_gpu(pmx, ctx, sars, sars_index, tmp_path):
     assert res.n_reads == 102338 and res.n_unique_seeds == 317148 and res.readUniqueSeedCount == 117645
 
 
+def test_native_fastq_ingest_feeds_the_device(pmx, ctx, sars_index):
+    """FASTQ pair -> pmx_fastx_read_paired -> ReadSet.from_fastx (flat buffers, qualities attached) gives the same
+    histogram and placement as the Python-list route (reverse-complementing mate 2 does not change canonical seeds, so
+    the golden counts of the interleaved-as-read route hold here too)"""
+    r1, r2 = os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz")
+    fx = pmx.read_fastq_paired_native(r1, r2)
+    params = pmx.TraversalParams()
+    out = []
+    for rs in (pmx.ReadSet.from_fastx(ctx, fx, with_qualities=True), pmx.ReadSet(ctx, pmx.read_fastq_paired(r1, r2)[0])):
+        placer = pmx.Placer(ctx, sars_index)
+        placer.add_reads(rs, params)
+        res = placer.score(params, rs.n_reads)
+        out.append((placer.histogram_size(), res.n_unique_seeds, res.readUniqueSeedCount, tuple(res.best_index), tuple(res.best_score)))
+    assert out[0] == out[1]
+    assert out[0][1] == 317148 and out[0][2] == 117645
+
+
 def test_histogram_shard_merge_equals_single_pass(pmx, ctx, sars, sars_index):
     """multi-GPU exchange step: per-shard histograms merged == one pass over all reads."""
     g = sars.genome("node_7618")
