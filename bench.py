@@ -270,7 +270,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": dom_ms,
                          "note": "thread-per-pair mapping kernel: per-pair work state (~10 KB touched) lives in an interleaved "
                                  "HBM arena, so its traffic, not the 93 B/read of input+output, is what the kernel moves; "
-                                 "it is bound by a mix of dependent L1/L2/HBM round trips on that state and instruction issue (DESIGN.md 4.1)"},
+                                 "against that traffic it runs at a third to a half of the HBM peak in scattered 16-64 byte transactions (DESIGN.md 4.1)"},
             "kernels_ms": {"seed stage (k_seed_histogram, chunked)": seed_ms, "score stage (k_score_terms + k_score_chains)": score_ms,
                            "align stage (all tiers)": align_ms, "k_align_reads_tpp round 0": tpp0_ms},
             "checks": {"placed_node": placed_id, "mapped_fraction": mapped_frac, "records_flagged": flagged,
