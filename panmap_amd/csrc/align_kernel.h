@@ -32,6 +32,10 @@ struct AlignArgs {
     // (slot s: entry [s * mv_stride] holds the count in .x, the list follows), so the wave-per-pair tier does not have to
     // sketch the reads again when it takes the pair over (the sketch is ~40 % of a pair's time there).  Slots >= mv_slots
     // have no entry.
+    // Thread-per-pair kernel, round 0: item of position `it` (pairs sorted by the first 16 bases of their first read,
+    // so that the 64 pairs of a wave are neighbours on the genome: similar minimizers, anchor counts and loop trip
+    // counts -> less lane divergence).  nullptr = identity.
+    const uint32_t* pair_perm;
     A128* mv_handover;
     uint32_t mv_stride, mv_slots, mv_epoch;   // epoch: stamps the entries of this call (a slot may hold one of an earlier call)
     int dp_class;               // k_align_dp_serve: 0 = every request, 1 = only small ones, 2 = only the others

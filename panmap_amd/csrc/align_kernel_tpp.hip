@@ -45,7 +45,7 @@ k_align_reads_tpp(AlignArgs A) {
         bool emit = false;
         Work W;
         if (it < A.n_items) do {   // `break` = this lane emits no record in this pass
-        if (A.dp_round == 0) item = it;
+        if (A.dp_round == 0) item = A.pair_perm ? (int64_t)A.pair_perm[it] : it;
         else {
             slot = A.worklist ? (int64_t)A.worklist[it] : it;
             item = (int64_t)A.dp_slot_pairs[slot];

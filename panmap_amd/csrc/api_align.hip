@@ -1,5 +1,8 @@
 // C ABI, device part 2: ALIGN stage (see include/panmap_amd.h).
 #include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
 
 #include <climits>
 #include <cstdio>
@@ -32,6 +35,8 @@ struct pmx_aligner {
     DevBuf<unsigned long long> cigar_used;
     DevBuf<uint8_t> slow, slow2, slab0, slab_raw;
     DevBuf<A128> mv_handover;
+    DevBuf<uint32_t> pp_key, pp_key2, pp_idx, pp_idx2;   // pair order of the thread-per-pair kernel
+    DevBuf<char> pp_tmp;
     uint32_t mv_epoch = 0;
     DevBuf<uint32_t> retry_list2;
     DevBuf<uint8_t> dp_req;
@@ -47,6 +52,16 @@ struct pmx_aligner {
     uint64_t cigar_cap = 0;
     double last_occupancy = 0;
 };
+
+// locality key of an item (read or read pair) for the thread-per-pair launch order: the first 16 bases of its first read
+__global__ void k_pair_prefix_keys(const uint64_t* __restrict__ words, const int64_t* __restrict__ woff, int64_t n_items, int reads_per_item,
+                                   uint32_t* key, uint32_t* idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i * reads_per_item;
+        key[i] = woff[r + 1] > woff[r] ? (uint32_t)words[woff[r]] : 0u;
+        idx[i] = (uint32_t)i;
+    }
+}
 
 namespace {
 int fail(int code, const std::string& msg) {
@@ -197,6 +212,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.dp_small_tb = 0; A.tpp_ring_w = 0;
     A.sk_no_lane_ring = getenv("PMX_ALIGN_NO_LANE_RING") ? 1 : 0;
     A.mv_handover = nullptr; A.mv_stride = 0; A.mv_slots = 0; A.mv_epoch = ++al->mv_epoch;
+    A.pair_perm = nullptr;
     timer_begin(ctx, "align");
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
@@ -275,7 +291,18 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 PMX_HIP(hipGetLastError());
             };
             timer_begin(ctx, "align_tpp0");   // the dominant kernel on its own (bench.py roofline)
+            if (n_items >= 4096 && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_PAIR_SORT")) {
+                al->pp_key.ensure((size_t)n_items); al->pp_key2.ensure((size_t)n_items); al->pp_idx.ensure((size_t)n_items); al->pp_idx2.ensure((size_t)n_items);
+                hipLaunchKernelGGL(k_pair_prefix_keys, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                                   rs->words.p, rs->woff.p, n_items, paired ? 2 : 1, al->pp_key.p, al->pp_idx.p);
+                size_t bytes = 0;
+                PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 32, ctx->stream));
+                al->pp_tmp.ensure(bytes);
+                PMX_HIP(rocprim::radix_sort_pairs(al->pp_tmp.p, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 32, ctx->stream));
+                A.pair_perm = al->pp_idx2.p;
+            }
             launch_tpp(0, n_items, nullptr, nullptr);
+            A.pair_perm = nullptr;
             timer_end(ctx, "align_tpp0", 1);
             int64_t n_dp = 0;
             read_counts(n_t1, n_dp, false);
