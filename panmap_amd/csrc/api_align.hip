@@ -53,12 +53,12 @@ struct pmx_aligner {
     double last_occupancy = 0;
 };
 
-// locality key of an item (read or read pair) for the thread-per-pair launch order: the first 16 bases of its first read
+// locality key of an item (read or read pair) for the thread-per-pair launch order: read_locality_key of its first read
 __global__ void k_pair_prefix_keys(const uint64_t* __restrict__ words, const int64_t* __restrict__ woff, int64_t n_items, int reads_per_item,
                                    uint32_t* key, uint32_t* idx) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i * reads_per_item;
-        key[i] = woff[r + 1] > woff[r] ? (uint32_t)words[woff[r]] : 0u;
+        key[i] = woff[r + 1] > woff[r] ? read_locality_key(words[woff[r]]) : 0u;
         idx[i] = (uint32_t)i;
     }
 }

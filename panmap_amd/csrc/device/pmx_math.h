@@ -26,6 +26,25 @@ PMX_HD uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// Locality key of a read for launch orders (seeding, thread-per-pair alignment): the smallest hashed canonical 16-mer
+// among the read's first 17 bases' worth of windows (positions 0..15, from its first packed word: 32 bases).  Reads
+// that start within a few bases of each other on the same strand share it, so equal keys = neighbours on the genome.
+// Only an ordering hint: any value is correct.
+PMX_HD uint32_t read_locality_key(uint64_t first_word) {
+    uint64_t best = ~0ULL;
+    for (int p = 0; p < 16; ++p) {
+        const uint64_t f = (first_word >> (2 * p)) & 0xffffffffULL;          // 16 bases, base p in the low bits
+        uint64_t r = ~f & 0xffffffffULL;                                      // complement (codes 0..3 -> 3..0) ...
+        r = (r & 0x33333333ULL) << 2 | (r >> 2 & 0x33333333ULL);              // ... reversed base by base
+        r = (r & 0x0f0f0f0fULL) << 4 | (r >> 4 & 0x0f0f0f0fULL);
+        r = (r & 0x00ff00ffULL) << 8 | (r >> 8 & 0x00ff00ffULL);
+        r = (r & 0x0000ffffULL) << 16 | (r >> 16 & 0x0000ffffULL);
+        const uint64_t h = mix64(f < r ? f : r);
+        best = h < best ? h : best;
+    }
+    return (uint32_t)(best >> 32);
+}
+
 PMX_HD uint32_t dbl_hi(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)(u >> 32); }
 PMX_HD double dbl_set_hi(double x, uint32_t hi) { uint64_t u; memcpy(&u, &x, 8); u = (u & 0xffffffffULL) | ((uint64_t)hi << 32); memcpy(&x, &u, 8); return x; }
 

@@ -556,10 +556,10 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
 template __global__ void k_seed_histogram_ks<19, 8>(const uint64_t*, const uint32_t*, const int64_t*, const int64_t*, int64_t, int64_t, SeedParams,
                                                     uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*);
 
-// locality key of a read for the seeding order: its first 16 bases (the low half of its first packed word)
+// locality key of a read for the seeding order (read_locality_key: reads that start within a few bases of each other)
 __global__ void k_read_prefix_keys(const uint64_t* __restrict__ words, const int64_t* __restrict__ woff, int64_t n_reads, uint32_t* key, uint32_t* idx) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
-        key[r] = woff[r + 1] > woff[r] ? (uint32_t)words[woff[r]] : 0u;
+        key[r] = woff[r + 1] > woff[r] ? read_locality_key(words[woff[r]]) : 0u;
         idx[r] = (uint32_t)r;
     }
 }
