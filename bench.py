@@ -276,7 +276,7 @@ def main():
             "checks": {"placed_node": placed_id, "mapped_fraction": mapped_frac, "records_flagged": flagged,
                        "unique_seeds": int(res.n_unique_seeds), "kept_seeds": int(res.readUniqueSeedCount)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported by the 1-GPU run only
             threads = max(1, min(os.cpu_count() or 1, 64))
             out["cpu_baseline"] = cpu_baseline(src, concat, off, index.arrays(), state["ref"], args.cpu_sample, threads)
         else:
