@@ -26,7 +26,6 @@ __global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
         const int64_t slot = A.worklist ? (int64_t)A.worklist[it] : it;
         const DpReq* rq = reinterpret_cast<const DpReq*>(A.dp_req_base + (size_t)slot * sizeof(DpReq));
         __syncthreads();
-        const unsigned long long tp0 = A.prof ? (unsigned long long)clock64() : 0ULL;
         bind_work(W, A.layout, fast, slow);
         W.prof = A.prof;
         W.prof_t = 0;
