@@ -258,6 +258,22 @@ int pmx_align_fetch(pmx_ctx *ctx, pmx_aligner *al, pmx_aln_record *records, int6
                     int64_t arena_cap);
 /* copy the fixed-size records into a caller-owned DEVICE buffer (for RCCL gathers) */
 int pmx_align_copy_records_device(pmx_ctx *ctx, pmx_aligner *al, void *d_records, int64_t n_records);
+/* the same for the CIGAR arena (pmx_align_cigar_words() words): records + arena are what rank 0 needs to write the BAM */
+int pmx_align_copy_cigars_device(pmx_ctx *ctx, pmx_aligner *al, void *d_cigars, int64_t n_words);
+/* Work statistics of the last pmx_align_readset call (no reference counterpart; bench.py reports GCUPS from them):
+   DP cells are counted as q * min(t, 2w+1) per ksw2 call. */
+typedef struct pmx_align_stats {
+    int64_t n_items;        /* pairs (paired) or reads aligned */
+    int64_t dp_pairs;       /* items that needed at least one ksw2 DP (the rest were answered by proved shortcuts) */
+    int64_t dp_calls;       /* ksw2 DPs run */
+    int64_t dp_cells;       /* their cells */
+    int64_t dp_rounds;      /* DP-service rounds of the thread-per-pair tier */
+    int64_t wave_tier_items;     /* items handed to the wave-per-pair tiers */
+    int64_t general_tier_items;  /* ... of which re-run with the general capacities */
+    int64_t compact_tier_items;  /* items finished by the compact LDS tier */
+    int64_t reserved[8];
+} pmx_align_stats;
+int pmx_align_get_stats(pmx_ctx *ctx, pmx_aligner *al, pmx_align_stats *out);
 /* device pointers of the last result (for RCCL gathers without a host bounce) */
 const void *pmx_align_device_records(const pmx_aligner *al);
 const void *pmx_align_device_cigars(const pmx_aligner *al);

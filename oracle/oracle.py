@@ -45,6 +45,10 @@ def olib():
         L.orc_hist_add.argtypes = [vp, C.c_uint64, i64]
         L.orc_hist_add_read.argtypes = [vp, C.c_char_p, i64, i32, i32, i32, i32, i32, i32, i32, i64]
         L.orc_hist_add_read_q.argtypes = [vp, C.c_char_p, C.c_char_p, i64, i64, i32, i32, i32, i32, i32, i32, i32, i32]
+        L.orc_hist_add_reads.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32]
+        L.orc_hist_merge.argtypes = [vp, vp]
+        L.orc_hist_build_mt.restype = vp
+        L.orc_hist_build_mt.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32]
         L.orc_hist_size.restype = i64
         L.orc_hist_size.argtypes = [vp]
         L.orc_hist_export_sorted.argtypes = [vp, vp, vp]
@@ -101,6 +105,18 @@ def histogram(reads, k, s, l, open_syncmer=False, t=0, trim_start=0, trim_end=0,
         it = set(reads) if dedup else reads
     for r in it:
         L.orc_hist_add_read(h, r, len(r), k, s, l, int(open_syncmer), t, trim_start, trim_end, 1)
+    n = L.orc_hist_size(h)
+    hs, cn = np.zeros(n, np.uint64), np.zeros(n, np.int64)
+    L.orc_hist_export_sorted(h, hs.ctypes.data, cn.ctypes.data)
+    L.orc_hist_free(h)
+    return hs, cn
+
+
+def histogram_flat_mt(concat, off, k, s, l, n_threads, open_syncmer=False, t=0, trim_start=0, trim_end=0):
+    """(hash asc, count) of the reads of one flat buffer, seeded on n_threads threads in ONE C call."""
+    L = olib()
+    concat = np.ascontiguousarray(concat, np.uint8); off = np.ascontiguousarray(off, np.int64)
+    h = C.c_void_p(L.orc_hist_build_mt(concat.ctypes.data, off.ctypes.data, len(off) - 1, k, s, l, int(open_syncmer), t, trim_start, trim_end, n_threads))
     n = L.orc_hist_size(h)
     hs, cn = np.zeros(n, np.uint64), np.zeros(n, np.int64)
     L.orc_hist_export_sorted(h, hs.ctypes.data, cn.ctypes.data)
@@ -192,8 +208,8 @@ def _unpack(ra: ReadAlign):
     return dict(pos=ra.pos, rs=ra.rs, re=ra.re, qs=ra.qs, qe=ra.qe, mapq=ra.mapq, rev=ra.rev, proper_frag=ra.proper_frag, cigar=cig)
 
 
-def call_align_reads_direct(fn, reference: bytes, reads, paired: bool, n_threads=1):
-    """Call an align_reads_direct-compatible entry point (the reference's or the product's)."""
+def prepare_align_call(reads, paired: bool):
+    """marshal the arguments of align_reads_direct once (outside any timed span)"""
     n = len(reads)
     arr = (C.c_char_p * n)(*reads)
     quals = (C.c_char_p * n)(*[b"I" * len(r) for r in reads])
@@ -201,11 +217,24 @@ def call_align_reads_direct(fn, reference: bytes, reads, paired: bool, n_threads
     lens = (C.c_int * n)(*[len(r) for r in reads])
     n_res = n // 2 if paired else n
     res = (AlignPairResult * max(n_res, 1))()
-    fn(reference, b"ref", n, arr, quals, names, lens, res, paired, n_threads)
-    out = []
-    for i in range(n_res):
-        out.append(dict(mapped=res[i].mapped, r1=_unpack(res[i].r1), r2=_unpack(res[i].r2) if paired else None))
-    return out
+    return dict(n=n, arr=arr, quals=quals, names=names, lens=lens, n_res=n_res, res=res, paired=paired)
+
+
+def run_align_call(fn, reference: bytes, prep, n_threads=1):
+    """the bare C call"""
+    fn(reference, b"ref", prep["n"], prep["arr"], prep["quals"], prep["names"], prep["lens"], prep["res"], prep["paired"], n_threads)
+
+
+def unpack_align_call(prep):
+    res, paired = prep["res"], prep["paired"]
+    return [dict(mapped=res[i].mapped, r1=_unpack(res[i].r1), r2=_unpack(res[i].r2) if paired else None) for i in range(prep["n_res"])]
+
+
+def call_align_reads_direct(fn, reference: bytes, reads, paired: bool, n_threads=1):
+    """Call an align_reads_direct-compatible entry point (the reference's or the product's)."""
+    prep = prepare_align_call(reads, paired)
+    run_align_call(fn, reference, prep, n_threads)
+    return unpack_align_call(prep)
 
 
 def ref_align_reads_direct(reference: bytes, reads, paired: bool, n_threads=1):

@@ -6,6 +6,7 @@
 #include "oracle_place.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -323,6 +324,50 @@ void orc_hist_add_read_q(orc_hist *h, const char *seq, const char *qual, int64_t
     }
     int64_t n = orc_read_seeds_q(seq, qual, len, qual_len, k, s, l, open, t, trim_start, trim_end, min_q, h->tmp);
     for (int64_t i = 0; i < n; ++i) orc_hist_add(h, h->tmp[i], 1);
+}
+
+/* Batch entry for the CPU baseline (bench.py): reads [r0, r1) of one flat buffer (concat + n+1 offsets) go into
+ * the histogram in ONE C call, so a timing around it measures the seeding, not a Python loop. */
+void orc_hist_add_reads(orc_hist *h, const char *concat, const int64_t *off, int64_t r0, int64_t r1, int k, int s, int l,
+                        int open, int t, int trim_start, int trim_end)
+{
+    for (int64_t r = r0; r < r1; ++r)
+        orc_hist_add_read(h, concat + off[r], off[r + 1] - off[r], k, s, l, open, t, trim_start, trim_end, 1);
+}
+
+/* mergeSeedMaps (src/placement.cpp:922-929): add every (key, count) of src into dst */
+void orc_hist_merge(orc_hist *dst, const orc_hist *src)
+{
+    for (uint64_t j = 0; j < src->cap; ++j)
+        if (src->used[j]) orc_hist_add(dst, src->key[j], src->val[j]);
+}
+
+/* The reference seeds the reads on all cores with per-thread maps merged afterwards (src/placement.cpp:1611-1686:
+ * tbb::parallel_for over the unique reads, then mergeSeedMaps): the same shape with pthreads, one call. */
+typedef struct { orc_hist *h; const char *concat; const int64_t *off; int64_t r0, r1; int k, s, l, open, t, ts, te; } hist_job;
+static void *hist_worker(void *p)
+{
+    hist_job *j = (hist_job *)p;
+    orc_hist_add_reads(j->h, j->concat, j->off, j->r0, j->r1, j->k, j->s, j->l, j->open, j->t, j->ts, j->te);
+    return NULL;
+}
+orc_hist *orc_hist_build_mt(const char *concat, const int64_t *off, int64_t n_reads, int k, int s, int l, int open, int t,
+                            int trim_start, int trim_end, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if ((int64_t)n_threads > n_reads) n_threads = n_reads > 0 ? (int)n_reads : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    hist_job *jobs = (hist_job *)malloc(sizeof(hist_job) * (size_t)n_threads);
+    for (int i = 0; i < n_threads; ++i) {
+        hist_job j = {orc_hist_new(), concat, off, n_reads * i / n_threads, n_reads * (i + 1) / n_threads, k, s, l, open, t, trim_start, trim_end};
+        jobs[i] = j;
+        pthread_create(&th[i], NULL, hist_worker, &jobs[i]);
+    }
+    for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
+    orc_hist *out = jobs[0].h;
+    for (int i = 1; i < n_threads; ++i) { orc_hist_merge(out, jobs[i].h); orc_hist_free(jobs[i].h); }
+    free(th); free(jobs);
+    return out;
 }
 
 int64_t orc_hist_size(const orc_hist *h) { return (int64_t)h->n; }

@@ -52,6 +52,12 @@ void orc_hist_add_read_q(orc_hist *h, const char *seq, const char *qual, int64_t
                          int open, int t, int trim_start, int trim_end, int min_q);
 void orc_hist_add_read(orc_hist *h, const char *seq, int64_t len, int k, int s, int l, int open, int t,
                        int trim_start, int trim_end, int64_t multiplicity);
+/* batch / multi-threaded entries for the CPU baseline (one C call; src/placement.cpp:1611-1686, :922-929) */
+void orc_hist_add_reads(orc_hist *h, const char *concat, const int64_t *off, int64_t r0, int64_t r1, int k, int s, int l,
+                        int open, int t, int trim_start, int trim_end);
+void orc_hist_merge(orc_hist *dst, const orc_hist *src);
+orc_hist *orc_hist_build_mt(const char *concat, const int64_t *off, int64_t n_reads, int k, int s, int l, int open, int t,
+                            int trim_start, int trim_end, int n_threads);
 int64_t orc_hist_size(const orc_hist *h);
 /* ascending hash order */
 void orc_hist_export_sorted(const orc_hist *h, uint64_t *hash, int64_t *count);

@@ -58,6 +58,12 @@ class AlignPairResult(C.Structure):
     _fields_ = [("r1", ReadAlign), ("r2", ReadAlign), ("mapped", C.c_int)]
 
 
+class AlignStats(C.Structure):
+    _fields_ = [("n_items", C.c_int64), ("dp_pairs", C.c_int64), ("dp_calls", C.c_int64), ("dp_cells", C.c_int64),
+                ("dp_rounds", C.c_int64), ("wave_tier_items", C.c_int64), ("general_tier_items", C.c_int64),
+                ("compact_tier_items", C.c_int64), ("reserved", C.c_int64 * 8)]
+
+
 class AlnRecord(C.Structure):
     _fields_ = [("rs", C.c_int32), ("re", C.c_int32), ("qs", C.c_int32), ("qe", C.c_int32),
                 ("mapq", C.c_uint8), ("rev", C.c_uint8), ("proper_frag", C.c_uint8), ("mapped", C.c_uint8),
@@ -111,6 +117,8 @@ SIGNATURES = {
     "pmx_place_histogram_merge_device_parts": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32]),
     "pmx_place_histogram_merge_device": (_i32, [_vp, _vp, _vp, _vp, _i64]),
     "pmx_align_copy_records_device": (_i32, [_vp, _vp, _vp, _i64]),
+    "pmx_align_copy_cigars_device": (_i32, [_vp, _vp, _vp, _i64]),
+    "pmx_align_get_stats": (_i32, [_vp, _vp, C.POINTER(AlignStats)]),
     "pmx_place_score": (_i32, [_vp, _vp, C.POINTER(PlaceParams), _i64, C.POINTER(PlaceResult)]),
     "pmx_place_tied": (_i32, [_vp, _i32, _vp, _i64]),
     "pmx_place_node_outputs": (_i32, [_vp, _vp, _vp, _vp, _vp]),

@@ -533,6 +533,11 @@ def place_lite(ctx: Context, placer: Placer, reads1: str, reads2: str, output_pa
 
 
 # ------------------------------------------------------------------------------------ align
+def last_error() -> bytes:
+    """pmx_last_error() of the calling thread (the drop-in boundary has no return code: it reports here)"""
+    return lib.pmx_last_error()
+
+
 REC_DTYPE = np.dtype([("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"), ("mapq", "u1"), ("rev", "u1"),
                       ("proper_frag", "u1"), ("mapped", "u1"), ("n_cigar", "<u2"), ("flags", "<u2"), ("cigar_off", "<u4"),
                       ("score", "<i4")])
@@ -570,6 +575,18 @@ class Aligner:
     def copy_records_device(self, d_ptr: int, n_records: int):
         check(lib.pmx_align_copy_records_device(self.ctx._h, self._h, d_ptr, n_records), "pmx_align_copy_records_device")
 
+    def copy_cigars_device(self, d_ptr: int, n_words: int):
+        check(lib.pmx_align_copy_cigars_device(self.ctx._h, self._h, d_ptr, n_words), "pmx_align_copy_cigars_device")
+
+    def cigar_words(self) -> int:
+        return int(lib.pmx_align_cigar_words(self.ctx._h, self._h))
+
+    def stats(self) -> dict:
+        """work statistics of the last align_readset call (DP cells = q * min(t, 2w+1) per ksw2 call)"""
+        st = _lib.AlignStats()
+        check(lib.pmx_align_get_stats(self.ctx._h, self._h, C.byref(st)), "pmx_align_get_stats")
+        return {k: int(getattr(st, k)) for k, _ in st._fields_ if k != "reserved"}
+
     @property
     def n_records(self) -> int:
         return lib.pmx_align_num_records(self._h)
@@ -602,15 +619,28 @@ def _one_result(r, cig):
                 cigar=[int(x) for x in cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]])
 
 
+_UNMAPPED = dict(pos=INT_MAX, rs=0, re=0, qs=0, qe=0, mapq=0, rev=0, proper_frag=0, cigar=[])
+
+
 def records_to_results(recs, cig, paired: bool):
+    """Records flagged ALN_OVERFLOW / ALN_UNSUPPORTED are invalid: like pmx_align_reads_direct, they are reported
+    unmapped (never as an alignment); `flags` still says why."""
     out = []
     if paired:
         for i in range(len(recs) // 2):
             a, b = recs[2 * i], recs[2 * i + 1]
-            out.append(dict(mapped=int(a["mapped"]), r1=_one_result(a, cig), r2=_one_result(b, cig), flags=int(a["flags"] | b["flags"])))
+            fl = int(a["flags"] | b["flags"])
+            if fl & (ALN_OVERFLOW | ALN_UNSUPPORTED):
+                out.append(dict(mapped=0, r1=dict(_UNMAPPED), r2=dict(_UNMAPPED), flags=fl))
+            else:
+                out.append(dict(mapped=int(a["mapped"]), r1=_one_result(a, cig), r2=_one_result(b, cig), flags=fl))
     else:
         for r in recs:
-            out.append(dict(mapped=int(r["mapped"]), r1=_one_result(r, cig), r2=None, flags=int(r["flags"])))
+            fl = int(r["flags"])
+            if fl & (ALN_OVERFLOW | ALN_UNSUPPORTED):
+                out.append(dict(mapped=0, r1=dict(_UNMAPPED), r2=None, flags=fl))
+            else:
+                out.append(dict(mapped=int(r["mapped"]), r1=_one_result(r, cig), r2=None, flags=fl))
     return out
 
 

@@ -225,7 +225,10 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
     Caps& c = L.caps;
     c.max_qlen = (max_read_len + 15) / 16 * 16 + 16;
     const int qsum = c.max_qlen * n_segs;
-    c.max_mini = std::max(64, (int)(qsum * 2 / (o.w + 1)) * 2 + 32);
+    // a low-complexity read emits a minimizer at nearly every k-mer position (equal hashes in a window are all kept,
+    // sketch.c:107-139), and a short tandem repeat re-emits the other copies of the minimum every time it slides out
+    // of the window: the general layout takes four per base
+    c.max_mini = std::max(64, qsum * 4 + 16);
     c.max_anchor = std::max(256, c.max_mini * 2);
     c.max_reg = 32;
     c.max_cigar = std::max(64, max_read_len / 2 + 16);
@@ -504,6 +507,7 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow, ui
     W.dp_req_base = nullptr; W.dp_res = nullptr; W.dp_slot_ctr = nullptr;
     W.dp_slot = -1; W.dp_slot_cap = 0; W.dp_n_cached = 0; W.dp_calls = 0;
     W.last_dp_shortcut = 0; W.skip_shortcut = 0;
+    W.dp_run_calls = 0; W.dp_run_cells = 0;
     W.sk_lds_x = nullptr; W.sk_lds_y = nullptr;
 }
 

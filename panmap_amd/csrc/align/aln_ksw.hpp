@@ -824,6 +824,13 @@ PMX_HD bool ksw_shortcut(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, 
     return ksw_shortcut_f(W, qlen, qf, tlen, tf, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
 }
 
+// DP cells of one ksw call as SURVEY 8d counts them: q * min(t, 2w+1)
+PMX_HD uint64_t dp_cells(int qlen, int tlen, int w) {
+    if (qlen <= 0 || tlen <= 0) return 0;
+    const int64_t band = w < 0 ? (int64_t)tlen : (int64_t)2 * w + 1;
+    return (uint64_t)qlen * (uint64_t)(band < tlen ? band : tlen);
+}
+
 PMX_HD void ksw_extd2_auto(Work& W, int qlen, Ptr<const uint8_t> query, int tlen, Ptr<const uint8_t> target, const int8_t* mat, int8_t q, int8_t e,
                            int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     W.last_dp_shortcut = 0;
@@ -877,6 +884,8 @@ PMX_HD void ksw_extd2_auto(Work& W, int qlen, Ptr<const uint8_t> query, int tlen
     ez_reset(ez);
     ez.zdropped = 1;
 #else
+    ++W.dp_run_calls;
+    W.dp_run_cells += dp_cells(qlen, tlen, w);
     ksw_extd2(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
 #endif
 }

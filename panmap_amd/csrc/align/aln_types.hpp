@@ -92,14 +92,15 @@ struct A128 {
 // and ptr_cast only converts between types of equal granule.  Objects with natural alignment never
 // straddle a granule, so operator[] can hand out real references; larger structs (Reg, Seed) stay in a
 // small per-thread contiguous region behind plain pointers.
-#if defined(PMX_THREAD_PER_PAIR) && defined(__HIPCC__)
+// The thread-per-pair arena of a launch: FIRST member of the kernel argument struct (AlignArgs), so that IPtr::phys
+// can read it from the kernarg segment at a fixed offset (scalar loads, hoisted like a __constant__ would be).  It is
+// per launch, not per module: two host threads aligning on one device never see each other's arena (the aligner
+// boundary is called concurrently from TBB workers in --batch mode, src/main.cpp:1581-1611).
 struct TppArena {
     uint8_t* base;          // first wave's slab
     uint32_t wave_stride;   // bytes per wave slab = 64 * per-thread logical arena size
     uint32_t pad;
 };
-__constant__ TppArena c_tpp_arena;
-#endif
 #if defined(PMX_THREAD_PER_PAIR) && defined(__HIP_DEVICE_COMPILE__)
 #define PMX_INTERLEAVED 1
 // interleave granule of an element type (log2 bytes); a type may opt into a 64-byte granule (Wide64)
@@ -114,7 +115,9 @@ struct IPtr {
     __device__ IPtr(const IPtr<U>& q) : o(q.o) {}
     static constexpr uint32_t LG = IGranule<T>::LG;   // log2 of the granule
     __device__ __forceinline__ static T* phys(uint32_t off) {
-        uint8_t* wave_base = c_tpp_arena.base + (size_t)blockIdx.x * c_tpp_arena.wave_stride;   // uniform
+        typedef const __attribute__((address_space(4))) TppArena* KernargArena;
+        const KernargArena ka = (KernargArena)__builtin_amdgcn_kernarg_segment_ptr();   // AlignArgs::tpp
+        uint8_t* wave_base = ka->base + (size_t)blockIdx.x * ka->wave_stride;   // uniform
         const uint32_t vo = ((threadIdx.x & 63u) << LG) + ((off >> LG) << (LG + 6)) + (off & ((1u << LG) - 1u));
         return reinterpret_cast<T*>(wave_base + vo);
     }
@@ -429,6 +432,9 @@ struct Work {
     unsigned long long* prof;
     unsigned long long prof_t;
     unsigned long long prof_acc[24];
+    // DP work actually run for this pair by the wave models / host (statistics only: GCUPS in bench.py)
+    uint32_t dp_run_calls;
+    uint64_t dp_run_cells;
     int sk_no_lane_ring;   // wave models: 1 = sketch with the ring in LDS (comparison / fallback switch)
     int mv_ready;          // mv[] / n_mv already hold this pair's minimizers (handed over by the thread-per-pair kernel)   // [0..11] phases, [16..23] sub-phases of seeding / chaining / align1 (PMX_ALIGN_PROF)
 };

@@ -8,6 +8,7 @@ namespace pmx {
 namespace aln {
 
 struct AlignArgs {
+    TppArena tpp;           // MUST stay first (IPtr::phys reads it from the kernarg segment); zero for the wave kernels
     // packed reads
     const uint64_t* words;
     const uint32_t* amb;
@@ -44,6 +45,7 @@ struct AlignArgs {
 
 
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
+    unsigned long long* stats;  // [0] DP calls run, [1] DP cells (q * min(t, 2w+1)), [2] pairs the wave tiers ran a DP for
     int paired;
     int revcomp_mate2;
     // reference + options
@@ -65,7 +67,6 @@ __global__ void k_align_reads_t1(AlignArgs A);
 __global__ void k_align_reads_t1_w4(AlignArgs A);
 __global__ void k_align_reads_tpp(AlignArgs A);
 __global__ void k_align_dp_serve(AlignArgs A);
-void tpp_set_arena(uint8_t* base, size_t wave_stride, hipStream_t stream);
 
 // bytes of the traceback matrix ksw_extd2 needs for a request (same n_col as ksw2_extd2_sse.c:95-98)
 PMX_HD size_t dp_request_tb_bytes(int qlen, int tlen, int w) {

@@ -117,6 +117,11 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
             }
             if (lane == 0) A.records[r] = rec;
         }
+        if (A.stats && lane == 0 && W.dp_run_calls) {
+            atomicAdd(&A.stats[0], (unsigned long long)W.dp_run_calls);
+            atomicAdd(&A.stats[1], (unsigned long long)W.dp_run_cells);
+            if (!A.dp_slot_pairs) atomicAdd(&A.stats[2], 1ULL);   // (pairs that came from a DP slot are counted by the slot allocator)
+        }
         if (A.prof) {
             PMX_STAMP(W, 11);
             __syncthreads();

@@ -64,6 +64,10 @@ __global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
         if (lane == 0) {
             const uint32_t* cg = W.cig_tmp; PMX_LDS(cg);
             dp_store_result(A, slot, rq, ez, cg, W.status);
+            if (A.stats) {
+                atomicAdd(&A.stats[0], 1ULL);
+                atomicAdd(&A.stats[1], (unsigned long long)dp_cells(qlen, tlen, rq->w));
+            }
         }
         if (A.prof && lane == 0) {
             atomicAdd(&A.prof[12], W.prof_t ? tp2 - W.prof_t : 0ULL);   // traceback part of the DP (register kernel)

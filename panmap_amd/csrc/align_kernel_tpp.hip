@@ -19,12 +19,13 @@ namespace pmx {
 namespace aln {
 
 // Per-thread memory: the interleaved arena is addressed through IPtr (aln_types.hpp) relative to the wave's
-// slab in c_tpp_arena; `raw` is this lane's base into the wave's strided Reg region (struct Reg).
+// slab named by A.tpp; `raw` is this lane's base into the wave's strided Reg region (struct Reg).
 #ifndef PMX_TPP_OCC
 #define PMX_TPP_OCC 4   // waves per SIMD the register allocation targets (latency-bound kernel: occupancy hides L2 round trips)
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PMX_TPP_OCC)))
 k_align_reads_tpp(AlignArgs A) {
+    static_assert(offsetof(AlignArgs, tpp) == 0, "IPtr::phys reads the arena from the start of the kernarg segment");
     const int64_t n_threads = (int64_t)gridDim.x * 64;
     uint8_t* raw = A.slow_base + (size_t)blockIdx.x * A.slow_stride + ((threadIdx.x & 63u) << 2);   // strided Reg region of this lane
     const int n_segs = A.paired ? 2 : 1;
@@ -222,16 +223,6 @@ k_align_reads_tpp(AlignArgs A) {
                     if (k < 12 || k >= 16) atomicAdd(&A.prof[k], W.prof_acc[k]);
         }
     }
-}
-
-// host side of c_tpp_arena (the symbol lives in this translation unit)
-void tpp_set_arena(uint8_t* base, size_t wave_stride, hipStream_t stream) {
-    TppArena h;
-    h.base = base;
-    h.wave_stride = (uint32_t)wave_stride;
-    h.pad = 0;
-    PMX_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tpp_arena), &h, sizeof(h), 0, hipMemcpyHostToDevice, stream));
-    PMX_HIP(hipStreamSynchronize(stream));   // h is a stack object
 }
 
 }  // namespace aln

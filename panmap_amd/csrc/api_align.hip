@@ -48,8 +48,12 @@ struct pmx_aligner {
     DevBuf<unsigned long long> retry_count;
     int64_t last_retry = 0, last_tpp_retry = 0;
     DevBuf<unsigned long long> prof;
+    DevBuf<unsigned long long> stats;   // AlignArgs::stats
+    pmx_align_stats last_stats;
+    int64_t last_dp_slots = 0, last_compact = 0;
     int64_t n_records = 0;
     uint64_t cigar_cap = 0;
+    unsigned long long last_cigar_used = 0;   // read back at the end of pmx_align_readset
     double last_occupancy = 0;
 };
 
@@ -129,16 +133,14 @@ void pmx_aligner_free(pmx_ctx* ctx, pmx_aligner* al) {
     delete al;
 }
 
-int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2) {
-    if (!ctx || !al || !rs) return PMX_ERR_ARG;
-    if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack first)");
+static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2, uint64_t cigar_cap) {
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     const int64_t n_items = paired ? rs->n / 2 : rs->n;   // an odd trailing read is ignored (src/mm_align.c:372)
     al->n_records = rs->n;
     al->records.ensure((size_t)std::max<int64_t>(rs->n, 1));
     PMX_HIP(hipMemsetAsync(al->records.p, 0, sizeof(AlnRecord) * (size_t)std::max<int64_t>(rs->n, 1), ctx->stream));
-    al->cigar_cap = (uint64_t)std::max<int64_t>(rs->n * 16, 4096);
+    al->cigar_cap = cigar_cap;
     al->cigars.ensure(al->cigar_cap);
     PMX_HIP(hipMemsetAsync(al->cigar_used.p, 0, sizeof(unsigned long long), ctx->stream));
     if (n_items <= 0) return PMX_OK;
@@ -154,6 +156,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     const int n_segs = paired ? 2 : 1;
 
     AlignArgs A;
+    A.tpp.base = nullptr; A.tpp.wave_stride = 0; A.tpp.pad = 0;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
     A.paired = paired ? 1 : 0;
     A.revcomp_mate2 = revcomp_mate2 ? 1 : 0;
@@ -163,6 +166,14 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     A.cigars = al->cigars.p;
     A.cigar_cap = al->cigar_cap;
     A.cigar_used = al->cigar_used.p;
+    al->stats.ensure(4);
+    PMX_HIP(hipMemsetAsync(al->stats.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    A.stats = al->stats.p;
+    al->last_dp_slots = 0;
+    al->last_compact = 0;
+    al->last_tpp_retry = 0; al->last_retry = 0; al->last_dp_rounds = 0; al->last_dp_requests = 0;
+    memset(&al->last_stats, 0, sizeof(al->last_stats));
+    al->last_stats.n_items = n_items;
     A.prof = nullptr;
     if (getenv("PMX_ALIGN_PROF")) {
         al->prof.ensure(24);
@@ -193,8 +204,13 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
 
     al->retry_count.ensure(2);   // [0] pairs for the next (wave) tier, [1] DP requests of the current tier-0 round
     PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    const Layout general = plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget);
-    const Layout compact = plan_layout_compact((int)rs->max_len, n_segs, al->opt);
+    // test hook: cap the CIGAR operations per region in EVERY tier, so that gapped alignments overflow and the
+    // boundary's handling of invalid records can be exercised (tests/test_align_gpu.py)
+    int test_max_cigar = 0;
+    if (const char* e = getenv("PMX_ALIGN_TEST_MAX_CIGAR")) test_max_cigar = atoi(e);
+    auto hooked = [&](Layout L) { if (test_max_cigar > 0 && L.caps.max_cigar > test_max_cigar) L.caps.max_cigar = test_max_cigar; return L; };
+    const Layout general = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget));
+    const Layout compact = hooked(plan_layout_compact((int)rs->max_len, n_segs, al->opt));
     const bool tier1_fits = use_tier1 && al->opt.is_sr_like && PMX_ALIGN_WORK_BYTES + compact.fast_bytes + 16 <= 40 * 1024;
     const bool use_tier0 = tier1_fits && !getenv("PMX_ALIGN_NO_TPP");
     const bool use_dp_service = !getenv("PMX_ALIGN_NO_DP_SERVICE");
@@ -229,12 +245,14 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             // thread-per-pair layout: interleaved arena per wave + a small contiguous struct region per thread
             size_t tpp_tb = 0;   // in-lane DPs measured slower than request + replay (divergence): off
             if (const char* e = getenv("PMX_ALIGN_TPP_TB")) tpp_tb = (size_t)atoll(e);
-            const Layout tpp_layout = plan_layout_tpp((int)rs->max_len, n_segs, al->opt, tpp_tb);
+            const Layout tpp_layout = hooked(plan_layout_tpp((int)rs->max_len, n_segs, al->opt, tpp_tb));
             const size_t tpp_wave_stride = tpp_arena_bytes(tpp_layout) * 64;
             const size_t tpp_raw_stride = (tpp_layout.raw_bytes + 255) & ~(size_t)255;
             al->slab0.ensure(tpp_wave_stride * (size_t)max_grid);
             al->slab_raw.ensure(tpp_raw_stride * (size_t)max_grid);   // per wave
-            tpp_set_arena(al->slab0.p, tpp_wave_stride, ctx->stream);
+            if (tpp_wave_stride > UINT32_MAX) throw std::runtime_error("thread-per-pair arena stride exceeds 32 bits");
+            A.tpp.base = al->slab0.p;
+            A.tpp.wave_stride = (uint32_t)tpp_wave_stride;
             const Layout dp_layout = plan_layout_dp((int)rs->max_len, n_segs, al->opt);
             const size_t dp_lds = PMX_ALIGN_WORK_BYTES + dp_layout.fast_bytes + 16;
             const size_t dp_stride = (dp_layout.slow_bytes + 255) & ~(size_t)255;
@@ -290,7 +308,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
                 hipLaunchKernelGGL(k_align_reads_tpp, dim3((unsigned)grid), dim3(64), tpp_lds_bytes, ctx->stream, A);
                 PMX_HIP(hipGetLastError());
             };
-            timer_begin(ctx, "align_tpp0");   // the dominant kernel on its own (bench.py roofline)
+            timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
             if (n_items >= 4096 && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_PAIR_SORT")) {
                 al->pp_key.ensure((size_t)n_items); al->pp_key2.ensure((size_t)n_items); al->pp_idx.ensure((size_t)n_items); al->pp_idx2.ensure((size_t)n_items);
                 hipLaunchKernelGGL(k_pair_prefix_keys, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
@@ -303,10 +321,11 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
             }
             launch_tpp(0, n_items, nullptr, nullptr);
             A.pair_perm = nullptr;
-            timer_end(ctx, "align_tpp0", 1);
+            timer_end(ctx, "align_dom", 1);
             int64_t n_dp = 0;
             read_counts(n_t1, n_dp, false);
             n_dp = std::min<int64_t>(n_dp, (int64_t)A.dp_slot_cap);
+            al->last_dp_slots = n_dp;
             const uint32_t* cur = nullptr;   // round 1 serves slots 0..n_dp-1
             uint32_t* lists[2] = {al->dp_list_a.p, al->dp_list_b.p};
             int round = 1;
@@ -398,17 +417,42 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     PMX_CATCH
 }
 
+// The CIGAR arena is sized optimistically (16 words per read); the kernels count what they WOULD have written
+// exactly (cigar_used runs past the capacity), so a call that overflowed is redone once with the counted size:
+// no record ever leaves this function with PMX_REC_OVERFLOW set because of the arena.
+int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2) {
+    if (!ctx || !al || !rs) return PMX_ERR_ARG;
+    if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack first)");
+    uint64_t cap = (uint64_t)std::max<int64_t>(rs->n * 16, 4096);
+    if (const char* e = getenv("PMX_ALIGN_CIGAR_CAP")) cap = (uint64_t)std::max<long long>(atoll(e), 16);   // tests: force the redo
+    for (int attempt = 0;; ++attempt) {
+        const int rc = align_readset_once(ctx, al, rs, paired, revcomp_mate2, cap);
+        if (rc != PMX_OK) return rc;
+        unsigned long long used = 0, st[4] = {0, 0, 0, 0};
+        PMX_TRY
+        PMX_HIP(hipMemcpyAsync(&used, al->cigar_used.p, sizeof(used), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(st, al->stats.p, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        PMX_CATCH
+        al->last_cigar_used = used;
+        al->last_stats.dp_calls = (int64_t)st[0];
+        al->last_stats.dp_cells = (int64_t)st[1];
+        al->last_stats.dp_pairs = al->last_dp_slots + (int64_t)st[2];
+        al->last_stats.dp_rounds = al->last_dp_rounds;
+        al->last_stats.wave_tier_items = al->last_tpp_retry;
+        al->last_stats.general_tier_items = al->last_retry;
+        al->last_stats.compact_tier_items = al->last_compact;
+        if (used <= cap) return PMX_OK;
+        if (attempt >= 2) return fail(PMX_ERR_CAPACITY, "CIGAR arena overflow persists after resizing");
+        cap = used + 64;
+    }
+}
+
 int64_t pmx_align_num_records(const pmx_aligner* al) { return al ? al->n_records : 0; }
 
 int64_t pmx_align_cigar_words(pmx_ctx* ctx, pmx_aligner* al) {
     if (!ctx || !al) return PMX_ERR_ARG;
-    PMX_TRY
-    PMX_HIP(hipSetDevice(ctx->device));
-    unsigned long long used = 0;
-    PMX_HIP(hipMemcpyAsync(&used, al->cigar_used.p, sizeof(used), hipMemcpyDeviceToHost, ctx->stream));
-    PMX_HIP(hipStreamSynchronize(ctx->stream));
-    return (int64_t)std::min<unsigned long long>(used, al->cigar_cap);
-    PMX_CATCH
+    return (int64_t)std::min<unsigned long long>(al->last_cigar_used, al->cigar_cap);
 }
 
 int pmx_align_fetch(pmx_ctx* ctx, pmx_aligner* al, pmx_aln_record* records, int64_t n_records, uint32_t* cigar_arena, int64_t arena_cap) {
@@ -435,6 +479,24 @@ int pmx_align_copy_records_device(pmx_ctx* ctx, pmx_aligner* al, void* d_records
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
     PMX_CATCH
+}
+
+int pmx_align_copy_cigars_device(pmx_ctx* ctx, pmx_aligner* al, void* d_cigars, int64_t n_words) {
+    if (!ctx || !al || (!d_cigars && n_words > 0)) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    const int64_t used = pmx_align_cigar_words(ctx, al);
+    if (n_words < used) return fail(PMX_ERR_CAPACITY, "CIGAR arena buffer too small");
+    if (used > 0) PMX_HIP(hipMemcpyAsync(d_cigars, al->cigars.p, sizeof(uint32_t) * (size_t)used, hipMemcpyDeviceToDevice, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_align_get_stats(pmx_ctx* ctx, pmx_aligner* al, pmx_align_stats* out) {
+    if (!ctx || !al || !out) return PMX_ERR_ARG;
+    *out = al->last_stats;
+    return PMX_OK;
 }
 
 const void* pmx_align_device_records(const pmx_aligner* al) { return al ? al->records.p : nullptr; }
@@ -480,10 +542,18 @@ void pmx_align_reads_direct(const char* reference, const char* refName, int n_re
             } else o->pos = INT_MAX;
         };
         const int n_items = pairedEndReads ? n_reads / 2 : n_reads;
+        // A record flagged PMX_REC_OVERFLOW / PMX_REC_UNSUPPORTED is INVALID (a work capacity or an unrestated
+        // branch of the reference was hit): it never leaves the boundary as an alignment.  The pair is reported
+        // unmapped and pmx_last_error() says how many were withheld.
+        int64_t n_withheld = 0;
         for (int k = 0; k < n_items; ++k) {
             align_pair_result_t* res = &results[k];
             memset(res, 0, sizeof(*res));
-            if (pairedEndReads) {
+            const bool invalid = pairedEndReads ? ((recs[2 * k].flags | recs[2 * k + 1].flags) & 3) != 0 : (recs[k].flags & 3) != 0;
+            if (invalid) {
+                ++n_withheld;
+                res->mapped = 0; res->r1.pos = INT_MAX; res->r2.pos = INT_MAX;
+            } else if (pairedEndReads) {
                 const pmx_aln_record &a = recs[2 * k], &b = recs[2 * k + 1];
                 if (a.mapped) { res->mapped = 1; fill(a, &res->r1); fill(b, &res->r2); }
                 else { res->mapped = 0; res->r1.pos = INT_MAX; res->r2.pos = INT_MAX; }
@@ -493,6 +563,7 @@ void pmx_align_reads_direct(const char* reference, const char* refName, int n_re
                 else res->r1.pos = INT_MAX;
             }
         }
+        if (n_withheld) set_error("pmx_align_reads_direct: " + std::to_string(n_withheld) + " invalid record(s) withheld (reported unmapped)");
     } while (0);
     if (al) pmx_aligner_free(ctx, al);
     if (rs) pmx_readset_free(ctx, rs);

@@ -1,5 +1,6 @@
 // C ABI, device part 1: context, read sets, PLACE stage orchestration (see include/panmap_amd.h).
 #include <hip/hip_runtime.h>
+#include <memory>
 
 #include <algorithm>
 #include <cmath>
@@ -264,7 +265,7 @@ int pmx_readset_upload(pmx_ctx* ctx, const char* concat, const int64_t* offsets,
     if (!ctx || !offsets || !out || n_reads < 0 || (!concat && n_reads > 0 && offsets[n_reads] > 0)) return PMX_ERR_ARG;
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
-    pmx_readset* rs = new pmx_readset();
+    std::unique_ptr<pmx_readset> rs(new pmx_readset());
     rs->n = n_reads;
     const int64_t total = offsets[n_reads] - offsets[0];
     rs->ascii.alloc((size_t)total + 32);
@@ -273,33 +274,41 @@ int pmx_readset_upload(pmx_ctx* ctx, const char* concat, const int64_t* offsets,
     std::vector<int64_t> rel((size_t)n_reads + 1);
     for (int64_t i = 0; i <= n_reads; ++i) rel[i] = offsets[i] - offsets[0];
     PMX_HIP(hipMemcpyAsync(rs->off.p, rel.data(), sizeof(int64_t) * ((size_t)n_reads + 1), hipMemcpyHostToDevice, ctx->stream));
-    readset_finish(ctx, rs, rel.data());
-    *out = rs;
+    readset_finish(ctx, rs.get(), rel.data());
+    *out = rs.release();
     return PMX_OK;
     PMX_CATCH
 }
 
 int pmx_readset_wrap_device(pmx_ctx* ctx, const void* d_concat, const void* d_offsets, int64_t n_reads, int64_t total_bytes,
                             int64_t max_read_len, pmx_readset** out) {
-    (void)total_bytes; (void)max_read_len;
-    if (!ctx || !d_concat || !d_offsets || !out || n_reads < 0) return PMX_ERR_ARG;
+    if (!ctx || !d_concat || !d_offsets || !out || n_reads < 0 || total_bytes < 0) return PMX_ERR_ARG;
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
-    pmx_readset* rs = new pmx_readset();
+    std::unique_ptr<pmx_readset> rs(new pmx_readset());
     rs->n = n_reads;
     rs->ascii.wrap((uint8_t*)d_concat, (size_t)total_bytes);
     rs->off.wrap((int64_t*)d_offsets, (size_t)n_reads + 1);
     std::vector<int64_t> h_off((size_t)n_reads + 1);
     PMX_HIP(hipMemcpy(h_off.data(), d_offsets, sizeof(int64_t) * ((size_t)n_reads + 1), hipMemcpyDeviceToHost));
-    if (h_off[0] != 0) { delete rs; return fail(PMX_ERR_ARG, "device offsets must start at 0"); }
-    readset_finish(ctx, rs, h_off.data());
-    *out = rs;
+    // the kernels trust these offsets: they must lie inside the wrapped buffer, in order.  (offsets need not start at 0:
+    // a slice [r0, r1] of a larger offsets array addresses its reads in the same buffer.)
+    if (h_off[0] < 0 || h_off[n_reads] > total_bytes) return fail(PMX_ERR_ARG, "device offsets run outside the wrapped buffer");
+    for (int64_t i = 0; i < n_reads; ++i)
+        if (h_off[i + 1] < h_off[i]) return fail(PMX_ERR_ARG, "device offsets are not monotone");
+    if (max_read_len > 0)
+        for (int64_t i = 0; i < n_reads; ++i)
+            if (h_off[i + 1] - h_off[i] > max_read_len) return fail(PMX_ERR_ARG, "a read is longer than max_read_len");
+    rs->off0 = h_off[0];
+    readset_finish(ctx, rs.get(), h_off.data());
+    *out = rs.release();
     return PMX_OK;
     PMX_CATCH
 }
 
 int pmx_readset_set_qualities(pmx_ctx* ctx, pmx_readset* rs, const char* qual_concat) {
     if (!ctx || !rs || (rs->total > 0 && !qual_concat)) return PMX_ERR_ARG;
+    if (rs->off0 != 0) return fail(PMX_ERR_ARG, "qualities need a read set whose offsets start at 0");
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     rs->qual.ensure((size_t)rs->total + 32);

@@ -15,4 +15,5 @@ struct pmx_readset {
     pmx::DevBuf<uint32_t> amb;     // 1 bit per base: not A/C/G/T
     pmx::DevBuf<uint8_t> qual;     // optional: Phred+33 per base, same offsets as ascii (--min-seed-quality)
     bool has_qual = false;
+    int64_t off0 = 0;              // first offset (non-zero for a wrapped slice of a larger offsets array)
 };

@@ -23,8 +23,12 @@ def test_bench_single_rank_line():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline"):
+              "config", "roofline", "cpu_baseline", "value_host_to_host", "dp", "real_reads"):
         assert k in d, k
+    assert d["value_host_to_host"] > 0 and d["host_to_host"]["equals_device_resident_run"]
+    assert set(("pair_share", "cells_per_step", "gcups_align_stage")) <= set(d["dp"])
+    assert d["real_reads"]["value"] > 0 and d["real_reads"]["placed_node"] == "node_7618" and d["real_reads"]["records_flagged"] == 0
+    assert d["cpu_baseline"]["cores"] == os.cpu_count()
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "reads/s" and d["value"] > 0
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
@@ -40,3 +44,26 @@ def test_bench_two_ranks_functional():
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["checks"]["placed_node"] == "node_7618" and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
+    assert d["checks"]["rank0_gather_has_every_cigar"] is True
+
+
+def test_bench_strong_scaling_two_ranks():
+    """--scaling strong: the job's reads are split over the ranks (configs[2] shape, small here)"""
+    env = dict(os.environ, PMX_BENCH_TEST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--scaling", "strong",
+                        "--total-reads", "200000", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _line(r.stdout)
+    assert d["scaling"] == "strong" and d["config"]["total_reads"] == 200000 and d["config"]["reads_per_gpu"] == 100000
+
+
+def test_two_rank_gather_equals_single_rank():
+    """rank 0 reconstructs every CIGAR of rank 1, and the merged records equal a single-rank run bit for bit"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29535", os.path.join("tests", "dist_gpu_worker.py")], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert d["n_records"] == d["n_expected"] == 40000
+    assert d["fields_equal"] and d["cigars_equal"] and d["flagged"] == 0
+    assert d["rank1_base_nonzero"] and d["rank1_has_cigars"] and d["multi_op_cigars"] > 1000

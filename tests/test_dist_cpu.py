@@ -20,6 +20,11 @@ def _free_port():
     return p
 
 
+def pmx_rec_dtype():
+    return np.dtype([("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"), ("mapq", "u1"), ("rev", "u1"), ("proper_frag", "u1"),
+                     ("mapped", "u1"), ("n_cigar", "<u2"), ("flags", "<u2"), ("cigar_off", "<u4"), ("score", "<i4")])
+
+
 def _worker(rank, world, port, reads, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,6 +38,31 @@ def _worker(rank, world, port, reads, out_dir):
     parts = [(g[r, 0, :sizes[r]].numpy().view(np.uint64), g[r, 1, :sizes[r]].numpy()) for r in range(world)]
     mh, mc = pd.merge_histograms_host(parts)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), h=mh, c=mc, lo=lo, hi=hi)
+    # alignment results: records whose cigar_off indexes a per-rank arena -> rank 0 gets both, offsets rebased
+    n_loc = hi - lo
+    rec = np.zeros(n_loc, pmx_rec_dtype())
+    rec["rs"] = np.arange(lo, hi)
+    rec["n_cigar"] = 1 + (np.arange(n_loc) % 3)
+    rec["flags"] = 4
+    rec["flags"][::5] = 0                      # no alignment: cigar_off stays 0
+    rec["n_cigar"][::5] = 0
+    rec["cigar_off"] = np.concatenate([[0], np.cumsum(rec["n_cigar"])[:-1]]) * (rec["flags"] != 0)
+    arena = np.concatenate([np.full(int(k), (int(r) << 4), np.uint32) for r, k in zip(rec["rs"], rec["n_cigar"])] + [np.zeros(0, np.uint32)])
+    gal = pd.gather_alignments(torch.from_numpy(rec.view(np.uint8).reshape(n_loc, 32).copy()), torch.from_numpy(arena.view(np.int32).copy()), 0)
+    if rank == 0:
+        g_recs, g_arena, n_rec, bases = gal
+        m = g_recs.numpy().view(pmx_rec_dtype()).reshape(-1)
+        ar = g_arena.numpy().view(np.uint32)
+        assert len(m) == len(reads) and n_rec == [1500, 1502] and bases[0] == 0 and bases[1] > 0
+        for i in range(len(m)):                 # every record finds ITS CIGAR words in the merged arena
+            k = int(m["n_cigar"][i])
+            assert m["rs"][i] == i
+            if k:
+                assert np.all(ar[int(m["cigar_off"][i]):int(m["cigar_off"][i]) + k] == (i << 4))
+            else:
+                assert m["cigar_off"][i] == 0
+    else:
+        assert gal is None
     recs = torch.full((hi - lo, 32), rank, dtype=torch.uint8)
     got = pd.gather_records(recs, 0)
     if rank == 0:
