@@ -127,7 +127,7 @@ def main():
     index = pmx.Index.build(pm, k=19, s=8, t=0, l=3, open_syncmer=False, flank_mask=250)
     ctx = pmx.Context(local_rank)
     placer = pmx.Placer(ctx, index)
-    ctx_stream = torch.cuda.ExternalStream(ctx.stream(), device=dev) if ctx.stream() else torch.cuda.current_stream(dev)
+    ctx_stream = torch.cuda.ExternalStream(ctx.stream, device=dev) if ctx.stream else torch.cuda.current_stream(dev)
 
     # ---------------------------------------------------------------------------------------------- workload
     # Source genome: node_7618 of the tree (the node the repository's example sample places on; SURVEY 8d asks for

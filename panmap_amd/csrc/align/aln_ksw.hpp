@@ -682,6 +682,116 @@ PMX_HD int count_diff(Ptr<const uint8_t> a, Ptr<const uint8_t> b, int n) {
 // Everything else runs the DP.
 // QF / TF: callables returning the query / target base at position i (so the bases can come from the work
 // arena, straight from the reference in global memory, or be read back to front for a left extension)
+// The decisions of the shortcuts, separated from how the mismatch statistics were obtained (a per-base scan here, a
+// packed XOR in the compact tier, aln_compact.hpp): both tiers answer from the SAME code.
+// Extension (EXTZ_ONLY): d = positions i < qlen where the bases differ or one is ambiguous, pf / pm = the smallest /
+// largest such position.  cig0 receives the single CIGAR operation when ez.n_cigar == 1.
+template <class QF, class TF>
+PMX_HD bool ksw_shortcut_ext_decide(int qlen, int tlen, int d, int pf, int pm, QF& qf, TF& tf, int a, int b, int8_t q, int8_t e, int8_t q2,
+                                    int8_t e2, int zdrop, int end_bonus, Ez& ez, uint32_t* cig0) {
+    const int g1 = q + e, g2 = q2 + e2;
+    const int gmin = g1 < g2 ? g1 : g2, gmax = g1 > g2 ? g1 : g2;
+    if (d == 0) {
+        ez_reset(ez);
+        ez.max = (uint32_t)(qlen * a);
+        ez.max_t = ez.max_q = qlen - 1;
+        ez.mqe = qlen * a;
+        ez.mqe_t = qlen - 1;
+        if (tlen == qlen) { ez.mte = qlen * a; ez.mte_q = qlen - 1; }
+        ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
+        *cig0 = (uint32_t)qlen << 4;
+        ez.n_cigar = 1;
+        return true;
+    }
+    if (d == 1 && a + b < gmin) {
+        const int pos = pm;
+        if (qf(pos) <= 3 && tf(pos) <= 3) {   // a real mismatch, not an ambiguous base
+            ez_reset(ez);
+            const int hend = qlen * a - (a + b);
+            if (pos >= 1) { ez.max = (uint32_t)(pos * a); ez.max_t = ez.max_q = pos - 1; }
+            if (hend > (int)ez.max) { ez.max = (uint32_t)hend; ez.max_t = ez.max_q = qlen - 1; }
+            ez.mqe = hend;
+            ez.mqe_t = qlen - 1;
+            if (tlen == qlen) { ez.mte = hend; ez.mte_q = qlen - 1; }
+            ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
+            const int len = ez.reach_end ? qlen : ez.max_q + 1;
+            if (len > 0) { *cig0 = (uint32_t)len << 4; ez.n_cigar = 1; }
+            return true;
+        }
+    }
+    // (1c) exactly TWO mismatches p1 < p2 (no ambiguous base), both at least 6 bases before the query end.
+    // A path with two or more gaps costs >= 2*gmin > 2(a+b) more than it can win back, a single gap longer
+    // than G = the largest k with min(q+ke, q2+ke2) <= 2(a+b) likewise; a single gap of length <= G can only
+    // rival the diagonal if it dodges BOTH mismatches without meeting a new one, i.e. if the diagonal shifted
+    // by that gap matches the target everywhere between p1 and p2.  If every such shifted diagonal (both
+    // directions, 1..G) has a mismatch in [p1, p2], every cell off the main diagonal scores strictly below
+    // the diagonal cell of its row/column minimum, and the results follow from
+    // H(m,m) = a(m+1) - (a+b)[m >= p1] - (a+b)[m >= p2] as in (1b).  (checked against the DP on millions of
+    // random problems with tandem repeats: tests/test_align_host.py)
+    if (d == 2 && 2 * (a + b) < 2 * gmin && zdrop >= 2 * gmax + a + 2 * (a + b)) {
+        const int p1 = pf, p2 = pm;
+        bool ok = p2 <= qlen - 6 && qf(p1) <= 3 && tf(p1) <= 3 && qf(p2) <= 3 && tf(p2) <= 3;
+        int G = 0;
+        for (int k = 1; k <= 64 && ok; ++k) {
+            const int gk = (q + k * e) < (q2 + k * e2) ? (q + k * e) : (q2 + k * e2);
+            if (gk <= 2 * (a + b)) G = k;
+            else break;
+        }
+        for (int k = 1; k <= G && ok; ++k) {
+            // query shifted forward by k against the target (k query bases inserted before the shifted run),
+            // and the target shifted forward by k (k target bases deleted): a mismatch must exist at some
+            // u in [p1, p2]; a shifted diagonal that runs off a sequence before p2 cannot reach that far
+            bool hit_i = false, hit_d = false;
+            for (int u = p1; u <= p2; ++u) {
+                if (u + k >= qlen || qf(u + k) != tf(u) || qf(u + k) > 3) hit_i = true;
+                if (u + k >= tlen || qf(u) != tf(u + k) || tf(u + k) > 3) hit_d = true;
+            }
+            ok = hit_i && hit_d;
+        }
+        if (ok) {
+            ez_reset(ez);
+            const int ab = a + b;
+            const int h1 = p1 * a, h2 = p2 * a - ab, hend = qlen * a - 2 * ab;   // H at m = p1-1, p2-1, qlen-1
+            if (p1 >= 1) { ez.max = (uint32_t)h1; ez.max_t = ez.max_q = p1 - 1; }
+            if (h2 > (int)ez.max) { ez.max = (uint32_t)h2; ez.max_t = ez.max_q = p2 - 1; }
+            if (hend > (int)ez.max) { ez.max = (uint32_t)hend; ez.max_t = ez.max_q = qlen - 1; }
+            ez.mqe = hend;
+            ez.mqe_t = qlen - 1;
+            if (tlen == qlen) { ez.mte = hend; ez.mte_q = qlen - 1; }
+            ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
+            const int len = ez.reach_end ? qlen : ez.max_q + 1;
+            if (len > 0) { *cig0 = (uint32_t)len << 4; ez.n_cigar = 1; }
+            return true;
+        }
+    }
+    return false;
+}
+// pre-conditions shared by every shortcut, and the ones of the extension / gap-fill class
+PMX_HD bool ksw_shortcut_applicable(int qlen, int tlen, int a, int b, int gmin, int w) {
+    return qlen > 0 && tlen > 0 && a > 0 && b > 0 && (w < 0 || (w >= qlen && w >= tlen)) && b <= 2 * gmin;
+}
+PMX_HD bool ksw_shortcut_is_ext(int qlen, int tlen, int a, int b, int gmax, int zdrop, int flag) {
+    return (flag & PMX_EZ_EXTZ_ONLY) && tlen >= qlen && zdrop >= 2 * gmax + a + (a + b);
+}
+PMX_HD bool ksw_shortcut_is_fill(int qlen, int tlen, int flag) {
+    return !(flag & PMX_EZ_EXTZ_ONLY) && (flag & PMX_EZ_APPROX_MAX) && !(flag & PMX_EZ_APPROX_DROP) && qlen == tlen;
+}
+// Gap fill in the approximate-max first pass: d differing positions (an ambiguous query base counts), amb ambiguous ones
+PMX_HD bool ksw_shortcut_fill_decide(int qlen, int d, int amb, int a, int b, int gmin, int flag, Ez& ez, uint32_t* cig0) {
+    // gap-free = a*n - d(a+b); any gapped global path has >= 2 gaps and <= n-1 pairs: <= a(n-1) - 2*gmin.  With
+    // left-aligned gaps (no RIGHT flag) a tie is harmless: the traceback takes a gap only when it is strictly
+    // better (`d = a > z ? 1 : 0`), and the score is the same.
+    const bool right = (flag & PMX_EZ_RIGHT) != 0;
+    if (amb == 0 && (right ? d * (a + b) < a + 2 * gmin : d * (a + b) <= a + 2 * gmin)) {
+        ez_reset(ez);
+        ez.score = qlen * a - d * (a + b);
+        *cig0 = (uint32_t)qlen << 4;
+        ez.n_cigar = 1;
+        return true;
+    }
+    return false;
+}
+
 template <class QF, class TF>
 PMX_HD bool ksw_shortcut_f(Work& W, int qlen, QF& qf, int tlen, TF& tf, const int8_t* mat, int8_t q, int8_t e, int8_t q2, int8_t e2, int w,
                            int zdrop, int end_bonus, int flag, Ez& ez) {
@@ -690,116 +800,36 @@ PMX_HD bool ksw_shortcut_f(Work& W, int qlen, QF& qf, int tlen, TF& tf, const in
     const int a = mat[0], b = -mat[1];
     const int g1 = q + e, g2 = q2 + e2;
     const int gmin = g1 < g2 ? g1 : g2, gmax = g1 > g2 ? g1 : g2;
-    if (qlen > 0 && tlen > 0 && a > 0 && b > 0 && (w < 0 || (w >= qlen && w >= tlen)) && -mat[1] <= 2 * gmin) {
-        if ((flag & PMX_EZ_EXTZ_ONLY) && tlen >= qlen && zdrop >= 2 * gmax + a + (a + b)) {
-            // d = differing or ambiguous positions among the first qlen; pm = the largest such position
-            int d = 0, pm = -1, pf = INT32_MAX;   // pf / pm: smallest / largest such position
-            for (int i = lane_id(); i < qlen; i += PMX_W) {
-                const uint32_t cq = qf(i), ct = tf(i);
-                if (cq != ct || cq > 3 || ct > 3) { ++d; pm = i; pf = i < pf ? i : pf; }
-            }
-            d = wave_sum_i32(d);
-            if (d == 0) {
-                ez_reset(ez);
-                ez.max = (uint32_t)(qlen * a);
-                ez.max_t = ez.max_q = qlen - 1;
-                ez.mqe = qlen * a;
-                ez.mqe_t = qlen - 1;
-                if (tlen == qlen) { ez.mte = qlen * a; ez.mte_q = qlen - 1; }
-                ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
-                cig_tmp[0] = (uint32_t)qlen << 4;
-                ez.n_cigar = 1;
-                wave_sync();
-                return true;
-            }
-            if (d == 1 && a + b < gmin) {
-                const int pos = wave_max_i32(pm);
-                if (qf(pos) <= 3 && tf(pos) <= 3) {   // a real mismatch, not an ambiguous base
-                    ez_reset(ez);
-                    const int hend = qlen * a - (a + b);
-                    if (pos >= 1) { ez.max = (uint32_t)(pos * a); ez.max_t = ez.max_q = pos - 1; }
-                    if (hend > (int)ez.max) { ez.max = (uint32_t)hend; ez.max_t = ez.max_q = qlen - 1; }
-                    ez.mqe = hend;
-                    ez.mqe_t = qlen - 1;
-                    if (tlen == qlen) { ez.mte = hend; ez.mte_q = qlen - 1; }
-                    ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
-                    const int len = ez.reach_end ? qlen : ez.max_q + 1;
-                    if (len > 0) { cig_tmp[0] = (uint32_t)len << 4; ez.n_cigar = 1; }
-                    wave_sync();
-                    return true;
-                }
-            }
-            // (1c) exactly TWO mismatches p1 < p2 (no ambiguous base), both at least 6 bases before the query end.
-            // A path with two or more gaps costs >= 2*gmin > 2(a+b) more than it can win back, a single gap longer
-            // than G = the largest k with min(q+ke, q2+ke2) <= 2(a+b) likewise; a single gap of length <= G can only
-            // rival the diagonal if it dodges BOTH mismatches without meeting a new one, i.e. if the diagonal shifted
-            // by that gap matches the target everywhere between p1 and p2.  If every such shifted diagonal (both
-            // directions, 1..G) has a mismatch in [p1, p2], every cell off the main diagonal scores strictly below
-            // the diagonal cell of its row/column minimum, and the results follow from
-            // H(m,m) = a(m+1) - (a+b)[m >= p1] - (a+b)[m >= p2] as in (1b).  (checked against the DP on millions of
-            // random problems with tandem repeats: tests/test_align_host.py)
-            if (d == 2 && 2 * (a + b) < 2 * gmin && zdrop >= 2 * gmax + a + 2 * (a + b)) {
-                const int p1 = -wave_max_i32(-pf), p2 = wave_max_i32(pm);
-                bool ok = p2 <= qlen - 6 && qf(p1) <= 3 && tf(p1) <= 3 && qf(p2) <= 3 && tf(p2) <= 3;
-                int G = 0;
-                for (int k = 1; k <= 64 && ok; ++k) {
-                    const int gk = (q + k * e) < (q2 + k * e2) ? (q + k * e) : (q2 + k * e2);
-                    if (gk <= 2 * (a + b)) G = k;
-                    else break;
-                }
-                for (int k = 1; k <= G && ok; ++k) {
-                    // query shifted forward by k against the target (k query bases inserted before the shifted run),
-                    // and the target shifted forward by k (k target bases deleted): a mismatch must exist at some
-                    // u in [p1, p2]; a shifted diagonal that runs off a sequence before p2 cannot reach that far
-                    bool hit_i = false, hit_d = false;
-                    for (int u = p1; u <= p2; ++u) {
-                        if (u + k >= qlen || qf(u + k) != tf(u) || qf(u + k) > 3) hit_i = true;
-                        if (u + k >= tlen || qf(u) != tf(u + k) || tf(u + k) > 3) hit_d = true;
-                    }
-                    ok = hit_i && hit_d;
-                }
-                if (ok) {
-                    ez_reset(ez);
-                    const int ab = a + b;
-                    const int h1 = p1 * a, h2 = p2 * a - ab, hend = qlen * a - 2 * ab;   // H at m = p1-1, p2-1, qlen-1
-                    if (p1 >= 1) { ez.max = (uint32_t)h1; ez.max_t = ez.max_q = p1 - 1; }
-                    if (h2 > (int)ez.max) { ez.max = (uint32_t)h2; ez.max_t = ez.max_q = p2 - 1; }
-                    if (hend > (int)ez.max) { ez.max = (uint32_t)hend; ez.max_t = ez.max_q = qlen - 1; }
-                    ez.mqe = hend;
-                    ez.mqe_t = qlen - 1;
-                    if (tlen == qlen) { ez.mte = hend; ez.mte_q = qlen - 1; }
-                    ez.reach_end = ez.mqe + end_bonus > (int)ez.max ? 1 : 0;
-                    const int len = ez.reach_end ? qlen : ez.max_q + 1;
-                    if (len > 0) { cig_tmp[0] = (uint32_t)len << 4; ez.n_cigar = 1; }
-                    wave_sync();
-                    return true;
-                }
-            }
-        } else if (!(flag & PMX_EZ_EXTZ_ONLY) && (flag & PMX_EZ_APPROX_MAX) && !(flag & PMX_EZ_APPROX_DROP) && qlen == tlen) {
-            // differing positions, and ambiguous bases (any of those forces the DP)
-            int d = 0, amb = 0;
-            for (int i = lane_id(); i < qlen; i += PMX_W) {
-                const uint32_t cq = qf(i), ct = tf(i);
-                d += (cq != ct || cq > 3) ? 1 : 0;
-                amb += (cq > 3 || ct > 3) ? 1 : 0;
-            }
-            d = wave_sum_i32(d);
-            amb = wave_sum_i32(amb);
-            // gap-free = a*n - d(a+b); any gapped global path has >= 2 gaps and <= n-1 pairs: <= a(n-1) - 2*gmin.  With
-            // left-aligned gaps (no RIGHT flag) a tie is harmless: the traceback takes a gap only when it is strictly
-            // better (`d = a > z ? 1 : 0`), and the score is the same.
-            const bool right = (flag & PMX_EZ_RIGHT) != 0;
-            if (amb == 0 && (right ? d * (a + b) < a + 2 * gmin : d * (a + b) <= a + 2 * gmin)) {
-                ez_reset(ez);
-                ez.score = qlen * a - d * (a + b);
-                cig_tmp[0] = (uint32_t)qlen << 4;
-                ez.n_cigar = 1;
-                wave_sync();
-                return true;
-            }
+    if (!ksw_shortcut_applicable(qlen, tlen, a, b, gmin, w)) return false;
+    uint32_t cig0 = 0;
+    bool done = false;
+    if (ksw_shortcut_is_ext(qlen, tlen, a, b, gmax, zdrop, flag)) {
+        // d = differing or ambiguous positions among the first qlen; pf / pm: smallest / largest such position
+        int d = 0, pm = -1, pf = INT32_MAX;
+        for (int i = lane_id(); i < qlen; i += PMX_W) {
+            const uint32_t cq = qf(i), ct = tf(i);
+            if (cq != ct || cq > 3 || ct > 3) { ++d; pm = i; pf = i < pf ? i : pf; }
         }
+        d = wave_sum_i32(d);
+        if (d > 0 && d <= 2) { pm = wave_max_i32(pm); pf = -wave_max_i32(-pf); }
+        done = ksw_shortcut_ext_decide(qlen, tlen, d, pf, pm, qf, tf, a, b, q, e, q2, e2, zdrop, end_bonus, ez, &cig0);
+    } else if (ksw_shortcut_is_fill(qlen, tlen, flag)) {
+        // differing positions, and ambiguous bases (any of those forces the DP)
+        int d = 0, amb = 0;
+        for (int i = lane_id(); i < qlen; i += PMX_W) {
+            const uint32_t cq = qf(i), ct = tf(i);
+            d += (cq != ct || cq > 3) ? 1 : 0;
+            amb += (cq > 3 || ct > 3) ? 1 : 0;
+        }
+        d = wave_sum_i32(d);
+        amb = wave_sum_i32(amb);
+        done = ksw_shortcut_fill_decide(qlen, d, amb, a, b, gmin, flag, ez, &cig0);
     }
-    return false;
+    if (done) {
+        if (ez.n_cigar > 0) cig_tmp[0] = cig0;
+        wave_sync();
+    }
+    return done;
 }
 
 // base readers for ksw_shortcut_f

@@ -128,18 +128,15 @@ PMX_HD void sketch_segment_t(Work& W, const Ring& buf, Ptr<const uint8_t> seq, i
 //    the largest age rank (j - buf_pos - 1) mod w;
 //  * an entry is "another occurrence" iff its x equals the minimum's and it is not the minimum's slot (y holds the
 //    position, unique per slot; invalid entries are excluded by mn.x != UINT64_MAX).
-template <int WMAX>
-PMX_HD void sketch_segment_reg(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
+// BaseFn: int(int i) = nt4 code of base i (>= 4: ambiguous); PushFn: void(uint64_t x, uint64_t y) appends a minimizer
+// (the caller owns the output list and its overflow handling).  Used by the scalar models of the general pipeline
+// (sketch_segment_reg below: bases from the work arena, output to W.mv) and by the compact tier (aln_compact.hpp:
+// bases straight from the packed read words, output to its LDS staging list).
+template <int WMAX, class BaseFn, class PushFn>
+PMX_HD void sketch_core(int len, int w, int k, uint64_t y_hi, BaseFn& base_at, PushFn& push) {
     const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
-    const uint64_t y_hi = (uint64_t)rid << 32;
     uint64_t kmer0 = 0, kmer1 = 0;
     int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
-    PMX_LDS(&W); PMX_LDS(seq);
-    Ptr<A128> mvp = W.mv; PMX_LDS(mvp);
-    // the output cursor and its bound live in registers for the whole segment (W is memory to the compiler)
-    int n_mv = W.n_mv;
-    const int max_mini = W.caps.max_mini;
-    bool overflow = false;
     A128 mn;
     mn.x = mn.y = UINT64_MAX;
     uint64_t xs[WMAX];
@@ -156,14 +153,8 @@ PMX_HD void sketch_segment_reg(Work& W, Ptr<const uint8_t> seq, int len, int w, 
         v.y = v.x == UINT64_MAX ? UINT64_MAX : (y_hi | yl);
         return v;
     };
-#define PMX_MV_PUSH(val)                             \
-    do {                                             \
-        if (n_mv < max_mini) mvp[n_mv++] = (val);    \
-        else overflow = true;                        \
-    } while (0)
-    ByteReader seq_r(seq);
     for (int i = 0; i < len; ++i) {
-        const int c = (int)seq_r[i];
+        const int c = base_at(i);
         A128 info;
         info.x = info.y = UINT64_MAX;
         if (c < 4) {
@@ -186,15 +177,15 @@ PMX_HD void sketch_segment_reg(Work& W, Ptr<const uint8_t> seq, int len, int w, 
             if (j == buf_pos) { xs[j] = info.x; ys[j] = (uint32_t)info.y; }
         if (l == w + k - 1 && mn.x != UINT64_MAX) {   // first full window: emit earlier identical k-mers
             for (int j = buf_pos + 1; j < w; ++j)
-                { const A128 bj = ring_get(j); if (mn.x == bj.x && bj.y != mn.y) PMX_MV_PUSH(bj); }
+                { const A128 bj = ring_get(j); if (mn.x == bj.x && bj.y != mn.y) push(bj.x, bj.y); }
             for (int j = 0; j < buf_pos; ++j)
-                { const A128 bj = ring_get(j); if (mn.x == bj.x && bj.y != mn.y) PMX_MV_PUSH(bj); }
+                { const A128 bj = ring_get(j); if (mn.x == bj.x && bj.y != mn.y) push(bj.x, bj.y); }
         }
         // the three outcomes of sketch_segment_t's if / else-if, with ONE push site and a branch-free re-scan (in a
         // wave of 64 reads some lane needs the re-scan at almost every base, so it is computed unconditionally)
         const bool new_min = info.x <= mn.x;
         const bool slid = !new_min && buf_pos == min_pos;
-        if (mn.x != UINT64_MAX && ((new_min && l >= w + k) || (slid && l >= w + k - 1))) PMX_MV_PUSH(mn);
+        if (mn.x != UINT64_MAX && ((new_min && l >= w + k) || (slid && l >= w + k - 1))) push(mn.x, mn.y);
         uint64_t m = UINT64_MAX;
 #pragma unroll
         for (int j = 0; j < WMAX; ++j) m = xs[j] < m ? xs[j] : m;
@@ -218,15 +209,31 @@ PMX_HD void sketch_segment_reg(Work& W, Ptr<const uint8_t> seq, int len, int w, 
             min_pos = best_j;
             if (l >= w + k - 1 && mn.x != UINT64_MAX && (eq & ~(1u << min_pos)) != 0u) {   // other occurrences of the minimum
                 for (int j = buf_pos + 1; j < w; ++j)
-                    if ((eq >> j & 1u) && j != min_pos) PMX_MV_PUSH(ring_get(j));
+                    if ((eq >> j & 1u) && j != min_pos) { const A128 bj = ring_get(j); push(bj.x, bj.y); }
                 for (int j = 0; j <= buf_pos; ++j)
-                    if ((eq >> j & 1u) && j != min_pos) PMX_MV_PUSH(ring_get(j));
+                    if ((eq >> j & 1u) && j != min_pos) { const A128 bj = ring_get(j); push(bj.x, bj.y); }
             }
         }
         if (++buf_pos == w) buf_pos = 0;
     }
-    if (mn.x != UINT64_MAX) PMX_MV_PUSH(mn);
-#undef PMX_MV_PUSH
+    if (mn.x != UINT64_MAX) push(mn.x, mn.y);
+}
+
+template <int WMAX>
+PMX_HD void sketch_segment_reg(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
+    PMX_LDS(&W); PMX_LDS(seq);
+    Ptr<A128> mvp = W.mv; PMX_LDS(mvp);
+    // the output cursor and its bound live in registers for the whole segment (W is memory to the compiler)
+    int n_mv = W.n_mv;
+    const int max_mini = W.caps.max_mini;
+    bool overflow = false;
+    ByteReader seq_r(seq);
+    auto base_at = [&](int i) { return (int)seq_r[i]; };
+    auto push = [&](uint64_t x, uint64_t y) {
+        if (n_mv < max_mini) { A128 v; v.x = x; v.y = y; mvp[n_mv++] = v; }
+        else overflow = true;
+    };
+    sketch_core<WMAX>(len, w, k, (uint64_t)rid << 32, base_at, push);
     W.n_mv = n_mv;
     if (overflow) W.status |= PMX_ST_OVERFLOW;
 }

@@ -115,8 +115,13 @@ struct IPtr {
     __device__ IPtr(const IPtr<U>& q) : o(q.o) {}
     static constexpr uint32_t LG = IGranule<T>::LG;   // log2 of the granule
     __device__ __forceinline__ static T* phys(uint32_t off) {
+        // The kernarg segment of this dispatch, found through the AQL dispatch packet (hsa_kernel_dispatch_packet_t:
+        // kernarg_address at byte 40).  llvm.amdgcn.kernarg.segment.ptr itself is only defined in the kernel function, the
+        // dispatch pointer is handed down to callees.  Both loads are uniform and from the constant address space.
+        typedef const __attribute__((address_space(4))) uint8_t* CPtr;
         typedef const __attribute__((address_space(4))) TppArena* KernargArena;
-        const KernargArena ka = (KernargArena)__builtin_amdgcn_kernarg_segment_ptr();   // AlignArgs::tpp
+        const CPtr pkt = (CPtr)__builtin_amdgcn_dispatch_ptr();
+        const KernargArena ka = *(const KernargArena __attribute__((address_space(4)))*)(pkt + 40);   // AlignArgs::tpp
         uint8_t* wave_base = ka->base + (size_t)blockIdx.x * ka->wave_stride;   // uniform
         const uint32_t vo = ((threadIdx.x & 63u) << LG) + ((off >> LG) << (LG + 6)) + (off & ((1u << LG) - 1u));
         return reinterpret_cast<T*>(wave_base + vo);
