@@ -77,6 +77,7 @@ struct HostRefIndex {
     std::vector<HtEnt> ht;
     std::vector<uint64_t> pos;
     std::vector<float> logf_ratio, logf_int;
+    std::vector<uint64_t> pk, pk_amb;   // RefIndex::pk / pk_amb
     std::vector<uint32_t> occ;   // occurrences per distinct minimizer
     int logf_a = 0;              // match score the logf tables were built for
     RefIndex view() const {
@@ -89,6 +90,8 @@ struct HostRefIndex {
         r.logf_ratio = logf_ratio.data();
         r.logf_int = logf_int.data();
         r.n_logf = (int32_t)logf_int.size();
+        r.pk = pk.data();
+        r.pk_amb = pk_amb.data();
         return r;
     }
 };
@@ -113,7 +116,14 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
     keep_int.swap(out.logf_int);
     out = HostRefIndex();
     out.seq.assign((size_t)ref_len + 8, 0);   // padded: readers fetch aligned 32-bit words
-    for (int64_t i = 0; i < ref_len; ++i) out.seq[i] = nt4_of_char((unsigned char)ref[i]);
+    out.pk.assign((size_t)(ref_len + 31) / 32 + 2, 0);
+    out.pk_amb.assign((size_t)(ref_len + 31) / 32 + 2, 0);
+    for (int64_t i = 0; i < ref_len; ++i) {
+        const uint8_t c = nt4_of_char((unsigned char)ref[i]);
+        out.seq[i] = c;
+        if (c < 4) out.pk[(size_t)(i >> 5)] |= (uint64_t)c << (2 * (i & 31));
+        else out.pk_amb[(size_t)(i >> 5)] |= 1ULL << (2 * (i & 31));
+    }
     o.ref_len = (int)ref_len;
     Work W;
     memset(&W, 0, sizeof(W));

@@ -261,6 +261,10 @@ struct RefIndex {
     const float* logf_ratio;
     const float* logf_int;
     int32_t n_logf;
+    // the same sequence 2 bit/base (base j of word k at bits 2(j % 32); ambiguous bases as 0) and its ambiguity mask
+    // (bit 2(j % 32) of word k set when base j is not A/C/G/T): what the compact tier XORs packed reads against
+    const uint64_t* pk;
+    const uint64_t* pk_amb;
 };
 
 // chain-DP state of one anchor (f, p, t, v of mg_lchain_dp, lchain.c:148-230) as ONE 16-byte cell: the inner

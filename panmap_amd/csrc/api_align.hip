@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 
+#include "align/aln_compact_defs.hpp"
 #include "align_kernel.h"
 #include "device/dev_util.hpp"
 #include "readset.hpp"
@@ -27,6 +28,7 @@ struct pmx_aligner {
     DevBuf<uint64_t> d_pos;
     DevBuf<HtEnt> d_ht;
     DevBuf<float> d_logf_ratio, d_logf_int;
+    DevBuf<uint64_t> d_pk, d_pk_amb;
     RefIndex ri;
     int mean_len = 150;
     // last result
@@ -38,7 +40,7 @@ struct pmx_aligner {
     DevBuf<uint32_t> pp_key, pp_key2, pp_idx, pp_idx2;   // pair order of the thread-per-pair kernel
     DevBuf<char> pp_tmp;
     uint32_t mv_epoch = 0;
-    DevBuf<uint32_t> retry_list2;
+    DevBuf<uint32_t> retry_list2, bail_list;
     DevBuf<uint8_t> dp_req;
     DevBuf<DpRes> dp_res;
     DevBuf<uint32_t> dp_ncached, dp_slot_pairs, dp_list_a, dp_list_b;
@@ -101,6 +103,8 @@ int pmx_aligner_set_reference(pmx_ctx* ctx, pmx_aligner* al, const char* referen
     upload(al->d_pos, al->host.pos, ctx->stream);
     upload(al->d_logf_ratio, al->host.logf_ratio, ctx->stream);
     upload(al->d_logf_int, al->host.logf_int, ctx->stream);
+    upload(al->d_pk, al->host.pk, ctx->stream);
+    upload(al->d_pk_amb, al->host.pk_amb, ctx->stream);
     RefIndex& r = al->ri;
     r.seq = al->d_seq.p;
     r.len = (int32_t)ref_len;
@@ -110,6 +114,8 @@ int pmx_aligner_set_reference(pmx_ctx* ctx, pmx_aligner* al, const char* referen
     r.logf_ratio = al->d_logf_ratio.p;
     r.logf_int = al->d_logf_int.p;
     r.n_logf = (int32_t)al->host.logf_int.size();
+    r.pk = al->d_pk.p;
+    r.pk_amb = al->d_pk_amb.p;
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
     PMX_CATCH
@@ -202,8 +208,8 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         PMX_HIP(hipGetLastError());
     };
 
-    al->retry_count.ensure(2);   // [0] pairs for the next (wave) tier, [1] DP requests of the current tier-0 round
-    PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    al->retry_count.ensure(4);   // [0] pairs for the next (wave) tier, [1] DP requests of the current tier-0 round, [2] compact-tier bails
+    PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     // test hook: cap the CIGAR operations per region in EVERY tier, so that gapped alignments overflow and the
     // boundary's handling of invalid records can be exercised (tests/test_align_gpu.py)
     int test_max_cigar = 0;
@@ -308,7 +314,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 hipLaunchKernelGGL(k_align_reads_tpp, dim3((unsigned)grid), dim3(64), tpp_lds_bytes, ctx->stream, A);
                 PMX_HIP(hipGetLastError());
             };
-            timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
+            const uint32_t* order = nullptr;   // launch order of the first pass: pairs sorted by a locality key
             if (n_items >= 4096 && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_PAIR_SORT")) {
                 al->pp_key.ensure((size_t)n_items); al->pp_key2.ensure((size_t)n_items); al->pp_idx.ensure((size_t)n_items); al->pp_idx2.ensure((size_t)n_items);
                 hipLaunchKernelGGL(k_pair_prefix_keys, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
@@ -317,11 +323,40 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 32, ctx->stream));
                 al->pp_tmp.ensure(bytes);
                 PMX_HIP(rocprim::radix_sort_pairs(al->pp_tmp.p, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 32, ctx->stream));
-                A.pair_perm = al->pp_idx2.p;
+                order = al->pp_idx2.p;
             }
-            launch_tpp(0, n_items, nullptr, nullptr);
+            // Compact tier (align_kernel_compact.hip): every pair first, work state in LDS; what it cannot finish comes
+            // back as the bail list, which is the launch order of the general thread-per-pair kernel below.
+            int64_t n_t0 = n_items;
+            const bool use_compact = paired && al->opt.is_sr_like && rs->max_len <= PMX_C_MAXLEN && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_COMPACT");
+            timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
+            if (use_compact) {
+                al->bail_list.ensure((size_t)n_items);
+                const size_t c_lds = (size_t)PMX_C_LANE_WORDS * 64 * sizeof(uint32_t);
+                PMX_HIP(hipFuncSetAttribute((const void*)k_align_compact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c_lds));
+                int c_waves = (int)((size_t)(160 * 1024) / c_lds);
+                if (const char* e = getenv("PMX_ALIGN_COMPACT_WAVES")) c_waves = atoi(e);
+                const int64_t c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(c_waves, 1), (n_items + 63) / 64);
+                A.n_items = n_items;
+                A.pair_perm = order;
+                A.retry_list = al->bail_list.p;
+                A.retry_count = al->retry_count.p + 2;
+                hipLaunchKernelGGL(k_align_compact, dim3((unsigned)c_grid), dim3(64), c_lds, ctx->stream, A);
+                PMX_HIP(hipGetLastError());
+                timer_end(ctx, "align_dom", 1);
+                unsigned long long h_bail = 0;
+                PMX_HIP(hipMemcpyAsync(&h_bail, al->retry_count.p + 2, sizeof(h_bail), hipMemcpyDeviceToHost, ctx->stream));
+                PMX_HIP(hipStreamSynchronize(ctx->stream));
+                n_t0 = (int64_t)h_bail;
+                al->last_compact = n_items - n_t0;
+                order = al->bail_list.p;
+                A.retry_list = al->retry_list2.p;
+                A.retry_count = al->retry_count.p;
+            }
+            A.pair_perm = order;
+            if (n_t0 > 0) launch_tpp(0, n_t0, nullptr, nullptr);
             A.pair_perm = nullptr;
-            timer_end(ctx, "align_dom", 1);
+            if (!use_compact) timer_end(ctx, "align_dom", 1);
             int64_t n_dp = 0;
             read_counts(n_t1, n_dp, false);
             n_dp = std::min<int64_t>(n_dp, (int64_t)A.dp_slot_cap);

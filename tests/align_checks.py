@@ -62,6 +62,23 @@ def hostsim_align(reference: bytes, reads, paired, verbose=0, tpp=False):
     return records_to_results(recs, cig, n, paired)
 
 
+def hostsim_align_compact(reference: bytes, reads, rc2=False):
+    """the compact tier (align/aln_compact.hpp) on the host -> (results, done flags per pair)"""
+    L = hostsim(False)
+    L.hs_align_compact.restype = C.c_int
+    L.hs_align_compact.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.POINTER(Rec),
+                                   C.c_void_p, C.c_void_p]
+    n = len(reads)
+    arr = (C.c_char_p * n)(*reads)
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    recs = (Rec * max(n, 1))()
+    cig = np.zeros(max(n, 1), np.uint32)
+    done = np.zeros(max(n // 2, 1), np.int8)
+    rc = L.hs_align_compact(reference, len(reference), n, arr, lens, int(rc2), recs, cig.ctypes.data, done.ctypes.data)
+    assert rc == 0, rc
+    return records_to_results(recs, cig, n, True), done[:n // 2]
+
+
 def golden_cases(pmx):
     """(genome, {name: (reads, expected results)}) of tests/golden/align_golden.json.gz; the inputs are regenerated
     exactly as tests/golden/make_align_golden.py made them"""

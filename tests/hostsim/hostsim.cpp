@@ -12,6 +12,9 @@
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 #endif
 #include "align/aln_host.hpp"
+#ifndef PMX_HOSTSIM_TPP
+#include "align/aln_compact.hpp"
+#endif
 
 using namespace pmx::aln;
 
@@ -132,6 +135,65 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
 }
 
 #ifndef PMX_HOSTSIM_TPP
+// The compact tier (align/aln_compact.hpp) on the host: every pair goes through compact_map_pair with a plain array as
+// its "LDS"; done[i] = 1 when the tier finished pair i (its records are then final), 0 when it bailed (the general
+// tiers would run it).  rc2 != 0: mate 2 arrives in FASTQ orientation and is reverse-complemented on the fly.
+extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, const char** reads, const int* lens, int rc2, AlnRecord* recs,
+                                uint32_t* cigars, int8_t* done) {
+    int64_t total = 0;
+    int max_len = 0;
+    for (int i = 0; i < n_reads; ++i) { total += lens[i]; max_len = std::max(max_len, lens[i]); }
+    const int avg_len = n_reads > 0 ? (int)(total / n_reads) : 150;
+    Opt o = make_opt(avg_len);
+    HostRefIndex hri;
+    build_ref_index(ref, ref_len, o, std::max(4096, max_len * (o.a + 1) * 2 + 64), hri);
+    const RefIndex ri = hri.view();
+    std::vector<uint32_t> lds(PMX_C_LANE_WORDS + 8);
+    for (int it = 0; it < n_reads / 2; ++it) {
+        std::vector<uint64_t> w[2];
+        std::vector<uint32_t> am[2];
+        CRead rd[2];
+        const uint32_t* amb[2];
+        for (int s = 0; s < 2; ++s) {
+            const int idx = 2 * it + s, len = lens[idx];
+            w[s].assign((size_t)(len + 31) / 32 + 1, 0);
+            am[s].assign((size_t)(len + 31) / 32 + 1, 0);
+            for (int i = 0; i < len; ++i) {   // k_pack_reads (place_kernels.hip): A C G T -> 0 1 2 3, anything else ambiguous
+                const unsigned char ch = (unsigned char)reads[idx][i] & 0xDF;
+                const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+                const uint64_t code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : (ch == 'T' || ch == 'U') ? 3 : 0;
+                w[s][(size_t)(i >> 5)] |= code << (2 * (i & 31));
+                if (!acgt) am[s][(size_t)(i >> 5)] |= 1u << (i & 31);
+            }
+            rd[s].w = w[s].data();
+            rd[s].len = len;
+            rd[s].flip = rc2 && s == 1;
+            amb[s] = am[s].data();
+        }
+        std::fill(lds.begin(), lds.end(), 0xdeadbeefu);
+        CMem m{lds.data()};
+        CResult res;
+        const int rc = compact_map_pair(m, o, ri, rd, amb, res);
+        done[it] = rc == PMX_C_DONE ? 1 : 0;
+        for (int s = 0; s < 2; ++s) {
+            AlnRecord& rec = recs[2 * it + s];
+            memset(&rec, 0, sizeof(rec));
+            cigars[2 * it + s] = 0;
+            if (rc != PMX_C_DONE || !res.mapped) continue;
+            const CMate& t = res.m[s];
+            rec.mapped = 1;
+            rec.flags = PMX_REC_HAS_ALN;
+            rec.rs = t.rs; rec.re = t.re; rec.qs = t.qs; rec.qe = t.qe;
+            rec.mapq = t.mapq; rec.rev = t.rev; rec.proper_frag = t.proper_frag;
+            rec.n_cigar = 1;
+            rec.score = t.dp_max;
+            rec.cigar_off = (uint32_t)(2 * it + s);
+            cigars[2 * it + s] = t.cigar;
+        }
+    }
+    return 0;
+}
+
 // Property check of the DP shortcuts: random extension / gap-fill problems (small alphabets provoke repeats, which
 // is where a gapped path can rival the gap-free one); whenever ksw_shortcut answers, the full DP must give the
 // same consumed fields (max, max_t, max_q, mqe_t when reach_end, reach_end, score, zdropped, CIGAR).

@@ -12,13 +12,17 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default_tiers", "dp_service_forced", "wave_per_pair_only"])
+@pytest.fixture(autouse=True, params=["default_tiers", "compact_off", "dp_service_forced", "wave_per_pair_only"])
 def _tier_mode(request, monkeypatch):
-    """Every test of this module runs three times: with the library's own tier choice (thread-per-pair kernel, its
-    DP leftovers to the wave-per-pair tier when they are few), with the DP service + replay rounds forced for any number
-    of leftovers (PMX_ALIGN_TPP_MIN=0), and with every pair on the wave-per-pair kernels (PMX_ALIGN_NO_TPP=1): the
-    exact-parity cases cover all execution models and both DP kernels on the GPU."""
-    if request.param == "dp_service_forced":
+    """Every test of this module runs four times: with the library's own tier choice (compact LDS tier first, its bails
+    to the general thread-per-pair kernel, DP leftovers to the wave-per-pair tier when they are few), with the compact
+    tier off (every pair through the general thread-per-pair kernel), with the compact tier off and the DP service +
+    replay rounds forced for any number of leftovers (PMX_ALIGN_TPP_MIN=0), and with every pair on the wave-per-pair
+    kernels (PMX_ALIGN_NO_TPP=1): the exact-parity cases cover all execution models and both DP kernels on the GPU."""
+    if request.param == "compact_off":
+        monkeypatch.setenv("PMX_ALIGN_NO_COMPACT", "1")
+    elif request.param == "dp_service_forced":
+        monkeypatch.setenv("PMX_ALIGN_NO_COMPACT", "1")
         monkeypatch.setenv("PMX_ALIGN_TPP_MIN", "0")
     elif request.param == "wave_per_pair_only":
         monkeypatch.setenv("PMX_ALIGN_NO_TPP", "1")

@@ -88,3 +88,27 @@ def test_dp_shortcuts_against_the_dp_fuzz():
     declined, agreed, bad = counts[0], counts[1], counts[2]
     assert bad == 0, (declined, agreed, bad)
     assert agreed > 50000, (declined, agreed)
+
+
+def test_compact_tier_equals_reference(pmx, oracle, cases):
+    """the compact LDS tier (align/aln_compact.hpp): every pair it finishes carries exactly the reference's result, on
+    clean synthetic pairs (which it must finish nearly always), noisy ones, the real example reads and the indel / N
+    cases (which it must hand on); mate 2 reverse-complemented on the fly gives the same answers"""
+    g, sets = cases
+    concat, off = pmx.simulate_paired_reads(g, 6000, seed=5)
+    raw = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+    clean = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(raw)]
+    concat, off = pmx.simulate_paired_reads(g, 3000, seed=6, sub_rate=0.01)
+    noisy = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+    noisy = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(noisy)]
+    floors = {"clean": 0.97, "noisy": 0.80, "real": 0.25, "synthetic": 0.0}
+    for name, reads in (("clean", clean), ("noisy", noisy), ("real", sets["real"]), ("synthetic", sets["synthetic"])):
+        want = oracle.ref_align_reads_direct(g, reads, True, 8)
+        got, done = ac.hostsim_align_compact(g, reads)
+        idx = [i for i in range(len(want)) if done[i]]
+        bad = ac.compare_results([got[i] for i in idx], [want[i] for i in idx])
+        assert not bad, (name, bad[:10])
+        assert len(idx) >= floors[name] * len(want), (name, len(idx), len(want))
+    got_rc, done_rc = ac.hostsim_align_compact(g, raw, rc2=True)
+    got, done = ac.hostsim_align_compact(g, clean)
+    assert np.array_equal(done, done_rc) and not ac.compare_results(got_rc, got)
