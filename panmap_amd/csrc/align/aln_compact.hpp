@@ -406,8 +406,18 @@ PMX_HD int c_align1(const CMem& m, int base, const Opt& o, const RefIndex& ri, c
 }
 
 // The pair.  `in` = the two mates as packed by the host; `out` is only meaningful when PMX_C_DONE is returned.
-PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PMX_C_STAMP(k) do { if (prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
+#else
+#define PMX_C_STAMP(k) ((void)0)
+#endif
+// prof: NULL, or 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
+PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
+                             unsigned long long* prof = nullptr) {
     out.mapped = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long prof_t = prof ? (unsigned long long)clock64() : 0ULL;
+#endif
     const int k = o.k, w = o.w;
     const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
     if (qlen0 > PMX_C_MAXLEN || qlen1 > PMX_C_MAXLEN || qlen0 <= 0 || qlen1 <= 0 || w < 1 || w > 12 || 2 * k + 11 > 64 || k > 255 || !o.is_sr_like)
@@ -441,6 +451,7 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
             if (w <= 8) sketch_core<8>(r.len, w, k, 0, base_at, push);
             else sketch_core<12>(r.len, w, k, 0, base_at, push);
             if (ovf) return PMX_C_BAIL;
+            PMX_C_STAMP(0);
             const int sum = s ? qlen0 : 0;
             for (int i = 0; i < n_m; ++i) {
                 const uint64_t mi = m.M(i);
@@ -468,6 +479,7 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
                 prev_key = key;
                 have_prev = true;
             }
+            PMX_C_STAMP(1);
         }
     }
     if (n_s == 0) return PMX_C_DONE;   // no anchors: unmapped
@@ -523,6 +535,7 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
         }
     }
 
+    PMX_C_STAMP(2);
     // ---------------------------------------------------------------- chain fill (lchain.c:148-230) -> F
     int max_chain_gap_ref;
     if (o.max_gap_ref > 0) max_chain_gap_ref = o.max_gap_ref;
@@ -600,6 +613,7 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
         }
     }
 
+    PMX_C_STAMP(3);
     // ---------------------------------------------------------------- backtrack (lchain.c:27-76) -> V, up to two chains
     int n_u = 0;
     int32_t u_sc[2] = {0, 0}, u_cnt[2] = {0, 0};
@@ -648,6 +662,7 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
         }
     }
     if (n_u == 0) return PMX_C_DONE;   // unmapped
+    PMX_C_STAMP(4);
 
     // ---------------------------------------------------------------- chains -> one region per mate (hit.c:54-94, 345-400)
     // anchors of segment s in chain c; a mate followed here has exactly one chain (then regs0's parent / secondary logic
@@ -700,6 +715,7 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
         }
     }
 
+    PMX_C_STAMP(5);
     // ---------------------------------------------------------------- align each mate, filter, mapq (hit.c:301-322, 421-466)
     for (int s = 0; s < 2; ++s) {
         CReg& r = R[s];
@@ -728,6 +744,7 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
         if (r.dp_max > 0 && r.mapq == 0) r.mapq = 1;
     }
 
+    PMX_C_STAMP(6);
     // ---------------------------------------------------------------- pairing (pe.c:76-177) with one region per mate
     if (o.pe_ori >= 0) {
         const int sub_diff = o.a * 2 + o.b;
@@ -769,6 +786,7 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
         }
     }
 
+    PMX_C_STAMP(7);
     // ---------------------------------------------------------------- the record (src/mm_align.c:271-354)
     if (!(R[0].score > 0 && R[1].score > 0)) return PMX_C_DONE;
     out.mapped = 1;

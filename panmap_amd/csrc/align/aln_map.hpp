@@ -163,7 +163,7 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
 
     if (!W.mv_ready) collect_minimizers(W, o);
     PMX_STAMP(W, 1);
-    if (o.q_occ_frac > 0.0f && W.n_mv > o.mid_occ && o.mid_occ > 0) W.status |= PMX_ST_UNSUPPORTED;   // mm_seed_mz_flt (seed.c:5-26)
+    if (o.q_occ_frac > 0.0f) seed_mz_flt(W, o.mid_occ, o.q_occ_frac);   // map.c:251
     collect_seed_hits_heap(W, o, ri, qlen_sum, o.mid_occ);
     PMX_STAMP(W, 2);
 

@@ -4,6 +4,7 @@
 // (mm_seed_collect_all, mm_seed_select, mm_collect_matches), map.c:59-166 (collect_minimizers,
 // collect_seed_hits_heap).
 #pragma once
+#include "aln_sort.hpp"
 #include "aln_types.hpp"
 
 namespace pmx {
@@ -381,6 +382,44 @@ PMX_HD void collect_minimizers(Work& W, const Opt& o) {
         for (int j = n0; j < W.n_mv; ++j) mvp[j].y += (uint64_t)sum << 1;
         sum += W.qlen[s];
     }
+}
+
+// mm_seed_mz_flt (seed.c:5-26): a query with more than q_occ_max minimizers drops every minimizer VALUE that occurs in
+// it more than q_occ_max times and more than q_occ_frac of all (long reads through repeats).  Which copies go does not
+// depend on how the sort orders equal keys (whole groups go, survivors keep their order).  Scratch: W.a2 (idle here).
+PMX_HDN void seed_mz_flt(Work& W, int32_t q_occ_max, float q_occ_frac) {
+    PMX_LDS(&W);
+    const int n = W.n_mv;
+    if (n <= q_occ_max || q_occ_frac <= 0.0f || q_occ_max <= 0) return;
+    if (n > W.caps.max_anchor) { W.status |= PMX_ST_OVERFLOW; return; }
+    Ptr<A128> mv = W.mv; PMX_LDS(mv);
+    Ptr<A128> a = W.a2; PMX_LDS(a);
+    wave_sync();
+    for (int i = lane_id(); i < n; i += PMX_W) { A128 t; t.x = mv[i].x; t.y = (uint64_t)i; a[i] = t; }
+    wave_sync();
+    radix_sort_128x(a, a + n, &W.status);
+    wave_sync();
+    bool any = false;
+    for (int st = 0, i = 1; i <= n; ++i) {
+        if (i == n || a[i].x != a[st].x) {
+            const int32_t cnt = i - st;
+            if (cnt > q_occ_max && (float)cnt > (float)n * q_occ_frac) {
+                any = true;
+                for (int j = st; j < i; ++j) mv[(int)a[j].y].x = 0;
+            }
+            st = i;
+        }
+    }
+    wave_sync();
+    if (any) {
+        int j = 0;
+        for (int i = 0; i < n; ++i) {
+            const A128 t = mv[i];
+            if (t.x != 0) { mv[j] = t; ++j; }
+        }
+        W.n_mv = j;
+    }
+    wave_sync();
 }
 
 // mm_idx_get (index.c:81-99)

@@ -40,7 +40,10 @@ __global__ void __launch_bounds__(64) k_align_compact(AlignArgs A) {
                 rd[s].flip = A.revcomp_mate2 && s == 1;
                 amb[s] = A.amb + A.woff[r];
             }
-            rc = compact_map_pair(m, A.opt, A.ri, rd, amb, res);
+            unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            rc = compact_map_pair(m, A.opt, A.ri, rd, amb, res, A.prof ? pacc : nullptr);
+            if (A.prof && lane == 0)   // lane 0's stamps are the wave's phase timeline (diagnostic runs: PMX_ALIGN_PROF)
+                for (int k = 0; k < 8; ++k) atomicAdd(&A.prof[k], pacc[k]);
         }
         // bail list: one atomic per wave
         const bool bail = item >= 0 && rc != PMX_C_DONE;

@@ -344,6 +344,17 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 hipLaunchKernelGGL(k_align_compact, dim3((unsigned)c_grid), dim3(64), c_lds, ctx->stream, A);
                 PMX_HIP(hipGetLastError());
                 timer_end(ctx, "align_dom", 1);
+                if (A.prof) {   // the compact tier's own phase profile, then the accumulators start over for the general tiers
+                    unsigned long long h[8];
+                    PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+                    PMX_HIP(hipStreamSynchronize(ctx->stream));
+                    PMX_HIP(hipMemsetAsync(al->prof.p, 0, 24 * sizeof(unsigned long long), ctx->stream));
+                    static const char* cn[8] = {"sketch", "probes", "merge", "chain fill", "backtrack", "regions", "align+mapq", "pairing"};
+                    const double waves = (double)((n_items + 63) / 64);
+                    fprintf(stderr, "[pmx compact tier: cycles per wave (lane 0)]");
+                    for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.0f", cn[k], (double)h[k] / waves);
+                    fprintf(stderr, "\n");
+                }
                 unsigned long long h_bail = 0;
                 PMX_HIP(hipMemcpyAsync(&h_bail, al->retry_count.p + 2, sizeof(h_bail), hipMemcpyDeviceToHost, ctx->stream));
                 PMX_HIP(hipStreamSynchronize(ctx->stream));
