@@ -4,14 +4,15 @@
 // region records, byte-per-base sequences -- about 10 KB of work state per pair, which in the thread-per-pair kernel
 // lives in an HBM arena and is what that kernel moves (23-35 GB per launch of 500k pairs against 93 MB of input and
 // output, profiles/r01).  This tier restates the SAME decisions for the pairs that make up a short-read batch on a small
-// genome, with the state packed to 13 bytes per anchor:
+// genome, with the state packed to 7 bytes per anchor (9 when the reference is longer than 32,767 bases):
 //   * reads stay 2 bit/base where the host left them (no decode pass); mismatches against the reference come from
 //     XOR + popcount on 32-base words, once per mate and diagonal;
-//   * a minimizer is 8 bytes while it waits for its index probe, a seed 6 bytes (reference position word + query word),
-//     an anchor 6 bytes (strand | reference position, query position | segment | flags), a chain cell 2 bytes
-//     (score | predecessor), the merge heap 1 byte per entry;
-//   * 48 anchors per pair (99.2 % of 150 bp pairs; mean 40): 624 bytes per pair, interleaved word-wise across the 64
-//     lanes of a wave in LDS (conflict-free), 39 KB per wave;
+//   * a minimizer is 8 bytes while it waits for its index probe; a seed is a reference position word (2 or 4 bytes) and
+//     a query word (2 bytes) and BECOMES the anchor in place (the heap merge of map.c:102-166 runs on a heap of one-byte
+//     seed indices, its pop order is turned into destinations and the seeds are permuted along the cycles); a chain
+//     cell is 2 bytes (score | predecessor); chain members and per-mate anchor lists are one-byte indices;
+//   * 48 anchors per pair (99.2 % of 150 bp pairs; mean 40): 336 bytes per pair (432 with 32-bit positions),
+//     interleaved word-wise across the 64 lanes of a wave in LDS (conflict-free): 21 KB per wave, seven waves per CU;
 //   * regions are a handful of scalars in registers: at most one region per mate is followed.
 // Everything outside that envelope -- an ambiguous base, a seed that occurs twice in the reference, more than 48 seeds,
 // a third chain, two regions on one mate, an extension or gap fill the closed forms (aln_ksw.hpp, ksw_shortcut_*) do
@@ -47,31 +48,39 @@ typedef uint8_t c_u8;
 #define PMX_C_STRIDE 1
 #endif
 
-// one lane's 156 words; word i of lane l sits at base + i * 64 + l (device), so a wave touching word i of its 64
-// pairs touches 256 contiguous bytes of LDS
-struct CMem {
+// One lane's work memory; word i of lane l sits at base + i * 64 + l (device), so a wave touching word i of its 64
+// pairs touches 256 contiguous bytes of LDS.  PT = uint16_t when every reference position word fits 16 bits
+// (position << 1 | strand: references up to 32,767 bases), uint32_t otherwise.
+//   X  PT  [48]  seed: reference position word (position << 1 | strand)  ->  anchor x: strand << (bits-1) | position
+//   Y  u16 [48]  seed / anchor query word (PMX_CQ_*)
+//   G  u16 [48]  merge: destination of every seed | chain cells F | after the backtrack: per-mate anchor index lists
+//   B  u8  [48]  merge heap of seed indices, then its pop order | chain members in walk order
+//   M  u64 [..]  minimizers of one read waiting for their probes: overlays everything from word 0
+template <class PT>
+struct CMemT {
     c_u32* base;
+    static constexpr int kXH = 0;                                        // X in units of PT
+    static constexpr int kYH = (int)(sizeof(PT) / 2) * PMX_C_CAP;        // Y, G in halves
+    static constexpr int kGH = kYH + PMX_C_CAP;
+    static constexpr int kBB = 2 * (kGH + PMX_C_CAP);                    // B in bytes
+    static constexpr int kWords = (kBB + PMX_C_CAP + 3) / 4;
+    static constexpr int kMCap = kWords / 2 < PMX_C_MCAP ? kWords / 2 : PMX_C_MCAP;
+    static constexpr uint32_t kRevBit = 1u << (8 * sizeof(PT) - 1);
     PMX_HD c_u32& w(int i) const { return base[i * PMX_C_STRIDE]; }
     PMX_HD c_u16& h(int i) const { return ((c_u16*)(base + (i >> 1) * PMX_C_STRIDE))[i & 1]; }
     PMX_HD c_u8& b(int i) const { return ((c_u8*)(base + (i >> 2) * PMX_C_STRIDE))[i & 3]; }
-    // regions (never live together when they overlap):
-    //   words   0..47   P  seed: reference position word      | halves 0..47 F chain cells | SX per-mate anchor x
-    //   words  48..71   Q  seed: query word (u16)             | Z backtrack sort keys       | SY per-mate anchor y
-    //   words  72..119  AX anchor x                           | M minimizers of one read (u64 x 40: words 72..151)
-    //   words 120..143  AY anchor y (u16)
-    //   words 144..155  HI merge heap (u8)                    | V chain members in walk order
-    PMX_HD c_u32& P(int i) const { return w(i); }
-    PMX_HD c_u16& F(int i) const { return h(i); }
-    PMX_HD c_u32& SX(int i) const { return w(i); }
-    PMX_HD c_u16& Q(int i) const { return h(96 + i); }
-    PMX_HD c_u16& Z(int i) const { return h(96 + i); }
-    PMX_HD c_u16& SY(int i) const { return h(96 + i); }
-    PMX_HD c_u32& AX(int i) const { return w(72 + i); }
-    PMX_HD c_u16& AY(int i) const { return h(240 + i); }
-    PMX_HD c_u8& HI(int i) const { return b(576 + i); }
-    PMX_HD c_u8& V(int i) const { return b(576 + i); }
-    PMX_HD uint64_t M(int i) const { return (uint64_t)w(72 + 2 * i) | (uint64_t)w(73 + 2 * i) << 32; }
-    PMX_HD void setM(int i, uint64_t v) const { w(72 + 2 * i) = (uint32_t)v; w(73 + 2 * i) = (uint32_t)(v >> 32); }
+    PMX_HD uint32_t X(int i) const { return sizeof(PT) == 2 ? (uint32_t)h(i) : (uint32_t)w(i); }
+    PMX_HD void setX(int i, uint32_t v) const { if (sizeof(PT) == 2) h(i) = (c_u16)v; else w(i) = v; }
+    PMX_HD c_u16& Y(int i) const { return h(kYH + i); }
+    PMX_HD c_u16& G(int i) const { return h(kGH + i); }
+    PMX_HD c_u8& B(int i) const { return b(kBB + i); }
+    PMX_HD uint64_t M(int i) const { return (uint64_t)w(2 * i) | (uint64_t)w(2 * i + 1) << 32; }
+    PMX_HD void setM(int i, uint64_t v) const { w(2 * i) = (uint32_t)v; w(2 * i + 1) = (uint32_t)(v >> 32); }
+    // anchor x split: strand, reference position
+    PMX_HD static uint32_t rev_of(uint32_t x) { return x >> (8 * sizeof(PT) - 1); }
+    PMX_HD static uint32_t pos_of(uint32_t x) { return x & (kRevBit - 1u); }
+    // 64-bit anchor x as the reference holds it (strand in bit 63, one reference sequence: rid = 0)
+    PMX_HD static uint64_t x64(uint32_t x) { return (uint64_t)rev_of(x) << 63 | (uint64_t)pos_of(x); }
 };
 
 // query word of a seed / anchor: bits 0..9 position (seed: position << 1 | strand), 10 segment, 11 tandem, 12 ignore
@@ -181,13 +190,31 @@ struct CReg {
     int32_t cnt, score, rev, qs, qe, rs, re, mlen, blen, dp_score, dp_max, has_p, mapq, proper_frag, m_len;
 };
 
-// 64-bit anchor x as the reference holds it (strand in bit 63, one reference sequence: rid = 0)
-PMX_HD uint64_t c_x64(uint32_t ax) { return (uint64_t)(ax >> 31) << 63 | (uint64_t)(ax & 0x7fffffffu); }
+// does any lane of the wave that is still with us see `p`? (host: the one "lane")
+PMX_HD bool c_wave_any(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(p) != 0ULL;
+#else
+    return p;
+#endif
+}
+
+// The anchors of one mate's only region, in chain order: anchor i of the list = anchor G(base + i) of the pair, its query
+// position rebased to the mate (hit.c:381).  (x: reference position, y: query position; flags never survive into this
+// tier's regions -- a LONG_JOIN / IGNORE mark needs the bad-seed filters, which make the pair bail.)
+template <class PT>
+struct CList {
+    const CMemT<PT>& m;
+    int base, shift;
+    PMX_HD int32_t x(int i) const { return (int32_t)CMemT<PT>::pos_of(m.X((int)m.G(base + i))); }
+    PMX_HD int32_t y(int i) const { return (int32_t)(m.Y((int)m.G(base + i)) & 0x3ffu) - shift; }
+};
 
 // mm_cal_fuzzy_len + mm_reg_set_coor (hit.c:8-40) on a per-mate anchor list
-PMX_HD void c_reg_set_coor(const CMem& m, int base, CReg& r, int32_t qlen, int span) {
-    const int32_t x0 = (int32_t)(m.SX(base) & 0x7fffffffu), y0 = (int32_t)(m.SY(base) & 0x3ffu);
-    const int32_t xl = (int32_t)(m.SX(base + r.cnt - 1) & 0x7fffffffu), yl = (int32_t)(m.SY(base + r.cnt - 1) & 0x3ffu);
+template <class PT>
+PMX_HD void c_reg_set_coor(const CList<PT>& a, CReg& r, int32_t qlen, int span) {
+    const int32_t x0 = a.x(0), y0 = a.y(0);
+    const int32_t xl = a.x(r.cnt - 1), yl = a.y(r.cnt - 1);
     r.rs = x0 + 1 > span ? x0 + 1 - span : 0;
     r.re = xl + 1;
     if (!r.rev) { r.qs = y0 + 1 - span; r.qe = yl + 1; }
@@ -195,7 +222,7 @@ PMX_HD void c_reg_set_coor(const CMem& m, int base, CReg& r, int32_t qlen, int s
     r.mlen = r.blen = span;
     int32_t px = x0, py = y0;
     for (int i = 1; i < r.cnt; ++i) {
-        const int32_t x = (int32_t)(m.SX(base + i) & 0x7fffffffu), y = (int32_t)(m.SY(base + i) & 0x3ffu);
+        const int32_t x = a.x(i), y = a.y(i);
         const int tl = x - px, ql = y - py;
         r.blen += tl > ql ? tl : ql;
         r.mlen += tl > span && ql > span ? span : tl < ql ? tl : ql;
@@ -203,16 +230,16 @@ PMX_HD void c_reg_set_coor(const CMem& m, int base, CReg& r, int32_t qlen, int s
     }
 }
 
-// mm_fix_bad_ends (align.c:464-502) on a per-mate list (r.as == 0)
-PMX_HD void c_fix_bad_ends(const CMem& m, int base, const CReg& r, int span, int bw, int min_match, int32_t* as, int32_t* cnt) {
+// mm_fix_bad_ends (align.c:464-502) on a per-mate list (r.as == 0, no LONG_JOIN marks)
+template <class PT>
+PMX_HD void c_fix_bad_ends(const CList<PT>& a, const CReg& r, int span, int bw, int min_match, int32_t* as, int32_t* cnt) {
     *as = 0;
     *cnt = r.cnt;
     if (r.cnt < 3) return;
     int32_t mm_ = span, l = span;
     for (int32_t i = 1; i < r.cnt - 1; ++i) {
-        if (m.SY(base + i) & PMX_CQ_LONG_JOIN) break;
-        const int32_t lr = (int32_t)(m.SX(base + i) & 0x7fffffffu) - (int32_t)(m.SX(base + i - 1) & 0x7fffffffu);
-        const int32_t lq = (int32_t)(m.SY(base + i) & 0x3ffu) - (int32_t)(m.SY(base + i - 1) & 0x3ffu);
+        const int32_t lr = a.x(i) - a.x(i - 1);
+        const int32_t lq = a.y(i) - a.y(i - 1);
         const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
         if (mx - mn > l >> 1) *as = i;
         l += mn;
@@ -222,9 +249,8 @@ PMX_HD void c_fix_bad_ends(const CMem& m, int base, const CReg& r, int span, int
     *cnt = r.cnt - *as;
     mm_ = l = span;
     for (int32_t i = r.cnt - 2; i > *as; --i) {
-        if (m.SY(base + i + 1) & PMX_CQ_LONG_JOIN) break;
-        const int32_t lr = (int32_t)(m.SX(base + i + 1) & 0x7fffffffu) - (int32_t)(m.SX(base + i) & 0x7fffffffu);
-        const int32_t lq = (int32_t)(m.SY(base + i + 1) & 0x3ffu) - (int32_t)(m.SY(base + i) & 0x3ffu);
+        const int32_t lr = a.x(i + 1) - a.x(i);
+        const int32_t lq = a.y(i + 1) - a.y(i);
         const int32_t mn = lr < lq ? lr : lq, mx = lr > lq ? lr : lq;
         if (mx - mn > l >> 1) *cnt = i + 1 - *as;
         l += mn;
@@ -233,8 +259,8 @@ PMX_HD void c_fix_bad_ends(const CMem& m, int base, const CReg& r, int span, int
     }
 }
 
-// base readers for the (1c) probe of ksw_shortcut_ext_decide: position i of the extension = query base qa + qstep * i
-// of the mate (orientation `orient`) / reference base ta + qstep * i
+// base readers for the (1c) probe of ksw_shortcut_ext_decide: position i of the extension = query base at + step * i
+// of the mate (orientation `orient`) / reference base at + step * i
 struct CQryFn {
     const CRead& r;
     int orient, at, step;
@@ -249,7 +275,8 @@ struct CRefFn {
 // mm_align1 (align.c:575-833) for a region that is its mate's only one (as == 0, n_a == cnt): every extension / fill is
 // answered by the closed forms or the pair bails.  All three lie on the diagonal of the first kept anchor, so one
 // mismatch mask per mate serves them and the statistics pass.
-PMX_HD int c_align1(const CMem& m, int base, const Opt& o, const RefIndex& ri, const CRead& rd, int qlen, CReg& r) {
+template <class PT>
+PMX_HD int c_align1(const CList<PT>& al, const Opt& o, const RefIndex& ri, const CRead& rd, int qlen, CReg& r) {
     const int span = o.k;
     const int32_t rev = r.rev;
     const int32_t ref_len = ri.len;
@@ -257,25 +284,22 @@ PMX_HD int c_align1(const CMem& m, int base, const Opt& o, const RefIndex& ri, c
     int bw_long = (int)(o.bw_long * 1.5 + 1.);
     if (bw_long < bw) bw_long = bw;
     int32_t as1, cnt1;
-    c_fix_bad_ends(m, base, r, span, o.bw, o.min_chain_score * 2, &as1, &cnt1);
+    c_fix_bad_ends(al, r, span, o.bw, o.min_chain_score * 2, &as1, &cnt1);
     {   // mm_filter_bad_seeds / _alt (align.c:391-462) act only when two or more anchor steps change the diagonal by more
         // than 10 (their min_gap; the second filter's 30 is implied): not followed here
         int n_long = 0;
         for (int i = 1; i < cnt1; ++i) {
-            const int gap = ((int32_t)(m.SY(base + as1 + i) & 0x3ffu) - (int32_t)(m.SY(base + as1 + i - 1) & 0x3ffu)) -
-                            ((int32_t)(m.SX(base + as1 + i) & 0x7fffffffu) - (int32_t)(m.SX(base + as1 + i - 1) & 0x7fffffffu));
+            const int gap = (al.y(as1 + i) - al.y(as1 + i - 1)) - (al.x(as1 + i) - al.x(as1 + i - 1));
             if (gap < -10 || gap > 10) ++n_long;
         }
         if (n_long > 1) return PMX_C_BAIL;
     }
-    auto ax = [&](int i) { return (int32_t)(m.SX(base + i) & 0x7fffffffu); };
-    auto ay = [&](int i) { return (int32_t)(m.SY(base + i) & 0x3ffu); };
-    int32_t rs = ax(as1) - (o.k >> 1), qs = ay(as1) - (o.k >> 1);                           // mm_adjust_minier, non-HPC
-    int32_t re = ax(as1 + cnt1 - 1) - (o.k >> 1), qe = ay(as1 + cnt1 - 1) - (o.k >> 1);
+    int32_t rs = al.x(as1) - (o.k >> 1), qs = al.y(as1) - (o.k >> 1);                           // mm_adjust_minier, non-HPC
+    int32_t re = al.x(as1 + cnt1 - 1) - (o.k >> 1), qe = al.y(as1 + cnt1 - 1) - (o.k >> 1);
     int32_t l, rs0, re0, qs0, qe0, rs1, qs1, re1, qe1;
     // region to align (align.c:636-691); the region is the only one of its list: no neighbouring anchors to stop at
-    rs0 = ax(0) + 1 - span;
-    qs0 = ay(0) + 1 - span;
+    rs0 = al.x(0) + 1 - span;
+    qs0 = al.y(0) + 1 - span;
     if (rs0 < 0) rs0 = 0;
     rs1 = qs1 = 0;
     if (qs > 0 && rs > 0) {
@@ -289,8 +313,8 @@ PMX_HD int c_align1(const CMem& m, int base, const Opt& o, const RefIndex& ri, c
         rs0 = rs0 < rs1 ? rs0 : rs1;
         rs0 = rs0 < rs ? rs0 : rs;
     } else { rs0 = rs; qs0 = qs; }
-    re0 = ax(r.cnt - 1) + 1;
-    qe0 = ay(r.cnt - 1) + 1;
+    re0 = al.x(r.cnt - 1) + 1;
+    qe0 = al.y(r.cnt - 1) + 1;
     re1 = ref_len; qe1 = qlen;
     if (qe < qlen && re < ref_len) {
         l = qlen - qe < o.max_gap ? qlen - qe : o.max_gap;
@@ -346,7 +370,6 @@ PMX_HD int c_align1(const CMem& m, int base, const Opt& o, const RefIndex& ri, c
     // at the last kept anchor (flagged anchors are only skipped on the way)
     if (cnt1 > 1) {
         if (qlen >= o.min_ksw_len) return PMX_C_BAIL;
-        if (m.SY(base + as1 + cnt1 - 1) & PMX_CQ_LONG_JOIN) return PMX_C_BAIL;
         re1 = re; qe1 = qe;
         const int ql = qe - qs, tl = re - rs;
         if (!ksw_shortcut_applicable(ql, tl, a, b, gmin, bw_long) || !ksw_shortcut_is_fill(ql, tl, PMX_EZ_APPROX_MAX)) return PMX_C_BAIL;
@@ -405,15 +428,45 @@ PMX_HD int c_align1(const CMem& m, int base, const Opt& o, const RefIndex& ri, c
     return PMX_C_DONE;
 }
 
-// The pair.  `in` = the two mates as packed by the host; `out` is only meaningful when PMX_C_DONE is returned.
+// mm_filter_regs + mm_set_mapq (hit.c:301-322, 421-466) for a mate's lone primary without secondaries (the region is a
+// segment split, so the min_cnt test does not apply; subsc = n_sub = dp_max2 = 0, rep_len = 0).  PMX_C_DONE with
+// *kept = false: the region is filtered, i.e. the pair is unmapped.
+PMX_HD int c_filter_mapq(const Opt& o, const RefIndex& ri, int qlen, CReg& r, bool* kept) {
+    *kept = false;
+    bool flt = false;
+    if (r.mlen < o.min_chain_score) flt = true;
+    else if (r.dp_max < o.min_dp_max) flt = true;
+    else if (r.qs > qlen * o.max_clip_ratio && qlen - r.qe > qlen * o.max_clip_ratio) flt = true;
+    if (flt) return PMX_C_DONE;
+    if (qlen >= o.rank_min_len) return PMX_C_BAIL;
+    if (r.dp_max < 0 || r.dp_max >= ri.n_logf || r.score < 0 || r.score >= ri.n_logf) return PMX_C_BAIL;
+    const float uniq_ratio = (float)(int64_t)r.score / (float)((int64_t)r.score + 0);
+    const float pen_s1 = (r.score > 100 ? 1.0f : 0.01f * r.score) * uniq_ratio;
+    float pen_cm = r.cnt > 10 ? 1.0f : 0.1f * r.cnt;
+    pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
+    const int subsc = o.min_chain_score;   // max(r.subsc = 0, min_chain_sc)
+    const float x = (float)subsc / r.score;   // score0 == score
+    const float identity = (float)r.mlen / r.blen;
+    int mapq = (int)(identity * pen_cm * 40.0f * (1.0f - x) * ri.logf_ratio[r.dp_max]);
+    mapq -= (int)(4.343f * ri.logf_int[1] + .499f);
+    mapq = mapq > 0 ? mapq : 0;
+    r.mapq = mapq < 60 ? mapq : 60;
+    if (r.dp_max > 0 && r.mapq == 0) r.mapq = 1;
+    *kept = true;
+    return PMX_C_DONE;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PMX_C_STAMP(k) do { if (prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
 #else
 #define PMX_C_STAMP(k) ((void)0)
 #endif
+// The pair.  rd / amb = the two mates as packed by the host; `out` is only meaningful when PMX_C_DONE is returned.
 // prof: NULL, or 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
-PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
+template <class PT>
+PMX_HDN int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
                              unsigned long long* prof = nullptr) {
+    typedef CMemT<PT> MT;
     out.mapped = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long prof_t = prof ? (unsigned long long)clock64() : 0ULL;
@@ -422,121 +475,180 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
     const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
     if (qlen0 > PMX_C_MAXLEN || qlen1 > PMX_C_MAXLEN || qlen0 <= 0 || qlen1 <= 0 || w < 1 || w > 12 || 2 * k + 11 > 64 || k > 255 || !o.is_sr_like)
         return PMX_C_BAIL;
+    if (sizeof(PT) == 2 ? ri.len > 32767 : ri.len > 0x3fffffff) return PMX_C_BAIL;   // position << 1 | strand must fit PT
     for (int s = 0; s < 2; ++s)   // an ambiguous base anywhere: general tier
         for (int c = 0; c < (rd[s].len + 31) >> 5; ++c)
             if (amb[s][c]) return PMX_C_BAIL;
 
-    // ---------------------------------------------------------------- minimizers -> index probes -> seeds (P, Q)
+    // ---------------------------------------------------------------- minimizers -> index probes -> seeds (X, Y)
+    // Minimizers wait for their probes in a short queue that overlays G and B (18 entries); the whole wave drains its
+    // queues together -- four probes in flight per lane -- whenever some lane holds six (one base can add up to w), so the
+    // drain is a uniform branch and the seeds never need a staging copy of the minimizer list.  The newest entry stays
+    // queued until its right neighbour is known (the tandem mark compares adjacent minimizers, seed.c:40-46).
     int n_s = 0;
+    bool bail = false;
     {
+        constexpr int kQBase = (MT::kGH / 2 + 1) / 2;              // first M entry that lies above X and Y
+        constexpr int kQCap = MT::kWords / 2 - kQBase;             // 18
+        constexpr int kQDrain = kQCap - 12 > 1 ? kQCap - 12 : 1;   // drain threshold
+        static_assert(kQCap >= 14, "minimizer queue too short for one base's worth of pushes");
         bool have_prev = false;
         uint64_t prev_key = 0;
         int pending = -1;                 // seed of the previous read's last minimizer (its right neighbour is not known yet)
         for (int s = 0; s < 2; ++s) {
             const CRead& r = rd[s];
-            int n_m = 0;
-            bool ovf = false;
+            const int sum = s ? qlen0 : 0;
+            int n_q = 0;
+            bool first_of_read = true, ovf = false;
+            // entries [0, lim) of the queue -> seeds; final: the read is over, the last entry has no right neighbour here
+            auto drain = [&](bool final) {
+                const int lim = final ? n_q : n_q - 1;
+                for (int e0 = 0; c_wave_any(e0 < lim && !bail); e0 += 4) {
+                    uint64_t key[5];
+                    uint32_t yl[4], slot[4], pv[4];
+                    HtEnt e[4];
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) {
+                        const uint64_t mi = e0 + b < n_q ? m.M(kQBase + e0 + b) : 0ULL;
+                        key[b] = mi >> 11;
+                        if (b < 4) yl[b] = (uint32_t)mi & 0x7ffu;
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {   // mm_idx_get (index.c:81-99): first probes of four minimizers together
+                        slot[b] = (uint32_t)mix64(key[b]) & ri.ht_mask;
+                        e[b] = HtEnt{UINT64_MAX, 0u, 0u};
+                        pv[b] = 0;
+                        if (e0 + b < lim && !bail) { e[b] = ri.ht[slot[b]]; pv[b] = ri.ht_pv[slot[b]]; }
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (e0 + b >= lim || bail) break;
+                        while (e[b].key != key[b] && e[b].key != UINT64_MAX) {   // collision: keep probing
+                            slot[b] = (slot[b] + 1) & ri.ht_mask;
+                            e[b] = ri.ht[slot[b]];
+                            pv[b] = ri.ht_pv[slot[b]];
+                        }
+                        const uint32_t cnt = e[b].key == key[b] ? e[b].cnt : 0u;
+                        bool tandem = have_prev && key[b] == prev_key;
+                        if (first_of_read && tandem && pending >= 0) m.Y(pending) |= PMX_CQ_TANDEM;   // ... of the previous read's last one
+                        const bool has_next = e0 + b + 1 < n_q;
+                        if (has_next && key[b] == key[b + 1]) tandem = true;
+                        if (first_of_read) pending = -1;
+                        first_of_read = false;
+                        if (cnt > 1) { bail = true; break; }       // a repeated minimizer: general tier
+                        if (cnt == 1) {
+                            if (n_s >= PMX_C_CAP || (pv[b] >> (8 * sizeof(PT) - 1) >> 1) != 0u) { bail = true; break; }
+                            m.setX(n_s, pv[b]);
+                            m.Y(n_s) = (c_u16)((yl[b] + ((uint32_t)sum << 1)) | (s ? PMX_CQ_SEG : 0u) | (tandem ? PMX_CQ_TANDEM : 0u));
+                            pending = has_next ? -1 : n_s;   // (only the read's last minimizer has no right neighbour yet)
+                            ++n_s;
+                        } else if (!has_next) pending = -1;
+                        prev_key = key[b];
+                        have_prev = true;
+                    }
+                }
+                if (!final && n_q > 0 && lim >= 0) {   // the newest entry moves to the front
+                    const uint64_t last = m.M(kQBase + n_q - 1);
+                    m.setM(kQBase, last);
+                    n_q = 1;
+                } else if (final) n_q = 0;
+            };
             uint64_t cw = 0;
             int ck = -1;
             auto base_at = [&](int i) {
+                if (c_wave_any(n_q >= kQDrain)) drain(false);
                 const int j = r.flip ? r.len - 1 - i : i;
                 if ((j >> 5) != ck) { ck = j >> 5; cw = r.w[ck]; }
                 const int c = (int)(cw >> (2 * (j & 31))) & 3;
                 return r.flip ? 3 - c : c;
             };
             auto push = [&](uint64_t x, uint64_t y) {
-                if (n_m < PMX_C_MCAP) m.setM(n_m++, (x >> 8) << 11 | ((uint32_t)y & 0x7ffu));
+                if (n_q < kQCap) { m.setM(kQBase + n_q, (x >> 8) << 11 | ((uint32_t)y & 0x7ffu)); ++n_q; }
                 else ovf = true;
             };
             if (w <= 8) sketch_core<8>(r.len, w, k, 0, base_at, push);
             else sketch_core<12>(r.len, w, k, 0, base_at, push);
-            if (ovf) return PMX_C_BAIL;
             PMX_C_STAMP(0);
-            const int sum = s ? qlen0 : 0;
-            for (int i = 0; i < n_m; ++i) {
-                const uint64_t mi = m.M(i);
-                const uint64_t key = mi >> 11;
-                const uint32_t ylow = (uint32_t)mi & 0x7ffu;
-                bool tandem = have_prev && key == prev_key;
-                if (i == 0 && tandem && pending >= 0) m.Q(pending) |= PMX_CQ_TANDEM;   // ... of the previous read's last one
-                if (i + 1 < n_m && key == m.M(i + 1) >> 11) tandem = true;
-                // mm_idx_get (index.c:81-99)
-                uint32_t slot = (uint32_t)mix64(key) & ri.ht_mask;
-                HtEnt e = ri.ht[slot];
-                while (e.key != key && e.key != UINT64_MAX) { slot = (slot + 1) & ri.ht_mask; e = ri.ht[slot]; }
-                const uint32_t cnt = e.key == key ? e.cnt : 0u;
-                if (i == 0) pending = -1;
-                if (cnt > 1) return PMX_C_BAIL;       // a repeated minimizer: general tier
-                if (cnt == 1) {
-                    if (n_s >= PMX_C_CAP) return PMX_C_BAIL;
-                    const uint64_t pv = ri.pos[e.off];
-                    if (pv >> 32) return PMX_C_BAIL;
-                    m.P(n_s) = (uint32_t)pv;
-                    m.Q(n_s) = (c_u16)((ylow + ((uint32_t)sum << 1)) | (s ? PMX_CQ_SEG : 0u) | (tandem ? PMX_CQ_TANDEM : 0u));
-                    if (i == n_m - 1) pending = n_s;
-                    ++n_s;
-                } else if (i == n_m - 1) pending = -1;
-                prev_key = key;
-                have_prev = true;
-            }
+            if (ovf) bail = true;
+            drain(true);
             PMX_C_STAMP(1);
         }
     }
+    if (bail) return PMX_C_BAIL;
     if (n_s == 0) return PMX_C_DONE;   // no anchors: unmapped
 
-    // ---------------------------------------------------------------- heap merge -> anchors (AX, AY), map.c:102-166
+    // ---------------------------------------------------------------- heap merge (map.c:102-166) -> anchors in place
     const int n = n_s;
     {
-        for (int i = 0; i < n; ++i) m.HI(i) = (c_u8)i;
+        for (int i = 0; i < n; ++i) m.B(i) = (c_u8)i;
         auto heapdown = [&](int i, int sz) {   // ks_heapdown with "less" = larger reference position word (min-heap)
-            const uint32_t tmp = m.HI(i);
-            const uint32_t tk = m.P((int)tmp);
+            const uint32_t tmp = m.B(i);
+            const uint32_t tk = m.X((int)tmp);
             int kk;
             while ((kk = (i << 1) + 1) < sz) {
-                uint32_t ce = m.HI(kk);
-                uint32_t ckey = m.P((int)ce);
+                uint32_t ce = m.B(kk);
+                uint32_t ckey = m.X((int)ce);
                 if (kk != sz - 1) {
-                    const uint32_t c1 = m.HI(kk + 1);
-                    const uint32_t k1 = m.P((int)c1);
+                    const uint32_t c1 = m.B(kk + 1);
+                    const uint32_t k1 = m.X((int)c1);
                     if (ckey > k1) { ++kk; ce = c1; ckey = k1; }
                 }
                 if (ckey > tk) break;
-                m.HI(i) = (c_u8)ce;
+                m.B(i) = (c_u8)ce;
                 i = kk;
             }
-            m.HI(i) = (c_u8)tmp;
+            m.B(i) = (c_u8)tmp;
         };
         for (int q = (n >> 1) - 1; q >= 0; --q) heapdown(q, n);
-        int sz = n, n_for = 0, n_rev = 0;
-        while (sz > 0) {
-            const int si = (int)m.HI(0);
-            const uint32_t r = m.P(si);
-            const uint32_t qy = m.Q(si);
-            const uint32_t rpos = r >> 1, qp = qy & 0x3ffu;
-            const uint32_t fl = qy & (PMX_CQ_SEG | PMX_CQ_TANDEM);
-            if ((r & 1u) == (qp & 1u)) {
-                m.AX(n_for) = rpos;
-                m.AY(n_for) = (c_u16)((qp >> 1) | fl);
-                ++n_for;
-            } else {
-                ++n_rev;
-                m.AX(n - n_rev) = 0x80000000u | rpos;
-                m.AY(n - n_rev) = (c_u16)((uint32_t)(qlen_sum - ((int)(qp >> 1) + 1 - k) - 1) | fl);
-            }
-            const uint32_t last = m.HI(sz - 1);
+        // pops: the root leaves, the last element takes its place (every occurrence list has one entry), the slot the
+        // heap gave up keeps the popped seed -> B(n-1-t) = t-th seed out
+        int n_for = 0;
+        for (int sz = n; sz > 0;) {
+            const uint32_t si = m.B(0);
+            const uint32_t last = m.B(sz - 1);
             --sz;
-            if (sz > 0) { m.HI(0) = (c_u8)last; heapdown(0, sz); }
+            if (sz > 0) { m.B(0) = (c_u8)last; heapdown(0, sz); }
+            m.B(sz) = (c_u8)si;
+            n_for += ((m.X((int)si) ^ m.Y((int)si)) & 1u) ? 0 : 1;   // strand of the reference copy == strand of the query copy
         }
-        for (int j = 0; j < n_rev >> 1; ++j) {   // the reverse-strand block was filled back to front
-            const int p = n - 1 - j, q2 = n - n_rev + j;
-            const uint32_t tx = m.AX(p); const uint32_t ty = m.AY(p);
-            m.AX(p) = m.AX(q2); m.AY(p) = m.AY(q2);
-            m.AX(q2) = tx; m.AY(q2) = (c_u16)ty;
+        // destinations: forward-strand anchors first, in pop order, then the reverse-strand ones, in pop order
+        {
+            int df = 0, dr = n_for;
+            for (int t = 0; t < n; ++t) {
+                const int si = (int)m.B(n - 1 - t);
+                const bool fwd = ((m.X(si) ^ m.Y(si)) & 1u) == 0u;
+                m.G(si) = (c_u16)(fwd ? df : dr);
+                df += fwd ? 1 : 0;
+                dr += fwd ? 0 : 1;
+            }
+        }
+        // seeds -> anchors, moved along the cycles of the destination map (bit 15 of G: already placed)
+        auto to_anchor = [&](uint32_t pv, uint32_t qy, uint32_t* ax, uint32_t* ay) {
+            const uint32_t rpos = pv >> 1, qp = qy & 0x3ffu, fl = qy & (PMX_CQ_SEG | PMX_CQ_TANDEM);
+            if ((pv & 1u) == (qp & 1u)) { *ax = rpos; *ay = (qp >> 1) | fl; }
+            else { *ax = MT::kRevBit | rpos; *ay = (uint32_t)(qlen_sum - ((int)(qp >> 1) + 1 - k) - 1) | fl; }
+        };
+        for (int s0 = 0; s0 < n; ++s0) {
+            if (m.G(s0) & 0x8000u) continue;
+            uint32_t cx, cy;
+            to_anchor(m.X(s0), m.Y(s0), &cx, &cy);
+            int d = (int)m.G(s0);
+            m.G(s0) = (c_u16)(d | 0x8000);
+            while (d != s0) {
+                uint32_t nx, ny;
+                to_anchor(m.X(d), m.Y(d), &nx, &ny);
+                m.setX(d, cx); m.Y(d) = (c_u16)cy;
+                cx = nx; cy = ny;
+                const int d2 = (int)(m.G(d) & 0x7fffu);
+                m.G(d) = (c_u16)(d2 | 0x8000);
+                d = d2;
+            }
+            m.setX(s0, cx); m.Y(s0) = (c_u16)cy;
         }
     }
 
     PMX_C_STAMP(2);
-    // ---------------------------------------------------------------- chain fill (lchain.c:148-230) -> F
+    // ---------------------------------------------------------------- chain fill (lchain.c:148-230) -> F = G
     int max_chain_gap_ref;
     if (o.max_gap_ref > 0) max_chain_gap_ref = o.max_gap_ref;
     else if (o.max_frag_len > 0) {
@@ -551,28 +663,28 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
         if (max_dist_y < bw) max_dist_y = bw;
         const float gp = o.chn_pen_gap, sp = o.chn_pen_skip;
         int st = 0, max_ii = -1;
-        uint32_t ax_st = m.AX(0);
+        uint32_t ax_st = m.X(0);
         uint64_t x_mi = 0;
         int32_t f_mi = 0;
         for (int i = 0; i < n; ++i) {
-            const uint32_t axi = m.AX(i);
-            const uint32_t ayi = m.AY(i);
-            const uint64_t xi = c_x64(axi);
-            const uint32_t rpi = axi & 0x7fffffffu;
+            const uint32_t axi = m.X(i);
+            const uint32_t ayi = m.Y(i);
+            const uint64_t xi = MT::x64(axi);
+            const uint32_t rpi = MT::pos_of(axi);
             const int32_t qi = (int32_t)(ayi & 0x3ffu), sidi = (int32_t)(ayi >> 10 & 1u);
             int32_t max_f = k, n_skip = 0, mj = -1;
-            while (st < i && (((axi ^ ax_st) >> 31) != 0u || xi > c_x64(ax_st) + (uint64_t)max_dist_x)) {
+            while (st < i && (MT::rev_of(axi ^ ax_st) != 0u || xi > MT::x64(ax_st) + (uint64_t)max_dist_x)) {
                 ++st;
-                ax_st = st < i ? (uint32_t)m.AX(st) : axi;
+                ax_st = st < i ? m.X(st) : axi;
             }
             uint64_t mark = 0;   // bit (j - st): anchor j is the predecessor of an anchor already visited for this i
             int32_t ej = st - 1;
             bool stop = false;
             for (int32_t j = i - 1; j >= st && !stop; --j) {
-                const uint32_t axj = m.AX(j);
-                const uint32_t ayj = m.AY(j);
-                const uint32_t fj = m.F(j);
-                const int32_t sc0 = chain_score_sel(rpi, qi, sidi, axj & 0x7fffffffu, (int32_t)(ayj & 0x3ffu), (int32_t)(ayj >> 10 & 1u), k, max_dist_x,
+                const uint32_t axj = m.X(j);
+                const uint32_t ayj = m.Y(j);
+                const uint32_t fj = m.G(j);
+                const int32_t sc0 = chain_score_sel(rpi, qi, sidi, MT::pos_of(axj), (int32_t)(ayj & 0x3ffu), (int32_t)(ayj >> 10 & 1u), k, max_dist_x,
                                                     max_dist_y, bw, gp, sp, 2);
                 const bool valid = sc0 != INT32_MIN;
                 const int32_t sc = sc0 + (int32_t)(fj & 0x3ffu);
@@ -594,60 +706,57 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
                 int32_t mx = INT32_MIN;
                 max_ii = -1;
                 for (int32_t j = i - 1; j >= st; --j) {
-                    const int32_t fj = (int32_t)(m.F(j) & 0x3ffu);
+                    const int32_t fj = (int32_t)(m.G(j) & 0x3ffu);
                     if (mx < fj) { mx = fj; max_ii = j; }
                 }
-                if (max_ii >= 0) { x_mi = c_x64(m.AX(max_ii)); f_mi = mx; }
+                if (max_ii >= 0) { x_mi = MT::x64(m.X(max_ii)); f_mi = mx; }
             }
             if (max_ii >= 0 && max_ii < end_j) {
-                const uint32_t axm = m.AX(max_ii);
-                const uint32_t aym = m.AY(max_ii);
-                const int32_t tmp = chain_score_sel(rpi, qi, sidi, axm & 0x7fffffffu, (int32_t)(aym & 0x3ffu), (int32_t)(aym >> 10 & 1u), k, max_dist_x,
+                const uint32_t axm = m.X(max_ii);
+                const uint32_t aym = m.Y(max_ii);
+                const int32_t tmp = chain_score_sel(rpi, qi, sidi, MT::pos_of(axm), (int32_t)(aym & 0x3ffu), (int32_t)(aym >> 10 & 1u), k, max_dist_x,
                                                     max_dist_y, bw, gp, sp, 2);
-                const int32_t fm = (int32_t)(m.F(max_ii) & 0x3ffu);
+                const int32_t fm = (int32_t)(m.G(max_ii) & 0x3ffu);
                 if (tmp != INT32_MIN && max_f < tmp + fm) { max_f = tmp + fm; max_j = max_ii; }
             }
             if (max_f < 0 || max_f > 1023) return PMX_C_BAIL;
-            m.F(i) = (c_u16)((uint32_t)max_f | (uint32_t)(max_j + 1) << 10);
+            m.G(i) = (c_u16)((uint32_t)max_f | (uint32_t)(max_j + 1) << 10);
             if (max_ii < 0 || ((int64_t)(xi - x_mi) <= (int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = xi; f_mi = max_f; }
         }
     }
 
     PMX_C_STAMP(3);
-    // ---------------------------------------------------------------- backtrack (lchain.c:27-76) -> V, up to two chains
+    // ---------------------------------------------------------------- backtrack (lchain.c:27-76) -> B, up to two chains
+    // The reference sorts the chain ends by (score, index) and walks them from the top, skipping ends that a kept chain
+    // already uses: picking, each time, the largest (score, index) below the previous pick among the unused anchors is
+    // the same sequence without the sorted copy.
     int n_u = 0;
-    int32_t u_sc[2] = {0, 0}, u_cnt[2] = {0, 0};
+    int32_t u_sc0 = 0, u_sc1 = 0, u_cnt0 = 0, u_cnt1 = 0;
     {
-        int n_z = 0;
-        for (int i = 0; i < n; ++i) {
-            const uint32_t f = m.F(i) & 0x3ffu;
-            if ((int32_t)f >= min_sc) m.Z(n_z++) = (c_u16)(f << 6 | (uint32_t)i);
-        }
-        if (n_z == 0) return PMX_C_DONE;   // no chain: unmapped
-        for (int i = 1; i < n_z; ++i) {    // (score, index) ascending = the stable insertion sort of radix_sort_128x for n <= 64
-            const uint32_t t = m.Z(i);
-            if (t < m.Z(i - 1)) {
-                int j = i;
-                for (; j > 0 && t < m.Z(j - 1); --j) m.Z(j) = m.Z(j - 1);
-                m.Z(j) = (c_u16)t;
-            }
-        }
         uint64_t used = 0;
         int n_v = 0;
-        for (int kz = n_z - 1; kz >= 0; --kz) {
-            const uint32_t zk = m.Z(kz);
-            const int i0 = (int)(zk & 63u);
-            if (used >> i0 & 1ULL) continue;
-            const int32_t zx = (int32_t)(zk >> 6);
+        uint32_t below = 0xffffffffu;   // (score << 6 | index) of the previous pick
+        for (;;) {
+            uint32_t best = 0;
+            bool found = false;
+            for (int i = 0; i < n; ++i) {
+                const uint32_t f = m.G(i) & 0x3ffu;
+                const uint32_t key = f << 6 | (uint32_t)i;
+                if ((int32_t)f >= min_sc && key < below && !(used >> i & 1ULL) && (!found || key > best)) { best = key; found = true; }
+            }
+            if (!found) break;
+            below = best;
+            const int i0 = (int)(best & 63u);
+            const int32_t zx = (int32_t)(best >> 6);
             const int n_v0 = n_v;
             int i = i0;
             int32_t max_s = 0;
             uint64_t walk = 0, keep = 0;
             do {
                 walk |= 1ULL << i;
-                m.V(n_v0 + __builtin_popcountll(walk) - 1) = (c_u8)i;
-                i = (int)(m.F(i) >> 10) - 1;
-                const int32_t s = i < 0 ? zx : zx - (int32_t)(m.F(i) & 0x3ffu);
+                m.B(n_v0 + __builtin_popcountll(walk) - 1) = (c_u8)i;
+                i = (int)(m.G(i) >> 10) - 1;
+                const int32_t s = i < 0 ? zx : zx - (int32_t)(m.G(i) & 0x3ffu);
                 if (s > max_s) { max_s = s; keep = walk; }
                 else if (max_s - s > max_drop) break;
             } while (i >= 0 && !(used >> i & 1ULL));
@@ -656,7 +765,8 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
             n_v = n_v0 + cnt;
             if (max_s >= min_sc && cnt > 0 && cnt >= min_cnt) {
                 if (n_u >= 2) return PMX_C_BAIL;   // a third chain: general tier
-                u_sc[n_u] = max_s; u_cnt[n_u] = cnt;
+                if (n_u == 0) { u_sc0 = max_s; u_cnt0 = cnt; }
+                else { u_sc1 = max_s; u_cnt1 = cnt; }
                 ++n_u;
             } else n_v = n_v0;
         }
@@ -668,134 +778,91 @@ PMX_HDN int compact_map_pair(const CMem& m, const Opt& o, const RefIndex& ri, co
     // anchors of segment s in chain c; a mate followed here has exactly one chain (then regs0's parent / secondary logic
     // has nothing to decide: the chains of different mates do not overlap on the fragment), a mate without anchors makes
     // the pair unmapped whatever the other one does
-    int cs[2][2] = {{0, 0}, {0, 0}};
+    int c00 = 0, c01 = 0, c10 = 0, c11 = 0;   // c<chain><segment>
+    for (int j = 0; j < u_cnt0; ++j) { const uint32_t sg = (m.Y((int)m.B(j)) >> 10) & 1u; c00 += sg ? 0 : 1; c01 += sg ? 1 : 0; }
+    for (int j = 0; j < u_cnt1; ++j) { const uint32_t sg = (m.Y((int)m.B(u_cnt0 + j)) >> 10) & 1u; c10 += sg ? 0 : 1; c11 += sg ? 1 : 0; }
+    if ((c00 == 0 && c10 == 0) || (c01 == 0 && c11 == 0)) return PMX_C_DONE;   // a mate without a region: unmapped
+    if ((c00 > 0 && c10 > 0) || (c01 > 0 && c11 > 0)) return PMX_C_BAIL;        // a mate with two regions
+    // per-mate anchor index lists in G (the chain cells are dead): mate 0 from 0, mate 1 behind it, ascending = the
+    // chain walked backwards
+    CReg R0, R1;
+    int base1;
     {
-        int off = 0;
-        for (int c = 0; c < n_u; ++c) {
-            for (int j = 0; j < u_cnt[c]; ++j) ++cs[c][(m.AY((int)m.V(off + j)) >> 10) & 1u];
-            off += u_cnt[c];
-        }
-    }
-    int chain_of[2];
-    for (int s = 0; s < 2; ++s) {
-        const int nreg = (cs[0][s] > 0) + (cs[1][s] > 0);
-        if (nreg == 0) return PMX_C_DONE;   // unmapped
-        chain_of[s] = cs[0][s] > 0 ? 0 : 1;
-    }
-    for (int s = 0; s < 2; ++s)
-        if ((cs[0][s] > 0) + (cs[1][s] > 0) > 1) return PMX_C_BAIL;
-    CReg R[2];
-    int base[2];
-    {
-        // per-mate lists (ascending = the chain walked backwards), y rebased to the mate (hit.c:381)
         int wr = 0;
+#pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int c = chain_of[s];
-            const int off = c ? u_cnt[0] : 0;
-            base[s] = wr;
-            int rev = 0;
-            for (int j = u_cnt[c] - 1; j >= 0; --j) {
-                const int ai = (int)m.V(off + j);
-                const uint32_t ay = m.AY(ai);
-                if ((int)((ay >> 10) & 1u) != s) continue;
-                const uint32_t ax = m.AX(ai);
-                rev = (int)(ax >> 31);
-                const int ql = s ? qlen1 : qlen0, acc = s ? qlen0 : 0;
-                const int shift = rev ? qlen_sum - (ql + acc) : acc;
-                m.SX(wr) = ax;
-                m.SY(wr) = (c_u16)(((ay & 0x3ffu) - (uint32_t)shift) | (ay & ~0x7ffu));   // position rebased, flags kept, segment dropped
-                ++wr;
+            const bool from1 = s == 0 ? c00 == 0 : c01 == 0;   // the mate's chain
+            const int off = from1 ? u_cnt0 : 0, cnt_c = from1 ? u_cnt1 : u_cnt0;
+            if (s == 1) base1 = wr;
+            uint32_t rev = 0;
+            for (int j = cnt_c - 1; j >= 0; --j) {
+                const int ai = (int)m.B(off + j);
+                if ((int)((m.Y(ai) >> 10) & 1u) != s) continue;
+                rev = MT::rev_of(m.X(ai));
+                m.G(wr++) = (c_u16)ai;
             }
-            CReg& r = R[s];
-            r.cnt = cs[c][s];
-            r.score = u_sc[c];
-            r.rev = rev;
+            CReg& r = s == 0 ? R0 : R1;
+            r.cnt = s == 0 ? (from1 ? c10 : c00) : (from1 ? c11 : c01);
+            r.score = from1 ? u_sc1 : u_sc0;
+            r.rev = (int32_t)rev;
             r.has_p = 0; r.dp_score = r.dp_max = 0; r.mapq = 0; r.proper_frag = 0; r.m_len = 0;
-            c_reg_set_coor(m, base[s], r, s ? qlen1 : qlen0, k);
         }
     }
+    const CList<PT> L0{m, 0, R0.rev ? qlen_sum - qlen0 : 0};                     // hit.c:381: rev ? qlen_sum - (ql + acc) : acc
+    const CList<PT> L1{m, base1, R1.rev ? qlen_sum - (qlen1 + qlen0) : qlen0};
+    c_reg_set_coor(L0, R0, qlen0, k);
+    c_reg_set_coor(L1, R1, qlen1, k);
 
     PMX_C_STAMP(5);
-    // ---------------------------------------------------------------- align each mate, filter, mapq (hit.c:301-322, 421-466)
-    for (int s = 0; s < 2; ++s) {
-        CReg& r = R[s];
-        const int qlen = s ? qlen1 : qlen0;
-        if (c_align1(m, base[s], o, ri, rd[s], qlen, r) != PMX_C_DONE) return PMX_C_BAIL;
-        // mm_filter_regs (the region is a segment split: the min_cnt test does not apply)
-        bool flt = false;
-        if (r.mlen < o.min_chain_score) flt = true;
-        else if (r.dp_max < o.min_dp_max) flt = true;
-        else if (r.qs > qlen * o.max_clip_ratio && qlen - r.qe > qlen * o.max_clip_ratio) flt = true;
-        if (flt) return PMX_C_DONE;   // the mate loses its only region: unmapped pair
-        if (qlen >= o.rank_min_len) return PMX_C_BAIL;
-        // mm_set_mapq for a lone primary without secondaries (subsc = n_sub = dp_max2 = 0, rep_len = 0)
-        if (r.dp_max < 0 || r.dp_max >= ri.n_logf || r.score < 0 || r.score >= ri.n_logf) return PMX_C_BAIL;
-        const float uniq_ratio = (float)(int64_t)r.score / (float)((int64_t)r.score + 0);
-        const float pen_s1 = (r.score > 100 ? 1.0f : 0.01f * r.score) * uniq_ratio;
-        float pen_cm = r.cnt > 10 ? 1.0f : 0.1f * r.cnt;
-        pen_cm = pen_s1 < pen_cm ? pen_s1 : pen_cm;
-        const int subsc = o.min_chain_score;   // max(r.subsc = 0, min_chain_sc)
-        const float x = (float)subsc / r.score;   // score0 == score
-        const float identity = (float)r.mlen / r.blen;
-        int mapq = (int)(identity * pen_cm * 40.0f * (1.0f - x) * ri.logf_ratio[r.dp_max]);
-        mapq -= (int)(4.343f * ri.logf_int[1] + .499f);
-        mapq = mapq > 0 ? mapq : 0;
-        r.mapq = mapq < 60 ? mapq : 60;
-        if (r.dp_max > 0 && r.mapq == 0) r.mapq = 1;
+    // ---------------------------------------------------------------- align each mate, filter, mapq
+    {
+        bool kept;
+        if (c_align1(L0, o, ri, rd[0], qlen0, R0) != PMX_C_DONE) return PMX_C_BAIL;
+        if (c_filter_mapq(o, ri, qlen0, R0, &kept) != PMX_C_DONE) return PMX_C_BAIL;
+        if (!kept) return PMX_C_DONE;   // the mate loses its only region: unmapped pair
+        if (c_align1(L1, o, ri, rd[1], qlen1, R1) != PMX_C_DONE) return PMX_C_BAIL;
+        if (c_filter_mapq(o, ri, qlen1, R1, &kept) != PMX_C_DONE) return PMX_C_BAIL;
+        if (!kept) return PMX_C_DONE;
     }
 
     PMX_C_STAMP(6);
     // ---------------------------------------------------------------- pairing (pe.c:76-177) with one region per mate
+    // Two entries sorted by key = rs << 1 | (segment ^ rev) (ties keep mate 0 first).  The scan pairs the SECOND entry with
+    // the first iff the first is a "left" end (key bit 0 clear), the second a "right" end on the same strand, the gap
+    // between them at most max_gap_ref and their DP scores reach the threshold; with one candidate the pair's mapq is the
+    // larger of the two, floored at 2.
     if (o.pe_ori >= 0) {
-        const int sub_diff = o.a * 2 + o.b;
-        (void)sub_diff;
-        uint64_t key[2];
-        int ps[2] = {0, 1};
-        for (int s = 0; s < 2; ++s) key[s] = (uint64_t)(uint32_t)(R[s].rs << 1) | (uint32_t)(s ^ R[s].rev);
-        int dp_thres = R[0].dp_max + R[1].dp_max - o.pe_bonus;
+        const uint64_t key0 = (uint64_t)(uint32_t)(R0.rs << 1) | (uint32_t)(0 ^ R0.rev), key1 = (uint64_t)(uint32_t)(R1.rs << 1) | (uint32_t)(1 ^ R1.rev);
+        int dp_thres = R0.dp_max + R1.dp_max - o.pe_bonus;
         if (dp_thres < 0) dp_thres = 0;
-        if (key[1] < key[0]) { const uint64_t t = key[0]; key[0] = key[1]; key[1] = t; ps[0] = 1; ps[1] = 0; }
-        int64_t mx = -1;
-        int n_sc = 0;
-        int last[2] = {-1, -1};
-        for (int i = 0; i < 2; ++i) {
-            const CReg& ri_ = R[ps[i]];
-            const int rev_i = ri_.rev;
-            if (key[i] & 1) {   // reverse first read or forward second read
-                if (last[rev_i] < 0) continue;
-                const CReg* q = &R[ps[last[rev_i]]];
-                if (ri_.rs - q->re > max_chain_gap_ref) continue;
-                for (int j = last[rev_i]; j >= 0; --j) {
-                    q = &R[ps[j]];
-                    if (q->rev != rev_i || ps[j] == ps[i]) continue;
-                    if (ri_.rs - q->re > max_chain_gap_ref) break;
-                    if (ri_.dp_max + q->dp_max < dp_thres) continue;
-                    const int64_t score = (int64_t)(ri_.dp_max + q->dp_max) << 32;   // (+ hash sum: only ranks several candidates)
-                    if (score > mx) mx = score;
-                    ++n_sc;
-                }
-            } else last[rev_i] = i;
-        }
-        if (n_sc > 0 && mx > 0) {   // one candidate pair: n_sc == 1
-            R[0].proper_frag = R[1].proper_frag = 1;
-            const int mapq_pe = R[0].mapq > R[1].mapq ? R[0].mapq : R[1].mapq;
-            if (R[0].mapq < mapq_pe) R[0].mapq = (int)(.2f * R[0].mapq + .8f * mapq_pe + .499f);
-            if (R[1].mapq < mapq_pe) R[1].mapq = (int)(.2f * R[1].mapq + .8f * mapq_pe + .499f);
-            if (R[0].mapq < 2) R[0].mapq = 2;
-            if (R[1].mapq < 2) R[1].mapq = 2;
+        const bool swap = key1 < key0;
+        const CReg& A_ = swap ? R1 : R0;
+        const CReg& B_ = swap ? R0 : R1;
+        const uint64_t ka = swap ? key1 : key0, kb = swap ? key0 : key1;
+        const bool proper = !(ka & 1ULL) && (kb & 1ULL) && A_.rev == B_.rev && !(B_.rs - A_.re > max_chain_gap_ref) &&
+                            !(B_.dp_max + A_.dp_max < dp_thres) && ((int64_t)(B_.dp_max + A_.dp_max) << 32) > 0;
+        if (proper) {
+            R0.proper_frag = R1.proper_frag = 1;
+            const int mapq_pe = R0.mapq > R1.mapq ? R0.mapq : R1.mapq;
+            if (R0.mapq < mapq_pe) R0.mapq = (int)(.2f * R0.mapq + .8f * mapq_pe + .499f);
+            if (R1.mapq < mapq_pe) R1.mapq = (int)(.2f * R1.mapq + .8f * mapq_pe + .499f);
+            if (R0.mapq < 2) R0.mapq = 2;
+            if (R1.mapq < 2) R1.mapq = 2;
         }
     }
 
     PMX_C_STAMP(7);
     // ---------------------------------------------------------------- the record (src/mm_align.c:271-354)
-    if (!(R[0].score > 0 && R[1].score > 0)) return PMX_C_DONE;
+    if (!(R0.score > 0 && R1.score > 0)) return PMX_C_DONE;
     out.mapped = 1;
+#pragma unroll
     for (int s = 0; s < 2; ++s) {
+        const CReg& r = s == 0 ? R0 : R1;
         CMate& t = out.m[s];
-        t.rs = R[s].rs; t.re = R[s].re; t.qs = R[s].qs; t.qe = R[s].qe;
-        t.dp_max = R[s].dp_max;
-        t.cigar = (uint32_t)R[s].m_len << 4;
-        t.mapq = (uint8_t)R[s].mapq; t.rev = (uint8_t)R[s].rev; t.proper_frag = (uint8_t)R[s].proper_frag; t.has_aln = 1;
+        t.rs = r.rs; t.re = r.re; t.qs = r.qs; t.qe = r.qe;
+        t.dp_max = r.dp_max;
+        t.cigar = (uint32_t)r.m_len << 4;
+        t.mapq = (uint8_t)r.mapq; t.rev = (uint8_t)r.rev; t.proper_frag = (uint8_t)r.proper_frag; t.has_aln = 1;
     }
     return PMX_C_DONE;
 }

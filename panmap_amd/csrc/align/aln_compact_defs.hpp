@@ -4,4 +4,6 @@
 #define PMX_C_MCAP 40           // minimizers of one read waiting for their probes
 #define PMX_C_NW 5              // 32-base words per read: reads up to 160 bases
 #define PMX_C_MAXLEN (32 * PMX_C_NW)
-#define PMX_C_LANE_WORDS 156    // 624 bytes per pair
+// LDS words per pair (CMemT<PT>::kWords): X (PT) + Y (u16) + G (u16) + B (u8), 48 entries each
+#define PMX_C_LANE_WORDS16 84    // 336 bytes: reference position words of 16 bits
+#define PMX_C_LANE_WORDS32 108   // 432 bytes

@@ -78,6 +78,7 @@ struct HostRefIndex {
     std::vector<uint64_t> pos;
     std::vector<float> logf_ratio, logf_int;
     std::vector<uint64_t> pk, pk_amb;   // RefIndex::pk / pk_amb
+    std::vector<uint32_t> ht_pv;        // RefIndex::ht_pv
     std::vector<uint32_t> occ;   // occurrences per distinct minimizer
     int logf_a = 0;              // match score the logf tables were built for
     RefIndex view() const {
@@ -92,6 +93,7 @@ struct HostRefIndex {
         r.n_logf = (int32_t)logf_int.size();
         r.pk = pk.data();
         r.pk_amb = pk_amb.data();
+        r.ht_pv = ht_pv.data();
         return r;
     }
 };
@@ -167,6 +169,7 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
     size_t cap = 16;
     while (cap < n_keys * 2 + 2) cap <<= 1;
     out.ht.assign(cap, HtEnt{UINT64_MAX, 0u, 0u});
+    out.ht_pv.assign(cap, 0xffffffffu);
     out.pos.resize(mv.size());
     for (size_t i = 0; i < mv.size();) {
         size_t j = i;
@@ -176,6 +179,7 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
         uint32_t slot = (uint32_t)mix64(key) & (uint32_t)(cap - 1);
         while (out.ht[slot].key != UINT64_MAX) slot = (slot + 1) & (uint32_t)(cap - 1);
         out.ht[slot] = HtEnt{key, (uint32_t)i, (uint32_t)(j - i)};
+        if (j - i == 1 && (mv[i].y >> 32) == 0) out.ht_pv[slot] = (uint32_t)mv[i].y;
         out.occ.push_back((uint32_t)(j - i));
         i = j;
     }

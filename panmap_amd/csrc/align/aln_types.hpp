@@ -265,6 +265,9 @@ struct RefIndex {
     // (bit 2(j % 32) of word k set when base j is not A/C/G/T): what the compact tier XORs packed reads against
     const uint64_t* pk;
     const uint64_t* pk_amb;
+    // per table slot: the low 32 bits of the ONLY occurrence's position word (cnt == 1), so that a probe of a unique
+    // minimizer needs no second, dependent load from pos[]
+    const uint32_t* ht_pv;
 };
 
 // chain-DP state of one anchor (f, p, t, v of mg_lchain_dp, lchain.c:148-230) as ONE 16-byte cell: the inner

@@ -67,7 +67,8 @@ __global__ void k_align_reads_t1(AlignArgs A);
 __global__ void k_align_reads_t1_w4(AlignArgs A);
 __global__ void k_align_reads_tpp(AlignArgs A);
 __global__ void k_align_dp_serve(AlignArgs A);
-__global__ void k_align_compact(AlignArgs A);   // retry_list / retry_count = its bail list
+__global__ void k_align_compact16(AlignArgs A);   // retry_list / retry_count = its bail list; reference <= 32,767 bases
+__global__ void k_align_compact32(AlignArgs A);
 
 // bytes of the traceback matrix ksw_extd2 needs for a request (same n_col as ksw2_extd2_sse.c:95-98)
 PMX_HD size_t dp_request_tb_bytes(int qlen, int tlen, int w) {

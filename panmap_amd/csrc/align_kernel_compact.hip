@@ -1,5 +1,6 @@
-// ALIGN stage, compact tier kernel for gfx950: THREAD per read pair, the pair's whole work state in LDS (624 bytes,
-// word-interleaved across the wave: 39 KB per wave, four waves per CU) and registers -- align/aln_compact.hpp.
+// ALIGN stage, compact tier kernel for gfx950: THREAD per read pair, the pair's whole work state in LDS (336 bytes,
+// word-interleaved across the wave: 21 KB per wave, seven waves per CU; 432 bytes / five waves when the reference is
+// longer than 32,767 bases) and registers -- align/aln_compact.hpp.
 // It takes every pair of the batch first.  A pair it finishes has its records written here; a pair outside the tier's
 // envelope is appended to the bail list and run by the general thread-per-pair kernel (align_kernel_tpp.hip) and its
 // DP service.  HBM traffic per pair: the packed read words in (38 B per 150 bp read, + the ambiguity words), index /
@@ -15,10 +16,12 @@
 namespace pmx {
 namespace aln {
 
-__global__ void __launch_bounds__(64) k_align_compact(AlignArgs A) {
+template <class PT>
+__device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t c_lds[];
     const int lane = (int)(threadIdx.x & 63u);
-    CMem m;
+    CMemT<PT> m;
+    static_assert(CMemT<PT>::kWords == (sizeof(PT) == 2 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32), "LDS size the host launches with");
     m.base = (c_u32*)c_lds + lane;
     const int64_t n_threads = (int64_t)gridDim.x * 64;
     // every lane of the wave runs the same number of iterations (arena and bail-list slots are claimed once per wave)
@@ -91,6 +94,9 @@ __global__ void __launch_bounds__(64) k_align_compact(AlignArgs A) {
         }
     }
 }
+
+__global__ void __launch_bounds__(64) k_align_compact16(AlignArgs A) { align_compact_body<uint16_t>(A); }
+__global__ void __launch_bounds__(64) k_align_compact32(AlignArgs A) { align_compact_body<uint32_t>(A); }
 
 }  // namespace aln
 }  // namespace pmx

@@ -29,6 +29,7 @@ struct pmx_aligner {
     DevBuf<HtEnt> d_ht;
     DevBuf<float> d_logf_ratio, d_logf_int;
     DevBuf<uint64_t> d_pk, d_pk_amb;
+    DevBuf<uint32_t> d_ht_pv;
     RefIndex ri;
     int mean_len = 150;
     // last result
@@ -105,6 +106,7 @@ int pmx_aligner_set_reference(pmx_ctx* ctx, pmx_aligner* al, const char* referen
     upload(al->d_logf_int, al->host.logf_int, ctx->stream);
     upload(al->d_pk, al->host.pk, ctx->stream);
     upload(al->d_pk_amb, al->host.pk_amb, ctx->stream);
+    upload(al->d_ht_pv, al->host.ht_pv, ctx->stream);
     RefIndex& r = al->ri;
     r.seq = al->d_seq.p;
     r.len = (int32_t)ref_len;
@@ -116,6 +118,7 @@ int pmx_aligner_set_reference(pmx_ctx* ctx, pmx_aligner* al, const char* referen
     r.n_logf = (int32_t)al->host.logf_int.size();
     r.pk = al->d_pk.p;
     r.pk_amb = al->d_pk_amb.p;
+    r.ht_pv = al->d_ht_pv.p;
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
     PMX_CATCH
@@ -332,8 +335,9 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
             if (use_compact) {
                 al->bail_list.ensure((size_t)n_items);
-                const size_t c_lds = (size_t)PMX_C_LANE_WORDS * 64 * sizeof(uint32_t);
-                PMX_HIP(hipFuncSetAttribute((const void*)k_align_compact, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c_lds));
+                const bool pos16 = al->ri.len <= 32767 && !getenv("PMX_ALIGN_COMPACT_POS32");
+                auto c_kern = pos16 ? k_align_compact16 : k_align_compact32;
+                const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t);
                 int c_waves = (int)((size_t)(160 * 1024) / c_lds);
                 if (const char* e = getenv("PMX_ALIGN_COMPACT_WAVES")) c_waves = atoi(e);
                 const int64_t c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(c_waves, 1), (n_items + 63) / 64);
@@ -341,7 +345,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 A.pair_perm = order;
                 A.retry_list = al->bail_list.p;
                 A.retry_count = al->retry_count.p + 2;
-                hipLaunchKernelGGL(k_align_compact, dim3((unsigned)c_grid), dim3(64), c_lds, ctx->stream, A);
+                hipLaunchKernelGGL(c_kern, dim3((unsigned)c_grid), dim3(64), c_lds, ctx->stream, A);
                 PMX_HIP(hipGetLastError());
                 timer_end(ctx, "align_dom", 1);
                 if (A.prof) {   // the compact tier's own phase profile, then the accumulators start over for the general tiers

@@ -148,7 +148,7 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
     HostRefIndex hri;
     build_ref_index(ref, ref_len, o, std::max(4096, max_len * (o.a + 1) * 2 + 64), hri);
     const RefIndex ri = hri.view();
-    std::vector<uint32_t> lds(PMX_C_LANE_WORDS + 8);
+    std::vector<uint32_t> lds(CMemT<uint32_t>::kWords + 8);
     for (int it = 0; it < n_reads / 2; ++it) {
         std::vector<uint64_t> w[2];
         std::vector<uint32_t> am[2];
@@ -171,9 +171,10 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
             amb[s] = am[s].data();
         }
         std::fill(lds.begin(), lds.end(), 0xdeadbeefu);
-        CMem m{lds.data()};
         CResult res;
-        const int rc = compact_map_pair(m, o, ri, rd, amb, res);
+        int rc;
+        if (ref_len <= 32767 && !getenv("PMX_HS_COMPACT_POS32")) { CMemT<uint16_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res); }
+        else { CMemT<uint32_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res); }
         done[it] = rc == PMX_C_DONE ? 1 : 0;
         for (int s = 0; s < 2; ++s) {
             AlnRecord& rec = recs[2 * it + s];
