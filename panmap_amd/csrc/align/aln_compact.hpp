@@ -190,6 +190,7 @@ struct CReg {
     int32_t cnt, score, rev, qs, qe, rs, re, mlen, blen, dp_score, dp_max, has_p, mapq, proper_frag, m_len;
 };
 
+#define PMX_LAMBDA_INLINE __attribute__((always_inline))
 // does any lane of the wave that is still with us see `p`? (host: the one "lane")
 PMX_HD bool c_wave_any(bool p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -456,6 +457,100 @@ PMX_HD int c_filter_mapq(const Opt& o, const RefIndex& ri, int qlen, CReg& r, bo
     return PMX_C_DONE;
 }
 
+// Minimizers -> index probes -> seeds, one read at a time.  The object is BOTH functors of sketch_core: operator()(i)
+// hands out base i (and is where the wave drains its queues: it runs once per base in every lane), operator()(x, y)
+// queues a minimizer.  Minimizers wait for their probes in a short queue that overlays G and B (18 entries); the whole
+// wave drains its queues together -- four probes in flight per lane -- whenever some lane holds six (one base can add
+// up to w), so the drain is a uniform branch and the seeds never need a staging copy of the minimizer list.  The newest
+// entry stays queued until its right neighbour is known (the tandem mark compares adjacent minimizers, seed.c:40-46).
+template <class PT>
+struct CSeeder {
+    typedef CMemT<PT> MT;
+    static constexpr int kQBase = (MT::kGH / 2 + 1) / 2;              // first M entry that lies above X and Y
+    static constexpr int kQCap = MT::kWords / 2 - kQBase;             // 18
+    static constexpr int kQDrain = kQCap - 12 > 1 ? kQCap - 12 : 1;   // drain threshold
+    static_assert(kQCap >= 14, "minimizer queue too short for one base's worth of pushes");
+    const MT& m;
+    const RefIndex& ri;
+    CRead r;
+    int seg, sum;          // segment, summed length of the segments before it
+    int n_q, n_s;          // queue fill, seeds so far (both reads)
+    bool first_of_read, ovf, bail, have_prev;
+    uint64_t prev_key;
+    int pending;           // seed of the previous read's last minimizer (its right neighbour is not known yet)
+    uint64_t cw;
+    int ck;
+
+    // entries [0, lim) of the queue -> seeds; final: the read is over, the last entry has no right neighbour here
+    PMX_HD void drain(bool final) {
+        const int lim = final ? n_q : n_q - 1;
+        for (int e0 = 0; c_wave_any(e0 < lim && !bail); e0 += 4) {
+            uint64_t key[5];
+            uint32_t yl[4], slot[4], pv[4];
+            HtEnt e[4];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const uint64_t mi = e0 + b < n_q ? m.M(kQBase + e0 + b) : 0ULL;
+                key[b] = mi >> 11;
+                if (b < 4) yl[b] = (uint32_t)mi & 0x7ffu;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {   // mm_idx_get (index.c:81-99): first probes of four minimizers together
+                slot[b] = (uint32_t)mix64(key[b]) & ri.ht_mask;
+                e[b] = HtEnt{UINT64_MAX, 0u, 0u};
+                pv[b] = 0;
+                if (e0 + b < lim && !bail) { e[b] = ri.ht[slot[b]]; pv[b] = ri.ht_pv[slot[b]]; }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool live = e0 + b < lim && !bail;
+                if (live) {
+                    while (e[b].key != key[b] && e[b].key != UINT64_MAX) {   // collision: keep probing
+                        slot[b] = (slot[b] + 1) & ri.ht_mask;
+                        e[b] = ri.ht[slot[b]];
+                        pv[b] = ri.ht_pv[slot[b]];
+                    }
+                    const uint32_t cnt = e[b].key == key[b] ? e[b].cnt : 0u;
+                    bool tandem = have_prev && key[b] == prev_key;
+                    if (first_of_read && tandem && pending >= 0) m.Y(pending) |= PMX_CQ_TANDEM;   // ... of the previous read's last one
+                    const bool has_next = e0 + b + 1 < n_q;
+                    if (has_next && key[b] == key[b + 1]) tandem = true;
+                    if (first_of_read) pending = -1;
+                    first_of_read = false;
+                    if (cnt > 1) bail = true;                      // a repeated minimizer: general tier
+                    else if (cnt == 1) {
+                        if (n_s >= PMX_C_CAP || (pv[b] >> (8 * sizeof(PT) - 1) >> 1) != 0u) bail = true;
+                        else {
+                            m.setX(n_s, pv[b]);
+                            m.Y(n_s) = (c_u16)((yl[b] + ((uint32_t)sum << 1)) | (seg ? PMX_CQ_SEG : 0u) | (tandem ? PMX_CQ_TANDEM : 0u));
+                            pending = has_next ? -1 : n_s;   // (only the read's last minimizer has no right neighbour yet)
+                            ++n_s;
+                        }
+                    } else if (!has_next) pending = -1;
+                    prev_key = key[b];
+                    have_prev = true;
+                }
+            }
+        }
+        if (!final && n_q > 0) {   // the newest entry moves to the front
+            const uint64_t last = m.M(kQBase + n_q - 1);
+            m.setM(kQBase, last);
+            n_q = 1;
+        } else if (final) n_q = 0;
+    }
+    PMX_HD int operator()(int i) {   // base i of the read in the orientation the aligner sees
+        if (c_wave_any(n_q >= kQDrain)) drain(false);
+        const int j = r.flip ? r.len - 1 - i : i;
+        if ((j >> 5) != ck) { ck = j >> 5; cw = r.w[ck]; }
+        const int c = (int)(cw >> (2 * (j & 31))) & 3;
+        return r.flip ? 3 - c : c;
+    }
+    PMX_HD void operator()(uint64_t x, uint64_t y) {   // a minimizer
+        if (n_q < kQCap) { m.setM(kQBase + n_q, (x >> 8) << 11 | ((uint32_t)y & 0x7ffu)); ++n_q; }
+        else ovf = true;
+    }
+};
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PMX_C_STAMP(k) do { if (prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
 #else
@@ -464,7 +559,7 @@ PMX_HD int c_filter_mapq(const Opt& o, const RefIndex& ri, int qlen, CReg& r, bo
 // The pair.  rd / amb = the two mates as packed by the host; `out` is only meaningful when PMX_C_DONE is returned.
 // prof: NULL, or 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
 template <class PT>
-PMX_HDN int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
+PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
                              unsigned long long* prof = nullptr) {
     typedef CMemT<PT> MT;
     out.mapped = 0;
@@ -481,99 +576,23 @@ PMX_HDN int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& r
             if (amb[s][c]) return PMX_C_BAIL;
 
     // ---------------------------------------------------------------- minimizers -> index probes -> seeds (X, Y)
-    // Minimizers wait for their probes in a short queue that overlays G and B (18 entries); the whole wave drains its
-    // queues together -- four probes in flight per lane -- whenever some lane holds six (one base can add up to w), so the
-    // drain is a uniform branch and the seeds never need a staging copy of the minimizer list.  The newest entry stays
-    // queued until its right neighbour is known (the tandem mark compares adjacent minimizers, seed.c:40-46).
-    int n_s = 0;
-    bool bail = false;
+    CSeeder<PT> sd{m, ri};
+    sd.n_s = 0; sd.bail = false; sd.have_prev = false; sd.prev_key = 0; sd.pending = -1;
     {
-        constexpr int kQBase = (MT::kGH / 2 + 1) / 2;              // first M entry that lies above X and Y
-        constexpr int kQCap = MT::kWords / 2 - kQBase;             // 18
-        constexpr int kQDrain = kQCap - 12 > 1 ? kQCap - 12 : 1;   // drain threshold
-        static_assert(kQCap >= 14, "minimizer queue too short for one base's worth of pushes");
-        bool have_prev = false;
-        uint64_t prev_key = 0;
-        int pending = -1;                 // seed of the previous read's last minimizer (its right neighbour is not known yet)
+        const CRead r0 = rd[0], r1 = rd[1];
         for (int s = 0; s < 2; ++s) {
-            const CRead& r = rd[s];
-            const int sum = s ? qlen0 : 0;
-            int n_q = 0;
-            bool first_of_read = true, ovf = false;
-            // entries [0, lim) of the queue -> seeds; final: the read is over, the last entry has no right neighbour here
-            auto drain = [&](bool final) {
-                const int lim = final ? n_q : n_q - 1;
-                for (int e0 = 0; c_wave_any(e0 < lim && !bail); e0 += 4) {
-                    uint64_t key[5];
-                    uint32_t yl[4], slot[4], pv[4];
-                    HtEnt e[4];
-#pragma unroll
-                    for (int b = 0; b < 5; ++b) {
-                        const uint64_t mi = e0 + b < n_q ? m.M(kQBase + e0 + b) : 0ULL;
-                        key[b] = mi >> 11;
-                        if (b < 4) yl[b] = (uint32_t)mi & 0x7ffu;
-                    }
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {   // mm_idx_get (index.c:81-99): first probes of four minimizers together
-                        slot[b] = (uint32_t)mix64(key[b]) & ri.ht_mask;
-                        e[b] = HtEnt{UINT64_MAX, 0u, 0u};
-                        pv[b] = 0;
-                        if (e0 + b < lim && !bail) { e[b] = ri.ht[slot[b]]; pv[b] = ri.ht_pv[slot[b]]; }
-                    }
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        if (e0 + b >= lim || bail) break;
-                        while (e[b].key != key[b] && e[b].key != UINT64_MAX) {   // collision: keep probing
-                            slot[b] = (slot[b] + 1) & ri.ht_mask;
-                            e[b] = ri.ht[slot[b]];
-                            pv[b] = ri.ht_pv[slot[b]];
-                        }
-                        const uint32_t cnt = e[b].key == key[b] ? e[b].cnt : 0u;
-                        bool tandem = have_prev && key[b] == prev_key;
-                        if (first_of_read && tandem && pending >= 0) m.Y(pending) |= PMX_CQ_TANDEM;   // ... of the previous read's last one
-                        const bool has_next = e0 + b + 1 < n_q;
-                        if (has_next && key[b] == key[b + 1]) tandem = true;
-                        if (first_of_read) pending = -1;
-                        first_of_read = false;
-                        if (cnt > 1) { bail = true; break; }       // a repeated minimizer: general tier
-                        if (cnt == 1) {
-                            if (n_s >= PMX_C_CAP || (pv[b] >> (8 * sizeof(PT) - 1) >> 1) != 0u) { bail = true; break; }
-                            m.setX(n_s, pv[b]);
-                            m.Y(n_s) = (c_u16)((yl[b] + ((uint32_t)sum << 1)) | (s ? PMX_CQ_SEG : 0u) | (tandem ? PMX_CQ_TANDEM : 0u));
-                            pending = has_next ? -1 : n_s;   // (only the read's last minimizer has no right neighbour yet)
-                            ++n_s;
-                        } else if (!has_next) pending = -1;
-                        prev_key = key[b];
-                        have_prev = true;
-                    }
-                }
-                if (!final && n_q > 0 && lim >= 0) {   // the newest entry moves to the front
-                    const uint64_t last = m.M(kQBase + n_q - 1);
-                    m.setM(kQBase, last);
-                    n_q = 1;
-                } else if (final) n_q = 0;
-            };
-            uint64_t cw = 0;
-            int ck = -1;
-            auto base_at = [&](int i) {
-                if (c_wave_any(n_q >= kQDrain)) drain(false);
-                const int j = r.flip ? r.len - 1 - i : i;
-                if ((j >> 5) != ck) { ck = j >> 5; cw = r.w[ck]; }
-                const int c = (int)(cw >> (2 * (j & 31))) & 3;
-                return r.flip ? 3 - c : c;
-            };
-            auto push = [&](uint64_t x, uint64_t y) {
-                if (n_q < kQCap) { m.setM(kQBase + n_q, (x >> 8) << 11 | ((uint32_t)y & 0x7ffu)); ++n_q; }
-                else ovf = true;
-            };
-            if (w <= 8) sketch_core<8>(r.len, w, k, 0, base_at, push);
-            else sketch_core<12>(r.len, w, k, 0, base_at, push);
+            sd.r.w = s ? r1.w : r0.w; sd.r.len = s ? r1.len : r0.len; sd.r.flip = s ? r1.flip : r0.flip;
+            sd.seg = s; sd.sum = s ? qlen0 : 0;
+            sd.n_q = 0; sd.first_of_read = true; sd.ovf = false; sd.cw = 0; sd.ck = -1;
+            sketch_core<12>(sd.r.len, w, k, 0, sd, sd);
             PMX_C_STAMP(0);
-            if (ovf) bail = true;
-            drain(true);
+            if (sd.ovf) sd.bail = true;
+            sd.drain(true);
             PMX_C_STAMP(1);
         }
     }
+    const int n_s = sd.n_s;
+    const bool bail = sd.bail;
     if (bail) return PMX_C_BAIL;
     if (n_s == 0) return PMX_C_DONE;   // no anchors: unmapped
 
@@ -581,7 +600,7 @@ PMX_HDN int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& r
     const int n = n_s;
     {
         for (int i = 0; i < n; ++i) m.B(i) = (c_u8)i;
-        auto heapdown = [&](int i, int sz) {   // ks_heapdown with "less" = larger reference position word (min-heap)
+        auto heapdown = [&](int i, int sz) PMX_LAMBDA_INLINE {   // ks_heapdown with "less" = larger reference position word (min-heap)
             const uint32_t tmp = m.B(i);
             const uint32_t tk = m.X((int)tmp);
             int kk;
@@ -623,7 +642,7 @@ PMX_HDN int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& r
             }
         }
         // seeds -> anchors, moved along the cycles of the destination map (bit 15 of G: already placed)
-        auto to_anchor = [&](uint32_t pv, uint32_t qy, uint32_t* ax, uint32_t* ay) {
+        auto to_anchor = [&](uint32_t pv, uint32_t qy, uint32_t* ax, uint32_t* ay) PMX_LAMBDA_INLINE {
             const uint32_t rpos = pv >> 1, qp = qy & 0x3ffu, fl = qy & (PMX_CQ_SEG | PMX_CQ_TANDEM);
             if ((pv & 1u) == (qp & 1u)) { *ax = rpos; *ay = (qp >> 1) | fl; }
             else { *ax = MT::kRevBit | rpos; *ay = (uint32_t)(qlen_sum - ((int)(qp >> 1) + 1 - k) - 1) | fl; }
