@@ -56,6 +56,41 @@ typedef uint8_t c_u8;
 //   G  u16 [48]  merge: destination of every seed | chain cells F | after the backtrack: per-mate anchor index lists
 //   B  u8  [48]  merge heap of seed indices, then its pop order | chain members in walk order
 //   M  u64 [..]  minimizers of one read waiting for their probes: overlays everything from word 0
+// Chain gap penalties by diagonal difference (lchain.c:113-141 with chn_pen_skip == 0): the two float expressions of
+// comput_sc depend on dd alone, so a wave tabulates them once per kernel (exactly as chain_score_sel evaluates them) and the
+// fill reads a byte instead of doing ~25 VALU operations per anchor pair.  same[dd] = (int)(gp*dd + .5f*log2(dd+1)),
+// diff[dd] = (int)min(gp*dd, log2(dd+1)); dd == 0 -> 0.
+struct CPenTab {
+    const c_u8* same;   // NULL: no tables (evaluate arithmetically)
+    const c_u8* diff;
+};
+PMX_HD void c_pen_values(float gp, int dd, int* same, int* diff) {
+    const float lin_pen = gp * (float)dd;
+    const float log_pen = dd >= 1 ? mg_log2f((float)((uint32_t)dd + 1u)) : 0.0f;
+    const float ps = lin_pen + .5f * log_pen, pd = lin_pen < log_pen ? lin_pen : log_pen;
+    *same = (int)ps;
+    *diff = (int)pd;
+}
+
+// comput_sc (lchain.c:113-141) for two segments with the float penalties read from the tables; same integer
+// expressions as chain_score_sel, values of rejected pairs are discarded
+PMX_HD int32_t c_chain_score_tab(const CPenTab& T, uint32_t xi, int32_t yi, int32_t sidi, uint32_t xj, int32_t yj, int32_t sidj, int32_t q_span,
+                                 int32_t max_dist_x, int32_t max_dist_y, int32_t bw) {
+    const int32_t dq = yi - yj;
+    const int32_t dr = (int32_t)(xi - xj);
+    const bool same = sidi == sidj;
+    const int32_t dd = dr > dq ? dr - dq : dq - dr;
+    bool bad = dq <= 0 || dq > max_dist_x;
+    bad = bad || (same && (dr == 0 || dq > max_dist_y || dd > bw || dr > max_dist_y));
+    const int32_t dg = dr < dq ? dr : dq;
+    const int32_t sc = q_span < dg ? q_span : dg;
+    const int32_t lim = same ? PMX_C_PEN_SAME - 1 : PMX_C_PEN_DIFF - 1;
+    const int32_t ddc = dd < lim ? dd : lim;                 // (only rejected pairs can exceed the tables)
+    const int32_t pen = same ? (int32_t)T.same[ddc] : (int32_t)T.diff[ddc];
+    const int32_t r = (!same && dr == 0) ? sc + 1 : sc - pen;   // overlapping paired ends (lchain.c:135)
+    return bad ? INT32_MIN : r;
+}
+
 template <class PT>
 struct CMemT {
     c_u32* base;
@@ -560,7 +595,7 @@ struct CSeeder {
 // prof: NULL, or 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
 template <class PT>
 PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
-                             unsigned long long* prof = nullptr) {
+                             const CPenTab& pen_tab, unsigned long long* prof = nullptr) {
     typedef CMemT<PT> MT;
     out.mapped = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -681,6 +716,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
         if (max_dist_x < bw) max_dist_x = bw;
         if (max_dist_y < bw) max_dist_y = bw;
         const float gp = o.chn_pen_gap, sp = o.chn_pen_skip;
+        const bool use_tab = pen_tab.same != nullptr && sp == 0.0f && bw < PMX_C_PEN_SAME && max_dist_x < PMX_C_PEN_DIFF;   // uniform
         int st = 0, max_ii = -1;
         uint32_t ax_st = m.X(0);
         uint64_t x_mi = 0;
@@ -703,8 +739,10 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
                 const uint32_t axj = m.X(j);
                 const uint32_t ayj = m.Y(j);
                 const uint32_t fj = m.G(j);
-                const int32_t sc0 = chain_score_sel(rpi, qi, sidi, MT::pos_of(axj), (int32_t)(ayj & 0x3ffu), (int32_t)(ayj >> 10 & 1u), k, max_dist_x,
-                                                    max_dist_y, bw, gp, sp, 2);
+                const int32_t sc0 = use_tab ? c_chain_score_tab(pen_tab, rpi, qi, sidi, MT::pos_of(axj), (int32_t)(ayj & 0x3ffu), (int32_t)(ayj >> 10 & 1u), k,
+                                                                max_dist_x, max_dist_y, bw)
+                                            : chain_score_sel(rpi, qi, sidi, MT::pos_of(axj), (int32_t)(ayj & 0x3ffu), (int32_t)(ayj >> 10 & 1u), k, max_dist_x,
+                                                              max_dist_y, bw, gp, sp, 2);
                 const bool valid = sc0 != INT32_MIN;
                 const int32_t sc = sc0 + (int32_t)(fj & 0x3ffu);
                 const bool better = valid && sc > max_f;

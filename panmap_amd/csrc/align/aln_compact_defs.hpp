@@ -7,3 +7,7 @@
 // LDS words per pair (CMemT<PT>::kWords): X (PT) + Y (u16) + G (u16) + B (u8), 48 entries each
 #define PMX_C_LANE_WORDS16 84    // 336 bytes: reference position words of 16 bits
 #define PMX_C_LANE_WORDS32 108   // 432 bytes
+// gap-penalty tables of the chain fill, per wave (aln_compact.hpp CPenTab)
+#define PMX_C_PEN_SAME 128
+#define PMX_C_PEN_DIFF 1024
+#define PMX_C_PEN_BYTES (PMX_C_PEN_SAME + PMX_C_PEN_DIFF)

@@ -21,6 +21,17 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t c_lds[];
     const int lane = (int)(threadIdx.x & 63u);
     CMemT<PT> m;
+    // gap-penalty tables behind the lanes' work memory (see CPenTab): 1152 bytes per wave
+    c_u8* pen = (c_u8*)((c_u32*)c_lds + CMemT<PT>::kWords * 64);
+    CPenTab tab;
+    tab.same = pen; tab.diff = pen + PMX_C_PEN_SAME;
+    for (int dd = lane; dd < PMX_C_PEN_DIFF; dd += 64) {
+        int ps, pd;
+        c_pen_values(A.opt.chn_pen_gap, dd, &ps, &pd);
+        if (dd < PMX_C_PEN_SAME) pen[dd] = (uint8_t)(ps < 255 ? ps : 255);
+        pen[PMX_C_PEN_SAME + dd] = (uint8_t)(pd < 255 ? pd : 255);
+    }
+    __syncthreads();
     static_assert(CMemT<PT>::kWords == (sizeof(PT) == 2 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32), "LDS size the host launches with");
     m.base = (c_u32*)c_lds + lane;
     const int64_t n_threads = (int64_t)gridDim.x * 64;
@@ -44,7 +55,7 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
                 amb[s] = A.amb + A.woff[r];
             }
             unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            rc = compact_map_pair(m, A.opt, A.ri, rd, amb, res, A.prof ? pacc : nullptr);
+            rc = compact_map_pair(m, A.opt, A.ri, rd, amb, res, tab, A.prof ? pacc : nullptr);
             if (A.prof && lane == 0)   // lane 0's stamps are the wave's phase timeline (diagnostic runs: PMX_ALIGN_PROF)
                 for (int k = 0; k < 8; ++k) atomicAdd(&A.prof[k], pacc[k]);
         }

@@ -337,7 +337,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 al->bail_list.ensure((size_t)n_items);
                 const bool pos16 = al->ri.len <= 32767 && !getenv("PMX_ALIGN_COMPACT_POS32");
                 auto c_kern = pos16 ? k_align_compact16 : k_align_compact32;
-                const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t);
+                const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
                 int c_waves = (int)((size_t)(160 * 1024) / c_lds);
                 if (const char* e = getenv("PMX_ALIGN_COMPACT_WAVES")) c_waves = atoi(e);
                 const int64_t c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(c_waves, 1), (n_items + 63) / 64);
@@ -368,12 +368,17 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 A.retry_list = al->retry_list2.p;
                 A.retry_count = al->retry_count.p;
             }
+            // Few bails: a thread-per-pair launch that small cannot fill the chip and lasts as long as a full one (a wave
+            // takes ~2 ms whatever the grid); the wave-per-pair tier runs them instead.
+            int64_t bail_tpp_min = 32768;
+            if (const char* e = getenv("PMX_ALIGN_BAIL_TPP_MIN")) bail_tpp_min = atoll(e);
+            const bool skip_t0 = use_compact && n_t0 < bail_tpp_min;
             A.pair_perm = order;
-            if (n_t0 > 0) launch_tpp(0, n_t0, nullptr, nullptr);
+            if (n_t0 > 0 && !skip_t0) launch_tpp(0, n_t0, nullptr, nullptr);
             A.pair_perm = nullptr;
             if (!use_compact) timer_end(ctx, "align_dom", 1);
             int64_t n_dp = 0;
-            read_counts(n_t1, n_dp, false);
+            if (!skip_t0) read_counts(n_t1, n_dp, false);
             n_dp = std::min<int64_t>(n_dp, (int64_t)A.dp_slot_cap);
             al->last_dp_slots = n_dp;
             const uint32_t* cur = nullptr;   // round 1 serves slots 0..n_dp-1
@@ -429,6 +434,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             A.dp_slot_pairs = nullptr;
             PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
             t1_list = al->retry_list2.p;
+            if (skip_t0) { t1_list = al->bail_list.p; n_t1 = n_t0; }
             al->last_tpp_retry = n_t1;
         }
         int64_t n_retry = 0, unused = 0;

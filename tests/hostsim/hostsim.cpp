@@ -149,6 +149,15 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
     build_ref_index(ref, ref_len, o, std::max(4096, max_len * (o.a + 1) * 2 + 64), hri);
     const RefIndex ri = hri.view();
     std::vector<uint32_t> lds(CMemT<uint32_t>::kWords + 8);
+    std::vector<uint8_t> pen(PMX_C_PEN_BYTES);
+    for (int dd = 0; dd < PMX_C_PEN_DIFF; ++dd) {
+        int ps, pd;
+        c_pen_values(o.chn_pen_gap, dd, &ps, &pd);
+        if (dd < PMX_C_PEN_SAME) pen[(size_t)dd] = (uint8_t)(ps < 255 ? ps : 255);
+        pen[(size_t)PMX_C_PEN_SAME + dd] = (uint8_t)(pd < 255 ? pd : 255);
+    }
+    CPenTab tab{pen.data(), pen.data() + PMX_C_PEN_SAME};
+    if (getenv("PMX_HS_COMPACT_NO_TAB")) tab.same = tab.diff = nullptr;
     for (int it = 0; it < n_reads / 2; ++it) {
         std::vector<uint64_t> w[2];
         std::vector<uint32_t> am[2];
@@ -173,8 +182,8 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
         std::fill(lds.begin(), lds.end(), 0xdeadbeefu);
         CResult res;
         int rc;
-        if (ref_len <= 32767 && !getenv("PMX_HS_COMPACT_POS32")) { CMemT<uint16_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res); }
-        else { CMemT<uint32_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res); }
+        if (ref_len <= 32767 && !getenv("PMX_HS_COMPACT_POS32")) { CMemT<uint16_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res, tab); }
+        else { CMemT<uint32_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res, tab); }
         done[it] = rc == PMX_C_DONE ? 1 : 0;
         for (int s = 0; s < 2; ++s) {
             AlnRecord& rec = recs[2 * it + s];
