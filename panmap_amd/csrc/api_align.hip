@@ -370,7 +370,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             }
             // Few bails: a thread-per-pair launch that small cannot fill the chip and lasts as long as a full one (a wave
             // takes ~2 ms whatever the grid); the wave-per-pair tier runs them instead.
-            int64_t bail_tpp_min = 32768;
+            int64_t bail_tpp_min = 0;   // (measured: 7.8 -> 8.7 ms when 7k bails skip the thread-per-pair tier; kept as a switch)
             if (const char* e = getenv("PMX_ALIGN_BAIL_TPP_MIN")) bail_tpp_min = atoll(e);
             const bool skip_t0 = use_compact && n_t0 < bail_tpp_min;
             A.pair_perm = order;
