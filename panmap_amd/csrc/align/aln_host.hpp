@@ -234,7 +234,9 @@ struct Layout {
 };
 
 // Capacities for a read-length regime; fast = LDS budget (bytes) per wave.
-inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fast_budget) {
+// tb_limit: cap of the per-wave traceback area (a DP that needs more reports PMX_ST_OVERFLOW and is re-run by a launch
+// with the full capacity: long reads, whose band allows matrices up to max_sw_mat cells, align.c:326-328, 590-592)
+inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fast_budget, size_t tb_limit = 0) {
     Layout L;
     Caps& c = L.caps;
     c.max_qlen = (max_read_len + 15) / 16 * 16 + 16;
@@ -253,6 +255,9 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
     const int wband = (int)(std::max(o.bw, o.bw_long) * 1.5 + 1.);
     const int n_col = ((std::min(std::min(c.max_tlen, c.max_qlen), wband + 1) + 15) / 16 + 1) * 16;
     L.tb_cap = (size_t)(c.max_qlen + c.max_tlen) * n_col;
+    if (o.max_sw_mat > 0 && L.tb_cap > (size_t)o.max_sw_mat + (size_t)(c.max_qlen + c.max_tlen) * 32)   // larger matrices are never filled (align.c:326)
+        L.tb_cap = (size_t)o.max_sw_mat + (size_t)(c.max_qlen + c.max_tlen) * 32;
+    if (tb_limit > 0 && L.tb_cap > tb_limit) L.tb_cap = tb_limit;
 
     size_t used[2] = {0, 0};
     auto place = [&](Layout::Ent& e, size_t bytes, int pref) {

@@ -191,7 +191,8 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     }
 
     auto kern_t1 = waves_per_simd >= 4 ? k_align_reads_t1_w4 : k_align_reads_t1;
-    auto launch = [&](decltype(kern) kfn, const Layout& L, int64_t n_work, const uint32_t* worklist, uint32_t* retry_list, DevBuf<uint8_t>& slab) {
+    auto launch = [&](decltype(kern) kfn, const Layout& L, int64_t n_work, const uint32_t* worklist, uint32_t* retry_list, DevBuf<uint8_t>& slab,
+                      int64_t max_grid = 0) {
         const size_t lds_bytes = PMX_ALIGN_WORK_BYTES + L.fast_bytes + 16;
         if (lds_bytes > 160 * 1024) throw std::runtime_error("reads too long for the LDS work arena");
         if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -199,6 +200,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         if (waves_per_cu < 1) waves_per_cu = 1;
         int64_t grid = (int64_t)ctx->n_cu * waves_per_cu;
         if (grid > n_work) grid = n_work;
+        if (max_grid > 0 && grid > max_grid) grid = max_grid;
         A.layout = L;
         A.slow_stride = (L.slow_bytes + 255) & ~(size_t)255;
         slab.ensure(A.slow_stride * (size_t)grid);
@@ -445,8 +447,25 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         al->last_retry = n_retry;
         if (n_retry > 0) launch(kern, general, n_retry, al->retry_list.p, nullptr, al->slow2);
     } else {
-        al->last_retry = 0;
-        launch(kern, general, n_items, nullptr, nullptr, al->slow2);
+        // Long reads (map-ont / map-hifi branch): wave per read with the general capacities.  The band of those presets
+        // allows traceback matrices up to max_sw_mat bytes (100 MB) although nearly every DP between two anchors is a few
+        // hundred bases wide: the first launch gives every wave 8 MB of traceback in HBM, the reads that need more come
+        // back on the retry list and run in a second launch of few waves with the full capacity.
+        size_t tb_small = (size_t)8 << 20;
+        if (const char* e = getenv("PMX_ALIGN_TB_MB")) tb_small = (size_t)atoll(e) << 20;
+        const Layout g1 = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget, tb_small));
+        al->retry_list.ensure((size_t)n_items);
+        timer_begin(ctx, "align_dom");
+        launch(kern, g1, n_items, nullptr, general.tb_cap > g1.tb_cap ? al->retry_list.p : nullptr, al->slow2);
+        timer_end(ctx, "align_dom", 1);
+        int64_t n_retry = 0, unused = 0;
+        read_counts(n_retry, unused, true);
+        al->last_retry = n_retry;
+        if (n_retry > 0) {
+            const size_t stride = (general.slow_bytes + 255) & ~(size_t)255;
+            const int64_t big_grid = std::max<int64_t>(1, std::min<int64_t>(64, (int64_t)(((size_t)24 << 30) / std::max<size_t>(stride, 1))));
+            launch(kern, general, n_retry, al->retry_list.p, nullptr, al->slow, big_grid);
+        }
     }
     timer_end(ctx, "align", 1);
     if (A.prof) {
