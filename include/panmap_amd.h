@@ -73,6 +73,15 @@ int pmx_index_build_ex(const pmx_panman *pm, int k, int s, int t, int l, int ope
 int pmx_index_from_arrays(const pmx_index_info *info, const uint32_t *parent, const uint64_t *offsets,
                           const uint64_t *hash, const int16_t *parent_count, const int16_t *child_count,
                           pmx_index **out);
+/* The `.idx` container the reference's place stage loads and its index stage writes (32-byte PMI1 header + Cap'n Proto
+ * LiteIndex message, raw or as concatenated zstd frames; src/index_single_mode.cpp:1561-1640, src/placement.cpp:1009-1092,
+ * src/index_lite.capnp:36-70).  Load rejects a stale format version / missing struct-of-arrays fields / short offsets with
+ * the reference's messages (pmx_last_error).  zstd_level as --zstd-level; uncompressed != 0 writes the mmap-able form. */
+int pmx_index_save(const pmx_index *idx, const char *path, int zstd_level, int uncompressed);
+int pmx_index_load(const char *path, pmx_index **out);
+/* the seeding parameters from the header alone (cache validation, src/main.cpp:371-396); PMX_ERR_FORMAT if absent */
+int pmx_index_read_header(const char *path, pmx_index_info *info, int *uncompressed);
+const char *pmx_index_node_id(const pmx_index *idx, int64_t dfs_index); /* "" when the index was adopted from arrays */
 void pmx_index_close(pmx_index *idx);
 int pmx_index_get_info(const pmx_index *idx, pmx_index_info *info);
 const uint32_t *pmx_index_parents(const pmx_index *idx);      /* n_nodes   */

@@ -117,6 +117,10 @@ SIGNATURES = {
     "pmx_place_histogram_merge_device_parts": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32]),
     "pmx_place_histogram_merge_device": (_i32, [_vp, _vp, _vp, _vp, _i64]),
     "pmx_align_copy_records_device": (_i32, [_vp, _vp, _vp, _i64]),
+    "pmx_index_save": (_i32, [_vp, _cp, _i32, _i32]),
+    "pmx_index_load": (_i32, [_cp, _PP]),
+    "pmx_index_read_header": (_i32, [_cp, C.POINTER(IndexInfo), C.POINTER(C.c_int)]),
+    "pmx_index_node_id": (_cp, [_vp, _i64]),
     "pmx_align_copy_cigars_device": (_i32, [_vp, _vp, _vp, _i64]),
     "pmx_align_get_stats": (_i32, [_vp, _vp, C.POINTER(AlignStats)]),
     "pmx_place_score": (_i32, [_vp, _vp, C.POINTER(PlaceParams), _i64, C.POINTER(PlaceResult)]),

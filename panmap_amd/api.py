@@ -5,6 +5,7 @@ Names follow the reference: ``TraversalParams`` (src/placement.hpp:28-54), ``Pla
 (src/mm_align.h:44-53).  All compute goes through the C ABI of libpanmap_amd.so.
 """
 import ctypes as C
+import os
 import dataclasses
 import gzip
 from typing import List, Optional, Sequence
@@ -101,6 +102,30 @@ class Index:
         check(lib.pmx_index_from_arrays(C.byref(info), parent.ctypes.data, offsets.ctypes.data, hashes.ctypes.data,
                                         pc.ctypes.data, cc.ctypes.data, C.byref(h)), "pmx_index_from_arrays")
         return cls(h)
+
+    @classmethod
+    def load(cls, path: str) -> "Index":
+        """read a `.idx` file (the reference's single-sample index container, src/placement.cpp:1009-1092)"""
+        h = C.c_void_p()
+        check(lib.pmx_index_load(os.fsencode(path), C.byref(h)), "pmx_index_load")
+        return cls(h)
+
+    def save(self, path: str, zstd_level: int = 3, uncompressed: bool = False):
+        """write the `.idx` container (src/index_single_mode.cpp:1593-1640)"""
+        check(lib.pmx_index_save(self._h, os.fsencode(path), int(zstd_level), int(uncompressed)), "pmx_index_save")
+
+    @staticmethod
+    def read_header(path: str):
+        """(k, s, t, l, open, hpc, uncompressed) from the 32-byte header, or None if the file has none"""
+        info = _lib.IndexInfo()
+        unc = C.c_int()
+        if lib.pmx_index_read_header(os.fsencode(path), C.byref(info), C.byref(unc)) != 0:
+            return None
+        return dict(k=info.k, s=info.s, t=info.t, l=info.l, open=bool(info.open_syncmer), hpc=bool(info.hpc), uncompressed=bool(unc.value))
+
+    def node_id(self, dfs_index: int) -> str:
+        p = lib.pmx_index_node_id(self._h, int(dfs_index))
+        return p.decode() if p else ""
 
     def close(self):
         if self._h:

@@ -843,7 +843,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
     // per-mate anchor index lists in G (the chain cells are dead): mate 0 from 0, mate 1 behind it, ascending = the
     // chain walked backwards
     CReg R0, R1;
-    int base1;
+    int base1 = 0;
     {
         int wr = 0;
 #pragma unroll

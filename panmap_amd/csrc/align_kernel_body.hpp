@@ -106,7 +106,7 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
                     __syncthreads();
                     const uint64_t coff = W.tmp64;
                     rec.cigar_off = (uint32_t)coff;
-                    if (coff + g.n_cigar <= A.cigar_cap) {
+                    if (coff + g.n_cigar <= A.cigar_cap && g.n_cigar <= 0xffffu) {   // (n_cigar is 16 bits wide in the record)
                         const uint32_t* cg = reg_cigar(W, g); PMX_LDS(cg);
                         for (uint32_t i = lane; i < g.n_cigar; i += 64) A.cigars[coff + i] = cg[i];
                     } else {

@@ -204,7 +204,7 @@ k_align_reads_tpp(AlignArgs A) {
                     rec.n_cigar = (uint16_t)g.n_cigar;
                     rec.score = g.dp_max;
                     rec.cigar_off = (uint32_t)coff;
-                    if (coff + g.n_cigar <= A.cigar_cap) {
+                    if (coff + g.n_cigar <= A.cigar_cap && g.n_cigar <= 0xffffu) {   // (n_cigar is 16 bits wide in the record)
                         Ptr<const uint32_t> cg = reg_cigar(W, g);
                         for (uint32_t i = 0; i < g.n_cigar; ++i) A.cigars[coff + i] = cg[i];
                     } else {

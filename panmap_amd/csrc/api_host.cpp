@@ -1,10 +1,12 @@
 // C ABI, host-only part: PanMAN access, node genomes, seed-index build (see include/panmap_amd.h).
 #include <cstring>
+#include <memory>
 #include <string>
 
 #include "api_internal.hpp"
 #include "host/bam_writer.hpp"
 #include "host/fastx_reader.hpp"
+#include "host/idx_file.hpp"
 #include "host/index_build.hpp"
 #include "host/panman.hpp"
 
@@ -112,6 +114,44 @@ int pmx_index_from_arrays(const pmx_index_info* info, const uint32_t* parent, co
     L.node_id.resize(n);
     *out = ix;
     return PMX_OK;
+}
+
+// ---- .idx container (host/idx_file.cpp)
+int pmx_index_save(const pmx_index* idx, const char* path, int zstd_level, int uncompressed) {
+    if (!idx || !path) return PMX_ERR_ARG;
+    try {
+        pmx::save_idx(idx->ix, path, zstd_level, uncompressed != 0);
+        return PMX_OK;
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return PMX_ERR_IO;
+    }
+}
+int pmx_index_load(const char* path, pmx_index** out) {
+    if (!path || !out) return PMX_ERR_ARG;
+    try {
+        std::unique_ptr<pmx_index> ix(new pmx_index());
+        pmx::load_idx(path, ix->ix);
+        ix->ix.flank_mask = -1;   // not recorded in the file
+        *out = ix.release();
+        return PMX_OK;
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return PMX_ERR_FORMAT;
+    }
+}
+int pmx_index_read_header(const char* path, pmx_index_info* info, int* uncompressed) {
+    if (!path || !info) return PMX_ERR_ARG;
+    pmx::IdxHeader h;
+    if (!pmx::read_idx_header(path, h)) { pmx::set_error(std::string(path) + ": absent or without a PMI1 header"); return PMX_ERR_FORMAT; }
+    std::memset(info, 0, sizeof(*info));
+    info->k = h.k; info->s = h.s; info->t = h.t; info->l = h.l; info->open_syncmer = h.open; info->hpc = h.hpc; info->flank_mask = -1;
+    if (uncompressed) *uncompressed = h.uncompressed ? 1 : 0;
+    return PMX_OK;
+}
+const char* pmx_index_node_id(const pmx_index* idx, int64_t dfs_index) {
+    if (!idx || dfs_index < 0 || (size_t)dfs_index >= idx->ix.node_id.size()) return nullptr;
+    return idx->ix.node_id[(size_t)dfs_index].c_str();
 }
 
 void pmx_index_close(pmx_index* idx) { delete idx; }

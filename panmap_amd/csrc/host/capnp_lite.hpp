@@ -15,6 +15,15 @@ struct Message {
     std::vector<const uint64_t*> seg;
     std::vector<uint32_t> seg_words;
 
+    // every object a pointer leads to must lie inside its segment (a truncated or crafted file must end in a format
+    // error, never in an out-of-bounds read: the capnp library bounds-checks every pointer as well)
+    void check(uint32_t sid, const uint64_t* at, uint64_t words) const {
+        if (sid >= seg.size()) throw std::runtime_error("capnp: bad segment id");
+        const uint64_t* b = seg[sid];
+        if (at < b || (uint64_t)(at - b) > seg_words[sid] || words > seg_words[sid] - (uint64_t)(at - b))
+            throw std::runtime_error("capnp: pointer target outside its segment");
+    }
+
     // stream-framed message: u32 nseg-1, u32 sizes[nseg] (words), pad to 8 B, segments
     void parse(const uint8_t* buf, size_t len) {
         if (len < 8) throw std::runtime_error("capnp: truncated header");
@@ -66,9 +75,11 @@ inline Resolved resolve(const Ptr& ptr) {
         uint32_t sid = (uint32_t)(w >> 32);
         if (sid >= m->seg.size()) throw std::runtime_error("capnp: bad far segment");
         const uint64_t* pad = m->seg[sid] + off;
+        m->check(sid, pad, dbl ? 2 : 1);
         if (!dbl) {
             uint64_t pw = *pad;
             int32_t o = (int32_t)((int32_t)(uint32_t)(pw & 0xffffffffu) >> 2);
+            if ((pw & 3) == 2) throw std::runtime_error("capnp: far pointer lands on a far pointer");
             r.tag = pw;
             r.target = pad + 1 + o;
             r.seg = sid;
@@ -78,7 +89,7 @@ inline Resolved resolve(const Ptr& ptr) {
         uint64_t far2 = pad[0];
         uint32_t off2 = (uint32_t)((far2 >> 3) & 0x1fffffff);
         uint32_t sid2 = (uint32_t)(far2 >> 32);
-        if (sid2 >= m->seg.size()) throw std::runtime_error("capnp: bad double-far segment");
+        if (sid2 >= m->seg.size() || (far2 & 3) != 2 || ((far2 >> 2) & 1)) throw std::runtime_error("capnp: bad double-far landing pad");
         r.tag = pad[1];
         r.target = m->seg[sid2] + off2;
         r.seg = sid2;
@@ -126,6 +137,7 @@ inline StructR as_struct(const Ptr& ptr) {
     s.data = r.target;
     s.dwords = (uint16_t)(r.tag >> 32);
     s.pwords = (uint16_t)(r.tag >> 48);
+    ptr.m->check(r.seg, r.target, (uint64_t)s.dwords + s.pwords);
     return s;
 }
 
@@ -175,14 +187,18 @@ inline ListR as_list(const Ptr& ptr) {
     l.esize = (uint32_t)((r.tag >> 32) & 7);
     uint32_t cnt = (uint32_t)(r.tag >> 35);
     if (l.esize == 7) {
+        ptr.m->check(r.seg, r.target, 1 + (uint64_t)cnt);   // tag word + content words
         uint64_t tag = *r.target;
         l.n = (uint32_t)((tag & 0xffffffffu) >> 2);
         l.dwords = (uint16_t)(tag >> 32);
         l.pwords = (uint16_t)(tag >> 48);
         l.base = r.target + 1;
+        if ((uint64_t)l.n * ((uint64_t)l.dwords + l.pwords) > cnt) throw std::runtime_error("capnp: composite list overruns its word count");
     } else {
+        static const uint32_t bits[7] = {0, 1, 8, 16, 32, 64, 64};
         l.n = cnt;
         l.base = r.target;
+        ptr.m->check(r.seg, r.target, ((uint64_t)cnt * bits[l.esize] + 63) / 64);
     }
     return l;
 }
