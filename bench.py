@@ -280,7 +280,7 @@ def main():
         unit = 2 if paired else 1
         bounds = [(n_reads // unit) * c // n_chunks * unit for c in range(n_chunks + 1)]
         out_recs = torch.empty((n_reads, 32), dtype=torch.uint8).pin_memory()
-        out_cig = torch.empty(max(n_reads * 16, 4096), dtype=torch.int32).pin_memory()
+        out_cig = torch.empty(max(n_reads * 16, int(concat.size) // 4, 4096), dtype=torch.int32).pin_memory()
         d_recs = torch.empty((n_reads, 32), dtype=torch.uint8, device=dev)
 
         def step_h2h():

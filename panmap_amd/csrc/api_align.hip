@@ -452,7 +452,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         // hundred bases wide: the first launch gives every wave 8 MB of traceback in HBM, the reads that need more come
         // back on the retry list and run in a second launch of few waves with the full capacity.
         size_t tb_small = (size_t)8 << 20;
-        if (const char* e = getenv("PMX_ALIGN_TB_MB")) tb_small = (size_t)atoll(e) << 20;
+        if (const char* e = getenv("PMX_ALIGN_TB_KB")) tb_small = std::max<size_t>((size_t)atoll(e), 1) << 10;
         const Layout g1 = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget, tb_small));
         al->retry_list.ensure((size_t)n_items);
         timer_begin(ctx, "align_dom");

@@ -45,7 +45,7 @@ def test_long_reads_equal_reference_fixture(pmx, ctx, name):
 
 
 def test_long_reads_live_reference_and_small_traceback_tier(pmx, oracle, ctx, monkeypatch):
-    """a fresh set against the compiled reference; then the same with a 1 MB traceback area in the first launch, so that
+    """a fresh set against the compiled reference; then the same with a 64 KB traceback area in the first launch, so that
     reads are re-run by the full-capacity launch: same records"""
     g = mg.genome()
     reads = pmx.simulate_long_reads(g, 300, read_len=6000, seed=91)
@@ -53,7 +53,7 @@ def test_long_reads_live_reference_and_small_traceback_tier(pmx, oracle, ctx, mo
     al = pmx.Aligner(ctx, g, 6000)
     got = al.align_reads(reads, paired=False)
     assert not ac.compare_results(got, want) and all(x["flags"] & 3 == 0 for x in got)
-    monkeypatch.setenv("PMX_ALIGN_TB_MB", "0")     # (0 MB: every DP that needs a traceback goes to the second launch)
+    monkeypatch.setenv("PMX_ALIGN_TB_KB", "64")    # (64 KB: a 300 x 300 DP no longer fits, its read goes to the second launch)
     got2 = al.align_reads(reads, paired=False)
     assert not ac.compare_results(got2, want) and all(x["flags"] & 3 == 0 for x in got2)
     assert al.stats()["general_tier_items"] > 0
