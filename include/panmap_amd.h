@@ -249,6 +249,7 @@ typedef struct {
 
 #define PMX_ALN_OVERFLOW 0x1     /* a fixed-capacity work buffer overflowed: record is invalid */
 #define PMX_ALN_UNSUPPORTED 0x2  /* hit a reference branch not implemented on the GPU yet */
+#define PMX_ALN_HAS_ALN 0x4      /* the record carries an alignment (rs/re/qs/qe/mapq/CIGAR are set) */
 
 typedef struct pmx_aligner pmx_aligner;
 /* builds the minimizer index of one reference genome on the device; preset chosen from the mean

@@ -1,0 +1,343 @@
+// `panmap <panman> [reads1] [reads2] [options]` -- the reference's command line (src/main.cpp:1941-2131, 2225-2276) for
+// the stages this library implements, written against the C ABI only (include/panmap_amd.h):
+//   index   PanMAN -> seed index, cached as `<panman>.idx` (reused when newer than the PanMAN and built with the same
+//           seeding parameters, src/main.cpp:371-396; -f rebuilds; -i loads a given file; --index-out names the output)
+//   place   reads -> `<prefix>.placement.tsv` (src/placement.cpp:1952-2003)
+//   align   placed genome -> `<prefix>.ref.fa` (+ .fai), reads aligned to it -> `<prefix>.bam` (+ .bai)
+// `--stop index|place|align` ends after that stage.  The later stages of the reference (genotype, consensus), --meta,
+// --batch, --refine, the bwa backend and HPC seeds are outside this library: asking for them is an error, not a silent
+// no-op (a `--stop` beyond align stops after align with a note).  Output prefix: -o, else derived from reads1 as the
+// reference derives it.  Exit code 130 on SIGINT.
+#include <signal.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "panmap_amd.h"
+
+namespace {
+
+struct Config {
+    std::string panman, reads1, reads2, output, index, index_out, stop = "consensus", aligner = "minimap2";
+    int threads = 1, k = 19, s = 8, t = 0, l = 3, flank_mask = 250, zstd_level = 7;
+    bool open_syncmer = false, hpc = false, force_reindex = false, index_uncompressed = false, quiet = false;
+    double seed_mask_fraction = 0.0;
+    bool dedup = false, force_leaf = false;
+    int trim_start = 0, trim_end = 0, min_seed_quality = 0, min_read_support = -1;
+};
+
+void on_sigint(int) { _exit(130); }
+
+[[noreturn]] void die(const std::string& msg, int code = 1) {
+    fprintf(stderr, "panmap: error: %s\n", msg.c_str());
+    exit(code);
+}
+void check(int rc, const char* what) {
+    if (rc != PMX_OK) die(std::string(what) + ": " + pmx_last_error());
+}
+void say(const Config& c, const char* stage, const std::string& what) {
+    if (!c.quiet) fprintf(stderr, "[%s] %s\n", stage, what.c_str());
+}
+bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+time_t mtime(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 ? st.st_mtime : 0; }
+
+void usage() {
+    fputs("Usage: panmap <panman> [reads1.fq[.gz]] [reads2.fq[.gz]] [options]\n"
+          "  -o, --output PREFIX        output prefix (default: derived from reads1)\n"
+          "  -t, --threads N            accepted (the GPU owns the parallelism)\n"
+          "      --stop STAGE           index|place|align (later stages are not part of this build)\n"
+          "  -i, --index PATH           load a pre-built index       --index-out PATH   write the built index here\n"
+          "  -f, --reindex              force rebuild                --zstd-level N     (default 7)   --index-uncompressed\n"
+          "  -k N  -s N  -l N  --offset N  --open-syncmer  --flank-mask N  --seed-mask-fraction F\n"
+          "      --dedup --trim-start N --trim-end N --min-seed-quality N --min-read-support N --force-leaf\n"
+          "  -a, --aligner minimap2     -q, --quiet   -h, --help   -V, --version\n", stderr);
+}
+
+Config parse(int argc, char** argv) {
+    Config c;
+    std::vector<std::string> pos;
+    auto need = [&](int& i) -> const char* { if (i + 1 >= argc) die(std::string("option ") + argv[i] + " needs a value"); return argv[++i]; };
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        std::string val;
+        const size_t eq = a.rfind("--", 0) == 0 ? a.find('=') : std::string::npos;   // --opt=value
+        bool has_val = false;
+        if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); has_val = true; }
+        auto v = [&]() -> std::string { return has_val ? val : std::string(need(i)); };
+        if (a == "-h" || a == "--help" || a == "--help-all") { usage(); exit(0); }
+        else if (a == "-V" || a == "--version") { puts(pmx_version()); exit(0); }
+        else if (a == "-o" || a == "--output") c.output = v();
+        else if (a == "-t" || a == "--threads") c.threads = atoi(v().c_str());
+        else if (a == "--stop") c.stop = v();
+        else if (a == "-i" || a == "--index") c.index = v();
+        else if (a == "--index-out") c.index_out = v();
+        else if (a == "-f" || a == "--reindex") c.force_reindex = true;
+        else if (a == "-k" || a == "--kmer") c.k = atoi(v().c_str());
+        else if (a == "-s" || a == "--syncmer") c.s = atoi(v().c_str());
+        else if (a == "--offset") c.t = atoi(v().c_str());
+        else if (a == "-l" || a == "--lmer") c.l = atoi(v().c_str());
+        else if (a == "--open-syncmer") c.open_syncmer = true;
+        else if (a == "--hpc") c.hpc = true;
+        else if (a == "--flank-mask") c.flank_mask = atoi(v().c_str());
+        else if (a == "--seed-mask-fraction") c.seed_mask_fraction = atof(v().c_str());
+        else if (a == "--zstd-level") c.zstd_level = atoi(v().c_str());
+        else if (a == "--index-uncompressed") c.index_uncompressed = true;
+        else if (a == "-a" || a == "--aligner") c.aligner = v();
+        else if (a == "--dedup") c.dedup = true;
+        else if (a == "--trim-start") c.trim_start = atoi(v().c_str());
+        else if (a == "--trim-end") c.trim_end = atoi(v().c_str());
+        else if (a == "--min-seed-quality") c.min_seed_quality = atoi(v().c_str());
+        else if (a == "--min-read-support") c.min_read_support = atoi(v().c_str());
+        else if (a == "--force-leaf") c.force_leaf = true;
+        else if (a == "-q" || a == "--quiet") c.quiet = true;
+        else if (a == "-v" || a == "--verbose" || a == "--no-color" || a == "--no-progress") {}
+        else if (a == "--meta" || a == "--batch" || a == "--refine" || a == "--impute" || a == "--extent-guard" || a == "--reference-node" ||
+                 a == "--dump-sequence" || a == "--dump-all-scores")
+            die("option " + a + " belongs to a part of panmap this build does not implement (index / place / align only)");
+        else if (a.size() > 1 && a[0] == '-') die("unknown option " + a + " (see --help)");
+        else pos.push_back(a);
+    }
+    if (pos.empty()) { usage(); exit(1); }
+    c.panman = pos[0];
+    if (pos.size() > 1) c.reads1 = pos[1];
+    if (pos.size() > 2) c.reads2 = pos[2];
+    if (pos.size() > 3) die("at most two read files");
+    return c;
+}
+
+// src/main.cpp:2253-2276
+std::string derive_prefix(const Config& c) {
+    if (c.reads1.empty()) return c.panman;
+    std::string stem = c.reads1;
+    const size_t slash = stem.find_last_of('/');
+    if (slash != std::string::npos) stem = stem.substr(slash + 1);
+    const size_t dot = stem.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) stem = stem.substr(0, dot);            // fs::path::stem()
+    auto strip = [&](std::initializer_list<const char*> sfx) {
+        for (const char* s : sfx) {
+            const size_t n = strlen(s);
+            if (stem.size() > n && stem.compare(stem.size() - n, n, s) == 0) { stem.erase(stem.size() - n); return; }
+        }
+    };
+    strip({"_R1", "_R2", "_1", "_2", ".R1", ".R2", ".1", ".2"});
+    strip({".fastq", ".fq"});
+    return stem;
+}
+
+// cachedIndexUsable (src/main.cpp:371-396)
+bool cached_index_usable(const Config& c) {
+    if (exists(c.panman) && mtime(c.index) < mtime(c.panman)) {
+        fprintf(stderr, "panmap: cached index %s is older than %s; rebuilding.\n", c.index.c_str(), c.panman.c_str());
+        return false;
+    }
+    pmx_index_info h;
+    int unc = 0;
+    if (pmx_index_read_header(c.index.c_str(), &h, &unc) != PMX_OK) {
+        fprintf(stderr, "panmap: cached index %s has no readable param header (old format/corrupt); rebuilding.\n", c.index.c_str());
+        return false;
+    }
+    if (h.k != c.k || h.s != c.s || h.t != c.t || h.l != c.l || (h.hpc != 0) != c.hpc || (h.open_syncmer != 0) != c.open_syncmer) {
+        fprintf(stderr, "panmap: cached index %s was built with different seeding parameters (k/s/t/l/hpc/open-syncmer); rebuilding.\n", c.index.c_str());
+        return false;
+    }
+    return true;
+}
+
+char comp(char b) {   // seeding::reverseComplement (src/seeding.cpp:271-284): A/C/G/T only, everything else kept
+    switch (b) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return b; }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    signal(SIGINT, on_sigint);
+    Config c = parse(argc, argv);
+    if (c.s <= 0 || c.s > c.k) die("Invalid syncmer s=" + std::to_string(c.s) + " (must be in 1..k, k=" + std::to_string(c.k) + ")");
+    if (c.t < 0 || c.t > c.k - c.s) die("Invalid syncmer offset=" + std::to_string(c.t) + " (must be in 0..k-s = 0.." + std::to_string(c.k - c.s) + ")");
+    if (c.hpc) die("--hpc (homopolymer-compressed seeds) is not implemented in this build");
+    if (c.aligner != "minimap2") die("aligner '" + c.aligner + "' is not implemented in this build (minimap2 only)");
+    int stop = c.stop == "index" ? 0 : c.stop == "place" ? 1 : c.stop == "align" ? 2 : (c.stop == "genotype" || c.stop == "consensus") ? 3 : -1;
+    if (stop < 0) die("--stop expects index|place|align|genotype|consensus");
+    if (c.index.empty()) c.index = c.index_out.empty() ? c.panman + ".idx" : c.index_out;
+    else if (!exists(c.index)) die("index file not found: " + c.index + " (--index expects a pre-built index; use --index-out to build at a custom path)");
+    if (c.output.empty()) c.output = derive_prefix(c);
+
+    // ------------------------------------------------------------------------------------------------ index
+    pmx_panman* pm = nullptr;
+    pmx_index* idx = nullptr;
+    if (exists(c.index) && !c.force_reindex && cached_index_usable(c)) {
+        check(pmx_index_load(c.index.c_str(), &idx), "loading the index");
+        say(c, "index", c.index + " (cached)");
+    } else {
+        check(pmx_panman_open(c.panman.c_str(), &pm), "opening the PanMAN");
+        check(pmx_index_build(pm, c.k, c.s, c.t, c.l, c.open_syncmer ? 1 : 0, c.flank_mask, &idx), "building the index");
+        check(pmx_index_save(idx, c.index.c_str(), c.zstd_level, c.index_uncompressed ? 1 : 0), "writing the index");
+        say(c, "index", c.index + " (built)");
+    }
+    if (stop == 0 || c.reads1.empty()) return 0;
+
+    // ------------------------------------------------------------------------------------------------ reads
+    pmx_fastx *f1 = nullptr, *f2 = nullptr;
+    check(pmx_fastx_read(c.reads1.c_str(), &f1), "reading reads1");
+    const bool paired = !c.reads2.empty();
+    if (paired) check(pmx_fastx_read(c.reads2.c_str(), &f2), "reading reads2");
+    const int64_t n1 = pmx_fastx_num_reads(f1), n2 = paired ? pmx_fastx_num_reads(f2) : 0;
+    if (paired && n1 != n2) die("File " + c.reads2 + " does not contain the same number of reads as " + c.reads1);   // src/placement.cpp:189-192
+    const char *s1, *q1, *nm1, *s2 = nullptr, *q2 = nullptr, *nm2 = nullptr;
+    const int64_t *o1, *no1, *o2 = nullptr, *no2 = nullptr;
+    check(pmx_fastx_views(f1, &s1, &q1, &o1, &nm1, &no1), "reads1 views");
+    if (paired) check(pmx_fastx_views(f2, &s2, &q2, &o2, &nm2, &no2), "reads2 views");
+    // interleaved R1, R2 in FASTQ orientation (extractReadSequences: R2 is NOT reverse-complemented for placement)
+    const int64_t n_reads = n1 + n2;
+    std::string concat, quals;
+    std::vector<int64_t> off((size_t)n_reads + 1, 0);
+    concat.reserve((size_t)(o1[n1] + (paired ? o2[n2] : 0)));
+    quals.reserve(concat.capacity());
+    for (int64_t i = 0; i < n1; ++i) {
+        off[(size_t)(paired ? 2 * i : i)] = (int64_t)concat.size();
+        concat.append(s1 + o1[i], (size_t)(o1[i + 1] - o1[i]));
+        quals.append(q1 + o1[i], (size_t)(o1[i + 1] - o1[i]));
+        if (paired) {
+            off[(size_t)(2 * i + 1)] = (int64_t)concat.size();
+            concat.append(s2 + o2[i], (size_t)(o2[i + 1] - o2[i]));
+            quals.append(q2 + o2[i], (size_t)(o2[i + 1] - o2[i]));
+        }
+    }
+    off[(size_t)n_reads] = (int64_t)concat.size();
+
+    // ------------------------------------------------------------------------------------------------ place
+    pmx_ctx* ctx = nullptr;
+    int dev = 0;
+    if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
+    check(pmx_ctx_create(dev, &ctx), "opening the GPU");
+    pmx_place* pl = nullptr;
+    check(pmx_place_create(ctx, idx, &pl), "uploading the index");
+    pmx_readset* rs = nullptr;
+    check(pmx_readset_upload(ctx, concat.data(), off.data(), n_reads, &rs), "uploading the reads");
+    check(pmx_readset_pack(ctx, rs), "packing the reads");
+    pmx_place_params pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.seed_mask_fraction = c.seed_mask_fraction; pp.min_read_support = c.min_read_support; pp.trim_start = c.trim_start; pp.trim_end = c.trim_end;
+    pp.dedup_reads = c.dedup; pp.force_leaf = c.force_leaf; pp.min_seed_quality = c.min_seed_quality;
+    if (c.min_seed_quality > 0) check(pmx_readset_set_qualities(ctx, rs, quals.data()), "attaching the qualities");
+    pmx_place_result res;
+    check(pmx_place_reset(ctx, pl), "place reset");
+    check(pmx_place_add_reads(ctx, pl, rs, &pp), "seeding the reads");
+    check(pmx_place_score(ctx, pl, &pp, n_reads, &res), "scoring the tree");
+    static const char* metric_names[5] = {"log_raw", "log_cosine", "containment", "weighted_containment", "log_containment"};
+    {
+        const std::string path = c.output + ".placement.tsv";
+        FILE* f = fopen(path.c_str(), "w");
+        if (!f) die("cannot write " + path);
+        fputs("metric\tscore\tnodes\n", f);
+        for (int m = 0; m < 5; ++m) {
+            std::string ids;
+            if (res.n_tied[m] > 0) {
+                std::vector<uint32_t> tied((size_t)res.n_tied[m]);
+                check(pmx_place_tied(pl, m, tied.data(), (int64_t)tied.size()), "tied nodes");
+                for (size_t j = 0; j < tied.size(); ++j) { if (j) ids += ","; ids += pmx_index_node_id(idx, tied[j]); }
+            } else if (res.best_index[m] != UINT32_MAX) ids = pmx_index_node_id(idx, res.best_index[m]);
+            fprintf(f, "%s\t%.6f\t%s\n", metric_names[m], res.best_score[m], ids.c_str());
+        }
+        fclose(f);
+        say(c, "place", path);
+    }
+    if (res.best_index[4] == UINT32_MAX) die("No placement found");
+    const std::string node_id = pmx_index_node_id(idx, res.best_index[4]);
+    say(c, "place", node_id + " (log_containment " + std::to_string(res.best_score[4]) + ")");
+    if (stop == 1) return 0;
+
+    // ------------------------------------------------------------------------------------------------ align
+    if (!pm) check(pmx_panman_open(c.panman.c_str(), &pm), "opening the PanMAN");
+    const int64_t node = pmx_panman_find_node(pm, node_id.c_str());
+    if (node < 0) die("placed node '" + node_id + "' is not in the PanMAN");
+    std::string genome((size_t)pmx_panman_node_genome(pm, node, nullptr, 0), '\0');
+    pmx_panman_node_genome(pm, node, &genome[0], (int64_t)genome.size());
+    if (genome.empty()) die("Empty sequence for node '" + node_id + "', cannot align");
+    {
+        const std::string fa = c.output + ".ref.fa";
+        FILE* f = fopen(fa.c_str(), "w");
+        if (!f) die("Cannot write reference file: " + fa);
+        fprintf(f, ">%s\n%s\n", node_id.c_str(), genome.c_str());
+        fclose(f);
+        FILE* g = fopen((fa + ".fai").c_str(), "w");   // faidx: name, length, offset of the first base, bases per line, bytes per line
+        if (g) { fprintf(g, "%s\t%zu\t%zu\t%zu\t%zu\n", node_id.c_str(), genome.size(), node_id.size() + 2, genome.size(), genome.size() + 1); fclose(g); }
+        say(c, "align", fa);
+    }
+    pmx_aligner* al = nullptr;
+    check(pmx_aligner_create(ctx, genome.data(), (int64_t)genome.size(), (int)(concat.size() / (size_t)std::max<int64_t>(n_reads, 1)), &al), "indexing the placed genome");
+    check(pmx_align_readset(ctx, al, rs, paired ? 1 : 0, paired ? 1 : 0), "aligning");   // mate 2 reverse-complemented on the device
+    std::vector<pmx_aln_record> recs((size_t)n_reads);
+    const int64_t words = pmx_align_cigar_words(ctx, al);
+    std::vector<uint32_t> arena((size_t)std::max<int64_t>(words, 1));
+    check(pmx_align_fetch(ctx, al, recs.data(), n_reads, arena.data(), (int64_t)arena.size()), "fetching the alignments");
+    // what alignAndWriteBam holds after the aligner call: R2 reverse-complemented, its qualities reversed (src/seeding.cpp:231-269)
+    std::vector<std::string> seq_s((size_t)n_reads), qual_s((size_t)n_reads), name_s((size_t)n_reads);
+    for (int64_t r = 0; r < n_reads; ++r) {
+        const bool second = paired && (r & 1);
+        const int64_t i = paired ? r / 2 : r;
+        const char* nm = second ? nm2 + no2[i] : nm1 + no1[i];
+        name_s[(size_t)r].assign(nm, (size_t)((second ? no2[i + 1] - no2[i] : no1[i + 1] - no1[i])));
+        while (!name_s[(size_t)r].empty() && name_s[(size_t)r].back() == '\0') name_s[(size_t)r].pop_back();
+        std::string sq(concat, (size_t)off[(size_t)r], (size_t)(off[(size_t)r + 1] - off[(size_t)r]));
+        std::string ql(quals, (size_t)off[(size_t)r], sq.size());
+        for (char& ch : ql) if (ch == '\0') ch = 'I';   // FASTA input: missing qualities
+        if (second) {
+            std::string rc(sq.rbegin(), sq.rend());
+            for (char& ch : rc) ch = comp(ch);
+            sq.swap(rc);
+            std::string rq(ql.rbegin(), ql.rend());
+            ql.swap(rq);
+        }
+        seq_s[(size_t)r].swap(sq);
+        qual_s[(size_t)r].swap(ql);
+    }
+    std::vector<const char*> seq_p((size_t)n_reads), qual_p((size_t)n_reads), name_p((size_t)n_reads);
+    std::vector<int> lens((size_t)n_reads);
+    for (int64_t r = 0; r < n_reads; ++r) { seq_p[(size_t)r] = seq_s[(size_t)r].c_str(); qual_p[(size_t)r] = qual_s[(size_t)r].c_str(); name_p[(size_t)r] = name_s[(size_t)r].c_str(); lens[(size_t)r] = (int)seq_s[(size_t)r].size(); }
+    const int64_t n_items = paired ? n_reads / 2 : n_reads;
+    std::vector<align_pair_result_t> results((size_t)std::max<int64_t>(n_items, 1));
+    int64_t n_mapped = 0, n_withheld = 0;
+    auto fill = [&](const pmx_aln_record& r, read_align_t* o) {
+        memset(o, 0, sizeof(*o));
+        if (r.mapped && (r.flags & PMX_ALN_HAS_ALN)) {
+            o->pos = r.rs + 1; o->rs = r.rs; o->re = r.re; o->qs = r.qs; o->qe = r.qe;
+            o->mapq = r.mapq; o->rev = r.rev; o->proper_frag = r.proper_frag; o->n_cigar = r.n_cigar;
+            o->cigar = arena.data() + r.cigar_off;   // (points into the arena: nothing to free)
+        } else o->pos = INT_MAX;
+    };
+    for (int64_t k = 0; k < n_items; ++k) {
+        align_pair_result_t& out = results[(size_t)k];
+        memset(&out, 0, sizeof(out));
+        const pmx_aln_record& a = recs[(size_t)(paired ? 2 * k : k)];
+        const bool invalid = paired ? ((a.flags | recs[(size_t)(2 * k + 1)].flags) & 3) != 0 : (a.flags & 3) != 0;
+        out.r1.pos = out.r2.pos = INT_MAX;
+        if (invalid) { ++n_withheld; continue; }
+        if (!a.mapped) continue;
+        out.mapped = 1;
+        ++n_mapped;
+        fill(a, &out.r1);
+        if (paired) fill(recs[(size_t)(2 * k + 1)], &out.r2);
+    }
+    const std::string bam = c.output + ".bam";
+    check(pmx_write_bam(bam.c_str(), node_id.c_str(), (int64_t)genome.size(), (int)n_reads, seq_p.data(), qual_p.data(), name_p.data(), lens.data(),
+                        results.data(), paired), "writing the BAM");
+    say(c, "align", bam + " (" + std::to_string(n_mapped) + " of " + std::to_string(n_items) + (paired ? " pairs" : " reads") + " mapped" +
+                    (n_withheld ? ", " + std::to_string(n_withheld) + " invalid records withheld" : "") + ")");
+    if (stop > 2) fprintf(stderr, "panmap: note: stages after align (genotype, consensus) are not part of this build; stopped after align.\n");
+    pmx_aligner_free(ctx, al);
+    pmx_readset_free(ctx, rs);
+    pmx_place_free(ctx, pl);
+    pmx_ctx_destroy(ctx);
+    pmx_fastx_free(f1);
+    if (f2) pmx_fastx_free(f2);
+    pmx_index_close(idx);
+    if (pm) pmx_panman_close(pm);
+    return 0;
+}
