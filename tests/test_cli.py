@@ -1,0 +1,83 @@
+"""The `panmap` command line built over the C ABI (panmap_amd/csrc/cli/panmap_main.cpp; reference surface:
+src/main.cpp:1941-2131, 2225-2276, 371-396).  CPU part: the index stage, the `.idx` cache rules, argument errors.
+GPU part: the README demo `panmap <panman> R1 R2 --stop align` -- placement TSV byte-equal to the reference's golden,
+placed genome equal to the golden FASTA, the BAM parsed back and compared with the reference aligner's results."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+CLI = os.path.join(ROOT, "panmap_amd", "bin", "panmap")
+
+
+def run(args, cwd):
+    return subprocess.run([CLI] + args, cwd=cwd, capture_output=True, text=True, timeout=1200)
+
+
+def test_index_stage_and_cache_rules(pmx, tmp_path):
+    shutil.copy(os.path.join(GOLDEN, "rsv_4K.panman"), tmp_path / "rsv.panman")
+    r = run(["rsv.panman", "--stop", "index"], tmp_path)
+    assert r.returncode == 0 and "(built)" in r.stderr, r.stderr
+    idx = tmp_path / "rsv.panman.idx"                                   # <panman>.idx (src/main.cpp:2242-2244)
+    assert pmx.Index.read_header(str(idx)) == dict(k=19, s=8, t=0, l=3, open=False, hpc=False, uncompressed=False)
+    r = run(["rsv.panman", "--stop", "index"], tmp_path)
+    assert r.returncode == 0 and "(cached)" in r.stderr                 # reused
+    r = run(["rsv.panman", "--stop", "index", "-k", "15", "-s", "6"], tmp_path)
+    assert r.returncode == 0 and "different seeding parameters" in r.stderr and "(built)" in r.stderr
+    assert pmx.Index.read_header(str(idx))["k"] == 15
+    os.utime(tmp_path / "rsv.panman")                                   # PanMAN newer than the index -> rebuild
+    os.utime(idx, (1, 1))
+    r = run(["rsv.panman", "--stop", "index", "-k", "15", "-s", "6"], tmp_path)
+    assert "is older than" in r.stderr and "(built)" in r.stderr
+    r = run(["rsv.panman", "--stop", "index", "-f", "-k", "15", "-s", "6", "--index-out", "custom.idx", "--index-uncompressed"], tmp_path)
+    assert r.returncode == 0 and pmx.Index.read_header(str(tmp_path / "custom.idx"))["uncompressed"] is True
+    built = pmx.Index.build(pmx.Panman(str(tmp_path / "rsv.panman")), k=15, s=6)
+    back = pmx.Index.load(str(tmp_path / "custom.idx"))
+    assert all(np.array_equal(built.arrays()[k], back.arrays()[k]) for k in ("parent", "offsets", "hash", "parent_count", "child_count"))
+
+
+def test_argument_errors(tmp_path):
+    shutil.copy(os.path.join(GOLDEN, "rsv_4K.panman"), tmp_path / "rsv.panman")
+    assert run([], tmp_path).returncode == 1
+    r = run(["rsv.panman", "-s", "30"], tmp_path)
+    assert r.returncode == 1 and "Invalid syncmer s=30 (must be in 1..k, k=19)" in r.stderr                # src/main.cpp:2227-2230
+    r = run(["rsv.panman", "--offset", "12"], tmp_path)
+    assert r.returncode == 1 and "Invalid syncmer offset=12 (must be in 0..k-s = 0..11)" in r.stderr
+    r = run(["rsv.panman", "-i", "missing.idx"], tmp_path)
+    assert r.returncode == 1 and "index file not found: missing.idx" in r.stderr
+    for opt in (["--meta"], ["--hpc"], ["-a", "bwa"], ["--stop", "nowhere"], ["--no-such-option"]):
+        assert run(["rsv.panman"] + opt, tmp_path).returncode == 1
+
+
+@pytest.mark.gpu
+def test_readme_demo_through_the_cli(pmx, oracle, tmp_path):
+    for f in ("sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz"):
+        shutil.copy(os.path.join(GOLDEN, f), tmp_path / f)
+    r = run(["sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz", "--stop", "align"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    # prefix derived from reads1: "isolate" (.gz and .fastq stripped, then _R1)
+    assert open(tmp_path / "isolate.placement.tsv", "rb").read() == open(os.path.join(GOLDEN, "isolate.placement.tsv"), "rb").read()
+    assert open(tmp_path / "isolate.ref.fa", "rb").read() == open(os.path.join(GOLDEN, "isolate.ref.fa"), "rb").read()
+    fai = open(tmp_path / "isolate.ref.fa.fai").read().split("\t")
+    assert fai[0] == "node_7618" and int(fai[1]) == 29709
+    import test_bam as tb
+    text, refs, recs = tb.parse_bam(str(tmp_path / "isolate.bam"))
+    assert refs == [("node_7618", 29709)] and os.path.exists(tmp_path / "isolate.bam.bai")
+    # against the reference aligner on the same reads
+    g = b"".join(l.strip() for l in open(os.path.join(GOLDEN, "isolate.ref.fa"), "rb") if not l.startswith(b">"))
+    seqs, _, _ = pmx.read_fastq_paired(os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz"))
+    want = oracle.ref_align_reads_direct(g, seqs, True, 8)
+    n_mapped = sum(w["mapped"] for w in want)
+    assert n_mapped == 41003 and len(recs) == 2 * n_mapped
+    assert "41003 of 51169 pairs mapped" in r.stderr
+    assert [x["pos"] for x in recs] == sorted(x["pos"] for x in recs)                        # coordinate sorted
+    want_pos = sorted([w["r1"]["rs"] for w in want if w["mapped"]] + [w["r2"]["rs"] for w in want if w["mapped"]])
+    assert [x["pos"] for x in recs] == want_pos
+    # a second run reuses the index written next to the PanMAN
+    r2 = run(["sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz", "--stop", "place", "-o", "again"], tmp_path)
+    assert r2.returncode == 0 and "(cached)" in r2.stderr
+    assert open(tmp_path / "again.placement.tsv", "rb").read() == open(os.path.join(GOLDEN, "isolate.placement.tsv"), "rb").read()
