@@ -3,7 +3,10 @@
 Short reads: fragment start uniform, insert ~ round(N(300,30)) clamped to [150,600], R1 = first 150 bp
 forward, R2 = reverse complement of the last 150 bp (FR); i.i.d. substitutions at `sub_rate`, no indels,
 no N.  Reads are returned in FASTQ orientation (R2 as sequenced), interleaved R1,R2,...
-RNG: numpy PCG64 seeded with `seed` (documented draw order: starts, inserts, error mask, error bases).
+RNG: numpy PCG64 seeded with `seed` (documented draw order: inserts, starts, error mask, error bases).
+Deviation from SURVEY.md 8d, on purpose: the survey sketches a splitmix64 stream and a source leaf chosen as the
+splitmix64(42) mod 20000-th leaf; this generator uses numpy's PCG64 and callers pass the genome (bench.py: node_7618,
+the node the repository's example sample places on).  Nothing downstream depends on which deterministic stream it is.
 """
 import numpy as np
 

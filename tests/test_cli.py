@@ -59,14 +59,15 @@ def test_readme_demo_through_the_cli(pmx, oracle, tmp_path):
         shutil.copy(os.path.join(GOLDEN, f), tmp_path / f)
     r = run(["sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz", "--stop", "align"], tmp_path)
     assert r.returncode == 0, r.stderr[-2000:]
-    # prefix derived from reads1: "isolate" (.gz and .fastq stripped, then _R1)
-    assert open(tmp_path / "isolate.placement.tsv", "rb").read() == open(os.path.join(GOLDEN, "isolate.placement.tsv"), "rb").read()
-    assert open(tmp_path / "isolate.ref.fa", "rb").read() == open(os.path.join(GOLDEN, "isolate.ref.fa"), "rb").read()
-    fai = open(tmp_path / "isolate.ref.fa.fai").read().split("\t")
+    # prefix derived from reads1 as src/main.cpp:2253-2276 derives it: stem "isolate_R1.fastq", the mate suffixes are
+    # tried FIRST (none matches a stem that still ends in .fastq), then .fastq goes -> "isolate_R1"
+    assert open(tmp_path / "isolate_R1.placement.tsv", "rb").read() == open(os.path.join(GOLDEN, "isolate.placement.tsv"), "rb").read()
+    assert open(tmp_path / "isolate_R1.ref.fa", "rb").read() == open(os.path.join(GOLDEN, "isolate.ref.fa"), "rb").read()
+    fai = open(tmp_path / "isolate_R1.ref.fa.fai").read().split("\t")
     assert fai[0] == "node_7618" and int(fai[1]) == 29709
     import test_bam as tb
-    text, refs, recs = tb.parse_bam(str(tmp_path / "isolate.bam"))
-    assert refs == [("node_7618", 29709)] and os.path.exists(tmp_path / "isolate.bam.bai")
+    text, refs, recs = tb.parse_bam(str(tmp_path / "isolate_R1.bam"))
+    assert refs == [("node_7618", 29709)] and os.path.exists(tmp_path / "isolate_R1.bam.bai")
     # against the reference aligner on the same reads
     g = b"".join(l.strip() for l in open(os.path.join(GOLDEN, "isolate.ref.fa"), "rb") if not l.startswith(b">"))
     seqs, _, _ = pmx.read_fastq_paired(os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz"))
