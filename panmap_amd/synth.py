@@ -17,7 +17,17 @@ for _a, _b in zip(b"ACGT", b"TGCA"):
 
 def simulate_paired_reads(genome: bytes, n_pairs: int, read_len: int = 150, seed: int = 42, sub_rate: float = 0.002,
                           mean_insert: float = 300.0, sd_insert: float = 30.0):
-    """-> (concat uint8 array, offsets int64[n_reads+1]) with n_reads = 2*n_pairs, fixed read_len."""
+    """-> (concat uint8 array, offsets int64[n_reads+1]) with n_reads = 2*n_pairs, fixed read_len.
+    More than a million pairs are drawn in blocks of a million (block c with seed + 1000003 * c), which bounds the
+    generator's memory (the error mask costs 8 bytes per base while it exists); up to a million pairs the stream is the
+    single-block one the committed fixtures were made with."""
+    block = 1000000
+    if n_pairs > block:
+        parts = []
+        for c, lo in enumerate(range(0, n_pairs, block)):
+            part, _ = simulate_paired_reads(genome, min(block, n_pairs - lo), read_len, seed + 1000003 * c, sub_rate, mean_insert, sd_insert)
+            parts.append(part)
+        return np.concatenate(parts), np.arange(2 * n_pairs + 1, dtype=np.int64) * read_len
     g = np.frombuffer(genome, np.uint8)
     G = len(g)
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -233,3 +233,4 @@ def test_golden_fixture_gpu(pmx, ctx):
         bad = ac.compare_results(got, want)
         assert not bad, (name, bad[:10])
         assert sum(1 for x in got if x["flags"] & 3) <= 2
+
