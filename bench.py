@@ -282,6 +282,16 @@ def main():
         out_recs = torch.empty((n_reads, 32), dtype=torch.uint8).pin_memory()
         out_cig = torch.empty(max(n_reads * 16, int(concat.size) // 4, 4096), dtype=torch.int32).pin_memory()
         d_recs = torch.empty((n_reads, 32), dtype=torch.uint8, device=dev)
+        d_cig = torch.empty(out_cig.numel(), dtype=torch.int32, device=dev)
+
+        pool = {}   # read set objects reused from step to step (pmx_readset_rewrap_device: no hipMalloc, offsets handled on the device)
+
+        def read_set(key, d_off_ptr, n):
+            if key in pool:
+                pool[key].rewrap_device(d_concat2.data_ptr(), d_off_ptr, n, int(concat.size), max_len)
+            else:
+                pool[key] = pmx.ReadSet.wrap_device(ctx, d_concat2.data_ptr(), d_off_ptr, n, int(concat.size), max_len)
+            return pool[key]
 
         def step_h2h():
             # offsets first (8 B per read), then the bases chunk by chunk on the copy stream; chunk c is packed and seeded
@@ -289,6 +299,8 @@ def main():
             evs = []
             with torch.cuda.stream(copy_stream):
                 d_off2.copy_(h_off, non_blocking=True)
+                ev_off = torch.cuda.Event()
+                ev_off.record(copy_stream)
                 for c in range(n_chunks):
                     b0, b1 = int(off[bounds[c]]), int(off[bounds[c + 1]])
                     d_concat2[b0:b1].copy_(h_concat[b0:b1], non_blocking=True)
@@ -296,17 +308,18 @@ def main():
                     ev.record(copy_stream)
                     evs.append(ev)
             placer.reset()
+            ctx_stream.wait_event(ev_off)
             parts = []
             for c in range(n_chunks):
                 r0, r1 = bounds[c], bounds[c + 1]
                 if r1 <= r0:
                     continue
-                evs[c].synchronize() if c == 0 else ctx_stream.wait_event(evs[c])   # (wrap_device reads the offsets back)
-                part = pmx.ReadSet.wrap_device(ctx, d_concat2.data_ptr(), d_off2.data_ptr() + 8 * r0, r1 - r0, int(concat.size), max_len)
+                part = read_set(c, d_off2.data_ptr() + 8 * r0, r1 - r0)   # (needs the offsets only)
+                ctx_stream.wait_event(evs[c])
                 part.pack()
                 placer.add_reads(part, params)
                 parts.append(part)
-            whole = pmx.ReadSet.wrap_device(ctx, d_concat2.data_ptr(), d_off2.data_ptr(), n_reads, int(concat.size), max_len)
+            whole = read_set("whole", d_off2.data_ptr(), n_reads)
             whole.pack()
             aligner = place_and_align(parts, total_reads, mean_len, paired, paired, all_rs=whole)
             nw = aligner.cigar_words()
@@ -317,13 +330,11 @@ def main():
             out_recs.copy_(d_recs, non_blocking=True)
             if nw > out_cig.numel():
                 raise RuntimeError("pinned CIGAR buffer too small")
-            d_cig = torch.empty(max(nw, 1), dtype=torch.int32, device=dev)
+            if nw > d_cig.numel():
+                raise RuntimeError("device CIGAR buffer too small")
             aligner.copy_cigars_device(d_cig.data_ptr(), max(nw, 1))
             out_cig[:nw].copy_(d_cig[:nw], non_blocking=True)
             torch.cuda.synchronize()
-            for p_ in parts:
-                p_.close()
-            whole.close()
             return nw
 
         for _ in range(max(1, args.warmup)):
@@ -335,6 +346,8 @@ def main():
         sync_all()
         el2 = max_over_ranks(time.perf_counter() - t0)
         same = bool(np.array_equal(out_recs.numpy().view(pmx.REC_DTYPE).reshape(-1)["rs"], recs["rs"]) and nw_last == len(cig))
+        for p_ in pool.values():
+            p_.close()
         h2h = dict(value=total_reads * args.steps / el2, ms_per_step=el2 / args.steps * 1e3, h2d_chunks=n_chunks,
                    equals_device_resident_run=same,
                    note="pinned host ASCII + offsets -> H2D in %d chunks on a copy stream (chunk c packed + seeded while chunk c+1 is in flight) "

@@ -112,6 +112,10 @@ int pmx_readset_upload(pmx_ctx *ctx, const char *concat, const int64_t *offsets,
 /* wrap ASCII reads already resident in device memory (d_concat: total bytes, d_offsets: n+1 int64) */
 int pmx_readset_wrap_device(pmx_ctx *ctx, const void *d_concat, const void *d_offsets, int64_t n_reads,
                             int64_t total_bytes, int64_t max_read_len, pmx_readset **out);
+/* re-point an existing read set at another batch resident in device memory (streaming: the object's packed-read buffers
+   are reused, the word offsets are computed and the offsets validated on the device; call pmx_readset_pack afterwards) */
+int pmx_readset_rewrap_device(pmx_ctx *ctx, pmx_readset *rs, const void *d_concat, const void *d_offsets, int64_t n_reads,
+                              int64_t total_bytes, int64_t max_read_len);
 int pmx_readset_pack(pmx_ctx *ctx, pmx_readset *rs);
 /* FASTQ quality strings of the same reads (same offsets; one Phred+33 byte per base): only needed for
  * pmx_place_params.min_seed_quality > 0 (allReadQualities, src/placement.cpp:1386) */

@@ -117,6 +117,7 @@ SIGNATURES = {
     "pmx_place_histogram_merge_device_parts": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32]),
     "pmx_place_histogram_merge_device": (_i32, [_vp, _vp, _vp, _vp, _i64]),
     "pmx_align_copy_records_device": (_i32, [_vp, _vp, _vp, _i64]),
+    "pmx_readset_rewrap_device": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     "pmx_index_save": (_i32, [_vp, _cp, _i32, _i32]),
     "pmx_index_load": (_i32, [_cp, _PP]),
     "pmx_index_read_header": (_i32, [_cp, C.POINTER(IndexInfo), C.POINTER(C.c_int)]),

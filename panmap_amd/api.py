@@ -376,6 +376,14 @@ class ReadSet:
         self.total_bases = total_bytes
         return self
 
+    def rewrap_device(self, d_concat_ptr: int, d_offsets_ptr: int, n_reads: int, total_bytes: int, max_len: int = 0, keepalive=None):
+        """point this read set at another batch in device memory (buffers reused, offsets handled on the device)"""
+        check(lib.pmx_readset_rewrap_device(self.ctx._h, self._h, d_concat_ptr, d_offsets_ptr, n_reads, total_bytes, max_len),
+              "pmx_readset_rewrap_device")
+        self._keep = keepalive
+        self.n_reads = n_reads
+        self.total_bases = total_bytes
+
     def pack(self):
         check(lib.pmx_readset_pack(self.ctx._h, self._h), "pmx_readset_pack")
 

@@ -306,6 +306,49 @@ int pmx_readset_wrap_device(pmx_ctx* ctx, const void* d_concat, const void* d_of
     PMX_CATCH
 }
 
+// A read set object re-pointed at another batch in device memory: the word offsets are computed ON THE DEVICE (count
+// kernel + exclusive scan; offsets checked there too) and the packed-read buffers of the object are reused when they are
+// large enough -- the streaming form of pmx_readset_wrap_device (no host pass over the offsets, no hipMalloc per batch).
+// One 24-byte read-back per call.
+int pmx_readset_rewrap_device(pmx_ctx* ctx, pmx_readset* rs, const void* d_concat, const void* d_offsets, int64_t n_reads, int64_t total_bytes,
+                              int64_t max_read_len) {
+    if (!ctx || !rs || !d_concat || !d_offsets || n_reads < 0 || total_bytes < 0) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    rs->packed = false;
+    rs->has_qual = false;
+    rs->n = n_reads;
+    rs->ascii.wrap((uint8_t*)d_concat, (size_t)total_bytes);
+    rs->off.wrap((int64_t*)d_offsets, (size_t)n_reads + 1);
+    rs->nw_tmp.ensure((size_t)n_reads + 1);
+    rs->woff.ensure((size_t)n_reads + 1);
+    rs->stats.ensure(2);
+    PMX_HIP(hipMemsetAsync(rs->stats.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_read_word_counts, dim3(grid_for(n_reads + 1, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rs->off.p, n_reads, total_bytes,
+                       rs->nw_tmp.p, rs->stats.p);
+    size_t bytes = 0;
+    PMX_HIP(rocprim::exclusive_scan(nullptr, bytes, rs->nw_tmp.p, rs->woff.p, (int64_t)0, (size_t)n_reads + 1, rocprim::plus<int64_t>(), ctx->stream));
+    rs->scan_tmp.ensure(bytes);
+    PMX_HIP(rocprim::exclusive_scan(rs->scan_tmp.p, bytes, rs->nw_tmp.p, rs->woff.p, (int64_t)0, (size_t)n_reads + 1, rocprim::plus<int64_t>(), ctx->stream));
+    struct { int64_t n_words; unsigned long long st[2]; } h = {0, {0, 0}};
+    PMX_HIP(hipMemcpyAsync(&h.n_words, rs->woff.p + n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(h.st, rs->stats.p, sizeof(h.st), hipMemcpyDeviceToHost, ctx->stream));
+    int64_t first = 0, last = 0;
+    PMX_HIP(hipMemcpyAsync(&first, rs->off.p, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(&last, rs->off.p + n_reads, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    if (h.st[1]) return fail(PMX_ERR_ARG, "device offsets are not monotone or run outside the wrapped buffer");
+    if (max_read_len > 0 && (int64_t)h.st[0] > max_read_len) return fail(PMX_ERR_ARG, "a read is longer than max_read_len");
+    rs->n_words = h.n_words;
+    rs->max_len = (int64_t)h.st[0];
+    rs->total = last - first;
+    rs->off0 = first;
+    rs->words.ensure((size_t)std::max<int64_t>(h.n_words, 1));
+    rs->amb.ensure((size_t)std::max<int64_t>(h.n_words, 1));
+    return PMX_OK;
+    PMX_CATCH
+}
+
 int pmx_readset_set_qualities(pmx_ctx* ctx, pmx_readset* rs, const char* qual_concat) {
     if (!ctx || !rs || (rs->total > 0 && !qual_concat)) return PMX_ERR_ARG;
     if (rs->off0 != 0) return fail(PMX_ERR_ARG, "qualities need a read set whose offsets start at 0");

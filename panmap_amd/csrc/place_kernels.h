@@ -19,6 +19,9 @@ struct SeedParams {
 
 __global__ void k_pack_reads(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int64_t n_reads, int64_t n_words,
                              uint64_t* words, uint32_t* amb);
+// read -> its number of 32-base words, plus the checks a wrapped read set needs (stats: [0] max length, [1] 1 if offsets are
+// not monotone or leave [0, total_bytes])
+__global__ void k_read_word_counts(const int64_t* off, int64_t n_reads, int64_t total_bytes, int64_t* nwords, unsigned long long* stats);
 __global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin, int64_t n_reads,
                                  SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters,
                                  const uint8_t* keep, const uint8_t* qual, int min_q);

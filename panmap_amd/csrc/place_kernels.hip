@@ -16,6 +16,29 @@ namespace pmx {
 // ------------------------------------------------------------------------------------- pack
 // One thread per output word (32 bases): 2-bit code + ambiguity bit.  Under an ambiguity bit the
 // code field is 3 for 'U'/'u' (minimap2's nt4 table maps U to T, the seeding hash does not) else 0.
+__global__ void k_read_word_counts(const int64_t* __restrict__ off, int64_t n_reads, int64_t total_bytes, int64_t* __restrict__ nwords,
+                                   unsigned long long* stats) {
+    unsigned long long mx = 0, bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_reads; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i == n_reads) { nwords[i] = 0; continue; }   // (the scan's last output = the total)
+        const int64_t a = off[i], b = off[i + 1];
+        const int64_t len = b - a;
+        if (len < 0 || a < 0 || b > total_bytes) { bad = 1; nwords[i] = 0; continue; }
+        nwords[i] = (len + 31) / 32;
+        mx = (unsigned long long)len > mx ? (unsigned long long)len : mx;
+    }
+    // one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long m2 = __shfl_xor(mx, o), b2 = __shfl_xor(bad, o);
+        mx = m2 > mx ? m2 : mx;
+        bad |= b2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mx) atomicMax(&stats[0], mx);
+        if (bad) atomicOr(&stats[1], 1ULL);
+    }
+}
+
 __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ off,
                              const int64_t* __restrict__ woff, int64_t n_reads, int64_t n_words,
                              uint64_t* __restrict__ words, uint32_t* __restrict__ amb) {

@@ -15,5 +15,8 @@ struct pmx_readset {
     pmx::DevBuf<uint32_t> amb;     // 1 bit per base: not A/C/G/T
     pmx::DevBuf<uint8_t> qual;     // optional: Phred+33 per base, same offsets as ascii (--min-seed-quality)
     bool has_qual = false;
+    pmx::DevBuf<int64_t> nw_tmp;   // rewrap: words per read (scan input)
+    pmx::DevBuf<char> scan_tmp;    // rewrap: rocprim temp storage
+    pmx::DevBuf<unsigned long long> stats;
     int64_t off0 = 0;              // first offset (non-zero for a wrapped slice of a larger offsets array)
 };

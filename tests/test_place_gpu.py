@@ -260,3 +260,62 @@ def test_full_size_properties(pmx, ctx, sars, sars_index):
     res = p.score(pmx.TraversalParams(), 2 * (len(off) - 1))
     assert sars.node_id(res.best_index[4]) in {sars.node_id(int(t)) for t in res.tied_indices[4]}
     assert "node_7618" in {sars.node_id(int(t)) for t in res.tied_indices[0]}
+
+
+def test_streaming_read_sets_rewrap_on_the_device(pmx, ctx, sars, sars_index):
+    """pmx_readset_rewrap_device: one read set object pointed at batch after batch in device memory (word offsets and the
+    offset checks on the device, packed buffers reused) gives what fresh uploads give -- also for a slice of a larger offsets
+    array and for ragged reads -- and refuses offsets that leave the buffer"""
+    import torch
+    g = sars.genome("node_7618")
+    dev = torch.device("cuda", 0)
+
+    def fresh_hist(reads):
+        p = pmx.Placer(ctx, sars_index); p.reset(); p.add_reads(pmx.ReadSet(ctx, reads))
+        out = p.histogram(); p.close()
+        return out
+
+    batches = []
+    for seed, n in ((11, 3000), (12, 5000), (13, 1000)):
+        concat, off = pmx.simulate_paired_reads(g, n, seed=seed)
+        batches.append((concat, off))
+    rag = [bytes(batches[0][0][i * 150:i * 150 + (i % 140) + 5]) for i in range(2000)] + [b"", b"ACGTN" * 7]     # ragged, empty, N
+    rc, ro = pmx.concat_reads(rag)
+    batches.append((np.frombuffer(rc, np.uint8).copy(), ro))
+    rs = None
+    for concat, off in batches:
+        d_c = torch.from_numpy(concat).to(dev)
+        d_o = torch.from_numpy(off).to(dev)
+        n = len(off) - 1
+        if rs is None:
+            rs = pmx.ReadSet.wrap_device(ctx, d_c.data_ptr(), d_o.data_ptr(), n, int(concat.size), 0, keepalive=(d_c, d_o))
+        else:
+            rs.rewrap_device(d_c.data_ptr(), d_o.data_ptr(), n, int(concat.size), 0, keepalive=(d_c, d_o))
+        rs.pack()
+        p = pmx.Placer(ctx, sars_index); p.reset(); p.add_reads(rs)
+        hh, hc = p.histogram(); p.close()
+        wh, wc = fresh_hist(_as_reads(concat, off))
+        assert np.array_equal(hh, wh) and np.array_equal(hc, wc)
+        # a slice [r0, r1] of the same offsets array addresses its reads in the same buffer
+        r0, r1 = n // 4 & ~1, n // 2 & ~1
+        if r1 > r0:
+            rs.rewrap_device(d_c.data_ptr(), d_o.data_ptr() + 8 * r0, r1 - r0, int(concat.size), 0, keepalive=(d_c, d_o))
+            rs.pack()
+            p = pmx.Placer(ctx, sars_index); p.reset(); p.add_reads(rs)
+            hh, hc = p.histogram(); p.close()
+            wh, wc = fresh_hist(_as_reads(concat, off)[r0:r1])
+            assert np.array_equal(hh, wh) and np.array_equal(hc, wc)
+    concat, off = batches[0]
+    d_c = torch.from_numpy(concat).to(dev)
+    bad = off.copy(); bad[-1] += 10
+    d_o = torch.from_numpy(bad).to(dev)
+    with pytest.raises(pmx.PmxError):
+        rs.rewrap_device(d_c.data_ptr(), d_o.data_ptr(), len(off) - 1, int(concat.size), 0)
+    bad = off.copy(); bad[5] = bad[7]
+    bad[6] = bad[5] - 3
+    d_o = torch.from_numpy(bad).to(dev)
+    with pytest.raises(pmx.PmxError):
+        rs.rewrap_device(d_c.data_ptr(), d_o.data_ptr(), len(off) - 1, int(concat.size), 0)
+    with pytest.raises(pmx.PmxError):
+        pmx.ReadSet.wrap_device(ctx, d_c.data_ptr(), d_o.data_ptr(), len(off) - 1, int(concat.size), 0)
+    rs.close()
