@@ -21,36 +21,10 @@ PMX_HD float mg_log2f(float x) {
     return log_2;
 }
 
-// comput_sc (lchain.c:113-141), is_cdna == 0
-PMX_HD int32_t chain_score(const A128 ai, const A128 aj, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, float chn_pen_gap,
-                           float chn_pen_skip, int n_seg) {
-    const int32_t dq = (int32_t)ai.y - (int32_t)aj.y;
-    const int32_t sidi = (int32_t)((ai.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
-    const int32_t sidj = (int32_t)((aj.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
-    if (dq <= 0 || dq > max_dist_x) return INT32_MIN;
-    const int32_t dr = (int32_t)(ai.x - aj.x);
-    if (sidi == sidj && (dr == 0 || dq > max_dist_y)) return INT32_MIN;
-    const int32_t dd = dr > dq ? dr - dq : dq - dr;
-    if (sidi == sidj && dd > bw) return INT32_MIN;
-    if (n_seg > 1 && sidi == sidj && dr > max_dist_y) return INT32_MIN;
-    const int32_t dg = dr < dq ? dr : dq;
-    const int32_t q_span = (int32_t)(aj.y >> 32 & 0xff);
-    int32_t sc = q_span < dg ? q_span : dg;
-    if (dd || dg > q_span) {
-        const float lin_pen = chn_pen_gap * (float)dd + chn_pen_skip * (float)dg;
-        const float log_pen = dd >= 1 ? mg_log2f((float)(dd + 1)) : 0.0f;
-        if (sidi != sidj) {
-            if (dr == 0) ++sc;   // overlapping paired ends
-            else sc -= (int)(lin_pen < log_pen ? lin_pen : log_pen);
-        } else sc -= (int)(lin_pen + .5f * log_pen);
-    }
-    return sc;
-}
-
-// The same function on the fields of two packed cells, written without early returns (selects instead of
-// branches: in the thread-per-pair kernel 64 lanes evaluate different anchor pairs at once, and every early return
-// of chain_score costs the wave a divergent branch).  Same integer and float expressions in the same order; the
-// values computed for a pair that chain_score would have rejected early are discarded.
+// comput_sc (lchain.c:113-141; is_cdna == 0): the score of chaining anchor i behind anchor j, evaluated on the anchors'
+// fields without early exits (selects instead of branches: in the thread-per-pair kernels 64 lanes evaluate different
+// anchor pairs at once, and an early return is a divergent branch).  The integer and float expressions are the
+// reference's in the reference's order; what is computed for a pair it rejects is discarded (INT32_MIN).
 PMX_HD int32_t chain_score_sel(uint32_t xi, int32_t yi, int32_t sidi, uint32_t xj, int32_t yj, int32_t sidj, int32_t q_span, int32_t max_dist_x,
                                int32_t max_dist_y, int32_t bw, float chn_pen_gap, float chn_pen_skip, int n_seg) {
     const int32_t dq = yi - yj;
@@ -75,21 +49,12 @@ PMX_HD int32_t chain_score_sel(uint32_t xi, int32_t yi, int32_t sidi, uint32_t x
     return bad ? INT32_MIN : sc;
 }
 
-// mg_chain_bk_end (lchain.c:9-25)
-PMX_HD int64_t chain_bk_end(int32_t max_drop, Ptr<const A128> z, Ptr<ChainCell> c, int64_t k) {
-    PMX_LDS(z); PMX_LDS(c);
-    int64_t i = (int64_t)z[k].y, end_i = -1, max_i = i;
-    int32_t max_s = 0;
-    if (i < 0 || c[i].t != 0) return i;
-    do {
-        c[i].t = 2;
-        end_i = i = c[i].p;
-        const int32_t s = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - c[i].f;
-        if (s > max_s) { max_s = s; max_i = i; }
-        else if (max_s - s > max_drop) break;
-    } while (i >= 0 && c[i].t == 0);
-    for (i = (int64_t)z[k].y; i >= 0 && i != end_i; i = c[i].p) c[i].t = 0;
-    return max_i;
+// the same for two anchors in the reference's packing
+PMX_HD int32_t chain_score(const A128 ai, const A128 aj, int32_t max_dist_x, int32_t max_dist_y, int32_t bw, float chn_pen_gap,
+                           float chn_pen_skip, int n_seg) {
+    return chain_score_sel((uint32_t)ai.x, (int32_t)ai.y, (int32_t)((ai.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT), (uint32_t)aj.x, (int32_t)aj.y,
+                           (int32_t)((aj.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT), (int32_t)(aj.y >> 32 & 0xff), max_dist_x, max_dist_y, bw,
+                           chn_pen_gap, chn_pen_skip, n_seg);
 }
 
 #if PMX_W > 1
@@ -187,8 +152,7 @@ __device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_d
 }
 #endif
 
-#if PMX_W == 1
-// Scalar execution models (thread per pair, host): everything the inner loop of the fill needs from anchor j --
+// The fill for more than 64 anchors (every model) and for the scalar models: everything the inner loop needs from anchor j --
 // reference position, query position, span, segment, f, p, the t mark -- packed into ONE 16-byte cell, so an
 // inner iteration needs one 16-byte cell instead of an anchor load plus a cell load.  Four cells form one 64-byte
 // block (Cell4: its own interleave granule in the thread-per-pair arena, so a lane's block is ONE contiguous line):
@@ -232,7 +196,6 @@ PMX_HD A128 packed_anchor(const PackedCell& c) {
     r.y = (uint64_t)c.seg << PMX_SEED_SEG_SHIFT | (uint64_t)c.span << 32 | c.y_lo;
     return r;
 }
-#endif
 
 // mg_lchain_dp (lchain.c:148-230) followed by mg_chain_backtrack (:27-76) and compact_a (:78-111).
 // In: W.a[0..n_a) sorted anchors.  Out: W.a holds the chained anchors grouped by chain, W.u[0..n_u)
@@ -255,15 +218,20 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
 #else
     const bool wave_fill = false;
 #endif
+    // (wave models: the scalar fill runs redundantly-uniform on the 64 lanes, like the rest of the bookkeeping)
     bool packed_fill = false;
-#if PMX_W == 1
-    {
+    if (!wave_fill) {
         int qsum = 0;
         for (int sg = 0; sg < W.n_segs; ++sg) qsum += W.qlen[sg];
         packed_fill = n < 65535 && qsum < 65536;
+        if (!packed_fill) {   // reads of 64 kb and more: the packed cells do not hold their positions
+            W.status |= PMX_ST_UNSUPPORTED;
+            W.n_a = 0;
+            return;
+        }
     }
     if (packed_fill) {
-        Ptr<Cell4> pk4 = ptr_region_cast<Cell4>(W.z);   // z[] is idle until the backtrack
+        Ptr<Cell4> pk4 = ptr_region_cast<Cell4>(W.z); PMX_LDS(pk4);   // z[] is idle until the backtrack
         int64_t st = 0, max_ii = -1;
         uint64_t x_st = a[0].x, x_mi = 0;   // a[st].x and a[max_ii].x, kept in registers
         int32_t f_mi = 0;                   // f[max_ii]
@@ -369,56 +337,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
             if (max_ii < 0 || ((int64_t)(ai.x - x_mi) <= (int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = ai.x; f_mi = max_f; }
         }
     }
-#endif
-    if (!wave_fill && !packed_fill) {
-        for (int64_t i = 0; i < n; ++i) c[i].t = 0;
-        int64_t st = 0, max_ii = -1;
-        for (int64_t i = 0; i < n; ++i) {
-            int64_t max_j = -1, end_j;
-            const A128 ai = a[i];
-            int32_t max_f = (int32_t)(ai.y >> 32 & 0xff), n_skip = 0;
-            while (st < i && (ai.x >> 32 != a[st].x >> 32 || ai.x > a[st].x + (uint64_t)max_dist_x)) ++st;
-            if (i - st > max_iter) st = i - max_iter;
-            int64_t j;
-            for (j = i - 1; j >= st; --j) {
-                int32_t sc = chain_score(ai, a[j], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
-                if (sc == INT32_MIN) continue;
-                const ChainCell cj = c[j];
-                sc += cj.f;
-                if (sc > max_f) {
-                    max_f = sc;
-                    max_j = j;
-                    if (n_skip > 0) --n_skip;
-                } else if (cj.t == (int32_t)i) {
-                    if (++n_skip > max_skip) break;
-                }
-                if (cj.p >= 0) c[cj.p].t = (int32_t)i;
-            }
-            end_j = j;
-            if (max_ii < 0 || (int64_t)(ai.x - a[max_ii].x) > (int64_t)max_dist_x) {
-                int32_t mx = INT32_MIN;
-                max_ii = -1;
-                for (j = i - 1; j >= st; --j) {
-                    const int32_t fj = c[j].f;
-                    if (mx < fj) { mx = fj; max_ii = j; }
-                }
-            }
-            if (max_ii >= 0 && max_ii < end_j) {
-                const int32_t tmp = chain_score(ai, a[max_ii], max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
-                const int32_t fm = c[max_ii].f;
-                if (tmp != INT32_MIN && max_f < tmp + fm) { max_f = tmp + fm; max_j = max_ii; }
-            }
-            {
-                const int32_t vm = max_j >= 0 ? c[max_j].v : 0;
-                ChainCell ci = c[i];
-                ci.f = max_f;
-                ci.p = (int32_t)max_j;
-                ci.v = max_j >= 0 && vm > max_f ? vm : max_f;
-                c[i] = ci;
-            }
-            if (max_ii < 0 || ((int64_t)(ai.x - a[max_ii].x) <= (int64_t)max_dist_x && c[max_ii].f < max_f)) max_ii = i;
-        }
-    }
+    wave_sync();
 
     PMX_STAMP(W, 18);
     // ---- backtrack (lchain.c:27-76)
@@ -469,25 +388,37 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
             } else n_v = n_v0;
         }
     } else {
-    for (int64_t i = 0; i < n; ++i) c[i].t = 0;
-    // (the reference runs this loop twice, first only to size u[]; one pass gives the same u[] and v[])
-    // (scan to the next unused chain end, then trace it: the lanes of a wave meet at the trace)
-    for (int64_t k = n_z - 1; k >= 0; --k) {
-        for (; k >= 0; --k)
-            if (c[z[k].y].t == 0) break;
-        if (k < 0) break;
-        {
+        // More than 64 anchors: the same single walk with the "used" marks in the cells' t field (0 free, 1 in a kept chain).
+        // The reference walks a chain to its drop point with temporary marks, un-marks it and traces the best prefix in a
+        // second pass; the predecessor links strictly decrease, so a walk never meets its own marks and one pass that
+        // remembers how many of the visited anchors precede the best cut is the same thing.
+        for (int64_t i = 0; i < n; ++i) c[i].t = 0;
+        wave_sync();
+        for (int64_t k = n_z - 1; k >= 0; --k) {
+            const A128 zk = z[k];
+            int64_t i = (int64_t)zk.y;
+            if (c[i].t != 0) continue;
+            const int32_t zx = (int32_t)zk.x;
             const int64_t n_v0 = n_v;
-            const int64_t end_i = chain_bk_end(max_drop, z, c, k);
-            int64_t i;
-            for (i = (int64_t)z[k].y; i != end_i; i = c[i].p) { c[n_v++].v = (int32_t)i; c[i].t = 1; }
-            const int32_t sc = i < 0 ? (int32_t)z[k].x : (int32_t)z[k].x - c[i].f;
-            if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
-                if (n_u < W.caps.max_reg * 4) u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint64_t)(n_v - n_v0);
+            int64_t seen = 0, keep = 0;
+            int32_t max_s = 0;
+            do {
+                c[n_v0 + seen].v = (int32_t)i;
+                ++seen;
+                i = c[i].p;
+                const int32_t s_ = i < 0 ? zx : zx - c[i].f;
+                if (s_ > max_s) { max_s = s_; keep = seen; }
+                else if (max_s - s_ > max_drop) break;
+            } while (i >= 0 && c[i].t == 0);
+            wave_sync();
+            for (int64_t q = 0; q < keep; ++q) c[c[n_v0 + q].v].t = 1;   // used, whether or not the chain is then accepted
+            wave_sync();
+            n_v = n_v0 + keep;
+            if (max_s >= min_sc && keep > 0 && keep >= min_cnt) {
+                if (n_u < W.caps.max_reg * 4) u[n_u++] = (uint64_t)(uint32_t)max_s << 32 | (uint64_t)keep;
                 else { W.status |= PMX_ST_OVERFLOW; n_v = n_v0; }
             } else n_v = n_v0;
         }
-    }
     }
     if (n_u == 0) { W.n_a = 0; W.n_u = 0; return; }
 

@@ -882,6 +882,10 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
                                pl->tree_done.p, pl->tree_epoch, pl->tree_done.p + pl->n_nodes);
         }
         tree_kernel = true;
+        if (getenv("PMX_PLACE_TEST_STARVED")) {   // tests: pretend a wave gave up, so that the level-kernel redo runs
+            const uint32_t one = 1;
+            PMX_HIP(hipMemcpyAsync(pl->tree_done.p + pl->n_nodes, &one, sizeof(one), hipMemcpyHostToDevice, st));
+        }
     } else if (getenv("PMX_PLACE_NO_GRAPH")) launch_levels();
     else {
         if (!pl->level_graph_exec || pl->level_graph_sig[0] != sig[0] || pl->level_graph_sig[1] != sig[1] || pl->level_graph_sig[2] != sig[2]) {
@@ -897,19 +901,30 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
         PMX_HIP(hipGraphLaunch(pl->level_graph_exec, st));
     }
     timer_end(ctx, "score", 1);
-    hipLaunchKernelGGL(k_score_getters, dim3(grid_for(pl->n_nodes, 256, G)), dim3(256), 0, st, pl->metrics5.p, pl->counts2.p, pl->n_nodes, pl->scalars.p,
-                       n_kept, pl->scores5.p, pl->level_nodes.p, pl->scores_bfs.p);
-    PMX_HIP(hipGetLastError());
-    pl->h_scores.resize(5 * (size_t)pl->n_nodes);
-    PMX_HIP(hipMemcpyAsync(pl->h_scores.data(), pl->scores_bfs.p, sizeof(double) * 5 * (size_t)pl->n_nodes, hipMemcpyDeviceToHost, st));
-    PMX_HIP(hipMemcpyAsync(h_scal, pl->scalars.p, sizeof(h_scal), hipMemcpyDeviceToHost, st));
     uint32_t tree_status = 0;
-    if (tree_kernel) PMX_HIP(hipMemcpyAsync(&tree_status, pl->tree_done.p + pl->n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    PMX_HIP(hipStreamSynchronize(st));
+    auto finish = [&]() {   // node scores from the accumulators, everything the host needs back in one synchronisation
+        hipLaunchKernelGGL(k_score_getters, dim3(grid_for(pl->n_nodes, 256, G)), dim3(256), 0, st, pl->metrics5.p, pl->counts2.p, pl->n_nodes, pl->scalars.p,
+                           n_kept, pl->scores5.p, pl->level_nodes.p, pl->scores_bfs.p);
+        PMX_HIP(hipGetLastError());
+        pl->h_scores.resize(5 * (size_t)pl->n_nodes);
+        PMX_HIP(hipMemcpyAsync(pl->h_scores.data(), pl->scores_bfs.p, sizeof(double) * 5 * (size_t)pl->n_nodes, hipMemcpyDeviceToHost, st));
+        PMX_HIP(hipMemcpyAsync(h_scal, pl->scalars.p, sizeof(h_scal), hipMemcpyDeviceToHost, st));
+        if (tree_kernel) PMX_HIP(hipMemcpyAsync(&tree_status, pl->tree_done.p + pl->n_nodes, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PMX_HIP(hipStreamSynchronize(st));
+    };
+    finish();
     mark("terms + tree scoring + getters + D2H of the scores");
     if (tree_status != 0) {
+        // The persistent kernel is only correct while all of its workgroups are resident; a wave that polled 2^24 times
+        // without seeing its parent's flag gave up (the GPU is shared with another process, or with collectives in
+        // flight).  The level kernels need no co-residency and add the same terms in the same order: redo with them.
         PMX_HIP(hipMemsetAsync(pl->tree_done.p + pl->n_nodes, 0, sizeof(uint32_t), st));
-        throw std::runtime_error("k_score_tree: a wave timed out waiting for its parent node");
+        tree_kernel = false;
+        tree_status = 0;
+        launch_levels();
+        PMX_HIP(hipGetLastError());
+        finish();
+        mark("level-kernel redo after a starved persistent launch");
     }
 
     // ---- sequential best/tie rule in BFS visit order (src/placement.cpp:355-401)

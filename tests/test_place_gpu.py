@@ -319,3 +319,13 @@ def test_streaming_read_sets_rewrap_on_the_device(pmx, ctx, sars, sars_index):
     with pytest.raises(pmx.PmxError):
         pmx.ReadSet.wrap_device(ctx, d_c.data_ptr(), d_o.data_ptr(), len(off) - 1, int(concat.size), 0)
     rs.close()
+
+
+def test_scoring_redone_with_level_kernels_when_the_persistent_launch_starves(pmx, oracle, ctx, sars, sars_index, monkeypatch):
+    """the heavy-path scoring kernel spin-waits on flags and needs all of its workgroups resident; when a wave
+    gives up (shared GPU) the call must not fail but redo the scoring with the level kernels -- the same bits"""
+    g = sars.genome("node_7618")
+    concat, off = pmx.simulate_paired_reads(g, 1500, seed=8)
+    reads = _as_reads(concat, off)
+    monkeypatch.setenv("PMX_PLACE_TEST_STARVED", "1")
+    _check_place(pmx, oracle, ctx, sars_index, reads)
