@@ -577,7 +577,7 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, 32, ctx->stream));
             perm = pl->sk_idx2.p;
         }
-        const size_t lds_ks = lds + 16 + (size_t)PMX_SEED_CACHE * 12;
+        const size_t lds_ks = lds + 16 + (size_t)PMX_SEED_CACHE * 14;   // keys 8 B + counts 4 B + admission tags 2 B
         for (int attempt = 0; attempt < 2; ++attempt) {
         // A launch of one chunk is latency-bound (every wave walks its 150 bases one after the other, a few waves per
         // SIMD): the chunks of a group run concurrently on side streams, sharing the table (all they do is atomics).

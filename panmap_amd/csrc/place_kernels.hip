@@ -422,9 +422,14 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
     // the seed to the table directly.  Sums commute: same histogram (and with unsorted or low-coverage reads nothing is
     // lost but the cache's few instructions).  512 entries measured best (128: 3.0 ms, 256: 2.6, 512: 2.5, 1024: 2.8,
     // 2048: 3.7 for the stage: a larger cache costs resident blocks and a longer flush).
+    // Admission filter (round 2): two thirds of a block's distinct seeds are sequencing-error singletons; taking slots
+    // first come first served they kept the sample's true seeds (seen dozens of times per block) out of half of the cache.
+    // A seed is now admitted on its SECOND sighting: the first one leaves a 16-bit tag in the slot's side word and goes to
+    // the table itself, so singletons cost the one atomic they always cost and never hold a slot.
     unsigned long long* ckey = reinterpret_cast<unsigned long long*>(lds + (size_t)(2 * W + l) * PMX_SEED_BLOCK + (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP + 2);
     uint32_t* ccnt = reinterpret_cast<uint32_t*>(ckey + PMX_SEED_CACHE);
-    for (int i = tid; i < PMX_SEED_CACHE; i += PMX_SEED_BLOCK) { ckey[i] = PMX_EMPTY_KEY; ccnt[i] = 0; }
+    uint16_t* ctag = reinterpret_cast<uint16_t*>(ccnt + PMX_SEED_CACHE);
+    for (int i = tid; i < PMX_SEED_CACHE; i += PMX_SEED_BLOCK) { ckey[i] = PMX_EMPTY_KEY; ccnt[i] = 0; ctag[i] = 0; }
     __syncthreads();
     auto drain = [&]() {   // called with the wave's in-loop lanes converged; strides over the ACTIVE lanes
         const unsigned long long act = __ballot(1);
@@ -433,9 +438,16 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
         for (int q = rank; q < n_q; q += n_act) {
             const uint64_t h = queue[q];
             if (h == PMX_EMPTY_KEY) { table_insert(keys, vals, mask, h, 1ULL, counters); continue; }   // (the sentinel value itself)
-            const uint32_t cs = (uint32_t)mix64(h) & (PMX_SEED_CACHE - 1);
-            const unsigned long long prev = atomicCAS(&ckey[cs], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)h);
-            if (prev == PMX_EMPTY_KEY || prev == h) {
+            const uint64_t hm = mix64(h);
+            const uint32_t cs = (uint32_t)hm & (PMX_SEED_CACHE - 1);
+            const uint16_t tag = (uint16_t)((hm >> 40) | 1u);
+            unsigned long long cur = ckey[cs];
+            if (cur == PMX_EMPTY_KEY) {
+                if (ctag[cs] != tag) { ctag[cs] = tag; continue; }   // first sighting: to the table (stays queued)
+                cur = atomicCAS(&ckey[cs], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)h);
+                if (cur == PMX_EMPTY_KEY) cur = h;
+            }
+            if (cur == h) {
                 atomicAdd(&ccnt[cs], 1u);
                 queue[q] = PMX_EMPTY_KEY;
             }
