@@ -45,6 +45,10 @@ int64_t pmx_panman_parent(const pmx_panman *pm, int64_t dfs_index);
 int64_t pmx_panman_find_node(const pmx_panman *pm, const char *node_id); /* -1 if absent */
 /* writes the ungapped genome (no NUL) into buf if cap suffices; always returns its length */
 int64_t pmx_panman_node_genome(const pmx_panman *pm, int64_t dfs_index, char *buf, int64_t cap);
+/* test hook (src/test/test_index.cpp:145-193 injects the same mutation into a loaded tree): appends a pure
+ * inversion of the largest forward block with >= min_bases bases to the node's block mutations; returns the
+ * block id, or -1 when the node has no such block */
+int64_t pmx_panman_test_invert_block(pmx_panman *pm, int64_t dfs_index, int min_bases);
 
 /* ------------------------------------------------------------------------------------------
  * Seed index (host).  Replaces IndexBuilder::buildIndexParallel (src/index_single_mode.hpp:207-214)

@@ -86,6 +86,7 @@ SIGNATURES = {
     "pmx_panman_parent": (_i64, [_vp, _i64]),
     "pmx_panman_find_node": (_i64, [_vp, _cp]),
     "pmx_panman_node_genome": (_i64, [_vp, _i64, _vp, _i64]),
+    "pmx_panman_test_invert_block": (_i64, [_vp, _i64, _i32]),
     "pmx_index_build": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _PP]),
     "pmx_index_build_ex": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _PP]),
     "pmx_index_from_arrays": (_i32, [C.POINTER(IndexInfo), _vp, _vp, _vp, _vp, _vp, _PP]),

@@ -68,6 +68,32 @@ int64_t pmx_panman_node_genome(const pmx_panman* pm, int64_t i, char* buf, int64
     }
 }
 
+int64_t pmx_panman_test_invert_block(pmx_panman* pm, int64_t i, int min_bases) {
+    if (!pm || i < 0 || i >= (int64_t)pm->pm.nodes.size()) return -1;
+    try {
+        const pmx::Panman& P = pm->pm;
+        std::vector<int32_t> path;
+        for (int32_t x = (int32_t)i; x >= 0; x = P.nodes[x].parent) path.push_back(x);
+        pmx::PanmanState st;
+        st.init(P);
+        for (auto it = path.rbegin(); it != path.rend(); ++it) pmx::apply_node(P, *it, st, nullptr, nullptr);
+        int32_t best = -1;
+        int64_t best_len = 0;
+        for (int32_t b = 0; b < P.n_blocks; ++b) {
+            if (!st.block_exists[b] || !st.block_fwd[b]) continue;
+            int64_t bases = 0;
+            for (uint32_t c = P.block_col0[b]; c < P.block_col0[b + 1]; ++c)
+                bases += st.cols[c] != '-' && st.cols[c] != 'x';
+            if (bases >= min_bases && bases > best_len) { best_len = bases; best = b; }
+        }
+        if (best >= 0) pm->pm.nodes[i].block_muts.push_back(pmx::BlockMut{best, false, true});
+        return best;
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return -1;
+    }
+}
+
 int pmx_index_build(const pmx_panman* pm, int k, int s, int t, int l, int open_syncmer, int flank_mask, pmx_index** out) {
     return pmx_index_build_ex(pm, k, s, t, l, open_syncmer, flank_mask, 0, -1, out);
 }

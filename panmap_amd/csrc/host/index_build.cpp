@@ -1,5 +1,10 @@
 // Incremental DFS index producer (see index_build.hpp).
 //
+// Inverted blocks (rsv_4K: 93 inverted block insertions) are handled by walking GENOME-ORDER coordinates (see
+// Builder::mirror): a strand flip dirties its whole block, whose k-mers are then re-seeded in the new orientation
+// (src/index_single_mode.cpp:28-427 does the same with its strand-flip recompute).  Pinned by the reference's own test
+// contract (src/test/test_index.cpp:80-110, 145-264: seeds reconstructed from the index deltas == seeds extracted from
+// the genome) on rsv_4K and on synthetic pure inversions, tests/test_host_stage.py.
 // Rule implemented (validated end-to-end against the reference's golden placement TSV, SURVEY.md
 // Appendix E-4/E-7):
 //   * apply the node's mutations to the column array, recording each mutated column range;
@@ -54,30 +59,44 @@ struct Builder {
 
     Builder(const Panman& pm_, const SyncmerParams& p_, int flank_) : pm(pm_), p(p_), flank(flank_) { st.init(pm); }
 
-    inline bool is_base(uint32_t c) const {
-        char ch = st.cols[c];
-        return ch != '-' && ch != 'x' && st.block_exists[pm.col_block[c]];
+    // GENOME-ORDER coordinates.  The genome of a node is its existing blocks in id order, an inverted block contributing
+    // the reverse complement of its columns (src/panmap_utils.cpp:134-180).  Everything below walks positions x in
+    // [0, n_cols) in genome order: x is the column itself in a forward block and the column mirrored inside its block
+    // in an inverted one (an involution: the same formula maps back), and the base at x is complemented there.  With no
+    // inverted block x == column throughout.
+    inline uint32_t mirror(uint32_t x) const {
+        const uint32_t b = pm.col_block[x];
+        return st.block_fwd[b] ? x : pm.block_col0[b] + pm.block_col0[b + 1] - 1 - x;
     }
-    // smallest base column >= c, or n_cols
-    uint32_t next_base(uint32_t c) const {
+    inline char base_at(uint32_t x) const {
+        const uint32_t b = pm.col_block[x];
+        const char ch = st.cols[st.block_fwd[b] ? x : pm.block_col0[b] + pm.block_col0[b + 1] - 1 - x];
+        return st.block_fwd[b] || ch == '-' || ch == 'x' ? ch : complement_iupac(ch);
+    }
+    inline bool is_base(uint32_t x) const {
+        const char ch = st.cols[mirror(x)];
+        return ch != '-' && ch != 'x' && st.block_exists[pm.col_block[x]];
+    }
+    // smallest base position >= x, or n_cols
+    uint32_t next_base(uint32_t x) const {
         const uint32_t n = pm.n_cols;
-        while (c < n) {
-            uint32_t b = pm.col_block[c];
-            if (!st.block_exists[b]) { c = pm.block_col0[b + 1]; continue; }
-            char ch = st.cols[c];
-            if (ch != '-' && ch != 'x') return c;
-            ++c;
+        while (x < n) {
+            uint32_t b = pm.col_block[x];
+            if (!st.block_exists[b]) { x = pm.block_col0[b + 1]; continue; }
+            char ch = st.cols[mirror(x)];
+            if (ch != '-' && ch != 'x') return x;
+            ++x;
         }
         return n;
     }
-    // largest base column <= c, or -1
-    int64_t prev_base(int64_t c) const {
-        while (c >= 0) {
-            uint32_t b = pm.col_block[c];
-            if (!st.block_exists[b]) { c = (int64_t)pm.block_col0[b] - 1; continue; }
-            char ch = st.cols[c];
-            if (ch != '-' && ch != 'x') return c;
-            --c;
+    // largest base position <= x, or -1
+    int64_t prev_base(int64_t x) const {
+        while (x >= 0) {
+            uint32_t b = pm.col_block[x];
+            if (!st.block_exists[b]) { x = (int64_t)pm.block_col0[b] - 1; continue; }
+            char ch = st.cols[mirror((uint32_t)x)];
+            if (ch != '-' && ch != 'x') return x;
+            --x;
         }
         return -1;
     }
@@ -112,9 +131,11 @@ struct Builder {
         std::vector<ColRange> ranges;
         apply_node(pm, ni, st, &u.cols, &ranges);
         if (ranges.empty()) return;
-        for (int32_t b = 0; b < pm.n_blocks; ++b)
-            if (st.block_exists[b] && !st.block_fwd[b])
-                throw std::runtime_error("index build: inverted blocks are not supported yet (node " + pm.nodes[ni].id + ")");
+        for (ColRange& r : ranges) {   // column ranges (each inside one block) -> genome-order ranges
+            const uint32_t xa = mirror(r.a), xb = mirror(r.b);
+            r.a = std::min(xa, xb);
+            r.b = std::max(xa, xb);
+        }
         std::sort(ranges.begin(), ranges.end(), [](const ColRange& x, const ColRange& y) { return x.a < y.a; });
         std::vector<ColRange> merged;
         for (const ColRange& r : ranges) {
@@ -162,7 +183,7 @@ struct Builder {
                     if ((int64_t)c <= R) ++n_starts;
                     else if (lc.size() >= n_starts + (size_t)(K - 1)) break;
                     lc.push_back(c);
-                    lseq.push_back(st.cols[c]);
+                    lseq.push_back(base_at(c));
                     ++c;
                 }
                 host_syncmers(lseq.data(), (int64_t)lseq.size(), p, is_sync, shash);
@@ -318,7 +339,8 @@ void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, 
         out.parent[i] = pm.nodes[i].parent < 0 ? 0u : (uint32_t)pm.nodes[i].parent;
     }
     if (n == 0) return;
-    if (mode == 1 || (mode == 0 && has_inverted_blocks(pm))) {
+    (void)has_inverted_blocks;
+    if (mode == 1) {
         build_from_scratch(pm, p, flank_mask, max_nodes, out);
         return;
     }

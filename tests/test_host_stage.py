@@ -131,13 +131,83 @@ def test_incremental_and_from_scratch_producers_agree(pmx, sars):
         assert np.array_equal(a[key], b[key]), key      # the first 20 nodes of the DFS have equal-length genomes
 
 
-def test_inverted_block_panman_indexes_from_scratch(pmx):
-    """rsv_4K (src/test/data, 93 inverted block insertions): the automatic mode falls back to the from-scratch
-    producer; every node's reconstructed seed multiset equals the direct extraction of its genome"""
+def _path_to_root(parent, nd):
+    path = []
+    x = int(nd)
+    while True:
+        path.append(x)
+        if x == 0:
+            return path[::-1]
+        x = int(parent[x])
+
+
+def _reconstruct(a, off, nd, check_parent_counts=False):
+    counts = {}
+    for p in _path_to_root(a["parent"], nd):
+        sl = slice(off[p], off[p + 1])
+        for hh, pc, cc in zip(a["hash"][sl].tolist(), a["parent_count"][sl].tolist(), a["child_count"][sl].tolist()):
+            if check_parent_counts:
+                assert counts.get(hh, 0) == pc
+            if cc:
+                counts[hh] = cc
+            else:
+                counts.pop(hh, None)
+    return counts
+
+
+def _direct(oracle, genome, k, s):
+    want = {}
+    for h, _, _, _ in oracle.rolling_syncmers(genome, k, s, False, 0, False):
+        want[h] = want.get(h, 0) + 1
+    return want
+
+
+def test_rsv_incremental_producer_equals_from_scratch_and_direct_extraction(pmx, oracle):
+    """rsv_4K (src/test/data; multi-block, gap lists, inverted block insertions) at the reference's own test
+    setting K=15, S=8, L=1, flank 0 (src/test/test_index.cpp:16): the incremental producer walks inverted
+    blocks in genome order and must equal the from-scratch producer array for array; offsets / parent counts
+    are consistent along root paths (:41-78) and the reconstructed multiset of sampled nodes equals the direct
+    extraction of their genomes (:80-110)"""
     rsv = pmx.Panman(os.path.join(GOLDEN, "rsv_4K.panman"))
-    idx = pmx.Index.build(rsv, k=19, s=8, t=0, l=1, flank_mask=0, max_nodes=400)
-    a = idx.arrays()
-    assert int(a["offsets"][400]) == len(a["hash"]) > 0
+    a = pmx.Index.build(rsv, k=15, s=8, t=0, l=1, flank_mask=0, mode=2).arrays()
+    b = pmx.Index.build(rsv, k=15, s=8, t=0, l=1, flank_mask=0, mode=1).arrays()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    off = a["offsets"].astype(np.int64)
+    n = len(off) - 1
+    assert off[0] == 0 and np.all(np.diff(off) >= 0) and off[-1] == len(a["hash"])
+    assert np.all(a["parent_count"] != a["child_count"])
+    rng = np.random.default_rng(5)
+    for nd in [0, rsv.find_node("MZ515733.1"), rsv.find_node("node_1330")] + rng.integers(0, n, 5).tolist():
+        assert _reconstruct(a, off, nd, check_parent_counts=True) == _direct(oracle, rsv.genome(nd), 15, 8)
+
+
+def test_injected_block_inversions_reconstruct_like_direct_extraction(pmx, oracle):
+    """src/test/test_index.cpp:145-264: pure inversions of the largest forward block injected at 25 leaves; the
+    incremental index of the mutated tree reconstructs every injected and control leaf to the direct extraction
+    of its (changed) genome, and equals the from-scratch index"""
+    rsv = pmx.Panman(os.path.join(GOLDEN, "rsv_4K.panman"))
+    n = rsv.num_nodes
+    parents = np.array([rsv.parent(i) for i in range(n)])
+    is_leaf = np.ones(n, bool)
+    is_leaf[parents[1:]] = False
+    leaves = np.flatnonzero(is_leaf)
+    np.random.default_rng(7).shuffle(leaves)
+    injected, before = [], {}
+    for nd in leaves[:25].tolist():
+        before[nd] = rsv.genome(nd)
+        assert pmx.lib.pmx_panman_test_invert_block(rsv._h, nd, 15) >= 0
+        injected.append(nd)
+    controls = leaves[25:45].tolist()
+    # one of these leaves' largest forward block is a run of N, which is its own reverse complement
+    assert sum(rsv.genome(nd) != before[nd] for nd in injected) >= 24
+    a = pmx.Index.build(rsv, k=15, s=8, t=0, l=1, flank_mask=0, mode=2).arrays()
+    b = pmx.Index.build(rsv, k=15, s=8, t=0, l=1, flank_mask=0, mode=1).arrays()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    off = a["offsets"].astype(np.int64)
+    for nd in injected + controls:
+        assert _reconstruct(a, off, nd) == _direct(oracle, rsv.genome(nd), 15, 8), nd
 
 
 def test_fastq_readers(pmx, tmp_path):
