@@ -586,6 +586,71 @@ struct CSeeder {
     }
 };
 
+// (w,k)-minimizers of a read without ambiguous bases, k odd, when no window holds its minimum twice: then sketch.c:77-143
+// emits exactly the distinct minima of the full windows (w consecutive k-mers) from left to right -- or, for a read with
+// fewer than w k-mers, the minimum of all of them.  k odd: no k-mer equals its reverse complement, so the window
+// advances at every base.  The minima come from block prefix / suffix minima (blocks of W k-mers; the window that ends
+// at offset r of a block = the previous block's suffix from r+1 and this block's prefix up to r), three comparisons per
+// k-mer with every slot index a compile-time constant, instead of the branch-free W-slot ring scan of sketch_core.
+// Returns false when two k-mers that share a window tie for a minimum (the duplicate-emission rules of sketch.c:107-139
+// would apply): the caller hands the pair to the general tier.  Pushes arrive in the same order as sketch_core's.
+template <int W, class BaseFn, class PushFn>
+PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
+    const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
+    const int n_k = len - k + 1;
+    if (n_k <= 0) return true;
+    uint64_t kmer0 = 0, kmer1 = 0;
+    for (int i = 0; i < k - 1; ++i) {
+        const int c = base_at(i);
+        kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+        kmer1 = (kmer1 >> 2) | (uint64_t)(3 ^ c) << shift1;
+    }
+    // slot r: until step r of the current block the previous block's suffix minimum from offset r, afterwards the
+    // block's own k-mer r
+    uint64_t sx[W];
+    uint32_t sy[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) { sx[r] = UINT64_MAX; sy[r] = 0xffffffffu; }
+    uint64_t px = UINT64_MAX;
+    uint32_t py = 0xffffffffu, last_y = 0xffffffffu;
+    bool tie = false;
+    for (int e0 = 0; e0 < n_k; e0 += W) {
+        px = UINT64_MAX; py = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+            const int e = e0 + r;
+            uint64_t x = UINT64_MAX;
+            uint32_t y = 0xffffffffu;
+            if (e < n_k) {
+                const int i = e + k - 1;
+                const int c = base_at(i);
+                kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+                kmer1 = (kmer1 >> 2) | (uint64_t)(3 ^ c) << shift1;
+                const uint32_t z = kmer0 < kmer1 ? 0u : 1u;
+                x = mz_hash64(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)k;
+                y = (uint32_t)i << 1 | z;
+                tie |= x == px;
+                if (x < px) { px = x; py = y; }
+                uint64_t wx = px;
+                uint32_t wy = py;
+                if (r + 1 < W) {
+                    tie |= sx[r + 1 < W ? r + 1 : 0] == px;
+                    if (sx[r + 1 < W ? r + 1 : 0] < px) { wx = sx[r + 1 < W ? r + 1 : 0]; wy = sy[r + 1 < W ? r + 1 : 0]; }
+                }
+                if (e >= W - 1 && wy != last_y) { push(wx, (uint64_t)wy); last_y = wy; }
+            }
+            sx[r] = x; sy[r] = y;
+        }
+#pragma unroll
+        for (int r = W - 2; r >= 1; --r) {
+            tie |= sx[r] == sx[r + 1] && sx[r] != UINT64_MAX;
+            if (sx[r + 1] < sx[r]) { sx[r] = sx[r + 1]; sy[r] = sy[r + 1]; }
+        }
+    }
+    if (n_k < W) push(px, (uint64_t)py);
+    return !tie;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PMX_C_STAMP(k) do { if (prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
 #else
@@ -603,7 +668,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
 #endif
     const int k = o.k, w = o.w;
     const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
-    if (qlen0 > PMX_C_MAXLEN || qlen1 > PMX_C_MAXLEN || qlen0 <= 0 || qlen1 <= 0 || w < 1 || w > 12 || 2 * k + 11 > 64 || k > 255 || !o.is_sr_like)
+    if (qlen0 > PMX_C_MAXLEN || qlen1 > PMX_C_MAXLEN || qlen0 <= 0 || qlen1 <= 0 || w != PMX_C_W || !(k & 1) || 2 * k + 11 > 64 || k > 255 || !o.is_sr_like)
         return PMX_C_BAIL;
     if (sizeof(PT) == 2 ? ri.len > 32767 : ri.len > 0x3fffffff) return PMX_C_BAIL;   // position << 1 | strand must fit PT
     for (int s = 0; s < 2; ++s)   // an ambiguous base anywhere: general tier
@@ -619,7 +684,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             sd.r.w = s ? r1.w : r0.w; sd.r.len = s ? r1.len : r0.len; sd.r.flip = s ? r1.flip : r0.flip;
             sd.seg = s; sd.sum = s ? qlen0 : 0;
             sd.n_q = 0; sd.first_of_read = true; sd.ovf = false; sd.cw = 0; sd.ck = -1;
-            sketch_core<12>(sd.r.len, w, k, 0, sd, sd);
+            if (!sketch_distinct<PMX_C_W>(sd.r.len, k, sd, sd)) sd.bail = true;
             PMX_C_STAMP(0);
             if (sd.ovf) sd.bail = true;
             sd.drain(true);

@@ -1,5 +1,6 @@
 // Capacities of the compact align tier (aln_compact.hpp), shared with the host launcher.
 #pragma once
+#define PMX_C_W 11              // minimizer window of the tier's sketch (the preset's, src/mm_align.c:140-166; k must be odd)
 #define PMX_C_CAP 48            // seeds / anchors per pair
 #define PMX_C_MCAP 40           // minimizers of one read waiting for their probes
 #define PMX_C_NW 5              // 32-base words per read: reads up to 160 bases

@@ -333,7 +333,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             // Compact tier (align_kernel_compact.hip): every pair first, work state in LDS; what it cannot finish comes
             // back as the bail list, which is the launch order of the general thread-per-pair kernel below.
             int64_t n_t0 = n_items;
-            const bool use_compact = paired && al->opt.is_sr_like && rs->max_len <= PMX_C_MAXLEN && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_COMPACT");
+            const bool use_compact = paired && al->opt.is_sr_like && al->opt.w == PMX_C_W && (al->opt.k & 1) && rs->max_len <= PMX_C_MAXLEN && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_COMPACT");
             timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
             if (use_compact) {
                 al->bail_list.ensure((size_t)n_items);

@@ -1,0 +1,6 @@
+set -x
+python -m pytest tests/test_align_gpu.py -x -q -m gpu 2>&1 | tail -3
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-to-host 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['kernels_ms'], d['real_reads']['value'], d['real_reads']['align_stage_ms'], d['checks']['tiers'])"
+PMX_ALIGN_PROF=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-to-host --no-real-reads 2>&1 | grep "compact tier" | tail -1
