@@ -651,6 +651,9 @@ PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
     return !tie;
 }
 
+#ifndef PMX_C_COUNT
+#define PMX_C_COUNT(k, v) ((void)0)   // tests/hostsim counts work here
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PMX_C_STAMP(k) do { if (prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
 #else
@@ -786,6 +789,17 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
         uint32_t ax_st = m.X(0);
         uint64_t x_mi = 0;
         int32_t f_mi = 0;
+        // Colinear runs.  Anchors r0 .. i-1 form a run when consecutive ones lie on one diagonal of one mate and strand,
+        // are a valid pair for comput_sc, and each has its left neighbour as predecessor.  If anchor i extends the run,
+        // the visits of j = i-1 .. r0 have a known outcome: j = i-1 gives sc = f[i-1] + min(dq, k) > k; for every
+        // other valid j of the run sc_j = f[j] + min(d(j,i), k) <= f[i-1] + min(d(i-1,i), k), because f[t] >= f[t-1] +
+        // min(d(t-1,t), k) along the run and min(a,k) + min(b,k) >= min(a+b,k) -- not better, and marked (its right
+        // neighbour was visited and points at it), so it only counts towards max_skip; run members farther than the
+        // distance limits are invalid and have no effect at all (d grows with every step down).  The loop below then
+        // starts under the run with that state instead of visiting up to max_skip + 2 anchors for nothing.
+        const int32_t run_lim = max_dist_x < max_dist_y ? max_dist_x : max_dist_y;
+        int r0 = 0, jv = 0;
+        uint32_t ax_p = 0, ay_p = 0, f_p = 0;   // anchor i - 1
         for (int i = 0; i < n; ++i) {
             const uint32_t axi = m.X(i);
             const uint32_t ayi = m.Y(i);
@@ -800,7 +814,30 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             uint64_t mark = 0;   // bit (j - st): anchor j is the predecessor of an anchor already visited for this i
             int32_t ej = st - 1;
             bool stop = false;
-            for (int32_t j = i - 1; j >= st && !stop; --j) {
+            int32_t j_from = i - 1;
+            const int32_t dq_p = qi - (int32_t)(ay_p & 0x3ffu);
+            const bool extends = use_tab && i > 0 && st <= i - 1 && MT::rev_of(axi ^ ax_p) == 0u && ((ayi ^ ay_p) >> 10 & 1u) == 0u && dq_p > 0 &&
+                                 (int32_t)(rpi - MT::pos_of(ax_p)) == dq_p && dq_p <= run_lim;
+            if (extends) {
+                const int lo = r0 > st ? r0 : st;
+                if (jv < lo) jv = lo;
+                while (qi - (int32_t)(m.Y(jv) & 0x3ffu) > run_lim) ++jv;   // ends at i - 1 at the latest
+                const int32_t n_marked = i - 1 - jv;
+                max_f = (int32_t)(f_p & 0x3ffu) + (dq_p < k ? dq_p : k);
+                mj = i - 1;
+                if (n_marked > max_skip) { ej = i - 2 - max_skip; stop = true; }
+                else {
+                    n_skip = n_marked;
+                    if (jv == r0) {
+                        const int32_t pj = (int32_t)(m.G(r0) >> 10) - 1 - st;
+                        if (pj >= 0) mark = 1ULL << (pj & 63);
+                    }
+                    j_from = lo - 1;
+                }
+            }
+            PMX_C_COUNT(0, 1);
+            for (int32_t j = j_from; j >= st && !stop; --j) {
+                PMX_C_COUNT(1, 1);
                 const uint32_t axj = m.X(j);
                 const uint32_t ayj = m.Y(j);
                 const uint32_t fj = m.G(j);
@@ -821,6 +858,32 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
                 stop = brk;
                 const int32_t pj = (int32_t)(fj >> 10) - 1 - st;   // p[j] relative to st
                 mark |= (valid && !brk && (fj >> 10) != 0u && pj >= 0) ? 1ULL << (pj & 63) : 0ULL;
+                // j is the top of a run a .. j of OTHER anchors (B[j]): seen from i all of them have one diagonal
+                // difference, so one penalty; with dr > 0 at the top (then dg >= 0 and no dr == 0 below) and the
+                // bottom within the distance limits every member is valid and sc falls (weakly) from the top down, by
+                // the inequality above -- the rest of the run is not better and marked: it only counts skips
+                if (use_tab && valid && !stop) {
+                    const int32_t a0 = (int32_t)m.B(j);
+                    const int32_t a = a0 > st ? a0 : st;
+                    if (j - a >= 2) {
+                        const uint32_t axa = m.X(a);
+                        const uint32_t aya = m.Y(a);
+                        const int32_t dq_a = qi - (int32_t)(aya & 0x3ffu), dr_a = (int32_t)(rpi - MT::pos_of(axa));
+                        const bool same = ((ayi ^ ayj) >> 10 & 1u) == 0u;
+                        const bool whole = (int32_t)(rpi - MT::pos_of(axj)) > 0 && dq_a <= max_dist_x && (!same || (dq_a <= max_dist_y && dr_a <= max_dist_y));
+                        if (whole) {
+                            PMX_C_COUNT(2, 1);
+                            const int32_t c = j - a;
+                            if (n_skip + c > max_skip) { ej = j - (max_skip + 1 - n_skip); stop = true; }
+                            else {
+                                n_skip += c;
+                                const int32_t pa = (int32_t)(m.G(a) >> 10) - 1 - st;
+                                if (pa >= 0) mark |= 1ULL << (pa & 63);
+                                j = a;
+                            }
+                        }
+                    }
+                }
             }
             int32_t max_j = mj;
             const int32_t end_j = ej;
@@ -844,6 +907,12 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             if (max_f < 0 || max_f > 1023) return PMX_C_BAIL;
             m.G(i) = (c_u16)((uint32_t)max_f | (uint32_t)(max_j + 1) << 10);
             if (max_ii < 0 || ((int64_t)(xi - x_mi) <= (int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = xi; f_mi = max_f; }
+            if (!(extends && max_j == i - 1)) { r0 = i; jv = i; }
+            m.B(i) = (c_u8)r0;
+#ifdef PMX_C_DUMP
+            if (getenv("PMX_C_DUMP")) fprintf(stderr, "i=%d pos=%u q=%d seg=%d f=%d p=%d r0=%d ext=%d st=%d\n", i, rpi, qi, sidi, max_f, max_j, r0, (int)extends, st);
+#endif
+            ax_p = axi; ay_p = ayi; f_p = (uint32_t)max_f;
         }
     }
 

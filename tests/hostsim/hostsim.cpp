@@ -13,7 +13,12 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 #endif
 #include "align/aln_host.hpp"
 #ifndef PMX_HOSTSIM_TPP
+// work counters of the compact tier (0: anchors, 1: anchor pairs the chain fill evaluated, 2: run skips)
+static long long pmx_c_cnt[4];
+#define PMX_C_DUMP 1
+#define PMX_C_COUNT(k, v) (pmx_c_cnt[k] += (v))
 #include "align/aln_compact.hpp"
+extern "C" void hs_compact_counts(long long* out, int reset) { for (int i = 0; i < 4; ++i) { out[i] = pmx_c_cnt[i]; if (reset) pmx_c_cnt[i] = 0; } }
 #endif
 
 using namespace pmx::aln;
