@@ -564,7 +564,7 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         timer_begin(ctx, "seed");
         // seeding order (default-parameter kernel): reads that start with the same 16 bases next to each other, so that a
         // block's (seed, count) cache sees its seeds many times (k_seed_histogram_ks)
-        const bool ks_path = sp.k == 19 && sp.s == 8 && sp.t == 0 && !quality_mode && !getenv("PMX_SEED_GENERIC");
+        const bool ks_path = sp.k == 19 && sp.s == 8 && sp.t == 0 && (l == 3 || l == 1) && !quality_mode && !getenv("PMX_SEED_GENERIC");
         const uint32_t* perm = nullptr;
         if (ks_path && rs->n >= 4096 && rs->n < (int64_t)UINT32_MAX && !getenv("PMX_SEED_NO_SORT")) {
             const int64_t n = rs->n;
@@ -577,7 +577,9 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, 32, ctx->stream));
             perm = pl->sk_idx2.p;
         }
-        const size_t lds_ks = lds + 16 + (size_t)PMX_SEED_CACHE * 14;   // keys 8 B + counts 4 B + admission tags 2 B
+        // the specialised kernel keeps its rings in registers: LDS = the waves' seed queues + the block cache (keys 8 B +
+        // counts 4 B + admission tags 2 B per entry)
+        const size_t lds_ks = (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS * sizeof(uint64_t) + (size_t)PMX_SEED_CACHE * 14;
         for (int attempt = 0; attempt < 2; ++attempt) {
         // A launch of one chunk is latency-bound (every wave walks its 150 bases one after the other, a few waves per
         // SIMD): the chunks of a group run concurrently on side streams, sharing the table (all they do is atomics).
@@ -602,8 +604,8 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             const dim3 grid(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
             // the default seeding parameters run the kernel specialised for them (same results, ~3x fewer instructions)
             if (ks_path)
-                hipLaunchKernelGGL((k_seed_histogram_ks<19, 8>), grid, block, lds_ks, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp,
-                                   pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep, perm);
+                hipLaunchKernelGGL((l == 3 ? k_seed_histogram_ks<19, 8, 3> : k_seed_histogram_ks<19, 8, 1>), grid, block, lds_ks, st, rs->words.p, rs->amb.p,
+                                   rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep, perm);
             else
                 hipLaunchKernelGGL(k_seed_histogram, grid, block, lds, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p,
                                    pl->vals.p, pl->cap - 1, pl->counters.p, keep, quality_mode ? rs->qual.p : nullptr,

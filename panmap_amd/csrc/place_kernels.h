@@ -6,6 +6,7 @@
 #define PMX_SEED_BLOCK 128
 #define PMX_SEED_CACHE 512   // entries of a block's (seed, count) cache in LDS (k_seed_histogram_ks)
 #define PMX_SEED_QCAP 256   // seeds a wave queues in LDS before it inserts them 64 at a time (k_seed_histogram)
+#define PMX_SEED_QCAP_KS 1024   // k_seed_histogram_ks: drained once per block of k-s+1 bases
 #define PMX_SUM_BLOCK 1024
 #define PMX_CTR_NSHARD 256
 enum { PMX_CTR_ENTRIES = 0, PMX_CTR_OVERFLOW = 1, PMX_CTR_SEEDS = 2, PMX_CTR_COMPACT = 3, PMX_CTR_SHARD0 = 8, PMX_CTR_N = 8 + PMX_CTR_NSHARD };
@@ -25,7 +26,7 @@ __global__ void k_read_word_counts(const int64_t* off, int64_t n_reads, int64_t 
 __global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin, int64_t n_reads,
                                  SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters,
                                  const uint8_t* keep, const uint8_t* qual, int min_q);
-template <int K, int S>
+template <int K, int S, int L>
 __global__ void k_seed_histogram_ks(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin,
                                     int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask,
                                     unsigned long long* counters, const uint8_t* keep, const uint32_t* perm);

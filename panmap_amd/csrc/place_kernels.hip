@@ -399,88 +399,106 @@ __device__ __forceinline__ uint64_t hb_rot(uint32_t c, uint32_t am) {
     return am ? 0ULL : v;
 }
 
-template <int K, int S>
+// k_seed_histogram_ks: a wave's queued seeds go to the block's (seed, count) cache, or -- first sightings, slots taken by
+// another seed -- to the table.  Called by all 64 lanes.
+__device__ __forceinline__ void seed_queue_to_cache_and_table(uint64_t* queue, int n_q, int lane, unsigned long long* ckey, uint32_t* ccnt, uint16_t* ctag,
+                                                           uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters) {
+    for (int q = lane; q < n_q; q += 64) {
+        const uint64_t h = queue[q];
+        if (h == PMX_EMPTY_KEY) { table_insert(keys, vals, mask, h, 1ULL, counters); continue; }   // (the sentinel value itself)
+        const uint64_t hm = mix64(h);
+        const uint32_t cs = (uint32_t)hm & (PMX_SEED_CACHE - 1);
+        const uint16_t tag = (uint16_t)((hm >> 40) | 1u);
+        unsigned long long cur = ckey[cs];
+        if (cur == PMX_EMPTY_KEY) {
+            if (ctag[cs] != tag) { ctag[cs] = tag; continue; }   // first sighting: to the table (stays queued)
+            cur = atomicCAS(&ckey[cs], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)h);
+            if (cur == PMX_EMPTY_KEY) cur = h;
+        }
+        if (cur == h) {
+            atomicAdd(&ccnt[cs], 1u);
+            queue[q] = PMX_EMPTY_KEY;
+        }
+    }
+    drain_seed_queue(queue, n_q, lane, 64, keys, vals, mask, counters);
+}
+
+template <int K, int S, int L>
 __global__ void __launch_bounds__(PMX_SEED_BLOCK)
 k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
                     const int64_t* __restrict__ off, int64_t r_begin, int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals,
                     uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ perm) {
     constexpr int W = K - S + 1;
-    static_assert(K <= 32 && S >= 1 && W >= 2 && W <= 32, "window of 2..32 s-mers");
+    static_assert(K <= 32 && S >= 2 && W >= 2 && W <= 32, "window of 2..32 s-mers");
+    static_assert(PMX_SEED_QCAP_KS >= 64 * W + 64, "the queue must take a block of W bases from every lane");
+    // Per-base LDS round trips were this kernel's time (round-2 counters: 10 LDS instructions per base, each a full stall
+    // with two waves per SIMD; half of every wave's cycles waiting): the s-mer ring now lives in REGISTERS.  The base loop
+    // runs over s-mer indices in blocks of W with the block fully unrolled, so every ring slot is a compile-time register;
+    // the last l syncmer hashes are a four-deep shift register (l <= 4, host-checked); the queue cursor is a wave-uniform
+    // register advanced by a ballot (all 64 lanes run every iteration: reads that are too short, filtered or past their end
+    // are predicated off, never branched around).  LDS holds only the wave's seed queue and the block's (seed, count) cache.
     extern __shared__ uint64_t lds[];
-    const int l = sp.l < 1 ? 1 : sp.l;
+    constexpr int l = L;   // sp.l, host-checked
+    static_assert(L >= 1 && L <= 4, "the syncmer shift register holds four hashes");
     const int tid = threadIdx.x;
-    uint64_t* ringF = lds + tid;                                      // [W][B] forward s-mer hashes / suffix minima
-    uint64_t* ringR = lds + (size_t)W * PMX_SEED_BLOCK + tid;         // [W][B]
-    uint64_t* ringS = lds + (size_t)2 * W * PMX_SEED_BLOCK + tid;     // [l][B] last l syncmer hashes
-    uint64_t* queue = lds + (size_t)(2 * W + l) * PMX_SEED_BLOCK + (size_t)(tid >> 6) * PMX_SEED_QCAP;
-    uint32_t* qcnt = reinterpret_cast<uint32_t*>(lds + (size_t)(2 * W + l) * PMX_SEED_BLOCK + (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP) + (tid >> 6);
-    if ((tid & 63) == 0) *qcnt = 0;
-    // Block cache: every table increment is a memory-side atomic, the stage's bound.  The host hands the reads over
-    // sorted by their first 16 bases (perm[]), so the 128 reads of a block are a few stacks of reads that start at the
-    // same place and carry the same seeds: a small direct-mapped (seed, count) cache in LDS absorbs the repeats and the
-    // block adds each cached seed to the table ONCE, with its count, when it ends.  A slot taken by another seed sends
-    // the seed to the table directly.  Sums commute: same histogram (and with unsorted or low-coverage reads nothing is
-    // lost but the cache's few instructions).  512 entries measured best (128: 3.0 ms, 256: 2.6, 512: 2.5, 1024: 2.8,
-    // 2048: 3.7 for the stage: a larger cache costs resident blocks and a longer flush).
-    // Admission filter (round 2): two thirds of a block's distinct seeds are sequencing-error singletons; taking slots
-    // first come first served they kept the sample's true seeds (seen dozens of times per block) out of half of the cache.
-    // A seed is now admitted on its SECOND sighting: the first one leaves a 16-bit tag in the slot's side word and goes to
-    // the table itself, so singletons cost the one atomic they always cost and never hold a slot.
-    unsigned long long* ckey = reinterpret_cast<unsigned long long*>(lds + (size_t)(2 * W + l) * PMX_SEED_BLOCK + (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP + 2);
+    const int lane = tid & 63;
+    uint64_t* queue = lds + (size_t)(tid >> 6) * PMX_SEED_QCAP_KS;
+    // Block cache: every table increment is a memory-side atomic.  The host hands the reads over sorted by their first 16
+    // bases (perm[]), so the 128 reads of a block are a few stacks of reads that start at the same place and carry the same
+    // seeds: a small direct-mapped (seed, count) cache in LDS absorbs the repeats and the block adds each cached seed to the
+    // table ONCE, with its count, when it ends.  A slot taken by another seed sends the seed to the table directly.  Sums
+    // commute: same histogram.  A seed is admitted on its SECOND sighting (the first leaves a 16-bit tag in the slot's side
+    // word and goes to the table itself), so the sequencing-error singletons -- two thirds of a block's distinct seeds --
+    // never hold a slot.
+    unsigned long long* ckey = reinterpret_cast<unsigned long long*>(lds + (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS);
     uint32_t* ccnt = reinterpret_cast<uint32_t*>(ckey + PMX_SEED_CACHE);
     uint16_t* ctag = reinterpret_cast<uint16_t*>(ccnt + PMX_SEED_CACHE);
     for (int i = tid; i < PMX_SEED_CACHE; i += PMX_SEED_BLOCK) { ckey[i] = PMX_EMPTY_KEY; ccnt[i] = 0; ctag[i] = 0; }
     __syncthreads();
-    auto drain = [&]() {   // called with the wave's in-loop lanes converged; strides over the ACTIVE lanes
-        const unsigned long long act = __ballot(1);
-        const int rank = (int)__popcll(act & ((1ULL << (tid & 63)) - 1ULL)), n_act = (int)__popcll(act);
-        const int n_q = (int)__hip_atomic_load(qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int q = rank; q < n_q; q += n_act) {
-            const uint64_t h = queue[q];
-            if (h == PMX_EMPTY_KEY) { table_insert(keys, vals, mask, h, 1ULL, counters); continue; }   // (the sentinel value itself)
-            const uint64_t hm = mix64(h);
-            const uint32_t cs = (uint32_t)hm & (PMX_SEED_CACHE - 1);
-            const uint16_t tag = (uint16_t)((hm >> 40) | 1u);
-            unsigned long long cur = ckey[cs];
-            if (cur == PMX_EMPTY_KEY) {
-                if (ctag[cs] != tag) { ctag[cs] = tag; continue; }   // first sighting: to the table (stays queued)
-                cur = atomicCAS(&ckey[cs], (unsigned long long)PMX_EMPTY_KEY, (unsigned long long)h);
-                if (cur == PMX_EMPTY_KEY) cur = h;
-            }
-            if (cur == h) {
-                atomicAdd(&ccnt[cs], 1u);
-                queue[q] = PMX_EMPTY_KEY;
-            }
-        }
-        drain_seed_queue(queue, n_q, rank, n_act, keys, vals, mask, counters);
-        if (rank == 0) *qcnt = 0;
+    int n_q = 0;   // wave-uniform
+    auto drain = [&]() {   // all 64 lanes; called once per block of W bases (inlined at every unrolled base it was most of the kernel's code)
+        seed_queue_to_cache_and_table(queue, n_q, lane, ckey, ccnt, ctag, keys, vals, mask, counters);
+        n_q = 0;
     };
     unsigned long long n_seeds = 0;
-    const unsigned rot_k = (unsigned)K, rot_kl = (unsigned)(K * l) & 63u, rot_kl1 = (unsigned)(K * (l - 1)) & 63u;
+    constexpr unsigned rot_k = (unsigned)K & 63u, rot_kl = (unsigned)(K * l) & 63u, rot_kl1 = (unsigned)(K * (l - 1)) & 63u;
 
-    for (int64_t rp = r_begin + (int64_t)blockIdx.x * PMX_SEED_BLOCK + tid; rp < n_reads; rp += (int64_t)gridDim.x * PMX_SEED_BLOCK) {
-        const int64_t r = perm ? (int64_t)perm[rp] : rp;
-        const int64_t len = off[r + 1] - off[r];
-        if (len < K) continue;
-        if (keep && !keep[r]) continue;   // --dedup: a later copy of an identical read
-        const uint64_t* rw = words + woff[r];
-        const uint32_t* ra = amb + woff[r];
-        const int valid_start = sp.trim_start, valid_end = (int)len - sp.trim_end - K;
+    const int64_t stride = (int64_t)gridDim.x * PMX_SEED_BLOCK;
+    for (int64_t rb = r_begin + (int64_t)blockIdx.x * PMX_SEED_BLOCK + (tid & ~63); rb < n_reads; rb += stride) {   // wave-uniform
+        const int64_t rp = rb + lane;
+        int ilen = 0;
+        const uint64_t* rw = words;
+        const uint32_t* ra = amb;
+        if (rp < n_reads) {
+            const int64_t r = perm ? (int64_t)perm[rp] : rp;
+            const int64_t len = off[r + 1] - off[r];
+            if (len >= K && !(keep && !keep[r])) {   // (--dedup: a later copy of an identical read is skipped)
+                ilen = (int)len;
+                rw = words + woff[r];
+                ra = amb + woff[r];
+            }
+        }
+        const int valid_start = sp.trim_start, valid_end = ilen - sp.trim_end - K;
+        const int n_words = (ilen + 31) >> 5;
         uint64_t fS = 0, rS = 0, fK = 0, rK = 0;
-        uint64_t hist2 = 0;   // last 32 base codes, newest in bits 1:0
-        uint32_t hista = 0;   // last 32 ambiguity bits, newest in bit 0
+        uint64_t hist2 = 0;            // last 32 base codes, newest in bits 1:0
+        uint32_t hista = 0xffffffffu;  // last 32 ambiguity bits, newest in bit 0; all set: no base leaves the first windows
         int last_amb = -1;
-        uint64_t cw = 0, cw_next = rw[0];   // the next 32 bases are requested while these are processed
-        uint32_t ca = 0, ca_next = ra[0];
-        const int n_words = ((int)len + 31) >> 5;
+        uint64_t cw = 0, cw_next = ilen > 0 ? rw[0] : 0;   // the next 32 bases are requested while these are processed
+        uint32_t ca = 0, ca_next = ilen > 0 ? ra[0] : 0;
         uint64_t F = 0, R = 0;  // k-min-mer rolling hashes
-        int n_sync = 0, slot_l = 0;
-        int slot_w = 0;                                  // ring slot of the s-mer that ends at this base
+        int n_sync = 0;
+        uint64_t sy0 = 0, sy1 = 0, sy2 = 0, sy3 = 0;   // the last four syncmer hashes, newest first
+        uint64_t rgF[W], rgR[W];                          // open block: the s-mer hashes; closed block: its suffix minima
+#pragma unroll
+        for (int j = 0; j < W; ++j) { rgF[j] = 0; rgR[j] = 0; }
         uint64_t pfF = 0, pfR = 0, pf0F = 0, pf0R = 0;   // prefix minima of the current block, and the block's first s-mers
         uint32_t selfF = 0, selfR = 0;                   // previous block: bit j = s-mer j was its own suffix minimum
-        const int ilen = (int)len;
-        for (int i = 0; i < ilen; ++i) {
-            if (__hip_atomic_load(qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (uint32_t)(PMX_SEED_QCAP - 64)) drain();
+
+        // one base: the rolling ntHash values of the s-mer and the k-mer that end at it (src/seeding.hpp).  The rolling form
+        // serves from base 0 on: while nothing leaves the window the outgoing term is zero (hista starts all ones), and with
+        // zero start values the first complete k-mer / s-mer hashes equal the direct sums.
+        auto step_base = [&](int i) {
             if ((i & 31) == 0) {
                 cw = cw_next; ca = ca_next;
                 if ((i >> 5) + 1 < n_words) { cw_next = rw[(i >> 5) + 1]; ca_next = ra[(i >> 5) + 1]; }
@@ -490,106 +508,112 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
             cw >>= 2; ca >>= 1;
             last_amb = am ? i : last_amb;
             const uint64_t hb = hb_rot<0, false>(code, am);
-            // s-mer and k-mer hashes (src/seeding.hpp rolling ntHash); i is uniform across the wave
-            if (i < S) {
-                fS ^= c_rotl64(hb, (unsigned)(S - 1 - i));
-                rS ^= c_rotl64(hb_rot<0, true>(code, am), (unsigned)i);
-            } else {
-                const uint32_t oc = (uint32_t)(hist2 >> (2 * (S - 1))) & 3u, oa = (hista >> (S - 1)) & 1u;
-                fS = c_rotl64(fS, 1) ^ hb_rot<S, false>(oc, oa) ^ hb;
-                rS = c_rotl64(rS, 63) ^ hb_rot<63, true>(oc, oa) ^ hb_rot<S - 1, true>(code, am);
-            }
-            if (i < K) {
-                fK ^= c_rotl64(hb, (unsigned)(K - 1 - i));
-                rK ^= c_rotl64(hb_rot<0, true>(code, am), (unsigned)i);
-            } else {
-                const uint32_t oc = (uint32_t)(hist2 >> (2 * (K - 1))) & 3u, oa = (hista >> (K - 1)) & 1u;
-                fK = c_rotl64(fK, 1) ^ hb_rot<K, false>(oc, oa) ^ hb;
-                rK = c_rotl64(rK, 63) ^ hb_rot<63, true>(oc, oa) ^ hb_rot<K - 1, true>(code, am);
-            }
+            const uint32_t ocS = (uint32_t)(hist2 >> (2 * (S - 1))) & 3u, oaS = (hista >> (S - 1)) & 1u;
+            fS = c_rotl64(fS, 1) ^ hb_rot<S, false>(ocS, oaS) ^ hb;
+            rS = c_rotl64(rS, 63) ^ hb_rot<63, true>(ocS, oaS) ^ hb_rot<S - 1, true>(code, am);
+            const uint32_t ocK = (uint32_t)(hist2 >> (2 * (K - 1))) & 3u, oaK = (hista >> (K - 1)) & 1u;
+            fK = c_rotl64(fK, 1) ^ hb_rot<K, false>(ocK, oaK) ^ hb;
+            rK = c_rotl64(rK, 63) ^ hb_rot<63, true>(ocK, oaK) ^ hb_rot<K - 1, true>(code, am);
             hist2 = (hist2 << 2) | code;
             hista = (hista << 1) | am;
-            if (i < S - 1) continue;
-            // ---- window minimum of the last W s-mers
-            uint64_t fmin, rmin;
-            bool f_old_min, r_old_min;   // the OLDEST s-mer of the window equals the minimum
-            pfF = slot_w == 0 ? fS : (fS < pfF ? fS : pfF);
-            pfR = slot_w == 0 ? rS : (rS < pfR ? rS : pfR);
-            pf0F = slot_w == 0 ? fS : pf0F;
-            pf0R = slot_w == 0 ? rS : pf0R;
-            if (slot_w == W - 1) {   // the window is exactly the current block; then turn the block into suffix minima
-                fmin = pfF; rmin = pfR;
-                f_old_min = pf0F == pfF;
-                r_old_min = pf0R == pfR;
-                uint64_t sF = fS, sR = rS;
-                selfF = selfR = 1u << (W - 1);
-                ringF[(size_t)(W - 1) * PMX_SEED_BLOCK] = sF;
-                ringR[(size_t)(W - 1) * PMX_SEED_BLOCK] = sR;
+        };
+        for (int i = 0; i < S - 1 && __any(i < ilen); ++i)
+            if (i < ilen) step_base(i);
+        for (int p0 = 0; __any(p0 + S - 1 < ilen); p0 += W) {
+            if (n_q > PMX_SEED_QCAP_KS - 64 * W) drain();   // a block adds at most 64 * W seeds
 #pragma unroll
-                for (int j = W - 2; j >= 0; --j) {
-                    const uint64_t xF = ringF[(size_t)j * PMX_SEED_BLOCK], xR = ringR[(size_t)j * PMX_SEED_BLOCK];
-                    selfF |= xF <= sF ? 1u << j : 0u;
-                    selfR |= xR <= sR ? 1u << j : 0u;
-                    sF = xF < sF ? xF : sF;
-                    sR = xR < sR ? xR : sR;
-                    ringF[(size_t)j * PMX_SEED_BLOCK] = sF;
-                    ringR[(size_t)j * PMX_SEED_BLOCK] = sR;
+            for (int r = 0; r < W; ++r) {
+                const int i = p0 + r + S - 1;
+                bool have = false;
+                uint64_t out = 0;
+                if (i < ilen) {
+                    step_base(i);
+                    // ---- window minimum of the last W s-mers (block prefix / suffix minima, see the header comment)
+                    uint64_t fmin, rmin;
+                    bool f_old_min, r_old_min;   // the OLDEST s-mer of the window equals the minimum
+                    pfF = r == 0 ? fS : (fS < pfF ? fS : pfF);
+                    pfR = r == 0 ? rS : (rS < pfR ? rS : pfR);
+                    pf0F = r == 0 ? fS : pf0F;
+                    pf0R = r == 0 ? rS : pf0R;
+                    if (r == W - 1) {   // the window is exactly the current block; then turn the block into suffix minima
+                        fmin = pfF; rmin = pfR;
+                        f_old_min = pf0F == pfF;
+                        r_old_min = pf0R == pfR;
+                        uint64_t sF = fS, sR = rS;
+                        selfF = selfR = 1u << (W - 1);
+                        rgF[W - 1] = sF;
+                        rgR[W - 1] = sR;
+#pragma unroll
+                        for (int j = W - 2; j >= 0; --j) {
+                            const uint64_t xF = rgF[j], xR = rgR[j];
+                            selfF |= xF <= sF ? 1u << j : 0u;
+                            selfR |= xR <= sR ? 1u << j : 0u;
+                            sF = xF < sF ? xF : sF;
+                            sR = xR < sR ? xR : sR;
+                            rgF[j] = sF;
+                            rgR[j] = sR;
+                        }
+                    } else {
+                        const uint64_t sufF = rgF[r + 1 < W ? r + 1 : 0], sufR = rgR[r + 1 < W ? r + 1 : 0];
+                        fmin = sufF < pfF ? sufF : pfF;
+                        rmin = sufR < pfR ? sufR : pfR;
+                        f_old_min = (selfF >> (r + 1) & 1u) != 0u && sufF <= pfF;
+                        r_old_min = (selfR >> (r + 1) & 1u) != 0u && sufR <= pfR;
+                        rgF[r] = fS;   // (the block is still open: raw values)
+                        rgR[r] = rS;
+                    }
+                    if (p0 > 0 || r == W - 1) {   // i >= K - 1: a whole k-mer
+                        const int ks = i - K + 1;
+                        // closed syncmer: the minimum sits at the first or the last s-mer; open: at the first (forward strand) /
+                        // the last (reverse strand).  t == 0: first = oldest, last = newest of the window.
+                        const bool f_new_min = fS == fmin, r_new_min = rS == rmin;
+                        const bool fs = sp.open ? f_old_min : (f_old_min || f_new_min);
+                        const bool rs = sp.open ? r_new_min : (r_new_min || r_old_min);
+                        const bool sync = !(last_amb >= ks || fK == rK) && (fs || rs) && ks >= valid_start && ks <= valid_end;
+                        if (sync) {
+                            const uint64_t h = fK < rK ? fK : rK;
+                            ++n_sync;
+                            out = h;
+                            have = true;
+                            if (l > 1) {
+                                if (n_sync <= l) {
+                                    F = c_rotl64(F, rot_k) ^ h;
+                                    R ^= rotl64(h, (unsigned)(K * (n_sync - 1)) & 63u);
+                                    have = n_sync == l;
+                                } else {
+                                    const uint64_t prev = l == 2 ? sy1 : l == 3 ? sy2 : sy3;   // the syncmer that leaves the k-min-mer
+                                    F = c_rotl64(F, rot_k) ^ c_rotl64(prev, rot_kl) ^ h;
+                                    R = c_rotl64(R, 64u - rot_k) ^ c_rotl64(prev, 64u - rot_k) ^ c_rotl64(h, rot_kl1);
+                                }
+                                sy3 = sy2; sy2 = sy1; sy1 = sy0; sy0 = h;
+                                have = have && F != R;
+                                out = F < R ? F : R;
+                            }
+                        }
+                    }
                 }
-            } else {
-                const uint64_t sufF = ringF[(size_t)(slot_w + 1) * PMX_SEED_BLOCK], sufR = ringR[(size_t)(slot_w + 1) * PMX_SEED_BLOCK];
-                fmin = sufF < pfF ? sufF : pfF;
-                rmin = sufR < pfR ? sufR : pfR;
-                f_old_min = (selfF >> (slot_w + 1) & 1u) != 0u && sufF <= pfF;
-                r_old_min = (selfR >> (slot_w + 1) & 1u) != 0u && sufR <= pfR;
-                ringF[(size_t)slot_w * PMX_SEED_BLOCK] = fS;   // (slot_w < W-1: the block is still open, raw values)
-                ringR[(size_t)slot_w * PMX_SEED_BLOCK] = rS;
-            }
-            slot_w = slot_w + 1 == W ? 0 : slot_w + 1;
-            if (i < K - 1) continue;
-            const int ks = i - K + 1;
-            // closed syncmer: the minimum sits at the first or the last s-mer; open: at the first (forward strand) /
-            // the last (reverse strand).  t == 0: first = oldest, last = newest of the window.
-            const bool f_new_min = fS == fmin, r_new_min = rS == rmin;
-            const bool fs = sp.open ? f_old_min : (f_old_min || f_new_min);
-            const bool rs = sp.open ? r_new_min : (r_new_min || r_old_min);
-            const bool sync = !(last_amb >= ks || fK == rK) && (fs || rs) && ks >= valid_start && ks <= valid_end;
-            if (!sync) continue;
-            const uint64_t h = fK < rK ? fK : rK;
-            ++n_sync;
-            uint64_t out = h;
-            bool have = true;
-            if (l > 1) {
-                if (n_sync <= l) {
-                    F = rotl64(F, rot_k) ^ h;
-                    R ^= rotl64(h, (unsigned)(K * (n_sync - 1)) & 63u);
-                    have = n_sync == l;
-                } else {
-                    const uint64_t prev = ringS[(size_t)slot_l * PMX_SEED_BLOCK];
-                    F = rotl64(F, rot_k) ^ rotl64(prev, rot_kl) ^ h;
-                    R = rotr64(R, rot_k) ^ rotr64(prev, rot_k) ^ rotl64(h, rot_kl1);
+                const unsigned long long pushers = __ballot(have);
+                if (have) {
+                    queue[n_q + (int)__popcll(pushers & ((1ULL << lane) - 1ULL))] = out;
+                    ++n_seeds;
                 }
-                ringS[(size_t)slot_l * PMX_SEED_BLOCK] = h;
-                slot_l = slot_l + 1 == l ? 0 : slot_l + 1;
-                have = have && F != R;
-                out = F < R ? F : R;
-            }
-            if (have) {
-                queue[atomicAdd(qcnt, 1u)] = out;
-                ++n_seeds;
+                n_q += (int)__popcll(pushers);
             }
         }
     }
-    drain();   // every lane of the wave is here
+    drain();
     __syncthreads();
     for (int i = tid; i < PMX_SEED_CACHE; i += PMX_SEED_BLOCK) {   // the cached seeds go to the table once, with their counts
         const uint32_t c = ccnt[i];
         if (c) table_insert(keys, vals, mask, (uint64_t)ckey[i], (unsigned long long)c, counters);
     }
     for (int o = 32; o > 0; o >>= 1) n_seeds += __shfl_xor(n_seeds, o);
-    if ((tid & 63) == 0 && n_seeds) atomicAdd(&counters[PMX_CTR_SEEDS], n_seeds);
+    if (lane == 0 && n_seeds) atomicAdd(&counters[PMX_CTR_SEEDS], n_seeds);
 }
-template __global__ void k_seed_histogram_ks<19, 8>(const uint64_t*, const uint32_t*, const int64_t*, const int64_t*, int64_t, int64_t, SeedParams,
-                                                    uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*);
+template __global__ void k_seed_histogram_ks<19, 8, 3>(const uint64_t*, const uint32_t*, const int64_t*, const int64_t*, int64_t, int64_t, SeedParams,
+                                                       uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*);
+template __global__ void k_seed_histogram_ks<19, 8, 1>(const uint64_t*, const uint32_t*, const int64_t*, const int64_t*, int64_t, int64_t, SeedParams,
+                                                       uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*);
 
 // locality key of a read for the seeding order (read_locality_key: reads that start within a few bases of each other)
 __global__ void k_read_prefix_keys(const uint64_t* __restrict__ words, const int64_t* __restrict__ woff, int64_t n_reads, uint32_t* key, uint32_t* idx) {
