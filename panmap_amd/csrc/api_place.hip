@@ -579,7 +579,7 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         }
         // the specialised kernel keeps its rings in registers: LDS = the waves' seed queues + the block cache (keys 8 B +
         // counts 4 B + admission tags 2 B per entry)
-        const size_t lds_ks = (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS * sizeof(uint64_t) + (size_t)PMX_SEED_CACHE * 14;
+        const size_t lds_ks = (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS * sizeof(uint64_t) + (size_t)PMX_SEED_CACHE * 14 + 35 * sizeof(uint64_t);   // + the base-hash tables
         for (int attempt = 0; attempt < 2; ++attempt) {
         // A launch of one chunk is latency-bound (every wave walks its 150 bases one after the other, a few waves per
         // SIMD): the chunks of a group run concurrently on side streams, sharing the table (all they do is atomics).

@@ -424,7 +424,7 @@ __device__ __forceinline__ void seed_queue_to_cache_and_table(uint64_t* queue, i
 }
 
 template <int K, int S, int L>
-__global__ void __launch_bounds__(PMX_SEED_BLOCK)
+__global__ void __launch_bounds__(PMX_SEED_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 170 VGPRs: the LDS footprint admits 12 waves per CU
 k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
                     const int64_t* __restrict__ off, int64_t r_begin, int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals,
                     uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ perm) {
@@ -454,6 +454,14 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
     uint32_t* ccnt = reinterpret_cast<uint32_t*>(ckey + PMX_SEED_CACHE);
     uint16_t* ctag = reinterpret_cast<uint16_t*>(ccnt + PMX_SEED_CACHE);
     for (int i = tid; i < PMX_SEED_CACHE; i += PMX_SEED_BLOCK) { ckey[i] = PMX_EMPTY_KEY; ccnt[i] = 0; ctag[i] = 0; }
+    // base-hash tables: seven rotations x (A, C, G, T, ambiguous = 0), read with one ds_read_b64 each instead of six selects
+    uint64_t* hb_tab = reinterpret_cast<uint64_t*>(ctag + PMX_SEED_CACHE);
+    if (tid < 35) {
+        const int t = tid / 5, c = tid % 5;
+        const bool comp = t == 1 || t == 2 || t == 4 || t == 6;
+        const unsigned rot = t == 0 ? 0u : t == 1 ? (unsigned)(S - 1) : t == 2 ? (unsigned)(K - 1) : t == 3 ? (unsigned)S : t == 5 ? (unsigned)K : 63u;
+        hb_tab[tid] = c == 4 ? 0ULL : rotl64(c_hb((uint32_t)(comp ? 3 - c : c)), rot);
+    }
     __syncthreads();
     int n_q = 0;   // wave-uniform
     auto drain = [&]() {   // all 64 lanes; called once per block of W bases (inlined at every unrolled base it was most of the kernel's code)
@@ -498,25 +506,38 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
         // one base: the rolling ntHash values of the s-mer and the k-mer that end at it (src/seeding.hpp).  The rolling form
         // serves from base 0 on: while nothing leaves the window the outgoing term is zero (hista starts all ones), and with
         // zero start values the first complete k-mer / s-mer hashes equal the direct sums.
-        auto step_base = [&](int i) {
+        // The table values of base i + 1 are requested while base i is processed (the outgoing codes are known from the
+        // history words, the incoming one from the read word): no LDS round trip in the base's dependency chain.
+        uint32_t n_code = 0, n_am = 0;
+        uint64_t n_hb = 0, n_cS = 0, n_cK = 0, n_oS = 0, n_oSr = 0, n_oK = 0, n_oKr = 0;
+        auto fetch_base = [&](int i) {
             if ((i & 31) == 0) {
                 cw = cw_next; ca = ca_next;
                 if ((i >> 5) + 1 < n_words) { cw_next = rw[(i >> 5) + 1]; ca_next = ra[(i >> 5) + 1]; }
             }
-            const uint32_t code = (uint32_t)(cw & 3u);
-            const uint32_t am = ca & 1u;
+            n_code = (uint32_t)(cw & 3u);
+            n_am = ca & 1u;
             cw >>= 2; ca >>= 1;
-            last_amb = am ? i : last_amb;
-            const uint64_t hb = hb_rot<0, false>(code, am);
             const uint32_t ocS = (uint32_t)(hist2 >> (2 * (S - 1))) & 3u, oaS = (hista >> (S - 1)) & 1u;
-            fS = c_rotl64(fS, 1) ^ hb_rot<S, false>(ocS, oaS) ^ hb;
-            rS = c_rotl64(rS, 63) ^ hb_rot<63, true>(ocS, oaS) ^ hb_rot<S - 1, true>(code, am);
             const uint32_t ocK = (uint32_t)(hist2 >> (2 * (K - 1))) & 3u, oaK = (hista >> (K - 1)) & 1u;
-            fK = c_rotl64(fK, 1) ^ hb_rot<K, false>(ocK, oaK) ^ hb;
-            rK = c_rotl64(rK, 63) ^ hb_rot<63, true>(ocK, oaK) ^ hb_rot<K - 1, true>(code, am);
-            hist2 = (hist2 << 2) | code;
-            hista = (hista << 1) | am;
+            const uint64_t* tc = hb_tab + (n_am ? 4u : n_code);   // tables: 0 hb, 1 comp << S-1, 2 comp << K-1, 3 << S, 4 comp << 63, 5 << K
+            const uint64_t* tS = hb_tab + (oaS ? 4u : ocS);
+            const uint64_t* tK = hb_tab + (oaK ? 4u : ocK);
+            n_hb = tc[0]; n_cS = tc[5]; n_cK = tc[10];
+            n_oS = tS[15]; n_oSr = tS[20];
+            n_oK = tK[25]; n_oKr = tK[20];
         };
+        auto step_base = [&](int i) {
+            last_amb = n_am ? i : last_amb;
+            fS = c_rotl64(fS, 1) ^ n_oS ^ n_hb;
+            rS = c_rotl64(rS, 63) ^ n_oSr ^ n_cS;
+            fK = c_rotl64(fK, 1) ^ n_oK ^ n_hb;
+            rK = c_rotl64(rK, 63) ^ n_oKr ^ n_cK;
+            hist2 = (hist2 << 2) | n_code;
+            hista = (hista << 1) | n_am;
+            fetch_base(i + 1);
+        };
+        fetch_base(0);
         for (int i = 0; i < S - 1 && __any(i < ilen); ++i)
             if (i < ilen) step_base(i);
         for (int p0 = 0; __any(p0 + S - 1 < ilen); p0 += W) {
