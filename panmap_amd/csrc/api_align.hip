@@ -325,9 +325,11 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 hipLaunchKernelGGL(k_pair_prefix_keys, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
                                    rs->words.p, rs->woff.p, n_items, paired ? 2 : 1, al->pp_key.p, al->pp_idx.p);
                 size_t bytes = 0;
-                PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 32, ctx->stream));
+                unsigned sort_bits = 32;
+                if (const char* e = getenv("PMX_ALIGN_SORT_BITS")) sort_bits = (unsigned)std::max(1, std::min(32, atoi(e)));
+                PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, sort_bits, ctx->stream));
                 al->pp_tmp.ensure(bytes);
-                PMX_HIP(rocprim::radix_sort_pairs(al->pp_tmp.p, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 32, ctx->stream));
+                PMX_HIP(rocprim::radix_sort_pairs(al->pp_tmp.p, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, sort_bits, ctx->stream));
                 order = al->pp_idx2.p;
             }
             // Compact tier (align_kernel_compact.hip): every pair first, work state in LDS; what it cannot finish comes

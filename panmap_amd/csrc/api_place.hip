@@ -37,6 +37,9 @@ struct pmx_place {
     DevBuf<unsigned long long> counters;   // PMX_CTR_N
     int64_t n_reads_added = 0;
     bool table_dirty = false;              // something was inserted since the last reset
+    bool needs_clear = false;              // reset happened: the slots are cleared (or the table re-made at a better size) by the next reservation
+    double bases_added = 0;                // read bases (n x max_len) seeded since the last reset
+    double keys_per_base = 0;              // distinct seeds per read base of the last finished histogram (0: none yet): sizes the next table
     DevBuf<uint32_t> sk_key, sk_key2, sk_idx, sk_idx2;   // seeding order: reads sorted by their first 16 bases
     hipStream_t seed_streams[3] = {nullptr, nullptr, nullptr};   // side streams: seeding launches of one group run concurrently
     hipEvent_t seed_go = nullptr, seed_done[3] = {nullptr, nullptr, nullptr};
@@ -104,6 +107,17 @@ uint64_t next_pow2(uint64_t x) {
 
 // make room for `bound_new` more distinct keys at load factor <= 0.7 (never overflows afterwards)
 void table_reserve(pmx_ctx* ctx, pmx_place* pl, uint64_t bound_new) {
+    if (pl->needs_clear || pl->cap == 0) {   // empty table (the counters are already zero): size it for this batch, no counter round trip
+        uint64_t need0 = next_pow2((uint64_t)((double)bound_new / 0.7) + 1024);
+        if (need0 < (1u << 16)) need0 = 1u << 16;
+        pl->needs_clear = false;
+        if (pl->cap < need0 || pl->cap > 4 * need0) table_alloc(ctx, pl, need0);   // (also shrinks: clearing and compacting scan every slot)
+        else {
+            hipLaunchKernelGGL(k_fill_u64, dim3(grid_for((int64_t)pl->cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p, PMX_EMPTY_KEY, pl->cap);
+            PMX_HIP(hipMemsetAsync(pl->vals.p, 0, pl->cap * sizeof(unsigned long long), ctx->stream));
+        }
+        return;
+    }
     unsigned long long h_ctr[PMX_CTR_N];
     PMX_HIP(hipMemcpyAsync(h_ctr, pl->counters.p, sizeof(h_ctr), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -138,6 +152,7 @@ void finalize_histogram(pmx_ctx* ctx, pmx_place* pl) {
     int64_t n = 0;
     for (int i = 0; i < PMX_CTR_NSHARD; ++i) n += (int64_t)h_ctr[PMX_CTR_SHARD0 + i];
     pl->n_hist = n;
+    if (pl->bases_added > 0 && n > 0) pl->keys_per_base = (double)n / pl->bases_added;
     pl->hist_hash.ensure(n);
     pl->hist_count.ensure(n);
     pl->hist_hash_tmp.ensure(n);
@@ -492,11 +507,8 @@ int pmx_place_reset(pmx_ctx* ctx, pmx_place* pl) {
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     PMX_HIP(hipMemsetAsync(pl->counters.p, 0, sizeof(unsigned long long) * PMX_CTR_N, ctx->stream));
-    if (pl->cap) {
-        hipLaunchKernelGGL(k_fill_u64, dim3(grid_for((int64_t)pl->cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p, PMX_EMPTY_KEY,
-                           pl->cap);
-        PMX_HIP(hipMemsetAsync(pl->vals.p, 0, pl->cap * sizeof(unsigned long long), ctx->stream));
-    }
+    pl->needs_clear = pl->cap != 0;   // the slots are cleared by the next reservation, which may also pick a better size
+    pl->bases_added = 0;
     pl->n_reads_added = 0;
     pl->hist_sorted = false;
     pl->n_hist = 0;
@@ -556,10 +568,15 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         // with an eighth of the safe bound (a smaller table to clear, probe and compact); an insert that finds no slot is
         // counted (probe sequences are capped), and in that case the table is cleared and the call is redone with the safe
         // bound.  Same histogram either way.
+        // Once a histogram has been finished its density (distinct seeds per read base) sizes the next optimistic table:
+        // twice that, at least 1/64 of the safe bound -- batches of one run look alike, and a table 16x smaller is 16x
+        // cheaper to clear and to compact.
         int64_t bound_div = 1;
+        double bound_frac = 0;   // > 0: optimistic bound as a fraction of the safe one (takes the place of 1 / bound_div)
         if (!pl->table_dirty && !getenv("PMX_SEED_SAFE_BOUND")) {
             bound_div = 8;
             if (const char* e = getenv("PMX_SEED_BOUND_DIV")) bound_div = std::max<int64_t>(1, atoll(e));   // (tests force the redo with a large value)
+            else if (pl->keys_per_base > 0 && !getenv("PMX_SEED_NO_HINT")) bound_frac = std::min(1.0 / 8, std::max(2 * pl->keys_per_base, 1.0 / 64));
         }
         timer_begin(ctx, "seed");
         // seeding order (default-parameter kernel): reads that start with the same 16 bases next to each other, so that a
@@ -572,9 +589,11 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             hipLaunchKernelGGL(k_read_prefix_keys, dim3(grid_for(n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rs->words.p, rs->woff.p, n,
                                pl->sk_key.p, pl->sk_idx.p);
             size_t bytes = 0;
-            PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, 32, ctx->stream));
+            unsigned sort_bits = 32;
+            if (const char* e = getenv("PMX_SEED_SORT_BITS")) sort_bits = (unsigned)std::max(1, std::min(32, atoi(e)));
+            PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, sort_bits, ctx->stream));
             pl->tmp.ensure(bytes);
-            PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, 32, ctx->stream));
+            PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, sort_bits, ctx->stream));
             perm = pl->sk_idx2.p;
         }
         // the specialised kernel keeps its rings in registers: LDS = the waves' seed queues + the block cache (keys 8 B +
@@ -594,7 +613,8 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         }
         for (int64_t g0 = 0; g0 < rs->n; g0 += chunk_reads * n_par) {
             const int64_t g1 = std::min<int64_t>(rs->n, g0 + chunk_reads * n_par);
-            table_reserve(ctx, pl, (uint64_t)((g1 - g0) * rs->max_len / bound_div) + 1);
+            const double safe_bound = (double)(g1 - g0) * (double)rs->max_len;
+            table_reserve(ctx, pl, (uint64_t)(bound_div > 1 && bound_frac > 0 ? safe_bound * bound_frac : safe_bound / (double)bound_div) + 1);
             if (n_par > 1) PMX_HIP(hipEventRecord(pl->seed_go, ctx->stream));
             int j = 0;
             for (int64_t r0 = g0; r0 < g1; r0 += chunk_reads, ++j) {
@@ -632,6 +652,7 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         timer_end(ctx, "seed", 1);
     }
     pl->n_reads_added += rs->n;
+    pl->bases_added += (double)rs->n * (double)rs->max_len;
     pl->hist_sorted = false;
     pl->table_dirty = true;
     return PMX_OK;
