@@ -265,6 +265,11 @@ typedef struct pmx_aligner pmx_aligner;
 int pmx_aligner_create(pmx_ctx *ctx, const char *reference, int64_t ref_len, int mean_read_len, pmx_aligner **out);
 /* re-target an existing aligner at another reference genome (keeps the work buffers) */
 int pmx_aligner_set_reference(pmx_ctx *ctx, pmx_aligner *al, const char *reference, int64_t ref_len, int mean_read_len);
+/* What the current reference index holds, for checks of the two index builders against each other (the device build of
+ * ref_index_kernels.hip is the default; PMX_ALIGN_HOST_INDEX=1 selects the host restatement of mm_idx_str):
+ * out[0] minimizer occurrences, out[1] distinct minimizers, out[2] mid_occ, out[3] a digest of every
+ * (minimizer, occurrence list) pair, independent of the table's slot order; out[4] = 1 when the index was built on the device. */
+int pmx_aligner_index_digest(pmx_ctx *ctx, pmx_aligner *al, uint64_t out[5]);
 void pmx_aligner_free(pmx_ctx *ctx, pmx_aligner *al);
 /* [hot] map + align every read (pair) of a packed read set.  revcomp_mate2 != 0: odd-indexed reads
    are reverse-complemented on the fly (what readFastqPaired does on the host, src/seeding.cpp:251).

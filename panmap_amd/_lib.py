@@ -141,6 +141,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_int), C.POINTER(AlignPairResult), C.c_bool, _i32]),
     "pmx_aligner_create": (_i32, [_vp, _cp, _i64, _i32, _PP]),
     "pmx_aligner_set_reference": (_i32, [_vp, _vp, _cp, _i64, _i32]),
+    "pmx_aligner_index_digest": (_i32, [_vp, _vp, _vp]),
     "pmx_aligner_free": (None, [_vp, _vp]),
     "pmx_align_readset": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "pmx_align_num_records": (_i64, [_vp]),

@@ -592,6 +592,12 @@ class Aligner:
         self._ref = bytes(reference)
         check(lib.pmx_aligner_set_reference(self.ctx._h, self._h, self._ref, len(self._ref), int(mean_read_len)), "pmx_aligner_set_reference")
 
+    def index_digest(self):
+        """(occurrences, distinct minimizers, mid_occ, digest, built_on_device) of the current reference index"""
+        out = (C.c_uint64 * 5)()
+        check(lib.pmx_aligner_index_digest(self.ctx._h, self._h, out), "pmx_aligner_index_digest")
+        return tuple(int(x) for x in out)
+
     def align_readset(self, rs: ReadSet, paired: bool, revcomp_mate2: bool = False):
         check(lib.pmx_align_readset(self.ctx._h, self._h, rs._h, int(paired), int(revcomp_mate2)), "pmx_align_readset")
 

@@ -108,15 +108,54 @@ inline uint8_t nt4_of_char(unsigned char c) {   // seq_nt4_table (sketch.c:9-26)
     }
 }
 
+// mid_occ from the occurrence counts of the index when the preset left it unset (mm_mapopt_update, options.c:66-81);
+// a_kk = the kk-th smallest count, kk = (uint32)((1 - 2e-4f) * n_keys) clamped to the last one (INT32_MAX - 1 without keys)
+inline size_t mid_occ_rank(size_t n_keys) {
+    const float f = 2e-4f;
+    const size_t kk = (size_t)(uint32_t)((1. - f) * n_keys);
+    return n_keys ? std::min(kk, n_keys - 1) : 0;
+}
+inline void set_mid_occ(Opt& o, int32_t a_kk_plus_1) {
+    int min_mid_occ = 10, max_mid_occ = 1000000;
+    if (o.k == 19 && o.w == 19) { min_mid_occ = 50; max_mid_occ = 500; }   // map-hifi
+    o.mid_occ = a_kk_plus_1;
+    if (o.mid_occ < min_mid_occ) o.mid_occ = min_mid_occ;
+    if (max_mid_occ > min_mid_occ && o.mid_occ > max_mid_occ) o.mid_occ = max_mid_occ;
+}
+// what the options and the score tables take from the reference once its index exists; returns true when the logf tables
+// were (re)computed (they only depend on (a, size) and are kept across references)
+inline bool finish_ref_opt(Opt& o, int max_dp_score, HostRefIndex& out) {
+    if (o.bw_long < o.bw) o.bw_long = o.bw;
+    o.chn_pen_gap = (float)(o.chain_gap_scale * 0.01 * o.k);
+    o.chn_pen_skip = (float)(o.chain_skip_scale * 0.01 * o.k);
+    gen_simple_mat(o.mat, (int8_t)o.a, (int8_t)o.b, (int8_t)o.sc_ambi);
+    // logf tables from the host libm (hit.c:440-457, pe.c:160)
+    const int n = max_dp_score + 2;
+    const bool keep = out.logf_a == o.a && (int)out.logf_ratio.size() == n && (int)out.logf_int.size() == n;
+    if (!keep) {
+        out.logf_ratio.resize(n);
+        out.logf_int.resize(n);
+        for (int i = 0; i < n; ++i) {
+            out.logf_ratio[i] = logf((float)i / o.a);
+            out.logf_int[i] = logf((float)i);
+        }
+    }
+    out.logf_a = o.a;
+    return !keep;
+}
+
 // mm_idx_str(w, k, 0, 14, 1, &ref) (index.c:408-451): sketch the reference, group occurrences by minimizer
 #ifndef PMX_INTERLEAVED   // host-only (raw pointers); the thread-per-pair device pass skips it
-inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp_score, HostRefIndex& out) {
+inline bool build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp_score, HostRefIndex& out) {
     // the logf tables only depend on (a, size): keep them across references
     std::vector<float> keep_ratio, keep_int;
     const int keep_a = out.logf_a;
     keep_ratio.swap(out.logf_ratio);
     keep_int.swap(out.logf_int);
     out = HostRefIndex();
+    out.logf_ratio.swap(keep_ratio);
+    out.logf_int.swap(keep_int);
+    out.logf_a = keep_a;
     out.seq.assign((size_t)ref_len + 8, 0);   // padded: readers fetch aligned 32-bit words
     out.pk.assign((size_t)(ref_len + 31) / 32 + 2, 0);
     out.pk_amb.assign((size_t)(ref_len + 31) / 32 + 2, 0);
@@ -185,38 +224,16 @@ inline void build_ref_index(const char* ref, int64_t ref_len, Opt& o, int max_dp
     }
     // mm_mapopt_update (options.c:66-81): mid_occ from the index when the preset left it unset
     if (o.mid_occ <= 0) {
-        const float f = 2e-4f;
         int32_t thres = INT32_MAX;
         if (!out.occ.empty()) {
             std::vector<uint32_t> a = out.occ;
-            const size_t kk = (size_t)(uint32_t)((1. - f) * a.size());
-            std::nth_element(a.begin(), a.begin() + std::min(kk, a.size() - 1), a.end());
-            thres = (int32_t)a[std::min(kk, a.size() - 1)] + 1;
+            const size_t kk = mid_occ_rank(a.size());
+            std::nth_element(a.begin(), a.begin() + kk, a.end());
+            thres = (int32_t)a[kk] + 1;
         }
-        int min_mid_occ = 10, max_mid_occ = 1000000;
-        if (o.k == 19 && o.w == 19) { min_mid_occ = 50; max_mid_occ = 500; }   // map-hifi
-        o.mid_occ = thres;
-        if (o.mid_occ < min_mid_occ) o.mid_occ = min_mid_occ;
-        if (max_mid_occ > min_mid_occ && o.mid_occ > max_mid_occ) o.mid_occ = max_mid_occ;
+        set_mid_occ(o, thres);
     }
-    if (o.bw_long < o.bw) o.bw_long = o.bw;
-    o.chn_pen_gap = (float)(o.chain_gap_scale * 0.01 * o.k);
-    o.chn_pen_skip = (float)(o.chain_skip_scale * 0.01 * o.k);
-    gen_simple_mat(o.mat, (int8_t)o.a, (int8_t)o.b, (int8_t)o.sc_ambi);
-    // logf tables from the host libm (hit.c:440-457, pe.c:160)
-    const int n = max_dp_score + 2;
-    if (keep_a == o.a && (int)keep_ratio.size() == n) {
-        out.logf_ratio.swap(keep_ratio);
-        out.logf_int.swap(keep_int);
-    } else {
-        out.logf_ratio.resize(n);
-        out.logf_int.resize(n);
-        for (int i = 0; i < n; ++i) {
-            out.logf_ratio[i] = logf((float)i / o.a);
-            out.logf_int[i] = logf((float)i);
-        }
-    }
-    out.logf_a = o.a;
+    return finish_ref_opt(o, max_dp_score, out);
 }
 
 #endif

@@ -134,7 +134,7 @@ PMX_HD void sketch_segment_t(Work& W, const Ring& buf, Ptr<const uint8_t> seq, i
 // (sketch_segment_reg below: bases from the work arena, output to W.mv) and by the compact tier (aln_compact.hpp:
 // bases straight from the packed read words, output to its LDS staging list).
 template <int WMAX, class BaseFn, class PushFn>
-PMX_HD void sketch_core(int len, int w, int k, uint64_t y_hi, BaseFn& base_at, PushFn& push) {
+PMX_HD void sketch_core(int len, int w, int k, uint64_t y_hi, BaseFn& base_at, PushFn& push, bool final_push = true) {
     const uint64_t shift1 = 2 * (uint64_t)(k - 1), mask = (1ULL << 2 * k) - 1;
     uint64_t kmer0 = 0, kmer1 = 0;
     int l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0;
@@ -217,7 +217,27 @@ PMX_HD void sketch_core(int len, int w, int k, uint64_t y_hi, BaseFn& base_at, P
         }
         if (++buf_pos == w) buf_pos = 0;
     }
-    if (mn.x != UINT64_MAX) push(mn.x, mn.y);
+    if (final_push && mn.x != UINT64_MAX) push(mn.x, mn.y);
+}
+
+// A slice of a long sequence's sketch, computed on its own (the reference index is built by one thread per slice,
+// ref_index_kernels.hip): the minimizers that sketch.c:77-143 emits while it processes bases [begin, end) of a sequence
+// of `len` bases (the closing push of the last minimum belongs to the slice that ends at len).  With k odd no k-mer is
+// its own reverse complement, so the window advances at every base and the state after base i -- the last w entries,
+// their minimum (always the newest minimal entry, whatever path led there), the run length since the last ambiguous base
+// as far as the thresholds k, w+k-1 and w+k can tell -- is a function of the bases (i - w - k, i]: a run that starts
+// 2 (w + k) bases early is in the true state by `begin`.  emit(x, y): y carries the position in the whole sequence.
+template <int WMAX, class BaseFn, class EmitFn>
+struct SketchSlice {
+    BaseFn& base; EmitFn& emit; int s0, begin, cur;
+    PMX_HD int operator()(int i) { cur = i; return base(s0 + i); }
+    PMX_HD void operator()(uint64_t x, uint64_t y) { if (s0 + cur >= begin) emit(x, y + ((uint64_t)(uint32_t)s0 << 1)); }
+};
+template <int WMAX, class BaseFn, class EmitFn>
+PMX_HD void sketch_slice(int begin, int end, int len, int w, int k, BaseFn& base_at, EmitFn& emit) {
+    const int warm = 2 * (w + k);
+    SketchSlice<WMAX, BaseFn, EmitFn> f{base_at, emit, begin > warm ? begin - warm : 0, begin, 0};
+    sketch_core<WMAX>(end - f.s0, w, k, 0, f, f, end >= len);
 }
 
 template <int WMAX>

@@ -14,6 +14,7 @@
 #include "align_kernel.h"
 #include "device/dev_util.hpp"
 #include "readset.hpp"
+#include "ref_index_device.h"
 
 using namespace pmx;
 using namespace pmx::aln;
@@ -30,6 +31,8 @@ struct pmx_aligner {
     DevBuf<float> d_logf_ratio, d_logf_int;
     DevBuf<uint64_t> d_pk, d_pk_amb;
     DevBuf<uint32_t> d_ht_pv;
+    RefIndexDevice dev_index;   // the index when it was built on the device (set_reference)
+    bool logf_uploaded = false;
     RefIndex ri;
     int mean_len = 150;
     // last result
@@ -94,32 +97,98 @@ int pmx_aligner_set_reference(pmx_ctx* ctx, pmx_aligner* al, const char* referen
     if (!ctx || !al || !reference || ref_len <= 0) return PMX_ERR_ARG;
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
-    PMX_HIP(hipStreamSynchronize(ctx->stream));   // nothing may still read the old index
     al->mean_len = mean_read_len;
     al->opt = make_opt(mean_read_len);
     const int max_score = std::max(8192, (mean_read_len * 4 + 1024) * (al->opt.a + 1));
-    build_ref_index(reference, ref_len, al->opt, max_score, al->host);
-    upload(al->d_seq, al->host.seq, ctx->stream);
-    upload(al->d_ht, al->host.ht, ctx->stream);
-    upload(al->d_pos, al->host.pos, ctx->stream);
-    upload(al->d_logf_ratio, al->host.logf_ratio, ctx->stream);
-    upload(al->d_logf_int, al->host.logf_int, ctx->stream);
-    upload(al->d_pk, al->host.pk, ctx->stream);
-    upload(al->d_pk_amb, al->host.pk_amb, ctx->stream);
-    upload(al->d_ht_pv, al->host.ht_pv, ctx->stream);
     RefIndex& r = al->ri;
-    r.seq = al->d_seq.p;
+    // Device build (ref_index_kernels.hip): stream-ordered behind whatever still reads the old index, one short host round
+    // trip.  PMX_ALIGN_HOST_INDEX=1, an even k, a reference of 2 Mb or more, or a repeat-rich reference whose mid_occ the
+    // counters cannot decide: the host build.
+    bool on_device = false;
+    if (!getenv("PMX_ALIGN_HOST_INDEX") && ref_index_device_supported(al->opt, ref_len))
+        on_device = build_ref_index_device(ctx->stream, reference, ref_len, al->opt, al->dev_index);
+    if (on_device) {
+        const bool new_tables = finish_ref_opt(al->opt, max_score, al->host) || !al->logf_uploaded;
+        if (new_tables) {
+            upload(al->d_logf_ratio, al->host.logf_ratio, ctx->stream);
+            upload(al->d_logf_int, al->host.logf_int, ctx->stream);
+            PMX_HIP(hipStreamSynchronize(ctx->stream));   // (pageable source)
+            al->logf_uploaded = true;
+        }
+        const RefIndexDevice& d = al->dev_index;
+        r.seq = d.seq.p;
+        r.ht_mask = d.ht_mask;
+        r.ht = d.ht.p;
+        r.pos = d.pos.p;
+        r.pk = d.pk.p;
+        r.pk_amb = d.pk_amb.p;
+        r.ht_pv = d.ht_pv.p;
+    } else {
+        PMX_HIP(hipStreamSynchronize(ctx->stream));   // nothing may still read the old index
+        al->opt = make_opt(mean_read_len);
+        build_ref_index(reference, ref_len, al->opt, max_score, al->host);
+        upload(al->d_seq, al->host.seq, ctx->stream);
+        upload(al->d_ht, al->host.ht, ctx->stream);
+        upload(al->d_pos, al->host.pos, ctx->stream);
+        upload(al->d_logf_ratio, al->host.logf_ratio, ctx->stream);
+        upload(al->d_logf_int, al->host.logf_int, ctx->stream);
+        upload(al->d_pk, al->host.pk, ctx->stream);
+        upload(al->d_pk_amb, al->host.pk_amb, ctx->stream);
+        upload(al->d_ht_pv, al->host.ht_pv, ctx->stream);
+        al->logf_uploaded = true;
+        r.seq = al->d_seq.p;
+        r.ht_mask = (uint32_t)al->host.ht.size() - 1;
+        r.ht = al->d_ht.p;
+        r.pos = al->d_pos.p;
+        r.pk = al->d_pk.p;
+        r.pk_amb = al->d_pk_amb.p;
+        r.ht_pv = al->d_ht_pv.p;
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+    }
     r.len = (int32_t)ref_len;
-    r.ht_mask = (uint32_t)al->host.ht.size() - 1;
-    r.ht = al->d_ht.p;
-    r.pos = al->d_pos.p;
     r.logf_ratio = al->d_logf_ratio.p;
     r.logf_int = al->d_logf_int.p;
     r.n_logf = (int32_t)al->host.logf_int.size();
-    r.pk = al->d_pk.p;
-    r.pk_amb = al->d_pk_amb.p;
-    r.ht_pv = al->d_ht_pv.p;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+int pmx_aligner_index_digest(pmx_ctx* ctx, pmx_aligner* al, uint64_t out[5]) {
+    if (!ctx || !al || !out) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    const RefIndex& r = al->ri;
+    const size_t cap = (size_t)r.ht_mask + 1;
+    std::vector<HtEnt> ht(cap);
+    std::vector<uint32_t> pv(cap);
+    PMX_HIP(hipMemcpyAsync(ht.data(), r.ht, cap * sizeof(HtEnt), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipMemcpyAsync(pv.data(), r.ht_pv, cap * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t n_pos = 0, n_keys = 0;
+    for (const HtEnt& e : ht)
+        if (e.key != UINT64_MAX) { ++n_keys; n_pos = std::max<uint64_t>(n_pos, (uint64_t)e.off + e.cnt); }
+    std::vector<uint64_t> pos((size_t)n_pos);
+    if (n_pos) PMX_HIP(hipMemcpy(pos.data(), r.pos, n_pos * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    uint64_t digest = 0, covered = 0;
+    for (size_t s = 0; s < cap; ++s) {
+        const HtEnt& e = ht[s];
+        if (e.key == UINT64_MAX) continue;
+        if (((uint32_t)mix64(e.key) & r.ht_mask) != s) {   // every slot between the home slot and this one must be taken
+            for (uint32_t q = (uint32_t)mix64(e.key) & r.ht_mask; q != s; q = (q + 1) & r.ht_mask)
+                if (ht[q].key == UINT64_MAX) return fail(PMX_ERR_DEVICE, "reference index: a key is not reachable by linear probing");
+        }
+        uint64_t h = mix64(e.key) ^ mix64((uint64_t)e.cnt + 0x9e3779b97f4a7c15ULL);
+        for (uint32_t q = 0; q < e.cnt; ++q) h = mix64(h ^ (pos[(size_t)e.off + q] + q));
+        if (e.cnt == 1 && (pos[e.off] >> 32) == 0 && pv[s] != (uint32_t)pos[e.off]) return fail(PMX_ERR_DEVICE, "reference index: ht_pv does not match pos");
+        if (e.cnt != 1 && pv[s] != 0xffffffffu) return fail(PMX_ERR_DEVICE, "reference index: ht_pv set for a repeated minimizer");
+        digest += h;
+        covered += e.cnt;
+    }
+    out[0] = covered;
+    out[1] = n_keys;
+    out[2] = (uint64_t)(int64_t)al->opt.mid_occ;
+    out[3] = digest;
+    out[4] = r.ht == al->dev_index.ht.p ? 1 : 0;
     return PMX_OK;
     PMX_CATCH
 }

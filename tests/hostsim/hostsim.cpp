@@ -274,3 +274,28 @@ extern "C" int hs_shortcut_fuzz(uint64_t seed, int64_t n_cases, int64_t* counts 
     return 0;
 }
 #endif
+
+// The reference sketch: slice == 0 -> the sequential sketch_segment_t (what build_ref_index runs); slice > 0 -> the
+// concatenation of sketch_slice over consecutive slices of that many bases (what the device index build runs).
+extern "C" int64_t hs_ref_sketch(const char* ref, int64_t len, int w, int k, int slice, uint64_t* out_x, uint64_t* out_y, int64_t cap) {
+    std::vector<uint8_t> seq((size_t)len + 8, 0);
+    for (int64_t i = 0; i < len; ++i) seq[(size_t)i] = nt4_of_char((unsigned char)ref[i]);
+    int64_t n = 0;
+    if (slice <= 0) {
+        Work W;
+        memset(&W, 0, sizeof(W));
+        std::vector<A128> mv((size_t)len + 16), buf(256);
+        W.mv = mv.data();
+        W.sk_buf = buf.data();
+        W.caps.max_mini = (int)mv.size();
+        RingMem ring{W.sk_buf};
+        sketch_segment_t(W, ring, (Ptr<const uint8_t>)seq.data(), (int)len, w, k, 0);
+        for (int i = 0; i < W.n_mv && n < cap; ++i, ++n) { out_x[n] = mv[(size_t)i].x; out_y[n] = mv[(size_t)i].y; }
+        return W.n_mv;
+    }
+    auto base_at = [&](int i) { return (int)seq[(size_t)i]; };
+    auto emit = [&](uint64_t x, uint64_t y) { if (n < cap) { out_x[n] = x; out_y[n] = y; } ++n; };
+    for (int64_t b = 0; b < len; b += slice)
+        sketch_slice<12>((int)b, (int)std::min<int64_t>(len, b + slice), (int)len, w, k, base_at, emit);
+    return n;
+}

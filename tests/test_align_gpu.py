@@ -234,3 +234,52 @@ def test_golden_fixture_gpu(pmx, ctx):
         assert not bad, (name, bad[:10])
         assert sum(1 for x in got if x["flags"] & 3) <= 2
 
+
+
+@pytest.mark.gpu
+def test_device_and_host_reference_index_are_the_same_index(pmx, sars, monkeypatch):
+    """mm_idx_str (index.c:408-451) twice: on the device from 64-base slices (ref_index_kernels.hip) and by the host
+    restatement (build_ref_index): same minimizers, same occurrence lists in the same order, same mid_occ -- on real
+    genomes, on references with N runs / homopolymers / tandem repeats, and for the long-read preset (mid_occ taken
+    from the index); a repeat-rich reference makes the device build hand over to the host build"""
+    ctx = pmx.Context(0)
+    rng = np.random.default_rng(17)
+
+    def rand_ref(n, junk=True):
+        s = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+        if junk:
+            for _ in range(n // 300 + 1):
+                p = int(rng.integers(0, n)); t = int(rng.integers(0, 4)); ln = int(rng.integers(1, 80))
+                if t == 0:
+                    s[p:p + ln] = ord("N")
+                elif t == 1:
+                    s[p:p + ln] = s[p]
+                elif t == 2:
+                    u = s[p:p + int(rng.integers(2, 7))].copy()
+                    rep = np.tile(u, 60)[:3 * ln]
+                    s[p:p + len(rep)] = rep[:len(s[p:p + len(rep)])]
+                else:
+                    s[p] = ord("n")
+        return bytes(s)
+    rsv = pmx.Panman(os.path.join(os.path.dirname(__file__), "golden", "rsv_4K.panman"))
+    refs = [sars.genome("node_7618"), sars.genome(0), rsv.genome("MZ515733.1"), rand_ref(70), rand_ref(1000), rand_ref(30000), rand_ref(200000),
+            b"ACGT" * 40, rand_ref(5000, junk=False).lower()]
+    al = pmx.Aligner(ctx, refs[0], 150)
+    for ref in refs:
+        for mean_len in (150, 3000):          # short-read preset (mid_occ fixed) and map-ont (mid_occ from the index)
+            monkeypatch.delenv("PMX_ALIGN_HOST_INDEX", raising=False)
+            al.set_reference(ref, mean_len)
+            dev = al.index_digest()
+            monkeypatch.setenv("PMX_ALIGN_HOST_INDEX", "1")
+            al.set_reference(ref, mean_len)
+            host = al.index_digest()
+            assert host[4] == 0
+            assert dev[:4] == host[:4], (len(ref), mean_len, dev, host)
+            if mean_len == 150:
+                assert dev[4] == 1, len(ref)       # (the long-read preset may hand a repeat-rich reference to the host build)
+    # forty copies of one 500-base unit: every minimizer occurs forty times, the mid_occ quantile is above the clamp
+    monkeypatch.delenv("PMX_ALIGN_HOST_INDEX", raising=False)
+    unit = rand_ref(500, junk=False)
+    al.set_reference(unit * 40, 3000)
+    rep = al.index_digest()
+    assert rep[4] == 0 and rep[2] > 10
