@@ -226,7 +226,7 @@ PMX_HD void sketch_core(int len, int w, int k, uint64_t y_hi, BaseFn& base_at, P
 // its own reverse complement, so the window advances at every base and the state after base i -- the last w entries,
 // their minimum (always the newest minimal entry, whatever path led there), the run length since the last ambiguous base
 // as far as the thresholds k, w+k-1 and w+k can tell -- is a function of the bases (i - w - k, i]: a run that starts
-// 2 (w + k) bases early is in the true state by `begin`.  emit(x, y): y carries the position in the whole sequence.
+// w + k + 1 bases early is in the true state by `begin` (tests/test_align_host.py runs the slices against the whole).  emit(x, y): y carries the position in the whole sequence.
 template <int WMAX, class BaseFn, class EmitFn>
 struct SketchSlice {
     BaseFn& base; EmitFn& emit; int s0, begin, cur;
@@ -235,7 +235,7 @@ struct SketchSlice {
 };
 template <int WMAX, class BaseFn, class EmitFn>
 PMX_HD void sketch_slice(int begin, int end, int len, int w, int k, BaseFn& base_at, EmitFn& emit) {
-    const int warm = 2 * (w + k);
+    const int warm = w + k + 1;
     SketchSlice<WMAX, BaseFn, EmitFn> f{base_at, emit, begin > warm ? begin - warm : 0, begin, 0};
     sketch_core<WMAX>(end - f.s0, w, k, 0, f, f, end >= len);
 }

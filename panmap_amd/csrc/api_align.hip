@@ -41,7 +41,7 @@ struct pmx_aligner {
     DevBuf<unsigned long long> cigar_used;
     DevBuf<uint8_t> slow, slow2, slab0, slab_raw;
     DevBuf<A128> mv_handover;
-    DevBuf<uint32_t> pp_key, pp_key2, pp_idx, pp_idx2;   // pair order of the thread-per-pair kernel
+    DevBuf<uint32_t> pp_idx, pp_idx2;   // pair order of the thread-per-pair kernels
     DevBuf<char> pp_tmp;
     uint32_t mv_epoch = 0;
     DevBuf<uint32_t> retry_list2, bail_list;
@@ -63,14 +63,12 @@ struct pmx_aligner {
     double last_occupancy = 0;
 };
 
-// locality key of an item (read or read pair) for the thread-per-pair launch order: read_locality_key of its first read
-__global__ void k_pair_prefix_keys(const uint64_t* __restrict__ words, const int64_t* __restrict__ woff, int64_t n_items, int reads_per_item,
-                                   uint32_t* key, uint32_t* idx) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i * reads_per_item;
-        key[i] = woff[r + 1] > woff[r] ? read_locality_key(words[woff[r]]) : 0u;
-        idx[i] = (uint32_t)i;
-    }
+// pair order from the read order: first mates (even read indices) of the read set's locality order -> pair indices
+struct IsEvenRead {
+    __host__ __device__ bool operator()(const uint32_t& r) const { return (r & 1u) == 0u; }
+};
+__global__ void k_halve(const uint32_t* __restrict__ in, int64_t n, uint32_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[i] >> 1;
 }
 
 namespace {
@@ -389,17 +387,20 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 PMX_HIP(hipGetLastError());
             };
             const uint32_t* order = nullptr;   // launch order of the first pass: pairs sorted by a locality key
-            if (n_items >= 4096 && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_PAIR_SORT")) {
-                al->pp_key.ensure((size_t)n_items); al->pp_key2.ensure((size_t)n_items); al->pp_idx.ensure((size_t)n_items); al->pp_idx2.ensure((size_t)n_items);
-                hipLaunchKernelGGL(k_pair_prefix_keys, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
-                                   rs->words.p, rs->woff.p, n_items, paired ? 2 : 1, al->pp_key.p, al->pp_idx.p);
-                size_t bytes = 0;
-                unsigned sort_bits = 32;
-                if (const char* e = getenv("PMX_ALIGN_SORT_BITS")) sort_bits = (unsigned)std::max(1, std::min(32, atoi(e)));
-                PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, sort_bits, ctx->stream));
-                al->pp_tmp.ensure(bytes);
-                PMX_HIP(rocprim::radix_sort_pairs(al->pp_tmp.p, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, sort_bits, ctx->stream));
-                order = al->pp_idx2.p;
+            if (!getenv("PMX_ALIGN_NO_PAIR_SORT")) {
+                // the read set's locality order (shared with the seeding stage); pairs: the even reads of it, in that order
+                const uint32_t* read_order = readset_locality_order(ctx, rs);
+                if (read_order && !paired) order = read_order;
+                else if (read_order) {
+                    al->pp_idx.ensure((size_t)rs->n); al->pp_idx2.ensure((size_t)n_items + 1);
+                    size_t bytes = 0;
+                    PMX_HIP(rocprim::select(nullptr, bytes, read_order, al->pp_idx.p, al->pp_idx2.p + n_items, (size_t)rs->n, IsEvenRead(), ctx->stream));
+                    al->pp_tmp.ensure(bytes);
+                    PMX_HIP(rocprim::select(al->pp_tmp.p, bytes, read_order, al->pp_idx.p, al->pp_idx2.p + n_items, (size_t)rs->n, IsEvenRead(), ctx->stream));
+                    hipLaunchKernelGGL(k_halve, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                                       al->pp_idx.p, n_items, al->pp_idx2.p);
+                    order = al->pp_idx2.p;
+                }
             }
             // Compact tier (align_kernel_compact.hip): every pair first, work state in LDS; what it cannot finish comes
             // back as the bail list, which is the launch order of the general thread-per-pair kernel below.

@@ -39,8 +39,9 @@ struct pmx_place {
     bool table_dirty = false;              // something was inserted since the last reset
     bool needs_clear = false;              // reset happened: the slots are cleared (or the table re-made at a better size) by the next reservation
     double bases_added = 0;                // read bases (n x max_len) seeded since the last reset
+    unsigned long long h_ctr[PMX_CTR_N];   // the counters as last read back; valid while nothing has been inserted since
+    bool h_ctr_valid = false;
     double keys_per_base = 0;              // distinct seeds per read base of the last finished histogram (0: none yet): sizes the next table
-    DevBuf<uint32_t> sk_key, sk_key2, sk_idx, sk_idx2;   // seeding order: reads sorted by their first 16 bases
     hipStream_t seed_streams[3] = {nullptr, nullptr, nullptr};   // side streams: seeding launches of one group run concurrently
     hipEvent_t seed_go = nullptr, seed_done[3] = {nullptr, nullptr, nullptr};
     // finalised histogram
@@ -145,9 +146,12 @@ void table_reserve(pmx_ctx* ctx, pmx_place* pl, uint64_t bound_new) {
 // table -> hash-sorted (hash,count) arrays
 void finalize_histogram(pmx_ctx* ctx, pmx_place* pl) {
     if (pl->hist_sorted) return;
-    unsigned long long h_ctr[PMX_CTR_N];
-    PMX_HIP(hipMemcpyAsync(h_ctr, pl->counters.p, sizeof(h_ctr), hipMemcpyDeviceToHost, ctx->stream));
-    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long* h_ctr = pl->h_ctr;
+    if (!pl->h_ctr_valid) {   // (the overflow check that ends an optimistic seeding pass has read them already)
+        PMX_HIP(hipMemcpyAsync(h_ctr, pl->counters.p, sizeof(pl->h_ctr), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        pl->h_ctr_valid = true;
+    }
     if (h_ctr[PMX_CTR_OVERFLOW]) throw std::runtime_error("seed table overflow (internal sizing error)");
     int64_t n = 0;
     for (int i = 0; i < PMX_CTR_NSHARD; ++i) n += (int64_t)h_ctr[PMX_CTR_SHARD0 + i];
@@ -158,8 +162,7 @@ void finalize_histogram(pmx_ctx* ctx, pmx_place* pl) {
     pl->hist_hash_tmp.ensure(n);
     pl->hist_count_tmp.ensure(n);
     if (n > 0) {
-        unsigned long long zero = 0;
-        PMX_HIP(hipMemcpyAsync(pl->counters.p + PMX_CTR_COMPACT, &zero, sizeof(zero), hipMemcpyHostToDevice, ctx->stream));
+        PMX_HIP(hipMemsetAsync(pl->counters.p + PMX_CTR_COMPACT, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_table_compact, dim3(grid_for((int64_t)pl->cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p,
                            pl->vals.p, pl->cap, pl->hist_hash_tmp.p, pl->hist_count_tmp.p, pl->counters.p + PMX_CTR_COMPACT);
         size_t bytes = 0;
@@ -198,6 +201,23 @@ struct Best {
 };
 
 }  // namespace
+
+namespace pmx {
+const uint32_t* readset_locality_order(pmx_ctx* ctx, const pmx_readset* rs) {
+    const int64_t n = rs->n;
+    if (!rs->packed || n < 4096 || n >= (int64_t)UINT32_MAX) return nullptr;
+    if (rs->has_order) return rs->loc_perm.p;
+    rs->loc_key.ensure((size_t)n); rs->loc_key2.ensure((size_t)n); rs->loc_idx.ensure((size_t)n); rs->loc_perm.ensure((size_t)n);
+    hipLaunchKernelGGL(k_read_prefix_keys, dim3(grid_for(n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rs->words.p, rs->woff.p, n, rs->loc_key.p,
+                       rs->loc_idx.p);
+    size_t bytes = 0;
+    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, rs->loc_key.p, rs->loc_key2.p, rs->loc_idx.p, rs->loc_perm.p, (size_t)n, 0, 32, ctx->stream));
+    rs->loc_tmp.ensure(bytes);
+    PMX_HIP(rocprim::radix_sort_pairs(rs->loc_tmp.p, bytes, rs->loc_key.p, rs->loc_key2.p, rs->loc_idx.p, rs->loc_perm.p, (size_t)n, 0, 32, ctx->stream));
+    rs->has_order = true;
+    return rs->loc_perm.p;
+}
+}  // namespace pmx
 
 extern "C" {
 
@@ -331,6 +351,7 @@ int pmx_readset_rewrap_device(pmx_ctx* ctx, pmx_readset* rs, const void* d_conca
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     rs->packed = false;
+    rs->has_order = false;
     rs->has_qual = false;
     rs->n = n_reads;
     rs->ascii.wrap((uint8_t*)d_concat, (size_t)total_bytes);
@@ -386,6 +407,7 @@ int pmx_readset_pack(pmx_ctx* ctx, pmx_readset* rs) {
                            rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p);
     PMX_HIP(hipGetLastError());
     rs->packed = true;
+    rs->has_order = false;   // (the buffer behind a wrapped read set may hold new reads)
     return PMX_OK;
     PMX_CATCH
 }
@@ -507,6 +529,7 @@ int pmx_place_reset(pmx_ctx* ctx, pmx_place* pl) {
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     PMX_HIP(hipMemsetAsync(pl->counters.p, 0, sizeof(unsigned long long) * PMX_CTR_N, ctx->stream));
+    pl->h_ctr_valid = false;
     pl->needs_clear = pl->cap != 0;   // the slots are cleared by the next reservation, which may also pick a better size
     pl->bases_added = 0;
     pl->n_reads_added = 0;
@@ -522,6 +545,7 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
     if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack first)");
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
+    pl->h_ctr_valid = false;
     SeedParams sp;
     sp.k = pl->params.k; sp.s = pl->params.s; sp.t = pl->params.t; sp.l = pl->params.l; sp.open = pl->params.open ? 1 : 0;
     sp.trim_start = pp->trim_start; sp.trim_end = pp->trim_end;
@@ -582,20 +606,7 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         // seeding order (default-parameter kernel): reads that start with the same 16 bases next to each other, so that a
         // block's (seed, count) cache sees its seeds many times (k_seed_histogram_ks)
         const bool ks_path = sp.k == 19 && sp.s == 8 && sp.t == 0 && (l == 3 || l == 1) && !quality_mode && !getenv("PMX_SEED_GENERIC");
-        const uint32_t* perm = nullptr;
-        if (ks_path && rs->n >= 4096 && rs->n < (int64_t)UINT32_MAX && !getenv("PMX_SEED_NO_SORT")) {
-            const int64_t n = rs->n;
-            pl->sk_key.ensure((size_t)n); pl->sk_key2.ensure((size_t)n); pl->sk_idx.ensure((size_t)n); pl->sk_idx2.ensure((size_t)n);
-            hipLaunchKernelGGL(k_read_prefix_keys, dim3(grid_for(n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rs->words.p, rs->woff.p, n,
-                               pl->sk_key.p, pl->sk_idx.p);
-            size_t bytes = 0;
-            unsigned sort_bits = 32;
-            if (const char* e = getenv("PMX_SEED_SORT_BITS")) sort_bits = (unsigned)std::max(1, std::min(32, atoi(e)));
-            PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, sort_bits, ctx->stream));
-            pl->tmp.ensure(bytes);
-            PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->sk_key.p, pl->sk_key2.p, pl->sk_idx.p, pl->sk_idx2.p, (size_t)n, 0, sort_bits, ctx->stream));
-            perm = pl->sk_idx2.p;
-        }
+        const uint32_t* perm = ks_path && !getenv("PMX_SEED_NO_SORT") ? readset_locality_order(ctx, rs) : nullptr;
         // the specialised kernel keeps its rings in registers: LDS = the waves' seed queues + the block cache (keys 8 B +
         // counts 4 B + admission tags 2 B per entry)
         const size_t lds_ks = (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS * sizeof(uint64_t) + (size_t)PMX_SEED_CACHE * 14 + 35 * sizeof(uint64_t);   // + the base-hash tables
@@ -638,9 +649,10 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             }
         }
         if (bound_div == 1) break;
-        unsigned long long h_ovf = 0;
-        PMX_HIP(hipMemcpyAsync(&h_ovf, pl->counters.p + PMX_CTR_OVERFLOW, sizeof(h_ovf), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(pl->h_ctr, pl->counters.p, sizeof(pl->h_ctr), hipMemcpyDeviceToHost, ctx->stream));   // (finalize_histogram reuses them)
         PMX_HIP(hipStreamSynchronize(ctx->stream));
+        pl->h_ctr_valid = true;
+        const unsigned long long h_ovf = pl->h_ctr[PMX_CTR_OVERFLOW];
         if (getenv("PMX_PLACE_PROF")) fprintf(stderr, "[pmx place] seeding with bound 1/%lld: table %llu slots, %llu failed inserts\n", (long long)bound_div, (unsigned long long)pl->cap, h_ovf);
         if (h_ovf == 0) break;
         // the optimistic table overflowed: start over with the safe bound
@@ -709,6 +721,7 @@ int pmx_place_histogram_merge_device(pmx_ctx* ctx, pmx_place* pl, const void* d_
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     pl->hist_sorted = false;
     pl->table_dirty = true;
+    pl->h_ctr_valid = false;
     return PMX_OK;
     PMX_CATCH
 }
@@ -736,6 +749,7 @@ int pmx_place_histogram_merge_device_parts(pmx_ctx* ctx, pmx_place* pl, const vo
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     pl->hist_sorted = false;
     pl->table_dirty = true;
+    pl->h_ctr_valid = false;
     return PMX_OK;
     PMX_CATCH
 }
@@ -756,6 +770,7 @@ int pmx_place_histogram_merge(pmx_ctx* ctx, pmx_place* pl, const uint64_t* hash,
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     pl->hist_sorted = false;
     pl->table_dirty = true;
+    pl->h_ctr_valid = false;
     return PMX_OK;
     PMX_CATCH
 }

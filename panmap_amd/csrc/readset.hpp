@@ -19,4 +19,16 @@ struct pmx_readset {
     pmx::DevBuf<char> scan_tmp;    // rewrap: rocprim temp storage
     pmx::DevBuf<unsigned long long> stats;
     int64_t off0 = 0;              // first offset (non-zero for a wrapped slice of a larger offsets array)
+    // locality order of the reads (read_locality_key, device/pmx_math.h): computed once per packing, on first request, and
+    // shared by the seeding launch order (place stage) and the pair order of the align stage
+    mutable pmx::DevBuf<uint32_t> loc_key, loc_key2, loc_idx, loc_perm;
+    mutable pmx::DevBuf<char> loc_tmp;
+    mutable bool has_order = false;
 };
+
+struct pmx_ctx;
+namespace pmx {
+// reads sorted by locality key (stable), as a permutation of 0..n-1 on the device; enqueued on the context's stream the
+// first time it is asked for after a (re)packing.  nullptr for read sets too small or too large for it.
+const uint32_t* readset_locality_order(pmx_ctx* ctx, const pmx_readset* rs);
+}

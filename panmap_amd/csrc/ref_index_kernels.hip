@@ -2,7 +2,7 @@
 // 408-451, called once per sample at src/mm_align.c:192) built ON THE DEVICE.  The host build (align/aln_host.hpp
 // build_ref_index: sequential sketch, sort, table, eight uploads) kept the GPU idle for ~1 ms of an 11 ms step between
 // the placement result and the first align kernel; here the genome goes up as ASCII once and five small launches make
-// the same index: encode -> sketch (one thread per 64-base slice, align/aln_seed.hpp sketch_slice) -> radix sort of
+// the same index: encode -> sketch (one thread per 32-base slice, align/aln_seed.hpp sketch_slice) -> radix sort of
 // (minimizer << 22 | position word) -> run starts / counts -> hash table.  One host round trip in the middle sizes the
 // table by the number of distinct minimizers exactly as the host build does, so both builds describe the same index
 // (same keys, same occurrence lists in the same order; slot order within a probe run may differ, lookups cannot).
@@ -22,7 +22,7 @@ namespace pmx {
 namespace aln {
 
 namespace {
-constexpr int kSlice = 64;        // bases per sketch thread (+ 2 (w + k) of run-in)
+constexpr int kSlice = 32;        // bases per sketch thread (+ w + k + 1 of run-in)
 constexpr int kPosBits = 22;      // position word (position << 1 | strand) in the sort key: references below 2^21 bases
 constexpr uint64_t kNoKey = ~0ULL;
 

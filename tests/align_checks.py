@@ -79,6 +79,20 @@ def hostsim_align_compact(reference: bytes, reads, rc2=False):
     return records_to_results(recs, cig, n, True), done[:n // 2]
 
 
+def hostsim_ref_sketch(reference: bytes, w: int, k: int, slice_len: int = 0):
+    """minimizers of a reference: slice_len == 0 -> the sequential sketch the host index build runs, > 0 -> the
+    concatenation of independent slices of that many bases (what the device index build runs) -> (x, y) arrays"""
+    L = hostsim(False)
+    L.hs_ref_sketch.restype = C.c_int64
+    L.hs_ref_sketch.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+    cap = len(reference) + 16
+    x = np.zeros(cap, np.uint64)
+    y = np.zeros(cap, np.uint64)
+    n = L.hs_ref_sketch(reference, len(reference), w, k, slice_len, x.ctypes.data, y.ctypes.data, cap)
+    assert 0 <= n <= cap
+    return x[:n].copy(), y[:n].copy()
+
+
 def golden_cases(pmx):
     """(genome, {name: (reads, expected results)}) of tests/golden/align_golden.json.gz; the inputs are regenerated
     exactly as tests/golden/make_align_golden.py made them"""

@@ -112,3 +112,33 @@ def test_compact_tier_equals_reference(pmx, oracle, cases):
     got_rc, done_rc = ac.hostsim_align_compact(g, raw, rc2=True)
     got, done = ac.hostsim_align_compact(g, clean)
     assert np.array_equal(done, done_rc) and not ac.compare_results(got_rc, got)
+
+
+def test_sliced_reference_sketch_equals_the_sequential_one(pmx, sars):
+    """the device index build sketches the reference in independent 32-base slices with w + k + 1 bases of run-in
+    (align/aln_seed.hpp sketch_slice); the host build runs sketch.c:77-143 from end to end: same minimizers in the same
+    order, on genomes and on sequences full of N runs, homopolymers and tandem repeats, for several slice lengths"""
+    rng = np.random.default_rng(3)
+
+    def rand_seq(n):
+        s = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+        for _ in range(n // 300 + 1):
+            p = int(rng.integers(0, n)); t = int(rng.integers(0, 4)); ln = int(rng.integers(1, 60))
+            if t == 0:
+                s[p:p + ln] = ord("N")
+            elif t == 1:
+                s[p:p + ln] = s[p]
+            elif t == 2:
+                u = s[p:p + int(rng.integers(2, 7))].copy()
+                rep = np.tile(u, 40)[:3 * ln]
+                s[p:p + len(rep)] = rep[:len(s[p:p + len(rep)])]
+            else:
+                s[p] = ord("N")
+        return bytes(s)
+    seqs = [sars.genome("node_7618")] + [rand_seq(n) for n in (50, 200, 1000, 5000, 20000, 777)] + [b"A" * 500, b"AC" * 300, b"N" * 100 + b"ACGTTGCA" * 50]
+    for s in seqs:
+        for w, k in ((11, 21), (5, 15), (12, 19), (10, 15)):
+            x0, y0 = ac.hostsim_ref_sketch(s, w, k, 0)
+            for sl in (32, 37, 128, 1000):
+                x1, y1 = ac.hostsim_ref_sketch(s, w, k, sl)
+                assert np.array_equal(x0, x1) and np.array_equal(y0, y1), (len(s), w, k, sl)
