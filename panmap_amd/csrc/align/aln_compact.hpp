@@ -11,10 +11,10 @@
 //     a query word (2 bytes) and BECOMES the anchor in place (the heap merge of map.c:102-166 runs on a heap of one-byte
 //     seed indices, its pop order is turned into destinations and the seeds are permuted along the cycles); a chain
 //     cell is 2 bytes (score | predecessor); chain members and per-mate anchor lists are one-byte indices;
-//   * 48 anchors per pair (99.2 % of 150 bp pairs; mean 40): 336 bytes per pair (432 with 32-bit positions),
-//     interleaved word-wise across the 64 lanes of a wave in LDS (conflict-free): 21 KB per wave, seven waves per CU;
+//   * 56 anchors per pair (99.9 % of 150 bp pairs; mean 40): 392 bytes per pair (504 with 32-bit positions),
+//     interleaved word-wise across the 64 lanes of a wave in LDS (conflict-free): 25 KB per wave, six waves per CU;
 //   * regions are a handful of scalars in registers: at most one region per mate is followed.
-// Everything outside that envelope -- an ambiguous base, a seed that occurs twice in the reference, more than 48 seeds,
+// Everything outside that envelope -- an ambiguous base, a seed that occurs twice in the reference, more than 56 seeds,
 // a third chain, two regions on one mate, an extension or gap fill the closed forms (aln_ksw.hpp, ksw_shortcut_*) do
 // not answer -- makes the pair BAIL: nothing is written and the general thread-per-pair tier (which posts DP requests,
 // splits regions, ...) runs it.  A pair this tier finishes gets exactly the record the general pipeline computes; the
@@ -94,11 +94,13 @@ PMX_HD int32_t c_chain_score_tab(const CPenTab& T, uint32_t xi, int32_t yi, int3
 template <class PT>
 struct CMemT {
     c_u32* base;
+    static constexpr int kCap = PMX_C_CAP;
     static constexpr int kXH = 0;                                        // X in units of PT
-    static constexpr int kYH = (int)(sizeof(PT) / 2) * PMX_C_CAP;        // Y, G in halves
-    static constexpr int kGH = kYH + PMX_C_CAP;
-    static constexpr int kBB = 2 * (kGH + PMX_C_CAP);                    // B in bytes
-    static constexpr int kWords = (kBB + PMX_C_CAP + 3) / 4;
+    static constexpr int kYH = (int)(sizeof(PT) / 2) * kCap;             // Y, G in halves
+    static constexpr int kGH = kYH + kCap;
+    static constexpr int kBB = 2 * (kGH + kCap);                         // B in bytes
+    static constexpr int kWords = (kBB + kCap + 3) / 4;
+    static_assert(kCap <= 63, "predecessor + 1 in six bits, marks and the used set in 64");
     static constexpr int kMCap = kWords / 2 < PMX_C_MCAP ? kWords / 2 : PMX_C_MCAP;
     static constexpr uint32_t kRevBit = 1u << (8 * sizeof(PT) - 1);
     PMX_HD c_u32& w(int i) const { return base[i * PMX_C_STRIDE]; }
@@ -494,7 +496,7 @@ PMX_HD int c_filter_mapq(const Opt& o, const RefIndex& ri, int qlen, CReg& r, bo
 
 // Minimizers -> index probes -> seeds, one read at a time.  The object is BOTH functors of sketch_core: operator()(i)
 // hands out base i (and is where the wave drains its queues: it runs once per base in every lane), operator()(x, y)
-// queues a minimizer.  Minimizers wait for their probes in a short queue that overlays G and B (18 entries); the whole
+// queues a minimizer.  Minimizers wait for their probes in a short queue that overlays G and B (21 entries); the whole
 // wave drains its queues together -- four probes in flight per lane -- whenever some lane holds six (one base can add
 // up to w), so the drain is a uniform branch and the seeds never need a staging copy of the minimizer list.  The newest
 // entry stays queued until its right neighbour is known (the tandem mark compares adjacent minimizers, seed.c:40-46).
@@ -502,7 +504,7 @@ template <class PT>
 struct CSeeder {
     typedef CMemT<PT> MT;
     static constexpr int kQBase = (MT::kGH / 2 + 1) / 2;              // first M entry that lies above X and Y
-    static constexpr int kQCap = MT::kWords / 2 - kQBase;             // 18
+    static constexpr int kQCap = MT::kWords / 2 - kQBase;             // 21
     static constexpr int kQDrain = kQCap - 12 > 1 ? kQCap - 12 : 1;   // drain threshold
     static_assert(kQCap >= 14, "minimizer queue too short for one base's worth of pushes");
     const MT& m;
@@ -554,7 +556,7 @@ struct CSeeder {
                     first_of_read = false;
                     if (cnt > 1) bail = true;                      // a repeated minimizer: general tier
                     else if (cnt == 1) {
-                        if (n_s >= PMX_C_CAP || (pv[b] >> (8 * sizeof(PT) - 1) >> 1) != 0u) bail = true;
+                        if (n_s >= MT::kCap || (pv[b] >> (8 * sizeof(PT) - 1) >> 1) != 0u) bail = true;
                         else {
                             m.setX(n_s, pv[b]);
                             m.Y(n_s) = (c_u16)((yl[b] + ((uint32_t)sum << 1)) | (seg ? PMX_CQ_SEG : 0u) | (tandem ? PMX_CQ_TANDEM : 0u));

@@ -437,14 +437,15 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 PMX_HIP(hipMemcpyAsync(&h_bail, al->retry_count.p + 2, sizeof(h_bail), hipMemcpyDeviceToHost, ctx->stream));
                 PMX_HIP(hipStreamSynchronize(ctx->stream));
                 n_t0 = (int64_t)h_bail;
-                al->last_compact = n_items - n_t0;
                 order = al->bail_list.p;
+                al->last_compact = n_items - n_t0;
                 A.retry_list = al->retry_list2.p;
                 A.retry_count = al->retry_count.p;
             }
-            // Few bails: a thread-per-pair launch that small cannot fill the chip and lasts as long as a full one (a wave
-            // takes ~2 ms whatever the grid); the wave-per-pair tier runs them instead.
-            int64_t bail_tpp_min = 0;   // (measured: 7.8 -> 8.7 ms when 7k bails skip the thread-per-pair tier; kept as a switch)
+            // Few bails: a thread-per-pair launch that small cannot fill the chip and lasts as long as a full one (a wave takes
+            // ~2 ms whatever the grid) before the wave-per-pair tier gets the pairs that need a DP; below 4096 bails the wave
+            // tier takes all of them at once (measured with 2.8k bails of 500k pairs: 5.8 ms for the stage instead of 7.0).
+            int64_t bail_tpp_min = 4096;
             if (const char* e = getenv("PMX_ALIGN_BAIL_TPP_MIN")) bail_tpp_min = atoll(e);
             const bool skip_t0 = use_compact && n_t0 < bail_tpp_min;
             A.pair_perm = order;
@@ -508,7 +509,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             A.dp_slot_pairs = nullptr;
             PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
             t1_list = al->retry_list2.p;
-            if (skip_t0) { t1_list = al->bail_list.p; n_t1 = n_t0; }
+            if (skip_t0) { t1_list = order; n_t1 = n_t0; }
             al->last_tpp_retry = n_t1;
         }
         int64_t n_retry = 0, unused = 0;
