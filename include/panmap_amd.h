@@ -190,6 +190,30 @@ int pmx_place_tied(const pmx_place *pl, int metric, uint32_t *out, int64_t cap);
 /* optional per-node outputs (host copies): scores [n_nodes][5] double, metrics [n_nodes][5] double,
    counts [n_nodes][2] int64; any pointer may be NULL */
 int pmx_place_node_outputs(pmx_ctx *ctx, pmx_place *pl, double *scores5, double *metrics5, int64_t *counts2);
+/* --refine (refineTopCandidates, src/placement.cpp:516-698): per metric the top refine_top_pct of the nodes (at most
+ * max_top_n, always with the metric's winner) plus their neighbours within neighbor_radius branches (at most
+ * max_neighbor_n each) are candidates; every candidate is scored once through `fn` (minus the total edit distance of the
+ * reads against its genome: pmx_align_score_reads on pmx_panman_node_genome) and each metric keeps its best candidate
+ * (ties: higher seed score, then lower DFS index).  Host logic; parent / scores5 / best_index as pmx_index_arrays,
+ * pmx_place_node_outputs and pmx_place_result give them.  fn returns 0 on success; anything else aborts with that code. */
+typedef struct {
+    double top_pct;          /* 0.01  (src/main.cpp:186-190) */
+    int32_t max_top_n;       /* 150 */
+    int32_t neighbor_radius; /* 2 */
+    int32_t max_neighbor_n;  /* 150 */
+    int32_t reserved;
+} pmx_refine_params;
+typedef struct {
+    int32_t ran;             /* 0: no node had a positive score */
+    int32_t n_candidates;
+    int64_t score[5];        /* refined_<metric> score, metric order of the placement TSV */
+    uint32_t node[5];        /* DFS index, 0xffffffff = none */
+    uint32_t reserved;
+} pmx_refine_result;
+typedef int (*pmx_refine_score_fn)(void *user, uint32_t dfs_index, int64_t *score);
+int pmx_refine_top_candidates(const uint32_t *parent, int64_t n_nodes, const double *scores5, const uint32_t best_index[5],
+                              const pmx_refine_params *rp, pmx_refine_score_fn fn, void *user, pmx_refine_result *out,
+                              uint32_t *cand_nodes, int64_t *cand_scores, int64_t cand_cap);
 /* kept read seeds after filtering: hash ascending + log1p(count) */
 int64_t pmx_place_kept_seeds(pmx_ctx *ctx, pmx_place *pl, uint64_t *hash, double *logc, int64_t cap);
 
@@ -275,6 +299,11 @@ void pmx_aligner_free(pmx_ctx *ctx, pmx_aligner *al);
    are reverse-complemented on the fly (what readFastqPaired does on the host, src/seeding.cpp:251).
    Results stay on the device until fetched. */
 int pmx_align_readset(pmx_ctx *ctx, pmx_aligner *al, const pmx_readset *rs, int paired, int revcomp_mate2);
+/* [hot, --refine] score_reads_vs_reference (src/mm_align.c:144-199): maps every read (pair) against the aligner's
+ * reference and returns minus the summed count_read_errors (edit distance of the first region: block length - matches +
+ * ambiguous bases; the read length without one).  Leaves the records of the run behind like pmx_align_readset.
+ * Paired scoring needs an even number of reads. */
+int pmx_align_score_reads(pmx_ctx *ctx, pmx_aligner *al, const pmx_readset *rs, int paired, int revcomp_mate2, int64_t *score);
 int64_t pmx_align_num_records(const pmx_aligner *al);
 int64_t pmx_align_cigar_words(pmx_ctx *ctx, pmx_aligner *al);
 int pmx_align_fetch(pmx_ctx *ctx, pmx_aligner *al, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,

@@ -239,3 +239,15 @@ def call_align_reads_direct(fn, reference: bytes, reads, paired: bool, n_threads
 
 def ref_align_reads_direct(reference: bytes, reads, paired: bool, n_threads=1):
     return call_align_reads_direct(rlib().align_reads_direct, reference, reads, paired, n_threads)
+
+
+def ref_score_reads(reference: bytes, reads, paired: bool) -> int:
+    """score_reads_vs_reference of the compiled reference (src/mm_align.c:144-199): minus the total edit distance of the
+    reads' first regions against `reference` (the alignment score of one --refine candidate, src/placement.cpp:489-514)"""
+    L = rlib()
+    L.score_reads_vs_reference.restype = C.c_int64
+    L.score_reads_vs_reference.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_bool]
+    n = len(reads)
+    arr = (C.c_char_p * n)(*reads)
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    return int(L.score_reads_vs_reference(reference, n, arr, lens, 0, bool(paired)))

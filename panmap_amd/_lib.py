@@ -28,6 +28,23 @@ class PmxError(RuntimeError):
         self.code = code
 
 
+class RefineParams(C.Structure):
+    """pmx_refine_params (defaults: src/main.cpp:186-190)"""
+    _fields_ = [("top_pct", C.c_double), ("max_top_n", C.c_int32), ("neighbor_radius", C.c_int32), ("max_neighbor_n", C.c_int32),
+                ("reserved", C.c_int32)]
+
+    def __init__(self, top_pct=0.01, max_top_n=150, neighbor_radius=2, max_neighbor_n=150):
+        super().__init__(top_pct, max_top_n, neighbor_radius, max_neighbor_n, 0)
+
+
+class RefineResult(C.Structure):
+    """pmx_refine_result"""
+    _fields_ = [("ran", C.c_int32), ("n_candidates", C.c_int32), ("score", C.c_int64 * 5), ("node", C.c_uint32 * 5), ("reserved", C.c_uint32)]
+
+
+REFINE_SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_int64))
+
+
 class IndexInfo(C.Structure):
     _fields_ = [("k", C.c_int32), ("s", C.c_int32), ("t", C.c_int32), ("l", C.c_int32),
                 ("open_syncmer", C.c_int32), ("hpc", C.c_int32), ("flank_mask", C.c_int32),
@@ -144,6 +161,8 @@ SIGNATURES = {
     "pmx_aligner_index_digest": (_i32, [_vp, _vp, _vp]),
     "pmx_aligner_free": (None, [_vp, _vp]),
     "pmx_align_readset": (_i32, [_vp, _vp, _vp, _i32, _i32]),
+    "pmx_align_score_reads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "pmx_refine_top_candidates": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "pmx_align_num_records": (_i64, [_vp]),
     "pmx_align_cigar_words": (_i64, [_vp, _vp]),
     "pmx_align_fetch": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64]),

@@ -565,6 +565,68 @@ def place_lite(ctx: Context, placer: Placer, reads1: str, reads2: str, output_pa
     return res
 
 
+def refine_top_candidates(parent, scores5, best_index, score_node, params=None):
+    """refineTopCandidates (src/placement.cpp:516-698) over plain arrays: parent[n] (DFS indices), scores5[n][5] (metric
+    order of the TSV), best_index[5]; score_node(dfs_index) -> int (minus the reads' total edit distance against that
+    node's genome).  -> dict(ran, score[5], node[5], candidates, candidate_scores)"""
+    parent = np.ascontiguousarray(parent, np.uint32)
+    scores5 = np.ascontiguousarray(scores5, np.float64)
+    n = len(parent)
+    assert scores5.shape == (n, 5)
+    best = (C.c_uint32 * 5)(*[int(b) & 0xFFFFFFFF for b in best_index])
+    rp = params if params is not None else _lib.RefineParams()
+    err = []
+
+    def _cb(_user, node, out):
+        try:
+            out[0] = int(score_node(int(node)))
+            return 0
+        except Exception as e:     # noqa: BLE001  (reported after the C call returns)
+            err.append(e)
+            return -3
+    cb = _lib.REFINE_SCORE_FN(_cb)
+    res = _lib.RefineResult()
+    cand = np.zeros(n, np.uint32)
+    cs = np.zeros(n, np.int64)
+    rc = lib.pmx_refine_top_candidates(parent.ctypes.data, n, scores5.ctypes.data, best, C.byref(rp), cb, None, C.byref(res), cand.ctypes.data,
+                                       cs.ctypes.data, n)
+    if err:
+        raise err[0]
+    check(rc, "pmx_refine_top_candidates")
+    k = res.n_candidates
+    return dict(ran=bool(res.ran), score=list(res.score), node=list(res.node), candidates=cand[:k].copy(), candidate_scores=cs[:k].copy())
+
+
+def refine_placement(ctx: Context, placer: "Placer", pm: Panman, result: "PlacementResult", rs: "ReadSet", paired: bool, mean_read_len: int,
+                     params=None, aligner=None):
+    """--refine on the device: every candidate's genome is indexed (pmx_aligner_set_reference) and the reads are aligned
+    against it (pmx_align_score_reads); reads as extractReadSequences leaves them (mate 2 as sequenced,
+    src/placement.cpp:164-197, 1910-1914)"""
+    parent = placer.index.arrays()["parent"]
+    scores5 = placer.node_outputs()[0]
+    state = {"aligner": aligner}
+
+    def score_node(node):
+        g = pm.genome(node)
+        if state["aligner"] is None:
+            state["aligner"] = Aligner(ctx, g, mean_read_len)
+        else:
+            state["aligner"].set_reference(g, mean_read_len)
+        return state["aligner"].score_reads(rs, paired, False)
+    return refine_top_candidates(parent, scores5, result.best_index, score_node, params)
+
+
+def format_refined_tsv(refined, node_id) -> str:
+    """the refined_<metric> lines of <prefix>.placement.tsv (src/placement.cpp:1987-2000)"""
+    if not refined["ran"]:
+        return ""
+    lines = []
+    for m, name in enumerate(METRICS):
+        if refined["node"][m] != 0xFFFFFFFF:
+            lines.append("refined_%s\t%.0f\t%s" % (name, float(refined["score"][m]), node_id(refined["node"][m])))
+    return "\n".join(lines) + ("\n" if lines else "")
+
+
 # ------------------------------------------------------------------------------------ align
 def last_error() -> bytes:
     """pmx_last_error() of the calling thread (the drop-in boundary has no return code: it reports here)"""
@@ -591,6 +653,13 @@ class Aligner:
     def set_reference(self, reference: bytes, mean_read_len: int):
         self._ref = bytes(reference)
         check(lib.pmx_aligner_set_reference(self.ctx._h, self._h, self._ref, len(self._ref), int(mean_read_len)), "pmx_aligner_set_reference")
+
+    def score_reads(self, rs: ReadSet, paired: bool, revcomp_mate2: bool = False) -> int:
+        """score_reads_vs_reference (src/mm_align.c:144-199): minus the total edit distance of the reads against the
+        aligner's reference"""
+        out = C.c_int64(0)
+        check(lib.pmx_align_score_reads(self.ctx._h, self._h, rs._h, int(paired), int(revcomp_mate2), C.byref(out)), "pmx_align_score_reads")
+        return int(out.value)
 
     def index_digest(self):
         """(occurrences, distinct minimizers, mid_occ, digest, built_on_device) of the current reference index"""

@@ -115,7 +115,7 @@ __device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_d
             if (pp >= 0) mark |= 1ULL << pp;
         }
         const int end_j = j;
-        if (max_ii < 0 || (int64_t)(ai.x - rl64(mine.x, max_ii < 0 ? 0 : max_ii)) > (int64_t)max_dist_x) {
+        if (max_ii < 0 || (ai.x - rl64(mine.x, max_ii < 0 ? 0 : max_ii)) > (uint64_t)(int64_t)max_dist_x) {
             // max f over [st, i-1]; equal values keep the largest j (scan runs downwards with strict <)
             int64_t key = in_rng ? ((int64_t)fj << 32 | (uint32_t)lane) : INT64_MIN;
             for (int ofs = 32; ofs > 0; ofs >>= 1) {
@@ -141,7 +141,7 @@ __device__ void chain_fill_wave(Work& W, const Opt& o, int max_dist_x, int max_d
         else {
             const uint64_t xm = rl64(mine.x, max_ii);
             const int32_t fm = rl32(fj, max_ii);
-            if ((int64_t)(ai.x - xm) <= (int64_t)max_dist_x && fm < max_f) max_ii = i;
+            if ((ai.x - xm) <= (uint64_t)(int64_t)max_dist_x && fm < max_f) max_ii = i;
         }
     }
     {
@@ -308,7 +308,8 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
                     if (cj.p1) packed_cell(pk4, (int64_t)cj.p1 - 1).t = (uint16_t)i;
                 }
             }
-            if (max_ii < 0 || (int64_t)(ai.x - x_mi) > (int64_t)max_dist_x) {
+            // (unsigned, as lchain.c:197 compares: across a strand or target change the difference is huge and max_ii starts over)
+            if (max_ii < 0 || (ai.x - x_mi) > (uint64_t)(int64_t)max_dist_x) {
                 int32_t mx = INT32_MIN;
                 max_ii = -1;
                 for (int64_t j = i - 1; j >= st; --j) {
@@ -334,7 +335,7 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
                 ci.p1 = (uint16_t)(max_j + 1);
                 packed_cell(pk4, i) = ci;
             }
-            if (max_ii < 0 || ((int64_t)(ai.x - x_mi) <= (int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = ai.x; f_mi = max_f; }
+            if (max_ii < 0 || ((ai.x - x_mi) <= (uint64_t)(int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = ai.x; f_mi = max_f; }
         }
     }
     wave_sync();

@@ -218,6 +218,7 @@ struct CMate {
 struct CResult {
     int mapped;
     CMate m[2];
+    int32_t edit[2];      // want_edits: count_read_errors of each mate (valid whenever PMX_C_DONE is returned)
 };
 #define PMX_C_DONE 0
 #define PMX_C_BAIL 1
@@ -665,7 +666,7 @@ PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
 // prof: NULL, or 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
 template <class PT>
 PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
-                             const CPenTab& pen_tab, unsigned long long* prof = nullptr) {
+                             const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false) {
     typedef CMemT<PT> MT;
     out.mapped = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -673,6 +674,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
 #endif
     const int k = o.k, w = o.w;
     const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
+    out.edit[0] = qlen0; out.edit[1] = qlen1;   // a mate without a region counts its whole length
     if (qlen0 > PMX_C_MAXLEN || qlen1 > PMX_C_MAXLEN || qlen0 <= 0 || qlen1 <= 0 || w != PMX_C_W || !(k & 1) || 2 * k + 11 > 64 || k > 255 || !o.is_sr_like)
         return PMX_C_BAIL;
     if (sizeof(PT) == 2 ? ri.len > 32767 : ri.len > 0x3fffffff) return PMX_C_BAIL;   // position << 1 | strand must fit PT
@@ -889,7 +891,8 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             }
             int32_t max_j = mj;
             const int32_t end_j = ej;
-            if (max_ii < 0 || (int64_t)(xi - x_mi) > (int64_t)max_dist_x) {
+            // (unsigned, as lchain.c:197 compares: across a strand change the difference is huge and max_ii starts over)
+            if (max_ii < 0 || (xi - x_mi) > (uint64_t)(int64_t)max_dist_x) {
                 int32_t mx = INT32_MIN;
                 max_ii = -1;
                 for (int32_t j = i - 1; j >= st; --j) {
@@ -908,7 +911,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             }
             if (max_f < 0 || max_f > 1023) return PMX_C_BAIL;
             m.G(i) = (c_u16)((uint32_t)max_f | (uint32_t)(max_j + 1) << 10);
-            if (max_ii < 0 || ((int64_t)(xi - x_mi) <= (int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = xi; f_mi = max_f; }
+            if (max_ii < 0 || ((xi - x_mi) <= (uint64_t)(int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = xi; f_mi = max_f; }
             if (!(extends && max_j == i - 1)) { r0 = i; jv = i; }
             m.B(i) = (c_u8)r0;
 #ifdef PMX_C_DUMP
@@ -974,7 +977,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
     int c00 = 0, c01 = 0, c10 = 0, c11 = 0;   // c<chain><segment>
     for (int j = 0; j < u_cnt0; ++j) { const uint32_t sg = (m.Y((int)m.B(j)) >> 10) & 1u; c00 += sg ? 0 : 1; c01 += sg ? 1 : 0; }
     for (int j = 0; j < u_cnt1; ++j) { const uint32_t sg = (m.Y((int)m.B(u_cnt0 + j)) >> 10) & 1u; c10 += sg ? 0 : 1; c11 += sg ? 1 : 0; }
-    if ((c00 == 0 && c10 == 0) || (c01 == 0 && c11 == 0)) return PMX_C_DONE;   // a mate without a region: unmapped
+    if ((c00 == 0 && c10 == 0) || (c01 == 0 && c11 == 0)) return want_edits ? PMX_C_BAIL : PMX_C_DONE;   // a mate without a region: unmapped (the other mate's edit count: general tier)
     if ((c00 > 0 && c10 > 0) || (c01 > 0 && c11 > 0)) return PMX_C_BAIL;        // a mate with two regions
     // per-mate anchor index lists in G (the chain cells are dead): mate 0 from 0, mate 1 behind it, ascending = the
     // chain walked backwards
@@ -1012,10 +1015,10 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
         bool kept;
         if (c_align1(L0, o, ri, rd[0], qlen0, R0) != PMX_C_DONE) return PMX_C_BAIL;
         if (c_filter_mapq(o, ri, qlen0, R0, &kept) != PMX_C_DONE) return PMX_C_BAIL;
-        if (!kept) return PMX_C_DONE;   // the mate loses its only region: unmapped pair
+        if (!kept) return want_edits ? PMX_C_BAIL : PMX_C_DONE;   // the mate loses its only region: unmapped pair
         if (c_align1(L1, o, ri, rd[1], qlen1, R1) != PMX_C_DONE) return PMX_C_BAIL;
         if (c_filter_mapq(o, ri, qlen1, R1, &kept) != PMX_C_DONE) return PMX_C_BAIL;
-        if (!kept) return PMX_C_DONE;
+        if (!kept) return want_edits ? PMX_C_BAIL : PMX_C_DONE;
     }
 
     PMX_C_STAMP(6);
@@ -1046,6 +1049,8 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
 
     PMX_C_STAMP(7);
     // ---------------------------------------------------------------- the record (src/mm_align.c:271-354)
+    if (R0.has_p && R0.blen > 0) out.edit[0] = R0.blen - R0.mlen;   // (no ambiguous base on either side in this tier)
+    if (R1.has_p && R1.blen > 0) out.edit[1] = R1.blen - R1.mlen;
     if (!(R0.score > 0 && R1.score > 0)) return PMX_C_DONE;
     out.mapped = 1;
 #pragma unroll

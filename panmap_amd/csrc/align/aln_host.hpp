@@ -560,6 +560,16 @@ struct AlnRecord {
 #define PMX_REC_UNSUPPORTED 0x2
 #define PMX_REC_HAS_ALN 0x4
 
+// count_read_errors (src/mm_align.c:122-133): edit distance of the segment's first region (block length - matches +
+// ambiguous bases), or the read length when it has none
+PMX_HD int32_t read_errors(const Work& W, int s) {
+    if (W.n_regs[s] > 0) {
+        const Reg& g = W.regs[s][0];
+        if (g.has_p && g.blen > 0) return g.blen - g.mlen + (int32_t)g.n_ambi;
+    }
+    return W.qlen[s];
+}
+
 // extract_align_result + the mapped test of align_worker_func (src/mm_align.c:271-354)
 PMX_HD bool frag_is_mapped(const Work& W, int paired) {
     if (paired) return W.n_regs[0] > 0 && W.n_regs[1] > 0 && W.regs[0][0].score > 0 && W.regs[1][0].score > 0;

@@ -45,6 +45,7 @@ struct AlignArgs {
 
 
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
+    int32_t* edits;             // NULL, or per read: count_read_errors (src/mm_align.c:122-133) of its first region, the read length without one
     unsigned long long* stats;  // [0] DP calls run, [1] DP cells (q * min(t, 2w+1)), [2] pairs the wave tiers ran a DP for
     int paired;
     int revcomp_mate2;

@@ -116,6 +116,7 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
                 }
             }
             if (lane == 0) A.records[r] = rec;
+            if (A.edits && lane == 0) A.edits[r] = too_long ? W.qlen[s] : read_errors(W, s);
         }
         if (A.stats && lane == 0 && W.dp_run_calls) {
             atomicAdd(&A.stats[0], (unsigned long long)W.dp_run_calls);

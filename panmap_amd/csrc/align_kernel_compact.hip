@@ -55,7 +55,7 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
                 amb[s] = A.amb + A.woff[r];
             }
             unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            rc = compact_map_pair(m, A.opt, A.ri, rd, amb, res, tab, A.prof ? pacc : nullptr);
+            rc = compact_map_pair(m, A.opt, A.ri, rd, amb, res, tab, A.prof ? pacc : nullptr, A.edits != nullptr);
             if (A.prof && lane == 0)   // lane 0's stamps are the wave's phase timeline (diagnostic runs: PMX_ALIGN_PROF)
                 for (int k = 0; k < 8; ++k) atomicAdd(&A.prof[k], pacc[k]);
         }
@@ -101,6 +101,7 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
                     ++coff;
                 }
                 A.records[2 * item + s] = rec;
+                if (A.edits) A.edits[2 * item + s] = res.edit[s];
             }
         }
     }

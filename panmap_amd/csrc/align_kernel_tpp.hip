@@ -215,6 +215,7 @@ k_align_reads_tpp(AlignArgs A) {
                 }
             }
             A.records[r] = rec;
+            if (A.edits) A.edits[r] = read_errors(W, s);
         }
         if (A.prof && emit) {
             PMX_STAMP(W, 11);

@@ -55,6 +55,8 @@ struct pmx_aligner {
     int64_t last_retry = 0, last_tpp_retry = 0;
     DevBuf<unsigned long long> prof;
     DevBuf<unsigned long long> stats;   // AlignArgs::stats
+    DevBuf<int32_t> edits;              // AlignArgs::edits while pmx_align_score_reads runs
+    bool want_edits = false;
     pmx_align_stats last_stats;
     int64_t last_dp_slots = 0, last_compact = 0;
     int64_t n_records = 0;
@@ -62,6 +64,20 @@ struct pmx_aligner {
     unsigned long long last_cigar_used = 0;   // read back at the end of pmx_align_readset
     double last_occupancy = 0;
 };
+
+// [0] += edit counts, [1] += records flagged invalid (pmx_align_score_reads)
+__global__ void k_sum_edits(const AlnRecord* __restrict__ recs, const int32_t* __restrict__ edits, int64_t n, unsigned long long* out) {
+    unsigned long long sum = 0, bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        sum += (unsigned long long)(uint32_t)edits[i];
+        bad += (recs[i].flags & 3u) ? 1ULL : 0ULL;
+    }
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); bad += __shfl_xor(bad, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (sum) atomicAdd(&out[0], sum);
+        if (bad) atomicAdd(&out[1], bad);
+    }
+}
 
 // pair order from the read order: first mates (even read indices) of the read set's locality order -> pair indices
 struct IsEvenRead {
@@ -245,6 +261,8 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     al->stats.ensure(4);
     PMX_HIP(hipMemsetAsync(al->stats.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
     A.stats = al->stats.p;
+    A.edits = nullptr;
+    if (al->want_edits) { al->edits.ensure((size_t)std::max<int64_t>(rs->n, 1)); A.edits = al->edits.p; }
     al->last_dp_slots = 0;
     al->last_compact = 0;
     al->last_tpp_retry = 0; al->last_retry = 0; al->last_dp_rounds = 0; al->last_dp_requests = 0;
@@ -594,6 +612,32 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         if (attempt >= 2) return fail(PMX_ERR_CAPACITY, "CIGAR arena overflow persists after resizing");
         cap = used + 64;
     }
+}
+
+// score_reads_vs_reference (src/mm_align.c:144-199): minus the summed count_read_errors of every read against the
+// aligner's reference -- the alignment-based score of one --refine candidate (src/placement.cpp:489-514)
+int pmx_align_score_reads(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2, int64_t* score) {
+    if (!ctx || !al || !rs || !score) return PMX_ERR_ARG;
+    if (paired && (rs->n & 1)) return fail(PMX_ERR_UNSUPPORTED, "paired scoring of an odd number of reads (the reference maps the last one alone)");
+    al->want_edits = true;
+    const int rc = pmx_align_readset(ctx, al, rs, paired, revcomp_mate2);
+    al->want_edits = false;
+    if (rc != PMX_OK) return rc;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    al->stats.ensure(4);
+    PMX_HIP(hipMemsetAsync(al->stats.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    const int64_t n = al->n_records;
+    if (n > 0)
+        hipLaunchKernelGGL(k_sum_edits, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, al->records.p,
+                           al->edits.p, n, al->stats.p);
+    unsigned long long h[2] = {0, 0};
+    PMX_HIP(hipMemcpyAsync(h, al->stats.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    if (h[1]) return fail(PMX_ERR_UNSUPPORTED, "reads with flagged (overflow / unsupported) records: their edit counts are not the reference's");
+    *score = -(int64_t)h[0];
+    return PMX_OK;
+    PMX_CATCH
 }
 
 int64_t pmx_align_num_records(const pmx_aligner* al) { return al ? al->n_records : 0; }

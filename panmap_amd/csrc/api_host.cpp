@@ -7,6 +7,7 @@
 #include "host/bam_writer.hpp"
 #include "host/fastx_reader.hpp"
 #include "host/idx_file.hpp"
+#include "host/refine.hpp"
 #include "host/index_build.hpp"
 #include "host/panman.hpp"
 
@@ -267,3 +268,31 @@ extern "C" int pmx_fastx_views(const pmx_fastx* fx, const char** seq_concat, con
     return PMX_OK;
 }
 extern "C" void pmx_fastx_free(pmx_fastx* fx) { delete fx; }
+
+extern "C" int pmx_refine_top_candidates(const uint32_t* parent, int64_t n_nodes, const double* scores5, const uint32_t best_index[5],
+                                         const pmx_refine_params* rp, pmx_refine_score_fn fn, void* user, pmx_refine_result* out,
+                                         uint32_t* cand_nodes, int64_t* cand_scores, int64_t cand_cap) {
+    if (!parent || n_nodes <= 0 || !scores5 || !best_index || !rp || !fn || !out) return PMX_ERR_ARG;
+    try {
+        pmx::RefineParams p;
+        p.top_pct = rp->top_pct; p.max_top_n = rp->max_top_n; p.neighbor_radius = rp->neighbor_radius; p.max_neighbor_n = rp->max_neighbor_n;
+        int cb_rc = 0;
+        const pmx::RefineResult r = pmx::refine_top_candidates(parent, n_nodes, scores5, best_index, p, [&](uint32_t node, int64_t* s) {
+            cb_rc = fn(user, node, s);
+            return cb_rc == 0;
+        });
+        if (cb_rc != 0) return cb_rc;
+        memset(out, 0, sizeof(*out));
+        out->ran = r.ran ? 1 : 0;
+        out->n_candidates = (int32_t)r.candidates.size();
+        for (int m = 0; m < 5; ++m) { out->score[m] = r.score[m]; out->node[m] = r.node[m]; }
+        for (size_t i = 0; i < r.candidates.size() && (int64_t)i < cand_cap; ++i) {
+            if (cand_nodes) cand_nodes[i] = r.candidates[i];
+            if (cand_scores) cand_scores[i] = r.candidate_scores[i];
+        }
+        return PMX_OK;
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return PMX_ERR_IO;
+    }
+}

@@ -25,6 +25,7 @@ using namespace pmx::aln;
 
 extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const char** reads, const int* lens, int paired, AlnRecord* recs,
                         uint32_t* cigars, int64_t cig_cap, int64_t* cig_used, int verbose) {
+    const bool edits_in_score = getenv("PMX_HS_EDITS") != nullptr;
     int64_t total = 0;
     int max_len = 0;
     for (int i = 0; i < n_reads; ++i) { total += lens[i]; max_len = std::max(max_len, lens[i]); }
@@ -112,10 +113,31 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
         map_frag(W, o, ri);
 #endif
         const bool mapped = frag_is_mapped(W, paired);
+        if (getenv("PMX_HS_DUMP")) {
+            int off = 0;
+            for (int c = 0; c < W.n_u; ++c) {
+                fprintf(stderr, "chain %d: score=%d cnt=%d:", c, (int)(W.u[c] >> 32), (int)(uint32_t)W.u[c]);
+                for (int j = 0; j < (int)(uint32_t)W.u[c]; ++j)
+                    fprintf(stderr, " [x=%d|%llu y: seg=%d q=%d span=%d]", (int)(W.a[off + j].x >> 63), (unsigned long long)(W.a[off + j].x & 0xffffffffULL),
+                            (int)((W.a[off + j].y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT), (int)(int32_t)W.a[off + j].y, (int)(W.a[off + j].y >> 32 & 0xff));
+                fprintf(stderr, "\n");
+                off += (int)(uint32_t)W.u[c];
+            }
+        }
+        if (getenv("PMX_HS_DUMP"))
+            for (int s = 0; s < n_segs; ++s) {
+                fprintf(stderr, "item %d seg %d: n_regs=%d n_mv=%d status=%u\n", it, s, W.n_regs[s], W.n_mv, (unsigned)W.status);
+                for (int j = 0; j < W.n_regs[s]; ++j) {
+                    const Reg& r = W.regs[s][j];
+                    fprintf(stderr, "   reg %d: cnt=%d score=%d q=[%d,%d) r=[%d,%d) rev=%d mlen=%d blen=%d dp_max=%d has_p=%d parent=%d subsc=%d mapq=%d\n", j, r.cnt, r.score, r.qs,
+                            r.qe, r.rs, r.re, r.rev, r.mlen, r.blen, r.dp_max, (int)r.has_p, r.parent, r.subsc, r.mapq);
+                }
+            }
         for (int s = 0; s < n_segs; ++s) {
             AlnRecord& rec = recs[paired ? 2 * it + s : it];
             memset(&rec, 0, sizeof(rec));
             rec.flags = (uint16_t)(W.status & 3);
+            if (edits_in_score) rec.score = read_errors(W, s);   // (debug aid: the --refine edit count instead of dp_max)
             if (!mapped) continue;
             rec.mapped = 1;
             const Reg& r = W.regs[s][0];
@@ -124,7 +146,7 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
             rec.rs = r.rs; rec.re = r.re; rec.qs = r.qs; rec.qe = r.qe;
             rec.mapq = r.mapq; rec.rev = r.rev; rec.proper_frag = r.proper_frag;
             rec.n_cigar = (uint16_t)r.n_cigar;
-            rec.score = r.dp_max;
+            if (!edits_in_score) rec.score = r.dp_max;
             rec.cigar_off = (uint32_t)used;
             if (used + r.n_cigar > cig_cap) return -2;
             const uint32_t* cg = reg_cigar(W, r);

@@ -36,10 +36,13 @@ def cases(pmx):
         else:
             r[p:p + 3] = b"NNN"
         syn[i] = bytes(r)
-    return g, {"real": real, "synthetic": syn}
+    # mate 2 as sequenced: the orientation --refine feeds (src/placement.cpp:164-197), the mates' anchors on opposite strands
+    # (regression: an adapter-dimer pair got one chain through both strands, lchain.c:197 compares unsigned)
+    real_fastq = [s if i % 2 == 0 else pmx.reverse_complement(s) for i, s in enumerate(seqs[:6000])]
+    return g, {"real": real, "synthetic": syn, "real_as_sequenced": real_fastq}
 
 
-@pytest.mark.parametrize("name", ["real", "synthetic"])
+@pytest.mark.parametrize("name", ["real", "synthetic", "real_as_sequenced"])
 def test_pipeline_sources_equal_reference(pmx, oracle, cases, name):
     g, sets = cases
     reads = sets[name]
@@ -50,7 +53,7 @@ def test_pipeline_sources_equal_reference(pmx, oracle, cases, name):
     assert sum(1 for x in got if x["flags"] & 3) <= 2
 
 
-@pytest.mark.parametrize("name", ["real", "synthetic"])
+@pytest.mark.parametrize("name", ["real", "synthetic", "real_as_sequenced"])
 def test_thread_per_pair_dp_service_replay(pmx, oracle, cases, name):
     """the tier-0 control flow: DP requests served out of line, pair replayed; pairs handed to the wave tiers
     (flag 0x8000) are excluded and must stay a small minority"""
@@ -102,7 +105,8 @@ def test_compact_tier_equals_reference(pmx, oracle, cases):
     noisy = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
     noisy = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(noisy)]
     floors = {"clean": 0.97, "noisy": 0.80, "real": 0.25, "synthetic": 0.0}
-    for name, reads in (("clean", clean), ("noisy", noisy), ("real", sets["real"]), ("synthetic", sets["synthetic"])):
+    floors["real_as_sequenced"] = 0.0
+    for name, reads in (("clean", clean), ("noisy", noisy), ("real", sets["real"]), ("synthetic", sets["synthetic"]), ("real_as_sequenced", sets["real_as_sequenced"])):
         want = oracle.ref_align_reads_direct(g, reads, True, 8)
         got, done = ac.hostsim_align_compact(g, reads)
         idx = [i for i in range(len(want)) if done[i]]
