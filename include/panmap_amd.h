@@ -194,7 +194,7 @@ int pmx_place_node_outputs(pmx_ctx *ctx, pmx_place *pl, double *scores5, double 
  * max_top_n, always with the metric's winner) plus their neighbours within neighbor_radius branches (at most
  * max_neighbor_n each) are candidates; every candidate is scored once through `fn` (minus the total edit distance of the
  * reads against its genome: pmx_align_score_reads on pmx_panman_node_genome) and each metric keeps its best candidate
- * (ties: higher seed score, then lower DFS index).  Host logic; parent / scores5 / best_index as pmx_index_arrays,
+ * (ties: higher seed score, then lower DFS index).  Host logic; parent / scores5 / best_index as pmx_index_parents,
  * pmx_place_node_outputs and pmx_place_result give them.  fn returns 0 on success; anything else aborts with that code. */
 typedef struct {
     double top_pct;          /* 0.01  (src/main.cpp:186-190) */

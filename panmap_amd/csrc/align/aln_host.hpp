@@ -253,7 +253,9 @@ struct Layout {
 // Capacities for a read-length regime; fast = LDS budget (bytes) per wave.
 // tb_limit: cap of the per-wave traceback area (a DP that needs more reports PMX_ST_OVERFLOW and is re-run by a launch
 // with the full capacity: long reads, whose band allows matrices up to max_sw_mat cells, align.c:326-328, 590-592)
-inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fast_budget, size_t tb_limit = 0) {
+// anchor_scale > 1: the last-resort layout for reads whose minimizers hit a repeat of the reference hundreds of times each (a
+// poly-A mate against a genome that ends in a poly-A tail): anchors, chains and regions by that factor
+inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fast_budget, size_t tb_limit = 0, int anchor_scale = 1) {
     Layout L;
     Caps& c = L.caps;
     c.max_qlen = (max_read_len + 15) / 16 * 16 + 16;
@@ -262,8 +264,8 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
     // sketch.c:107-139), and a short tandem repeat re-emits the other copies of the minimum every time it slides out
     // of the window: the general layout takes four per base
     c.max_mini = std::max(64, qsum * 4 + 16);
-    c.max_anchor = std::max(256, c.max_mini * 2);
-    c.max_reg = 32;
+    c.max_anchor = std::max(256, c.max_mini * 2) * anchor_scale;
+    c.max_reg = anchor_scale > 1 ? 256 : 32;
     c.max_cigar = std::max(64, max_read_len / 2 + 16);
     // DP target length: extension <= query part + gap allowance (align.c:652-688)
     c.max_tlen = ((std::min(max_read_len, std::max(o.max_gap, o.min_ksw_len + 2 * o.k) * 4) + 2 * o.max_gap + 64) + 15) / 16 * 16 + 32;

@@ -536,7 +536,17 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             read_counts(n_retry, unused, true);
         }
         al->last_retry = n_retry;
-        if (n_retry > 0) launch(kern, general, n_retry, al->retry_list.p, nullptr, al->slow2);
+        if (n_retry > 0) {
+            // general capacities; what overflows even those (a mate whose every minimizer hits a long repeat: hundreds of
+            // anchors per minimizer) runs once more with 16x the anchors (the chain cells index anchors with 16 bits), a few waves with their arrays in HBM
+            launch(kern, general, n_retry, al->retry_list.p, al->retry_list2.p, al->slow2);
+            int64_t n_huge = 0;
+            read_counts(n_huge, unused, true);
+            if (n_huge > 0) {
+                const Layout huge = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget, 0, 16));
+                launch(kern, huge, n_huge, al->retry_list2.p, nullptr, al->slow2, 64);
+            }
+        }
     } else {
         // Long reads (map-ont / map-hifi branch): wave per read with the general capacities.  The band of those presets
         // allows traceback matrices up to max_sw_mat bytes (100 MB) although nearly every DP between two anchors is a few

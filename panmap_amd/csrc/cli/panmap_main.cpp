@@ -5,7 +5,7 @@
 //   place   reads -> `<prefix>.placement.tsv` (src/placement.cpp:1952-2003)
 //   align   placed genome -> `<prefix>.ref.fa` (+ .fai), reads aligned to it -> `<prefix>.bam` (+ .bai)
 // `--stop index|place|align` ends after that stage.  The later stages of the reference (genotype, consensus), --meta,
-// --batch, --refine, the bwa backend and HPC seeds are outside this library: asking for them is an error, not a silent
+// --batch, the bwa backend and HPC seeds are outside this library: asking for them is an error, not a silent
 // no-op (a `--stop` beyond align stops after align with a note).  Output prefix: -o, else derived from reads1 as the
 // reference derives it.  Exit code 130 on SIGINT.
 #include <signal.h>
@@ -30,6 +30,9 @@ struct Config {
     double seed_mask_fraction = 0.0;
     bool dedup = false, force_leaf = false;
     int trim_start = 0, trim_end = 0, min_seed_quality = 0, min_read_support = -1;
+    bool refine = false;   // src/main.cpp:186-190, 2002-2011
+    double refine_top_pct = 0.01;
+    int refine_max_top_n = 150, refine_neighbor_radius = 2, refine_max_neighbor_n = 150;
 };
 
 void on_sigint(int) { _exit(130); }
@@ -52,6 +55,8 @@ void usage() {
           "  -o, --output PREFIX        output prefix (default: derived from reads1)\n"
           "  -t, --threads N            accepted (the GPU owns the parallelism)\n"
           "      --stop STAGE           index|place|align (later stages are not part of this build)\n"
+          "      --refine               re-rank the top candidates by aligning the reads against them\n"
+          "      --refine-top-pct F / --refine-max-top-n N / --refine-neighbor-radius N / --refine-max-neighbor-n N\n"
           "  -i, --index PATH           load a pre-built index       --index-out PATH   write the built index here\n"
           "  -f, --reindex              force rebuild                --zstd-level N     (default 7)   --index-uncompressed\n"
           "  -k N  -s N  -l N  --offset N  --open-syncmer  --flank-mask N  --seed-mask-fraction F\n"
@@ -97,7 +102,12 @@ Config parse(int argc, char** argv) {
         else if (a == "--force-leaf") c.force_leaf = true;
         else if (a == "-q" || a == "--quiet") c.quiet = true;
         else if (a == "-v" || a == "--verbose" || a == "--no-color" || a == "--no-progress") {}
-        else if (a == "--meta" || a == "--batch" || a == "--refine" || a == "--impute" || a == "--extent-guard" || a == "--reference-node" ||
+        else if (a == "--refine") c.refine = true;
+        else if (a == "--refine-top-pct") c.refine_top_pct = atof(v().c_str());
+        else if (a == "--refine-max-top-n") c.refine_max_top_n = atoi(v().c_str());
+        else if (a == "--refine-neighbor-radius") c.refine_neighbor_radius = atoi(v().c_str());
+        else if (a == "--refine-max-neighbor-n") c.refine_max_neighbor_n = atoi(v().c_str());
+        else if (a == "--meta" || a == "--batch" || a == "--impute" || a == "--extent-guard" || a == "--reference-node" ||
                  a == "--dump-sequence" || a == "--dump-all-scores")
             die("option " + a + " belongs to a part of panmap this build does not implement (index / place / align only)");
         else if (a.size() > 1 && a[0] == '-') die("unknown option " + a + " (see --help)");
@@ -231,6 +241,42 @@ int main(int argc, char** argv) {
     check(pmx_place_add_reads(ctx, pl, rs, &pp), "seeding the reads");
     check(pmx_place_score(ctx, pl, &pp, n_reads, &res), "scoring the tree");
     static const char* metric_names[5] = {"log_raw", "log_cosine", "containment", "weighted_containment", "log_containment"};
+    // --refine (refineTopCandidates, src/placement.cpp:516-698, called at :1910-1914): every candidate's genome is indexed on the
+    // device and the reads -- as extractReadSequences leaves them, mate 2 as sequenced -- are aligned against it
+    pmx_refine_result refined;
+    memset(&refined, 0, sizeof(refined));
+    if (c.refine) {
+        if (!pm && pmx_panman_open(c.panman.c_str(), &pm) != PMX_OK) {
+            fprintf(stderr, "panmap: warning: Failed to load full tree for refinement, disabling refinement\n");
+        } else {
+            pmx_index_info info;
+            check(pmx_index_get_info(idx, &info), "index info");
+            std::vector<double> scores5((size_t)info.n_nodes * 5);
+            check(pmx_place_node_outputs(ctx, pl, scores5.data(), nullptr, nullptr), "node scores");
+            struct RefineCtx { pmx_ctx* ctx; pmx_panman* pm; pmx_readset* rs; pmx_aligner* al; int paired, mean_len; std::string genome; int64_t n_done; } rc{
+                ctx, pm, rs, nullptr, paired ? 1 : 0, (int)(concat.size() / (size_t)std::max<int64_t>(n_reads, 1)), std::string(), 0};
+            auto score_node = [](void* user, uint32_t node, int64_t* score) -> int {
+                RefineCtx& r = *(RefineCtx*)user;
+                const int64_t len = pmx_panman_node_genome(r.pm, (int64_t)node, nullptr, 0);
+                if (len <= 0) { *score = 0; return PMX_OK; }   // (scoreNodeByAlignment returns 0 for an empty genome, src/placement.cpp:496-499)
+                r.genome.resize((size_t)len);
+                pmx_panman_node_genome(r.pm, (int64_t)node, &r.genome[0], len);
+                int rc2 = r.al ? pmx_aligner_set_reference(r.ctx, r.al, r.genome.data(), len, r.mean_len)
+                               : pmx_aligner_create(r.ctx, r.genome.data(), len, r.mean_len, &r.al);
+                if (rc2 != PMX_OK) return rc2;
+                ++r.n_done;
+                return pmx_align_score_reads(r.ctx, r.al, r.rs, r.paired, 0, score);
+            };
+            pmx_refine_params rp;
+            memset(&rp, 0, sizeof(rp));
+            rp.top_pct = c.refine_top_pct; rp.max_top_n = c.refine_max_top_n; rp.neighbor_radius = c.refine_neighbor_radius; rp.max_neighbor_n = c.refine_max_neighbor_n;
+            check(pmx_refine_top_candidates(pmx_index_parents(idx), info.n_nodes, scores5.data(), res.best_index, &rp, score_node, &rc, &refined, nullptr, nullptr, 0),
+                  "refining the placement");
+            if (rc.al) pmx_aligner_free(ctx, rc.al);
+            if (!refined.ran) fprintf(stderr, "panmap: warning: Refinement skipped: no nodes with positive scores\n");
+            else say(c, "place", "refined against " + std::to_string(refined.n_candidates) + " candidates");
+        }
+    }
     {
         const std::string path = c.output + ".placement.tsv";
         FILE* f = fopen(path.c_str(), "w");
@@ -245,6 +291,9 @@ int main(int argc, char** argv) {
             } else if (res.best_index[m] != UINT32_MAX) ids = pmx_index_node_id(idx, res.best_index[m]);
             fprintf(f, "%s\t%.6f\t%s\n", metric_names[m], res.best_score[m], ids.c_str());
         }
+        if (refined.ran)   // src/placement.cpp:1987-2000
+            for (int m = 0; m < 5; ++m)
+                if (refined.node[m] != UINT32_MAX) fprintf(f, "refined_%s\t%.0f\t%s\n", metric_names[m], (double)refined.score[m], pmx_index_node_id(idx, refined.node[m]));
         fclose(f);
         say(c, "place", path);
     }

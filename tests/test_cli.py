@@ -49,7 +49,7 @@ def test_argument_errors(tmp_path):
     assert r.returncode == 1 and "Invalid syncmer offset=12 (must be in 0..k-s = 0..11)" in r.stderr
     r = run(["rsv.panman", "-i", "missing.idx"], tmp_path)
     assert r.returncode == 1 and "index file not found: missing.idx" in r.stderr
-    for opt in (["--meta"], ["--hpc"], ["-a", "bwa"], ["--stop", "nowhere"], ["--no-such-option"]):
+    for opt in (["--meta"], ["--batch"], ["--hpc"], ["-a", "bwa"], ["--stop", "nowhere"], ["--no-such-option"]):
         assert run(["rsv.panman"] + opt, tmp_path).returncode == 1
 
 
@@ -82,3 +82,23 @@ def test_readme_demo_through_the_cli(pmx, oracle, tmp_path):
     r2 = run(["sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz", "--stop", "place", "-o", "again"], tmp_path)
     assert r2.returncode == 0 and "(cached)" in r2.stderr
     assert open(tmp_path / "again.placement.tsv", "rb").read() == open(os.path.join(GOLDEN, "isolate.placement.tsv"), "rb").read()
+    # --refine: the refined_<metric> lines follow the five seed metrics (src/placement.cpp:1987-2000); same numbers as the
+    # library's own refinement of the same placement
+    r3 = run(["sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz", "--stop", "place", "-o", "refined", "--refine",
+              "--refine-max-top-n", "4", "--refine-max-neighbor-n", "3"], tmp_path)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    lines = open(tmp_path / "refined.placement.tsv").read().splitlines()
+    assert "\n".join(lines[:6]) + "\n" == open(os.path.join(GOLDEN, "isolate.placement.tsv")).read()
+    assert [l.split("\t")[0] for l in lines[6:]] == ["refined_" + m for m in pmx.METRICS]
+    ctx = pmx.Context(0)
+    pm = pmx.Panman(str(tmp_path / "sars_20000_twilight_dipper.panman"))
+    index = pmx.Index.load(str(tmp_path / "sars_20000_twilight_dipper.panman.idx"))
+    placer = pmx.Placer(ctx, index)
+    raw = pmx.extract_read_sequences(str(tmp_path / "isolate_R1.fastq.gz"), str(tmp_path / "isolate_R2.fastq.gz"))
+    rs = pmx.ReadSet(ctx, raw)
+    params = pmx.TraversalParams()
+    placer.reset()
+    placer.add_reads(rs, params)
+    res = placer.score(params, len(raw))
+    refined = pmx.refine_placement(ctx, placer, pm, res, rs, True, int(sum(len(x) for x in raw) // len(raw)), pmx.RefineParams(0.01, 4, 2, 3))
+    assert pmx.format_refined_tsv(refined, index.node_id).splitlines() == lines[6:]
