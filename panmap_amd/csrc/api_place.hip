@@ -632,7 +632,12 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
             const int64_t r1 = std::min<int64_t>(g1, r0 + chunk_reads);
             hipStream_t st = j == 0 ? ctx->stream : pl->seed_streams[j - 1];
             if (j > 0) PMX_HIP(hipStreamWaitEvent(st, pl->seed_go, 0));
-            const dim3 grid(grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
+            // batches of PMX_SEED_BLOCK reads per block of the specialised kernel, contiguous in the seeding order.  More than one
+            // saves cache flushes (memory-side atomics) but measured slower: 1.55 ms for the stage with 1, 1.59 / 1.84 / 1.86 / 3.14
+            // with 2 / 4 / 8 / 16 -- fewer, longer blocks fill the chip worse, and the atomics are not what bounds the kernel
+            int seed_batches = 1;
+            if (const char* e = getenv("PMX_SEED_BATCHES")) seed_batches = std::max(1, atoi(e));
+            const dim3 grid(ks_path ? grid_for(r1 - r0, PMX_SEED_BLOCK * seed_batches, ctx->n_cu * 16) : grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
             // the default seeding parameters run the kernel specialised for them (same results, ~3x fewer instructions)
             if (ks_path)
                 hipLaunchKernelGGL((l == 3 ? k_seed_histogram_ks<19, 8, 3> : k_seed_histogram_ks<19, 8, 1>), grid, block, lds_ks, st, rs->words.p, rs->amb.p,

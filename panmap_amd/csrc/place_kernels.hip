@@ -471,13 +471,17 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
     unsigned long long n_seeds = 0;
     constexpr unsigned rot_k = (unsigned)K & 63u, rot_kl = (unsigned)(K * l) & 63u, rot_kl1 = (unsigned)(K * (l - 1)) & 63u;
 
-    const int64_t stride = (int64_t)gridDim.x * PMX_SEED_BLOCK;
-    for (int64_t rb = r_begin + (int64_t)blockIdx.x * PMX_SEED_BLOCK + (tid & ~63); rb < n_reads; rb += stride) {   // wave-uniform
+    // a block takes a CONTIGUOUS range of the (locality-sorted) reads, several batches of PMX_SEED_BLOCK one after the other:
+    // neighbours in that order carry the same seeds, so the longer a block's range, the fewer entries its cache flushes
+    // per read (every flushed entry and every first sighting is one memory-side atomic)
+    const int64_t per_block = (((n_reads - r_begin) + gridDim.x - 1) / gridDim.x + PMX_SEED_BLOCK - 1) / PMX_SEED_BLOCK * PMX_SEED_BLOCK;
+    const int64_t blk_lo = r_begin + (int64_t)blockIdx.x * per_block, blk_hi = blk_lo + per_block < n_reads ? blk_lo + per_block : n_reads;
+    for (int64_t rb = blk_lo + (tid & ~63); rb < blk_hi; rb += PMX_SEED_BLOCK) {   // wave-uniform
         const int64_t rp = rb + lane;
         int ilen = 0;
         const uint64_t* rw = words;
         const uint32_t* ra = amb;
-        if (rp < n_reads) {
+        if (rp < blk_hi) {
             const int64_t r = perm ? (int64_t)perm[rp] : rp;
             const int64_t len = off[r + 1] - off[r];
             if (len >= K && !(keep && !keep[r])) {   // (--dedup: a later copy of an identical read is skipped)

@@ -28,7 +28,8 @@ def per_launch(d, counter, kernel_substr):
 def main():
     fetch_dir, write_dir, reads, read_len, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     res = {"reads_per_gpu": reads, "read_len": read_len, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)"}
-    for name, sub in (("dominant_kernel", "k_align_compact"), ("k_align_reads_tpp_bails", "k_align_reads_tpp"), ("k_seed_histogram", "k_seed_histogram"),
+    for name, sub in (("dominant_kernel", "k_align_compact"), ("k_align_reads_tpp_bails", "k_align_reads_tpp"), ("k_align_reads_t1_bails", "k_align_reads_t1"),
+                      ("k_seed_histogram", "k_seed_histogram"),
                       ("k_score_chains", "k_score_chains")):
         f = per_launch(fetch_dir, "FETCH_SIZE", sub)
         w = per_launch(write_dir, "WRITE_SIZE", sub)
