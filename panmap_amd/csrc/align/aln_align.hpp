@@ -713,8 +713,10 @@ PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int*
             }
         }
         if (i > 0 && regs[i].split_inv) W.status |= PMX_ST_UNSUPPORTED;   // mm_align1_inv (inversion rescue)
-        if (W.status & PMX_ST_ABORT) return;   // thread-per-pair kernel: this pair is re-run by the wave kernel
+        if (W.status & PMX_ST_NEED_WAVE) return;   // thread-per-pair kernel: this pair is re-run by the wave kernel
+        // (after a posted DP request the loop goes on: the other regions post theirs in the same pass, ksw_extd2_auto)
     }
+    if (W.status & PMX_ST_ABORT) return;   // nothing below is meaningful on neutral DP results
     PMX_STAMP(W, 7);
     filter_regs(o, qlen, &n_regs, regs);
     if (qlen >= o.rank_min_len) {

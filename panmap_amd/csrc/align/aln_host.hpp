@@ -543,7 +543,7 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow, ui
     W.status = 0;
     W.cig_next = 0;
     W.dp_req_base = nullptr; W.dp_res = nullptr; W.dp_slot_ctr = nullptr;
-    W.dp_slot = -1; W.dp_slot_cap = 0; W.dp_n_cached = 0; W.dp_calls = 0;
+    W.dp_slot = -1; W.dp_slot_cap = 0; W.dp_n_cached = 0; W.dp_calls = 0; W.dp_post_end = 0; W.status_pre = 0;
     W.last_dp_shortcut = 0; W.skip_shortcut = 0;
     W.dp_run_calls = 0; W.dp_run_cells = 0;
     W.sk_lds_x = nullptr; W.sk_lds_y = nullptr;

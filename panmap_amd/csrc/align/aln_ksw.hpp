@@ -869,22 +869,27 @@ PMX_HD void ksw_extd2_auto(Work& W, int qlen, Ptr<const uint8_t> query, int tlen
         return;
     }
 #if defined(PMX_THREAD_PER_PAIR) && (defined(__HIP_DEVICE_COMPILE__) || defined(PMX_HOSTSIM_TPP))
-    // the thread-per-pair kernel never runs a DP itself: serve it from the pair's result list, or post
-    // it as a request (first unserved call only) and abort this pass
+    // the thread-per-pair kernel never runs a DP itself: it serves the call from the pair's result list, or posts it as a
+    // request.  After the first request of a pass the pair is lost for this pass (PMX_ST_NEED_DP), but the pass goes on with
+    // NEUTRAL results (nothing aligned, no Z-drop) so that the later DP calls of the pair -- the other extension, the other
+    // regions, the other mate: their inputs come from the chains, not from earlier results -- are posted in the same pass and
+    // served together.  Results are kept by call index; the replay is deterministic, so its c-th call is this pass's c-th
+    // call unless an earlier result changes the flow (a Z-drop re-run), which the key check catches (the pair then goes
+    // to the wave tier).
     // ... except a small one whose arrays fit the thread's own slab (the common case: an extension over a
     // mismatch near a read end): a scalar DP in this lane is cheaper than a request + replay round
     {
         int wb = w < 0 ? (tlen > qlen ? tlen : qlen) : w;
         int n_col = qlen < tlen ? qlen : tlen;
         n_col = (((n_col < wb + 1 ? n_col : wb + 1) + 15) / 16 + 1) * 16;
-        if (!(W.status & PMX_ST_ABORT) && qlen > 0 && tlen > 0 && (tlen + 15) / 16 * 16 <= W.caps.max_tlen && qlen <= W.caps.max_tlen &&
+        if (!(W.status & PMX_ST_NEED_WAVE) && qlen > 0 && tlen > 0 && (tlen + 15) / 16 * 16 <= W.caps.max_tlen && qlen <= W.caps.max_tlen &&
             (size_t)(qlen + tlen - 1) * (size_t)n_col <= W.tb_cap) {
             ksw_extd2(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
             return;
         }
     }
     const uint32_t key = (uint32_t)qlen | (uint32_t)tlen << 10 | (uint32_t)(flag & 0xff) << 20;
-    if (!(W.status & PMX_ST_ABORT)) {
+    if (!(W.status & PMX_ST_NEED_WAVE)) {
         const int c = W.dp_calls++;
         if (c < W.dp_n_cached) {
             const DpRes& R = W.dp_res[c];
@@ -894,25 +899,38 @@ PMX_HD void ksw_extd2_auto(Work& W, int qlen, Ptr<const uint8_t> query, int tlen
                 return;
             }
             W.status |= PMX_ST_NEED_WAVE;
-        } else if (W.dp_req_base && c < PMX_DP_MAX_CALLS && ((qlen + 15) & ~15) + tlen <= PMX_DP_SEQ_BYTES) {
-            if (W.dp_slot < 0 && W.dp_slot_ctr) {
-                const unsigned long long sl = atomicAdd(W.dp_slot_ctr, 1ULL);
-                if (sl < W.dp_slot_cap) W.dp_slot = (int64_t)sl;
+        } else {
+            bool posted = false;
+            const int e_ = c - W.dp_n_cached;   // request entry of this pass
+            if (W.dp_req_base && c < PMX_DP_MAX_CALLS && e_ < PMX_DP_REQ_PER_PASS && ((qlen + 15) & ~15) + tlen <= PMX_DP_SEQ_BYTES) {
+                if (W.dp_slot < 0 && W.dp_slot_ctr) {
+                    const unsigned long long sl = atomicAdd(W.dp_slot_ctr, 1ULL);
+                    if (sl < W.dp_slot_cap) {
+                        W.dp_slot = (int64_t)sl;
+                        for (int j = 0; j < PMX_DP_REQ_PER_PASS; ++j)
+                            reinterpret_cast<DpReq*>(W.dp_req_base + ((size_t)sl * PMX_DP_REQ_PER_PASS + (size_t)j) * sizeof(DpReq))->call = 0xffffffffu;
+                    }
+                }
+                if (W.dp_slot >= 0) {
+                    DpReq* rq = reinterpret_cast<DpReq*>(W.dp_req_base + ((size_t)W.dp_slot * PMX_DP_REQ_PER_PASS + (size_t)e_) * sizeof(DpReq));
+                    rq->qlen = qlen; rq->tlen = tlen; rq->w = w; rq->zdrop = zdrop; rq->end_bonus = end_bonus; rq->flag = flag;
+                    rq->call = (uint32_t)c; rq->key = key;
+                    uint8_t* sq = rq->seq;
+                    for (int i = 0; i < qlen; ++i) sq[i] = query[i];
+                    sq += (qlen + 15) & ~15;
+                    for (int i = 0; i < tlen; ++i) sq[i] = target[i];
+                    posted = true;
+                    if (c == W.dp_post_end) W.dp_post_end = c + 1;
+                }
             }
-            if (W.dp_slot >= 0) {
-                DpReq* rq = reinterpret_cast<DpReq*>(W.dp_req_base + (size_t)W.dp_slot * sizeof(DpReq));
-                rq->qlen = qlen; rq->tlen = tlen; rq->w = w; rq->zdrop = zdrop; rq->end_bonus = end_bonus; rq->flag = flag;
-                rq->call = (uint32_t)c; rq->key = key;
-                uint8_t* sq = rq->seq;
-                for (int i = 0; i < qlen; ++i) sq[i] = query[i];
-                sq += (qlen + 15) & ~15;
-                for (int i = 0; i < tlen; ++i) sq[i] = target[i];
-                W.status |= PMX_ST_NEED_DP;
-            } else W.status |= PMX_ST_NEED_WAVE;
-        } else W.status |= PMX_ST_NEED_WAVE;
+            if (!(W.status & PMX_ST_NEED_DP)) {   // the first miss of the pass
+                if (posted) { W.status_pre = W.status; W.status |= PMX_ST_NEED_DP; }
+                else W.status |= PMX_ST_NEED_WAVE;
+            }   // (a later call that cannot be posted is met again, as a first miss, by the replay)
+        }
     }
     ez_reset(ez);
-    ez.zdropped = 1;
+    if (W.status & PMX_ST_NEED_WAVE) ez.zdropped = 1;   // this pass is over; after a posted request: neutral result, the pass goes on
 #else
     ++W.dp_run_calls;
     W.dp_run_cells += dp_cells(qlen, tlen, w);

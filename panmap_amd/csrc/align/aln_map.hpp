@@ -226,10 +226,12 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
         for (int s = 0; s < n_segs; ++s) {
             set_parent(W, o.mask_level, o.mask_len, W.n_regs[s], W.regs[s], o.a * 2 + o.b);
             align_regs(W, o, ri, s, &W.n_regs[s], W.regs[s], W.seg_a[s]);
-            if (W.status & PMX_ST_ABORT) return;
+            if (W.status & PMX_ST_NEED_WAVE) return;
+            if (W.status & PMX_ST_NEED_DP) continue;   // thread-per-pair kernel: the other mate posts its DP requests in the same pass
             set_mapq(ri, W.n_regs[s], W.regs[s], o.min_chain_score, o.a, W.rep_len, 0, &W.status);
             PMX_STAMP(W, 9);
         }
+        if (W.status & PMX_ST_ABORT) return;
         if (n_segs == 2 && o.pe_ori >= 0) {
             Reg* rr[2] = {W.regs[0], W.regs[1]};
             pair_hits(W, ri, max_chain_gap_ref, o.pe_bonus, o.a * 2 + o.b, o.a, W.qlen, W.n_regs, rr);

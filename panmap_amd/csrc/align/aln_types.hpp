@@ -350,6 +350,7 @@ struct Ez {             // ksw_extz_t (ksw2.h:27-36)
 #define PMX_DP_SEQ_BYTES 480
 #define PMX_DP_MAX_CIGAR 20
 #define PMX_DP_MAX_CALLS 8
+#define PMX_DP_REQ_PER_PASS 4   // DP requests a pair may post in one thread-per-pair pass (its request slots)
 struct DpRes {   // 128 bytes
     Ez ez;
     uint32_t key;                    // must equal the request's key; 0xffffffff = the DP overflowed
@@ -358,7 +359,7 @@ struct DpRes {   // 128 bytes
 
 struct DpReq {   // 512 bytes
     int32_t qlen, tlen, w, zdrop, end_bonus, flag;
-    uint32_t call, key;
+    uint32_t call, key;   // call: index of the DP call within the pair (its place in the result list); 0xffffffff = no request in this entry
     uint8_t seq[PMX_DP_SEQ_BYTES];   // query, then target at ((qlen + 15) & ~15)
 };
 
@@ -438,6 +439,8 @@ struct Work {
     int64_t dp_slot;                  // this pair's slot, -1 = none yet
     uint32_t dp_slot_cap;
     int dp_n_cached, dp_calls;
+    int dp_post_end;        // calls [dp_n_cached, dp_post_end) were posted in this pass (contiguous: the next pass may rely on them)
+    uint32_t status_pre;    // status when the first request of this pass was posted (what follows runs on neutral dummy results)
     int last_dp_shortcut;   // the last align_pair call was answered by ksw_shortcut
     int skip_shortcut;      // align1 already tried the shortcut on the reference bases directly
     // optional phase profile (diagnostic runs only: AlignArgs::prof != NULL)

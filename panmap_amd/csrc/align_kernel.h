@@ -80,16 +80,15 @@ PMX_HD size_t dp_request_tb_bytes(int qlen, int tlen, int w) {
     return (size_t)(qlen + tlen - 1) * (size_t)n_col;
 }
 
-// append a served DP to its slot's result list
+// a served DP goes to its place (the call index) in the slot's result list
 PMX_HD void dp_store_result(const AlignArgs& A, int64_t slot, const DpReq* rq, const Ez& ez, const uint32_t* cigar, uint32_t status) {
-    const uint32_t n = A.dp_ncached[slot];
+    const uint32_t n = rq->call;
     if (n >= PMX_DP_MAX_CALLS) return;
     DpRes& R = A.dp_res_base[(size_t)slot * PMX_DP_MAX_CALLS + n];
-    const bool bad = (status & PMX_ST_OVERFLOW) || ez.n_cigar > PMX_DP_MAX_CIGAR || n != rq->call;
+    const bool bad = (status & PMX_ST_OVERFLOW) || ez.n_cigar > PMX_DP_MAX_CIGAR;
     R.ez = ez;
     R.key = bad ? 0xffffffffu : rq->key;
     if (!bad) for (int i = 0; i < ez.n_cigar; ++i) R.cigar[i] = cigar[i];
-    A.dp_ncached[slot] = n + 1;
 }
 
 }  // namespace aln

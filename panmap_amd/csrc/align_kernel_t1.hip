@@ -22,9 +22,14 @@ __global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
     uint8_t* fast = lds + PMX_ALIGN_WORK_BYTES;
     uint8_t* slow = A.slow_base + (size_t)blockIdx.x * A.slow_stride;
     const int lane = (int)(threadIdx.x & 63u);
-    for (int64_t it = blockIdx.x; it < A.n_items; it += gridDim.x) {
-        const int64_t slot = A.worklist ? (int64_t)A.worklist[it] : it;
-        const DpReq* rq = reinterpret_cast<const DpReq*>(A.dp_req_base + (size_t)slot * sizeof(DpReq));
+    // work items = request entries: PMX_DP_REQ_PER_PASS per pair slot, most of them empty (call != its place means: nothing
+    // posted there in this pass, or already served)
+    for (int64_t it = blockIdx.x; it < A.n_items * PMX_DP_REQ_PER_PASS; it += gridDim.x) {
+        // (entry-major: with the slot-major order and a grid that is a multiple of the entries per slot, every wave would
+        //  see one entry number only -- and nearly all requests sit in entry 0)
+        const int64_t slot = A.worklist ? (int64_t)A.worklist[it % A.n_items] : it % A.n_items;
+        DpReq* rq = reinterpret_cast<DpReq*>(A.dp_req_base + ((size_t)slot * PMX_DP_REQ_PER_PASS + (size_t)(it / A.n_items)) * sizeof(DpReq));
+        if (rq->call == 0xffffffffu) continue;   // (wave-uniform)
         __syncthreads();
         bind_work(W, A.layout, fast, slow);
         W.prof = A.prof;
@@ -64,6 +69,7 @@ __global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
         if (lane == 0) {
             const uint32_t* cg = W.cig_tmp; PMX_LDS(cg);
             dp_store_result(A, slot, rq, ez, cg, W.status);
+            rq->call = 0xffffffffu;   // served
             if (A.stats) {
                 atomicAdd(&A.stats[0], 1ULL);
                 atomicAdd(&A.stats[1], (unsigned long long)dp_cells(qlen, tlen, rq->w));

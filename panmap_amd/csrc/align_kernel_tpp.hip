@@ -66,6 +66,8 @@ k_align_reads_tpp(AlignArgs A) {
             W.dp_res = A.dp_res_base + (size_t)slot * PMX_DP_MAX_CALLS;
             W.dp_n_cached = (int)A.dp_ncached[slot];
         } else W.dp_slot_ctr = A.dp_count;
+        W.dp_post_end = W.dp_n_cached;
+        W.status_pre = 0;
         bool too_long = false;
         for (int s = 0; s < n_segs; ++s) {
             const int64_t r = A.paired ? 2 * item + s : item;
@@ -146,12 +148,15 @@ k_align_reads_tpp(AlignArgs A) {
         } else {
             W.status |= PMX_ST_OVERFLOW;
         }
+        // after a posted DP request the pass ran on neutral results: only what was known before it counts
+        if (W.status & PMX_ST_NEED_DP) W.status = W.status_pre | PMX_ST_NEED_DP;
         if (W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) {
             A.retry_list[atomicAdd(A.retry_count, 1ULL)] = (uint32_t)item;
             if (A.dp_round == 0 && W.dp_slot >= 0) A.dp_slot_pairs[W.dp_slot] = 0xffffffffu;   // slot taken, pair gone
             break;
         }
         if (W.status & PMX_ST_NEED_DP) {
+            A.dp_ncached[W.dp_slot] = (uint32_t)W.dp_post_end;   // what the next pass finds served
             if (A.dp_round == 0) {
                 A.dp_slot_pairs[W.dp_slot] = (uint32_t)item;
                 if (A.mv_handover && (uint64_t)W.dp_slot < (uint64_t)A.mv_slots && W.n_mv < (int)A.mv_stride) {   // see AlignArgs

@@ -366,7 +366,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             const size_t dps_stride = (dps_layout.slow_bytes + 255) & ~(size_t)255;
             const bool dp_two_class = !getenv("PMX_ALIGN_DP_ONE_CLASS");
             if (use_dp_service) {
-                al->dp_req.ensure((size_t)n_items * sizeof(DpReq));
+                al->dp_req.ensure((size_t)n_items * PMX_DP_REQ_PER_PASS * sizeof(DpReq));
                 al->dp_res.ensure((size_t)n_items * PMX_DP_MAX_CALLS);
                 al->dp_ncached.ensure((size_t)n_items);
                 al->dp_slot_pairs.ensure((size_t)n_items);
@@ -493,13 +493,13 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 A.dp_small_tlen = small_tlen;
                 A.dp_small_tb = (uint32_t)dps_layout.tb_cap;
                 A.dp_class = dp_two_class ? 2 : 0;
-                hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dp_max_grid, n_dp)), dim3(64), dp_lds, ctx->stream, A);
+                hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dp_max_grid, n_dp * PMX_DP_REQ_PER_PASS)), dim3(64), dp_lds, ctx->stream, A);
                 if (dp_two_class) {
                     A.layout = dps_layout;
                     A.slow_stride = dps_stride;
                     A.slow_base = al->slow2.p;
                     A.dp_class = 1;
-                    hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dps_max_grid, n_dp)), dim3(64), dps_lds, ctx->stream, A);
+                    hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dps_max_grid, n_dp * PMX_DP_REQ_PER_PASS)), dim3(64), dps_lds, ctx->stream, A);
                 }
                 PMX_HIP(hipGetLastError());
                 uint32_t* next = lists[round & 1];

@@ -40,7 +40,7 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
     L.slow_bytes += 64;
     const Layout Lserve = L;
     L.tb_cap = 0;   // like api_align.hip: no in-lane DPs, every DP is a request
-    std::vector<uint8_t> dp_req(sizeof(DpReq));
+    std::vector<uint8_t> dp_req(sizeof(DpReq) * PMX_DP_REQ_PER_PASS);
     std::vector<DpRes> dp_res(PMX_DP_MAX_CALLS);
     int64_t n_requests = 0, n_wave = 0;
 #else
@@ -71,7 +71,7 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
         if (too_long) return -1;
 #ifdef PMX_HOSTSIM_TPP
         int n_cached = 0;
-        for (;;) {
+        for (;;) {   // one thread-per-pair pass, then the DP service for every request it posted, then the replay
             const int ql[2] = {W.qlen[0], W.qlen[1]};
             bind_work(W, L, fast.data(), slow.data());
             W.qlen[0] = ql[0]; W.qlen[1] = ql[1];
@@ -80,25 +80,32 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
             W.dp_slot = 0;
             W.dp_slot_cap = 1;
             W.dp_n_cached = n_cached;
+            W.dp_post_end = n_cached;
+            for (int j = 0; j < PMX_DP_REQ_PER_PASS; ++j) reinterpret_cast<DpReq*>(dp_req.data() + (size_t)j * sizeof(DpReq))->call = 0xffffffffu;
             map_frag(W, o, ri);
+            if (W.status & PMX_ST_NEED_DP) W.status = W.status_pre | PMX_ST_NEED_DP;   // (align_kernel_tpp.hip)
             if ((W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) || !(W.status & PMX_ST_NEED_DP)) break;
-            const DpReq* rq = reinterpret_cast<const DpReq*>(dp_req.data());
-            if ((int)rq->call != n_cached) return -4;
-            if (getenv("PMX_HS_DUMP")) fprintf(stderr, "REQ %d %d %d %d\n", rq->qlen, rq->tlen, rq->w, rq->flag);
-            Work W2;
-            memset(&W2, 0, sizeof(W2));
-            bind_work(W2, Lserve, fast.data(), slow.data());
-            std::vector<uint8_t> seq(rq->seq, rq->seq + PMX_DP_SEQ_BYTES);
-            Ez ez;
-            ksw_extd2(W2, rq->qlen, seq.data(), rq->tlen, seq.data() + ((rq->qlen + 15) & ~15), o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2,
-                      (int8_t)o.e2, rq->w, rq->zdrop, rq->end_bonus, rq->flag, ez);
-            DpRes& R = dp_res[n_cached];
-            const bool bad = (W2.status & PMX_ST_OVERFLOW) || ez.n_cigar > PMX_DP_MAX_CIGAR;
-            R.ez = ez;
-            R.key = bad ? 0xffffffffu : rq->key;
-            if (!bad) for (int i = 0; i < ez.n_cigar; ++i) R.cigar[i] = W2.cig_tmp[i];
-            ++n_cached;
-            ++n_requests;
+            if (W.dp_post_end <= n_cached) return -4;
+            for (int j = 0; j < PMX_DP_REQ_PER_PASS; ++j) {
+                const DpReq* rq = reinterpret_cast<const DpReq*>(dp_req.data() + (size_t)j * sizeof(DpReq));
+                if (rq->call == 0xffffffffu) continue;
+                if ((int)rq->call != n_cached + j) return -4;
+                if (getenv("PMX_HS_DUMP")) fprintf(stderr, "REQ %d %d %d %d\n", rq->qlen, rq->tlen, rq->w, rq->flag);
+                Work W2;
+                memset(&W2, 0, sizeof(W2));
+                bind_work(W2, Lserve, fast.data(), slow.data());
+                std::vector<uint8_t> seq(rq->seq, rq->seq + PMX_DP_SEQ_BYTES);
+                Ez ez;
+                ksw_extd2(W2, rq->qlen, seq.data(), rq->tlen, seq.data() + ((rq->qlen + 15) & ~15), o.mat, (int8_t)o.q, (int8_t)o.e, (int8_t)o.q2,
+                          (int8_t)o.e2, rq->w, rq->zdrop, rq->end_bonus, rq->flag, ez);
+                DpRes& R = dp_res[rq->call];
+                const bool bad = (W2.status & PMX_ST_OVERFLOW) || ez.n_cigar > PMX_DP_MAX_CIGAR;
+                R.ez = ez;
+                R.key = bad ? 0xffffffffu : rq->key;
+                if (!bad) for (int i = 0; i < ez.n_cigar; ++i) R.cigar[i] = W2.cig_tmp[i];
+                ++n_requests;
+            }
+            n_cached = W.dp_post_end;
         }
         if (W.status & (PMX_ST_OVERFLOW | PMX_ST_NEED_WAVE)) {   // this pair goes to the wave-per-pair tiers
             ++n_wave;
