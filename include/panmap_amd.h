@@ -211,6 +211,10 @@ typedef struct {
     uint32_t reserved;
 } pmx_refine_result;
 typedef int (*pmx_refine_score_fn)(void *user, uint32_t dfs_index, int64_t *score);
+/* the candidate set alone (ascending DFS indices; returns its size): a caller may score the candidates concurrently and
+ * hand pmx_refine_top_candidates a lookup */
+int64_t pmx_refine_candidates(const uint32_t *parent, int64_t n_nodes, const double *scores5, const uint32_t best_index[5],
+                              const pmx_refine_params *rp, uint32_t *cand_nodes, int64_t cand_cap);
 int pmx_refine_top_candidates(const uint32_t *parent, int64_t n_nodes, const double *scores5, const uint32_t best_index[5],
                               const pmx_refine_params *rp, pmx_refine_score_fn fn, void *user, pmx_refine_result *out,
                               uint32_t *cand_nodes, int64_t *cand_scores, int64_t cand_cap);

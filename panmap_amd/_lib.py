@@ -162,6 +162,7 @@ SIGNATURES = {
     "pmx_aligner_free": (None, [_vp, _vp]),
     "pmx_align_readset": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "pmx_align_score_reads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "pmx_refine_candidates": (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _i64]),
     "pmx_refine_top_candidates": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "pmx_align_num_records": (_i64, [_vp]),
     "pmx_align_cigar_words": (_i64, [_vp, _vp]),

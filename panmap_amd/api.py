@@ -5,6 +5,7 @@ Names follow the reference: ``TraversalParams`` (src/placement.hpp:28-54), ``Pla
 (src/mm_align.h:44-53).  All compute goes through the C ABI of libpanmap_amd.so.
 """
 import ctypes as C
+import threading
 import os
 import dataclasses
 import gzip
@@ -63,14 +64,15 @@ class Panman:
         i = node if isinstance(node, int) else self.find_node(node)
         if i < 0:
             raise KeyError(node)
-        # one reconstruction per call: the buffer of the previous call is tried first (genomes of one tree are
+        # one reconstruction per call: the (per-thread) buffer of the previous call is tried first (genomes of one tree are
         # about the same length) and grown when the answer does not fit
-        buf = getattr(self, "_gbuf", None)
+        tl = self.__dict__.setdefault("_tl", threading.local())
+        buf = getattr(tl, "gbuf", None)
         n = lib.pmx_panman_node_genome(self._h, i, buf, len(buf) if buf is not None else 0)
         if n < 0:
             raise _lib.PmxError(-3, "pmx_panman_node_genome")
         if buf is None or n > len(buf):
-            buf = self._gbuf = C.create_string_buffer(max(n + n // 8, 1))
+            buf = tl.gbuf = C.create_string_buffer(max(n + n // 8, 1))
             lib.pmx_panman_node_genome(self._h, i, buf, len(buf))
         return buf.raw[:n]
 
@@ -597,23 +599,61 @@ def refine_top_candidates(parent, scores5, best_index, score_node, params=None):
     return dict(ran=bool(res.ran), score=list(res.score), node=list(res.node), candidates=cand[:k].copy(), candidate_scores=cs[:k].copy())
 
 
+def refine_candidates(parent, scores5, best_index, params=None) -> np.ndarray:
+    """the nodes --refine aligns against (steps 1-2 of refineTopCandidates), ascending"""
+    parent = np.ascontiguousarray(parent, np.uint32)
+    scores5 = np.ascontiguousarray(scores5, np.float64)
+    n = len(parent)
+    best = (C.c_uint32 * 5)(*[int(b) & 0xFFFFFFFF for b in best_index])
+    rp = params if params is not None else _lib.RefineParams()
+    cand = np.zeros(n, np.uint32)
+    k = lib.pmx_refine_candidates(parent.ctypes.data, n, scores5.ctypes.data, best, C.byref(rp), cand.ctypes.data, n)
+    if k < 0:
+        check(int(k), "pmx_refine_candidates")
+    return cand[:k].copy()
+
+
 def refine_placement(ctx: Context, placer: "Placer", pm: Panman, result: "PlacementResult", rs: "ReadSet", paired: bool, mean_read_len: int,
-                     params=None, aligner=None):
+                     params=None, aligner=None, streams: int = 4):
     """--refine on the device: every candidate's genome is indexed (pmx_aligner_set_reference) and the reads are aligned
     against it (pmx_align_score_reads); reads as extractReadSequences leaves them (mate 2 as sequenced,
-    src/placement.cpp:164-197, 1910-1914)"""
+    src/placement.cpp:164-197, 1910-1914).  The candidates are independent: `streams` aligners, each with its own context
+    (stream) and host thread, score them concurrently -- one sample's reads do not fill the GPU, and most of a small
+    batch's time is the latency of its few hard pairs."""
+    import concurrent.futures
+    import threading
     parent = placer.index.arrays()["parent"]
     scores5 = placer.node_outputs()[0]
-    state = {"aligner": aligner}
+    cands = refine_candidates(parent, scores5, result.best_index, params)
+    scores = {}
+    if len(cands):
+        first = int(cands[0])      # serially: also computes the read set's locality order once
+        al0 = aligner if aligner is not None else Aligner(ctx, pm.genome(first), mean_read_len)
+        if aligner is not None:
+            al0.set_reference(pm.genome(first), mean_read_len)
+        scores[first] = al0.score_reads(rs, paired, False)
+        ctx.synchronize()
+        n_workers = max(1, min(int(streams), len(cands) - 1))
+        local = threading.local()
+        pool0 = {"taken": False}
+        lock = threading.Lock()
 
-    def score_node(node):
-        g = pm.genome(node)
-        if state["aligner"] is None:
-            state["aligner"] = Aligner(ctx, g, mean_read_len)
-        else:
-            state["aligner"].set_reference(g, mean_read_len)
-        return state["aligner"].score_reads(rs, paired, False)
-    return refine_top_candidates(parent, scores5, result.best_index, score_node, params)
+        def work(node):
+            if not hasattr(local, "al"):
+                with lock:
+                    mine = not pool0["taken"]
+                    pool0["taken"] = True
+                if mine:
+                    local.ctx, local.al = ctx, al0
+                else:
+                    local.ctx = Context(ctx.device)
+                    local.al = Aligner(local.ctx, pm.genome(node), mean_read_len)
+            local.al.set_reference(pm.genome(node), mean_read_len)
+            return node, local.al.score_reads(rs, paired, False)
+        with concurrent.futures.ThreadPoolExecutor(n_workers) as ex:
+            for node, sc in ex.map(work, [int(c) for c in cands[1:]]):
+                scores[node] = sc
+    return refine_top_candidates(parent, scores5, result.best_index, lambda node: scores[node], params)
 
 
 def format_refined_tsv(refined, node_id) -> str:

@@ -296,3 +296,21 @@ extern "C" int pmx_refine_top_candidates(const uint32_t* parent, int64_t n_nodes
         return PMX_ERR_IO;
     }
 }
+
+// the candidate set alone (steps 1-2 of refineTopCandidates), ascending: lets a caller score the candidates in any order /
+// concurrently before pmx_refine_top_candidates picks the winners from a lookup
+extern "C" int64_t pmx_refine_candidates(const uint32_t* parent, int64_t n_nodes, const double* scores5, const uint32_t best_index[5],
+                                         const pmx_refine_params* rp, uint32_t* cand_nodes, int64_t cand_cap) {
+    if (!parent || n_nodes <= 0 || !scores5 || !best_index || !rp) return PMX_ERR_ARG;
+    try {
+        pmx::RefineParams p;
+        p.top_pct = rp->top_pct; p.max_top_n = rp->max_top_n; p.neighbor_radius = rp->neighbor_radius; p.max_neighbor_n = rp->max_neighbor_n;
+        const pmx::RefineResult r = pmx::refine_top_candidates(parent, n_nodes, scores5, best_index, p, [](uint32_t, int64_t* s) { *s = 0; return true; });
+        for (size_t i = 0; i < r.candidates.size() && (int64_t)i < cand_cap; ++i)
+            if (cand_nodes) cand_nodes[i] = r.candidates[i];
+        return (int64_t)r.candidates.size();
+    } catch (const std::exception& e) {
+        pmx::set_error(e.what());
+        return PMX_ERR_IO;
+    }
+}

@@ -16,6 +16,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -253,26 +257,71 @@ int main(int argc, char** argv) {
             check(pmx_index_get_info(idx, &info), "index info");
             std::vector<double> scores5((size_t)info.n_nodes * 5);
             check(pmx_place_node_outputs(ctx, pl, scores5.data(), nullptr, nullptr), "node scores");
-            struct RefineCtx { pmx_ctx* ctx; pmx_panman* pm; pmx_readset* rs; pmx_aligner* al; int paired, mean_len; std::string genome; int64_t n_done; } rc{
-                ctx, pm, rs, nullptr, paired ? 1 : 0, (int)(concat.size() / (size_t)std::max<int64_t>(n_reads, 1)), std::string(), 0};
-            auto score_node = [](void* user, uint32_t node, int64_t* score) -> int {
-                RefineCtx& r = *(RefineCtx*)user;
-                const int64_t len = pmx_panman_node_genome(r.pm, (int64_t)node, nullptr, 0);
-                if (len <= 0) { *score = 0; return PMX_OK; }   // (scoreNodeByAlignment returns 0 for an empty genome, src/placement.cpp:496-499)
-                r.genome.resize((size_t)len);
-                pmx_panman_node_genome(r.pm, (int64_t)node, &r.genome[0], len);
-                int rc2 = r.al ? pmx_aligner_set_reference(r.ctx, r.al, r.genome.data(), len, r.mean_len)
-                               : pmx_aligner_create(r.ctx, r.genome.data(), len, r.mean_len, &r.al);
-                if (rc2 != PMX_OK) return rc2;
-                ++r.n_done;
-                return pmx_align_score_reads(r.ctx, r.al, r.rs, r.paired, 0, score);
-            };
             pmx_refine_params rp;
             memset(&rp, 0, sizeof(rp));
             rp.top_pct = c.refine_top_pct; rp.max_top_n = c.refine_max_top_n; rp.neighbor_radius = c.refine_neighbor_radius; rp.max_neighbor_n = c.refine_max_neighbor_n;
-            check(pmx_refine_top_candidates(pmx_index_parents(idx), info.n_nodes, scores5.data(), res.best_index, &rp, score_node, &rc, &refined, nullptr, nullptr, 0),
+            std::vector<uint32_t> cands((size_t)info.n_nodes);
+            const int64_t n_cand = pmx_refine_candidates(pmx_index_parents(idx), info.n_nodes, scores5.data(), res.best_index, &rp, cands.data(), (int64_t)cands.size());
+            if (n_cand < 0) die(std::string("refining the placement: ") + pmx_last_error());
+            cands.resize((size_t)n_cand);
+            // The candidates are independent: a few aligners, each with its own context (stream) and host thread, score them
+            // concurrently -- one sample's reads do not fill the GPU.  The first one runs alone (it also computes the read set's
+            // locality order, which the others then share read-only).
+            std::vector<int64_t> cand_score((size_t)n_cand, 0);
+            const int mean_len = (int)(concat.size() / (size_t)std::max<int64_t>(n_reads, 1));
+            std::atomic<int64_t> next{1};
+            std::atomic<int> failed{0};
+            std::string fail_msg;
+            std::mutex fail_mu;
+            auto score_range = [&](pmx_ctx* wctx, pmx_aligner*& al, int64_t i) {
+                std::string genome;
+                const int64_t len = pmx_panman_node_genome(pm, (int64_t)cands[(size_t)i], nullptr, 0);
+                if (len <= 0) { cand_score[(size_t)i] = 0; return PMX_OK; }   // (scoreNodeByAlignment returns 0 for an empty genome, src/placement.cpp:496-499)
+                genome.resize((size_t)len);
+                pmx_panman_node_genome(pm, (int64_t)cands[(size_t)i], &genome[0], len);
+                int rc2 = al ? pmx_aligner_set_reference(wctx, al, genome.data(), len, mean_len) : pmx_aligner_create(wctx, genome.data(), len, mean_len, &al);
+                if (rc2 != PMX_OK) return rc2;
+                return pmx_align_score_reads(wctx, al, rs, paired ? 1 : 0, 0, &cand_score[(size_t)i]);
+            };
+            pmx_aligner* al0 = nullptr;
+            if (n_cand > 0) {
+                check(score_range(ctx, al0, 0), "refining the placement");
+                check(pmx_ctx_synchronize(ctx), "refining the placement");
+                int n_workers = 4;
+                if (const char* e = getenv("PMX_REFINE_STREAMS")) n_workers = std::max(1, atoi(e));
+                n_workers = (int)std::min<int64_t>(n_workers, std::max<int64_t>(n_cand - 1, 1));
+                std::vector<std::thread> pool;
+                for (int wk = 0; wk < n_workers; ++wk)
+                    pool.emplace_back([&, wk]() {
+                        pmx_ctx* wctx = ctx;
+                        pmx_aligner* al = wk == 0 ? al0 : nullptr;
+                        if (wk > 0 && pmx_ctx_create(dev, &wctx) != PMX_OK) { failed = 1; return; }
+                        for (;;) {
+                            const int64_t i = next.fetch_add(1);
+                            if (i >= n_cand || failed.load()) break;
+                            if (score_range(wctx, al, i) != PMX_OK) {
+                                std::lock_guard<std::mutex> g(fail_mu);
+                                if (!failed.exchange(1)) fail_msg = pmx_last_error();
+                                break;
+                            }
+                        }
+                        if (wk > 0) { if (al) pmx_aligner_free(wctx, al); pmx_ctx_destroy(wctx); }
+                        else al0 = al;
+                    });
+                for (auto& t : pool) t.join();
+                if (failed.load()) die("refining the placement: " + fail_msg);
+            }
+            if (al0) pmx_aligner_free(ctx, al0);
+            struct Lookup { const std::vector<uint32_t>* nodes; const std::vector<int64_t>* scores; } lk{&cands, &cand_score};
+            auto lookup = [](void* user, uint32_t node, int64_t* score) -> int {
+                const Lookup& l = *(const Lookup*)user;
+                const auto it = std::lower_bound(l.nodes->begin(), l.nodes->end(), node);
+                if (it == l.nodes->end() || *it != node) return PMX_ERR_ARG;
+                *score = (*l.scores)[(size_t)(it - l.nodes->begin())];
+                return PMX_OK;
+            };
+            check(pmx_refine_top_candidates(pmx_index_parents(idx), info.n_nodes, scores5.data(), res.best_index, &rp, lookup, &lk, &refined, nullptr, nullptr, 0),
                   "refining the placement");
-            if (rc.al) pmx_aligner_free(ctx, rc.al);
             if (!refined.ran) fprintf(stderr, "panmap: warning: Refinement skipped: no nodes with positive scores\n");
             else say(c, "place", "refined against " + std::to_string(refined.n_candidates) + " candidates");
         }
