@@ -10,9 +10,10 @@
 //   * a minimizer is 8 bytes while it waits for its index probe; a seed is a reference position word (2 or 4 bytes) and
 //     a query word (2 bytes) and BECOMES the anchor in place (the heap merge of map.c:102-166 runs on a heap of one-byte
 //     seed indices, its pop order is turned into destinations and the seeds are permuted along the cycles); a chain
-//     cell is 2 bytes (score | predecessor); chain members and per-mate anchor lists are one-byte indices;
-//   * 56 anchors per pair (99.9 % of 150 bp pairs; mean 40): 392 bytes per pair (504 with 32-bit positions),
-//     interleaved word-wise across the 64 lanes of a wave in LDS (conflict-free): 25 KB per wave, six waves per CU;
+//     cell is 2 bytes (score | predecessor); the members of a chain are a 64-bit set in a register (a chain walks to ever
+//     smaller indices), per-mate anchor lists are two-byte indices in the dead chain cells;
+//   * 56 anchors per pair (99.9 % of 150 bp pairs; mean 40): 336 bytes per pair (448 with 32-bit positions),
+//     interleaved word-wise across the 64 lanes of a wave in LDS (conflict-free): 21 KB per wave, seven waves per CU;
 //   * regions are a handful of scalars in registers: at most one region per mate is followed.
 // Everything outside that envelope -- an ambiguous base, a seed that occurs twice in the reference, more than 56 seeds,
 // a third chain, two regions on one mate, an extension or gap fill the closed forms (aln_ksw.hpp, ksw_shortcut_*) do
@@ -51,10 +52,10 @@ typedef uint8_t c_u8;
 // One lane's work memory; word i of lane l sits at base + i * 64 + l (device), so a wave touching word i of its 64
 // pairs touches 256 contiguous bytes of LDS.  PT = uint16_t when every reference position word fits 16 bits
 // (position << 1 | strand: references up to 32,767 bases), uint32_t otherwise.
-//   X  PT  [48]  seed: reference position word (position << 1 | strand)  ->  anchor x: strand << (bits-1) | position
-//   Y  u16 [48]  seed / anchor query word (PMX_CQ_*)
-//   G  u16 [48]  merge: destination of every seed | chain cells F | after the backtrack: per-mate anchor index lists
-//   B  u8  [48]  merge heap of seed indices, then its pop order | chain members in walk order
+//   X  PT  [56]  seed: reference position word (position << 1 | strand)  ->  anchor x: strand << (bits-1) | position
+//   Y  u16 [56]  seed / anchor query word (PMX_CQ_*); bits 12..15: during the chain fill, the length of the colinear run that ends here
+//   G  u16 [56]  merge: heap of seed indices / its pop order (high bytes) + destination of every seed (low bytes) | chain
+//                cells F | after the backtrack: per-mate anchor index lists
 //   M  u64 [..]  minimizers of one read waiting for their probes: overlays everything from word 0
 // Chain gap penalties by diagonal difference (lchain.c:113-141 with chn_pen_skip == 0): the two float expressions of
 // comput_sc depend on dd alone, so a wave tabulates them once per kernel (exactly as chain_score_sel evaluates them) and the
@@ -98,8 +99,7 @@ struct CMemT {
     static constexpr int kXH = 0;                                        // X in units of PT
     static constexpr int kYH = (int)(sizeof(PT) / 2) * kCap;             // Y, G in halves
     static constexpr int kGH = kYH + kCap;
-    static constexpr int kBB = 2 * (kGH + kCap);                         // B in bytes
-    static constexpr int kWords = (kBB + kCap + 3) / 4;
+    static constexpr int kWords = (kGH + kCap + 1) / 2;
     static_assert(kCap <= 63, "predecessor + 1 in six bits, marks and the used set in 64");
     static constexpr int kMCap = kWords / 2 < PMX_C_MCAP ? kWords / 2 : PMX_C_MCAP;
     static constexpr uint32_t kRevBit = 1u << (8 * sizeof(PT) - 1);
@@ -110,7 +110,8 @@ struct CMemT {
     PMX_HD void setX(int i, uint32_t v) const { if (sizeof(PT) == 2) h(i) = (c_u16)v; else w(i) = v; }
     PMX_HD c_u16& Y(int i) const { return h(kYH + i); }
     PMX_HD c_u16& G(int i) const { return h(kGH + i); }
-    PMX_HD c_u8& B(int i) const { return b(kBB + i); }
+    PMX_HD c_u8& GL(int i) const { return b(2 * (kGH + i)); }       // the two bytes of G(i), for the phases that keep two
+    PMX_HD c_u8& GH(int i) const { return b(2 * (kGH + i) + 1); }   // one-byte lists in it
     PMX_HD uint64_t M(int i) const { return (uint64_t)w(2 * i) | (uint64_t)w(2 * i + 1) << 32; }
     PMX_HD void setM(int i, uint64_t v) const { w(2 * i) = (uint32_t)v; w(2 * i + 1) = (uint32_t)(v >> 32); }
     // anchor x split: strand, reference position
@@ -497,7 +498,7 @@ PMX_HD int c_filter_mapq(const Opt& o, const RefIndex& ri, int qlen, CReg& r, bo
 
 // Minimizers -> index probes -> seeds, one read at a time.  The object is BOTH functors of sketch_core: operator()(i)
 // hands out base i (and is where the wave drains its queues: it runs once per base in every lane), operator()(x, y)
-// queues a minimizer.  Minimizers wait for their probes in a short queue that overlays G and B (21 entries); the whole
+// queues a minimizer.  Minimizers wait for their probes in a short queue that overlays G (14 entries); the whole
 // wave drains its queues together -- four probes in flight per lane -- whenever some lane holds six (one base can add
 // up to w), so the drain is a uniform branch and the seeds never need a staging copy of the minimizer list.  The newest
 // entry stays queued until its right neighbour is known (the tandem mark compares adjacent minimizers, seed.c:40-46).
@@ -505,9 +506,9 @@ template <class PT>
 struct CSeeder {
     typedef CMemT<PT> MT;
     static constexpr int kQBase = (MT::kGH / 2 + 1) / 2;              // first M entry that lies above X and Y
-    static constexpr int kQCap = MT::kWords / 2 - kQBase;             // 21
-    static constexpr int kQDrain = kQCap - 12 > 1 ? kQCap - 12 : 1;   // drain threshold
-    static_assert(kQCap >= 14, "minimizer queue too short for one base's worth of pushes");
+    static constexpr int kQCap = MT::kWords / 2 - kQBase;             // 14
+    static constexpr int kQDrain = kQCap - 2;                         // drain threshold (sketch_distinct pushes at most one minimizer per base)
+    static_assert(kQCap >= 8, "minimizer queue too short");
     const MT& m;
     const RefIndex& ri;
     CRead r;
@@ -706,67 +707,68 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
     // ---------------------------------------------------------------- heap merge (map.c:102-166) -> anchors in place
     const int n = n_s;
     {
-        for (int i = 0; i < n; ++i) m.B(i) = (c_u8)i;
+        // (heap of seed indices and, later, its pop order in the HIGH bytes of G; the destinations go to the LOW bytes)
+        for (int i = 0; i < n; ++i) m.GH(i) = (c_u8)i;
         auto heapdown = [&](int i, int sz) PMX_LAMBDA_INLINE {   // ks_heapdown with "less" = larger reference position word (min-heap)
-            const uint32_t tmp = m.B(i);
+            const uint32_t tmp = m.GH(i);
             const uint32_t tk = m.X((int)tmp);
             int kk;
             while ((kk = (i << 1) + 1) < sz) {
-                uint32_t ce = m.B(kk);
+                uint32_t ce = m.GH(kk);
                 uint32_t ckey = m.X((int)ce);
                 if (kk != sz - 1) {
-                    const uint32_t c1 = m.B(kk + 1);
+                    const uint32_t c1 = m.GH(kk + 1);
                     const uint32_t k1 = m.X((int)c1);
                     if (ckey > k1) { ++kk; ce = c1; ckey = k1; }
                 }
                 if (ckey > tk) break;
-                m.B(i) = (c_u8)ce;
+                m.GH(i) = (c_u8)ce;
                 i = kk;
             }
-            m.B(i) = (c_u8)tmp;
+            m.GH(i) = (c_u8)tmp;
         };
         for (int q = (n >> 1) - 1; q >= 0; --q) heapdown(q, n);
         // pops: the root leaves, the last element takes its place (every occurrence list has one entry), the slot the
-        // heap gave up keeps the popped seed -> B(n-1-t) = t-th seed out
+        // heap gave up keeps the popped seed -> GH(n-1-t) = t-th seed out
         int n_for = 0;
         for (int sz = n; sz > 0;) {
-            const uint32_t si = m.B(0);
-            const uint32_t last = m.B(sz - 1);
+            const uint32_t si = m.GH(0);
+            const uint32_t last = m.GH(sz - 1);
             --sz;
-            if (sz > 0) { m.B(0) = (c_u8)last; heapdown(0, sz); }
-            m.B(sz) = (c_u8)si;
+            if (sz > 0) { m.GH(0) = (c_u8)last; heapdown(0, sz); }
+            m.GH(sz) = (c_u8)si;
             n_for += ((m.X((int)si) ^ m.Y((int)si)) & 1u) ? 0 : 1;   // strand of the reference copy == strand of the query copy
         }
         // destinations: forward-strand anchors first, in pop order, then the reverse-strand ones, in pop order
         {
             int df = 0, dr = n_for;
             for (int t = 0; t < n; ++t) {
-                const int si = (int)m.B(n - 1 - t);
+                const int si = (int)m.GH(n - 1 - t);
                 const bool fwd = ((m.X(si) ^ m.Y(si)) & 1u) == 0u;
-                m.G(si) = (c_u16)(fwd ? df : dr);
+                m.GL(si) = (c_u8)(fwd ? df : dr);
                 df += fwd ? 1 : 0;
                 dr += fwd ? 0 : 1;
             }
         }
-        // seeds -> anchors, moved along the cycles of the destination map (bit 15 of G: already placed)
+        // seeds -> anchors, moved along the cycles of the destination map (bit 7 of the destination byte: already placed)
         auto to_anchor = [&](uint32_t pv, uint32_t qy, uint32_t* ax, uint32_t* ay) PMX_LAMBDA_INLINE {
             const uint32_t rpos = pv >> 1, qp = qy & 0x3ffu, fl = qy & (PMX_CQ_SEG | PMX_CQ_TANDEM);
             if ((pv & 1u) == (qp & 1u)) { *ax = rpos; *ay = (qp >> 1) | fl; }
             else { *ax = MT::kRevBit | rpos; *ay = (uint32_t)(qlen_sum - ((int)(qp >> 1) + 1 - k) - 1) | fl; }
         };
         for (int s0 = 0; s0 < n; ++s0) {
-            if (m.G(s0) & 0x8000u) continue;
+            if (m.GL(s0) & 0x80u) continue;
             uint32_t cx, cy;
             to_anchor(m.X(s0), m.Y(s0), &cx, &cy);
-            int d = (int)m.G(s0);
-            m.G(s0) = (c_u16)(d | 0x8000);
+            int d = (int)m.GL(s0);
+            m.GL(s0) = (c_u8)(d | 0x80);
             while (d != s0) {
                 uint32_t nx, ny;
                 to_anchor(m.X(d), m.Y(d), &nx, &ny);
                 m.setX(d, cx); m.Y(d) = (c_u16)cy;
                 cx = nx; cy = ny;
-                const int d2 = (int)(m.G(d) & 0x7fffu);
-                m.G(d) = (c_u16)(d2 | 0x8000);
+                const int d2 = (int)(m.GL(d) & 0x7fu);
+                m.GL(d) = (c_u8)(d2 | 0x80);
                 d = d2;
             }
             m.setX(s0, cx); m.Y(s0) = (c_u16)cy;
@@ -867,7 +869,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
                 // bottom within the distance limits every member is valid and sc falls (weakly) from the top down, by
                 // the inequality above -- the rest of the run is not better and marked: it only counts skips
                 if (use_tab && valid && !stop) {
-                    const int32_t a0 = (int32_t)m.B(j);
+                    const int32_t a0 = j - (int32_t)(ayj >> 12);   // (run length, at most 15: a longer run is skipped in several steps)
                     const int32_t a = a0 > st ? a0 : st;
                     if (j - a >= 2) {
                         const uint32_t axa = m.X(a);
@@ -913,7 +915,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             m.G(i) = (c_u16)((uint32_t)max_f | (uint32_t)(max_j + 1) << 10);
             if (max_ii < 0 || ((xi - x_mi) <= (uint64_t)(int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = xi; f_mi = max_f; }
             if (!(extends && max_j == i - 1)) { r0 = i; jv = i; }
-            m.B(i) = (c_u8)r0;
+            { const int rl = i - r0; m.Y(i) = (c_u16)(ayi | (uint32_t)(rl < 15 ? rl : 15) << 12); }   // bits 12..15 of Y: free in this tier
 #ifdef PMX_C_DUMP
             if (getenv("PMX_C_DUMP")) fprintf(stderr, "i=%d pos=%u q=%d seg=%d f=%d p=%d r0=%d ext=%d st=%d\n", i, rpi, qi, sidi, max_f, max_j, r0, (int)extends, st);
 #endif
@@ -927,7 +929,8 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
     // already uses: picking, each time, the largest (score, index) below the previous pick among the unused anchors is
     // the same sequence without the sorted copy.
     int n_u = 0;
-    int32_t u_sc0 = 0, u_sc1 = 0, u_cnt0 = 0, u_cnt1 = 0;
+    int32_t u_sc0 = 0, u_sc1 = 0;
+    uint64_t keep0 = 0, keep1 = 0;   // the members of the two chains (a chain walks to ever smaller indices: the set is the list)
     {
         uint64_t used = 0;
         int n_v = 0;
@@ -950,7 +953,6 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             uint64_t walk = 0, keep = 0;
             do {
                 walk |= 1ULL << i;
-                m.B(n_v0 + __builtin_popcountll(walk) - 1) = (c_u8)i;
                 i = (int)(m.G(i) >> 10) - 1;
                 const int32_t s = i < 0 ? zx : zx - (int32_t)(m.G(i) & 0x3ffu);
                 if (s > max_s) { max_s = s; keep = walk; }
@@ -961,8 +963,8 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             n_v = n_v0 + cnt;
             if (max_s >= min_sc && cnt > 0 && cnt >= min_cnt) {
                 if (n_u >= 2) return PMX_C_BAIL;   // a third chain: general tier
-                if (n_u == 0) { u_sc0 = max_s; u_cnt0 = cnt; }
-                else { u_sc1 = max_s; u_cnt1 = cnt; }
+                if (n_u == 0) { u_sc0 = max_s; keep0 = keep; }
+                else { u_sc1 = max_s; keep1 = keep; }
                 ++n_u;
             } else n_v = n_v0;
         }
@@ -975,8 +977,8 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
     // has nothing to decide: the chains of different mates do not overlap on the fragment), a mate without anchors makes
     // the pair unmapped whatever the other one does
     int c00 = 0, c01 = 0, c10 = 0, c11 = 0;   // c<chain><segment>
-    for (int j = 0; j < u_cnt0; ++j) { const uint32_t sg = (m.Y((int)m.B(j)) >> 10) & 1u; c00 += sg ? 0 : 1; c01 += sg ? 1 : 0; }
-    for (int j = 0; j < u_cnt1; ++j) { const uint32_t sg = (m.Y((int)m.B(u_cnt0 + j)) >> 10) & 1u; c10 += sg ? 0 : 1; c11 += sg ? 1 : 0; }
+    for (uint64_t wk = keep0; wk; wk &= wk - 1) { const uint32_t sg = (m.Y(__builtin_ctzll(wk)) >> 10) & 1u; c00 += sg ? 0 : 1; c01 += sg ? 1 : 0; }
+    for (uint64_t wk = keep1; wk; wk &= wk - 1) { const uint32_t sg = (m.Y(__builtin_ctzll(wk)) >> 10) & 1u; c10 += sg ? 0 : 1; c11 += sg ? 1 : 0; }
     if ((c00 == 0 && c10 == 0) || (c01 == 0 && c11 == 0)) return want_edits ? PMX_C_BAIL : PMX_C_DONE;   // a mate without a region: unmapped (the other mate's edit count: general tier)
     if ((c00 > 0 && c10 > 0) || (c01 > 0 && c11 > 0)) return PMX_C_BAIL;        // a mate with two regions
     // per-mate anchor index lists in G (the chain cells are dead): mate 0 from 0, mate 1 behind it, ascending = the
@@ -988,11 +990,10 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bool from1 = s == 0 ? c00 == 0 : c01 == 0;   // the mate's chain
-            const int off = from1 ? u_cnt0 : 0, cnt_c = from1 ? u_cnt1 : u_cnt0;
             if (s == 1) base1 = wr;
             uint32_t rev = 0;
-            for (int j = cnt_c - 1; j >= 0; --j) {
-                const int ai = (int)m.B(off + j);
+            for (uint64_t wk = from1 ? keep1 : keep0; wk; wk &= wk - 1) {   // ascending = the chain walked backwards
+                const int ai = __builtin_ctzll(wk);
                 if ((int)((m.Y(ai) >> 10) & 1u) != s) continue;
                 rev = MT::rev_of(m.X(ai));
                 m.G(wr++) = (c_u16)ai;

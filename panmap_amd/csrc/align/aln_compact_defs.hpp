@@ -1,14 +1,14 @@
 // Capacities of the compact align tier (aln_compact.hpp), shared with the host launcher.
 #pragma once
 #define PMX_C_W 11              // minimizer window of the tier's sketch (the preset's, src/mm_align.c:140-166; k must be odd)
-#define PMX_C_CAP 56            // seeds / anchors per pair: the most that leaves six waves per CU (48: seven waves and a 20 % faster kernel, but 0.9 % of
-                                // 150 bp pairs -- mean 40 anchors -- run out and a tier of bails costs more than that; at most 63, see CMemT)
+#define PMX_C_CAP 56            // seeds / anchors per pair: six bytes each: the most that leaves seven waves per CU (0.1 % of 150 bp pairs -- mean 40
+                                // anchors -- run out; with 48, 0.9 % did and a tier of bails costs more than that; at most 63, see CMemT)
 #define PMX_C_MCAP 40           // minimizers of one read waiting for their probes
 #define PMX_C_NW 5              // 32-base words per read: reads up to 160 bases
 #define PMX_C_MAXLEN (32 * PMX_C_NW)
-// LDS words per pair (CMemT<PT>::kWords): X (PT) + Y (u16) + G (u16) + B (u8), 48 entries each
-#define PMX_C_LANE_WORDS16 98    // 392 bytes: reference position words of 16 bits
-#define PMX_C_LANE_WORDS32 126   // 504 bytes
+// LDS words per pair (CMemT<PT>::kWords): X (PT) + Y (u16) + G (u16), PMX_C_CAP entries each
+#define PMX_C_LANE_WORDS16 84    // 336 bytes: reference position words of 16 bits
+#define PMX_C_LANE_WORDS32 112   // 448 bytes
 // gap-penalty tables of the chain fill, per wave (aln_compact.hpp CPenTab)
 #define PMX_C_PEN_SAME 128
 #define PMX_C_PEN_DIFF 1024

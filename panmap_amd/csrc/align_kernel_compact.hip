@@ -1,5 +1,5 @@
-// ALIGN stage, compact tier kernel for gfx950: THREAD per read pair, the pair's whole work state in LDS (392 bytes,
-// word-interleaved across the wave: 25 KB per wave, six waves per CU; 504 bytes / four waves when the reference is
+// ALIGN stage, compact tier kernel for gfx950: THREAD per read pair, the pair's whole work state in LDS (336 bytes,
+// word-interleaved across the wave: 21 KB per wave, seven waves per CU; 448 bytes / five waves when the reference is
 // longer than 32,767 bases) and registers -- align/aln_compact.hpp.
 // It takes every pair of the batch first.  A pair it finishes has its records written here; a pair outside the tier's
 // envelope is appended to the bail list and run by the general thread-per-pair kernel (align_kernel_tpp.hip) and its
