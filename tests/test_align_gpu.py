@@ -104,6 +104,42 @@ def test_noisy_and_edge_pairs(pmx, oracle, ctx):
     assert not bad, bad[:10]
 
 
+def test_varied_pair_shapes_exact(pmx, oracle, ctx, sars):
+    """read length, insert size (mates overlapping down to one fragment shorter than a read, and far apart), substitution
+    and indel rates, both mate orientations, three genomes of the tree: the compact tier's closed forms (colinear runs,
+    distinct-window sketch) and every general tier against the reference aligner"""
+    rng = np.random.default_rng(77)
+    al = None
+    for node, read_len, mean_insert, sub_rate, indel_every, as_sequenced in (
+            ("node_7618", 150, 300.0, 0.002, 0, False), ("node_7618", 150, 180.0, 0.01, 0, False), ("node_7618", 100, 150.0, 0.02, 7, False),
+            ("node_1", 75, 90.0, 0.005, 0, False), ("node_9000", 125, 500.0, 0.03, 5, False), ("node_7618", 150, 320.0, 0.004, 11, True),
+            ("node_9000", 100, 130.0, 0.0, 0, True), ("node_1", 150, 700.0, 0.001, 0, False)):
+        g = sars.genome(node)
+        concat, off = pmx.simulate_paired_reads(g, 6000, read_len=read_len, seed=int(rng.integers(1, 1 << 30)), sub_rate=sub_rate,
+                                                mean_insert=max(mean_insert, float(read_len)), sd_insert=mean_insert / 8)
+        reads = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+        if not as_sequenced:
+            reads = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(reads)]
+        if indel_every:
+            for i in range(0, len(reads), indel_every):
+                r = bytearray(reads[i])
+                p = int(rng.integers(10, max(11, len(r) - 10)))
+                if i % 2:
+                    del r[p:p + int(rng.integers(1, 6))]
+                else:
+                    r[p:p] = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(1, 6))))
+                reads[i] = bytes(r)
+        if al is None:
+            al = pmx.Aligner(ctx, g, read_len)
+        else:
+            al.set_reference(g, read_len)
+        got = al.align_reads(reads, paired=True)
+        want = oracle.ref_align_reads_direct(g, reads, True, 8)
+        bad = ac.compare_results(got, want)
+        assert not bad, (node, read_len, mean_insert, sub_rate, indel_every, as_sequenced, bad[:5])
+        assert sum(1 for x in got if x["flags"] & 3) == 0
+
+
 def test_align_reads_direct_dropin(pmx, oracle, ctx):
     """same signature, same results as the reference boundary (src/mm_align.h:44-53)"""
     g = _ref_genome()
