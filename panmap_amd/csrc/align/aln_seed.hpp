@@ -118,7 +118,6 @@ PMX_HD void sketch_segment_t(Work& W, const Ring& buf, Ptr<const uint8_t> seq, i
 #undef PMX_MV_PUSH
 }
 
-#if PMX_W == 1
 // The same sketch for the scalar execution models (thread per pair, host) with the window ring in REGISTERS
 // (w <= WMAX): sketch_segment_t re-scans the ring entry by entry whenever the minimum slides out of the window, and in
 // a wave of 64 reads some lane needs that at nearly every base, so every base paid ~2w dependent ring reads.  Here
@@ -240,6 +239,7 @@ PMX_HD void sketch_slice(int begin, int end, int len, int w, int k, BaseFn& base
     sketch_core<WMAX>(end - f.s0, w, k, 0, f, f, end >= len);
 }
 
+#if PMX_W == 1
 template <int WMAX>
 PMX_HD void sketch_segment_reg(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
     PMX_LDS(&W); PMX_LDS(seq);
@@ -362,8 +362,56 @@ __device__ void sketch_segment_wave(Work& W, const uint8_t* seq, int len, int w,
 }
 #endif
 
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+// Wave-per-pair kernels, k odd and w <= 12: the 64 lanes sketch 64 consecutive slices of the segment on their own
+// (sketch_slice above: w + k + 1 bases of run-in reproduce the sequential state, tests/test_align_host.py) -- ~36 steps
+// per lane for a 150-base read instead of 150 wave-uniform steps with the ring across the lanes.  A lane keeps its (few)
+// minimizers in registers; a wave prefix sum gives every lane its place in W.mv.
+struct SliceBase { const uint8_t* seq; __device__ int operator()(int i) const { return (int)seq[i]; } };
+struct SliceKeep {   // a lane's own minimizers: a handful at most for a slice of a few bases
+    uint64_t x0, y0, x1, y1, x2, y2, x3, y3;
+    int n;
+    __device__ void operator()(uint64_t x, uint64_t y) {
+        if (n == 0) { x0 = x; y0 = y; } else if (n == 1) { x1 = x; y1 = y; } else if (n == 2) { x2 = x; y2 = y; } else if (n == 3) { x3 = x; y3 = y; }
+        ++n;
+    }
+};
+struct SliceWrite { A128* mv; int at; uint64_t y_hi; __device__ void operator()(uint64_t x, uint64_t y) { A128 v; v.x = x; v.y = y_hi | y; mv[at++] = v; } };
+__device__ void sketch_segment_lanes(Work& W, const uint8_t* seq, int len, int w, int k, uint32_t rid) {
+    PMX_LDS(&W); PMX_LDS(seq);
+    A128* mvp = W.mv; PMX_LDS(mvp);
+    const int lane = lane_id();
+    const int per = (len + 63) / 64;
+    const int begin = lane * per, end = begin + per < len ? begin + per : len;
+    SliceBase base{seq};
+    SliceKeep kp;
+    kp.n = 0; kp.x0 = kp.y0 = kp.x1 = kp.y1 = kp.x2 = kp.y2 = kp.x3 = kp.y3 = 0;
+    if (begin < len) sketch_slice<12>(begin, end, len, w, k, base, kp);
+    int incl = kp.n;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    if (W.n_mv + total > W.caps.max_mini) { W.status |= PMX_ST_OVERFLOW; return; }
+    SliceWrite wr{mvp, W.n_mv + incl - kp.n, (uint64_t)rid << 32};
+    if (__ballot(kp.n > 4) == 0ULL) {   // (uniform) the usual case: what the lanes kept goes out
+        if (kp.n > 0) wr(kp.x0, kp.y0);
+        if (kp.n > 1) wr(kp.x1, kp.y1);
+        if (kp.n > 2) wr(kp.x2, kp.y2);
+        if (kp.n > 3) wr(kp.x3, kp.y3);
+    } else if (begin < len && kp.n > 0) sketch_slice<12>(begin, end, len, w, k, base, wr);   // a repeat-rich slice: second pass
+    W.n_mv += total;
+}
+#endif
+
 PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
 #if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+    if ((k & 1) && w >= 1 && w <= 12 && len >= 64 && !W.sk_no_lane_ring) {
+        sketch_segment_lanes(W, seq, len, w, k, rid);
+        wave_sync();
+        return;
+    }
     if (w >= 1 && w <= 64 && !W.sk_no_lane_ring) {
         sketch_segment_wave(W, seq, len, w, k, rid);
         return;
