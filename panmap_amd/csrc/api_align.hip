@@ -279,11 +279,15 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     auto launch = [&](decltype(kern) kfn, const Layout& L, int64_t n_work, const uint32_t* worklist, uint32_t* retry_list, DevBuf<uint8_t>& slab,
                       int64_t max_grid = 0) {
         const size_t lds_bytes = PMX_ALIGN_WORK_BYTES + L.fast_bytes + 16;
+        if (getenv("PMX_ALIGN_VERBOSE")) fprintf(stderr, "[pmx align] wave-tier launch: %lld items, %zu LDS bytes per wave, %zu HBM slab bytes per wave\n", (long long)n_work, lds_bytes, (size_t)L.slow_bytes);
         if (lds_bytes > 160 * 1024) throw std::runtime_error("reads too long for the LDS work arena");
         if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         int waves_per_cu = (int)std::min<size_t>((size_t)(waves_per_simd >= 4 ? 16 : 8), (size_t)(160 * 1024) / lds_bytes);
         if (waves_per_cu < 1) waves_per_cu = 1;
         int64_t grid = (int64_t)ctx->n_cu * waves_per_cu;
+        // a few thousand pairs: one workgroup each, so that the hardware hands a free slot the next pair (with a resident
+        // grid and a strided loop a wave that drew two slow pairs decides the launch)
+        if (n_work <= 16384 && !getenv("PMX_ALIGN_RESIDENT_GRID")) grid = n_work;
         if (grid > n_work) grid = n_work;
         if (max_grid > 0 && grid > max_grid) grid = max_grid;
         A.layout = L;

@@ -1,0 +1,4 @@
+PMX_ALIGN_VERBOSE=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-to-host 2>gpurun_out/aa.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.readline()); print(round(d['value']/1e6,2), round(d['ms_per_step'],3), [round(x,3) for x in d['kernels_ms'].values()], d['checks']['tiers'], d['real_reads']['value'], d['real_reads']['align_stage_ms'])"
+grep "wave-tier" gpurun_out/aa.err | sort | uniq -c | tail -4
