@@ -1,3 +1,4 @@
+# the numbers of profiles/r02 (v3): default bench line, config 3 on one GPU, config 4, --refine timing; outputs under gpurun_out/final
 O=gpurun_out/final
 rm -rf $O; mkdir -p $O
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err

@@ -1,3 +1,6 @@
+#!/bin/bash
+# One step of bench.py as a timeline (rocprofv3 kernel + memory-copy trace); outputs under gpurun_out/prof_tl.
+# Read it with tools/timeline_r02.py (prints every kernel / copy of the last step with the idle gap before it).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_tl
@@ -7,4 +10,3 @@ rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/t -- pyth
 find $O/t -name "*kernel_trace.csv" -exec cp {} $O/kernel_trace.csv \;
 find $O/t -name "*memory_copy_trace.csv" -exec cp {} $O/memcpy_trace.csv \;
 rm -rf $O/t
-ls -la $O
