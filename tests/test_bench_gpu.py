@@ -26,6 +26,7 @@ def test_bench_single_rank_line():
               "config", "roofline", "cpu_baseline", "value_host_to_host", "dp", "real_reads"):
         assert k in d, k
     assert d["value_host_to_host"] > 0 and d["host_to_host"]["equals_device_resident_run"]
+    assert d["two_batches_in_flight"]["value"] > 0 and d["two_batches_in_flight"]["equals_serial_run"]
     assert set(("pair_share", "cells_per_step", "gcups_align_stage")) <= set(d["dp"])
     assert d["real_reads"]["value"] > 0 and d["real_reads"]["placed_node"] == "node_7618" and d["real_reads"]["records_flagged"] == 0
     assert d["cpu_baseline"]["cores"] == os.cpu_count()
