@@ -5,7 +5,7 @@
 //   place   reads -> `<prefix>.placement.tsv` (src/placement.cpp:1952-2003)
 //   align   placed genome -> `<prefix>.ref.fa` (+ .fai), reads aligned to it -> `<prefix>.bam` (+ .bai)
 // `--stop index|place|align` ends after that stage.  The later stages of the reference (genotype, consensus), --meta,
-// --batch, the bwa backend and HPC seeds are outside this library: asking for them is an error, not a silent
+// the bwa backend and HPC seeds are outside this library: asking for them is an error, not a silent
 // no-op (a `--stop` beyond align stops after align with a note).  Output prefix: -o, else derived from reads1 as the
 // reference derives it.  Exit code 130 on SIGINT.
 #include <signal.h>
@@ -20,6 +20,9 @@
 #include <mutex>
 #include <thread>
 #include <algorithm>
+#include <chrono>
+#include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -28,7 +31,7 @@
 namespace {
 
 struct Config {
-    std::string panman, reads1, reads2, output, index, index_out, stop = "consensus", aligner = "minimap2";
+    std::string panman, reads1, reads2, output, index, index_out, stop = "consensus", aligner = "minimap2", batch;
     int threads = 1, k = 19, s = 8, t = 0, l = 3, flank_mask = 250, zstd_level = 7;
     bool open_syncmer = false, hpc = false, force_reindex = false, index_uncompressed = false, quiet = false;
     double seed_mask_fraction = 0.0;
@@ -41,10 +44,8 @@ struct Config {
 
 void on_sigint(int) { _exit(130); }
 
-[[noreturn]] void die(const std::string& msg, int code = 1) {
-    fprintf(stderr, "panmap: error: %s\n", msg.c_str());
-    exit(code);
-}
+struct Fatal { std::string msg; int code; };
+[[noreturn]] void die(const std::string& msg, int code = 1) { throw Fatal{msg, code}; }   // main (or the --batch loop) reports it
 void check(int rc, const char* what) {
     if (rc != PMX_OK) die(std::string(what) + ": " + pmx_last_error());
 }
@@ -59,6 +60,7 @@ void usage() {
           "  -o, --output PREFIX        output prefix (default: derived from reads1)\n"
           "  -t, --threads N            accepted (the GPU owns the parallelism)\n"
           "      --stop STAGE           index|place|align (later stages are not part of this build)\n"
+          "      --batch FILE           one sample per line: reads1 [reads2] [prefix]; the index stays resident\n"
           "      --refine               re-rank the top candidates by aligning the reads against them\n"
           "      --refine-top-pct F / --refine-max-top-n N / --refine-neighbor-radius N / --refine-max-neighbor-n N\n"
           "  -i, --index PATH           load a pre-built index       --index-out PATH   write the built index here\n"
@@ -106,12 +108,13 @@ Config parse(int argc, char** argv) {
         else if (a == "--force-leaf") c.force_leaf = true;
         else if (a == "-q" || a == "--quiet") c.quiet = true;
         else if (a == "-v" || a == "--verbose" || a == "--no-color" || a == "--no-progress") {}
+        else if (a == "--batch") c.batch = v();
         else if (a == "--refine") c.refine = true;
         else if (a == "--refine-top-pct") c.refine_top_pct = atof(v().c_str());
         else if (a == "--refine-max-top-n") c.refine_max_top_n = atoi(v().c_str());
         else if (a == "--refine-neighbor-radius") c.refine_neighbor_radius = atoi(v().c_str());
         else if (a == "--refine-max-neighbor-n") c.refine_max_neighbor_n = atoi(v().c_str());
-        else if (a == "--meta" || a == "--batch" || a == "--impute" || a == "--extent-guard" || a == "--reference-node" ||
+        else if (a == "--meta" || a == "--impute" || a == "--extent-guard" || a == "--reference-node" ||
                  a == "--dump-sequence" || a == "--dump-all-scores")
             die("option " + a + " belongs to a part of panmap this build does not implement (index / place / align only)");
         else if (a.size() > 1 && a[0] == '-') die("unknown option " + a + " (see --help)");
@@ -144,6 +147,68 @@ std::string derive_prefix(const Config& c) {
     return stem;
 }
 
+// readBatchFiles (src/main.cpp:1025-1087): one sample per line, `reads1 [reads2] [prefix]`; '#' starts a comment line; a
+// single optional field is reads2 when it looks like a FASTQ, else the output prefix; default prefix = reads1 without its
+// directory-independent mate suffix and .fastq / .fq
+struct BatchEntry { std::string reads1, reads2, prefix; };
+std::vector<BatchEntry> read_batch_file(const std::string& path) {
+    std::ifstream in(path);
+    if (!in.is_open()) die("Cannot open batch file: " + path);
+    std::vector<BatchEntry> out;
+    std::string line;
+    size_t line_no = 0;
+    while (std::getline(in, line)) {
+        ++line_no;
+        const size_t b = line.find_first_not_of(" \t\r\n"), e2 = line.find_last_not_of(" \t\r\n");
+        if (b == std::string::npos) continue;
+        line = line.substr(b, e2 - b + 1);
+        if (line[0] == '#') continue;
+        std::istringstream iss(line);
+        BatchEntry e;
+        std::string f2, f3;
+        iss >> e.reads1 >> f2 >> f3;
+        if (e.reads1.empty()) continue;
+        if (!f2.empty()) {
+            if (!f3.empty()) { e.reads2 = f2; e.prefix = f3; }
+            else {
+                std::string lower = f2;
+                for (char& ch : lower) ch = (char)tolower((unsigned char)ch);
+                if (lower.find(".fastq") != std::string::npos || lower.find(".fq") != std::string::npos) e.reads2 = f2;
+                else e.prefix = f2;
+            }
+        }
+        if (e.prefix.empty()) {
+            const size_t slash = e.reads1.find_last_of('/');
+            const std::string dir = slash == std::string::npos ? "" : e.reads1.substr(0, slash);
+            std::string stem = slash == std::string::npos ? e.reads1 : e.reads1.substr(slash + 1);
+            const size_t dot = stem.find_last_of('.');
+            if (dot != std::string::npos && dot > 0) stem = stem.substr(0, dot);
+            auto strip = [&](std::initializer_list<const char*> sfx) {
+                for (const char* sx : sfx) {
+                    const size_t n = strlen(sx);
+                    if (stem.size() > n && stem.compare(stem.size() - n, n, sx) == 0) { stem.erase(stem.size() - n); return; }
+                }
+            };
+            strip({"_R1", "_R2", "_1", "_2", ".R1", ".R2"});
+            strip({".fastq", ".fq"});
+            e.prefix = dir.empty() ? stem : dir + "/" + stem;
+        }
+        if (!exists(e.reads1)) die("Batch line " + std::to_string(line_no) + ": reads file not found: " + e.reads1);
+        if (!e.reads2.empty() && !exists(e.reads2)) die("Batch line " + std::to_string(line_no) + ": reads file not found: " + e.reads2);
+        out.push_back(e);
+    }
+    return out;
+}
+void mkdirs(const std::string& dir) {   // fs::create_directories
+    std::string cur;
+    for (size_t i = 0; i <= dir.size(); ++i) {
+        if (i == dir.size() || dir[i] == '/') {
+            if (!cur.empty() && !exists(cur)) mkdir(cur.c_str(), 0777);
+        }
+        if (i < dir.size()) cur += dir[i];
+    }
+}
+
 // cachedIndexUsable (src/main.cpp:371-396)
 bool cached_index_usable(const Config& c) {
     if (exists(c.panman) && mtime(c.index) < mtime(c.panman)) {
@@ -169,35 +234,26 @@ char comp(char b) {   // seeding::reverseComplement (src/seeding.cpp:271-284): A
 
 }  // namespace
 
-int main(int argc, char** argv) {
-    signal(SIGINT, on_sigint);
-    Config c = parse(argc, argv);
-    if (c.s <= 0 || c.s > c.k) die("Invalid syncmer s=" + std::to_string(c.s) + " (must be in 1..k, k=" + std::to_string(c.k) + ")");
-    if (c.t < 0 || c.t > c.k - c.s) die("Invalid syncmer offset=" + std::to_string(c.t) + " (must be in 0..k-s = 0.." + std::to_string(c.k - c.s) + ")");
-    if (c.hpc) die("--hpc (homopolymer-compressed seeds) is not implemented in this build");
-    if (c.aligner != "minimap2") die("aligner '" + c.aligner + "' is not implemented in this build (minimap2 only)");
-    int stop = c.stop == "index" ? 0 : c.stop == "place" ? 1 : c.stop == "align" ? 2 : (c.stop == "genotype" || c.stop == "consensus") ? 3 : -1;
-    if (stop < 0) die("--stop expects index|place|align|genotype|consensus");
-    if (c.index.empty()) c.index = c.index_out.empty() ? c.panman + ".idx" : c.index_out;
-    else if (!exists(c.index)) die("index file not found: " + c.index + " (--index expects a pre-built index; use --index-out to build at a custom path)");
-    if (c.output.empty()) c.output = derive_prefix(c);
-
-    // ------------------------------------------------------------------------------------------------ index
-    pmx_panman* pm = nullptr;
-    pmx_index* idx = nullptr;
-    if (exists(c.index) && !c.force_reindex && cached_index_usable(c)) {
-        check(pmx_index_load(c.index.c_str(), &idx), "loading the index");
-        say(c, "index", c.index + " (cached)");
-    } else {
-        check(pmx_panman_open(c.panman.c_str(), &pm), "opening the PanMAN");
-        check(pmx_index_build(pm, c.k, c.s, c.t, c.l, c.open_syncmer ? 1 : 0, c.flank_mask, &idx), "building the index");
-        check(pmx_index_save(idx, c.index.c_str(), c.zstd_level, c.index_uncompressed ? 1 : 0), "writing the index");
-        say(c, "index", c.index + " (built)");
-    }
-    if (stop == 0 || c.reads1.empty()) return 0;
-
-    // ------------------------------------------------------------------------------------------------ reads
+// per-sample resources (freed when the sample is done, whatever way it ends)
+struct SampleGuard {
+    pmx_ctx* ctx;
     pmx_fastx *f1 = nullptr, *f2 = nullptr;
+    pmx_readset* rs = nullptr;
+    pmx_aligner* al = nullptr;
+    ~SampleGuard() {
+        if (al) pmx_aligner_free(ctx, al);
+        if (rs) pmx_readset_free(ctx, rs);
+        if (f1) pmx_fastx_free(f1);
+        if (f2) pmx_fastx_free(f2);
+    }
+};
+
+// One sample through place (+ --refine) (+ align) against the resident index: c.reads1 / c.reads2 / c.output name it.
+// Returns the placed node; throws Fatal.
+std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* idx, pmx_ctx* ctx, pmx_place* pl, int dev) {
+    // ------------------------------------------------------------------------------------------------ reads
+    SampleGuard g{ctx};
+    pmx_fastx *&f1 = g.f1, *&f2 = g.f2;
     check(pmx_fastx_read(c.reads1.c_str(), &f1), "reading reads1");
     const bool paired = !c.reads2.empty();
     if (paired) check(pmx_fastx_read(c.reads2.c_str(), &f2), "reading reads2");
@@ -226,13 +282,7 @@ int main(int argc, char** argv) {
     off[(size_t)n_reads] = (int64_t)concat.size();
 
     // ------------------------------------------------------------------------------------------------ place
-    pmx_ctx* ctx = nullptr;
-    int dev = 0;
-    if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
-    check(pmx_ctx_create(dev, &ctx), "opening the GPU");
-    pmx_place* pl = nullptr;
-    check(pmx_place_create(ctx, idx, &pl), "uploading the index");
-    pmx_readset* rs = nullptr;
+    pmx_readset*& rs = g.rs;
     check(pmx_readset_upload(ctx, concat.data(), off.data(), n_reads, &rs), "uploading the reads");
     check(pmx_readset_pack(ctx, rs), "packing the reads");
     pmx_place_params pp;
@@ -349,7 +399,7 @@ int main(int argc, char** argv) {
     if (res.best_index[4] == UINT32_MAX) die("No placement found");
     const std::string node_id = pmx_index_node_id(idx, res.best_index[4]);
     say(c, "place", node_id + " (log_containment " + std::to_string(res.best_score[4]) + ")");
-    if (stop == 1) return 0;
+    if (stop == 1) return node_id;
 
     // ------------------------------------------------------------------------------------------------ align
     if (!pm) check(pmx_panman_open(c.panman.c_str(), &pm), "opening the PanMAN");
@@ -368,7 +418,7 @@ int main(int argc, char** argv) {
         if (g) { fprintf(g, "%s\t%zu\t%zu\t%zu\t%zu\n", node_id.c_str(), genome.size(), node_id.size() + 2, genome.size(), genome.size() + 1); fclose(g); }
         say(c, "align", fa);
     }
-    pmx_aligner* al = nullptr;
+    pmx_aligner*& al = g.al;
     check(pmx_aligner_create(ctx, genome.data(), (int64_t)genome.size(), (int)(concat.size() / (size_t)std::max<int64_t>(n_reads, 1)), &al), "indexing the placed genome");
     check(pmx_align_readset(ctx, al, rs, paired ? 1 : 0, paired ? 1 : 0), "aligning");   // mate 2 reverse-complemented on the device
     std::vector<pmx_aln_record> recs((size_t)n_reads);
@@ -428,14 +478,87 @@ int main(int argc, char** argv) {
                         results.data(), paired), "writing the BAM");
     say(c, "align", bam + " (" + std::to_string(n_mapped) + " of " + std::to_string(n_items) + (paired ? " pairs" : " reads") + " mapped" +
                     (n_withheld ? ", " + std::to_string(n_withheld) + " invalid records withheld" : "") + ")");
+    return node_id;
+}
+
+int real_main(int argc, char** argv) {
+    signal(SIGINT, on_sigint);
+    Config c = parse(argc, argv);
+    if (c.s <= 0 || c.s > c.k) die("Invalid syncmer s=" + std::to_string(c.s) + " (must be in 1..k, k=" + std::to_string(c.k) + ")");
+    if (c.t < 0 || c.t > c.k - c.s) die("Invalid syncmer offset=" + std::to_string(c.t) + " (must be in 0..k-s = 0.." + std::to_string(c.k - c.s) + ")");
+    if (c.hpc) die("--hpc (homopolymer-compressed seeds) is not implemented in this build");
+    if (c.aligner != "minimap2") die("aligner '" + c.aligner + "' is not implemented in this build (minimap2 only)");
+    int stop = c.stop == "index" ? 0 : c.stop == "place" ? 1 : c.stop == "align" ? 2 : (c.stop == "genotype" || c.stop == "consensus") ? 3 : -1;
+    if (stop < 0) die("--stop expects index|place|align|genotype|consensus");
+    if (c.index.empty()) c.index = c.index_out.empty() ? c.panman + ".idx" : c.index_out;
+    else if (!exists(c.index)) die("index file not found: " + c.index + " (--index expects a pre-built index; use --index-out to build at a custom path)");
+    if (c.output.empty()) c.output = derive_prefix(c);
+    if (!c.batch.empty() && !c.reads1.empty()) die("--batch takes the read files from the batch file, not from the command line");
+
+    // ------------------------------------------------------------------------------------------------ index
+    pmx_panman* pm = nullptr;
+    pmx_index* idx = nullptr;
+    if (exists(c.index) && !c.force_reindex && cached_index_usable(c)) {
+        check(pmx_index_load(c.index.c_str(), &idx), "loading the index");
+        say(c, "index", c.index + " (cached)");
+    } else {
+        check(pmx_panman_open(c.panman.c_str(), &pm), "opening the PanMAN");
+        check(pmx_index_build(pm, c.k, c.s, c.t, c.l, c.open_syncmer ? 1 : 0, c.flank_mask, &idx), "building the index");
+        check(pmx_index_save(idx, c.index.c_str(), c.zstd_level, c.index_uncompressed ? 1 : 0), "writing the index");
+        say(c, "index", c.index + " (built)");
+    }
+    if (stop == 0 || (c.reads1.empty() && c.batch.empty())) return 0;
+
+    // ------------------------------------------------------------------------------------------------ samples
+    pmx_ctx* ctx = nullptr;
+    int dev = 0;
+    if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
+    check(pmx_ctx_create(dev, &ctx), "opening the GPU");
+    pmx_place* pl = nullptr;
+    check(pmx_place_create(ctx, idx, &pl), "uploading the index");
+    int rc = 0;
+    if (c.batch.empty()) run_sample(c, stop, pm, idx, ctx, pl, dev);
+    else {
+        // runBatchPlacement (src/main.cpp:1464-1666): the samples of the batch file one after the other against the index
+        // that stays on the device; one line per sample on stderr, a failed sample does not stop the batch
+        const std::vector<BatchEntry> samples = read_batch_file(c.batch);
+        if (samples.empty()) die("No samples found in batch file");
+        fprintf(stderr, "Batch mode: %zu samples\n", samples.size());
+        int ok = 0, failed = 0;
+        for (size_t i = 0; i < samples.size(); ++i) {
+            Config sc = c;
+            sc.reads1 = samples[i].reads1; sc.reads2 = samples[i].reads2; sc.output = samples[i].prefix; sc.quiet = true;
+            const size_t slash = sc.output.find_last_of('/');
+            if (slash != std::string::npos && slash > 0) mkdirs(sc.output.substr(0, slash));
+            const auto t0 = std::chrono::steady_clock::now();
+            std::string node, err;
+            try { node = run_sample(sc, stop, pm, idx, ctx, pl, dev); }
+            catch (const Fatal& f) { err = f.msg; }
+            const long long ms = (long long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (!err.empty()) {
+                fprintf(stderr, "[%zu/%zu] %s -> %s (%lldms)\n", i + 1, samples.size(), sc.output.c_str(), err == "No placement found" ? "NO PLACEMENT" : ("failed: " + err).c_str(), ms);
+                ++failed;
+            } else {
+                fprintf(stderr, "[%zu/%zu] %s -> %s (%lldms)\n", i + 1, samples.size(), sc.output.c_str(), node.c_str(), ms);
+                ++ok;
+            }
+        }
+        fprintf(stderr, "Batch complete: %d placed, %d failed\n", ok, failed);
+        rc = failed ? 1 : 0;
+    }
     if (stop > 2) fprintf(stderr, "panmap: note: stages after align (genotype, consensus) are not part of this build; stopped after align.\n");
-    pmx_aligner_free(ctx, al);
-    pmx_readset_free(ctx, rs);
     pmx_place_free(ctx, pl);
     pmx_ctx_destroy(ctx);
-    pmx_fastx_free(f1);
-    if (f2) pmx_fastx_free(f2);
     pmx_index_close(idx);
     if (pm) pmx_panman_close(pm);
-    return 0;
+    return rc;
+}
+
+int main(int argc, char** argv) {
+    try {
+        return real_main(argc, argv);
+    } catch (const Fatal& f) {
+        fprintf(stderr, "panmap: error: %s\n", f.msg.c_str());
+        return f.code;
+    }
 }

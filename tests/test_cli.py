@@ -49,7 +49,7 @@ def test_argument_errors(tmp_path):
     assert r.returncode == 1 and "Invalid syncmer offset=12 (must be in 0..k-s = 0..11)" in r.stderr
     r = run(["rsv.panman", "-i", "missing.idx"], tmp_path)
     assert r.returncode == 1 and "index file not found: missing.idx" in r.stderr
-    for opt in (["--meta"], ["--batch"], ["--hpc"], ["-a", "bwa"], ["--stop", "nowhere"], ["--no-such-option"]):
+    for opt in (["--meta"], ["--hpc"], ["-a", "bwa"], ["--stop", "nowhere"], ["--no-such-option"]):
         assert run(["rsv.panman"] + opt, tmp_path).returncode == 1
 
 
@@ -102,3 +102,30 @@ def test_readme_demo_through_the_cli(pmx, oracle, tmp_path):
     res = placer.score(params, len(raw))
     refined = pmx.refine_placement(ctx, placer, pm, res, rs, True, int(sum(len(x) for x in raw) // len(raw)), pmx.RefineParams(0.01, 4, 2, 3))
     assert pmx.format_refined_tsv(refined, index.node_id).splitlines() == lines[6:]
+
+
+@pytest.mark.gpu
+def test_batch_mode(pmx, tmp_path):
+    """--batch (runBatchPlacement, src/main.cpp:1464-1666; batch file format :1025-1087): the samples one after the other
+    against the resident index, one line per sample on stderr, outputs under each sample's prefix"""
+    for f in ("sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz"):
+        shutil.copy(os.path.join(GOLDEN, f), tmp_path / f)
+    (tmp_path / "batch.txt").write_text("# reads1 [reads2] [prefix]\n"
+                                        "isolate_R1.fastq.gz isolate_R2.fastq.gz out/paired\n"
+                                        "\n"
+                                        "isolate_R1.fastq.gz single_end\n"
+                                        "isolate_R2.fastq.gz\n")
+    r = run(["sars_20000_twilight_dipper.panman", "--batch", "batch.txt", "--stop", "place"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Batch mode: 3 samples" in r.stderr and "[1/3] out/paired -> node_7618 (" in r.stderr and "[2/3] single_end -> " in r.stderr
+    assert "[3/3] isolate_R2 -> " in r.stderr                  # default prefix: mate suffix tried on the stem "isolate_R2.fastq", then .fastq goes
+    assert open(tmp_path / "out" / "paired.placement.tsv", "rb").read() == open(os.path.join(GOLDEN, "isolate.placement.tsv"), "rb").read()
+    assert os.path.exists(tmp_path / "single_end.placement.tsv") and os.path.exists(tmp_path / "isolate_R2.placement.tsv")
+    # through align as well: the BAM of every sample next to its prefix
+    (tmp_path / "b2.txt").write_text("isolate_R1.fastq.gz isolate_R2.fastq.gz again\n")
+    r = run(["sars_20000_twilight_dipper.panman", "--batch", "b2.txt", "--stop", "align"], tmp_path)
+    assert r.returncode == 0 and os.path.exists(tmp_path / "again.bam") and os.path.exists(tmp_path / "again.bam.bai"), r.stderr[-1000:]
+    # a missing read file is an error of the batch file (src/main.cpp:1074-1081)
+    (tmp_path / "b3.txt").write_text("nope.fastq\n")
+    r = run(["sars_20000_twilight_dipper.panman", "--batch", "b3.txt", "--stop", "place"], tmp_path)
+    assert r.returncode == 1 and "Batch line 1: reads file not found: nope.fastq" in r.stderr
