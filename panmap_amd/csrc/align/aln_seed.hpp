@@ -363,7 +363,7 @@ __device__ void sketch_segment_wave(Work& W, const uint8_t* seq, int len, int w,
 #endif
 
 #if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
-// Wave-per-pair kernels, k odd and w <= 12: the 64 lanes sketch 64 consecutive slices of the segment on their own
+// Wave-per-pair kernels, k odd and w <= 20: the 64 lanes sketch 64 consecutive slices of the segment on their own
 // (sketch_slice above: w + k + 1 bases of run-in reproduce the sequential state, tests/test_align_host.py) -- ~36 steps
 // per lane for a 150-base read instead of 150 wave-uniform steps with the ring across the lanes.  A lane keeps its (few)
 // minimizers in registers; a wave prefix sum gives every lane its place in W.mv.
@@ -377,6 +377,7 @@ struct SliceKeep {   // a lane's own minimizers: a handful at most for a slice o
     }
 };
 struct SliceWrite { A128* mv; int at; uint64_t y_hi; __device__ void operator()(uint64_t x, uint64_t y) { A128 v; v.x = x; v.y = y_hi | y; mv[at++] = v; } };
+template <int WMAX>
 __device__ void sketch_segment_lanes(Work& W, const uint8_t* seq, int len, int w, int k, uint32_t rid) {
     PMX_LDS(&W); PMX_LDS(seq);
     A128* mvp = W.mv; PMX_LDS(mvp);
@@ -386,7 +387,7 @@ __device__ void sketch_segment_lanes(Work& W, const uint8_t* seq, int len, int w
     SliceBase base{seq};
     SliceKeep kp;
     kp.n = 0; kp.x0 = kp.y0 = kp.x1 = kp.y1 = kp.x2 = kp.y2 = kp.x3 = kp.y3 = 0;
-    if (begin < len) sketch_slice<12>(begin, end, len, w, k, base, kp);
+    if (begin < len) sketch_slice<WMAX>(begin, end, len, w, k, base, kp);
     int incl = kp.n;
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o);
@@ -400,15 +401,16 @@ __device__ void sketch_segment_lanes(Work& W, const uint8_t* seq, int len, int w
         if (kp.n > 1) wr(kp.x1, kp.y1);
         if (kp.n > 2) wr(kp.x2, kp.y2);
         if (kp.n > 3) wr(kp.x3, kp.y3);
-    } else if (begin < len && kp.n > 0) sketch_slice<12>(begin, end, len, w, k, base, wr);   // a repeat-rich slice: second pass
+    } else if (begin < len && kp.n > 0) sketch_slice<WMAX>(begin, end, len, w, k, base, wr);   // a repeat-rich slice: second pass
     W.n_mv += total;
 }
 #endif
 
 PMX_HDN void sketch_segment(Work& W, Ptr<const uint8_t> seq, int len, int w, int k, uint32_t rid) {
 #if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
-    if ((k & 1) && w >= 1 && w <= 12 && len >= 64 && !W.sk_no_lane_ring) {
-        sketch_segment_lanes(W, seq, len, w, k, rid);
+    if ((k & 1) && w >= 1 && w <= 20 && len >= 64 && !W.sk_no_lane_ring) {   // (sr: w = 11, map-ont: 10, map-hifi: 19)
+        if (w <= 12) sketch_segment_lanes<12>(W, seq, len, w, k, rid);
+        else sketch_segment_lanes<20>(W, seq, len, w, k, rid);
         wave_sync();
         return;
     }
