@@ -620,6 +620,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
         }
         last_st = st;
         last_en = en;
+        if (W.prof) ++W.dp_run_calls;   // diagnostic: anti-diagonals actually filled (the serve kernel reports them)
     }
     wave_sync();
     if (W.prof) W.prof_t = (unsigned long long)clock64();   // diagnostic: the serve kernel reports fill vs traceback

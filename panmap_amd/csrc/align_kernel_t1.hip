@@ -34,6 +34,7 @@ __global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
         bind_work(W, A.layout, fast, slow);
         W.prof = A.prof;
         W.prof_t = 0;
+        W.dp_run_calls = 0;
         const int qlen = rq->qlen, tlen = rq->tlen;
         const int t_off = (qlen + 15) & ~15;
         const size_t tb_need = dp_request_tb_bytes(qlen, tlen, rq->w);
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
             atomicAdd(&A.prof[12], W.prof_t ? tp2 - W.prof_t : 0ULL);   // traceback part of the DP (register kernel)
             atomicAdd(&A.prof[13], tp2 - tp1);
             atomicAdd(&A.prof[14], (unsigned long long)clock64() - tp2);
-            atomicAdd(&A.prof[15], (unsigned long long)(qlen + tlen - 1));
+            atomicAdd(&A.prof[15], (unsigned long long)(W.dp_run_calls ? W.dp_run_calls : qlen + tlen - 1));   // filled anti-diagonals (register kernel) / their bound
         }
     }
 }

@@ -586,7 +586,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         // align1 (thread-per-pair kernel): "align1(all regs)" then holds only what follows the right extension
         fprintf(stderr, " [align1: prologue+filters=%.0f left ext=%.0f gap fills=%.0f right ext=%.0f]", (double)h[20] / (double)n_items,
                 (double)h[21] / (double)n_items, (double)h[22] / (double)n_items, (double)h[23] / (double)n_items);
-        fprintf(stderr, " [dp serve: cycles traceback=%.0f ksw=%.0f store=%.0f per request, diagonals=%.1f]", (double)h[12] / std::max<double>(1, (double)al->last_dp_requests),
+        fprintf(stderr, " [dp serve: cycles traceback=%.0f ksw=%.0f store=%.0f, anti-diagonals filled=%.1f per pair that posted requests]", (double)h[12] / std::max<double>(1, (double)al->last_dp_requests),
                 (double)h[13] / std::max<double>(1, (double)al->last_dp_requests), (double)h[14] / std::max<double>(1, (double)al->last_dp_requests),
                 (double)h[15] / std::max<double>(1, (double)al->last_dp_requests));
         fprintf(stderr, " dp_requests=%lld dp_rounds=%d tpp_retry=%lld retry=%lld\n", (long long)al->last_dp_requests, al->last_dp_rounds,
