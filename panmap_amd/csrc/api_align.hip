@@ -727,6 +727,10 @@ void pmx_align_reads_direct(const char* reference, const char* refName, int n_re
         std::string concat;
         concat.reserve((size_t)total);
         for (int i = 0; i < n_reads; ++i) concat.append(reads[i], (size_t)r_lens[i]);
+        // seq_nt4_table (sketch.c:9-26) passes the bytes 0..3 through as pre-encoded bases; the packed read set knows letters
+        // only (those bytes would be ambiguous), so they become letters here
+        for (char& ch : concat)
+            if ((unsigned char)ch < 4) ch = "ACGT"[(unsigned char)ch];
         const int avg_len = (int)(total / n_reads);   // src/mm_align.c:124-130
         if (pmx_readset_upload(ctx, concat.data(), off.data(), n_reads, &rs) != PMX_OK) break;
         if (pmx_readset_pack(ctx, rs) != PMX_OK) break;

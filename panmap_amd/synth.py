@@ -10,7 +10,7 @@ the node the repository's example sample places on).  Nothing downstream depends
 """
 import numpy as np
 
-_COMP = np.zeros(256, np.uint8)
+_COMP = np.arange(256, dtype=np.uint8)   # anything but ACGT (N runs of a genome) complements to itself
 for _a, _b in zip(b"ACGT", b"TGCA"):
     _COMP[_a] = _b
 

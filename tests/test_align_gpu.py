@@ -151,6 +151,19 @@ def test_align_reads_direct_dropin(pmx, oracle, ctx):
     assert not ac.compare_results(pmx.align_reads_direct(g, odd, True), oracle.ref_align_reads_direct(g, odd, True))
 
 
+def test_direct_boundary_takes_pre_encoded_bases(pmx, oracle):
+    """seq_nt4_table (sketch.c:9-26) maps the bytes 0..3 to the bases themselves: reads that carry them (a caller's 2-bit
+    encoding) align at the drop-in boundary as they do in the reference"""
+    g = _ref_genome()
+    reads = _pairs(pmx, g, 400, 31)
+    tr = bytes.maketrans(b"ACGT", bytes([0, 1, 2, 3]))
+    mixed = [r.translate(tr) if i % 3 == 0 else (r[:40] + r[40:90].translate(tr) + r[90:]) if i % 3 == 1 else r for i, r in enumerate(reads)]
+    want = oracle.ref_align_reads_direct(g, mixed, True, 8)
+    assert oracle.ref_align_reads_direct(g, reads, True, 8) == want
+    got = pmx.align_reads_direct(g, mixed, True)
+    assert not ac.compare_results(got, want)
+
+
 def test_direct_boundary_is_reentrant(pmx, oracle):
     """the reference calls the aligner concurrently from TBB workers in --batch mode (src/main.cpp:1581-1611): two
     host threads inside pmx_align_reads_direct at the same time, on different read sets and references, must each
