@@ -9,6 +9,7 @@
 #include "aln_chain.hpp"
 #include "aln_hit.hpp"
 #include "aln_ksw.hpp"
+#include "aln_swll.hpp"
 #include "aln_types.hpp"
 
 namespace pmx {
@@ -120,8 +121,9 @@ PMX_HD bool try_shortcut_direct(Work& W, const Opt& o, int qlen, QF& qf, int tle
     return true;
 }
 
-// update_max_zdrop + mm_test_zdrop (align.c:32-89).  The inversion probe (ksw_ll_i16) is reported as
-// unsupported instead of evaluated; it only decides between return codes 1 and 2.
+// update_max_zdrop + mm_test_zdrop (align.c:32-89).  The inversion probe -- a local alignment of the reverse complement
+// of the query part of the largest score drop against its target part (ksw_ll_i16 -> sw_ll, align/aln_swll.hpp) -- decides
+// between return codes 1 and 2; the thread-per-pair kernel has no DP scratch for it and hands the pair to the wave tiers.
 PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int n_cigar, Ptr<const uint32_t> cigar) {
     PMX_LDS(&W); PMX_LDS(qseq); PMX_LDS(tseq); PMX_LDS(cigar);
     int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
@@ -156,7 +158,18 @@ PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const
     }
     const int q_len = pos[1][1] - pos[1][0], t_len = pos[0][1] - pos[0][0];
     if (max_zdrop > o.zdrop_inv && q_len < o.max_gap && t_len < o.max_gap) {
-        W.status |= PMX_ST_UNSUPPORTED;   // would need the ksw_ll_i16 inversion probe
+#if defined(PMX_THREAD_PER_PAIR)
+        W.status |= PMX_ST_NEED_WAVE;
+#else
+        const int q_end = pos[1][1], t_beg = pos[0][0];
+        auto qf = [&](int k) { const uint32_t c = q_r[q_end - k - 1]; return (int)(c >= 4 ? 4u : 3u - c); };
+        auto tf = [&](int k) { return (int)t_r[t_beg + k]; };
+        int q_off, t_off;
+        bool ok;
+        const int sc = sw_ll(W, o, q_len, qf, t_len, tf, &q_off, &t_off, &ok);
+        if (!ok) W.status |= PMX_ST_OVERFLOW;   // DP scratch of this layout too small: the next tier's is not
+        else if (sc >= o.min_chain_score * o.a && sc >= o.min_dp_max) return 2;   // there is a potential inversion
+#endif
     }
     return max_zdrop > o.zdrop ? 1 : 0;
 }
@@ -687,6 +700,70 @@ PMX_HDN void update_dp_max(Work& W, int qlen, int n_regs, Reg* regs, float frac,
     }
 }
 
+// mm_align1_inv (align.c:835-885): between the two parts of a region that was split at a suspected inversion, align the
+// reverse strand of the query gap to the target gap -- the end of a local alignment of the reversed sequences fixes the
+// start, an extension from there gives the alignment.  1 = r_inv holds an inversion hit.
+PMX_HDN int align1_inv(Work& W, const Opt& o, const RefIndex& ri, int qlen, const Ptr<uint8_t>* qseq0, const Reg& r1, const Reg& r2, Reg& r_inv, Ez& ez) {
+    PMX_LDS(&W); PMX_LDS(&r1); PMX_LDS(&r2); PMX_LDS(&r_inv);
+    reg_clear(r_inv);
+    if (!(r1.split & 1) || !(r2.split & 2)) return 0;
+    if (r1.id != r1.parent && r1.parent != PMX_PARENT_TMP_PRI) return 0;
+    if (r2.id != r2.parent && r2.parent != PMX_PARENT_TMP_PRI) return 0;
+    if (r1.rev != r2.rev) return 0;   // (one reference sequence: the rid test always passes)
+    const int ql = r1.rev ? r1.qs - r2.qe : r2.qs - r1.qe;
+    const int tl = r2.rs - r1.re;
+    if (ql < o.min_chain_score || ql > o.max_gap) return 0;
+    if (tl < o.min_chain_score || tl > o.max_gap) return 0;
+#if defined(PMX_THREAD_PER_PAIR)
+    W.status |= PMX_ST_NEED_WAVE;
+    return 0;
+#else
+    Ptr<uint8_t> tseq = W.tseq; PMX_LDS(tseq);
+    ref_getseq(ri, r1.re, r2.rs, tseq);
+    Ptr<uint8_t> qseq = r1.rev ? qseq0[0] + r2.qe : qseq0[1] + (qlen - r2.qs); PMX_LDS(qseq);
+    int q_off, t_off;
+    {
+        ByteReader q_r{Ptr<const uint8_t>(qseq)}, t_r{Ptr<const uint8_t>(tseq)};
+        auto qf = [&](int k) { return (int)q_r[ql - 1 - k]; };   // mm_seq_rev on both, undone afterwards
+        auto tf = [&](int k) { return (int)t_r[tl - 1 - k]; };
+        bool ok;
+        const int score = sw_ll(W, o, ql, qf, tl, tf, &q_off, &t_off, &ok);
+        if (!ok) { W.status |= PMX_ST_OVERFLOW; return 0; }
+        if (score < o.min_dp_max) return 0;
+    }
+    q_off = ql - (q_off + 1);
+    t_off = tl - (t_off + 1);
+    // The local alignment may end on the padding behind the reversed query (aln_swll.hpp); q_off is then negative (down
+    // to -7) and the reference's extension starts that many bases BEFORE the query gap, in the neighbouring region's
+    // bases: the same here, as long as that stays inside this strand's copy of the read (it does unless a region ends
+    // within 7 bases of the read's end, where the reference reads past its array)
+    if (t_off < 0 || (r1.rev ? r2.qe : qlen - r2.qs) + q_off < 0) { W.status |= PMX_ST_UNSUPPORTED; return 0; }
+    if (t_off > 0) ref_getseq(ri, r1.re + t_off, r2.rs, tseq);   // the DP reads its target from the start of W.tseq
+    Ptr<uint32_t> cig_tmp = W.cig_tmp; PMX_LDS(cig_tmp);
+    align_pair(W, o, ql - q_off, qseq + q_off, tl - t_off, tseq, (int)(o.bw * 1.5), -1, o.zdrop, PMX_EZ_EXTZ_ONLY, ez);
+    if (W.status & PMX_ST_ABORT) return 0;
+    if (ez.n_cigar == 0) return 0;
+    append_cigar(W, r_inv, ez.n_cigar, cig_tmp);
+    r_inv.dp_score = (int32_t)ez.max;
+    r_inv.id = -1;
+    r_inv.parent = PMX_PARENT_UNSET;
+    r_inv.inv = 1;
+    r_inv.rev = !r1.rev;
+    r_inv.div = -1.0f;
+    if (r_inv.rev == 0) {
+        r_inv.qs = r2.qe + q_off;
+        r_inv.qe = r_inv.qs + ez.max_q + 1;
+    } else {
+        r_inv.qe = r2.qs - q_off;
+        r_inv.qs = r_inv.qe - (ez.max_q + 1);
+    }
+    r_inv.rs = r1.re + t_off;
+    r_inv.re = r_inv.rs + ez.max_t + 1;
+    update_extra(W, o, r_inv, qseq + q_off, tseq, (int8_t)o.q, (int8_t)o.e);
+    return 1;
+#endif
+}
+
 // mm_align_skeleton (align.c:967-1027) for one segment; then the tail of align_regs (map.c:225-234)
 PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int* n_regs_, Reg* regs, Ptr<A128> a) {
     PMX_LDS(&W); PMX_LDS(n_regs_); PMX_LDS(regs); PMX_LDS(a);
@@ -712,7 +789,17 @@ PMX_HDN void align_regs(Work& W, const Opt& o, const RefIndex& ri, int seg, int*
                 ++n_regs;
             }
         }
-        if (i > 0 && regs[i].split_inv) W.status |= PMX_ST_UNSUPPORTED;   // mm_align1_inv (inversion rescue)
+        if (i > 0 && regs[i].split_inv && !(W.status & PMX_ST_ABORT)) {
+            if (align1_inv(W, o, ri, qlen, qseq0, regs[i - 1], regs[i], r2, ez)) {
+                if (n_regs + 1 > W.caps.max_reg) { W.status |= PMX_ST_OVERFLOW; }
+                else {
+                    for (int j = n_regs - 1; j > i; --j) regs[j + 1] = regs[j];
+                    regs[i + 1] = r2;
+                    ++n_regs;
+                    ++i;   // skip the inserted inversion hit
+                }
+            }
+        }
         if (W.status & PMX_ST_NEED_WAVE) return;   // thread-per-pair kernel: this pair is re-run by the wave kernel
         // (after a posted DP request the loop goes on: the other regions post theirs in the same pass, ksw_extd2_auto)
     }

@@ -197,6 +197,8 @@ PMX_HD A128 packed_anchor(const PackedCell& c) {
     return r;
 }
 
+PMX_HDN void chain_finish(Work& W, const int64_t n, const int min_cnt, const int min_sc, const int32_t max_drop);
+
 // mg_lchain_dp (lchain.c:148-230) followed by mg_chain_backtrack (:27-76) and compact_a (:78-111).
 // In: W.a[0..n_a) sorted anchors.  Out: W.a holds the chained anchors grouped by chain, W.u[0..n_u)
 // = score<<32 | count, chains ordered by the target position of their first anchor.
@@ -341,6 +343,15 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
     wave_sync();
 
     PMX_STAMP(W, 18);
+    chain_finish(W, n, min_cnt, min_sc, max_drop);
+}
+
+// mg_chain_backtrack (lchain.c:27-76) + compact_a (:78-111) on the filled cells W.cc[0..n): shared by the two fills
+// (chain_dp above, chain_rmq in aln_rmq.hpp)
+PMX_HDN void chain_finish(Work& W, const int64_t n, const int min_cnt, const int min_sc, const int32_t max_drop) {
+    PMX_LDS(&W);
+    Ptr<A128> a = W.a; PMX_LDS(a);
+    Ptr<ChainCell> c = W.cc; PMX_LDS(c);
     // ---- backtrack (lchain.c:27-76)
     Ptr<A128> z = W.z; PMX_LDS(z);
     int64_t n_z = 0;

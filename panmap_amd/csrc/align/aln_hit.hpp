@@ -328,11 +328,14 @@ PMX_HDN void select_sub_multi(Work& W, float pri_ratio, float pri1, float pri2, 
     });
 }
 
-// mm_filter_strand_retained (hit.c:287-299)
-PMX_HD int filter_strand_retained(int n_regs, Reg* r) {
+// mm_filter_strand_retained (hit.c:277-290).  The divergences come from the device's pow() (aln_map.hpp est_err): a
+// comparison within a few float steps of equality is flagged, not decided.
+PMX_HD int filter_strand_retained(int n_regs, Reg* r, uint32_t* status) {
     PMX_LDS(r);
     int k = 0;
+    auto close = [](float x, float y) { const float d = x > y ? x - y : y - x, m = (x < 0 ? -x : x) > (y < 0 ? -y : y) ? (x < 0 ? -x : x) : (y < 0 ? -y : y); return d <= 1e-6f * m; };
     for (int i = 0; i < n_regs; ++i) {
+        if (r[i].strand_retained && r[i].div > 0.0f && (close(r[i].div, r[r[i].parent].div * 5.0f) || close(r[i].div, 0.01f))) *status |= PMX_ST_UNSUPPORTED;
         const bool drop = r[i].strand_retained && !(r[i].div < r[r[i].parent].div * 5.0f || r[i].div < 0.01f);
         if (drop) continue;
         if (k != i) r[k] = r[i];
@@ -461,7 +464,7 @@ PMX_HDN void seg_gen(Work& W, uint32_t hash, const int* qlens, int n_regs0, cons
 }
 
 // --------------------------------------------------------------------------------------------- mapping quality
-// mm_set_mapq (hit.c:421-466) without inversion hits.  The float expressions are the reference's, operand for operand
+// mm_set_mapq (hit.c:421-466) + mm_set_inv_mapq (:395-419).  The float expressions are the reference's, operand for operand
 // (they are compiled without contraction); logf comes from tables the host filled with ITS logf (see RefIndex).
 PMX_HDN void set_mapq(const RefIndex& ri, int n_regs, Reg* regs, int min_chain_sc, int match_sc, int rep_len, int is_sr, uint32_t* status) {
     PMX_LDS(regs); PMX_LDS(status);
@@ -503,6 +506,33 @@ PMX_HDN void set_mapq(const RefIndex& ri, int n_regs, Reg* regs, int min_chain_s
         mapq = mapq > 0 ? mapq : 0;
         r.mapq = (uint8_t)(mapq < 60 ? mapq : 60);
         if (r.has_p && r.dp_max > r.dp_max2 && r.mapq == 0) r.mapq = 1;
+    }
+    // an inversion hit takes the lower mapq of its neighbours along the reference (among the primary / parentless hits)
+    if (n_regs < 3) return;
+    bool any_inv = false;
+    for (int i = 0; i < n_regs; ++i) any_inv = any_inv || regs[i].inv;
+    if (!any_inv) return;
+    for (int i = 0; i < n_regs; ++i) {
+        const Reg& g = regs[i];
+        if (!g.inv || !(g.parent == i || g.parent < 0)) continue;
+        // predecessor / successor of g in the order radix_sort_128x leaves (key rs; equal keys: the order of the reference's
+        // sorter is not restated -> flagged)
+        int before = -1, after = -1;
+        for (int j = 0; j < n_regs; ++j) {
+            const Reg& h = regs[j];
+            if (!(h.parent == j || h.parent < 0) || j == i) continue;
+            if (h.rs == g.rs) { *status |= PMX_ST_UNSUPPORTED; continue; }
+            if (h.rs < g.rs) {
+                if (before >= 0 && regs[before].rs == h.rs) *status |= PMX_ST_UNSUPPORTED;
+                if (before < 0 || regs[before].rs < h.rs) before = j;
+            } else {
+                if (after >= 0 && regs[after].rs == h.rs) *status |= PMX_ST_UNSUPPORTED;
+                if (after < 0 || regs[after].rs > h.rs) after = j;
+            }
+        }
+        if (before < 0 || after < 0) continue;   // first or last in the order: untouched (the loop runs over 1 .. n_aux - 2)
+        if (regs[before].inv || regs[after].inv) *status |= PMX_ST_UNSUPPORTED;   // chained inversion hits: update order matters
+        regs[i].mapq = regs[before].mapq < regs[after].mapq ? regs[before].mapq : regs[after].mapq;
     }
 }
 

@@ -28,7 +28,7 @@ inline Opt make_opt(int mean_read_len) {
     o.bw = 500; o.bw_long = 20000;
     o.max_gap = 5000; o.max_gap_ref = -1;
     o.max_chain_skip = 25; o.max_chain_iter = 5000;
-    o.rmq_rescue_size = 1000; o.rmq_rescue_ratio = 0.1f;
+    o.rmq_rescue_size = 1000; o.rmq_rescue_ratio = 0.1f; o.rmq_inner_dist = 1000; o.rmq_size_cap = 100000;
     o.chain_gap_scale = 0.8f; o.chain_skip_scale = 0.0f;
     o.max_max_occ = 4095; o.occ_dist = 500;
     o.mask_level = 0.5f; o.mask_len = INT32_MAX;

@@ -5,6 +5,7 @@
 #include "aln_align.hpp"
 #include "aln_chain.hpp"
 #include "aln_hit.hpp"
+#include "aln_rmq.hpp"
 #include "aln_seed.hpp"
 #include "aln_types.hpp"
 
@@ -144,6 +145,55 @@ PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonu
 #undef PMX_REGS
 }
 
+// mm_est_err (esterr.c:30-64): per region, the fraction of the read's minimizers between its first and last anchor that
+// are anchors of the region -> a per-base divergence estimate.  mini_pos[] of the reference (query span << 32 | query
+// position of every minimizer that was kept as a seed, map.c:157) is read from the seed arrays, which still hold exactly
+// those minimizers in query order.  pow(): the device's, not glibc's -- the one reader of the value
+// (filter_strand_retained) flags a comparison that a last-bit difference could turn.
+PMX_HDN void est_err(Work& W, int l_ref, int qlen, int n_regs, Reg* regs, Ptr<A128> a) {
+    PMX_LDS(&W); PMX_LDS(regs);
+    const int n = W.n_seeds;
+    if (n == 0) return;
+    Ptr<SeedA> sa = W.seeds; PMX_LDS(sa);
+    Ptr<SeedB> sb = W.seeds_b; PMX_LDS(sb);
+    uint64_t sum_k = 0;
+    for (int i = 0; i < n; ++i) sum_k += sb[i].q_span & 0xff;
+    const float avg_k = (float)sum_k / n;
+    auto for_qpos = [&](const A128 p) {   // get_for_qpos
+        int32_t x = (int32_t)p.y;
+        const int32_t q_span = (int32_t)(p.y >> 32 & 0xff);
+        if (p.x >> 63) x = qlen - 1 - (x + 1 - q_span);
+        return x;
+    };
+    for (int i = 0; i < n_regs; ++i) {
+        Reg& r = regs[i];
+        r.div = -1.0f;
+        if (r.cnt == 0) continue;
+        int32_t st = -1;
+        {   // get_mini_idx: binary search of the first anchor's query position
+            const int32_t x = for_qpos(r.rev ? a[r.as + r.cnt - 1] : a[r.as]);
+            int32_t L = 0, R = n - 1;
+            while (L <= R) {
+                const int32_t m = (int32_t)(((uint64_t)L + (uint64_t)R) >> 1);
+                const int32_t y = (int32_t)(sa[m].q_pos >> 1);
+                if (y < x) L = m + 1;
+                else if (y > x) R = m - 1;
+                else { st = m; break; }
+            }
+        }
+        if (st < 0) continue;
+        int32_t en = st, k = 1, n_match = 1;
+        for (int32_t j = st + 1; j < n && k < r.cnt; ++j) {
+            const int32_t x = for_qpos(r.rev ? a[r.as + r.cnt - 1 - k] : a[r.as + k]);
+            if (x == (int32_t)(sa[j].q_pos >> 1)) { ++k; en = j; ++n_match; }
+        }
+        int32_t n_tot = en - st + 1;
+        if (r.qs > avg_k && r.rs > avg_k) ++n_tot;
+        if (qlen - r.qs > avg_k && l_ref - r.re > avg_k) ++n_tot;
+        r.div = n_match >= n_tot ? 0.0f : (float)(1.0 - pow((double)n_match / n_tot, 1.0 / avg_k));
+    }
+}
+
 // mm_map_frag (map.c:236-390) for n_segs in {1,2}.  Regions end up in W.regs[s] / W.n_regs[s].
 PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     PMX_LDS(&W);
@@ -178,9 +228,17 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     chain_dp(W, o, max_chain_gap_ref, max_chain_gap_qry, n_segs);
     PMX_STAMP(W, 3);
 
-    if (o.bw_long > o.bw && n_segs == 1 && W.n_u > 1) {   // long-join re-chaining (map.c:296-305): RMQ chaining not restated yet
+    if (o.bw_long > o.bw && n_segs == 1 && W.n_u > 1) {   // long-join re-chaining of long reads (map.c:296-305)
         const int32_t st = (int32_t)a_[0].y, en = (int32_t)a_[(int32_t)u_[0] - 1].y;
-        if (qlen_sum - (en - st) > o.rmq_rescue_size || en - st > qlen_sum * o.rmq_rescue_ratio) W.status |= PMX_ST_UNSUPPORTED;
+        if (qlen_sum - (en - st) > o.rmq_rescue_size || en - st > qlen_sum * o.rmq_rescue_ratio) {
+#if defined(PMX_ALL_LDS)
+            W.status |= PMX_ST_OVERFLOW;   // no room for the trees in this layout (and bw_long == bw for its reads): general tier
+#else
+            radix_sort_128x(a_, a_ + W.n_a, &W.status);   // W.n_a: the anchors that are in chains
+            chain_rmq(W, o.max_gap, o.rmq_inner_dist, o.bw_long, o.max_chain_skip, o.rmq_size_cap, o.min_cnt, o.min_chain_score, o.chn_pen_gap,
+                      o.chn_pen_skip);
+#endif
+        }
     } else if (o.max_occ > o.mid_occ && W.rep_len > 0) {   // re-chain with a higher occurrence cap (map.c:306-330)
         int rechain = 0;
         if (W.n_u > 0) {
@@ -206,11 +264,20 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     set_parent(W, o.mask_level, o.mask_len, W.n_regs0, regs0_, o.a * 2 + o.b);
     if (n_segs <= 1) select_sub(W, o.pri_ratio, o.k * 2, o.best_n, 1, (int)(o.max_gap * 0.8), &W.n_regs0, regs0_);
     else select_sub_multi(W, o.pri_ratio, 0.2f, 0.7f, max_chain_gap_ref, o.k * 2, o.best_n, n_segs, W.qlen, &W.n_regs0, regs0_);
-    // mm_est_err only feeds Reg::div, read by mm_filter_strand_retained for strand_retained hits
-    // (single-segment mode only): not evaluated, flagged when it would matter
-    if (n_segs == 1)
-        for (int i = 0; i < W.n_regs0; ++i)
-            if (regs0_[i].strand_retained) W.status |= PMX_ST_UNSUPPORTED;
+    // mm_est_err + mm_filter_strand_retained (map.c:334-335; single-segment mode only).  The divergence estimate only
+    // decides which strand_retained hits stay, so it is evaluated when there is one
+    if (n_segs == 1) {
+        bool any = false;
+        for (int i = 0; i < W.n_regs0; ++i) any = any || regs0_[i].strand_retained;
+        if (any) {
+#if defined(PMX_ALL_LDS)
+            W.status |= PMX_ST_OVERFLOW;   // this layout's seed arrays are overlaid by now: the general tier takes the read
+#else
+            est_err(W, ri.len, qlen_sum, W.n_regs0, regs0_, a_);
+            W.n_regs0 = filter_strand_retained(W.n_regs0, regs0_, &W.status);
+#endif
+        }
+    }
 
     if (n_segs == 1) {
         Reg* rs0 = W.regs[0]; PMX_LDS(rs0);

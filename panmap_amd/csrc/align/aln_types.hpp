@@ -237,7 +237,7 @@ struct Opt {
     int mid_occ, max_occ, max_max_occ, occ_dist;
     float q_occ_frac;
     int64_t max_sw_mat;
-    int rmq_rescue_size;
+    int rmq_rescue_size, rmq_inner_dist, rmq_size_cap;
     float rmq_rescue_ratio;
     int8_t mat[25];
     int ref_len;
