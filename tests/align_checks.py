@@ -93,6 +93,46 @@ def hostsim_ref_sketch(reference: bytes, w: int, k: int, slice_len: int = 0):
     return x[:n].copy(), y[:n].copy()
 
 
+def rearranged_long_reads(pmx, genome: bytes, n: int, read_len: int, seed: int, sub=0.03, ins=0.01, dele=0.01):
+    """long reads that make the long-read branches of mm_map_frag / mm_align1 run: a large deletion, a novel insertion,
+    an inversion, a tandem duplication or two deletions in every read (several chains -> the RMQ re-chaining pass,
+    map.c:296-305; z-drops across the breakpoints -> the inversion probe and mm_align1_inv, align.c:74-86, 835-885;
+    opposite-strand secondaries -> mm_est_err / mm_filter_strand_retained), on top of substitutions and short indels"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        st = int(rng.integers(0, len(genome) - read_len))
+        frag = bytearray(genome[st:st + read_len])
+        kind = int(rng.integers(5))
+        p = int(rng.integers(read_len // 5, 4 * read_len // 5))
+        m = int(rng.integers(100, min(3000, read_len // 2)))
+        if kind == 0:
+            del frag[p:p + m]
+        elif kind == 1:
+            frag[p:p] = bytes(rng.choice(list(b"ACGT"), m).astype(np.uint8))
+        elif kind == 2:
+            frag[p:p + m] = pmx.reverse_complement(bytes(frag[p:p + m]))
+        elif kind == 3:
+            frag[p:p] = frag[max(0, p - m):p]
+        else:
+            del frag[p:p + m]
+            q = int(rng.integers(0, max(1, len(frag) - 200)))
+            del frag[q:q + int(rng.integers(50, 800))]
+        u = rng.random(len(frag))
+        v = rng.random(len(frag))
+        nb = rng.integers(0, 4, (2, len(frag)))
+        r = bytearray()
+        for i, b in enumerate(frag):
+            if u[i] < dele:
+                continue
+            if u[i] < dele + ins:
+                r.append(b"ACGT"[nb[0, i]])
+            r.append(b"ACGT"[nb[1, i]] if v[i] < sub else b)
+        r = bytes(r)
+        out.append(pmx.reverse_complement(r) if rng.random() < 0.5 else r)
+    return out
+
+
 def golden_cases(pmx):
     """(genome, {name: (reads, expected results)}) of tests/golden/align_golden.json.gz; the inputs are regenerated
     exactly as tests/golden/make_align_golden.py made them"""

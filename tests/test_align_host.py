@@ -67,6 +67,18 @@ def test_thread_per_pair_dp_service_replay(pmx, oracle, cases, name):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("read_len,sub,seed", [(6000, 0.03, 21), (2500, 0.05, 22), (9000, 0.05, 23)])
+def test_rearranged_long_reads_equal_reference(pmx, oracle, read_len, sub, seed):
+    """the long-read branches (RMQ re-chaining on the restated AVL tree, inversion probe + inversion hits, divergence
+    filter) on the host build of the pipeline against the compiled reference"""
+    g = _ref_genome()
+    reads = ac.rearranged_long_reads(pmx, g, 40, read_len, seed, sub=sub)
+    want = oracle.ref_align_reads_direct(g, reads, False, 8)
+    got = ac.hostsim_align(g, reads, False)
+    assert not ac.compare_results(got, want)
+    assert sum(1 for x in got if x["flags"] & 3) == 0
+
+
 @pytest.mark.parametrize("tpp", [False, True])
 def test_golden_fixture(pmx, tpp):
     """committed outputs of the reference aligner (tests/golden/align_golden.json.gz): no oracle/_ref needed"""

@@ -59,6 +59,19 @@ def test_long_reads_live_reference_and_small_traceback_tier(pmx, oracle, ctx, mo
     assert al.stats()["general_tier_items"] > 0
 
 
+@pytest.mark.parametrize("read_len,sub,seed", [(6000, 0.03, 11), (9000, 0.05, 12), (2500, 0.05, 13), (14000, 0.02, 14), (1500, 0.03, 15)])
+def test_rearranged_long_reads_equal_reference(pmx, oracle, ctx, read_len, sub, seed):
+    """reads with a deletion / insertion / inversion / duplication each: the RMQ re-chaining pass, the inversion probe and
+    inversion hits, the divergence filter (both long-read presets) -- exact, and nothing flagged"""
+    g = mg.genome()
+    reads = ac.rearranged_long_reads(pmx, g, 150, read_len, seed, sub=sub)
+    want = oracle.ref_align_reads_direct(g, reads, False, 8)
+    al = pmx.Aligner(ctx, g, int(np.mean([len(r) for r in reads])))
+    got = al.align_reads(reads, paired=False)
+    assert not ac.compare_results(got, want)
+    assert sum(1 for x in got if x["flags"] & 3) == 0
+
+
 def test_config4_full_size_properties(pmx, ctx):
     """BASELINE config 4 at full size (100k x 10 kb): every read maps, CIGARs are consistent with the reported intervals,
     alignments cover the read and agree with where the read was drawn from"""
