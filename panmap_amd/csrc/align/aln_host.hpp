@@ -246,7 +246,7 @@ struct Layout {
     size_t tb_cap = 0;
     struct Ent { uint32_t space; size_t off; };
     Ent qseq, mv, sk_buf, seeds, seeds_b, mini_pos, heap, a, a2, cc, kidx, z, u, u2, regs0, regs1, regs2, reg_tmp, seg_a0, seg_a1, seg_u0,
-        seg_u1, aux64, aux32, aux128, du, sf, qr, H, off_, tseq, cig_tmp, cig_pool, tb, tb_fast;
+        seg_u1, aux64, aux32, aux128, du, sf, qr, H, off_, tseq, cig_tmp, cig_pool, tb, tb_fast, dp_fast;
     size_t tb_fast_cap = 0;   // DP-service layout only: LDS traceback area for small DPs
 };
 
@@ -255,9 +255,14 @@ struct Layout {
 // with the full capacity: long reads, whose band allows matrices up to max_sw_mat cells, align.c:326-328, 590-592)
 // anchor_scale > 1: the last-resort layout for reads whose minimizers hit a repeat of the reference hundreds of times each (a
 // poly-A mate against a genome that ends in a poly-A tail): anchors, chains and regions by that factor
-inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fast_budget, size_t tb_limit = 0, int anchor_scale = 1) {
+// dp_fast_tlen > 0 (long reads: the DP arrays, sized for the longest allowed target, do not fit LDS): a second, small set
+// of them in LDS for the DPs of at most that size -- nearly all of them (a gap fill between two anchors is a few hundred
+// bases)
+inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fast_budget, size_t tb_limit = 0, int anchor_scale = 1, int dp_fast_tlen = 0) {
     Layout L;
     Caps& c = L.caps;
+    c.dp_fast_tlen = dp_fast_tlen;
+    L.dp_fast.space = PMX_FAST; L.dp_fast.off = 0;
     c.max_qlen = (max_read_len + 15) / 16 * 16 + 16;
     const int qsum = c.max_qlen * n_segs;
     // a low-complexity read emits a minimizer at nearly every k-mer position (equal hashes in a window are all kept,
@@ -287,6 +292,8 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
         e.off = used[sp];
         used[sp] += bytes;
     };
+    if (dp_fast_tlen > 0) place(L.dp_fast, (size_t)9 * (dp_fast_tlen + 32) + 64, PMX_FAST);
+    if (L.dp_fast.space != PMX_FAST) c.dp_fast_tlen = 0;
     // hot small arrays first so they win the LDS budget
     place(L.du, (size_t)7 * (c.max_tlen + 32), PMX_FAST);       // u,v,x,y,x2,y2,s
     place(L.sf, (size_t)c.max_tlen + 32, PMX_FAST);
@@ -334,6 +341,8 @@ inline Layout plan_layout(int max_read_len, int n_segs, const Opt& o, size_t fas
 inline Layout plan_layout_compact(int max_read_len, int n_segs, const Opt& o) {
     Layout L;
     Caps& c = L.caps;
+    c.dp_fast_tlen = 0;
+    L.dp_fast.space = PMX_FAST; L.dp_fast.off = 0;
     c.max_qlen = (max_read_len + 15) / 16 * 16 + 16;
     // sized for EIGHT waves per CU (20.2 KB of LDS per wave): the pairs that come here are few and the tier is bound by the
     // latency of a pair, so resident waves are what counts (96 / 128 / 8 regions / 20 CIGAR slots = 24.3 KB = six waves:
@@ -408,6 +417,8 @@ inline Layout plan_layout_compact(int max_read_len, int n_segs, const Opt& o) {
 inline Layout plan_layout_dp(int max_read_len, int n_segs, const Opt& o, int small_qlen = 0, int small_tlen = 0) {
     Layout L = plan_layout_compact(max_read_len, n_segs, o);
     Caps& c = L.caps;
+    c.dp_fast_tlen = 0;
+    L.dp_fast.space = PMX_FAST; L.dp_fast.off = 0;
     if (small_qlen > 0) {
         c.max_qlen = small_qlen;
         c.max_tlen = small_tlen + 16;
@@ -539,6 +550,7 @@ PMX_HD void bind_work(Work& W, const Layout& L, uint8_t* fast, uint8_t* slow, ui
     W.H = PMX_AT(int32_t, H);
     W.off = PMX_AT(int32_t, off_); W.off_end = W.off + (L.caps.max_qlen + L.caps.max_tlen);
     W.tb = PMX_AT(uint8_t, tb); W.tb_cap = L.tb_cap;
+    W.dp_fast = L.caps.dp_fast_tlen > 0 ? (int8_t*)(base[L.dp_fast.space] + L.dp_fast.off) : nullptr;
     W.tseq = PMX_AT(uint8_t, tseq);
     W.cig_tmp = PMX_AT(uint32_t, cig_tmp); W.cig_pool = PMX_AT(uint32_t, cig_pool);
 #undef PMX_AT

@@ -128,6 +128,15 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
     const bool tb_lds = PMX_TB_IS_LDS(p);   // uniform
     (void)tb_lds;
     const int T16 = tlen_ * 16;
+#if !defined(PMX_INTERLEAVED)
+    if (W.dp_fast && T16 <= W.caps.dp_fast_tlen && qlen <= W.caps.dp_fast_tlen) {   // small DP of a long read: the LDS copy of the arrays
+        const int TF = W.caps.dp_fast_tlen + 32;
+        int8_t* d = W.dp_fast;
+        u = d; v = d + TF; x = d + 2 * TF; y = d + 3 * TF; x2 = d + 4 * TF; y2 = d + 5 * TF; s = d + 6 * TF;
+        sf = (uint8_t*)(d + 7 * TF);
+        qr = (uint8_t*)(d + 8 * TF);   // TF + 64 bytes
+    }
+#endif
     // initial fill (ksw2_extd2_sse.c:107-126): every lane takes a stride
     for (int t = lane; t < T16; t += PMX_W) {
         u[t] = v[t] = x[t] = y[t] = (int8_t)(-q - e);

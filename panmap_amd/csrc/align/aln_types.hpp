@@ -372,6 +372,7 @@ struct Caps {
     int max_cigar;     // CIGAR ops per region
     int max_tlen;      // DP target length
     int n_cig_slots;   // CIGAR buffers in the pool
+    int dp_fast_tlen;  // wave-per-read kernels, long reads: DPs up to this size run on the small LDS copy of the DP arrays (0 = none)
 };
 
 // Per-wave work memory: plain pointers into the LDS arena ("fast") or the global scratch slab ("slow");
@@ -423,6 +424,7 @@ struct Work {
     Ptr<int32_t> H;
     Ptr<int32_t> off, off_end;
     Ptr<uint8_t> tb;       // traceback matrix (global)
+    int8_t* dp_fast;       // u,v,x,y,x2,y2,s,sf,qr for DPs of at most caps.dp_fast_tlen (LDS; NULL = none)
     size_t tb_cap;
     Ptr<uint8_t> tseq;
     Ptr<uint32_t> cig_tmp;   // ez->cigar

@@ -61,6 +61,7 @@ struct pmx_aligner {
     int64_t last_dp_slots = 0, last_compact = 0;
     int64_t n_records = 0;
     uint64_t cigar_cap = 0;
+    double cigar_words_per_kbase = 0.0;   // CIGAR words per 1,000 read bases the last calls needed (sizes the next arena)
     unsigned long long last_cigar_used = 0;   // read back at the end of pmx_align_readset
     double last_occupancy = 0;
 };
@@ -558,7 +559,15 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         // back on the retry list and run in a second launch of few waves with the full capacity.
         size_t tb_small = (size_t)8 << 20;
         if (const char* e = getenv("PMX_ALIGN_TB_KB")) tb_small = std::max<size_t>((size_t)atoll(e), 1) << 10;
-        const Layout g1 = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget, tb_small));
+        // The arrays of a 10 kb read (anchors, chain cells, the DP arrays sized for the longest allowed target) live in the
+        // wave's HBM slab whatever the LDS budget, and the kernel is bound by the latency of those accesses: what counts is
+        // resident waves (16 per CU: 32.4 k reads/s, 8 per CU: 21.1 k) and that the DPs -- nearly all a few hundred bases
+        // wide -- run on a small LDS copy of their arrays (plan_layout dp_fast_tlen)
+        int dp_fast = 576;
+        if (const char* e = getenv("PMX_ALIGN_DP_FAST")) dp_fast = atoi(e);
+        size_t lr_budget = 8900;
+        if (const char* e = getenv("PMX_ALIGN_LDS_KB")) lr_budget = (size_t)atoi(e) * 1024;
+        const Layout g1 = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lr_budget, tb_small, 1, dp_fast));
         al->retry_list.ensure((size_t)n_items);
         timer_begin(ctx, "align_dom");
         launch(kern, g1, n_items, nullptr, general.tb_cap > g1.tb_cap ? al->retry_list.p : nullptr, al->slow2);
@@ -604,6 +613,10 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     if (!ctx || !al || !rs) return PMX_ERR_ARG;
     if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack first)");
     uint64_t cap = (uint64_t)std::max<int64_t>(rs->n * 16, 4096);
+    // long reads: an operation every ~20 bases at 5 % errors; and whatever the previous call on this aligner needed per base
+    // (a redo costs the whole stage again: 4.5 s per 100k reads of 10 kb)
+    if (!al->opt.is_sr_like) cap = std::max<uint64_t>(cap, (uint64_t)rs->total / 8 + (uint64_t)rs->n * 16);
+    if (al->cigar_words_per_kbase > 0.0) cap = std::max<uint64_t>(cap, (uint64_t)(al->cigar_words_per_kbase * 1.25 * (double)rs->total / 1000.0) + 4096);
     if (const char* e = getenv("PMX_ALIGN_CIGAR_CAP")) cap = (uint64_t)std::max<long long>(atoll(e), 16);   // tests: force the redo
     for (int attempt = 0;; ++attempt) {
         const int rc = align_readset_once(ctx, al, rs, paired, revcomp_mate2, cap);
@@ -622,6 +635,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
         al->last_stats.wave_tier_items = al->last_tpp_retry;
         al->last_stats.general_tier_items = al->last_retry;
         al->last_stats.compact_tier_items = al->last_compact;
+        if (rs->total > 0) al->cigar_words_per_kbase = std::max(al->cigar_words_per_kbase * 0.5, (double)used * 1000.0 / (double)rs->total);
         if (used <= cap) return PMX_OK;
         if (attempt >= 2) return fail(PMX_ERR_CAPACITY, "CIGAR arena overflow persists after resizing");
         cap = used + 64;
