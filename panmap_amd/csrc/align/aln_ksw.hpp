@@ -87,9 +87,12 @@ PMX_HD int64_t wave_max_i64(int64_t v) { return v; }
 #endif
 
 // ksw_extd2_sse.  query/target hold nt4 codes; with_cigar always on.  Results in ez and W.cig_tmp.
-template <class QP, class TP>
-PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const int8_t* mat, int8_t q, int8_t e,
-                      int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+// FAST (wave-per-read kernels, long reads): the arrays are the small LDS copy (Work::dp_fast) and the compiler is told
+// so -- through generic pointers every access is a flat instruction, and at ~1.2 M of them per 10 kb read the kernel was
+// bound by the rate the texture-address unit takes them (16 clocks each), not by their latency.
+template <bool FAST, class QP, class TP>
+PMX_HDN void ksw_extd2_t(Work& W, int qlen, QP query, int tlen, TP target, const int8_t* mat, int8_t q, int8_t e,
+                        int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
     const int lane = lane_id();
     const int approx_max = !!(flag & PMX_EZ_APPROX_MAX);
@@ -129,12 +132,15 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
     (void)tb_lds;
     const int T16 = tlen_ * 16;
 #if !defined(PMX_INTERLEAVED)
-    if (W.dp_fast && T16 <= W.caps.dp_fast_tlen && qlen <= W.caps.dp_fast_tlen) {   // small DP of a long read: the LDS copy of the arrays
+    if (FAST) {   // small DP of a long read: the LDS copy of the arrays
         const int TF = W.caps.dp_fast_tlen + 32;
         int8_t* d = W.dp_fast;
+        PMX_LDS_HERE(d);
         u = d; v = d + TF; x = d + 2 * TF; y = d + 3 * TF; x2 = d + 4 * TF; y2 = d + 5 * TF; s = d + 6 * TF;
         sf = (uint8_t*)(d + 7 * TF);
         qr = (uint8_t*)(d + 8 * TF);   // TF + 64 bytes
+        PMX_LDS_HERE(u); PMX_LDS_HERE(v); PMX_LDS_HERE(x); PMX_LDS_HERE(y); PMX_LDS_HERE(x2); PMX_LDS_HERE(y2); PMX_LDS_HERE(s);
+        PMX_LDS_HERE(sf); PMX_LDS_HERE(qr);
     }
 #endif
     // initial fill (ksw2_extd2_sse.c:107-126): every lane takes a stride
@@ -337,6 +343,18 @@ PMX_HDN void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const i
     wave_sync();
 }
 
+
+template <class QP, class TP>
+PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const int8_t* mat, int8_t q, int8_t e,
+                      int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+#if !defined(PMX_INTERLEAVED) && !defined(PMX_ALL_LDS)
+    if (W.dp_fast && (tlen + 15) / 16 * 16 <= W.caps.dp_fast_tlen && qlen <= W.caps.dp_fast_tlen) {
+        ksw_extd2_t<true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+        return;
+    }
+#endif
+    ksw_extd2_t<false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+}
 
 #if PMX_W == 64
 // ------------------------------------------------------------------------------------------------------

@@ -214,7 +214,9 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
     if (!W.mv_ready) collect_minimizers(W, o);
     PMX_STAMP(W, 1);
     if (o.q_occ_frac > 0.0f) seed_mz_flt(W, o.mid_occ, o.q_occ_frac);   // map.c:251
-    collect_seed_hits_heap(W, o, ri, qlen_sum, o.mid_occ);
+    // MM_F_HEAP_SORT is set for the short-read branch only (src/mm_align.c:140-166)
+    if (o.is_sr_like) collect_seed_hits_heap(W, o, ri, qlen_sum, o.mid_occ);
+    else collect_seed_hits_sorted(W, o, ri, qlen_sum, o.mid_occ);
     PMX_STAMP(W, 2);
 
     const int max_chain_gap_qry = o.max_gap;   // not MM_F_SR
@@ -252,7 +254,8 @@ PMX_HDN void map_frag(Work& W, const Opt& o, const RefIndex& ri) {
             if (n_chained_segs < n_segs) rechain = 1;
         } else rechain = 1;
         if (rechain) {
-            collect_seed_hits_heap(W, o, ri, qlen_sum, o.max_occ);
+            if (o.is_sr_like) collect_seed_hits_heap(W, o, ri, qlen_sum, o.max_occ);
+            else collect_seed_hits_sorted(W, o, ri, qlen_sum, o.max_occ);
             chain_dp(W, o, max_chain_gap_ref, max_chain_gap_qry, n_segs);
         }
     }

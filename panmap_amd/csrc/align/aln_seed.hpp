@@ -872,5 +872,141 @@ PMX_HDN void collect_seed_hits_heap(Work& W, const Opt& o, const RefIndex& ri, i
     //  n_for + n_rev == n_a; map.c:161-164 is a no-op)
 }
 
+// collect_seed_hits (map.c:168-204): the path of the reads that do not carry MM_F_HEAP_SORT -- the long-read presets
+// (src/mm_align.c:167-180 leaves the flag clear).  Every occurrence becomes an anchor, seed by seed, and the list is sorted
+// by x with radix_sort_128x, an UNSTABLE sort: anchors of equal x (one reference position hit by two minimizers of the
+// read that have the same value) end up in an order that only the reference's procedure defines.
+//   * host / scalar models: fill + the restated radix_sort_128x (aln_sort.hpp): the reference, step for step;
+//   * wave kernels: the fill runs one seed per lane, the sort is a stable LSD radix sort across the wave (8-bit digits of
+//     the reference position, then the strand bit; per-chunk ranks from ballots, bucket counters in the idle LDS DP area);
+//     without equal keys every sort gives the same list, so the list is checked for adjacent equal x afterwards and only
+//     then re-made by the exact sequential procedure.
+PMX_HD A128 seed_anchor(const SeedA q, const SeedB qb, uint64_t r, int qlen) {
+    const int32_t rpos = (int32_t)((uint32_t)r >> 1);
+    A128 p;
+    if ((r & 1) == (q.q_pos & 1)) {   // forward strand
+        p.x = (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+        p.y = (uint64_t)qb.q_span << 32 | q.q_pos >> 1;
+    } else {                          // reverse strand: query position mirrored
+        p.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | (uint32_t)rpos;
+        p.y = (uint64_t)qb.q_span << 32 | (uint32_t)(qlen - ((int)(q.q_pos >> 1) + 1 - (int)qb.q_span) - 1);
+    }
+    p.y |= (uint64_t)qb.seg_id << PMX_SEED_SEG_SHIFT;
+    if (qb.is_tandem) p.y |= PMX_SEED_TANDEM;
+    return p;
+}
+
+PMX_HDN void collect_seed_hits_sorted(Work& W, const Opt& o, const RefIndex& ri, int qlen, int max_occ) {
+    collect_matches(W, o, ri, qlen, max_occ);
+    PMX_STAMP(W, 16);
+    if (W.n_a > W.caps.max_anchor) {
+        W.status |= PMX_ST_OVERFLOW;
+        W.n_a = 0;
+        return;
+    }
+    PMX_LDS(&W);
+    const int n_m = W.n_seeds;
+    const int64_t n_a = W.n_a;
+    Ptr<A128> a = W.a; PMX_LDS(a);
+    Ptr<SeedA> seeds = W.seeds; PMX_LDS(seeds);
+    Ptr<SeedB> seeds_b = W.seeds_b; PMX_LDS(seeds_b);
+#if PMX_W > 1 && !defined(PMX_ALL_LDS)
+    const int lane = lane_id();
+    bool exact_path = W.dp_fast == nullptr || n_a >= (1 << 24) || ri.len >= (1 << 30);
+    if (!exact_path) {
+        // anchor offsets: exclusive prefix sum of the occurrence counts (64 seeds per step)
+        uint32_t acc = 0;
+        for (int i0 = 0; i0 < n_m; i0 += PMX_W) {
+            const int i = i0 + lane;
+            const uint32_t n = i < n_m ? seeds[i].n : 0u;
+            uint32_t incl = n;
+            for (int d = 1; d < PMX_W; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+            if (i < n_m) seeds[i].flt = acc + incl - n;   // flt is free now
+            acc += __shfl(incl, PMX_W - 1);
+        }
+        wave_sync();
+        for (int i = lane; i < n_m; i += PMX_W) {
+            const SeedA q = seeds[i];
+            const SeedB qb = seeds_b[i];
+            for (uint32_t j = 0; j < q.n; ++j) a[q.flt + j] = seed_anchor(q, qb, ri.pos[q.off + j], qlen);
+        }
+        wave_sync();
+        // stable LSD radix sort on key = strand << 31 | reference position
+        uint32_t* cnt = reinterpret_cast<uint32_t*>(W.dp_fast);   // 256 counters
+        Ptr<A128> src = a, dst = W.a2;
+        int pos_bits = 1;
+        while ((1 << pos_bits) < ri.len) ++pos_bits;
+        const int n_pass = (pos_bits + 7) / 8 + 1;   // the last pass sorts by the strand bit
+        for (int pass = 0; pass < n_pass; ++pass) {
+            const bool strand_pass = pass == n_pass - 1;
+            const int shift = pass * 8;
+            for (int b = lane; b < 256; b += PMX_W) cnt[b] = 0;
+            wave_sync();
+            for (int64_t i = lane; i < n_a; i += PMX_W) {
+                const uint64_t x = src[i].x;
+                const uint32_t dgt = strand_pass ? (uint32_t)(x >> 63) : ((uint32_t)x >> shift) & 255u;
+                atomicAdd(&cnt[dgt], 1u);
+            }
+            wave_sync();
+            {   // exclusive scan of the 256 counters: four per lane
+                uint32_t c0 = cnt[lane * 4], c1 = cnt[lane * 4 + 1], c2 = cnt[lane * 4 + 2], c3 = cnt[lane * 4 + 3];
+                const uint32_t tot = c0 + c1 + c2 + c3;
+                uint32_t incl = tot;
+                for (int d = 1; d < PMX_W; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+                uint32_t base = incl - tot;
+                wave_sync();
+                cnt[lane * 4] = base; base += c0;
+                cnt[lane * 4 + 1] = base; base += c1;
+                cnt[lane * 4 + 2] = base; base += c2;
+                cnt[lane * 4 + 3] = base;
+            }
+            wave_sync();
+            for (int64_t i0 = 0; i0 < n_a; i0 += PMX_W) {
+                const int64_t i = i0 + lane;
+                const bool act = i < n_a;
+                A128 v;
+                v.x = v.y = 0;
+                if (act) v = src[i];
+                const uint32_t dgt = !act ? 256u : strand_pass ? (uint32_t)(v.x >> 63) : ((uint32_t)v.x >> shift) & 255u;
+                unsigned long long same = __ballot(act);   // lanes with my digit
+                for (int b = 0; b < 8; ++b) {
+                    const unsigned long long m = __ballot((dgt >> b) & 1u);
+                    same &= ((dgt >> b) & 1u) ? m : ~m;
+                }
+                const unsigned long long below = same & ((1ULL << lane) - 1ULL);
+                uint32_t at = 0;
+                if (act) at = cnt[dgt] + (uint32_t)__builtin_popcountll(below);
+                wave_sync();
+                if (act) {
+                    dst[at] = v;
+                    if ((same >> lane) >> 1 == 0ULL) cnt[dgt] += (uint32_t)__builtin_popcountll(same);   // the group's last lane
+                }
+                wave_sync();
+            }
+            const Ptr<A128> t = src; src = dst; dst = t;
+        }
+        if (src != a) {
+            for (int64_t i = lane; i < n_a; i += PMX_W) a[i] = src[i];
+            wave_sync();
+        }
+        bool tie = false;
+        for (int64_t i = lane; i + 1 < n_a; i += PMX_W) tie = tie || a[i].x == a[i + 1].x;
+        exact_path = __ballot(tie) != 0ULL;
+        wave_sync();
+    }
+    if (!exact_path) return;
+#endif
+    {   // the reference's procedure
+        int64_t k = 0;
+        for (int i = 0; i < n_m; ++i) {
+            const SeedA q = seeds[i];
+            const SeedB qb = seeds_b[i];
+            for (uint32_t j = 0; j < q.n; ++j) a[k++] = seed_anchor(q, qb, ri.pos[q.off + j], qlen);
+        }
+        wave_sync();
+        radix_sort_128x(a, a + n_a, &W.status);
+    }
+}
+
 }  // namespace aln
 }  // namespace pmx

@@ -36,6 +36,12 @@ PMX_HD void wave_sync() {}
 // Tier-1 translation unit (PMX_ALL_LDS): every work array except the traceback matrix is in LDS, and the
 // compiler is told so pointer by pointer -- otherwise generic pointers compile to flat_load/flat_store,
 // whose latency dominated the kernel (measured: ~9k flat ops per pair, 56% of wave cycles waiting).
+// the same statement about ONE pointer in any device translation unit
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PMX_LDS_HERE(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#else
+#define PMX_LDS_HERE(p) ((void)0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(PMX_ALL_LDS)
 #define PMX_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
 #else
