@@ -1,6 +1,7 @@
 // C ABI, host-only part: PanMAN access, node genomes, seed-index build (see include/panmap_amd.h).
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 
 #include "api_internal.hpp"
@@ -18,6 +19,10 @@ void set_error(const std::string& s) { g_last_error = s; }
 
 struct pmx_panman {
     pmx::Panman pm;
+    // the state after the root's mutations, made at the first genome request (pmx_panman_node_genome is on the critical
+    // path of a sample: the GPU waits for the placed genome between the place and the align stage)
+    mutable std::mutex root_mu;
+    mutable std::shared_ptr<const pmx::PanmanState> root;
 };
 
 struct pmx_index {
@@ -60,7 +65,13 @@ int64_t pmx_panman_find_node(const pmx_panman* pm, const char* id) {
 int64_t pmx_panman_node_genome(const pmx_panman* pm, int64_t i, char* buf, int64_t cap) {
     if (!pm || i < 0 || i >= (int64_t)pm->pm.nodes.size()) return -1;
     try {
-        std::string g = pmx::node_genome(pm->pm, (int32_t)i);
+        std::shared_ptr<const pmx::PanmanState> root;
+        {
+            std::lock_guard<std::mutex> lk(pm->root_mu);
+            if (!pm->root) pm->root = std::make_shared<const pmx::PanmanState>(pmx::root_state_of(pm->pm));
+            root = pm->root;
+        }
+        std::string g = pmx::node_genome(pm->pm, (int32_t)i, root.get());
         if (buf && cap >= (int64_t)g.size()) std::memcpy(buf, g.data(), g.size());
         return (int64_t)g.size();
     } catch (const std::exception& e) {
@@ -87,7 +98,11 @@ int64_t pmx_panman_test_invert_block(pmx_panman* pm, int64_t i, int min_bases) {
                 bases += st.cols[c] != '-' && st.cols[c] != 'x';
             if (bases >= min_bases && bases > best_len) { best_len = bases; best = b; }
         }
-        if (best >= 0) pm->pm.nodes[i].block_muts.push_back(pmx::BlockMut{best, false, true});
+        if (best >= 0) {
+            pm->pm.nodes[i].block_muts.push_back(pmx::BlockMut{best, false, true});
+            std::lock_guard<std::mutex> lk(pm->root_mu);
+            pm->root.reset();   // (the root itself may be the node that changed)
+        }
         return best;
     } catch (const std::exception& e) {
         pmx::set_error(e.what());

@@ -365,13 +365,22 @@ std::string genome_of_state(const Panman& pm, const PanmanState& st) {
     return g;
 }
 
-std::string node_genome(const Panman& pm, int32_t ni) {
+PanmanState root_state_of(const Panman& pm) {
+    PanmanState st;
+    st.init(pm);
+    if (!pm.nodes.empty()) apply_node(pm, 0, st, nullptr, nullptr);
+    return st;
+}
+
+std::string node_genome(const Panman& pm, int32_t ni, const PanmanState* root_state) {
     std::vector<int32_t> path;
     for (int32_t x = ni; x >= 0; x = pm.nodes[x].parent) path.push_back(x);
     std::reverse(path.begin(), path.end());
     PanmanState st;
-    st.init(pm);
-    for (int32_t x : path) apply_node(pm, x, st, nullptr, nullptr);
+    size_t first = 0;
+    if (root_state && !path.empty() && path[0] == 0) { st = *root_state; first = 1; }
+    else st.init(pm);
+    for (size_t k = first; k < path.size(); ++k) apply_node(pm, path[k], st, nullptr, nullptr);
     return genome_of_state(pm, st);
 }
 

@@ -93,7 +93,9 @@ void undo_node(PanmanState& st, const UndoLog& undo);
 
 // Ungapped genome of the current state (src/panmap_utils.cpp:134-180, aligned=false).
 std::string genome_of_state(const Panman& pm, const PanmanState& st);
-// Genome of node `ni` (walks root -> node).
-std::string node_genome(const Panman& pm, int32_t ni);
+// Genome of node `ni` (walks root -> node).  root_state: NULL, or the state after the root's own mutations (the same for
+// every node of a tree, and most of the work: the root turns the consensus into a genome) -- the walk then starts there.
+std::string node_genome(const Panman& pm, int32_t ni, const PanmanState* root_state = nullptr);
+PanmanState root_state_of(const Panman& pm);
 
 }  // namespace pmx
