@@ -199,6 +199,115 @@ PMX_HD A128 packed_anchor(const PackedCell& c) {
 
 PMX_HDN void chain_finish(Work& W, const int64_t n, const int min_cnt, const int min_sc, const int32_t max_drop);
 
+#if PMX_W > 1
+// Fill phase of mg_lchain_dp for more than 64 anchors in the wave kernels (long reads: ~1,000 anchors, every earlier one in
+// range): the predecessors of anchor i are taken 64 at a time, nearest first -- lane l evaluates comput_sc for anchor
+// hi - l from its packed cell -- and the order-dependent part of the reference loop (strict-max update, the t[] marks with
+// the n_skip early exit, lchain.c:176-190) is replayed over the lanes' values with scalar reads, as chain_fill_wave does
+// for short lists.  A mark t[p[j]] = i that lands inside the chunk being replayed is a bit of a register mask, any other
+// goes to the cell's t field in memory (read back by the chunk that holds it).  The sequential form above pays ~60
+// instructions per visited predecessor (~26 of them per anchor before the skip limit ends the scan), this one ~10.
+__device__ void chain_fill_wide_wave(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int n_seg) {
+    const int64_t n = W.n_a;
+    const int lane = lane_id();
+    const int bw = o.bw, max_skip = o.max_chain_skip, max_iter = o.max_chain_iter;
+    const float chn_pen_gap = o.chn_pen_gap, chn_pen_skip = o.chn_pen_skip;
+    PMX_LDS(&W);
+    Ptr<A128> a = W.a; PMX_LDS(a);
+    Ptr<ChainCell> c = W.cc; PMX_LDS(c);
+    Ptr<Cell4> pk4 = ptr_region_cast<Cell4>(W.z); PMX_LDS(pk4);
+    int64_t st = 0, max_ii = -1;
+    uint64_t x_st = a[0].x, x_mi = 0;
+    int32_t f_mi = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t max_j = -1;
+        const A128 ai = a[i];
+        PackedCell ci;
+        ci.x_lo = (uint32_t)ai.x;
+        ci.y_lo = (uint16_t)(uint32_t)ai.y;
+        ci.span = (uint8_t)(ai.y >> 32 & 0xff);
+        ci.seg = (uint8_t)((ai.y & PMX_SEED_SEG_MASK) >> PMX_SEED_SEG_SHIFT);
+        ci.f = 0; ci.p1 = 0; ci.t = 0;
+        const A128 ri = packed_anchor(ci);
+        int32_t max_f = (int32_t)ci.span, n_skip = 0;
+        while (st < i && (ai.x >> 32 != x_st >> 32 || ai.x > x_st + (uint64_t)max_dist_x)) {
+            ++st;
+            x_st = st < i ? a[st].x : ai.x;
+        }
+        if (i - st > max_iter) { st = i - max_iter; x_st = a[st].x; }
+        int64_t end_j = st - 1;
+        bool stop = false;
+        for (int64_t hi = i - 1; hi >= st && !stop; hi -= PMX_W) {
+            const int64_t j = hi - lane;
+            const bool act = j >= st;
+            int32_t val = INT32_MIN, pj = -1;
+            bool valid = false, marked = false;
+            if (act) {
+                const CellWords q = packed_cell_words(pk4, j >> 2, (int)(j & 3));
+                const int32_t sc0 = chain_score_sel(ci.x_lo, (int32_t)ci.y_lo, (int32_t)ci.seg, q.w0, (int32_t)(q.w1 & 0xffffu), (int32_t)(q.w1 >> 24),
+                                                    (int32_t)(q.w1 >> 16 & 0xffu), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+                valid = sc0 != INT32_MIN;
+                val = valid ? sc0 + (int32_t)q.w2 : INT32_MIN;
+                pj = (int32_t)(q.w3 & 0xffffu) - 1;
+                marked = (q.w3 >> 16) == ((uint32_t)i & 0xffffu);
+            }
+            unsigned long long todo = __ballot(valid);
+            unsigned long long mark = __ballot(marked);
+            while (todo) {
+                const int l = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int32_t s_ = rl32(val, l);
+                if (s_ > max_f) {
+                    max_f = s_;
+                    max_j = hi - l;
+                    if (n_skip > 0) --n_skip;
+                } else if (mark >> l & 1ULL) {
+                    if (++n_skip > max_skip) { stop = true; end_j = hi - l; break; }
+                }
+                const int32_t pp = rl32(pj, l);
+                if (pp >= 0) {
+                    const int64_t dl = hi - (int64_t)pp;   // lane that holds anchor pp in this chunk
+                    if (dl < PMX_W) mark |= 1ULL << dl;
+                    else packed_cell(pk4, (int64_t)pp).t = (uint16_t)i;
+                }
+            }
+        }
+        // (unsigned, as lchain.c:197 compares: across a strand or target change the difference is huge and max_ii starts over)
+        if (max_ii < 0 || (ai.x - x_mi) > (uint64_t)(int64_t)max_dist_x) {
+            int64_t key = INT64_MIN;   // max f over [st, i-1]; equal values keep the largest j
+            for (int64_t j = i - 1 - lane; j >= st; j -= PMX_W) {
+                const int64_t k = (int64_t)packed_cell(pk4, j).f << 32 | (uint32_t)j;
+                key = k > key ? k : key;
+            }
+            for (int ofs = 32; ofs > 0; ofs >>= 1) {
+                const int64_t other = __shfl_xor(key, ofs);
+                key = other > key ? other : key;
+            }
+            max_ii = key == INT64_MIN ? -1 : (int64_t)(uint32_t)key;
+            if (max_ii >= 0) { x_mi = a[max_ii].x; f_mi = (int32_t)(key >> 32); }
+        }
+        if (max_ii >= 0 && max_ii < end_j) {
+            const PackedCell cm = packed_cell(pk4, max_ii);
+            const int32_t tmp = chain_score(ri, packed_anchor(cm), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
+            if (tmp != INT32_MIN && max_f < tmp + cm.f) { max_f = tmp + cm.f; max_j = max_ii; }
+        }
+        {
+            const int32_t vm = max_j >= 0 ? c[max_j].v : 0;
+            ChainCell co;
+            co.f = max_f;
+            co.p = (int32_t)max_j;
+            co.t = 0;
+            co.v = max_j >= 0 && vm > max_f ? vm : max_f;
+            c[i] = co;
+            ci.f = max_f;
+            ci.p1 = (uint16_t)(max_j + 1);
+            packed_cell(pk4, i) = ci;
+        }
+        if (max_ii < 0 || ((ai.x - x_mi) <= (uint64_t)(int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = ai.x; f_mi = max_f; }
+    }
+}
+#endif
+
 // mg_lchain_dp (lchain.c:148-230) followed by mg_chain_backtrack (:27-76) and compact_a (:78-111).
 // In: W.a[0..n_a) sorted anchors.  Out: W.a holds the chained anchors grouped by chain, W.u[0..n_u)
 // = score<<32 | count, chains ordered by the target position of their first anchor.
@@ -232,6 +341,12 @@ PMX_HDN void chain_dp(Work& W, const Opt& o, int max_dist_x, int max_dist_y, int
             return;
         }
     }
+#if PMX_W > 1
+    if (packed_fill) {
+        chain_fill_wide_wave(W, o, max_dist_x, max_dist_y, n_seg);
+        packed_fill = false;
+    }
+#endif
     if (packed_fill) {
         Ptr<Cell4> pk4 = ptr_region_cast<Cell4>(W.z); PMX_LDS(pk4);   // z[] is idle until the backtrack
         int64_t st = 0, max_ii = -1;

@@ -465,6 +465,24 @@ PMX_HDN void seed_mz_flt(Work& W, int32_t q_occ_max, float q_occ_frac) {
     Ptr<A128> mv = W.mv; PMX_LDS(mv);
     Ptr<A128> a = W.a2; PMX_LDS(a);
     wave_sync();
+#if PMX_W > 1 && !defined(PMX_ALL_LDS)
+    if (W.dp_fast && (size_t)9 * (W.caps.dp_fast_tlen + 32) >= 4096) {
+        // no minimizer value can occur more than q_occ_max times if no bucket of a 1,024-bucket count of the values holds
+        // more than that (the usual case: nothing to filter, and the sort below -- a sequential procedure -- is skipped)
+        uint32_t* cnt = reinterpret_cast<uint32_t*>(W.dp_fast);
+        const int lane = lane_id();
+        for (int b = lane; b < 1024; b += PMX_W) cnt[b] = 0;
+        wave_sync();
+        uint32_t mx = 0;
+        for (int i = lane; i < n; i += PMX_W) {
+            const uint32_t c = atomicAdd(&cnt[(uint32_t)mix64(mv[i].x >> 8) & 1023u], 1u) + 1u;
+            mx = c > mx ? c : mx;
+        }
+        const bool over = (int32_t)mx > q_occ_max;
+        wave_sync();
+        if (__ballot(over) == 0ULL) return;
+    }
+#endif
     for (int i = lane_id(); i < n; i += PMX_W) { A128 t; t.x = mv[i].x; t.y = (uint64_t)i; a[i] = t; }
     wave_sync();
     radix_sort_128x(a, a + n, &W.status);
@@ -692,13 +710,60 @@ PMX_HDN void collect_matches(Work& W, const Opt& o, const RefIndex& ri, int qlen
         }
     }
 #else
-    for (int i = lane_id(); i < W.n_mv; i += PMX_W) {
-        uint32_t off = 0;
-        const uint32_t t = index_lookup(ri, mv[i].x >> 8, &off);
-        hp[i].x = off;
-        hp[i].y = t;
+    const int lane = lane_id();
+    {
+        // 64 minimizers per step: probe, tandem flags from the neighbours, and the seed records of the minimizers the index
+        // knows written through a prefix sum.  When no seed is above the occurrence cap (the usual case) that is all of
+        // mm_collect_matches: mm_seed_select / the flt pass mark nothing and the compaction is the identity.
+        const int n_mv = W.n_mv;
+        bool high = false;
+        int64_t sum_n = 0;
+        int n_out = 0;
+        for (int i0 = 0; i0 < n_mv; i0 += PMX_W) {
+            const int i = i0 + lane;
+            uint32_t off = 0, t = 0;
+            A128 p;
+            p.x = p.y = 0;
+            bool tandem = false;
+            if (i < n_mv) {
+                p = mv[i];
+                const uint64_t key = p.x >> 8;
+                t = index_lookup(ri, key, &off);
+                hp[i].x = off;
+                hp[i].y = t;
+                if (i > 0 && key == mv[i - 1].x >> 8) tandem = true;
+                if (i < n_mv - 1 && key == mv[i + 1].x >> 8) tandem = true;
+            }
+            const unsigned long long keep = __ballot(t != 0);
+            const int at = n_out + (int)__builtin_popcountll(keep & ((1ULL << lane) - 1ULL));
+            if (t != 0) {
+                SeedA q;
+                SeedB qb;
+                q.q_pos = (uint32_t)p.y;
+                q.off = off;
+                q.n = t;
+                q.flt = 0;
+                qb.q_span = (uint32_t)(p.x & 0xff);
+                qb.seg_id = (uint32_t)(p.y >> 32);
+                qb.is_tandem = tandem ? 1u : 0u;
+                qb.pad = 0;
+                seeds[at] = q;
+                seeds_b[at] = qb;
+            }
+            n_out += (int)__builtin_popcountll(keep);
+            high = high || (int)t > max_occ;
+            sum_n += (int64_t)t;
+        }
+        wave_sync();
+        if (__ballot(high) == 0ULL) {
+            for (int d = PMX_W / 2; d > 0; d >>= 1) sum_n += __shfl_xor(sum_n, d);
+            W.n_mini_pos = n_out;
+            W.n_seeds = n_out;
+            W.n_a = sum_n;
+            W.rep_len = 0;
+            return;
+        }
     }
-    wave_sync();
     for (int i = 0; i < W.n_mv; ++i) {
         const A128 p = mv[i];
         const uint32_t off = (uint32_t)hp[i].x;
