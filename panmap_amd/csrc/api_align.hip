@@ -61,6 +61,7 @@ struct pmx_aligner {
     int64_t last_dp_slots = 0, last_compact = 0;
     int64_t n_records = 0;
     uint64_t cigar_cap = 0;
+    size_t dev_total_mem = 0;            // hipMemGetInfo total, asked once
     double cigar_words_per_kbase = 0.0;   // CIGAR words per 1,000 read bases the last calls needed (sizes the next arena)
     unsigned long long last_cigar_used = 0;   // read back at the end of pmx_align_readset
     double last_occupancy = 0;
@@ -293,6 +294,21 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         if (max_grid > 0 && grid > max_grid) grid = max_grid;
         A.layout = L;
         A.slow_stride = (L.slow_bytes + 255) & ~(size_t)255;
+        {
+            // every workgroup owns a slab (long reads: ~20 MB each, 8 MB of it traceback): the grid is what a third of the
+            // device memory -- at most 96 GB -- pays for (10 kb reads: 4,096 waves = 82 GB, the resident set of the chip);
+            // the kernel strides over the items with whatever grid it gets
+            if (al->dev_total_mem == 0) {
+                size_t free_b = 0, total_b = 0;
+                PMX_HIP(hipMemGetInfo(&free_b, &total_b));
+                al->dev_total_mem = total_b;
+            }
+            const size_t total_b = al->dev_total_mem;
+            size_t budget = std::max<size_t>(std::min<size_t>((size_t)96 << 30, total_b / 3), slab.n * sizeof(uint8_t));
+            if (const char* e = getenv("PMX_ALIGN_SLAB_MB")) budget = (size_t)std::max<long long>(atoll(e), 1) << 20;   // tests: force a small grid
+            const int64_t fit = (int64_t)(budget / std::max<size_t>(A.slow_stride, 1));
+            if (grid > fit) grid = std::max<int64_t>(fit, 1);
+        }
         slab.ensure(A.slow_stride * (size_t)grid);
         A.slow_base = slab.p;
         A.n_items = n_work;

@@ -72,6 +72,20 @@ def test_rearranged_long_reads_equal_reference(pmx, oracle, ctx, read_len, sub, 
     assert sum(1 for x in got if x["flags"] & 3) == 0
 
 
+def test_slab_budget_caps_the_grid_not_the_results(pmx, ctx, monkeypatch):
+    """every resident wave of the wave-per-read tier owns a ~20 MB slab; the launch takes the grid its memory budget pays for
+    (16,000 reads of 10 kb used to ask for 318 GB).  With the budget forced down to 100 MB -- a handful of waves -- the
+    records are the same"""
+    g = mg.genome()
+    reads = pmx.simulate_long_reads(g, 120, read_len=6000, seed=77)
+    al = pmx.Aligner(ctx, g, 6000)
+    want = al.align_reads(reads, paired=False)
+    monkeypatch.setenv("PMX_ALIGN_SLAB_MB", "100")
+    al2 = pmx.Aligner(ctx, g, 6000)
+    got = al2.align_reads(reads, paired=False)
+    assert not ac.compare_results(got, want) and all(x["flags"] & 3 == 0 for x in got)
+
+
 def test_config4_full_size_properties(pmx, ctx):
     """BASELINE config 4 at full size (100k x 10 kb): every read maps, CIGARs are consistent with the reported intervals,
     alignments cover the read and agree with where the read was drawn from"""
