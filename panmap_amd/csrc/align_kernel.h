@@ -39,6 +39,7 @@ struct AlignArgs {
     const uint32_t* pair_perm;
     A128* mv_handover;
     uint32_t mv_stride, mv_slots, mv_epoch;   // epoch: stamps the entries of this call (a slot may hold one of an earlier call)
+    unsigned long long* work_queue;   // wave-per-item kernels: NULL = strided loop, else the counter the waves draw items from (zeroed by the host)
     int dp_class;               // k_align_dp_serve: 0 = every request, 1 = only small ones, 2 = only the others
     int dp_small_qlen, dp_small_tlen;   // register-DP class: qlen <=, tlen <=, traceback bytes <= dp_small_tb
     uint32_t dp_small_tb;

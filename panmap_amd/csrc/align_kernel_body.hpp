@@ -21,7 +21,17 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
     const int lane = (int)(threadIdx.x & 63u);
     const int n_segs = A.paired ? 2 : 1;
 
-    for (int64_t it = blockIdx.x; it < A.n_items; it += gridDim.x) {
+    // work distribution: a strided loop, or (work_queue != NULL: long reads, whose ~25 items per wave differ by tens of
+    // milliseconds) the next item from a device counter, so that a wave that drew quick reads takes more of them
+    int64_t it = (int64_t)blockIdx.x - (int64_t)gridDim.x;
+    for (;;) {
+        if (A.work_queue) {
+            unsigned long long nx = 0;
+            if (lane == 0) nx = atomicAdd(A.work_queue, 1ULL);
+            it = (int64_t)((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)nx) |
+                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nx >> 32)) << 32);
+        } else it += gridDim.x;
+        if (it >= A.n_items) break;
         int64_t item = A.worklist ? (int64_t)A.worklist[it] : it;
         int64_t ho_slot = -1;
         if (A.dp_slot_pairs) {   // worklist holds DP-service slots

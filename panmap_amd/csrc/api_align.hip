@@ -251,6 +251,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
 
     AlignArgs A;
     A.tpp.base = nullptr; A.tpp.wave_stride = 0; A.tpp.pad = 0;
+    A.work_queue = nullptr;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
     A.paired = paired ? 1 : 0;
     A.revcomp_mate2 = revcomp_mate2 ? 1 : 0;
@@ -586,7 +587,12 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         const Layout g1 = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lr_budget, tb_small, 1, dp_fast));
         al->retry_list.ensure((size_t)n_items);
         timer_begin(ctx, "align_dom");
+        if (!getenv("PMX_ALIGN_NO_WORK_QUEUE")) {
+            PMX_HIP(hipMemsetAsync(al->retry_count.p + 3, 0, sizeof(unsigned long long), ctx->stream));
+            A.work_queue = al->retry_count.p + 3;
+        }
         launch(kern, g1, n_items, nullptr, general.tb_cap > g1.tb_cap ? al->retry_list.p : nullptr, al->slow2);
+        A.work_queue = nullptr;
         timer_end(ctx, "align_dom", 1);
         int64_t n_retry = 0, unused = 0;
         read_counts(n_retry, unused, true);
