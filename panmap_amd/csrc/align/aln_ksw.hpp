@@ -90,7 +90,9 @@ PMX_HD int64_t wave_max_i64(int64_t v) { return v; }
 // FAST (wave-per-read kernels, long reads): the arrays are the small LDS copy (Work::dp_fast) and the compiler is told
 // so -- through generic pointers every access is a flat instruction, and at ~1.2 M of them per 10 kb read the kernel was
 // bound by the rate the texture-address unit takes them (16 clocks each), not by their latency.
-template <bool FAST, class QP, class TP>
+// RIGHT = (flag & PMX_EZ_RIGHT) as a compile-time constant: with the gap-alignment rule chosen by a (uniform) run-time test
+// the compiler issues BOTH variants of the two 10-instruction blocks under execution masks, a quarter of the inner loop.
+template <bool FAST, bool RIGHT, class QP, class TP>
 PMX_HDN void ksw_extd2_t(Work& W, int qlen, QP query, int tlen, TP target, const int8_t* mat, int8_t q, int8_t e,
                         int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
@@ -219,7 +221,7 @@ PMX_HDN void ksw_extd2_t(Work& W, int qlen, QP query, int tlen, TP target, const
             wave_sync();   // all loads of the old diagonal done before any store
             if (act) {
                 uint8_t d;
-                if (!(flag & PMX_EZ_RIGHT)) {   // gap left-alignment (:228-268)
+                if (!RIGHT) {   // gap left-alignment (:228-268)
                     d = a > z ? 1 : 0;
                     z = z > a ? z : a;
                     d = b > z ? 2 : d;
@@ -248,7 +250,7 @@ PMX_HDN void ksw_extd2_t(Work& W, int qlen, QP query, int tlen, TP target, const
                 tmp = (int8_t)(z - q2);
                 a2 = (int8_t)(a2 - tmp);
                 b2 = (int8_t)(b2 - tmp);
-                if (!(flag & PMX_EZ_RIGHT)) {
+                if (!RIGHT) {
                     x[t] = (int8_t)((a > 0 ? a : 0) - qe);
                     d |= a > 0 ? 0x08 : 0;
                     y[t] = (int8_t)((b > 0 ? b : 0) - qe);
@@ -349,11 +351,13 @@ PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const in
                       int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
 #if !defined(PMX_INTERLEAVED) && !defined(PMX_ALL_LDS)
     if (W.dp_fast && (tlen + 15) / 16 * 16 <= W.caps.dp_fast_tlen && qlen <= W.caps.dp_fast_tlen) {
-        ksw_extd2_t<true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+        if (flag & PMX_EZ_RIGHT) ksw_extd2_t<true, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+        else ksw_extd2_t<true, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
         return;
     }
 #endif
-    ksw_extd2_t<false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+    if (flag & PMX_EZ_RIGHT) ksw_extd2_t<false, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+    else ksw_extd2_t<false, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
 }
 
 #if PMX_W == 64
@@ -395,9 +399,9 @@ __device__ __forceinline__ int rd_col(const int (&a)[NC], int idx) {   // a[] in
     return idx < 64 ? rl_i32(a[0], idx) : idx < 128 ? rl_i32(a[NC > 1 ? 1 : 0], idx - 64) : rl_i32(a[NC - 1], idx - 128);
 }
 
-template <int NC, bool TB_IN_LDS>
-__device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
-                              int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+template <int NC, bool TB_IN_LDS, bool RIGHT>
+__device__ void ksw_extd2_reg_t(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q, int8_t e,
+                                int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     static_assert(NC >= 1 && NC <= 3, "one to three target columns per lane");
     PMX_LDS(&W); PMX_LDS(query); PMX_LDS(target);
     const int lane = lane_id();
@@ -523,7 +527,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
                 int8_t a2 = (int8_t)(x2t1 + vt1);
                 int8_t b2 = (int8_t)((int8_t)y2[c] + ut);
                 uint8_t d;
-                if (!(flag & PMX_EZ_RIGHT)) {
+                if (!RIGHT) {
                     d = a > z ? 1 : 0;
                     z = z > a ? z : a;
                     d = b > z ? 2 : d;
@@ -552,7 +556,7 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
                 tmp = (int8_t)(z - q2);
                 a2 = (int8_t)(a2 - tmp);
                 b2 = (int8_t)(b2 - tmp);
-                if (!(flag & PMX_EZ_RIGHT)) {
+                if (!RIGHT) {
                     x[c] = (int8_t)((a > 0 ? a : 0) - qe);
                     d |= a > 0 ? 0x08 : 0;
                     y[c] = (int8_t)((b > 0 ? b : 0) - qe);
@@ -661,6 +665,13 @@ __device__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen,
         ksw_backtrack(W, rev_cigar, p, off, off_end, n_col, ez.max_t, ez.max_q, &ez.n_cigar);
     }
     wave_sync();
+}
+
+template <int NC, bool TB_IN_LDS>
+__device__ __forceinline__ void ksw_extd2_reg(Work& W, int qlen, const uint8_t* query, int tlen, const uint8_t* target, const int8_t* mat, int8_t q,
+                                              int8_t e, int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+    if (flag & PMX_EZ_RIGHT) ksw_extd2_reg_t<NC, TB_IN_LDS, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+    else ksw_extd2_reg_t<NC, TB_IN_LDS, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
 }
 #elif defined(__HIPCC__)
 // (device-only; declared so the host pass of the kernels parses)
