@@ -130,12 +130,12 @@ PMX_HDN void ksw_extd2_t(Work& W, int qlen, QP query, int tlen, TP target, const
     PMX_LDS(u); PMX_LDS(v); PMX_LDS(x); PMX_LDS(y); PMX_LDS(x2); PMX_LDS(y2); PMX_LDS(s);
     PMX_LDS(sf); PMX_LDS(qr); PMX_LDS(H); PMX_LDS(off); PMX_LDS(off_end);
     Ptr<uint8_t> p = W.tb;
-    const bool tb_lds = PMX_TB_IS_LDS(p);   // uniform
+    const bool tb_lds = FAST ? false : PMX_TB_IS_LDS(p);   // uniform (FAST: the traceback of a long read's DP is in its HBM slab)
     (void)tb_lds;
     const int T16 = tlen_ * 16;
 #if !defined(PMX_INTERLEAVED)
     if (FAST) {   // small DP of a long read: the LDS copy of the arrays
-        const int TF = W.caps.dp_fast_tlen + 32;
+        constexpr int TF = PMX_DP_FAST_TLEN + 32;
         int8_t* d = W.dp_fast;
         PMX_LDS_HERE(d);
         u = d; v = d + TF; x = d + 2 * TF; y = d + 3 * TF; x2 = d + 4 * TF; y2 = d + 5 * TF; s = d + 6 * TF;
@@ -209,9 +209,17 @@ PMX_HDN void ksw_extd2_t(Work& W, int qlen, QP query, int tlen, TP target, const
             int8_t z = 0, a = 0, b = 0, a2 = 0, b2 = 0, vt1 = 0, ut = 0;
             if (act) {
                 z = s[t];
-                const int8_t xt1 = t == st ? x1 : x[t - 1];
-                vt1 = t == st ? v1 : v[t - 1];
-                const int8_t x2t1 = t == st ? x21 : x2[t - 1];
+                int8_t xt1, x2t1;
+                if (FAST) {   // the element before an array's first is the last of the array in front of it: loads first, selects after
+                    const int8_t xm = x[t - 1], vm = v[t - 1], x2m = x2[t - 1];
+                    xt1 = t == st ? x1 : xm;
+                    vt1 = t == st ? v1 : vm;
+                    x2t1 = t == st ? x21 : x2m;
+                } else {
+                    xt1 = t == st ? x1 : x[t - 1];
+                    vt1 = t == st ? v1 : v[t - 1];
+                    x2t1 = t == st ? x21 : x2[t - 1];
+                }
                 ut = u[t];
                 a = (int8_t)(xt1 + vt1);
                 b = (int8_t)(y[t] + ut);
@@ -350,7 +358,7 @@ template <class QP, class TP>
 PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const int8_t* mat, int8_t q, int8_t e,
                       int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
 #if !defined(PMX_INTERLEAVED) && !defined(PMX_ALL_LDS)
-    if (W.dp_fast && (tlen + 15) / 16 * 16 <= W.caps.dp_fast_tlen && qlen <= W.caps.dp_fast_tlen) {
+    if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && (tlen + 15) / 16 * 16 <= PMX_DP_FAST_TLEN && qlen <= PMX_DP_FAST_TLEN) {
         if (flag & PMX_EZ_RIGHT) ksw_extd2_t<true, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
         else ksw_extd2_t<true, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
         return;

@@ -220,6 +220,9 @@ typedef RawByteReader ByteReader;
 #define PMX_EZ_EXTZ_ONLY 0x40
 #define PMX_EZ_REV_CIGAR 0x80
 #define PMX_KSW_NEG_INF (-0x40000000)
+// the small LDS copy of the DP arrays of the wave-per-read kernels (Work::dp_fast): DPs up to this size; a compile-time
+// constant so that the nine arrays are immediate offsets from one base address in the inner loop
+#define PMX_DP_FAST_TLEN 608
 
 // Mapping options actually read on this path: the option block of setup_minimap2(for_scoring=1)
 // (src/mm_align.c:118-188) on top of mm_mapopt_init (options.c:14-64) and mm_mapopt_update (:66-81).

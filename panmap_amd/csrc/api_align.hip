@@ -580,8 +580,8 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         // wave's HBM slab whatever the LDS budget, and the kernel is bound by the latency of those accesses: what counts is
         // resident waves (16 per CU: 32.4 k reads/s, 8 per CU: 21.1 k) and that the DPs -- nearly all a few hundred bases
         // wide -- run on a small LDS copy of their arrays (plan_layout dp_fast_tlen)
-        int dp_fast = 576;
-        if (const char* e = getenv("PMX_ALIGN_DP_FAST")) dp_fast = atoi(e);
+        int dp_fast = PMX_DP_FAST_TLEN;
+        if (getenv("PMX_ALIGN_NO_DP_FAST")) dp_fast = 0;
         size_t lr_budget = 8900;
         if (const char* e = getenv("PMX_ALIGN_LDS_KB")) lr_budget = (size_t)atoi(e) * 1024;
         const Layout g1 = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lr_budget, tb_small, 1, dp_fast));

@@ -44,8 +44,8 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
     std::vector<DpRes> dp_res(PMX_DP_MAX_CALLS);
     int64_t n_requests = 0, n_wave = 0;
 #else
-    // long reads: like api_align.hip, DPs of up to 576 bases run on the small copy of the DP arrays (PMX_HS_DP_FAST overrides)
-    const int dp_fast = getenv("PMX_HS_DP_FAST") ? atoi(getenv("PMX_HS_DP_FAST")) : (o.is_sr_like ? 0 : 576);
+    // long reads: like api_align.hip, DPs of up to PMX_DP_FAST_TLEN bases run on the small copy of the DP arrays (PMX_HS_DP_FAST overrides)
+    const int dp_fast = getenv("PMX_HS_DP_FAST") ? atoi(getenv("PMX_HS_DP_FAST")) : (o.is_sr_like ? 0 : PMX_DP_FAST_TLEN);
     Layout L = plan_layout(max_len, n_segs, o, (size_t)1 << 30, 0, 1, dp_fast);
 #endif
     std::vector<uint8_t> fast(L.fast_bytes + 64), slow(L.slow_bytes + 64);
