@@ -109,8 +109,14 @@ def main():
     test_gloo = os.environ.get("PMX_BENCH_TEST_BACKEND") == "gloo"
     if test_gloo:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    if world > 1:
+    # PMX_BENCH_FORCE_DIST=1: run the N>1 code path (process group, histogram exchange, record / CIGAR gather, barriers)
+    # in a one-rank RCCL group -- the functional check of the nccl backend that a one-GPU box allows (tests/test_bench_gpu.py)
+    dist_on = world > 1 or os.environ.get("PMX_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if test_gloo:
@@ -170,7 +176,7 @@ def main():
         """the hot path on read sets whose reads are already packed and seeded into `placer`; `all_rs` = the read set the
         aligner runs on (the only one, or a wrapper of the whole buffer when the upload was chunked)"""
         tk = time.perf_counter()
-        if world > 1:
+        if dist_on:
             # exchange step: all-gather the per-rank (hash,count) histograms, merge the other ranks' parts
             n_loc = placer.histogram_size()
             h_sizes = np.asarray(pdist.exchange_sizes(n_loc, dev, via_host=test_gloo), np.int64)   # one host round trip
@@ -220,19 +226,19 @@ def main():
         placer.add_reads(rs, params)
         tk = tick("seed", tk)
         aligner = place_and_align([rs], total_reads, mean_len, paired, paired)
-        if world > 1:
+        if dist_on:
             gather_results(aligner, n_reads)
         ctx.synchronize()
 
     def sync_all():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not dist_on:
             return x
         tt = torch.tensor([x], dtype=torch.float64, device="cpu" if test_gloo else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -263,7 +269,7 @@ def main():
     placed_id = pm.node_id(int(res.best_index[4]))
     mean_cigar = float(np.mean(recs["n_cigar"]))
     gather_ok = None
-    if world > 1 and rank == 0 and state.get("gathered") is not None:
+    if dist_on and rank == 0 and state.get("gathered") is not None:
         g_recs, g_arena, g_n, g_bases = state["gathered"]
         mine_r = g_recs[:n_reads].cpu().numpy().view(pmx.REC_DTYPE).reshape(-1)
         gather_ok = bool(g_recs.shape[0] == sum(g_n) and np.array_equal(mine_r["rs"], recs["rs"]) and
@@ -376,7 +382,7 @@ def main():
             whole.pack()
             aligner = place_and_align(parts, total_reads, mean_len, paired, paired, all_rs=whole)
             nw = aligner.cigar_words()
-            if world > 1:
+            if dist_on:
                 gather_results(aligner, n_reads)
             # records + CIGAR arena into pinned host memory
             aligner.copy_records_device(d_recs.data_ptr(), n_reads)
@@ -519,7 +525,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -48,6 +48,19 @@ def test_bench_two_ranks_functional():
     assert d["checks"]["rank0_gather_has_every_cigar"] is True
 
 
+def test_bench_exchange_path_on_rccl_one_rank():
+    """the N>1 code path -- RCCL process group, histogram all-gather + device merge, record / CIGAR gather, barriers, max over
+    ranks -- in a one-rank group on the real backend (PMX_BENCH_FORCE_DIST; a box of the pool has one GPU)"""
+    env = dict(os.environ, PMX_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--reads-per-gpu", "100000", "--no-cpu-baseline", "--no-real-reads",
+                        "--no-host-to-host", "--no-overlap"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["checks"]["placed_node"] == "node_7618" and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
+    assert d["checks"]["rank0_gather_has_every_cigar"] is True
+
+
 def test_bench_strong_scaling_two_ranks():
     """--scaling strong: the job's reads are split over the ranks (configs[2] shape, small here)"""
     env = dict(os.environ, PMX_BENCH_TEST_BACKEND="gloo")
