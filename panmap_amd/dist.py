@@ -35,6 +35,17 @@ def exchange_sizes(n_local: int, device, via_host=False):
     return [int(x) for x in sizes.tolist()]
 
 
+def exchange_size_pairs(a_local: int, b_local: int, device, via_host=False):
+    """two counts per rank in ONE all-reduce and one host read -> (list of a, list of b)"""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = torch.zeros((2, world), dtype=torch.int64, device="cpu" if via_host else device)
+    sizes[0, rank] = int(a_local)
+    sizes[1, rank] = int(b_local)
+    dist.all_reduce(sizes)
+    both = sizes.tolist()
+    return [int(x) for x in both[0]], [int(x) for x in both[1]]
+
+
 def allgather_padded(mine: torch.Tensor, via_host=False):
     """mine: this rank's max-padded buffer (same shape on every rank) -> [world, *mine.shape] on mine's device"""
     world = dist.get_world_size()
@@ -105,8 +116,7 @@ def gather_alignments(recs_u8: torch.Tensor, cigars_u32: torch.Tensor, dst: int 
     rank -> on rank dst: (records [N, 32] uint8 in rank order with cigar_off rebased, arena [W] int32 = the ranks'
     arenas back to back, per-rank record counts, per-rank arena bases); None elsewhere."""
     rank = dist.get_rank()
-    n_rec = exchange_sizes(recs_u8.shape[0], recs_u8.device, via_host)
-    n_cig = exchange_sizes(cigars_u32.shape[0], recs_u8.device, via_host)
+    n_rec, n_cig = exchange_size_pairs(recs_u8.shape[0], cigars_u32.shape[0], recs_u8.device, via_host)
     rl = _gather_padded(recs_u8, max(max(n_rec), 1), dst, via_host)
     cl = _gather_padded(cigars_u32.view(torch.int32), max(max(n_cig), 1), dst, via_host)
     if rank != dst:
