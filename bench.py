@@ -178,15 +178,17 @@ def main():
         tk = time.perf_counter()
         if dist_on:
             # exchange step: all-gather the per-rank (hash,count) histograms, merge the other ranks' parts
-            n_loc = placer.histogram_size()
+            n_loc = placer.histogram_entries()       # (no sort here: the one sorted histogram is made after the merge)
             h_sizes = np.asarray(pdist.exchange_sizes(n_loc, dev, via_host=test_gloo), np.int64)   # one host round trip
             mx = max(int(h_sizes.max()), 1)
             mine = torch.empty((2, mx), dtype=torch.int64, device=dev)
-            placer.export_device(mine[0].data_ptr(), mine[1].data_ptr(), mx)
+            placer.export_device_unsorted(mine[0].data_ptr(), mine[1].data_ptr(), mx)
+            ctx.synchronize()                          # the export ran on the context's stream, the collective runs on torch's
             allh = pdist.allgather_padded(mine, via_host=test_gloo)
             torch.cuda.synchronize()
             # rank p's run sits 2*mx elements after rank p-1's in both the hash and the count plane
             placer.merge_device_parts(allh[0, 0].data_ptr(), allh[0, 1].data_ptr(), 2 * mx, h_sizes, rank)
+            tk = tick("exchange", tk)
         res = placer.score(params, n_total_reads)
         tk = tick("score", tk)
         node = res.best_index[4]                      # bestLogContainmentNodeId (src/main.cpp:1771)
@@ -227,7 +229,9 @@ def main():
         tk = tick("seed", tk)
         aligner = place_and_align([rs], total_reads, mean_len, paired, paired)
         if dist_on:
+            tk = tick("", time.perf_counter()) if host_times is not None else 0.0
             gather_results(aligner, n_reads)
+            tk = tick("gather", tk)
         ctx.synchronize()
 
     def sync_all():

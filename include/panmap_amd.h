@@ -175,6 +175,11 @@ int pmx_place_histogram_export(pmx_ctx *ctx, pmx_place *pl, uint64_t *hash, int6
 int pmx_place_histogram_merge(pmx_ctx *ctx, pmx_place *pl, const uint64_t *hash, const int64_t *count, int64_t n);
 /* same with caller-owned DEVICE buffers (e.g. torch tensors fed to an RCCL all-gather): no host bounce */
 int pmx_place_histogram_export_device(pmx_ctx *ctx, pmx_place *pl, void *d_hash, void *d_count, int64_t cap);
+/* for the multi-GPU exchange: the number of distinct seeds without sorting them, and the (hash, count) pairs in table
+ * order written into DEVICE buffers (stream-ordered on the context's stream; synchronize the context before another
+ * stream reads them).  The ranks' parts are merged with pmx_place_histogram_merge_device_parts; order plays no role. */
+int64_t pmx_place_histogram_entries(pmx_ctx *ctx, pmx_place *pl);
+int pmx_place_histogram_export_device_unsorted(pmx_ctx *ctx, pmx_place *pl, void *d_hash, void *d_count, int64_t cap);
 /* n_parts (hash,count) runs laid out `part_stride` elements apart (the all-gather buffer of the multi-GPU
  * exchange: rank p's run at d_hash + p * part_stride, sizes[p] valid entries); skip_part = this rank's own run */
 int pmx_place_histogram_merge_device_parts(pmx_ctx *ctx, pmx_place *pl, const void *d_hash, const void *d_count,

@@ -132,6 +132,8 @@ SIGNATURES = {
     "pmx_place_histogram_export": (_i32, [_vp, _vp, _vp, _vp, _i64]),
     "pmx_place_histogram_merge": (_i32, [_vp, _vp, _vp, _vp, _i64]),
     "pmx_place_histogram_export_device": (_i32, [_vp, _vp, _vp, _vp, _i64]),
+    "pmx_place_histogram_entries": (_i64, [_vp, _vp]),
+    "pmx_place_histogram_export_device_unsorted": (_i32, [_vp, _vp, _vp, _vp, _i64]),
     "pmx_place_histogram_merge_device_parts": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32]),
     "pmx_place_histogram_merge_device": (_i32, [_vp, _vp, _vp, _vp, _i64]),
     "pmx_align_copy_records_device": (_i32, [_vp, _vp, _vp, _i64]),

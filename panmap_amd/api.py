@@ -492,6 +492,17 @@ class Placer:
     def export_device(self, d_hash_ptr: int, d_count_ptr: int, cap: int):
         check(lib.pmx_place_histogram_export_device(self.ctx._h, self._h, d_hash_ptr, d_count_ptr, cap), "pmx_place_histogram_export_device")
 
+    def histogram_entries(self) -> int:
+        """distinct seeds so far, without sorting them (the multi-GPU exchange sizes its buffers with it)"""
+        n = lib.pmx_place_histogram_entries(self.ctx._h, self._h)
+        if n < 0:
+            raise _lib.PmxError(n, "pmx_place_histogram_entries")
+        return n
+
+    def export_device_unsorted(self, d_hash_ptr: int, d_count_ptr: int, cap: int):
+        check(lib.pmx_place_histogram_export_device_unsorted(self.ctx._h, self._h, d_hash_ptr, d_count_ptr, cap),
+              "pmx_place_histogram_export_device_unsorted")
+
     def merge_device_parts(self, d_hash_ptr: int, d_count_ptr: int, part_stride: int, sizes, skip_part: int):
         sz = np.ascontiguousarray(sizes, np.int64)
         check(lib.pmx_place_histogram_merge_device_parts(self.ctx._h, self._h, d_hash_ptr, d_count_ptr, part_stride, sz.ctypes.data, len(sz), skip_part),

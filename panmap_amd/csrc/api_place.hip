@@ -715,6 +715,47 @@ int pmx_place_histogram_export_device(pmx_ctx* ctx, pmx_place* pl, void* d_hash,
     PMX_CATCH
 }
 
+// The multi-GPU exchange needs every rank's (hash, count) pairs, not their order: the distinct seeds of the table, counted
+// without the compaction + sort of finalize_histogram, and written -- in table order -- straight into the caller's buffers.
+// The one sorted histogram is made after the other ranks' parts were merged (pmx_place_score).
+int64_t pmx_place_histogram_entries(pmx_ctx* ctx, pmx_place* pl) {
+    if (!ctx || !pl) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    if (pl->hist_sorted) return pl->n_hist;
+    if (!pl->h_ctr_valid) {
+        PMX_HIP(hipMemcpyAsync(pl->h_ctr, pl->counters.p, sizeof(pl->h_ctr), hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        pl->h_ctr_valid = true;
+    }
+    if (pl->h_ctr[PMX_CTR_OVERFLOW]) throw std::runtime_error("seed table overflow (internal sizing error)");
+    int64_t n = 0;
+    for (int i = 0; i < PMX_CTR_NSHARD; ++i) n += (int64_t)pl->h_ctr[PMX_CTR_SHARD0 + i];
+    return n;
+    PMX_CATCH
+}
+
+int pmx_place_histogram_export_device_unsorted(pmx_ctx* ctx, pmx_place* pl, void* d_hash, void* d_count, int64_t cap) {
+    if (!ctx || !pl || (cap > 0 && (!d_hash || !d_count))) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    const int64_t n = pmx_place_histogram_entries(ctx, pl);
+    if (n < 0) return (int)n;
+    if (cap < n) return fail(PMX_ERR_CAPACITY, "histogram export buffer too small");
+    if (n == 0) return PMX_OK;
+    if (pl->hist_sorted) {   // already finalized: the sorted arrays are as good
+        PMX_HIP(hipMemcpyAsync(d_hash, pl->hist_hash.p, sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+        PMX_HIP(hipMemcpyAsync(d_count, pl->hist_count.p, sizeof(int64_t) * n, hipMemcpyDeviceToDevice, ctx->stream));
+        return PMX_OK;
+    }
+    PMX_HIP(hipMemsetAsync(pl->counters.p + PMX_CTR_COMPACT, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_table_compact, dim3(grid_for((int64_t)pl->cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p, pl->vals.p, pl->cap,
+                       (uint64_t*)d_hash, (int64_t*)d_count, pl->counters.p + PMX_CTR_COMPACT);
+    PMX_HIP(hipGetLastError());
+    return PMX_OK;   // (stream-ordered: the caller synchronizes before another stream reads the buffers)
+    PMX_CATCH
+}
+
 int pmx_place_histogram_merge_device(pmx_ctx* ctx, pmx_place* pl, const void* d_hash, const void* d_count, int64_t n) {
     if (!ctx || !pl || n < 0 || (n > 0 && (!d_hash || !d_count))) return PMX_ERR_ARG;
     if (n == 0) return PMX_OK;

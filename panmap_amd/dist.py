@@ -94,8 +94,11 @@ def shard_bounds(n_reads: int, world: int, rank: int, paired: bool = True):
 def _gather_padded(t: torch.Tensor, n_max: int, dst: int, via_host: bool):
     """rows of t ([n, ...]) padded to n_max rows, gathered to dst -> list of padded tensors on dst, None elsewhere"""
     world, rank = dist.get_world_size(), dist.get_rank()
-    pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[:t.shape[0]] = t
+    if t.shape[0] == n_max and t.is_contiguous():
+        pad = t                                    # (weak scaling: every rank holds the same number of records)
+    else:
+        pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
     pad = _coll_tensor(pad, via_host)
     gl = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, gl, dst=dst)
