@@ -112,7 +112,13 @@ def main():
     # PMX_BENCH_FORCE_DIST=1: run the N>1 code path (process group, histogram exchange, record / CIGAR gather, barriers)
     # in a one-rank RCCL group -- the functional check of the nccl backend that a one-GPU box allows (tests/test_bench_gpu.py)
     dist_on = world > 1 or os.environ.get("PMX_BENCH_FORCE_DIST") == "1"
+    saved_stdout_fd = None
     if dist_on:
+        # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner on stdout through C stdio, so
+        # descriptor 1 points at stderr until the line is printed
+        sys.stdout.flush()
+        saved_stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
         os.environ.setdefault("RANK", "0")
@@ -528,10 +534,30 @@ def main():
             out["cpu_baseline"] = cpu_baseline(concat, off, index.arrays(), state["ref"], sample, threads, paired)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+    else:
+        out = None
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if out is None and saved_stdout_fd is not None:   # other ranks: whatever is still buffered goes to stderr too
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    if out is not None:
+        # the C buffers (the banner) are flushed to where descriptor 1 points now -- stderr -- before it is restored
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        if saved_stdout_fd is not None:
+            os.dup2(saved_stdout_fd, 1)
+            os.close(saved_stdout_fd)
+            saved_stdout_fd = None
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -55,6 +55,7 @@ def test_bench_exchange_path_on_rccl_one_rank():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--reads-per-gpu", "100000", "--no-cpu-baseline", "--no-real-reads",
                         "--no-host-to-host", "--no-overlap"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout[:600]   # ONE JSON line (RCCL's banner goes to stderr)
     d = _line(r.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["checks"]["placed_node"] == "node_7618" and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
