@@ -946,9 +946,15 @@ __device__ __forceinline__ ScoreTerms load_terms(uint64_t i, uint64_t end, const
     return t;
 }
 
+// wave-wide integer sum through DPP (quad swaps, then the two row mirrors: every lane of a 16-lane row holds the row's
+// total; four scalar reads add the rows): ~10 instructions instead of six ds_bpermute round trips through the LDS
+// crossbar, each followed by a wait -- the sums sit in front of every chunk of the scoring kernels' serial add chains
 __device__ __forceinline__ int wave_sum_int(int v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
 // Pass 2, one launch per BFS level, one wave per node: parent state + the node's terms added in stored order.
@@ -1166,12 +1172,20 @@ k_score_chains(const uint32_t* __restrict__ chain_off, int64_t n_chains, const u
                 sh[lane * 5 + 4] = cur.d_mag;
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 5) {
+                    // eight terms per step, the next eight requested from LDS before these are added: the chain of FP64
+                    // adds is the kernel's critical path and no longer waits for an LDS round trip per step
                     int j = 0;
-                    for (; j + 8 <= cnt; j += 8) {
-                        const double v0 = sh[(j + 0) * 5 + lane], v1 = sh[(j + 1) * 5 + lane], v2 = sh[(j + 2) * 5 + lane],
-                                     v3 = sh[(j + 3) * 5 + lane], v4 = sh[(j + 4) * 5 + lane], v5 = sh[(j + 5) * 5 + lane],
-                                     v6 = sh[(j + 6) * 5 + lane], v7 = sh[(j + 7) * 5 + lane];
-                        acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+                    if (cnt >= 8) {
+                        const double* q = sh + lane;
+                        double a0 = q[0], a1 = q[5], a2 = q[10], a3 = q[15], a4 = q[20], a5 = q[25], a6 = q[30], a7 = q[35];
+                        for (; j + 16 <= cnt; j += 8) {
+                            q += 40;
+                            const double b0 = q[0], b1 = q[5], b2 = q[10], b3 = q[15], b4 = q[20], b5 = q[25], b6 = q[30], b7 = q[35];
+                            acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+                            a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+                        }
+                        acc += a0; acc += a1; acc += a2; acc += a3; acc += a4; acc += a5; acc += a6; acc += a7;
+                        j += 8;
                     }
                     for (; j < cnt; ++j) acc += sh[j * 5 + lane];
                 }
