@@ -133,6 +133,33 @@ def rearranged_long_reads(pmx, genome: bytes, n: int, read_len: int, seed: int, 
     return out
 
 
+def inverted_repeat_case(pmx, genome: bytes, n: int, seed: int, copy_div: float, read_err: float, copy=(3000, 23000), read_len=None):
+    """-> (reference, reads): the genome followed by a diverged reverse-complemented copy of a stretch of it (`copy`), and long
+    reads drawn from around that stretch -- every read has a second, weaker chain on the OTHER strand that overlaps its primary on the read:
+    mm_select_sub keeps it as strand_retained, and mm_est_err + mm_filter_strand_retained (esterr.c:30-64, hit.c:277-290)
+    decide whether it stays (a diverged copy goes, a short near-identical one stays)"""
+    rng = np.random.default_rng(seed)
+
+    def mutate(s, rate):
+        a = np.frombuffer(s, np.uint8).copy()
+        hit = rng.random(len(a)) < rate
+        a[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+        return a.tobytes()
+
+    ref = genome + pmx.reverse_complement(mutate(genome[copy[0]:copy[1]], copy_div))
+    reads = []
+    for _ in range(n):
+        if read_len is None:   # reads inside the copied stretch: the secondary is as long as the primary, only more diverged
+            ln = int(rng.integers(9000, 14000))
+            st = int(rng.integers(copy[0], copy[1] - ln))
+        else:                  # reads that cover the whole copied stretch: the secondary is shorter than the primary
+            ln = read_len
+            st = int(rng.integers(max(0, copy[1] - ln), min(copy[0], len(genome) - ln)))
+        r = mutate(genome[st:st + ln], read_err)
+        reads.append(r if rng.random() < 0.5 else pmx.reverse_complement(r))
+    return ref, reads
+
+
 def golden_cases(pmx):
     """(genome, {name: (reads, expected results)}) of tests/golden/align_golden.json.gz; the inputs are regenerated
     exactly as tests/golden/make_align_golden.py made them"""

@@ -79,6 +79,17 @@ def test_rearranged_long_reads_equal_reference(pmx, oracle, read_len, sub, seed)
     assert sum(1 for x in got if x["flags"] & 3) == 0
 
 
+@pytest.mark.parametrize("copy_div,read_err,copy,read_len", [(0.03, 0.01, (3000, 23000), None), (0.003, 0.003, (7000, 18000), 15000)])
+def test_strand_retained_secondaries_equal_reference(pmx, oracle, copy_div, read_err, copy, read_len):
+    """a reference with a diverged inverted copy: the divergence estimate and the strand-retained filter decide about the
+    opposite-strand secondary of every read"""
+    ref, reads = ac.inverted_repeat_case(pmx, _ref_genome(), 24, 31, copy_div, read_err, copy=copy, read_len=read_len)
+    want = oracle.ref_align_reads_direct(ref, reads, False, 8)
+    got = ac.hostsim_align(ref, reads, False)
+    assert not ac.compare_results(got, want)
+    assert sum(1 for x in got if x["flags"] & 3) == 0
+
+
 @pytest.mark.parametrize("tpp", [False, True])
 def test_golden_fixture(pmx, tpp):
     """committed outputs of the reference aligner (tests/golden/align_golden.json.gz): no oracle/_ref needed"""

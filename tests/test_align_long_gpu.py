@@ -72,6 +72,18 @@ def test_rearranged_long_reads_equal_reference(pmx, oracle, ctx, read_len, sub, 
     assert sum(1 for x in got if x["flags"] & 3) == 0
 
 
+@pytest.mark.parametrize("copy_div,read_err,copy,read_len", [(0.03, 0.01, (3000, 23000), None), (0.003, 0.003, (7000, 18000), 15000)])
+def test_strand_retained_secondaries_equal_reference(pmx, oracle, ctx, copy_div, read_err, copy, read_len):
+    """a reference with a diverged inverted copy of 20 kb: every read has an opposite-strand secondary that mm_select_sub keeps
+    as strand_retained; mm_est_err (with the device's pow) and mm_filter_strand_retained decide whether it stays"""
+    ref, reads = ac.inverted_repeat_case(pmx, mg.genome(), 100, 41, copy_div, read_err, copy=copy, read_len=read_len)
+    want = oracle.ref_align_reads_direct(ref, reads, False, 8)
+    al = pmx.Aligner(ctx, ref, int(np.mean([len(r) for r in reads])))
+    got = al.align_reads(reads, paired=False)
+    assert not ac.compare_results(got, want)
+    assert sum(1 for x in got if x["flags"] & 3) == 0
+
+
 def test_slab_budget_caps_the_grid_not_the_results(pmx, ctx, monkeypatch):
     """every resident wave of the wave-per-read tier owns a ~20 MB slab; the launch takes the grid its memory budget pays for
     (16,000 reads of 10 kb used to ask for 318 GB).  With the budget forced down to 100 MB -- a handful of waves -- the
