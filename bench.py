@@ -1,33 +1,43 @@
 #!/usr/bin/env python3
-"""Benchmark of the panmap hot path on MI355X: reads placed + aligned per second.
+"""Benchmark of the panmap hot path on MI355X: reads placed + aligned per second, host memory to host memory.
 
-One "step" = one pass of the hot path over one batch of synthetic reads resident in HBM (ASCII, as the
-boundary hands them over): 2-bit pack -> syncmer/k-min-mer seeding + seed histogram -> [N>1: RCCL
-all-gather + merge of the per-rank histograms] -> node scoring down the PanMAN tree -> materialise the
-placed genome + build its minimizer index -> map + align every read pair -> [N>1: RCCL gather of the
-alignment records AND the CIGAR arena to rank 0, panmap_amd/dist.py].
+One "step" = one pass of the hot path over one batch of synthetic reads that starts as FASTQ text in (pinned) host
+memory and ends as alignment records + CIGARs in (pinned) host memory (SURVEY 8d "Metric"):
+  H2D of the ASCII bases in chunks on a copy stream (chunk c is packed 2 bit/base and seeded while chunk c+1 is in flight)
+  -> syncmer / k-min-mer seeding + seed histogram -> [N>1: RCCL all-gather + merge of the per-rank histograms]
+  -> node scoring down the PanMAN tree -> materialise the placed genome + build its minimizer index
+  -> map + align every read pair -> [N>1: RCCL gather of the records AND the CIGAR arena to rank 0]
+  -> D2H of the records + CIGAR arena on a second copy stream.
+`--pipelines` (default 2) batches are in flight at a time: each pipeline owns a context (= HIP stream), a placer, an
+aligner, device staging, pinned output buffers and a host thread, and the pipelines take the steps alternately, so the
+H2D of batch n+1 and the D2H of batch n-1 overlap the kernels of batch n.  `value` counts the reads of all K steps over
+the wall time of the whole timed region (barrier + synchronize on both sides, max over ranks).
 
-Workload (BASELINE.json configs[1]): 1M x 150 bp synthetic paired reads vs the 20,000-genome SARS-CoV-2
-PanMAN on one GPU.  --gpus N: every rank takes its own shard, the seed index is replicated per GPU.
-  --scaling weak   (default) 1M reads per rank (8 ranks = 8M reads)
-  --scaling strong --total-reads 10000000   BASELINE configs[2] literally: 10M reads split over the ranks
-  --read-len >= 500: single-end long reads (configs[3], `--reads-per-gpu 100000 --read-len 10000`)
+Workload (default = BASELINE.json configs[2], the one the metric string is quoted on): 10M x 150 bp synthetic paired
+reads vs the 20,000-genome SARS-CoV-2 PanMAN, `--scaling strong`: the 10M reads are split over the ranks (N=1: all 10M on
+the one GPU, N=8: 1.25M each); the seed index is replicated per GPU.
+  --scaling weak --reads-per-gpu 1000000      configs[1] per rank
+  --read-len >= 500                           single-end long reads (configs[3]: `--scaling weak --reads-per-gpu 100000 --read-len 10000`)
 
 The ONE JSON line (rank 0) carries, next to the contract keys:
-  value_host_to_host   the SURVEY 8d metric: pinned host ASCII -> H2D (chunked, overlapped with packing + seeding on
-                       a side stream) -> the same step -> D2H of records + CIGAR arena into pinned host memory
-  roofline             dominant kernel vs the HBM peak (algorithmic bytes / its HIP-event duration)
-  dp                   share of pairs that ran a ksw2 DP, DP cells per step, GCUPS
-  real_reads           the repository's real example reads x8 through the same step (20 % of the pairs need a DP)
-  cpu_baseline         the CPU path on ALL host cores, timed around bare C calls (no Python in the timed spans)
+  value_device_resident  the same step with its inputs already in HBM and its outputs left there (no PCIe), one batch at a time
+  pcie                   measured H2D / D2H GB/s of this box (pinned, 256 MB) and the PCIe-bound reads/s that follows
+  roofline               dominant kernel vs the HBM peak (algorithmic bytes / its HIP-event duration in the resident run)
+  roofline_valu          the same kernel against the VALU issue rate (wave-instructions from the PMC pass of profiles/,
+                         only when that pass was collected on the sources of this build)
+  dp                     share of pairs that ran a ksw2 DP, DP cells per step, GCUPS
+  real_reads             the repository's real example reads x8 through the same step
+  cpu_baseline           the CPU path on the host cores, timed around bare C calls (no Python in the timed spans)
 
 Launched for N>1 as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -37,7 +47,38 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 
-def cpu_baseline(concat, off, index_arrays, placed_genome, sample_reads, threads, paired):
+def source_digest():
+    """digest of the kernel / library sources of this build: a PMC pass under profiles/ is only quoted when it carries it"""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "panmap_amd", "csrc")
+    for dp, dn, fn in sorted(os.walk(base)):
+        dn[:] = sorted(d for d in dn if d != "build")
+        for f in sorted(fn):
+            if f.endswith((".hip", ".hpp", ".h", ".cpp")):
+                h.update(os.path.relpath(os.path.join(dp, f), base).encode())
+                with open(os.path.join(dp, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def usable_cpus():
+    """threads this process may really use: affinity mask, capped by the cgroup CPU quota when there is one"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, p = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    return max(1, n), quota
+
+
+def cpu_baseline(concat, off, index_arrays, placed_genome, sample_reads, threads, paired, quota):
     """The CPU path timed on this box's host cores on a bounded sample of the SAME workload.
     place leg = oracle restatement (oracle/oracle_place.c; the reference's placement.cpp cannot be built without
     panman/TBB/abseil), seeded on `threads` pthreads in ONE C call, then finalize + node scoring + best/tie rule;
@@ -75,29 +116,73 @@ def cpu_baseline(concat, off, index_arrays, placed_genome, sample_reads, threads
     mapped = sum(r["mapped"] for r in res)
     total = t_seed + t_score + t_align
     return dict(value=n / total, unit="reads/s", cores=threads, kind="reference",
+                kind_by_leg={"align": "reference (oracle/_ref: src/mm_align.c + vendored minimap2, compiled where they lie)",
+                             "place": "port (oracle/oracle_place.c restatement; placement.cpp needs panman/TBB/abseil)"},
+                cgroup_cpu_quota=quota,
                 legs={"seed_reads_per_s": n / t_seed, "score_s_per_sample": t_score, "align_reads_per_s": n / t_align},
-                sample="%d of the workload's reads, %d threads (= all host cores): place leg = oracle port of seeding (one "
+                sample="%d of the workload's reads, %d threads (the CPUs this process may use): place leg = oracle port of seeding (one "
                        "pthread-chunked C call, %.2fs) + node scoring (%.2fs, once per sample, single thread as a fixed cost); "
                        "align leg = the reference's minimap2 via src/mm_align.c align_reads_direct, bare C call %.2fs; "
                        "%d/%d %s mapped" % (n, threads, t_seed, t_score, t_align, mapped, len(res), "pairs" if paired else "reads"))
 
 
+class Sequencer:
+    """Collectives issued from several host threads must reach the process group in ONE order on every rank.  The batches
+    are numbered; batch i has a histogram exchange H_i and a result gather G_i; the order is H0, H1, G0, H2, G1, H3, ...
+    (batch i+1 is seeded while batch i aligns), which every rank derives from the batch number alone."""
+
+    def __init__(self, n_batches):
+        self.n = n_batches
+        self.next = 0
+        self.cv = threading.Condition()
+        self.failed = None
+
+    def ticket(self, kind, i):
+        if kind == "H":
+            return 0 if i == 0 else 2 * i - 1
+        return 2 * i + 2 if i < self.n - 1 else 2 * self.n - 1
+
+    def run(self, kind, i, fn):
+        t = self.ticket(kind, i)
+        with self.cv:
+            while self.next != t and self.failed is None:
+                self.cv.wait(timeout=1.0)
+            if self.failed is not None:
+                raise RuntimeError("another pipeline failed: %s" % self.failed)
+        try:
+            return fn()
+        except BaseException as e:   # noqa: BLE001  (wake the other thread, then re-raise)
+            with self.cv:
+                self.failed = repr(e)
+                self.cv.notify_all()
+            raise
+        finally:
+            with self.cv:
+                self.next = t + 1
+                self.cv.notify_all()
+
+    def fail(self, e):
+        with self.cv:
+            self.failed = repr(e)
+            self.cv.notify_all()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # (defaults: the first steps after start-up run ~3 % slower -- clocks, first touches -- and 20 steps of 8.5 ms cost nothing)
+    # (10M reads per step: a step is 50-100 ms; 20 steps after 3 warm-up steps)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads-per-gpu", type=int, default=1000000)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--total-reads", type=int, default=10000000, help="--scaling strong: reads of the whole job")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong")
+    ap.add_argument("--total-reads", type=int, default=10000000, help="--scaling strong: reads of the whole job (BASELINE configs[2])")
+    ap.add_argument("--reads-per-gpu", type=int, default=1000000, help="--scaling weak: reads per rank (BASELINE configs[1])")
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--pipelines", type=int, default=0, help="batches in flight (0 = 2 for short reads, 1 for long reads)")
+    ap.add_argument("--h2d-chunks", type=int, default=0, help="H2D chunks per batch (0 = one per ~1M reads, at least 4)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads of the CPU baseline sample (0 = sized for ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-reads", action="store_true")
-    ap.add_argument("--no-host-to-host", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="skip the two-batches-in-flight figure")
-    ap.add_argument("--h2d-chunks", type=int, default=4)
+    ap.add_argument("--no-resident", action="store_true", help="skip the device-resident figure (and the roofline objects that need it)")
     args = ap.parse_args()
 
     import torch
@@ -139,9 +224,6 @@ def main():
     golden = os.path.join(ROOT, "tests", "golden")
     pm = pmx.Panman(os.path.join(golden, "sars_20000_twilight_dipper.panman"))
     index = pmx.Index.build(pm, k=19, s=8, t=0, l=3, open_syncmer=False, flank_mask=250)
-    ctx = pmx.Context(local_rank)
-    placer = pmx.Placer(ctx, index)
-    ctx_stream = torch.cuda.ExternalStream(ctx.stream, device=dev) if ctx.stream else torch.cuda.current_stream(dev)
 
     # ---------------------------------------------------------------------------------------------- workload
     # Source genome: node_7618 of the tree (the node the repository's example sample places on; SURVEY 8d asks for
@@ -150,6 +232,7 @@ def main():
     src = pm.genome("node_7618")
     long_reads = args.read_len >= 500
     paired = not long_reads
+    unit = 2 if paired else 1
     if args.scaling == "strong":
         lo, hi = pdist.shard_bounds(args.total_reads, world, rank, paired=paired)
         my_reads = hi - lo
@@ -165,26 +248,97 @@ def main():
     n_reads = len(off) - 1
     max_len = int(np.max(np.diff(off))) if n_reads else 0
     mean_len = int(off[-1] // max(n_reads, 1))
-    total_reads = n_reads * world if args.scaling == "weak" else args.total_reads // (2 if paired else 1) * (2 if paired else 1)
+    total_reads = n_reads * world if args.scaling == "weak" else args.total_reads // unit * unit
+    n_pipes = args.pipelines or (1 if long_reads else 2)
+    n_chunks = args.h2d_chunks or max(4, (n_reads + 999999) // 1000000)
+    n_chunks = max(1, min(n_chunks, n_reads // unit or 1))
+    bounds = [(n_reads // unit) * c // n_chunks * unit for c in range(n_chunks + 1)]
 
     params = pmx.TraversalParams()
-    state = {}
     host_times = {} if os.environ.get("PMX_BENCH_HOST_TIMES") else None   # diagnostic: serialised per-phase wall times
 
-    def tick(name, t_prev):
-        if host_times is None:
-            return t_prev
-        ctx.synchronize()
-        t = time.perf_counter()
-        host_times[name] = host_times.get(name, 0.0) + (t - t_prev) * 1e3
-        return t
+    # ------------------------------------------------------------------------------------------------- PCIe of this box
+    def measure_pcie(nbytes=256 << 20, reps=3):
+        h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = {}
+        for name, dst, s in (("h2d", d, h), ("d2h", h, d)):
+            dst.copy_(s, non_blocking=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dst.copy_(s, non_blocking=True)
+            torch.cuda.synchronize()
+            out[name + "_GBps"] = reps * nbytes / (time.perf_counter() - t0) / 1e9
+        # both directions at once (the pipelined step uploads batch n+1 while it downloads batch n-1)
+        h2 = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        d2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            with torch.cuda.stream(s1):
+                d.copy_(h, non_blocking=True)
+            with torch.cuda.stream(s2):
+                h2.copy_(d2, non_blocking=True)
+        torch.cuda.synchronize()
+        out["duplex_each_GBps"] = reps * nbytes / (time.perf_counter() - t0) / 1e9
+        return out
 
-    def place_and_align(read_sets, n_total_reads, mean_read_len, is_paired, revcomp_mate2, all_rs=None):
-        """the hot path on read sets whose reads are already packed and seeded into `placer`; `all_rs` = the read set the
-        aligner runs on (the only one, or a wrapper of the whole buffer when the upload was chunked)"""
-        tk = time.perf_counter()
-        if dist_on:
-            # exchange step: all-gather the per-rank (hash,count) histograms, merge the other ranks' parts
+    pcie = measure_pcie()
+
+    # ------------------------------------------------------------------------------------------------------ pipelines
+    h_concat = torch.from_numpy(concat).pin_memory()
+    h_off = torch.from_numpy(off).pin_memory()
+    n_out = total_reads if (dist_on and rank == 0) else n_reads       # rank 0 receives every rank's records
+    cig_words_cap = max(n_out * 4, int(concat.size) // 4 * (world if dist_on and rank == 0 else 1), 4096)
+
+    class Pipe:
+        """one batch in flight: context (= stream), placer, aligner, device staging, pinned outputs"""
+
+        def __init__(self):
+            self.ctx = pmx.Context(local_rank)
+            self.placer = pmx.Placer(self.ctx, index)
+            self.aligner = None
+            self.stream = torch.cuda.ExternalStream(self.ctx.stream, device=dev) if self.ctx.stream else torch.cuda.current_stream(dev)
+            self.copy_in = torch.cuda.Stream(device=dev)
+            self.copy_out = torch.cuda.Stream(device=dev)
+            self.d_concat = torch.empty(int(concat.size), dtype=torch.uint8, device=dev)
+            self.d_off = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
+            self.d_recs = torch.empty((n_reads, 32), dtype=torch.uint8, device=dev)
+            self.d_cig = None
+            self.out_recs = None
+            self.out_cig = None
+            self.pool = {}
+            self.res = None
+            self.ref = None
+            self.gathered = None
+            self.nw = 0
+
+        def alloc_outputs(self):
+            if self.out_recs is None and (not dist_on or rank == 0):
+                self.out_recs = torch.empty((n_out, 32), dtype=torch.uint8).pin_memory()
+                self.out_cig = torch.empty(cig_words_cap, dtype=torch.int32).pin_memory()
+
+        def read_set(self, key, d_concat, d_off_ptr, n):
+            # read set objects reused from step to step (pmx_readset_rewrap_device: no hipMalloc, offsets handled on the device)
+            if key in self.pool:
+                self.pool[key].rewrap_device(d_concat.data_ptr(), d_off_ptr, n, int(concat.size), max_len)
+            else:
+                self.pool[key] = pmx.ReadSet.wrap_device(self.ctx, d_concat.data_ptr(), d_off_ptr, n, int(concat.size), max_len)
+            return self.pool[key]
+
+        def tick(self, name, t_prev):
+            if host_times is None:
+                return t_prev
+            self.ctx.synchronize()
+            t = time.perf_counter()
+            host_times[name] = host_times.get(name, 0.0) + (t - t_prev) * 1e3
+            return t
+
+        def exchange_histograms(self):
+            """all-gather the per-rank (hash,count) histograms, merge the other ranks' parts"""
+            placer, ctx = self.placer, self.ctx
             n_loc = placer.histogram_entries()       # (no sort here: the one sorted histogram is made after the merge)
             h_sizes = np.asarray(pdist.exchange_sizes(n_loc, dev, via_host=test_gloo), np.int64)   # one host round trip
             mx = max(int(h_sizes.max()), 1)
@@ -192,57 +346,132 @@ def main():
             placer.export_device_unsorted(mine[0].data_ptr(), mine[1].data_ptr(), mx)
             ctx.synchronize()                          # the export ran on the context's stream, the collective runs on torch's
             allh = pdist.allgather_padded(mine, via_host=test_gloo)
-            torch.cuda.synchronize()
+            torch.cuda.current_stream(dev).synchronize()
             # rank p's run sits 2*mx elements after rank p-1's in both the hash and the count plane
             placer.merge_device_parts(allh[0, 0].data_ptr(), allh[0, 1].data_ptr(), 2 * mx, h_sizes, rank)
-            tk = tick("exchange", tk)
-        res = placer.score(params, n_total_reads)
-        tk = tick("score", tk)
-        node = res.best_index[4]                      # bestLogContainmentNodeId (src/main.cpp:1771)
-        ref = pm.genome(int(node))                    # getStringFromReference, every step (nothing cached)
-        tk = tick("genome", tk)
-        if "aligner" not in state:
-            state["aligner"] = pmx.Aligner(ctx, ref, mean_read_len)
-        else:
-            state["aligner"].set_reference(ref, mean_read_len)   # mm_idx_str of the placed genome, every step
-        aligner = state["aligner"]
-        tk = tick("ref_index", tk)
-        aligner.align_readset(all_rs if all_rs is not None else read_sets[0], paired=is_paired, revcomp_mate2=revcomp_mate2)
-        tk = tick("align", tk)
-        state["res"], state["ref"] = res, ref
-        return aligner
 
-    def gather_results(aligner, n_my_reads):
-        """N>1: fixed-size records + the CIGAR arena of every rank to rank 0, cigar_off rebased (dist.gather_alignments)"""
-        recs = torch.empty((n_my_reads, 32), dtype=torch.uint8, device=dev)
-        aligner.copy_records_device(recs.data_ptr(), n_my_reads)
-        nw = aligner.cigar_words()
-        cig = torch.empty(max(nw, 1), dtype=torch.int32, device=dev)
-        aligner.copy_cigars_device(cig.data_ptr(), max(nw, 1))
-        state["gathered"] = pdist.gather_alignments(recs, cig[:nw], 0, via_host=test_gloo)
+        def place_and_align(self, all_rs, n_total_reads, mean_read_len, is_paired, revcomp_mate2, seq=None, batch=0):
+            """the hot path on reads already packed and seeded into the placer; `all_rs` = the read set the aligner runs on"""
+            tk = time.perf_counter()
+            if dist_on:
+                if seq is not None:
+                    seq.run("H", batch, self.exchange_histograms)
+                else:
+                    self.exchange_histograms()
+                tk = self.tick("exchange", tk)
+            res = self.placer.score(params, n_total_reads)
+            tk = self.tick("score", tk)
+            node = res.best_index[4]                      # bestLogContainmentNodeId (src/main.cpp:1771)
+            ref = pm.genome(int(node))                    # getStringFromReference, every step (nothing cached)
+            tk = self.tick("genome", tk)
+            if self.aligner is None:
+                self.aligner = pmx.Aligner(self.ctx, ref, mean_read_len)
+            else:
+                self.aligner.set_reference(ref, mean_read_len)   # mm_idx_str of the placed genome, every step
+            tk = self.tick("ref_index", tk)
+            self.aligner.align_readset(all_rs, paired=is_paired, revcomp_mate2=revcomp_mate2)
+            tk = self.tick("align", tk)
+            self.res, self.ref = res, ref
 
-    # inputs resident in HBM before the timed region (ASCII + offsets, as torch tensors)
-    d_concat = torch.from_numpy(concat).to(dev)
-    d_off = torch.from_numpy(off).to(dev)
-    torch.cuda.synchronize()
-    rs = pmx.ReadSet.wrap_device(ctx, d_concat.data_ptr(), d_off.data_ptr(), n_reads, int(concat.size), max_len, keepalive=(d_concat, d_off))
+        def gather_results(self):
+            """N>1: fixed-size records + the CIGAR arena of every rank to rank 0, cigar_off rebased (dist.gather_alignments)"""
+            al = self.aligner
+            al.copy_records_device(self.d_recs.data_ptr(), n_reads)
+            nw = al.cigar_words()
+            if self.d_cig is None or self.d_cig.numel() < max(nw, 1):
+                self.d_cig = torch.empty(max(nw, 1) * 5 // 4 + 1024, dtype=torch.int32, device=dev)
+            al.copy_cigars_device(self.d_cig.data_ptr(), max(nw, 1))
+            self.gathered = pdist.gather_alignments(self.d_recs, self.d_cig[:nw], 0, via_host=test_gloo)
 
-    def step():
-        tk = tick("", time.perf_counter()) if host_times is not None else 0.0
-        rs.pack()
-        tk = tick("pack", tk)
-        placer.reset()
-        placer.add_reads(rs, params)
-        tk = tick("seed", tk)
-        aligner = place_and_align([rs], total_reads, mean_len, paired, paired)
-        if dist_on:
-            tk = tick("", time.perf_counter()) if host_times is not None else 0.0
-            gather_results(aligner, n_reads)
-            tk = tick("gather", tk)
-        ctx.synchronize()
+        # ---- the step with its inputs resident in HBM and its outputs left there (value_device_resident)
+        def run_resident(self, rs):
+            tk = self.tick("", time.perf_counter()) if host_times is not None else 0.0
+            rs.pack()
+            tk = self.tick("pack", tk)
+            self.placer.reset()
+            self.placer.add_reads(rs, params)
+            tk = self.tick("seed", tk)
+            self.place_and_align(rs, total_reads, mean_len, paired, paired)
+            if dist_on:
+                tk = self.tick("", time.perf_counter()) if host_times is not None else 0.0
+                self.gather_results()
+                tk = self.tick("gather", tk)
+            self.ctx.synchronize()
+
+        # ---- the step of `value`: host memory -> host memory
+        def run_h2h(self, seq=None, batch=0):
+            evs = []
+            with torch.cuda.stream(self.copy_in):
+                # offsets first (8 B per read), then the bases chunk by chunk; chunk c is packed and seeded on the
+                # library's stream as soon as its copy has landed, while chunk c+1 is still in flight
+                self.d_off.copy_(h_off, non_blocking=True)
+                ev_off = torch.cuda.Event()
+                ev_off.record(self.copy_in)
+                for c in range(n_chunks):
+                    b0, b1 = int(off[bounds[c]]), int(off[bounds[c + 1]])
+                    self.d_concat[b0:b1].copy_(h_concat[b0:b1], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.copy_in)
+                    evs.append(ev)
+            self.placer.reset()
+            self.stream.wait_event(ev_off)
+            for c in range(n_chunks):
+                r0, r1 = bounds[c], bounds[c + 1]
+                if r1 <= r0:
+                    continue
+                part = self.read_set(c, self.d_concat, self.d_off.data_ptr() + 8 * r0, r1 - r0)   # (needs the offsets only)
+                self.stream.wait_event(evs[c])
+                part.pack()
+                self.placer.add_reads(part, params)
+            whole = self.read_set("whole", self.d_concat, self.d_off.data_ptr(), n_reads)
+            whole.pack()
+            self.place_and_align(whole, total_reads, mean_len, paired, paired, seq=seq, batch=batch)
+            al = self.aligner
+            if dist_on:
+                if seq is not None:
+                    seq.run("G", batch, self.gather_results)
+                else:
+                    self.gather_results()
+                if rank != 0:
+                    self.ctx.synchronize()
+                    torch.cuda.current_stream(dev).synchronize()
+                    return 0
+                g_recs, g_arena, _, _ = self.gathered
+                nw = int(g_arena.numel())
+                src_recs, src_cig = g_recs, g_arena
+                ev_done = torch.cuda.Event()
+                ev_done.record(torch.cuda.current_stream(dev))
+            else:
+                nw = al.cigar_words()
+                al.copy_records_device(self.d_recs.data_ptr(), n_reads)
+                if self.d_cig is None or self.d_cig.numel() < max(nw, 1):
+                    self.d_cig = torch.empty(max(nw, 1) * 5 // 4 + 1024, dtype=torch.int32, device=dev)
+                al.copy_cigars_device(self.d_cig.data_ptr(), max(nw, 1))
+                src_recs, src_cig = self.d_recs, self.d_cig
+                ev_done = torch.cuda.Event()
+                ev_done.record(self.stream)
+            if nw > self.out_cig.numel():
+                raise RuntimeError("pinned CIGAR buffer too small")
+            # records + CIGAR arena into pinned host memory, on the pipeline's own download stream
+            with torch.cuda.stream(self.copy_out):
+                self.copy_out.wait_event(ev_done)
+                self.out_recs[:src_recs.shape[0]].copy_(src_recs, non_blocking=True)
+                self.out_cig[:nw].copy_(src_cig[:nw], non_blocking=True)
+            self.copy_out.synchronize()
+            self.nw = nw
+            return nw
+
+        def close(self):
+            for p_ in self.pool.values():
+                p_.close()
+            self.pool = {}
+
+    pipes = [Pipe() for _ in range(n_pipes)]
+    main_pipe = pipes[0]
 
     def sync_all():
-        ctx.synchronize()
+        for pp in pipes:
+            pp.ctx.synchronize()
         torch.cuda.synchronize()
         if dist_on:
             dist.barrier()
@@ -255,173 +484,118 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    for _ in range(args.warmup):
-        step()
+    def run_batches(n_batches):
+        """n_batches steps over the pipelines: pipeline p takes the batches p, p + P, p + 2P, ..."""
+        if len(pipes) == 1:
+            for b in range(n_batches):
+                pipes[0].run_h2h(None, b)
+            return
+        seq = Sequencer(n_batches) if dist_on else None
+        errs = []
+
+        def work(p):
+            try:
+                torch.cuda.set_device(local_rank)
+                for b in range(p, n_batches, len(pipes)):
+                    pipes[p].run_h2h(seq, b)
+            except BaseException as e:   # noqa: BLE001
+                errs.append(e)
+                if seq is not None:
+                    seq.fail(e)
+        th = [threading.Thread(target=work, args=(p,)) for p in range(len(pipes))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    # ------------------------------------------------------------------------------------------ value: host -> host
+    for pp in pipes:
+        pp.alloc_outputs()
+    run_batches(max(args.warmup, len(pipes)))
     sync_all()
     t0 = time.perf_counter()
-    kernel_ms = {"align": [], "align_dom": [], "seed": [], "score": []}
-    dp_stats = []
-    for _ in range(args.steps):
-        step()
-        for k in kernel_ms:
-            kernel_ms[k].append(ctx.kernel_ms(k))
-        dp_stats.append(state["aligner"].stats())
+    run_batches(args.steps)
     sync_all()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    if host_times is not None and rank == 0:
-        n_st = args.steps + args.warmup
-        print("[bench host times, ms/step, serialised] " + " ".join(f"{k}={v / n_st:.3f}" for k, v in host_times.items() if k), file=sys.stderr)
+    h2h_recs = [None if pp.out_recs is None else pp.out_recs.numpy().view(pmx.REC_DTYPE).reshape(-1) for pp in pipes]
+    h2h_nw = [pp.nw for pp in pipes]
+    h2h_nodes = [None if pp.res is None else int(pp.res.best_index[4]) for pp in pipes]
 
-    # sanity on the last step's output (not timed)
-    recs, cig = state["aligner"].fetch()
-    res = state["res"]
+    # ---------------------------------------------------------------- value_device_resident (one batch at a time, no PCIe)
+    kernel_ms = {"align": [], "align_dom": [], "seed": [], "score": []}
+    dp_stats = []
+    resident = None
+    d_concat = torch.from_numpy(concat).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    torch.cuda.synchronize()
+    rs = pmx.ReadSet.wrap_device(main_pipe.ctx, d_concat.data_ptr(), d_off.data_ptr(), n_reads, int(concat.size), max_len, keepalive=(d_concat, d_off))
+    if not args.no_resident:
+        for _ in range(max(1, min(args.warmup, 2))):
+            main_pipe.run_resident(rs)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            main_pipe.run_resident(rs)
+            for k in kernel_ms:
+                kernel_ms[k].append(main_pipe.ctx.kernel_ms(k))
+            dp_stats.append(main_pipe.aligner.stats())
+        sync_all()
+        el_r = max_over_ranks(time.perf_counter() - t0)
+        resident = dict(value=total_reads * args.steps / el_r, ms_per_step=el_r / args.steps * 1e3)
+        if host_times is not None and rank == 0:
+            n_st = args.steps + max(1, min(args.warmup, 2))
+            print("[bench host times, ms/step, serialised] " + " ".join(f"{k}={v / n_st:.3f}" for k, v in host_times.items() if k), file=sys.stderr)
+    else:
+        main_pipe.run_resident(rs)
+        dp_stats.append(main_pipe.aligner.stats())
+
+    # sanity on the last resident step's output (not timed), and host->host == resident
+    recs, cig = main_pipe.aligner.fetch()
+    res = main_pipe.res
+    placed_ref = main_pipe.ref
     mapped_frac = float(np.mean(recs["mapped"]))
     flagged = int(np.sum((recs["flags"] & 3) != 0))
     placed_id = pm.node_id(int(res.best_index[4]))
     mean_cigar = float(np.mean(recs["n_cigar"]))
+    same_as_resident = None
     gather_ok = None
-    if dist_on and rank == 0 and state.get("gathered") is not None:
-        g_recs, g_arena, g_n, g_bases = state["gathered"]
-        mine_r = g_recs[:n_reads].cpu().numpy().view(pmx.REC_DTYPE).reshape(-1)
-        gather_ok = bool(g_recs.shape[0] == sum(g_n) and np.array_equal(mine_r["rs"], recs["rs"]) and
-                         np.array_equal(g_arena[:len(cig)].cpu().numpy().view(np.uint32), cig))
 
-    # ------------------------------------------------------------------------------- two batches in flight (one GPU only)
-    # Not `value`: the same step on two independent pipelines (own context = own stream, own placer / aligner / packed read
-    # set, own host thread), each running half of the steps back to back.  What a streaming job over many batches gets: the
-    # latency-bound tail of one batch's align stage and the host round trips between its stages overlap with the other
-    # batch's kernels.  Results per batch are the ones of `value` (same code path, checked below).
-    overlapped = None
-    if world == 1 and not args.no_overlap and not long_reads:
-        try:
-            import threading
-            ctx_b = pmx.Context(local_rank)
-            placer_b = pmx.Placer(ctx_b, index)
-            rs_b = pmx.ReadSet.wrap_device(ctx_b, d_concat.data_ptr(), d_off.data_ptr(), n_reads, int(concat.size), max_len, keepalive=(d_concat, d_off))
-            pipes = [dict(ctx=ctx, placer=placer, rs=rs, aligner=state["aligner"]), dict(ctx=ctx_b, placer=placer_b, rs=rs_b, aligner=None)]
+    def cigar_ops(r_, arena):
+        """every CIGAR operation in record order (the arena is bump-allocated: its layout differs from run to run)"""
+        k = r_["n_cigar"].astype(np.int64)
+        tot = int(k.sum())
+        if tot == 0:
+            return np.zeros(0, np.uint32)
+        first = np.cumsum(k) - k
+        idx = np.repeat(r_["cigar_off"].astype(np.int64) - first, k) + np.arange(tot, dtype=np.int64)
+        return np.asarray(arena).view(np.uint32)[idx]
 
-            def pipe_step(pp):
-                pp["rs"].pack()
-                pp["placer"].reset()
-                pp["placer"].add_reads(pp["rs"], params)
-                res_p = pp["placer"].score(params, total_reads)
-                ref_p = pm.genome(int(res_p.best_index[4]))
-                if pp["aligner"] is None:
-                    pp["aligner"] = pmx.Aligner(pp["ctx"], ref_p, mean_len)
-                else:
-                    pp["aligner"].set_reference(ref_p, mean_len)
-                pp["aligner"].align_readset(pp["rs"], paired=paired, revcomp_mate2=paired)
-                pp["node"] = int(res_p.best_index[4])
-
-            def pipe_run(pp, n):
-                for _ in range(n):
-                    pipe_step(pp)
-                pp["ctx"].synchronize()
-            for pp in pipes:
-                pipe_run(pp, 1)       # warm-up (allocations of the second pipeline)
-            n_each = max(1, args.steps // 2)
-            sync_all()
-            t_o = time.perf_counter()
-            th = [threading.Thread(target=pipe_run, args=(pp, n_each)) for pp in pipes]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            sync_all()
-            el_o = time.perf_counter() - t_o
-            rb, cb = pipes[1]["aligner"].fetch()
-            same = bool(pipes[1]["node"] == int(res.best_index[4]) and np.array_equal(rb["rs"], recs["rs"]) and np.array_equal(rb["mapq"], recs["mapq"])
-                        and np.array_equal(rb["n_cigar"], recs["n_cigar"]))
-            overlapped = dict(value=n_reads * 2 * n_each / el_o, unit="reads/s", ms_per_step=el_o / (2 * n_each) * 1e3, steps=2 * n_each, batches_in_flight=2,
-                              equals_serial_run=same,
-                              note="two pipelines (context/stream + host thread each) alternate batches; every batch goes through the same step as `value`")
-        except Exception as e:     # noqa: BLE001  (an optional figure must not take the bench line down)
-            overlapped = dict(error=str(e)[:200])
-
-    # ------------------------------------------------------------------------------- host -> host (SURVEY 8d metric)
-    h2h = None
-    if not args.no_host_to_host:
-        h_concat = torch.from_numpy(concat).pin_memory()
-        h_off = torch.from_numpy(off).pin_memory()
-        d_concat2 = torch.empty_like(d_concat)
-        d_off2 = torch.empty_like(d_off)
-        copy_stream = torch.cuda.Stream(device=dev)
-        n_chunks = max(1, min(args.h2d_chunks, n_reads // 2 or 1))
-        unit = 2 if paired else 1
-        bounds = [(n_reads // unit) * c // n_chunks * unit for c in range(n_chunks + 1)]
-        out_recs = torch.empty((n_reads, 32), dtype=torch.uint8).pin_memory()
-        out_cig = torch.empty(max(n_reads * 16, int(concat.size) // 4, 4096), dtype=torch.int32).pin_memory()
-        d_recs = torch.empty((n_reads, 32), dtype=torch.uint8, device=dev)
-        d_cig = torch.empty(out_cig.numel(), dtype=torch.int32, device=dev)
-
-        pool = {}   # read set objects reused from step to step (pmx_readset_rewrap_device: no hipMalloc, offsets handled on the device)
-
-        def read_set(key, d_off_ptr, n):
-            if key in pool:
-                pool[key].rewrap_device(d_concat2.data_ptr(), d_off_ptr, n, int(concat.size), max_len)
-            else:
-                pool[key] = pmx.ReadSet.wrap_device(ctx, d_concat2.data_ptr(), d_off_ptr, n, int(concat.size), max_len)
-            return pool[key]
-
-        def step_h2h():
-            # offsets first (8 B per read), then the bases chunk by chunk on the copy stream; chunk c is packed and seeded
-            # on the library's stream as soon as its copy has landed, while chunk c+1 is still in flight
-            evs = []
-            with torch.cuda.stream(copy_stream):
-                d_off2.copy_(h_off, non_blocking=True)
-                ev_off = torch.cuda.Event()
-                ev_off.record(copy_stream)
-                for c in range(n_chunks):
-                    b0, b1 = int(off[bounds[c]]), int(off[bounds[c + 1]])
-                    d_concat2[b0:b1].copy_(h_concat[b0:b1], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(copy_stream)
-                    evs.append(ev)
-            placer.reset()
-            ctx_stream.wait_event(ev_off)
-            parts = []
-            for c in range(n_chunks):
-                r0, r1 = bounds[c], bounds[c + 1]
-                if r1 <= r0:
-                    continue
-                part = read_set(c, d_off2.data_ptr() + 8 * r0, r1 - r0)   # (needs the offsets only)
-                ctx_stream.wait_event(evs[c])
-                part.pack()
-                placer.add_reads(part, params)
-                parts.append(part)
-            whole = read_set("whole", d_off2.data_ptr(), n_reads)
-            whole.pack()
-            aligner = place_and_align(parts, total_reads, mean_len, paired, paired, all_rs=whole)
-            nw = aligner.cigar_words()
-            if dist_on:
-                gather_results(aligner, n_reads)
-            # records + CIGAR arena into pinned host memory
-            aligner.copy_records_device(d_recs.data_ptr(), n_reads)
-            out_recs.copy_(d_recs, non_blocking=True)
-            if nw > out_cig.numel():
-                raise RuntimeError("pinned CIGAR buffer too small")
-            if nw > d_cig.numel():
-                raise RuntimeError("device CIGAR buffer too small")
-            aligner.copy_cigars_device(d_cig.data_ptr(), max(nw, 1))
-            out_cig[:nw].copy_(d_cig[:nw], non_blocking=True)
-            torch.cuda.synchronize()
-            return nw
-
-        for _ in range(max(1, args.warmup)):
-            step_h2h()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            nw_last = step_h2h()
-        sync_all()
-        el2 = max_over_ranks(time.perf_counter() - t0)
-        same = bool(np.array_equal(out_recs.numpy().view(pmx.REC_DTYPE).reshape(-1)["rs"], recs["rs"]) and nw_last == len(cig))
-        for p_ in pool.values():
-            p_.close()
-        h2h = dict(value=total_reads * args.steps / el2, ms_per_step=el2 / args.steps * 1e3, h2d_chunks=n_chunks,
-                   equals_device_resident_run=same,
-                   note="pinned host ASCII + offsets -> H2D in %d chunks on a copy stream (chunk c packed + seeded while chunk c+1 is in flight) "
-                        "-> the same step -> D2H of the 32 B records and the CIGAR arena into pinned host memory" % n_chunks)
+    if rank == 0:
+        same_as_resident = True
+        want_ops = cigar_ops(recs, cig)
+        for pp, r_, nw_, node_ in zip(pipes, h2h_recs, h2h_nw, h2h_nodes):
+            mine = r_[:n_reads]
+            ok = node_ == int(res.best_index[4]) and all(np.array_equal(mine[f], recs[f]) for f in ("rs", "re", "qs", "qe", "mapq", "rev", "proper_frag",
+                                                                                                      "mapped", "n_cigar", "flags", "score"))
+            ok = ok and (nw_ == len(cig) if not dist_on else nw_ >= len(cig))
+            ok = ok and np.array_equal(cigar_ops(mine, pp.out_cig[:nw_].numpy()), want_ops)
+            same_as_resident = bool(same_as_resident and ok)
+        if dist_on:
+            # rank 0 holds every rank's records, and the CIGARs of the other ranks' records are reachable through the rebased offsets
+            gather_ok = bool(all(len(r_) == total_reads for r_ in h2h_recs))
+            for pp, r_, nw_ in zip(pipes, h2h_recs, h2h_nw):
+                k = r_["n_cigar"].astype(np.int64)
+                ops = cigar_ops(r_, pp.out_cig[:nw_].numpy())
+                spans = (r_["re"] - r_["rs"]).astype(np.int64)
+                # reference-consuming operations (M, D, N, =, X) of every record add up to its reference span
+                oplen, opc = (ops >> 4).astype(np.int64), ops & 15
+                ref_len = np.where(np.isin(opc, (0, 2, 3, 7, 8)), oplen, 0)
+                owner = np.repeat(np.arange(len(r_)), k)
+                got = np.bincount(owner, weights=ref_len, minlength=len(r_)).astype(np.int64)
+                has = (r_["flags"] & 4) != 0
+                gather_ok = bool(gather_ok and int(k.sum()) == nw_ and np.array_equal(got[has], spans[has]))
 
     # ------------------------------------------------------------------------------- real reads (one GPU only)
     real = None
@@ -433,14 +607,15 @@ def main():
         r_mean = int(r_off[-1] // len(rr))
         rd_concat = torch.from_numpy(r_concat).to(dev)
         rd_off = torch.from_numpy(r_off).to(dev)
+        ctx = main_pipe.ctx
         rrs = pmx.ReadSet.wrap_device(ctx, rd_concat.data_ptr(), rd_off.data_ptr(), len(rr), int(r_concat.size), int(np.max(np.diff(r_off))),
                                       keepalive=(rd_concat, rd_off))
 
         def step_real():
             rrs.pack()
-            placer.reset()
-            placer.add_reads(rrs, params)     # (canonical seeds: the orientation of R2 does not matter to the place stage)
-            place_and_align([rrs], len(rr), r_mean, True, False)
+            main_pipe.placer.reset()
+            main_pipe.placer.add_reads(rrs, params)     # (canonical seeds: the orientation of R2 does not matter to the place stage)
+            main_pipe.place_and_align(rrs, len(rr), r_mean, True, False)
             ctx.synchronize()
         step_real()
         ctx.synchronize()
@@ -452,91 +627,123 @@ def main():
             al_ms.append(ctx.kernel_ms("align"))
         ctx.synchronize()
         el3 = time.perf_counter() - t0
-        st = state["aligner"].stats()
-        rrecs, _ = state["aligner"].fetch()
+        st = main_pipe.aligner.stats()
+        rrecs, _ = main_pipe.aligner.fetch()
         real = dict(value=len(rr) * n_real_steps / el3, unit="reads/s", reads=len(rr), ms_per_step=el3 / n_real_steps * 1e3,
-                    align_stage_ms=float(np.mean(al_ms)), placed_node=pm.node_id(int(state["res"].best_index[4])),
+                    align_stage_ms=float(np.mean(al_ms)), placed_node=pm.node_id(int(main_pipe.res.best_index[4])),
                     mapped_fraction=float(np.mean(rrecs["mapped"])), records_flagged=int(np.sum((rrecs["flags"] & 3) != 0)),
                     dp_pair_share=st["dp_pairs"] / max(st["n_items"], 1), dp_cells_per_step=st["dp_cells"],
-                    gcups_align_stage=st["dp_cells"] / max(float(np.mean(al_ms)), 1e-9) / 1e6,
+                    gcups_align_stage=st["dp_cells"] / max(float(np.mean(al_ms)), 1e-9) / 1e6, tiers=st,
+                    inputs="resident in HBM (one batch at a time)",
                     workload="tests/golden/isolate_R{1,2}.fastq.gz (2 x 51,169 real reads, mean %d bp, indels / N / adapters) x8, place + align" % r_mean)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_reads * args.steps / elapsed
-        align_ms = float(np.mean(kernel_ms["align"]))
-        dom_ms = float(np.mean(kernel_ms["align_dom"]))
-        seed_ms = float(np.mean(kernel_ms["seed"]))
-        score_ms = float(np.mean(kernel_ms["score"]))
-        # Dominant kernel of the align stage, first launch over every pair of the batch (one launch per step); its duration
-        # is measured with HIP events recorded on the launch stream (pmx_last_kernel_ms "align_dom").  Algorithmic HBM
-        # bytes per read: 2 bit/base packed bases + 1 bit/base ambiguity words in, 32 B record +
-        # 4 B per CIGAR op out (~93 B for a 150 bp read); times the reads of one launch.
-        alg_bytes = n_reads * (mean_len * 3 / 8.0 + 32 + 4.0 * mean_cigar)
-        if dom_ms <= 0:
-            dom_ms = align_ms
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        dom_name = os.environ.get("PMX_BENCH_DOM_KERNEL", "k_align_compact (all pairs)" if not long_reads else "align stage (wave-per-read kernels)")
-        # HBM traffic of that kernel per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-        # runs; profiles/r02/make_pmc_traffic.py writes the json); only valid for the workload it was collected on.
-        traffic = None
-        for rd in ("r02", "r01"):
-            try:
-                with open(os.path.join(ROOT, "profiles", rd, "pmc_traffic.json")) as fh:
-                    pt = json.load(fh)
-                if pt.get("reads_per_gpu") == n_reads and pt.get("read_len") == args.read_len and world == 1:
-                    ent = pt.get("dominant_kernel") or pt.get("k_align_reads_tpp_round0")
-                    traffic = float(ent["hbm_bytes_per_launch"])
-                    dom_name = ent.get("name", dom_name)
-                    break
-            except (OSError, KeyError, ValueError, TypeError):
-                traffic = None
-        dp_cells = float(np.mean([s["dp_cells"] for s in dp_stats]))
-        dp_pairs = float(np.mean([s["dp_pairs"] for s in dp_stats]))
-        n_items = max(dp_stats[-1]["n_items"], 1)
+        # bytes one step moves over PCIe (per rank; rank 0 downloads the gathered records of every rank)
+        up_bytes = int(concat.size) + 8 * (n_reads + 1)
+        down_bytes = 32 * n_out + 4 * max(h2h_nw)
+        t_pcie = max(up_bytes / (pcie["h2d_GBps"] * 1e9), down_bytes / (pcie["d2h_GBps"] * 1e9))
+        pcie.update(h2d_bytes_per_step=up_bytes, d2h_bytes_per_step=down_bytes, bound_reads_per_s=total_reads / t_pcie,
+                    note="pinned host memory, 256 MB copies; bound = total reads / max(H2D time, D2H time) of one step at these rates (rank 0)")
         out = {
-            "metric": "reads placed+aligned/sec, 10M×150bp vs 20k-genome PanMAN, 1/2/4/8 MI355X",
+            "metric": "reads placed+aligned/sec, %gM×%dbp vs 20k-genome PanMAN, 1/2/4/8 MI355X" % (total_reads / 1e6, args.read_len),
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8/i8 DP + u64 hash + f64 score", "data": "synthetic",
-            "config": {"workload": ("%gM x %dbp synthetic %s reads %s vs SARS-CoV-2 20k PanMAN (39,999 nodes), place+align (%s%s)"
+            "config": {"workload": ("%gM x %dbp synthetic %s reads %s vs SARS-CoV-2 20k PanMAN (39,999 nodes), place+align, host memory -> host memory (%s%s)"
                                     % ((total_reads if args.scaling == "strong" else n_reads) / 1e6, args.read_len,
                                        "paired" if paired else "single-end long (2% sub, 1.5% ins, 1.5% del)",
                                        "in total, read-sharded over the ranks" if args.scaling == "strong" else "per GPU",
-                                       "configs[3]" if long_reads else ("configs[2]" if args.scaling == "strong" else "configs[1]"),
+                                       "configs[3]" if long_reads else ("configs[2]" if args.scaling == "strong" and args.total_reads == 10000000 else
+                                                                        ("configs[1]" if n_reads == 1000000 else "custom size")),
                                        "" if world == 1 else "; seed index replicated, RCCL histogram all-gather + record/CIGAR gather")),
                        "reads_per_gpu": n_reads, "total_reads": total_reads, "read_len": args.read_len,
+                       "batches_in_flight": len(pipes), "h2d_chunks": n_chunks,
                        "index": "k=19,s=8,l=3,closed syncmers,flank-mask 250",
                        "aligner_preset": ("k=21,w=11,a=2,b=8,q=12,e=2,q2=24,e2=1 (src/mm_align.c:140-166)" if not long_reads else
                                           "map-hifi / map-ont branch of setup_minimap2 (src/mm_align.c:167-180)")},
-            "value_host_to_host": None if h2h is None else h2h["value"],
-            "host_to_host": h2h,
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": dom_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "mapping kernel (sketch, index probes, chaining, region logic, extension): integer/latency bound by "
-                                 "construction (SURVEY 8d: S3/S4 are not HBM-bound), so the HBM fraction is low; `traffic` is what the "
-                                 "kernel really moves (PMC), `achieved` prices only the compulsory input + output"},
-            "dp": {"pair_share": dp_pairs / n_items, "cells_per_step": dp_cells,
-                   "gcups_align_stage": dp_cells / max(align_ms, 1e-9) / 1e6,
-                   "note": "ksw2 cells counted as q*min(t,2w+1) per DP actually run (SURVEY 8d); extensions / gap fills answered by the "
-                           "proved closed-form shortcuts run no DP and count no cells; GCUPS = cells / whole align-stage time"},
-            "kernels_ms": {"seed stage (k_seed_histogram, chunked)": seed_ms, "score stage (k_score_terms + k_score_chains)": score_ms,
-                           "align stage (all tiers)": align_ms, "dominant align kernel": dom_ms},
-            "two_batches_in_flight": overlapped,
+            "value_is": "host -> host: pinned FASTQ bases + offsets in host memory -> records + CIGAR arena in pinned host memory, %d batch(es) in flight" % len(pipes),
+            "equals_device_resident_run": same_as_resident,
+            "value_device_resident": None if resident is None else resident["value"],
+            "device_resident": resident,
+            "pcie": pcie,
+            "value_over_min_of_resident_and_pcie_bound": None if resident is None else value / min(resident["value"], pcie["bound_reads_per_s"]),
+        }
+        if resident is not None:
+            align_ms = float(np.mean(kernel_ms["align"]))
+            dom_ms = float(np.mean(kernel_ms["align_dom"]))
+            seed_ms = float(np.mean(kernel_ms["seed"]))
+            score_ms = float(np.mean(kernel_ms["score"]))
+            # Dominant kernel of the align stage, first launch over every pair of the batch (one launch per step); its duration
+            # is measured with HIP events recorded on the launch stream (pmx_last_kernel_ms "align_dom").  Algorithmic HBM
+            # bytes per read: 2 bit/base packed bases + 1 bit/base ambiguity words in, 32 B record +
+            # 4 B per CIGAR op out (~93 B for a 150 bp read); times the reads of one launch.
+            alg_bytes = n_reads * (mean_len * 3 / 8.0 + 32 + 4.0 * mean_cigar)
+            if dom_ms <= 0:
+                dom_ms = align_ms
+            achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+            dom_name = "k_align_compact16 (all pairs)" if not long_reads else "k_align_reads_w4 (wave per read)"
+            # HBM traffic and wave-instruction counts of that kernel per launch from the PMC passes (rocprofv3 --pmc in separate
+            # runs; profiles/rNN/make_pmc_traffic.py writes the json): quoted only for the workload AND the sources it was
+            # collected on (source_digest), otherwise null.
+            traffic, valu = None, None
+            digest = source_digest()
+            try:
+                with open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")) as fh:
+                    pt = json.load(fh)
+                if pt.get("reads_per_gpu") == n_reads and pt.get("read_len") == args.read_len and world == 1 and pt.get("source_digest") == digest:
+                    ent = pt["dominant_kernel"]
+                    traffic = float(ent["hbm_bytes_per_launch"])
+                    if ent.get("valu_wave_insts_per_launch"):
+                        props = torch.cuda.get_device_properties(dev)
+                        clock_hz = float(getattr(props, "clock_rate", 0)) * 1e3 or 2.4e9
+                        simds = props.multi_processor_count * 4
+                        # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD that holds >= 2 waves
+                        slots = simds * clock_hz / 2.0 * dom_ms * 1e-3
+                        valu = {"bound": "valu-issue", "kernel": dom_name, "valu_wave_insts": ent["valu_wave_insts_per_launch"],
+                                "salu_wave_insts": ent.get("salu_wave_insts_per_launch"), "simds": simds, "clock_hz": clock_hz,
+                                "cycles_per_wave64_valu": 2, "issue_slots": slots, "frac": ent["valu_wave_insts_per_launch"] / slots,
+                                "wait_any_share_of_wave_cycles": ent.get("wait_any_share")}
+            except (OSError, KeyError, ValueError, TypeError):
+                traffic, valu = None, None
+            dp_cells = float(np.mean([s["dp_cells"] for s in dp_stats]))
+            dp_pairs = float(np.mean([s["dp_pairs"] for s in dp_stats]))
+            n_items = max(dp_stats[-1]["n_items"], 1)
+            out.update({
+                "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0,
+                             "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": dom_ms,
+                             "algorithmic_bytes_per_launch": alg_bytes, "source_digest": digest,
+                             "note": "mapping kernel (sketch, index probes, chaining, region logic, extension): integer/latency bound by "
+                                     "construction (SURVEY 8d: S3/S4 are not HBM-bound), so the HBM fraction is low; `traffic` is what the "
+                                     "kernel really moves (PMC), `achieved` prices only the compulsory input + output"},
+                "roofline_valu": valu,
+                "dp": {"pair_share": dp_pairs / n_items, "cells_per_step": dp_cells,
+                       "gcups_align_stage": dp_cells / max(align_ms, 1e-9) / 1e6,
+                       "note": "ksw2 cells counted as q*min(t,2w+1) per DP actually run (SURVEY 8d); extensions / gap fills answered by the "
+                               "proved closed-form shortcuts run no DP and count no cells; GCUPS = cells / whole align-stage time"},
+                "kernels_ms": {"seed stage (k_seed_histogram, chunked)": seed_ms, "score stage (k_score_terms + k_score_chains)": score_ms,
+                               "align stage (all tiers)": align_ms, "dominant align kernel": dom_ms,
+                               "note": "HIP-event durations in the device-resident run (one batch at a time)"},
+            })
+        else:
+            out.update({"roofline": None, "roofline_valu": None})
+        out.update({
             "real_reads": real,
             "checks": {"placed_node": placed_id, "mapped_fraction": mapped_frac, "records_flagged": flagged,
                        "unique_seeds": int(res.n_unique_seeds), "kept_seeds": int(res.readUniqueSeedCount),
                        "tiers": dp_stats[-1], "rank0_gather_has_every_cigar": gather_ok},
-        }
+        })
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported by the 1-GPU run only
-            threads = max(1, os.cpu_count() or 1)     # all host cores, uncapped
+            threads, quota = usable_cpus()
             sample = args.cpu_sample or (int(min(n_reads, max(20000, 60000 * threads))) if not long_reads else int(min(n_reads, max(200, 150 * threads))))
-            out["cpu_baseline"] = cpu_baseline(concat, off, index.arrays(), state["ref"], sample, threads, paired)
+            out["cpu_baseline"] = cpu_baseline(concat, off, index.arrays(), placed_ref, sample, threads, paired, quota)
         else:
             out["cpu_baseline"] = None
     else:
         out = None
+    for pp in pipes:
+        pp.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
