@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=1000000, help="--scaling weak: reads per rank (BASELINE configs[1])")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--pipelines", type=int, default=0, help="batches in flight (0 = 2 for short reads, 1 for long reads)")
-    ap.add_argument("--h2d-chunks", type=int, default=0, help="H2D chunks per batch (0 = one per ~1M reads, at least 4)")
+    ap.add_argument("--h2d-chunks", type=int, default=0, help="H2D chunks per batch (default 1)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads of the CPU baseline sample (0 = sized for ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-reads", action="store_true")
@@ -250,12 +250,15 @@ def main():
     mean_len = int(off[-1] // max(n_reads, 1))
     total_reads = n_reads * world if args.scaling == "weak" else args.total_reads // unit * unit
     n_pipes = args.pipelines or (1 if long_reads else 2)
-    n_chunks = args.h2d_chunks or max(4, (n_reads + 999999) // 1000000)
+    # (one chunk by default: with two batches in flight the upload of a batch overlaps the kernels of the other one, and a
+    # batch seeded as a whole sizes its seed table once; --h2d-chunks > 1 packs + seeds range by range behind the copies)
+    n_chunks = args.h2d_chunks or 1
     n_chunks = max(1, min(n_chunks, n_reads // unit or 1))
     bounds = [(n_reads // unit) * c // n_chunks * unit for c in range(n_chunks + 1)]
 
     params = pmx.TraversalParams()
     host_times = {} if os.environ.get("PMX_BENCH_HOST_TIMES") else None   # diagnostic: serialised per-phase wall times
+    trace = [] if os.environ.get("PMX_BENCH_TRACE") else None             # diagnostic: host time stamps of the host->host phases
 
     # ------------------------------------------------------------------------------------------------- PCIe of this box
     def measure_pcie(nbytes=256 << 20, reps=3):
@@ -303,8 +306,10 @@ def main():
             self.stream = torch.cuda.ExternalStream(self.ctx.stream, device=dev) if self.ctx.stream else torch.cuda.current_stream(dev)
             self.copy_in = torch.cuda.Stream(device=dev)
             self.copy_out = torch.cuda.Stream(device=dev)
-            self.d_concat = torch.empty(int(concat.size), dtype=torch.uint8, device=dev)
-            self.d_off = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
+            # two staging slots: batch j+1 is uploaded into the other slot while batch j computes (double buffering)
+            self.d_concat = [torch.empty(int(concat.size), dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.d_off = [torch.empty(n_reads + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+            self.up_ev = [None, None]
             self.d_recs = torch.empty((n_reads, 32), dtype=torch.uint8, device=dev)
             self.d_cig = None
             self.out_recs = None
@@ -313,6 +318,7 @@ def main():
             self.res = None
             self.ref = None
             self.gathered = None
+            self.keep = None
             self.nw = 0
 
         def alloc_outputs(self):
@@ -399,33 +405,55 @@ def main():
             self.ctx.synchronize()
 
         # ---- the step of `value`: host memory -> host memory
-        def run_h2h(self, seq=None, batch=0):
+        def upload(self, slot):
+            """enqueue the H2D copies of one batch into a staging slot (copy-in stream): offsets first (8 B per read), then
+            the bases chunk by chunk"""
             evs = []
             with torch.cuda.stream(self.copy_in):
-                # offsets first (8 B per read), then the bases chunk by chunk; chunk c is packed and seeded on the
-                # library's stream as soon as its copy has landed, while chunk c+1 is still in flight
-                self.d_off.copy_(h_off, non_blocking=True)
+                self.d_off[slot].copy_(h_off, non_blocking=True)
                 ev_off = torch.cuda.Event()
                 ev_off.record(self.copy_in)
                 for c in range(n_chunks):
                     b0, b1 = int(off[bounds[c]]), int(off[bounds[c + 1]])
-                    self.d_concat[b0:b1].copy_(h_concat[b0:b1], non_blocking=True)
+                    self.d_concat[slot][b0:b1].copy_(h_concat[b0:b1], non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self.copy_in)
                     evs.append(ev)
+            self.up_ev[slot] = (ev_off, evs)
+
+        def run_h2h(self, seq=None, batch=0, slot=0, prefetch_next=False):
+            tr = [("start", time.perf_counter())] if trace is not None else None
+            if self.up_ev[slot] is None:
+                self.upload(slot)                 # the first batch of a run: nothing was prefetched
+            if prefetch_next:
+                self.upload(slot ^ 1)             # the next batch of this pipeline travels while this one computes
+            ev_off, evs = self.up_ev[slot]
+            self.up_ev[slot] = None
+            if tr is not None:
+                tr.append(("h2d_enqueued", time.perf_counter()))
             self.placer.reset()
             self.stream.wait_event(ev_off)
-            for c in range(n_chunks):
-                r0, r1 = bounds[c], bounds[c + 1]
-                if r1 <= r0:
-                    continue
-                part = self.read_set(c, self.d_concat, self.d_off.data_ptr() + 8 * r0, r1 - r0)   # (needs the offsets only)
-                self.stream.wait_event(evs[c])
-                part.pack()
-                self.placer.add_reads(part, params)
-            whole = self.read_set("whole", self.d_concat, self.d_off.data_ptr(), n_reads)
-            whole.pack()
+            # ONE read set over the whole staging buffer (word offsets from the device-resident offsets)
+            whole = self.read_set(("whole", slot), self.d_concat[slot], self.d_off[slot].data_ptr(), n_reads)
+            if n_chunks == 1:
+                self.stream.wait_event(evs[0])
+                whole.pack()
+                self.placer.add_reads(whole, params)
+            else:
+                # its reads are packed and seeded range by range as the chunks land (pmx_readset_pack_range /
+                # pmx_place_add_reads_range)
+                for c in range(n_chunks):
+                    r0, r1 = bounds[c], bounds[c + 1]
+                    if r1 <= r0:
+                        continue
+                    self.stream.wait_event(evs[c])
+                    whole.pack_range(r0, r1)
+                    self.placer.add_reads_range(whole, r0, r1, params)
+            if tr is not None:
+                tr.append(("seeded", time.perf_counter()))
             self.place_and_align(whole, total_reads, mean_len, paired, paired, seq=seq, batch=batch)
+            if tr is not None:
+                tr.append(("aligned", time.perf_counter()))
             al = self.aligner
             if dist_on:
                 if seq is not None:
@@ -443,6 +471,7 @@ def main():
                 ev_done.record(torch.cuda.current_stream(dev))
             else:
                 nw = al.cigar_words()
+                self.copy_out.synchronize()       # (the previous batch's download read d_recs / d_cig: long finished)
                 al.copy_records_device(self.d_recs.data_ptr(), n_reads)
                 if self.d_cig is None or self.d_cig.numel() < max(nw, 1):
                     self.d_cig = torch.empty(max(nw, 1) * 5 // 4 + 1024, dtype=torch.int32, device=dev)
@@ -452,14 +481,22 @@ def main():
                 ev_done.record(self.stream)
             if nw > self.out_cig.numel():
                 raise RuntimeError("pinned CIGAR buffer too small")
-            # records + CIGAR arena into pinned host memory, on the pipeline's own download stream
+            # records + CIGAR arena into pinned host memory on the pipeline's own download stream; the pipeline goes on with
+            # its next batch and waits for the download when it needs the buffers again (finish() at the end of a run)
             with torch.cuda.stream(self.copy_out):
                 self.copy_out.wait_event(ev_done)
                 self.out_recs[:src_recs.shape[0]].copy_(src_recs, non_blocking=True)
                 self.out_cig[:nw].copy_(src_cig[:nw], non_blocking=True)
-            self.copy_out.synchronize()
+            self.keep = (src_recs, src_cig)       # (alive until the copies have run)
+            if tr is not None:
+                tr.append(("d2h_enqueued", time.perf_counter()))
+                trace.append((id(self), batch, tr))
             self.nw = nw
             return nw
+
+        def finish(self):
+            self.copy_out.synchronize()
+            self.ctx.synchronize()
 
         def close(self):
             for p_ in self.pool.values():
@@ -485,28 +522,30 @@ def main():
         return float(tt.item())
 
     def run_batches(n_batches):
-        """n_batches steps over the pipelines: pipeline p takes the batches p, p + P, p + 2P, ..."""
-        if len(pipes) == 1:
-            for b in range(n_batches):
-                pipes[0].run_h2h(None, b)
-            return
-        seq = Sequencer(n_batches) if dist_on else None
+        """n_batches steps over the pipelines: pipeline p takes the batches p, p + P, p + 2P, ... and uploads its next batch
+        while it computes the current one; all downloads have landed when this returns"""
+        seq = Sequencer(n_batches) if (dist_on and len(pipes) > 1) else None
         errs = []
 
         def work(p):
             try:
                 torch.cuda.set_device(local_rank)
-                for b in range(p, n_batches, len(pipes)):
-                    pipes[p].run_h2h(seq, b)
+                mine = list(range(p, n_batches, len(pipes)))
+                for j, b in enumerate(mine):
+                    pipes[p].run_h2h(seq, b, slot=j & 1, prefetch_next=j + 1 < len(mine))
+                pipes[p].finish()
             except BaseException as e:   # noqa: BLE001
                 errs.append(e)
                 if seq is not None:
                     seq.fail(e)
-        th = [threading.Thread(target=work, args=(p,)) for p in range(len(pipes))]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        if len(pipes) == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(p,)) for p in range(len(pipes))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
         if errs:
             raise errs[0]
 
@@ -519,6 +558,10 @@ def main():
     run_batches(args.steps)
     sync_all()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    if trace is not None and rank == 0:
+        for pid, b, tr in sorted(trace, key=lambda x: x[2][0][1])[-2 * len(pipes) - 2:]:
+            print("[bench trace] pipe %x batch %d: " % (pid & 0xffff, b) + " ".join("%s=+%.1fms" % (nm, (t - tr[0][1]) * 1e3) for nm, t in tr[1:])
+                  + " (start at %.1f ms)" % ((tr[0][1] - t0) * 1e3), file=sys.stderr)
     h2h_recs = [None if pp.out_recs is None else pp.out_recs.numpy().view(pmx.REC_DTYPE).reshape(-1) for pp in pipes]
     h2h_nw = [pp.nw for pp in pipes]
     h2h_nodes = [None if pp.res is None else int(pp.res.best_index[4]) for pp in pipes]

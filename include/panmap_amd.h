@@ -101,7 +101,8 @@ typedef struct pmx_ctx pmx_ctx;
 int pmx_ctx_create(int device_ordinal, pmx_ctx **out);
 void pmx_ctx_destroy(pmx_ctx *ctx);
 int pmx_ctx_synchronize(pmx_ctx *ctx);
-/* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */
+/* the HIP stream all kernels of this context are launched on (hipStream_t as void*).  Every context owns a hardware queue
+   (a CU-masked stream with every CU enabled): contexts used from different host threads overlap their kernels. */
 void *pmx_ctx_stream(pmx_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------
@@ -121,6 +122,10 @@ int pmx_readset_wrap_device(pmx_ctx *ctx, const void *d_concat, const void *d_of
 int pmx_readset_rewrap_device(pmx_ctx *ctx, pmx_readset *rs, const void *d_concat, const void *d_offsets, int64_t n_reads,
                               int64_t total_bytes, int64_t max_read_len);
 int pmx_readset_pack(pmx_ctx *ctx, pmx_readset *rs);
+/* streaming form of the same: pack the reads [r0, r1) of a (re)wrapped read set as soon as THEIR bases have landed in the
+   wrapped buffer (the offsets of the whole set are in place since the wrap); the set counts as packed once the ranges
+   cover it.  Stream-ordered on the context's stream, no host round trip. */
+int pmx_readset_pack_range(pmx_ctx *ctx, pmx_readset *rs, int64_t r0, int64_t r1);
 /* FASTQ quality strings of the same reads (same offsets; one Phred+33 byte per base): only needed for
  * pmx_place_params.min_seed_quality > 0 (allReadQualities, src/placement.cpp:1386) */
 int pmx_readset_set_qualities(pmx_ctx *ctx, pmx_readset *rs, const char *qual_concat);
@@ -168,6 +173,11 @@ void pmx_place_free(pmx_ctx *ctx, pmx_place *pl);
    Accumulates into the place object's device histogram; call once per read shard. */
 int pmx_place_reset(pmx_ctx *ctx, pmx_place *pl);
 int pmx_place_add_reads(pmx_ctx *ctx, pmx_place *pl, const pmx_readset *rs, const pmx_place_params *pp);
+/* the reads [r0, r1) of the set alone (packed by pmx_readset_pack or pmx_readset_pack_range): a batch is seeded range by
+   range while the H2D copy of the next range is in flight; the sum over the ranges is the histogram of the set.
+   --dedup needs the whole set (PMX_ERR_UNSUPPORTED on a proper sub-range). */
+int pmx_place_add_reads_range(pmx_ctx *ctx, pmx_place *pl, const pmx_readset *rs, int64_t r0, int64_t r1,
+                              const pmx_place_params *pp);
 /* export / import of the (hash,count) histogram, ascending hash: the multi-GPU exchange step
    (all-gather of per-rank histograms, then merge) */
 int64_t pmx_place_histogram_size(pmx_ctx *ctx, pmx_place *pl);

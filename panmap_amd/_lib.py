@@ -122,12 +122,14 @@ SIGNATURES = {
     "pmx_readset_wrap_device": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _PP]),
     "pmx_readset_set_qualities": (_i32, [_vp, _vp, _vp]),
     "pmx_readset_pack": (_i32, [_vp, _vp]),
+    "pmx_readset_pack_range": (_i32, [_vp, _vp, _i64, _i64]),
     "pmx_readset_free": (None, [_vp, _vp]),
     "pmx_readset_num_reads": (_i64, [_vp]),
     "pmx_place_create": (_i32, [_vp, _vp, _PP]),
     "pmx_place_free": (None, [_vp, _vp]),
     "pmx_place_reset": (_i32, [_vp, _vp]),
     "pmx_place_add_reads": (_i32, [_vp, _vp, _vp, C.POINTER(PlaceParams)]),
+    "pmx_place_add_reads_range": (_i32, [_vp, _vp, _vp, _i64, _i64, C.POINTER(PlaceParams)]),
     "pmx_place_histogram_size": (_i64, [_vp, _vp]),
     "pmx_place_histogram_export": (_i32, [_vp, _vp, _vp, _vp, _i64]),
     "pmx_place_histogram_merge": (_i32, [_vp, _vp, _vp, _vp, _i64]),

@@ -389,6 +389,10 @@ class ReadSet:
     def pack(self):
         check(lib.pmx_readset_pack(self.ctx._h, self._h), "pmx_readset_pack")
 
+    def pack_range(self, r0: int, r1: int):
+        """streaming: pack the reads [r0, r1) alone (their bases have landed in the wrapped buffer)"""
+        check(lib.pmx_readset_pack_range(self.ctx._h, self._h, int(r0), int(r1)), "pmx_readset_pack_range")
+
     def set_qualities(self, quals):
         """attach the FASTQ quality strings (list of bytes, same lengths as the reads) for --min-seed-quality"""
         qc = b"".join(quals)
@@ -468,6 +472,11 @@ class Placer:
     def add_reads(self, rs: ReadSet, params: TraversalParams = TraversalParams()):
         cp = params.to_c()
         check(lib.pmx_place_add_reads(self.ctx._h, self._h, rs._h, C.byref(cp)), "pmx_place_add_reads")
+
+    def add_reads_range(self, rs: ReadSet, r0: int, r1: int, params: TraversalParams = TraversalParams()):
+        """seed the reads [r0, r1) of a read set (packed so far) into the histogram"""
+        cp = params.to_c()
+        check(lib.pmx_place_add_reads_range(self.ctx._h, self._h, rs._h, int(r0), int(r1), C.byref(cp)), "pmx_place_add_reads_range")
 
     def histogram(self):
         n = lib.pmx_place_histogram_size(self.ctx._h, self._h)

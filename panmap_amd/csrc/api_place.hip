@@ -31,9 +31,9 @@ struct pmx_place {
     std::vector<uint8_t> h_has_child;
     uint64_t root_beg = 0, root_end = 0;
     // seed table
-    DevBuf<uint64_t> keys;
-    DevBuf<unsigned long long> vals;
-    uint64_t cap = 0;
+    DevBuf<uint64_t> keys, keys_spare;
+    DevBuf<unsigned long long> vals, vals_spare;
+    uint64_t cap = 0;                      // logical table size (power of two); the buffers may be larger
     DevBuf<unsigned long long> counters;   // PMX_CTR_N
     int64_t n_reads_added = 0;
     bool table_dirty = false;              // something was inserted since the last reset
@@ -92,9 +92,12 @@ int fail(int code, const std::string& msg) {
     catch (const HipError& e) { return fail(PMX_ERR_DEVICE, e.msg); }  \
     catch (const std::exception& e) { return fail(PMX_ERR_DEVICE, e.what()); }
 
+// (the device memory stays at its high-water mark: a batch whose ranges want a small, then a large table would otherwise
+// free and allocate gigabytes per batch -- hipFree synchronises the device, and a fresh allocation of that size takes
+// hundreds of milliseconds; `cap` is the logical size, a power of two)
 void table_alloc(pmx_ctx* ctx, pmx_place* pl, uint64_t cap) {
-    pl->keys.alloc(cap);
-    pl->vals.alloc(cap);
+    pl->keys.ensure(cap);
+    pl->vals.ensure(cap);
     pl->cap = cap;
     hipLaunchKernelGGL(k_fill_u64, dim3(grid_for((int64_t)cap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->keys.p, PMX_EMPTY_KEY, cap);
     PMX_HIP(hipMemsetAsync(pl->vals.p, 0, cap * sizeof(unsigned long long), ctx->stream));
@@ -131,8 +134,9 @@ void table_reserve(pmx_ctx* ctx, pmx_place* pl, uint64_t bound_new) {
         table_alloc(ctx, pl, need);
         return;
     }
-    DevBuf<uint64_t> okeys;
-    DevBuf<unsigned long long> ovals;
+    // the old table moves to the spare pair of buffers (kept for the next rehash), the new one takes the other pair
+    DevBuf<uint64_t>& okeys = pl->keys_spare;
+    DevBuf<unsigned long long>& ovals = pl->vals_spare;
     okeys.swap(pl->keys);
     ovals.swap(pl->vals);
     const uint64_t ocap = pl->cap;
@@ -140,7 +144,7 @@ void table_reserve(pmx_ctx* ctx, pmx_place* pl, uint64_t bound_new) {
     PMX_HIP(hipMemsetAsync(pl->counters.p + PMX_CTR_SHARD0, 0, sizeof(unsigned long long) * PMX_CTR_NSHARD, ctx->stream));
     hipLaunchKernelGGL(k_table_rehash, dim3(grid_for((int64_t)ocap, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, okeys.p, ovals.p, ocap,
                        pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p);
-    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    PMX_HIP(hipGetLastError());
 }
 
 // table -> hash-sorted (hash,count) arrays
@@ -203,18 +207,40 @@ struct Best {
 }  // namespace
 
 namespace pmx {
+// keys + stable radix sort of the reads [r0, r1): their slice of loc_perm then holds them (absolute indices) in locality order
+static void order_range(pmx_ctx* ctx, const pmx_readset* rs, int64_t r0, int64_t r1) {
+    const int64_t n = rs->n, m = r1 - r0;
+    rs->loc_key.ensure((size_t)n); rs->loc_key2.ensure((size_t)n); rs->loc_idx.ensure((size_t)n); rs->loc_perm.ensure((size_t)n);
+    if (m <= 0) return;
+    hipLaunchKernelGGL(k_read_prefix_keys, dim3(grid_for(m, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rs->words.p, rs->woff.p, r0, r1, rs->loc_key.p,
+                       rs->loc_idx.p);
+    size_t bytes = 0;
+    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, rs->loc_key.p + r0, rs->loc_key2.p + r0, rs->loc_idx.p + r0, rs->loc_perm.p + r0, (size_t)m, 0, 32, ctx->stream));
+    rs->loc_tmp.ensure(bytes);
+    PMX_HIP(rocprim::radix_sort_pairs(rs->loc_tmp.p, bytes, rs->loc_key.p + r0, rs->loc_key2.p + r0, rs->loc_idx.p + r0, rs->loc_perm.p + r0, (size_t)m, 0, 32, ctx->stream));
+}
+
 const uint32_t* readset_locality_order(pmx_ctx* ctx, const pmx_readset* rs) {
     const int64_t n = rs->n;
     if (!rs->packed || n < 4096 || n >= (int64_t)UINT32_MAX) return nullptr;
     if (rs->has_order) return rs->loc_perm.p;
-    rs->loc_key.ensure((size_t)n); rs->loc_key2.ensure((size_t)n); rs->loc_idx.ensure((size_t)n); rs->loc_perm.ensure((size_t)n);
-    hipLaunchKernelGGL(k_read_prefix_keys, dim3(grid_for(n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rs->words.p, rs->woff.p, n, rs->loc_key.p,
-                       rs->loc_idx.p);
-    size_t bytes = 0;
-    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, rs->loc_key.p, rs->loc_key2.p, rs->loc_idx.p, rs->loc_perm.p, (size_t)n, 0, 32, ctx->stream));
-    rs->loc_tmp.ensure(bytes);
-    PMX_HIP(rocprim::radix_sort_pairs(rs->loc_tmp.p, bytes, rs->loc_key.p, rs->loc_key2.p, rs->loc_idx.p, rs->loc_perm.p, (size_t)n, 0, 32, ctx->stream));
+    order_range(ctx, rs, 0, n);
+    rs->ordered_ranges.clear();
+    rs->ordered_ranges.add(0, n);
     rs->has_order = true;
+    return rs->loc_perm.p;
+}
+
+const uint32_t* readset_locality_order_range(pmx_ctx* ctx, const pmx_readset* rs, int64_t r0, int64_t r1) {
+    const int64_t n = rs->n;
+    if (n < 4096 || n >= (int64_t)UINT32_MAX || r1 - r0 < 4096) return nullptr;
+    if (rs->has_order || rs->ordered_ranges.covers(r0, r1)) return rs->loc_perm.p;
+    if (!rs->packed && !rs->packed_ranges.covers(r0, r1)) return nullptr;
+    // the larger buffers may be re-made by ensure(): only before the first range of a set
+    if (rs->ordered_ranges.iv.empty()) { rs->loc_key.ensure((size_t)n); rs->loc_key2.ensure((size_t)n); rs->loc_idx.ensure((size_t)n); rs->loc_perm.ensure((size_t)n); }
+    order_range(ctx, rs, r0, r1);
+    rs->ordered_ranges.add(r0, r1);
+    if (rs->ordered_ranges.covers(0, n)) rs->has_order = true;
     return rs->loc_perm.p;
 }
 }  // namespace pmx
@@ -234,7 +260,7 @@ int pmx_ctx_create(int device_ordinal, pmx_ctx** out) {
     hipDeviceProp_t prop;
     PMX_HIP(hipGetDeviceProperties(&prop, device_ordinal));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    PMX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->stream = create_dedicated_stream(c->n_cu);   // a hardware queue of its own: contexts overlap their kernels
     *out = c;
     return PMX_OK;
     PMX_CATCH
@@ -352,6 +378,8 @@ int pmx_readset_rewrap_device(pmx_ctx* ctx, pmx_readset* rs, const void* d_conca
     PMX_HIP(hipSetDevice(ctx->device));
     rs->packed = false;
     rs->has_order = false;
+    rs->packed_ranges.clear();
+    rs->ordered_ranges.clear();
     rs->has_qual = false;
     rs->n = n_reads;
     rs->ascii.wrap((uint8_t*)d_concat, (size_t)total_bytes);
@@ -404,10 +432,36 @@ int pmx_readset_pack(pmx_ctx* ctx, pmx_readset* rs) {
     PMX_HIP(hipSetDevice(ctx->device));
     if (rs->n_words > 0)
         hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(rs->n_words, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p,
-                           rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p);
+                           rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p, (int64_t)0, (int64_t)-1);
     PMX_HIP(hipGetLastError());
     rs->packed = true;
     rs->has_order = false;   // (the buffer behind a wrapped read set may hold new reads)
+    rs->packed_ranges.clear();
+    rs->packed_ranges.add(0, rs->n);
+    rs->ordered_ranges.clear();
+    return PMX_OK;
+    PMX_CATCH
+}
+
+// streaming: the reads [r0, r1) alone (their bases have landed; the offsets of the whole set are in place since the
+// (re)wrap).  The word range comes from the device-side word offsets: no host round trip.
+int pmx_readset_pack_range(pmx_ctx* ctx, pmx_readset* rs, int64_t r0, int64_t r1) {
+    if (!ctx || !rs || r0 < 0 || r1 < r0 || r1 > rs->n) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    if (r1 > r0 && rs->n_words > 0) {
+        // grid sized by the range's share of the words (exact for reads of one length; any grid is correct: the kernel strides)
+        const int64_t est = (int64_t)((double)rs->n_words * (double)(r1 - r0) / (double)std::max<int64_t>(rs->n, 1)) + 1;
+        hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(est, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p,
+                           rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p, r0, r1);
+        PMX_HIP(hipGetLastError());
+    }
+    if (rs->packed) {   // re-packing part of a packed set: the order of those reads may have changed
+        rs->has_order = false;
+        rs->ordered_ranges.clear();
+    }
+    rs->packed_ranges.add(r0, r1);
+    if (rs->packed_ranges.covers(0, rs->n)) rs->packed = true;
     return PMX_OK;
     PMX_CATCH
 }
@@ -540,9 +594,11 @@ int pmx_place_reset(pmx_ctx* ctx, pmx_place* pl) {
     PMX_CATCH
 }
 
-int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, const pmx_place_params* pp) {
-    if (!ctx || !pl || !rs || !pp) return PMX_ERR_ARG;
-    if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack first)");
+static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, int64_t rr0, int64_t rr1, const pmx_place_params* pp) {
+    if (!ctx || !pl || !rs || !pp || rr0 < 0 || rr1 < rr0 || rr1 > rs->n) return PMX_ERR_ARG;
+    const bool whole = rr0 == 0 && rr1 == rs->n;
+    if (!rs->packed && !rs->packed_ranges.covers(rr0, rr1)) return fail(PMX_ERR_ARG, "read set is not packed (call pmx_readset_pack / pmx_readset_pack_range first)");
+    if (!whole && pp->dedup_reads) return fail(PMX_ERR_UNSUPPORTED, "--dedup collapses duplicates over a whole read set: seed it with pmx_place_add_reads");
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     pl->h_ctr_valid = false;
@@ -555,7 +611,7 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
     if (lds > 160 * 1024) return fail(PMX_ERR_UNSUPPORTED, "k-s+1 too large for the LDS ring");
     if (lds > 64 * 1024)
         PMX_HIP(hipFuncSetAttribute((const void*)k_seed_histogram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (rs->n > 0) {
+    if (rr1 > rr0) {
         // Reads go in chunks of <= ~64M bases, three at a time.  Before each group the table is grown (rehash) if the distinct
         // keys seen so far plus one new key per base of the chunk would push the load factor past 0.7, so an
         // insert can never fail, yet the table is sized by what the reads actually contain (a few million
@@ -606,7 +662,7 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         // seeding order (default-parameter kernel): reads that start with the same 16 bases next to each other, so that a
         // block's (seed, count) cache sees its seeds many times (k_seed_histogram_ks)
         const bool ks_path = sp.k == 19 && sp.s == 8 && sp.t == 0 && (l == 3 || l == 1) && !quality_mode && !getenv("PMX_SEED_GENERIC");
-        const uint32_t* perm = ks_path && !getenv("PMX_SEED_NO_SORT") ? readset_locality_order(ctx, rs) : nullptr;
+        const uint32_t* perm = ks_path && !getenv("PMX_SEED_NO_SORT") ? (whole ? readset_locality_order(ctx, rs) : readset_locality_order_range(ctx, rs, rr0, rr1)) : nullptr;
         // the specialised kernel keeps its rings in registers: LDS = the waves' seed queues + the block cache (keys 8 B +
         // counts 4 B + admission tags 2 B per entry)
         const size_t lds_ks = (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS * sizeof(uint64_t) + (size_t)PMX_SEED_CACHE * 14 + 35 * sizeof(uint64_t);   // + the base-hash tables
@@ -617,13 +673,13 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         if (const char* e = getenv("PMX_SEED_PAR")) n_par = std::max(1, std::min(4, atoi(e)));
         if (n_par > 1 && !pl->seed_go) {
             PMX_HIP(hipEventCreateWithFlags(&pl->seed_go, hipEventDisableTiming));
-            for (int j = 0; j < 3; ++j) {
-                PMX_HIP(hipStreamCreateWithFlags(&pl->seed_streams[j], hipStreamNonBlocking));
+            for (int j = 0; j < n_par - 1 && j < 3; ++j) {   // (own hardware queues: see create_dedicated_stream)
+                pl->seed_streams[j] = create_dedicated_stream(ctx->n_cu);
                 PMX_HIP(hipEventCreateWithFlags(&pl->seed_done[j], hipEventDisableTiming));
             }
         }
-        for (int64_t g0 = 0; g0 < rs->n; g0 += chunk_reads * n_par) {
-            const int64_t g1 = std::min<int64_t>(rs->n, g0 + chunk_reads * n_par);
+        for (int64_t g0 = rr0; g0 < rr1; g0 += chunk_reads * n_par) {
+            const int64_t g1 = std::min<int64_t>(rr1, g0 + chunk_reads * n_par);
             const double safe_bound = (double)(g1 - g0) * (double)rs->max_len;
             table_reserve(ctx, pl, (uint64_t)(bound_div > 1 && bound_frac > 0 ? safe_bound * bound_frac : safe_bound / (double)bound_div) + 1);
             if (n_par > 1) PMX_HIP(hipEventRecord(pl->seed_go, ctx->stream));
@@ -668,12 +724,21 @@ int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, cons
         }
         timer_end(ctx, "seed", 1);
     }
-    pl->n_reads_added += rs->n;
-    pl->bases_added += (double)rs->n * (double)rs->max_len;
+    pl->n_reads_added += rr1 - rr0;
+    pl->bases_added += (double)(rr1 - rr0) * (double)rs->max_len;
     pl->hist_sorted = false;
     pl->table_dirty = true;
     return PMX_OK;
     PMX_CATCH
+}
+
+int pmx_place_add_reads(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, const pmx_place_params* pp) {
+    if (!rs) return PMX_ERR_ARG;
+    return add_reads_impl(ctx, pl, rs, 0, rs->n, pp);
+}
+
+int pmx_place_add_reads_range(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, int64_t r0, int64_t r1, const pmx_place_params* pp) {
+    return add_reads_impl(ctx, pl, rs, r0, r1, pp);
 }
 
 int64_t pmx_place_histogram_size(pmx_ctx* ctx, pmx_place* pl) {

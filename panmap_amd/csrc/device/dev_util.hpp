@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -57,6 +58,25 @@ struct DevBuf {
         std::swap(owned, o.owned);
     }
 };
+
+// A stream with a HARDWARE queue of its own.  HIP multiplexes ordinary streams onto a few hardware queues
+// (GPU_MAX_HW_QUEUES, 4 by default); streams that land on one queue execute strictly in submission order: kernels of two
+// contexts then never overlap, and a kernel queued behind the barrier packet of a long host-to-device copy of ANOTHER stream
+// waits for that copy.  A stream created with a CU mask gets its own queue; the mask enables every CU.
+// (PMX_CTX_POOLED_QUEUE=1: ordinary pooled streams.)
+inline hipStream_t create_dedicated_stream(int n_cu) {
+    hipStream_t st = nullptr;
+    if (!getenv("PMX_CTX_POOLED_QUEUE") && n_cu > 0) {
+        std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0xffffffffu);
+        if (n_cu % 32) mask.back() = (1u << (n_cu % 32)) - 1u;
+        if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            st = nullptr;
+        }
+    }
+    if (!st) PMX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
+}
 
 struct KernelTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -19,7 +19,7 @@ struct SeedParams {
 };
 
 __global__ void k_pack_reads(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int64_t n_reads, int64_t n_words,
-                             uint64_t* words, uint32_t* amb);
+                             uint64_t* words, uint32_t* amb, int64_t r0, int64_t r1);
 // read -> its number of 32-base words, plus the checks a wrapped read set needs (stats: [0] max length, [1] 1 if offsets are
 // not monotone or leave [0, total_bytes])
 __global__ void k_read_word_counts(const int64_t* off, int64_t n_reads, int64_t total_bytes, int64_t* nwords, unsigned long long* stats);
@@ -30,7 +30,7 @@ template <int K, int S, int L>
 __global__ void k_seed_histogram_ks(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin,
                                     int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask,
                                     unsigned long long* counters, const uint8_t* keep, const uint32_t* perm);
-__global__ void k_read_prefix_keys(const uint64_t* words, const int64_t* woff, int64_t n_reads, uint32_t* key, uint32_t* idx);
+__global__ void k_read_prefix_keys(const uint64_t* words, const int64_t* woff, int64_t r_begin, int64_t n_reads, uint32_t* key, uint32_t* idx);
 __global__ void k_read_hashes(const uint8_t* ascii, const int64_t* off, int64_t n_reads, uint64_t* h1, uint64_t* h2, uint32_t* idx);
 __global__ void k_gather_u64(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst);
 __global__ void k_mark_first_of_run(const uint8_t* ascii, const int64_t* off, const uint64_t* h1s, const uint64_t* h2, const uint32_t* perm,

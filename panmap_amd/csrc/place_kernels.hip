@@ -39,10 +39,12 @@ __global__ void k_read_word_counts(const int64_t* __restrict__ off, int64_t n_re
     }
 }
 
+// reads [r0, r1) only (r1 < 0: every read): the words woff[r0] .. woff[r1] - 1
 __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ off,
                              const int64_t* __restrict__ woff, int64_t n_reads, int64_t n_words,
-                             uint64_t* __restrict__ words, uint32_t* __restrict__ amb) {
-    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+                             uint64_t* __restrict__ words, uint32_t* __restrict__ amb, int64_t r0, int64_t r1) {
+    const int64_t w_lo = r1 < 0 ? 0 : woff[r0], w_hi = r1 < 0 ? n_words : woff[r1];
+    for (int64_t w = w_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w_hi; w += (int64_t)gridDim.x * blockDim.x) {
         // read r with woff[r] <= w < woff[r+1]: start from the proportional guess (exact for reads of one length: two
         // loads instead of log2(n) dependent ones), gallop to a bracket, then bisect
         int64_t lo, hi;
@@ -641,8 +643,8 @@ template __global__ void k_seed_histogram_ks<19, 8, 1>(const uint64_t*, const ui
                                                        uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*);
 
 // locality key of a read for the seeding order (read_locality_key: reads that start within a few bases of each other)
-__global__ void k_read_prefix_keys(const uint64_t* __restrict__ words, const int64_t* __restrict__ woff, int64_t n_reads, uint32_t* key, uint32_t* idx) {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+__global__ void k_read_prefix_keys(const uint64_t* __restrict__ words, const int64_t* __restrict__ woff, int64_t r_begin, int64_t n_reads, uint32_t* key, uint32_t* idx) {
+    for (int64_t r = r_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x) {
         key[r] = woff[r + 1] > woff[r] ? read_locality_key(words[woff[r]]) : 0u;
         idx[r] = (uint32_t)r;
     }

@@ -1,6 +1,34 @@
 // Device-resident read set shared by the place and align translation units.
 #pragma once
+#include <utility>
+#include <vector>
+
 #include "device/dev_util.hpp"
+
+namespace pmx {
+// a set of disjoint half-open read ranges (streaming: which reads of a read set have been packed / ordered so far)
+struct RangeSet {
+    std::vector<std::pair<int64_t, int64_t>> iv;   // sorted, merged
+    void clear() { iv.clear(); }
+    void add(int64_t a, int64_t b) {
+        if (b <= a) return;
+        std::vector<std::pair<int64_t, int64_t>> out;
+        for (const auto& r : iv) {
+            if (r.second < a || r.first > b) out.push_back(r);
+            else { a = a < r.first ? a : r.first; b = b > r.second ? b : r.second; }
+        }
+        out.emplace_back(a, b);
+        for (size_t i = out.size() - 1; i > 0 && out[i].first < out[i - 1].first; --i) std::swap(out[i], out[i - 1]);
+        iv.swap(out);
+    }
+    bool covers(int64_t a, int64_t b) const {
+        if (b <= a) return true;
+        for (const auto& r : iv)
+            if (r.first <= a && b <= r.second) return true;
+        return false;
+    }
+};
+}  // namespace pmx
 
 struct pmx_readset {
     int64_t n = 0;          // reads
@@ -24,6 +52,11 @@ struct pmx_readset {
     mutable pmx::DevBuf<uint32_t> loc_key, loc_key2, loc_idx, loc_perm;
     mutable pmx::DevBuf<char> loc_tmp;
     mutable bool has_order = false;
+    // streaming (pmx_readset_pack_range / pmx_place_add_reads_range): the ranges packed so far (`packed` once they cover the
+    // set) and the ranges whose slice of loc_perm holds their reads in locality order (`has_order` once they cover the set:
+    // a permutation sorted range by range serves the align stage as well as one sorted as a whole)
+    pmx::RangeSet packed_ranges;
+    mutable pmx::RangeSet ordered_ranges;
 };
 
 struct pmx_ctx;
@@ -31,4 +64,6 @@ namespace pmx {
 // reads sorted by locality key (stable), as a permutation of 0..n-1 on the device; enqueued on the context's stream the
 // first time it is asked for after a (re)packing.  nullptr for read sets too small or too large for it.
 const uint32_t* readset_locality_order(pmx_ctx* ctx, const pmx_readset* rs);
+// the same for the reads [r0, r1) alone: their slice of the permutation (absolute read indices), sorted by locality key
+const uint32_t* readset_locality_order_range(pmx_ctx* ctx, const pmx_readset* rs, int64_t r0, int64_t r1);
 }

@@ -321,6 +321,75 @@ def test_streaming_read_sets_rewrap_on_the_device(pmx, ctx, sars, sars_index):
     rs.close()
 
 
+def test_streaming_ranges_equal_whole_set(pmx, ctx, sars, sars_index):
+    """pmx_readset_pack_range + pmx_place_add_reads_range (a batch packed and seeded range by range while its H2D copy is in
+    flight): the histogram, the packed reads and the alignments equal those of the set packed and seeded as a whole -- ragged
+    ranges, a range below the locality-sort threshold, an empty range; a range that was not packed is refused, so is --dedup
+    on a sub-range; and two contexts run from two threads give the same results (each owns a hardware queue)"""
+    import threading
+    import torch
+    g = sars.genome("node_7618")
+    dev = torch.device("cuda", 0)
+    concat, off = pmx.simulate_paired_reads(g, 30000, seed=21)
+    n = len(off) - 1
+    d_c = torch.from_numpy(concat).to(dev)
+    d_o = torch.from_numpy(off).to(dev)
+    whole = pmx.ReadSet.wrap_device(ctx, d_c.data_ptr(), d_o.data_ptr(), n, int(concat.size), 0, keepalive=(d_c, d_o))
+    whole.pack()
+    p = pmx.Placer(ctx, sars_index); p.reset(); p.add_reads(whole)
+    wh, wc = p.histogram()
+    al = pmx.Aligner(ctx, g, 150)
+    al.align_readset(whole, paired=True, revcomp_mate2=True)
+    w_recs, w_cig = al.fetch()
+
+    def ops(recs, cig):
+        return [tuple(cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["n_cigar"])]) for r in recs[:2000]]
+    for bounds in ([0, 20000, 20002, 20002, 41000, n], [0, n], [0, 100, n]):
+        rs = pmx.ReadSet.wrap_device(ctx, d_c.data_ptr(), d_o.data_ptr(), n, int(concat.size), 0, keepalive=(d_c, d_o))
+        p.reset()
+        with pytest.raises(pmx.PmxError):
+            p.add_reads_range(rs, 0, bounds[1])                   # nothing packed yet
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            rs.pack_range(a, b)
+            p.add_reads_range(rs, a, b)
+        hh, hc = p.histogram()
+        assert np.array_equal(hh, wh) and np.array_equal(hc, wc)
+        al.align_readset(rs, paired=True, revcomp_mate2=True)     # (the set counts as packed: the ranges cover it)
+        recs, cig = al.fetch()
+        for f in ("rs", "re", "qs", "qe", "mapq", "rev", "proper_frag", "mapped", "n_cigar", "flags", "score"):
+            assert np.array_equal(recs[f], w_recs[f]), f
+        assert ops(recs, cig) == ops(w_recs, w_cig)
+        rs.close()
+    rs = pmx.ReadSet.wrap_device(ctx, d_c.data_ptr(), d_o.data_ptr(), n, int(concat.size), 0, keepalive=(d_c, d_o))
+    rs.pack_range(0, 1000)
+    with pytest.raises(pmx.PmxError):
+        al.align_readset(rs, paired=True, revcomp_mate2=True)     # not every read is packed
+    with pytest.raises(pmx.PmxError):
+        p.add_reads_range(rs, 0, 1000, pmx.TraversalParams(dedupReads=True))
+    with pytest.raises(pmx.PmxError):
+        rs.pack_range(10, n + 2)
+    rs.close()
+    # two contexts from two host threads
+    out = {}
+
+    def work(key):
+        c2 = pmx.Context(0)
+        r2 = pmx.ReadSet.wrap_device(c2, d_c.data_ptr(), d_o.data_ptr(), n, int(concat.size), 0)
+        p2 = pmx.Placer(c2, sars_index)
+        for _ in range(3):
+            p2.reset()
+            r2.pack()
+            p2.add_reads(r2)
+            out[key] = p2.histogram()
+        p2.close(); r2.close()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(2):
+        assert np.array_equal(out[k][0], wh) and np.array_equal(out[k][1], wc)
+    p.close(); al.close(); whole.close()
+
+
 def test_scoring_redone_with_level_kernels_when_the_persistent_launch_starves(pmx, oracle, ctx, sars, sars_index, monkeypatch):
     """the heavy-path scoring kernel spin-waits on flags and needs all of its workgroups resident; when a wave
     gives up (shared GPU) the call must not fail but redo the scoring with the level kernels -- the same bits"""
