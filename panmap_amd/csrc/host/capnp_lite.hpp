@@ -168,13 +168,27 @@ struct ListR {
         p.p = base + i;
         return p;
     }
+    // bytes per element of a primitive list (codes 2..5); 0 for void / bit / pointer / composite lists
+    uint32_t elem_bytes() const { return esize >= 2 && esize <= 5 ? 1u << (esize - 2) : 0u; }
+    // as_list() validated n elements of the width the POINTER declares: an accessor of another width would read past that
+    // range (a crafted list that declares bytes and is read as 64-bit words), so the width and the index are checked here
     template <class T> T prim(uint32_t i) const {
+        if (elem_bytes() != sizeof(T)) throw std::runtime_error("capnp: list element width differs from the field's type");
+        if (i >= n) throw std::runtime_error("capnp: list index out of range");
         T v;
         std::memcpy(&v, reinterpret_cast<const uint8_t*>(base) + (size_t)i * sizeof(T), sizeof(T));
         return v;
     }
-    bool bit_at(uint32_t i) const { return (reinterpret_cast<const uint8_t*>(base)[i >> 3] >> (i & 7)) & 1; }
-    const uint8_t* bytes() const { return reinterpret_cast<const uint8_t*>(base); }
+    bool bit_at(uint32_t i) const {
+        if (esize != 1) throw std::runtime_error("capnp: list is not a bit list");
+        if (i >= n) throw std::runtime_error("capnp: list index out of range");
+        return (reinterpret_cast<const uint8_t*>(base)[i >> 3] >> (i & 7)) & 1;
+    }
+    // the raw content of a primitive list whose elements are `width` bytes wide (n * width bytes are inside the segment)
+    const uint8_t* bytes(uint32_t width) const {
+        if (n != 0 && elem_bytes() != width) throw std::runtime_error("capnp: list element width differs from the field's type");
+        return reinterpret_cast<const uint8_t*>(base);
+    }
 };
 
 inline ListR as_list(const Ptr& ptr) {

@@ -297,7 +297,7 @@ void load_idx(const std::string& path, LiteIndex& out) {
             const capnp::ListR inner = capnp::as_list(outer.ptr_at(sg));
             const uint64_t cnt = inner.size();
             if (at + cnt > total) throw std::runtime_error("index seed-change arrays are longer than the node offsets say");
-            if (cnt) std::memcpy(static_cast<uint8_t*>(dst) + at * elem_bytes, inner.bytes(), (size_t)cnt * elem_bytes);
+            if (cnt) std::memcpy(static_cast<uint8_t*>(dst) + at * elem_bytes, inner.bytes((uint32_t)elem_bytes), (size_t)cnt * elem_bytes);
             at += cnt;
         }
         if (at != total) throw std::runtime_error("index seed-change arrays are shorter than the node offsets say");

@@ -131,6 +131,20 @@ def test_loader_validation_errors(pmx, rsv_index, tmp_path):
     wild = bytearray(raw)
     struct.pack_into("<Q", wild, 32 + 8 + at + 16 + 8 * 4, (0x1fffffff << 2) | 1 | (5 << 32) | (1000 << 35))   # offsets list far outside
     assert "outside its segment" in load_mutated(wild, "wild.idx")
+    # a list pointer that declares narrower elements than the field's type passes the bounds check of ITS size and
+    # would then be read 8x (2x) past it -- the element-size code is checked against the type that is read
+    ptrs = 32 + 8 + at + 16
+    narrow = bytearray(raw)
+    w, = struct.unpack_from("<Q", narrow, ptrs + 8 * 4)                        # nodeChangeOffsets: List(UInt64) -> declared as bytes
+    struct.pack_into("<Q", narrow, ptrs + 8 * 4, (w & ~(7 << 32)) | (2 << 32))
+    assert "element width" in load_mutated(narrow, "narrow_offsets.idx")
+    for fld, code in ((1, 2), (2, 2), (3, 1)):                                 # inner lists of hashes / counts declared as bytes / bits
+        m = bytearray(raw)
+        loc, esize, cnt = _list(bytes(m[32 + 8:]), at + 16 + 8 * fld)
+        assert esize == 6 and cnt == 1
+        w, = struct.unpack_from("<Q", m, 32 + 8 + loc)
+        struct.pack_into("<Q", m, 32 + 8 + loc, (w & ~(7 << 32)) | (code << 32))
+        assert "element width" in load_mutated(m, "narrow_%d.idx" % fld)
     assert pmx.Index.read_header(str(tmp_path / "junk.idx")) is None
 
 
