@@ -76,21 +76,32 @@ PMX_HD void reg_alloc_p(Work& W, Reg& r) {
     else { W.status |= PMX_ST_OVERFLOW; r.cig_slot = 0; }
 }
 
-// mm_append_cigar (align.c:291-314)
-PMX_HD void append_cigar(Work& W, Reg& r, int n_cigar, Ptr<const uint32_t> cigar) {
-    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(cigar);
-    if (n_cigar == 0) return;
+// ---- CIGAR operations: BAM encoding, length << 4 | kind (M = 0, I = 1, D = 2) ---------------------------------------------
+enum : uint32_t { CG_M = 0, CG_I = 1, CG_D = 2 };
+PMX_HD uint32_t cg_kind(uint32_t c) { return c & 0xfu; }
+PMX_HD uint32_t cg_len(uint32_t c) { return c >> 4; }
+PMX_HD bool cg_is_indel(uint32_t kind) { return kind == CG_I || kind == CG_D; }
+
+// Appends one operation to a list under construction: nothing for an empty operation, an operation of the kind the list
+// ends with lengthens that entry.  `n` never exceeds the number of operations pushed, so a list can be rewritten in place.
+PMX_HD void cg_push(Ptr<uint32_t> c, uint32_t& n, uint32_t kind, uint32_t len) {
+    if (len == 0) return;
+    if (n > 0 && cg_kind(c[n - 1]) == kind) c[n - 1] += len << 4;
+    else c[n++] = len << 4 | kind;
+}
+
+// A region takes the operations of one more DP (what mm_append_cigar does, align.c:291-314).  Every DP's list comes out of
+// the backtrack without empty operations and without two neighbours of one kind, so pushing every operation joins exactly
+// the one pair the reference joins: the region's last operation with the DP's first.
+PMX_HD void append_cigar(Work& W, Reg& r, int n_new, Ptr<const uint32_t> ops) {
+    PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(ops);
+    if (n_new == 0) return;
     reg_alloc_p(W, r);
+    if ((int)r.n_cigar + n_new > W.caps.max_cigar) { W.status |= PMX_ST_OVERFLOW; return; }
     Ptr<uint32_t> c = reg_cigar(W, r); PMX_LDS(c);
-    if ((int)r.n_cigar + n_cigar > W.caps.max_cigar) { W.status |= PMX_ST_OVERFLOW; return; }
-    if (r.n_cigar > 0 && (c[r.n_cigar - 1] & 0xf) == (cigar[0] & 0xf)) {
-        c[r.n_cigar - 1] += cigar[0] >> 4 << 4;
-        for (int i = 1; i < n_cigar; ++i) c[r.n_cigar + i - 1] = cigar[i];
-        r.n_cigar += n_cigar - 1;
-    } else {
-        for (int i = 0; i < n_cigar; ++i) c[r.n_cigar + i] = cigar[i];
-        r.n_cigar += n_cigar;
-    }
+    uint32_t n = r.n_cigar;
+    for (int i = 0; i < n_new; ++i) cg_push(c, n, cg_kind(ops[i]), cg_len(ops[i]));
+    r.n_cigar = n;
 }
 
 // mm_align_pair (align.c:316-343) without the splice / single-affine branches (q != q2 on this path)
@@ -121,47 +132,72 @@ PMX_HD bool try_shortcut_direct(Work& W, const Opt& o, int qlen, QF& qf, int tle
     return true;
 }
 
-// update_max_zdrop + mm_test_zdrop (align.c:32-89).  The inversion probe -- a local alignment of the reverse complement
-// of the query part of the largest score drop against its target part (ksw_ll_i16 -> sw_ll, align/aln_swll.hpp) -- decides
-// between return codes 1 and 2; the thread-per-pair kernel has no DP scratch for it and hands the pair to the wave tiers.
-PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int n_cigar, Ptr<const uint32_t> cigar) {
-    PMX_LDS(&W); PMX_LDS(qseq); PMX_LDS(tseq); PMX_LDS(cigar);
-    int32_t score = 0, mx = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
-    int pos[2][2] = {{-1, -1}, {-1, -1}};
-    auto upd = [&](int32_t sc, int ii, int jj) {
-        if (sc < mx) {
-            const int li = ii - max_i, lj = jj - max_j;
-            const int diff = li > lj ? li - lj : lj - li;
-            const int z = mx - sc - diff * o.e;
-            if (z > max_zdrop) {
-                max_zdrop = z;
-                pos[0][0] = max_i; pos[0][1] = ii;
-                pos[1][0] = max_j; pos[1][1] = jj;
-            }
-        } else { mx = sc; max_i = ii; max_j = jj; }
-    };
+// The largest score drop along an alignment, and whether it hides an inversion (what update_max_zdrop + mm_test_zdrop
+// decide, align.c:32-89): 0 = fine, 1 = the drop exceeds zdrop, 2 = a local alignment of the reverse complement of the
+// query part of the drop against its target part scores like a chain (ksw_ll_i16 -> sw_ll, align/aln_swll.hpp).
+//
+// The reference re-scores the alignment base by base and tests the drop after every base.  Stated over RUNS here: along a
+// run of matching bases the running score only rises, so
+//   * while it is still below the best score so far, every drop it could report is smaller than the one reported at the
+//     event that ended the previous run (same diagonal offset, lower score there);
+//   * once it reaches the best score it stays the best to the end of the run: the run moves the best-score mark to its
+//     last base, or (when it never gets there) changes nothing.
+// Only the bases that do not match -- and the gaps -- are events that are evaluated one by one.
+struct DropScan {
+    int32_t score = 0, best = INT32_MIN, best_t = -1, best_q = -1, worst = 0;
+    int32_t t_from = -1, t_to = -1, q_from = -1, q_to = -1;   // the stretch of the largest drop
+    PMX_HD void event(int32_t t, int32_t q, int gap_ext) {     // the running score was changed at (t, q)
+        if (score >= best) { best = score; best_t = t; best_q = q; return; }
+        const int32_t dt = t - best_t, dq = q - best_q;
+        const int32_t drop = best - score - (dt > dq ? dt - dq : dq - dt) * gap_ext;
+        if (drop > worst) { worst = drop; t_from = best_t; t_to = t; q_from = best_q; q_to = q; }
+    }
+    PMX_HD void match_run(int32_t t_last, int32_t q_last, int32_t gain) {   // `gain` > 0 over a run that ends at (t_last, q_last)
+        score += gain;
+        if (score >= best) { best = score; best_t = t_last; best_q = q_last; }
+    }
+};
+
+PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int n_ops, Ptr<const uint32_t> ops) {
+    PMX_LDS(&W); PMX_LDS(qseq); PMX_LDS(tseq); PMX_LDS(ops);
+    DropScan ds;
     ByteReader q_r(qseq), t_r(tseq);
-    for (int k = 0; k < n_cigar; ++k) {
-        const uint32_t op = cigar[k] & 0xf, len = cigar[k] >> 4;
-        if (op == 0) {
-            for (uint32_t l = 0; l < len; ++l) {
-                score += simple_score(o, t_r[i + (int)l], q_r[j + (int)l]);
-                upd(score, i + (int)l, j + (int)l);
+    const int match = o.a < 0 ? -o.a : o.a;
+    int32_t t = 0, q = 0;   // target / query bases consumed
+    for (int k = 0; k < n_ops; ++k) {
+        const uint32_t kind = cg_kind(ops[k]);
+        const int32_t len = (int32_t)cg_len(ops[k]);
+        if (kind == CG_M) {
+            int32_t at = 0;
+            while (at < len) {
+                int32_t run = 0;
+                uint32_t ct = 0, cq = 0;
+                for (; at + run < len; ++run) {
+                    ct = t_r[t + at + run]; cq = q_r[q + at + run];
+                    if (ct != cq || ct > 3) break;
+                }
+                if (run > 0) ds.match_run(t + at + run - 1, q + at + run - 1, run * match);
+                at += run;
+                if (at < len) {   // a mismatch or an ambiguous base
+                    ds.score += simple_score(o, ct, cq);
+                    ds.event(t + at, q + at, o.e);
+                    ++at;
+                }
             }
-            i += len; j += len;
-        } else if (op == 1 || op == 2 || op == 3) {
-            score -= o.q + o.e * (int)len;
-            if (op == 1) j += len;
-            else i += len;
-            upd(score, i, j);
+            t += len; q += len;
+        } else if (kind == CG_I || kind == CG_D || kind == 3) {
+            ds.score -= o.q + o.e * len;
+            if (kind == CG_I) q += len;
+            else t += len;
+            ds.event(t, q, o.e);
         }
     }
-    const int q_len = pos[1][1] - pos[1][0], t_len = pos[0][1] - pos[0][0];
-    if (max_zdrop > o.zdrop_inv && q_len < o.max_gap && t_len < o.max_gap) {
+    const int q_len = ds.q_to - ds.q_from, t_len = ds.t_to - ds.t_from;
+    if (ds.worst > o.zdrop_inv && q_len < o.max_gap && t_len < o.max_gap) {
 #if defined(PMX_THREAD_PER_PAIR)
-        W.status |= PMX_ST_NEED_WAVE;
+        W.status |= PMX_ST_NEED_WAVE;   // no DP scratch for the inversion probe in this kernel: the wave tiers take the pair
 #else
-        const int q_end = pos[1][1], t_beg = pos[0][0];
+        const int q_end = ds.q_to, t_beg = ds.t_from;
         auto qf = [&](int k) { const uint32_t c = q_r[q_end - k - 1]; return (int)(c >= 4 ? 4u : 3u - c); };
         auto tf = [&](int k) { return (int)t_r[t_beg + k]; };
         int q_off, t_off;
@@ -171,125 +207,149 @@ PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const
         else if (sc >= o.min_chain_score * o.a && sc >= o.min_dp_max) return 2;   // there is a potential inversion
 #endif
     }
-    return max_zdrop > o.zdrop ? 1 : 0;
+    return ds.worst > o.zdrop ? 1 : 0;
 }
 
-// mm_fix_cigar (align.c:91-167)
+// How far a gap of `gap` bases that starts at `at` can slide to the left over `room` aligned bases: one step for every base
+// before the gap that equals the base `gap` positions later (the alignment stays the same alignment).
+template <class SEQ>
+PMX_HD int32_t gap_slide_left(SEQ& s, int32_t at, int32_t gap, int32_t room) {
+    int32_t n = 0;
+    while (n < room && s[at - 1 - n] == s[at + gap - 1 - n]) ++n;
+    return n;
+}
+
+// The CIGAR of a finished region in its final form (what mm_fix_cigar produces, align.c:91-167):
+//  1. every insertion / deletion between two match blocks moves as far left as the sequences allow;
+//  2. a stretch of insertions and deletions that follow each other directly (three operations or more, empty ones in
+//     between do not interrupt it once it has begun) becomes one insertion + one deletion with the summed lengths;
+//  3. empty operations go, neighbours of one kind join;
+//  4. a leading insertion / deletion is cut off and the region's start moves instead (*qshift / *tshift say by how much).
+// Steps 2 and 3 are one in-place rewrite here: the list is re-emitted through cg_push, which drops empty operations and
+// joins equal neighbours as it goes (the reference decides per list whether to compact; a list it leaves alone has
+// nothing to drop or join, so compacting always gives the same list).
 PMX_HDN void fix_cigar(Work& W, Reg& r, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int* qshift, int* tshift) {
     PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq); PMX_LDS(tseq);
-    Ptr<uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
-    int32_t toff = 0, qoff = 0, to_shrink = 0;
+    Ptr<uint32_t> c = reg_cigar(W, r); PMX_LDS(c);
     *qshift = *tshift = 0;
-    if (r.n_cigar <= 1) return;
-    for (uint32_t k = 0; k < r.n_cigar; ++k) {   // indel left alignment
-        const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
-        if (len == 0) to_shrink = 1;
-        if (op == 0) { toff += len; qoff += len; }
-        else if (op == 1 || op == 2) {
-            if (k > 0 && k < r.n_cigar - 1 && (cg[k - 1] & 0xf) == 0 && (cg[k + 1] & 0xf) == 0) {
-                int l;
-                const int prev_len = (int)(cg[k - 1] >> 4);
-                if (op == 1) {
-                    for (l = 0; l < prev_len; ++l)
-                        if (qseq[qoff - 1 - l] != qseq[qoff + len - 1 - l]) break;
-                } else {
-                    for (l = 0; l < prev_len; ++l)
-                        if (tseq[toff - 1 - l] != tseq[toff + len - 1 - l]) break;
-                }
-                if (l > 0) { cg[k - 1] -= (uint32_t)l << 4; cg[k + 1] += (uint32_t)l << 4; qoff -= l; toff -= l; }
-                if (l == prev_len) to_shrink = 1;
+    const uint32_t n_in = r.n_cigar;
+    if (n_in <= 1) return;
+    {   // 1. left alignment; (tpos, qpos) = bases consumed before operation k
+        int32_t tpos = 0, qpos = 0;
+        for (uint32_t k = 0; k < n_in; ++k) {
+            const uint32_t kind = cg_kind(c[k]);
+            const int32_t len = (int32_t)cg_len(c[k]);
+            if (kind == CG_M) { tpos += len; qpos += len; continue; }
+            if (!cg_is_indel(kind)) { if (kind == 3) tpos += len; continue; }
+            if (k > 0 && k + 1 < n_in && cg_kind(c[k - 1]) == CG_M && cg_kind(c[k + 1]) == CG_M) {
+                const int32_t room = (int32_t)cg_len(c[k - 1]);
+                const int32_t by = kind == CG_I ? gap_slide_left(qseq, qpos, len, room) : gap_slide_left(tseq, tpos, len, room);
+                c[k - 1] -= (uint32_t)by << 4;     // (may become empty: step 3 removes it)
+                c[k + 1] += (uint32_t)by << 4;
+                qpos -= by; tpos -= by;
             }
-            if (op == 1) qoff += len;
-            else toff += len;
-        } else if (op == 3) toff += len;
-    }
-    for (uint32_t k = 0; k + 2 < r.n_cigar; ++k) {   // fix CIGAR like 5I6D7I
-        if ((cg[k] & 0xf) > 0 && (cg[k] & 0xf) + (cg[k + 1] & 0xf) == 3) {
-            uint32_t l, s[3] = {0, 0, 0};
-            for (l = k; l < r.n_cigar; ++l) {
-                const uint32_t op = cg[l] & 0xf;
-                if (op == 1 || op == 2 || cg[l] >> 4 == 0) s[op] += cg[l] >> 4;
-                else break;
-            }
-            if (s[1] > 0 && s[2] > 0 && l - k > 2) {
-                cg[k] = s[1] << 4 | 1;
-                cg[k + 1] = s[2] << 4 | 2;
-                for (k += 2; k < l; ++k) cg[k] &= 0xf;
-                to_shrink = 1;
-            }
-            k = l;
+            if (kind == CG_I) qpos += len;
+            else tpos += len;
         }
     }
-    if (to_shrink) {
-        int32_t l = 0;
-        for (uint32_t k = 0; k < r.n_cigar; ++k)
-            if (cg[k] >> 4 != 0) cg[l++] = cg[k];
-        r.n_cigar = (uint32_t)l;
-        l = 0;
-        for (uint32_t k = 0; k < r.n_cigar; ++k) {
-            if (k == r.n_cigar - 1 || (cg[k] & 0xf) != (cg[k + 1] & 0xf)) cg[l++] = cg[k];
-            else cg[k + 1] += cg[k] >> 4 << 4;
+    uint32_t n_out = 0;
+    for (uint32_t k = 0; k < n_in;) {   // 2. + 3.
+        const uint32_t kind = cg_kind(c[k]);
+        // a stretch begins where an insertion and a deletion touch (and at least one more operation follows)
+        if (k + 2 < n_in && kind != CG_M && kind + cg_kind(c[k + 1]) == CG_I + CG_D) {
+            uint32_t end = k, sum[3] = {0, 0, 0};
+            for (; end < n_in; ++end) {
+                const uint32_t kd = cg_kind(c[end]), ln = cg_len(c[end]);
+                if (!cg_is_indel(kd) && ln != 0) break;
+                if (kd < 3) sum[kd] += ln;          // (an empty operation of any kind adds nothing)
+            }
+            if (sum[CG_I] > 0 && sum[CG_D] > 0 && end - k > 2) {
+                cg_push(c, n_out, CG_I, sum[CG_I]);
+                cg_push(c, n_out, CG_D, sum[CG_D]);
+            } else {
+                for (uint32_t j = k; j < end; ++j) cg_push(c, n_out, cg_kind(c[j]), cg_len(c[j]));
+            }
+            if (end < n_in) cg_push(c, n_out, cg_kind(c[end]), cg_len(c[end]));   // the operation that ended the stretch starts none
+            k = end + 1;
+        } else {
+            cg_push(c, n_out, kind, cg_len(c[k]));
+            ++k;
         }
-        r.n_cigar = (uint32_t)l;
     }
-    if ((cg[0] & 0xf) == 1 || (cg[0] & 0xf) == 2) {   // leading I or D
-        const int32_t l = (int32_t)(cg[0] >> 4);
-        if ((cg[0] & 0xf) == 1) {
-            if (r.rev) r.qe -= l;
-            else r.qs += l;
-            *qshift = l;
-        } else { r.rs += l; *tshift = l; }
-        --r.n_cigar;
-        for (uint32_t k = 0; k < r.n_cigar; ++k) cg[k] = cg[k + 1];
+    if (n_out > 0 && cg_is_indel(cg_kind(c[0]))) {   // 4.
+        const int32_t cut = (int32_t)cg_len(c[0]);
+        if (cg_kind(c[0]) == CG_I) {
+            if (r.rev) r.qe -= cut;
+            else r.qs += cut;
+            *qshift = cut;
+        } else {
+            r.rs += cut;
+            *tshift = cut;
+        }
+        --n_out;
+        for (uint32_t k = 0; k < n_out; ++k) c[k] = c[k + 1];
     }
+    r.n_cigar = n_out;
 }
 
-// mm_update_extra (align.c:240-289), log_gap = 1, is_eqx = 0
+// The statistics of a finished alignment (what mm_update_extra computes, align.c:240-289; log_gap = 1, is_eqx = 0):
+// aligned / matching / ambiguous bases and dp_max, the largest value of a running score that cannot fall below zero.
+// Over RUNS as in test_zdrop: along a run of matching bases the score rises from a value >= 0, so its maximum over the
+// run is its value at the end of the run; a base that does not match, and a gap, are single events.  (The running score
+// is a double like the reference's; every value it takes is a multiple of 2^-24 below 2^20 -- integers and
+// q + e * (a float) -- so all its additions are exact and a run added at once equals its bases added one by one.)
 template <class TR>
 PMX_HD void update_extra_core(Work& W, const Opt& o, Reg& r, Ptr<const uint8_t> qseq, TR& t_r, int8_t q, int8_t e) {
     PMX_LDS(&W); PMX_LDS(&r); PMX_LDS(qseq);
-    int32_t toff = 0, qoff = 0;
-    double s = 0.0, mx = 0.0;
-    Ptr<const uint32_t> cg = reg_cigar(W, r); PMX_LDS(cg);
+    Ptr<const uint32_t> c = reg_cigar(W, r); PMX_LDS(c);
     ByteReader q_r(qseq);
-    r.blen = r.mlen = 0;
+    const int match = o.a < 0 ? -o.a : o.a;
+    double run_score = 0.0, peak = 0.0;
+    int32_t t = 0, qp = 0, aligned = 0, same = 0, ambiguous = 0;
+    auto ambiguous_in = [&](auto& rd, int32_t from, int32_t len) { int n = 0; for (int32_t i = 0; i < len; ++i) n += rd[from + i] > 3; return n; };
     for (uint32_t k = 0; k < r.n_cigar; ++k) {
-        const uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
-        if (op == 0) {
-            int n_ambi = 0, n_diff = 0;
-            for (uint32_t l = 0; l < len; ++l) {
-                const int cq = (int)q_r[qoff + (int)l], ct = (int)t_r[toff + (int)l];
-                if (ct > 3 || cq > 3) ++n_ambi;
-                else if (ct != cq) ++n_diff;
-                s += simple_score(o, (uint32_t)ct, (uint32_t)cq);
-                if (s < 0) s = 0;
-                else mx = mx > s ? mx : s;
+        const uint32_t kind = cg_kind(c[k]);
+        const int32_t len = (int32_t)cg_len(c[k]);
+        if (kind == CG_M) {
+            int32_t at = 0, n_amb = 0, n_sub = 0;
+            while (at < len) {
+                int32_t run = 0;
+                uint32_t ct = 0, cq = 0;
+                for (; at + run < len; ++run) {
+                    ct = t_r[t + at + run]; cq = q_r[qp + at + run];
+                    if (ct != cq || ct > 3) break;
+                }
+                if (run > 0) {
+                    run_score += (double)(run * match);
+                    peak = peak > run_score ? peak : run_score;
+                    at += run;
+                }
+                if (at < len) {
+                    if (ct > 3 || cq > 3) ++n_amb; else ++n_sub;
+                    run_score += simple_score(o, ct, cq);
+                    if (run_score < 0) run_score = 0;
+                    else peak = peak > run_score ? peak : run_score;
+                    ++at;
+                }
             }
-            r.blen += len - n_ambi;
-            r.mlen += len - (n_ambi + n_diff);
-            r.n_ambi += n_ambi;
-            toff += len; qoff += len;
-        } else if (op == 1) {
-            int n_ambi = 0;
-            for (uint32_t l = 0; l < len; ++l)
-                if (q_r[qoff + (int)l] > 3) ++n_ambi;
-            r.blen += len - n_ambi;
-            r.n_ambi += n_ambi;
-            s -= q + (double)e * mg_log2f((float)(1.0 + len));
-            if (s < 0) s = 0;
-            qoff += len;
-        } else if (op == 2) {
-            int n_ambi = 0;
-            for (uint32_t l = 0; l < len; ++l)
-                if (t_r[toff + (int)l] > 3) ++n_ambi;
-            r.blen += len - n_ambi;
-            r.n_ambi += n_ambi;
-            s -= q + (double)e * mg_log2f((float)(1.0 + len));
-            if (s < 0) s = 0;
-            toff += len;
-        } else if (op == 3) toff += len;
+            aligned += len - n_amb;
+            same += len - n_amb - n_sub;
+            ambiguous += n_amb;
+            t += len; qp += len;
+        } else if (cg_is_indel(kind)) {
+            const int n_amb = kind == CG_I ? ambiguous_in(q_r, qp, len) : ambiguous_in(t_r, t, len);
+            aligned += len - n_amb;
+            ambiguous += n_amb;
+            run_score -= q + (double)e * mg_log2f((float)(1.0 + len));
+            if (run_score < 0) run_score = 0;
+            if (kind == CG_I) qp += len;
+            else t += len;
+        } else if (kind == 3) t += len;
     }
-    r.dp_max = (int32_t)(mx + .499);
+    r.blen = aligned;
+    r.mlen = same;
+    r.n_ambi += ambiguous;
+    r.dp_max = (int32_t)(peak + .499);
 }
 
 PMX_HDN void update_extra(Work& W, const Opt& o, Reg& r, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int8_t q, int8_t e) {
@@ -303,136 +363,194 @@ PMX_HDN void update_extra(Work& W, const Opt& o, Reg& r, Ptr<const uint8_t> qseq
     update_extra_core(W, o, r, qseq, t_r, q, e);
 }
 
-// mm_adjust_minier (align.c:355-372), non-HPC
+// ---- the anchors of one region as the clean-up passes see them -------------------------------------------------------------
+// Anchor i of the view ends at reference base tpos(i) and query base qpos(i) and spans span(i) bases; skew(i) is by how much
+// the step from anchor i-1 to anchor i leaves the diagonal (> 0: the query advances further than the reference).
+template <class AP>
+struct AnchorViewT {
+    AP a;
+    int first;
+    PMX_HD int32_t tpos(int i) const { return (int32_t)a[first + i].x; }
+    PMX_HD int32_t qpos(int i) const { return (int32_t)a[first + i].y; }
+    PMX_HD int32_t span(int i) const { return (int32_t)(a[first + i].y >> 32 & 0xff); }
+    PMX_HD int32_t skew(int i) const { return (qpos(i) - qpos(i - 1)) - (tpos(i) - tpos(i - 1)); }
+    PMX_HD bool joined(int i) const { return (a[first + i].y & PMX_SEED_LONG_JOIN) != 0; }
+    PMX_HD void flag(int i, uint64_t bits) { a[first + i].y |= bits; }
+};
+typedef AnchorViewT<Ptr<A128>> AnchorView;
+typedef AnchorViewT<Ptr<const A128>> ConstAnchorView;
+
+// mm_adjust_minier (align.c:355-372), non-HPC: the middle of the anchor's k-mer
 PMX_HD void adjust_minier(const Opt& o, const A128& a, int32_t* r, int32_t* q) {
     *r = (int32_t)a.x - (o.k >> 1);
     *q = (int32_t)a.y - (o.k >> 1);
 }
 
-PMX_HD int anchor_gap(Ptr<const A128> a, int i) {   // query advance minus reference advance between anchors i-1 and i
-    return ((int32_t)a[i].y - (int32_t)a[i - 1].y) - ((int32_t)a[i].x - (int32_t)a[i - 1].x);
-}
-
-// collect_long_gaps + mm_filter_bad_seeds (align.c:374-427).  K[] lives in W.kidx.
-PMX_HD int collect_long_gaps(Work& W, int as1, int cnt1, Ptr<const A128> a, int min_gap, Ptr<int32_t> K, int cap) {
-    PMX_LDS(&W); PMX_LDS(a); PMX_LDS(K);
+// The steps of the chain that leave the diagonal by more than `tol` bases, as indices into the view (W.kidx); fewer than two
+// of them: nothing for the filters below to do (0 is returned).
+PMX_HD int skewed_steps(Work& W, const AnchorView& v, int n_anchors, int tol, Ptr<int32_t> out, int cap) {
+    PMX_LDS(&W); PMX_LDS(out);
     int n = 0;
-    for (int i = 1; i < cnt1; ++i) {
-        const int gap = anchor_gap(a + as1, i);
-        if (gap < -min_gap || gap > min_gap) ++n;
+    bool full = false;
+    for (int i = 1; i < n_anchors; ++i) {
+        const int s = v.skew(i);
+        if (s >= -tol && s <= tol) continue;
+        if (n < cap) out[n] = i;
+        else full = true;
+        ++n;
     }
     if (n <= 1) return 0;
-    if (n > cap) { W.status |= PMX_ST_OVERFLOW; return 0; }
-    n = 0;
-    for (int i = 1; i < cnt1; ++i) {
-        const int gap = anchor_gap(a + as1, i);
-        if (gap < -min_gap || gap > min_gap) K[n++] = i;
-    }
+    if (full) { W.status |= PMX_ST_OVERFLOW; return 0; }
     return n;
 }
 
-PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, Ptr<A128> a, int min_gap, int diff_thres, int max_ext_len, int max_ext_cnt) {
+// Anchors inside a stretch where insertions and deletions cancel each other are unreliable (what mm_filter_bad_seeds drops,
+// align.c:391-427).  From every skewed step a window of at most `max_steps` further skewed steps (and `max_reach` bases) is
+// scanned; its weight is the largest amount of insertion that is matched by deletion, 2 * min(inserted, deleted), over
+// the prefixes of the window, and the window is cut where that maximum is first reached.  Windows heavier than
+// `min_weight` compete: of those that begin before the current winner ends, the heaviest one wins (the earlier one on a
+// tie); the anchors of a winner, from its first skewed step up to (not including) its last, are marked IGNORE.
+PMX_HDN void filter_bad_seeds(Work& W, int as1, int cnt1, Ptr<A128> a, int tol, int min_weight, int max_reach, int max_steps) {
     PMX_LDS(&W); PMX_LDS(a);
-    Ptr<int32_t> K = W.kidx; PMX_LDS(K);
-    const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
+    Ptr<int32_t> step = W.kidx; PMX_LDS(step);
+    AnchorView v{a, as1};
+    const int n = skewed_steps(W, v, cnt1, tol, step, W.caps.max_anchor);
     if (n == 0) return;
-    int mx = 0, max_st = -1, max_en = -1;
-    for (int k = 0;; ++k) {
-        int gap, l, n_ins = 0, n_del = 0, qs, rs, max_diff = 0, max_diff_l = -1;
-        if (k == n || k >= max_en) {
-            if (max_en > 0)
-                for (int i = K[max_st]; i < K[max_en]; ++i) a[as1 + i].y |= PMX_SEED_IGNORE;
-            mx = 0; max_st = max_en = -1;
-            if (k == n) break;
+    int win_from = -1, win_to = -1, win_weight = 0;     // the current winner, as positions in step[]
+    auto settle = [&]() {
+        if (win_to > 0)
+            for (int i = step[win_from]; i < step[win_to]; ++i) v.flag(i, PMX_SEED_IGNORE);
+        win_from = win_to = -1;
+        win_weight = 0;
+    };
+    for (int k = 0; k < n; ++k) {
+        if (k >= win_to) settle();
+        const int i0 = step[k];
+        int32_t ins = 0, del = 0;
+        { const int s = v.skew(i0); if (s > 0) ins = s; else del = -s; }
+        const int32_t q_from = v.qpos(i0 - 1), t_from = v.tpos(i0 - 1);
+        int weight = 0, cut = -1;
+        for (int m = k + 1; m < n && m <= k + max_steps; ++m) {
+            const int j = step[m];
+            if (v.qpos(j) - q_from > max_reach || v.tpos(j) - t_from > max_reach) break;
+            const int s = v.skew(j);
+            if (s > 0) ins += s; else del -= s;
+            const int cancelled = 2 * (ins < del ? ins : del);
+            if (cancelled > weight) { weight = cancelled; cut = m; }
         }
-        const int i = K[k];
-        gap = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - (int32_t)(a[as1 + i].x - a[as1 + i - 1].x);
-        if (gap > 0) n_ins += gap;
-        else n_del += -gap;
-        qs = (int32_t)a[as1 + i - 1].y;
-        rs = (int32_t)a[as1 + i - 1].x;
-        for (l = k + 1; l < n && l <= k + max_ext_cnt; ++l) {
-            const int j = K[l];
-            if ((int32_t)a[as1 + j].y - qs > max_ext_len || (int32_t)a[as1 + j].x - rs > max_ext_len) break;
-            gap = ((int32_t)a[as1 + j].y - (int32_t)a[as1 + j - 1].y) - (int32_t)(a[as1 + j].x - a[as1 + j - 1].x);
-            if (gap > 0) n_ins += gap;
-            else n_del += -gap;
-            const int ad = n_ins - n_del < 0 ? n_del - n_ins : n_ins - n_del;
-            const int diff = n_ins + n_del - ad;
-            if (max_diff < diff) { max_diff = diff; max_diff_l = l; }
+        if (weight > min_weight && weight > win_weight) { win_weight = weight; win_from = k; win_to = cut; }
+    }
+    settle();
+}
+
+// Skewed steps that lie close together are bridged (what mm_filter_bad_seeds_alt does, align.c:429-462): starting from a
+// skewed step, the next one joins the bridge while it begins within `max_reach` bases and the diagonal stretch between the
+// two is no longer than the two skews together.  The anchors under a bridge are marked IGNORE and its last anchor
+// LONG_JOIN: the gap filler aligns the whole bridge in one DP whose band is the bridge's length.
+PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, Ptr<A128> a, int tol, int max_reach) {
+    PMX_LDS(&W); PMX_LDS(a);
+    Ptr<int32_t> step = W.kidx; PMX_LDS(step);
+    AnchorView v{a, as1};
+    const int n = skewed_steps(W, v, cnt1, tol, step, W.caps.max_anchor);
+    int k = 0;
+    while (k < n) {
+        int last = k;                                   // the bridge covers step[k..last]
+        int32_t t_end = v.tpos(step[k]), q_end = v.qpos(step[k]);
+        int32_t skew_here = v.skew(step[k]);
+        if (skew_here < 0) skew_here = -skew_here;
+        for (int m = k + 1; m < n; ++m) {
+            const int j = step[m];
+            if (v.qpos(j) - q_end > max_reach || v.tpos(j) - t_end > max_reach) break;
+            int32_t skew_next = v.skew(j);
+            if (skew_next < 0) skew_next = -skew_next;
+            // the diagonal stretch between the bridge's end and the anchor before j (its span belongs to the stretch's end)
+            const int32_t t_gap = v.tpos(j - 1) + v.span(j - 1) - t_end, q_gap = v.qpos(j - 1) + v.span(j - 1) - q_end;
+            if ((t_gap < q_gap ? t_gap : q_gap) > skew_here + skew_next) break;
+            t_end = v.tpos(j); q_end = v.qpos(j);
+            skew_here = skew_next;
+            last = m;
         }
-        if (max_diff > diff_thres && max_diff > mx) { mx = max_diff; max_st = k; max_en = max_diff_l; }
+        if (last > k) {
+            for (int i = step[k]; i < step[last]; ++i) v.flag(i, PMX_SEED_IGNORE);
+            v.flag(step[last], PMX_SEED_LONG_JOIN);
+        }
+        k = last + 1;
     }
 }
 
-// mm_filter_bad_seeds_alt (align.c:429-462)
-PMX_HDN void filter_bad_seeds_alt(Work& W, int as1, int cnt1, Ptr<A128> a, int min_gap, int max_ext) {
-    PMX_LDS(&W); PMX_LDS(a);
-    Ptr<int32_t> K = W.kidx; PMX_LDS(K);
-    const int n = collect_long_gaps(W, as1, cnt1, a, min_gap, K, W.caps.max_anchor);
-    if (n == 0) return;
-    for (int k = 0; k < n;) {
-        const int i = K[k];
-        int l;
-        int gap1 = ((int32_t)a[as1 + i].y - (int32_t)a[as1 + i - 1].y) - ((int32_t)a[as1 + i].x - (int32_t)a[as1 + i - 1].x);
-        int re1 = (int32_t)a[as1 + i].x;
-        int qe1 = (int32_t)a[as1 + i].y;
-        gap1 = gap1 > 0 ? gap1 : -gap1;
-        for (l = k + 1; l < n; ++l) {
-            const int j = K[l];
-            if ((int32_t)a[as1 + j].y - qe1 > max_ext || (int32_t)a[as1 + j].x - re1 > max_ext) break;
-            int gap2 = ((int32_t)a[as1 + j].y - (int32_t)a[as1 + j - 1].y) - (int32_t)(a[as1 + j].x - a[as1 + j - 1].x);
-            const int q_span_pre = (int)(a[as1 + j - 1].y >> 32 & 0xff);
-            const int rs2 = (int32_t)a[as1 + j - 1].x + q_span_pre;
-            const int qs2 = (int32_t)a[as1 + j - 1].y + q_span_pre;
-            const int m = rs2 - re1 < qs2 - qe1 ? rs2 - re1 : qs2 - qe1;
-            gap2 = gap2 > 0 ? gap2 : -gap2;
-            if (m > gap1 + gap2) break;
-            re1 = (int32_t)a[as1 + j].x;
-            qe1 = (int32_t)a[as1 + j].y;
-            gap1 = gap2;
-        }
-        if (l > k + 1) {
-            const int end = K[l - 1];
-            for (int j = K[k]; j < end; ++j) a[as1 + j].y |= PMX_SEED_IGNORE;
-            a[as1 + end].y |= PMX_SEED_LONG_JOIN;
-        }
-        k = l;
+// The ends of a chain are trimmed where they run off the diagonal (what mm_fix_bad_ends does, align.c:464-502).  Both ends
+// are walked inwards over neighbouring anchors lo < hi with one rule: a step whose reference and query advance differ by
+// more than half of the bases covered so far moves the end to the step's inner anchor; the walk stops at a LONG_JOIN mark
+// and once enough bases were covered or matched (two band widths covered, `min_match` and a band width matched, or half of
+// the region's matching bases).
+struct EndWalk {
+    int32_t covered, matched;
+    PMX_HD explicit EndWalk(int32_t span0) : covered(span0), matched(span0) {}
+    // the step lo -> hi (= lo + 1); the span that counts is the later anchor's.  true: this step runs off the diagonal
+    template <class V> PMX_HD bool off_diagonal(const V& v, int lo, int hi) const {
+        const int32_t dt = v.tpos(hi) - v.tpos(lo), dq = v.qpos(hi) - v.qpos(lo);
+        return (dt > dq ? dt - dq : dq - dt) > covered >> 1;
     }
-}
+    template <class V> PMX_HD void take(const V& v, int lo, int hi) {
+        const int32_t dt = v.tpos(hi) - v.tpos(lo), dq = v.qpos(hi) - v.qpos(lo);
+        const int32_t adv = dt < dq ? dt : dq, sp = v.span(hi);
+        covered += adv;
+        matched += adv < sp ? adv : sp;
+    }
+    PMX_HD bool enough(int bw, int min_match, int32_t region_matches) const {
+        return covered >= bw << 1 || (matched >= min_match && matched >= bw) || matched >= region_matches >> 1;
+    }
+};
 
-// mm_fix_bad_ends (align.c:464-502)
 PMX_HDN void fix_bad_ends(const Reg& r, Ptr<const A128> a, int bw, int min_match, int32_t* as, int32_t* cnt) {
     PMX_LDS(&r); PMX_LDS(a);
     *as = r.as;
     *cnt = r.cnt;
     if (r.cnt < 3) return;
-    int32_t m, l;
-    m = l = (int32_t)(a[r.as].y >> 32 & 0xff);
-    for (int32_t i = r.as + 1; i < r.as + r.cnt - 1; ++i) {
-        const int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff);
-        if (a[i].y & PMX_SEED_LONG_JOIN) break;
-        const int32_t lr = (int32_t)a[i].x - (int32_t)a[i - 1].x;
-        const int32_t lq = (int32_t)a[i].y - (int32_t)a[i - 1].y;
-        const int32_t mn = lr < lq ? lr : lq, mxv = lr > lq ? lr : lq;
-        if (mxv - mn > l >> 1) *as = i;
-        l += mn;
-        m += mn < q_span ? mn : q_span;
-        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+    const ConstAnchorView v{a, r.as};
+    const int n = r.cnt;
+    int first = 0;                            // the kept anchors are [first, first + kept) of the view
+    {
+        EndWalk w(v.span(0));
+        for (int hi = 1; hi < n - 1; ++hi) {
+            if (v.joined(hi)) break;
+            if (w.off_diagonal(v, hi - 1, hi)) first = hi;
+            w.take(v, hi - 1, hi);
+            if (w.enough(bw, min_match, r.mlen)) break;
+        }
     }
-    *cnt = r.as + r.cnt - *as;
-    m = l = (int32_t)(a[r.as + r.cnt - 1].y >> 32 & 0xff);
-    for (int32_t i = r.as + r.cnt - 2; i > *as; --i) {
-        const int32_t q_span = (int32_t)(a[i + 1].y >> 32 & 0xff);
-        if (a[i + 1].y & PMX_SEED_LONG_JOIN) break;
-        const int32_t lr = (int32_t)a[i + 1].x - (int32_t)a[i].x;
-        const int32_t lq = (int32_t)a[i + 1].y - (int32_t)a[i].y;
-        const int32_t mn = lr < lq ? lr : lq, mxv = lr > lq ? lr : lq;
-        if (mxv - mn > l >> 1) *cnt = i + 1 - *as;
-        l += mn;
-        m += mn < q_span ? mn : q_span;
-        if (l >= bw << 1 || (m >= min_match && m >= bw) || m >= r.mlen >> 1) break;
+    int kept = n - first;
+    {
+        EndWalk w(v.span(n - 1));
+        for (int lo = n - 2; lo > first; --lo) {
+            if (v.joined(lo + 1)) break;
+            if (w.off_diagonal(v, lo, lo + 1)) kept = lo + 1 - first;
+            w.take(v, lo, lo + 1);
+            if (w.enough(bw, min_match, r.mlen)) break;
+        }
     }
+    *as = r.as + first;
+    *cnt = kept;
+}
+
+// How far beyond the chain's outermost (adjusted) anchor an end extension may reach, on the query and on the reference
+// (the window computation of mm_align1, align.c:636-691, written once for both ends in DISTANCES from that anchor):
+//   room_q / room_t   bases left on the read / the reference beyond the anchor
+//   fence_q / fence_t where neighbouring chains on the same strand begin to own the bases (the room if there are none)
+//   own_q / own_t     where the region's own outermost anchor ends (it may lie beyond the adjusted one)
+// The query reach is max_gap at most; the reference reach adds the bases a gap-free extension of that length could pay for
+// with gap extensions, capped by max_gap again.  Neither crosses the fence; the region's own anchor is always inside.
+struct Reach { int32_t q, t; };
+PMX_HD Reach extension_reach(const Opt& o, int32_t room_q, int32_t room_t, Reach fence, Reach own) {
+    int32_t len = room_q < o.max_gap ? room_q : o.max_gap;
+    if (fence.q > len) fence.q = len;
+    if (own.q < fence.q) own.q = fence.q;
+    if (len * o.a > o.q) len += (len * o.a - o.q) / o.e;
+    if (len > o.max_gap) len = o.max_gap;
+    if (len > room_t) len = room_t;
+    if (fence.t > len) fence.t = len;
+    if (own.t < fence.t) own.t = fence.t;
+    return own;
 }
 
 // mm_align1 (align.c:575-833)
@@ -442,7 +560,7 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
     const int32_t rev = (int32_t)(a[r.as].x >> 63);
     int32_t as1, cnt1;
     Ptr<uint8_t> tseq = W.tseq; PMX_LDS(tseq);
-    int32_t l, dropped = 0, rs0, re0, qs0, qe0;
+    int32_t dropped = 0, rs0, re0, qs0, qe0;
     int32_t rs, re, qs, qe;
     int32_t rs1, qs1, re1, qe1;
     const int32_t ref_len = ri.len;
@@ -459,60 +577,50 @@ PMX_HDN void align1(Work& W, const Opt& o, const RefIndex& ri, int qlen, const P
     adjust_minier(o, a[as1], &rs, &qs);
     adjust_minier(o, a[as1 + cnt1 - 1], &re, &qe);
 
-    // region to align (align.c:636-691)
-    rs0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
-    qs0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
-    if (rs0 < 0) rs0 = 0;
-    rs1 = qs1 = 0;
-    l = 0;
-    for (int32_t i = r.as - 1; i >= 0 && a[i].x >> 32 == a[r.as].x >> 32; --i) {
-        const int32_t x = (int32_t)a[i].x + 1 - (int32_t)(a[i].y >> 32 & 0xff);
-        const int32_t y = (int32_t)a[i].y + 1 - (int32_t)(a[i].y >> 32 & 0xff);
-        if (x < rs0 && y < qs0) {
-            if (++l > o.min_cnt) {
-                l = rs0 - x > qs0 - y ? rs0 - x : qs0 - y;
-                rs1 = rs0 - l; qs1 = qs0 - l;
-                if (rs1 < 0) rs1 = 0;
-                break;
+    // The window the end extensions may use (align.c:636-691), in distances from the adjusted outer anchors (rs, qs) and
+    // (re, qe): extension_reach.  A chain of the same strand fences an extension off once more than min_cnt of its anchors lie
+    // wholly beyond the region's own first (last) anchor: the fence stands as far out as the nearest such anchor's far corner.
+    {
+        const uint64_t strand_rid = a[r.as].x >> 32;
+        const int32_t own_t0 = (int32_t)a[r.as].x + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+        const int32_t own_q0 = (int32_t)a[r.as].y + 1 - (int32_t)(a[r.as].y >> 32 & 0xff);
+        const int32_t own_t = own_t0 < 0 ? 0 : own_t0;
+        if (qs > 0 && rs > 0) {
+            Reach fence{qs, rs};                                  // no neighbour: the start of the read / the reference
+            int seen = 0;
+            for (int32_t i = r.as - 1; i >= 0 && a[i].x >> 32 == strand_rid; --i) {
+                const int32_t sp = (int32_t)(a[i].y >> 32 & 0xff), t_i = (int32_t)a[i].x + 1 - sp, q_i = (int32_t)a[i].y + 1 - sp;
+                if (t_i >= own_t || q_i >= own_q0) continue;
+                if (++seen > o.min_cnt) {
+                    const int32_t back = own_t - t_i > own_q0 - q_i ? own_t - t_i : own_q0 - q_i;
+                    fence.q = qs - (own_q0 - back);
+                    fence.t = rs - (own_t - back);
+                    break;
+                }
             }
-        }
-    }
-    if (qs > 0 && rs > 0) {
-        l = qs < o.max_gap ? qs : o.max_gap;
-        qs1 = qs1 > qs - l ? qs1 : qs - l;
-        qs0 = qs0 < qs1 ? qs0 : qs1;
-        l += l * o.a > o.q ? (l * o.a - o.q) / o.e : 0;
-        l = l < o.max_gap ? l : o.max_gap;
-        l = l < rs ? l : rs;
-        rs1 = rs1 > rs - l ? rs1 : rs - l;
-        rs0 = rs0 < rs1 ? rs0 : rs1;
-        rs0 = rs0 < rs ? rs0 : rs;
-    } else { rs0 = rs; qs0 = qs; }
-    re0 = (int32_t)a[r.as + r.cnt - 1].x + 1;
-    qe0 = (int32_t)a[r.as + r.cnt - 1].y + 1;
-    re1 = ref_len; qe1 = qlen;
-    l = 0;
-    for (int32_t i = r.as + r.cnt; i < n_a && a[i].x >> 32 == a[r.as].x >> 32; ++i) {
-        const int32_t x = (int32_t)a[i].x + 1;
-        const int32_t y = (int32_t)a[i].y + 1;
-        if (x > re0 && y > qe0) {
-            if (++l > o.min_cnt) {
-                l = x - re0 > y - qe0 ? x - re0 : y - qe0;
-                re1 = re0 + l; qe1 = qe0 + l;
-                break;
+            const Reach rch = extension_reach(o, qs, rs, fence, Reach{qs - own_q0, rs - own_t});
+            qs0 = qs - rch.q;
+            rs0 = rs - (rch.t < 0 ? 0 : rch.t);                  // (never inside the adjusted anchor)
+        } else { rs0 = rs; qs0 = qs; }
+        const int32_t own_t1 = (int32_t)a[r.as + r.cnt - 1].x + 1, own_q1 = (int32_t)a[r.as + r.cnt - 1].y + 1;
+        if (qe < qlen && re < ref_len) {
+            Reach fence{qlen - qe, ref_len - re};
+            int seen = 0;
+            for (int32_t i = r.as + r.cnt; i < n_a && a[i].x >> 32 == strand_rid; ++i) {
+                const int32_t t_i = (int32_t)a[i].x + 1, q_i = (int32_t)a[i].y + 1;
+                if (t_i <= own_t1 || q_i <= own_q1) continue;
+                if (++seen > o.min_cnt) {
+                    const int32_t ahead = t_i - own_t1 > q_i - own_q1 ? t_i - own_t1 : q_i - own_q1;
+                    fence.q = own_q1 + ahead - qe;
+                    fence.t = own_t1 + ahead - re;
+                    break;
+                }
             }
-        }
+            const Reach rch = extension_reach(o, qlen - qe, ref_len - re, fence, Reach{own_q1 - qe, own_t1 - re});
+            qe0 = qe + rch.q;
+            re0 = re + rch.t;
+        } else { re0 = re; qe0 = qe; }
     }
-    if (qe < qlen && re < ref_len) {
-        l = qlen - qe < o.max_gap ? qlen - qe : o.max_gap;
-        qe1 = qe1 < qe + l ? qe1 : qe + l;
-        qe0 = qe0 > qe1 ? qe0 : qe1;
-        l += l * o.a > o.q ? (l * o.a - o.q) / o.e : 0;
-        l = l < o.max_gap ? l : o.max_gap;
-        l = l < ref_len - re ? l : ref_len - re;
-        re1 = re1 < re + l ? re1 : re + l;
-        re0 = re0 > re1 ? re0 : re1;
-    } else { re0 = re; qe0 = qe; }
     if (re0 - rs0 > W.caps.max_tlen || re0 <= rs0) { W.status |= PMX_ST_OVERFLOW; return; }
 
     PMX_STAMP(W, 20);

@@ -40,109 +40,138 @@ PMX_HD void set_pe_thru(const int* qlens, const int* n_regs, Reg* const* regs) {
     }
 }
 
-// mm_pair (pe.c:76-177)
+// Pairing of the two mates' regions (what mm_pair decides, pe.c:76-177).
+//
+// Every region of either mate is an END of a possible fragment: a forward region of mate 1 or a reverse region of mate 2
+// OPENS a fragment on its strand, the other two kinds CLOSE one.  The reference sorts the ends by (reference start, kind)
+// and sweeps the sorted array; with a handful of regions per mate no array is built here: the ends are visited in that
+// order by selection (the order of equal keys is the enumeration order -- mate 1's regions, then mate 2's -- which is what
+// the reference's stable insertion sort leaves; more than 64 ends would take its unstable radix sort and are refused).
+// For a closing end the candidates are the opening ends of the OTHER mate on the same strand that precede it, nearest
+// first, until one lies further back than the maximal fragment length; before that, the nearest opening end of the strand
+// from EITHER mate must pass the same distance test.  A pair scores the sum of the two dp_max (the regions' hashes break
+// ties); the first pair found with the best score wins.
+// The mapq of the winner needs the runner-up's score and the number of pairs within sub_diff of the best: a running
+// top two replaces the reference's sort of all scores, the count is taken from the stored upper halves.
 PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, const int* qlens, int* n_regs,
                       Reg* const* regs) {
-    // pair array (s, rev, key, reg index) kept as parallel arrays in the idle chaining scratch
     PMX_LDS(&W); PMX_LDS(qlens); PMX_LDS(n_regs);
-    Reg* r0_ = regs[0]; Reg* r1_ = regs[1];
-    PMX_LDS(r0_); PMX_LDS(r1_);
-#define PMX_REGS(s) ((s) ? r1_ : r0_)
-    const int cap = W.caps.max_reg * 2;
-    Ptr<uint64_t> key = W.aux64; PMX_LDS(key);                 // [cap]
-    Ptr<int32_t> ps = W.aux32; PMX_LDS(ps);                    // [cap] segment
-    Ptr<int32_t> pi = ps + cap;                                // [cap] index in regs[s]
-    Ptr<uint64_t> sc = ptr_cast<uint64_t>(W.z); PMX_LDS(sc);   // pair scores
-    const int sc_cap = W.caps.max_anchor * 2;      // z holds max_anchor A128
-    int n = 0, segs = 0, dp_thres = 0;
-    for (int s = 0; s < 2; ++s) {
-        int mx = 0;
-        for (int i = 0; i < n_regs[s]; ++i) {
-            const Reg& r = PMX_REGS(s)[i];
-            ps[n] = s;
-            pi[n] = i;
-            key[n] = (uint64_t)(uint32_t)r.rid << 32 | (uint32_t)(r.rs << 1) | (uint32_t)(s ^ r.rev);
-            mx = mx > r.dp_max ? mx : r.dp_max;
-            ++n;
-            segs |= 1 << s;
-        }
-        dp_thres += mx;
+    Reg* m0 = regs[0]; Reg* m1 = regs[1];
+    PMX_LDS(m0); PMX_LDS(m1);
+    const int n0 = n_regs[0], n_ends = n0 + n_regs[1];
+    if (n0 == 0 || n_regs[1] == 0) return;   // only one end is mapped
+    auto mate_of = [&](int e) { return e >= n0 ? 1 : 0; };
+    auto reg_of = [&](int e) -> Reg& { return e >= n0 ? m1[e - n0] : m0[e]; };
+    auto key_of = [&](int e) {
+        const Reg& r = reg_of(e);
+        return (uint64_t)(uint32_t)r.rid << 32 | (uint32_t)(r.rs << 1) | (uint32_t)(mate_of(e) ^ r.rev);
+    };
+    if (n_ends > 64) { W.status |= PMX_ST_UNSUPPORTED; return; }
+    // a pair must reach the two best single scores minus the bonus
+    int floor_dp = -pe_bonus;
+    for (int m = 0; m < 2; ++m) {
+        int top = 0;
+        for (int i = 0; i < n_regs[m]; ++i) { const int d = (m ? m1 : m0)[i].dp_max; top = top > d ? top : d; }
+        floor_dp += top;
     }
-    if (segs != 3) return;   // only one end is mapped
-    dp_thres -= pe_bonus;
-    if (dp_thres < 0) dp_thres = 0;
-    if (n > 64) { W.status |= PMX_ST_UNSUPPORTED; return; }   // beyond the stable insertion-sort regime of radix_sort_pair
-    for (int i = 1; i < n; ++i) {   // rs_insertsort on key
-        if (key[i] < key[i - 1]) {
-            const uint64_t tk = key[i];
-            const int32_t ts = ps[i], ti = pi[i];
-            int j;
-            for (j = i; j > 0 && tk < key[j - 1]; --j) { key[j] = key[j - 1]; ps[j] = ps[j - 1]; pi[j] = pi[j - 1]; }
-            key[j] = tk; ps[j] = ts; pi[j] = ti;
+    if (floor_dp < 0) floor_dp = 0;
+
+    Ptr<uint64_t> hi_scores = ptr_cast<uint64_t>(W.z); PMX_LDS(hi_scores);   // dp sums of every pair found (for the count)
+    const int hi_cap = W.caps.max_anchor * 2;                                 // z holds max_anchor 16-byte cells
+    int n_pairs = 0;
+    int64_t best = -1, second = -1;       // the two largest pair scores (equal scores count twice)
+    int best_end[2] = {-1, -1};
+
+    // the end after (k_prev, e_prev) in the sweep order whose kind bit equals `closing`; -1 when there is none
+    auto next_end = [&](bool started, uint64_t k_prev, int e_prev, uint32_t closing) {
+        int pick = -1;
+        uint64_t k_pick = 0;
+        for (int e = 0; e < n_ends; ++e) {
+            const uint64_t k = key_of(e);
+            if ((uint32_t)(k & 1) != closing) continue;
+            if (started && (k < k_prev || (k == k_prev && e <= e_prev))) continue;
+            if (pick < 0 || k < k_pick) { pick = e; k_pick = k; }   // (ascending e: the first of equal keys is kept)
+        }
+        return pick;
+    };
+    // the opening end of strand `rev` just before (k_lim, e_lim) in the sweep order, from mate `want` (-1: either mate)
+    auto opening_before = [&](uint64_t k_lim, int e_lim, int rev, int want) {
+        int pick = -1;
+        uint64_t k_pick = 0;
+        for (int e = 0; e < n_ends; ++e) {
+            const uint64_t k = key_of(e);
+            if ((k & 1) || (int)reg_of(e).rev != rev || (want >= 0 && mate_of(e) != want)) continue;
+            if (k > k_lim || (k == k_lim && e >= e_lim)) continue;
+            if (pick < 0 || k > k_pick || (k == k_pick && e > pick)) { pick = e; k_pick = k; }
+        }
+        return pick;
+    };
+
+    bool started = false;
+    uint64_t k_cur = 0;
+    int e_cur = -1;
+    for (;;) {
+        const int c = next_end(started, k_cur, e_cur, 1u);
+        if (c < 0) break;
+        started = true; k_cur = key_of(c); e_cur = c;
+        const Reg& rc = reg_of(c);
+        const int near = opening_before(k_cur, c, rc.rev, -1);
+        if (near < 0) continue;
+        { const Reg& q = reg_of(near); if (rc.rid != q.rid || rc.rs - q.re > max_gap_ref) continue; }
+        uint64_t k_lim = k_cur;
+        int e_lim = c;
+        for (;;) {
+            const int p = opening_before(k_lim, e_lim, rc.rev, 1 - mate_of(c));
+            if (p < 0) break;
+            k_lim = key_of(p); e_lim = p;
+            const Reg& q = reg_of(p);
+            if (rc.rid != q.rid || rc.rs - q.re > max_gap_ref) break;
+            if (rc.dp_max + q.dp_max < floor_dp) continue;
+            const int64_t score = (int64_t)(rc.dp_max + q.dp_max) << 32 | (uint32_t)(rc.hash + q.hash);
+            if (score > best) { second = best; best = score; best_end[mate_of(p)] = p; best_end[mate_of(c)] = c; }
+            else if (score > second) second = score;
+            if (n_pairs < hi_cap) hi_scores[n_pairs] = (uint64_t)(uint32_t)(rc.dp_max + q.dp_max);
+            else W.status |= PMX_ST_OVERFLOW;
+            ++n_pairs;
         }
     }
-    int64_t mx = -1;
-    int max_idx[2] = {-1, -1}, last[2] = {-1, -1};
-    int n_sc = 0;
-    for (int i = 0; i < n; ++i) {
-        const Reg& ri_ = PMX_REGS(ps[i])[pi[i]];
-        const int rev_i = ri_.rev;
-        if (key[i] & 1) {   // reverse first read or forward second read
-            if (last[rev_i] < 0) continue;
-            const Reg* q = &PMX_REGS(ps[last[rev_i]])[pi[last[rev_i]]];
-            if (ri_.rid != q->rid || ri_.rs - q->re > max_gap_ref) continue;
-            for (int j = last[rev_i]; j >= 0; --j) {
-                q = &PMX_REGS(ps[j])[pi[j]];
-                if (q->rev != rev_i || ps[j] == ps[i]) continue;
-                if (ri_.rid != q->rid || ri_.rs - q->re > max_gap_ref) break;
-                if (ri_.dp_max + q->dp_max < dp_thres) continue;
-                const int64_t score = (int64_t)(ri_.dp_max + q->dp_max) << 32 | (uint32_t)(ri_.hash + q->hash);
-                if (score > mx) { mx = score; max_idx[ps[j]] = j; max_idx[ps[i]] = i; }
-                if (n_sc < sc_cap) sc[n_sc++] = (uint64_t)score;
-                else W.status |= PMX_ST_OVERFLOW;
+    if (n_pairs > hi_cap) n_pairs = hi_cap;
+
+    if (n_pairs > 0 && best > 0) {
+        Reg* won[2] = {&reg_of(best_end[0]), &reg_of(best_end[1])};
+        won[0]->proper_frag = won[1]->proper_frag = 1;
+        for (int m = 0; m < 2; ++m) {
+            Reg* all = m ? m1 : m0;
+            Reg* w = won[m];
+            if (w->id != w->parent) {   // a secondary won: it takes its primary's place, the former primary keeps no mapq
+                Reg& old_pri = all[w->parent];
+                const int old_id = old_pri.id;
+                for (int i = 0; i < n_regs[m]; ++i)
+                    if (all[i].parent == old_id) all[i].parent = w->id;
+                old_pri.mapq = 0;
             }
-        } else last[rev_i] = i;
-    }
-    if (n_sc > 1) radix_sort_64(sc, sc + n_sc, &W.status);
-    if (n_sc > 0 && mx > 0) {
-        int n_sub = 0, mapq_pe;
-        Reg* r[2];
-        r[0] = &r0_[pi[max_idx[0]]];
-        r[1] = &r1_[pi[max_idx[1]]];
-        r[0]->proper_frag = r[1]->proper_frag = 1;
-        for (int s = 0; s < 2; ++s) {
-            if (r[s]->id != r[s]->parent) {   // lift to primary and update parent
-                Reg* p = &PMX_REGS(s)[r[s]->parent];
-                const int pid = p->id;
-                for (int i = 0; i < n_regs[s]; ++i)
-                    if (PMX_REGS(s)[i].parent == pid) PMX_REGS(s)[i].parent = r[s]->id;
-                p->mapq = 0;
-            }
-            if (!r[s]->sam_pri) {
-                for (int i = 0; i < n_regs[s]; ++i) PMX_REGS(s)[i].sam_pri = 0;
-                r[s]->sam_pri = 1;
+            if (!w->sam_pri) {
+                for (int i = 0; i < n_regs[m]; ++i) all[i].sam_pri = 0;
+                w->sam_pri = 1;
             }
         }
-        mapq_pe = r[0]->mapq > r[1]->mapq ? r[0]->mapq : r[1]->mapq;
-        for (int i = 0; i < n_sc; ++i)
-            if ((sc[i] >> 32) + (uint64_t)sub_diff >= (uint64_t)mx >> 32) ++n_sub;
-        if (n_sc > 1) {
-            if (n_sub >= ri.n_logf) { W.status |= PMX_ST_UNSUPPORTED; n_sub = ri.n_logf - 1; }
-            const int mapq_pe_alt = (int)(6.02f * (float)((mx >> 32) - (int64_t)(sc[n_sc - 2] >> 32)) / match_sc - 4.343f * ri.logf_int[n_sub]);
-            mapq_pe = mapq_pe < mapq_pe_alt ? mapq_pe : mapq_pe_alt;
+        const uint32_t best_hi = (uint32_t)((uint64_t)best >> 32);
+        int pe_q = won[0]->mapq > won[1]->mapq ? won[0]->mapq : won[1]->mapq;
+        if (n_pairs > 1) {
+            int close = 0;                // pairs within sub_diff of the best (the best included)
+            for (int i = 0; i < n_pairs; ++i) close += hi_scores[i] + (uint64_t)sub_diff >= (uint64_t)best_hi;
+            if (close >= ri.n_logf) { W.status |= PMX_ST_UNSUPPORTED; close = ri.n_logf - 1; }
+            const int by_margin = (int)(6.02f * (float)((best >> 32) - (second >> 32)) / match_sc - 4.343f * ri.logf_int[close]);
+            pe_q = pe_q < by_margin ? pe_q : by_margin;
         }
-        if (r[0]->mapq < mapq_pe) r[0]->mapq = (uint8_t)(int)(.2f * r[0]->mapq + .8f * mapq_pe + .499f);
-        if (r[1]->mapq < mapq_pe) r[1]->mapq = (uint8_t)(int)(.2f * r[1]->mapq + .8f * mapq_pe + .499f);
-        if (n_sc == 1) {
-            if (r[0]->mapq < 2) r[0]->mapq = 2;
-            if (r[1]->mapq < 2) r[1]->mapq = 2;
-        } else if ((uint64_t)mx >> 32 > sc[n_sc - 2] >> 32) {
-            if (r[0]->mapq < 1) r[0]->mapq = 1;
-            if (r[1]->mapq < 1) r[1]->mapq = 1;
+        const int at_least = n_pairs == 1 ? 2 : (best_hi > (uint32_t)((uint64_t)second >> 32) ? 1 : 0);
+        for (int m = 0; m < 2; ++m) {
+            Reg* w = won[m];
+            if (w->mapq < pe_q) w->mapq = (uint8_t)(int)(.2f * w->mapq + .8f * pe_q + .499f);
+            if (w->mapq < at_least) w->mapq = (uint8_t)at_least;
         }
     }
     set_pe_thru(qlens, n_regs, regs);
-#undef PMX_REGS
 }
 
 // mm_est_err (esterr.c:30-64): per region, the fraction of the read's minimizers between its first and last anchor that
@@ -152,45 +181,52 @@ PMX_HDN void pair_hits(Work& W, const RefIndex& ri, int max_gap_ref, int pe_bonu
 // (filter_strand_retained) flags a comparison that a last-bit difference could turn.
 PMX_HDN void est_err(Work& W, int l_ref, int qlen, int n_regs, Reg* regs, Ptr<A128> a) {
     PMX_LDS(&W); PMX_LDS(regs);
-    const int n = W.n_seeds;
-    if (n == 0) return;
-    Ptr<SeedA> sa = W.seeds; PMX_LDS(sa);
-    Ptr<SeedB> sb = W.seeds_b; PMX_LDS(sb);
-    uint64_t sum_k = 0;
-    for (int i = 0; i < n; ++i) sum_k += sb[i].q_span & 0xff;
-    const float avg_k = (float)sum_k / n;
-    auto for_qpos = [&](const A128 p) {   // get_for_qpos
-        int32_t x = (int32_t)p.y;
-        const int32_t q_span = (int32_t)(p.y >> 32 & 0xff);
-        if (p.x >> 63) x = qlen - 1 - (x + 1 - q_span);
-        return x;
-    };
+    const int n_mini = W.n_seeds;
+    if (n_mini == 0) return;
+    Ptr<SeedA> mini = W.seeds; PMX_LDS(mini);
+    Ptr<SeedB> mini_b = W.seeds_b; PMX_LDS(mini_b);
+    float mean_span;
+    {
+        uint64_t spans = 0;
+        for (int i = 0; i < n_mini; ++i) spans += mini_b[i].q_span & 0xff;
+        mean_span = (float)spans / n_mini;
+    }
+    auto mini_at = [&](int m) { return (int32_t)(mini[m].q_pos >> 1); };
     for (int i = 0; i < n_regs; ++i) {
         Reg& r = regs[i];
         r.div = -1.0f;
         if (r.cnt == 0) continue;
-        int32_t st = -1;
-        {   // get_mini_idx: binary search of the first anchor's query position
-            const int32_t x = for_qpos(r.rev ? a[r.as + r.cnt - 1] : a[r.as]);
-            int32_t L = 0, R = n - 1;
-            while (L <= R) {
-                const int32_t m = (int32_t)(((uint64_t)L + (uint64_t)R) >> 1);
-                const int32_t y = (int32_t)(sa[m].q_pos >> 1);
-                if (y < x) L = m + 1;
-                else if (y > x) R = m - 1;
-                else { st = m; break; }
+        // the region's anchors in the order of the read as sequenced (a reverse-strand chain runs backwards through it), each
+        // as the position of its minimizer's last base on that strand
+        auto anchor_at = [&](int k) {
+            const A128 p = r.rev ? a[r.as + r.cnt - 1 - k] : a[r.as + k];
+            const int32_t last = (int32_t)p.y, span = (int32_t)(p.y >> 32 & 0xff);
+            return (p.x >> 63) ? qlen - 1 - (last + 1 - span) : last;
+        };
+        // the first anchor among the minimizers (they are in read order): bisection; an anchor that is no minimizer of the
+        // list (cannot happen for a chain of this read) leaves the estimate unset
+        int first = -1;
+        {
+            const int32_t want = anchor_at(0);
+            int32_t lo = 0, hi = n_mini - 1;
+            while (lo <= hi && first < 0) {
+                const int32_t mid = (int32_t)(((uint64_t)lo + (uint64_t)hi) >> 1), at = mini_at(mid);
+                if (at == want) first = mid;
+                else if (at < want) lo = mid + 1;
+                else hi = mid - 1;
             }
         }
-        if (st < 0) continue;
-        int32_t en = st, k = 1, n_match = 1;
-        for (int32_t j = st + 1; j < n && k < r.cnt; ++j) {
-            const int32_t x = for_qpos(r.rev ? a[r.as + r.cnt - 1 - k] : a[r.as + k]);
-            if (x == (int32_t)(sa[j].q_pos >> 1)) { ++k; en = j; ++n_match; }
-        }
-        int32_t n_tot = en - st + 1;
-        if (r.qs > avg_k && r.rs > avg_k) ++n_tot;
-        if (qlen - r.qs > avg_k && l_ref - r.re > avg_k) ++n_tot;
-        r.div = n_match >= n_tot ? 0.0f : (float)(1.0 - pow((double)n_match / n_tot, 1.0 / avg_k));
+        if (first < 0) continue;
+        // walk the minimizers from there and tick off the anchors in turn: `hits` of the minimizers up to the last one
+        // ticked off are anchors of the chain
+        int32_t last_hit = first, hits = 1;
+        for (int32_t m = first + 1; m < n_mini && hits < r.cnt; ++m)
+            if (mini_at(m) == anchor_at(hits)) { last_hit = m; ++hits; }
+        int32_t trials = last_hit - first + 1;
+        // a chain that stops short of the read's (reference's) ends missed one more minimizer on that side
+        trials += (r.qs > mean_span && r.rs > mean_span) ? 1 : 0;
+        trials += (qlen - r.qs > mean_span && l_ref - r.re > mean_span) ? 1 : 0;
+        r.div = hits >= trials ? 0.0f : (float)(1.0 - pow((double)hits / trials, 1.0 / mean_span));
     }
 }
 
