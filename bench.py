@@ -310,15 +310,13 @@ def main():
             self.d_concat = [torch.empty(int(concat.size), dtype=torch.uint8, device=dev) for _ in range(2)]
             self.d_off = [torch.empty(n_reads + 1, dtype=torch.int64, device=dev) for _ in range(2)]
             self.up_ev = [None, None]
-            self.d_recs = torch.empty((n_reads, 32), dtype=torch.uint8, device=dev)
-            self.d_cig = None
+            self.dist = None
             self.out_recs = None
             self.out_cig = None
             self.pool = {}
             self.res = None
             self.ref = None
             self.gathered = None
-            self.keep = None
             self.nw = 0
 
         def alloc_outputs(self):
@@ -343,18 +341,8 @@ def main():
             return t
 
         def exchange_histograms(self):
-            """all-gather the per-rank (hash,count) histograms, merge the other ranks' parts"""
-            placer, ctx = self.placer, self.ctx
-            n_loc = placer.histogram_entries()       # (no sort here: the one sorted histogram is made after the merge)
-            h_sizes = np.asarray(pdist.exchange_sizes(n_loc, dev, via_host=test_gloo), np.int64)   # one host round trip
-            mx = max(int(h_sizes.max()), 1)
-            mine = torch.empty((2, mx), dtype=torch.int64, device=dev)
-            placer.export_device_unsorted(mine[0].data_ptr(), mine[1].data_ptr(), mx)
-            ctx.synchronize()                          # the export ran on the context's stream, the collective runs on torch's
-            allh = pdist.allgather_padded(mine, via_host=test_gloo)
-            torch.cuda.current_stream(dev).synchronize()
-            # rank p's run sits 2*mx elements after rank p-1's in both the hash and the count plane
-            placer.merge_device_parts(allh[0, 0].data_ptr(), allh[0, 1].data_ptr(), 2 * mx, h_sizes, rank)
+            """pmx_dist_merge_histograms: RCCL all-gather of the per-rank (hash,count) histograms + integer merge on the device"""
+            self.dist.merge_histograms(self.placer)
 
         def place_and_align(self, all_rs, n_total_reads, mean_read_len, is_paired, revcomp_mate2, seq=None, batch=0):
             """the hot path on reads already packed and seeded into the placer; `all_rs` = the read set the aligner runs on"""
@@ -380,14 +368,8 @@ def main():
             self.res, self.ref = res, ref
 
         def gather_results(self):
-            """N>1: fixed-size records + the CIGAR arena of every rank to rank 0, cigar_off rebased (dist.gather_alignments)"""
-            al = self.aligner
-            al.copy_records_device(self.d_recs.data_ptr(), n_reads)
-            nw = al.cigar_words()
-            if self.d_cig is None or self.d_cig.numel() < max(nw, 1):
-                self.d_cig = torch.empty(max(nw, 1) * 5 // 4 + 1024, dtype=torch.int32, device=dev)
-            al.copy_cigars_device(self.d_cig.data_ptr(), max(nw, 1))
-            self.gathered = pdist.gather_alignments(self.d_recs, self.d_cig[:nw], 0, via_host=test_gloo)
+            """pmx_dist_gather_alignments: fixed-size records + the CIGAR arena of every rank to rank 0, cigar_off rebased"""
+            self.gathered = self.dist.gather_alignments(self.aligner, 0)       # (n_records, n_words) on rank 0
 
         # ---- the step with its inputs resident in HBM and its outputs left there (value_device_resident)
         def run_resident(self, rs):
@@ -455,39 +437,25 @@ def main():
             if tr is not None:
                 tr.append(("aligned", time.perf_counter()))
             al = self.aligner
+            # records + CIGAR arena into pinned host memory on the pipeline's own download stream (pmx_align_fetch_async /
+            # pmx_dist_fetch_gathered_async: the copies wait for the results, the next batch's kernels do not wait for the
+            # copies); the pipeline goes on with its next batch, finish() waits for the last download
             if dist_on:
                 if seq is not None:
                     seq.run("G", batch, self.gather_results)
                 else:
                     self.gather_results()
                 if rank != 0:
-                    self.ctx.synchronize()
-                    torch.cuda.current_stream(dev).synchronize()
                     return 0
-                g_recs, g_arena, _, _ = self.gathered
-                nw = int(g_arena.numel())
-                src_recs, src_cig = g_recs, g_arena
-                ev_done = torch.cuda.Event()
-                ev_done.record(torch.cuda.current_stream(dev))
+                n_rec, nw = self.gathered
+                if nw > self.out_cig.numel() or n_rec > self.out_recs.shape[0]:
+                    raise RuntimeError("pinned output buffers too small")
+                self.dist.fetch_gathered_async(self.out_recs.data_ptr(), self.out_recs.shape[0], self.out_cig.data_ptr(), self.out_cig.numel(), self.copy_out.cuda_stream)
             else:
                 nw = al.cigar_words()
-                self.copy_out.synchronize()       # (the previous batch's download read d_recs / d_cig: long finished)
-                al.copy_records_device(self.d_recs.data_ptr(), n_reads)
-                if self.d_cig is None or self.d_cig.numel() < max(nw, 1):
-                    self.d_cig = torch.empty(max(nw, 1) * 5 // 4 + 1024, dtype=torch.int32, device=dev)
-                al.copy_cigars_device(self.d_cig.data_ptr(), max(nw, 1))
-                src_recs, src_cig = self.d_recs, self.d_cig
-                ev_done = torch.cuda.Event()
-                ev_done.record(self.stream)
-            if nw > self.out_cig.numel():
-                raise RuntimeError("pinned CIGAR buffer too small")
-            # records + CIGAR arena into pinned host memory on the pipeline's own download stream; the pipeline goes on with
-            # its next batch and waits for the download when it needs the buffers again (finish() at the end of a run)
-            with torch.cuda.stream(self.copy_out):
-                self.copy_out.wait_event(ev_done)
-                self.out_recs[:src_recs.shape[0]].copy_(src_recs, non_blocking=True)
-                self.out_cig[:nw].copy_(src_cig[:nw], non_blocking=True)
-            self.keep = (src_recs, src_cig)       # (alive until the copies have run)
+                if nw > self.out_cig.numel():
+                    raise RuntimeError("pinned CIGAR buffer too small")
+                al.fetch_async(self.out_recs.data_ptr(), self.out_recs.shape[0], self.out_cig.data_ptr(), self.out_cig.numel(), self.copy_out.cuda_stream)
             if tr is not None:
                 tr.append(("d2h_enqueued", time.perf_counter()))
                 trace.append((id(self), batch, tr))
@@ -502,9 +470,24 @@ def main():
             for p_ in self.pool.values():
                 p_.close()
             self.pool = {}
+            if self.dist is not None:
+                self.dist.close()
+                self.dist = None
 
     pipes = [Pipe() for _ in range(n_pipes)]
     main_pipe = pipes[0]
+    if dist_on:
+        # one communicator per pipeline (pmx_dist_init = ncclCommInitRank); the 128-byte ids travel over the process group
+        # that the launcher's rendezvous set up.  test_gloo (ranks share a device): the library's host-directory transport.
+        import tempfile
+        for pi, pp in enumerate(pipes):
+            box = [None, None]
+            if rank == 0:
+                box = [pmx.Dist.unique_id() if not test_gloo else bytes(pmx.Dist.ID_BYTES), tempfile.mkdtemp(prefix="pmx_dist_%d_" % pi) if test_gloo else None]
+            dist.broadcast_object_list(box, src=0)
+            if test_gloo:
+                os.environ["PMX_DIST_HOST_DIR"] = box[1]
+            pp.dist = pmx.Dist(pp.ctx, box[0], rank, world)
 
     def sync_all():
         for pp in pipes:

@@ -327,6 +327,11 @@ int64_t pmx_align_num_records(const pmx_aligner *al);
 int64_t pmx_align_cigar_words(pmx_ctx *ctx, pmx_aligner *al);
 int pmx_align_fetch(pmx_ctx *ctx, pmx_aligner *al, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,
                     int64_t arena_cap);
+/* the same download without waiting for it, on a stream of the caller's choice (hipStream_t as void*; NULL = the context's):
+ * the copies start once the results are complete, and the next pmx_align_readset on this aligner waits for them before it
+ * overwrites its buffers.  The caller synchronises `stream` before reading the (pinned) host buffers. */
+int pmx_align_fetch_async(pmx_ctx *ctx, pmx_aligner *al, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,
+                          int64_t arena_cap, void *stream);
 /* copy the fixed-size records into a caller-owned DEVICE buffer (for RCCL gathers) */
 int pmx_align_copy_records_device(pmx_ctx *ctx, pmx_aligner *al, void *d_records, int64_t n_records);
 /* the same for the CIGAR arena (pmx_align_cigar_words() words): records + arena are what rank 0 needs to write the BAM */
@@ -348,6 +353,40 @@ int pmx_align_get_stats(pmx_ctx *ctx, pmx_aligner *al, pmx_align_stats *out);
 /* device pointers of the last result (for RCCL gathers without a host bounce) */
 const void *pmx_align_device_records(const pmx_aligner *al);
 const void *pmx_align_device_cigars(const pmx_aligner *al);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: one rank per GPU (a process, or a host thread with its own context), RCCL over xGMI.
+ * The reference is a single process; the two exchange steps follow SURVEY.md section 8e.  Reads are sharded by the
+ * caller (contiguous, pair-aligned shards), the seed index and the placed genome are replicated per GPU.
+ *   rank 0: pmx_dist_unique_id(id); ship the 128 bytes to every rank (a file, a pipe, MPI, a torch store ...)
+ *   every rank: pmx_dist_init(ctx, id, rank, world, &d)            -- collective (ncclCommInitRank)
+ *   per sample: seed the shard, pmx_dist_merge_histograms(d, pl), pmx_place_score (replicated: same result on every
+ *               rank), align the shard, pmx_dist_gather_alignments(d, al, 0, ...), rank 0 writes the BAM.
+ * Every call is collective over the ranks of `d` and stream-ordered on the context's stream.  librccl.so.1 is loaded on
+ * first use.  PMX_DIST_HOST_DIR=<shared directory>: a file-based transport through host memory for functional tests on a
+ * box with fewer GPUs than ranks (RCCL refuses two ranks on one device).
+ * ------------------------------------------------------------------------------------------ */
+#define PMX_DIST_ID_BYTES 128
+typedef struct pmx_dist pmx_dist;
+int pmx_dist_unique_id(char id[PMX_DIST_ID_BYTES]);
+int pmx_dist_init(pmx_ctx *ctx, const char id[PMX_DIST_ID_BYTES], int rank, int world, pmx_dist **out);
+void pmx_dist_free(pmx_dist *d);
+int pmx_dist_rank(const pmx_dist *d);
+int pmx_dist_world(const pmx_dist *d);
+int pmx_dist_barrier(pmx_dist *d);
+/* all-gather of the ranks' (hash, count) histograms + integer merge: afterwards every rank's placer holds the histogram of
+ * the whole sample and pmx_place_score gives the same result on every rank (no floating-point reduction anywhere) */
+int pmx_dist_merge_histograms(pmx_dist *d, pmx_place *pl);
+/* the records and the CIGAR arena of the aligner's last call, from every rank to `root` (exact sizes, point to point); on
+ * the root the records stand in rank order with cigar_off rebased onto the arenas laid back to back.  n_records / n_words:
+ * totals on the root, 0 elsewhere. */
+int pmx_dist_gather_alignments(pmx_dist *d, pmx_aligner *al, int root, int64_t *n_records, int64_t *n_words);
+const void *pmx_dist_gathered_records(const pmx_dist *d);   /* device pointers of the last gather (root) */
+const void *pmx_dist_gathered_cigars(const pmx_dist *d);
+int pmx_dist_rank_counts(const pmx_dist *d, int64_t *records_per_rank, int64_t *words_per_rank);   /* world entries each */
+int pmx_dist_fetch_gathered(pmx_dist *d, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena, int64_t arena_cap);
+int pmx_dist_fetch_gathered_async(pmx_dist *d, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,
+                                  int64_t arena_cap, void *stream);   /* see pmx_align_fetch_async */
 
 /* kernel timing: average duration (ms) of the dominant kernel of the last call, measured with HIP
    events on the context stream; name selects "seed", "score", "align" */

@@ -171,9 +171,23 @@ SIGNATURES = {
     "pmx_align_num_records": (_i64, [_vp]),
     "pmx_align_cigar_words": (_i64, [_vp, _vp]),
     "pmx_align_fetch": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64]),
+    "pmx_align_fetch_async": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "pmx_align_device_records": (_vp, [_vp]),
     "pmx_align_device_cigars": (_vp, [_vp]),
     "pmx_last_kernel_ms": (C.c_double, [_vp, _cp]),
+    "pmx_dist_unique_id": (_i32, [_vp]),
+    "pmx_dist_init": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "pmx_dist_free": (None, [_vp]),
+    "pmx_dist_rank": (_i32, [_vp]),
+    "pmx_dist_world": (_i32, [_vp]),
+    "pmx_dist_barrier": (_i32, [_vp]),
+    "pmx_dist_merge_histograms": (_i32, [_vp, _vp]),
+    "pmx_dist_gather_alignments": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "pmx_dist_gathered_records": (_vp, [_vp]),
+    "pmx_dist_gathered_cigars": (_vp, [_vp]),
+    "pmx_dist_rank_counts": (_i32, [_vp, _vp, _vp]),
+    "pmx_dist_fetch_gathered": (_i32, [_vp, _vp, _i64, _vp, _i64]),
+    "pmx_dist_fetch_gathered_async": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
 }
 
 MISSING = []

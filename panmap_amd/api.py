@@ -740,6 +740,11 @@ class Aligner:
         check(lib.pmx_align_fetch(self.ctx._h, self._h, recs.ctypes.data, len(recs), cig.ctypes.data, len(cig)), "pmx_align_fetch")
         return recs[:n], cig[:words]
 
+    def fetch_async(self, host_records_ptr: int, n_records: int, host_cigars_ptr: int, cigar_cap: int, stream: int = 0):
+        """enqueue the download of the last results into (pinned) host buffers on `stream` (a raw hipStream_t; 0 = the
+        context's) without waiting; the next align_readset waits for it before it overwrites the device buffers"""
+        check(lib.pmx_align_fetch_async(self.ctx._h, self._h, host_records_ptr, n_records, host_cigars_ptr, cigar_cap, stream or None), "pmx_align_fetch_async")
+
     def copy_records_device(self, d_ptr: int, n_records: int):
         check(lib.pmx_align_copy_records_device(self.ctx._h, self._h, d_ptr, n_records), "pmx_align_copy_records_device")
 
@@ -770,6 +775,66 @@ class Aligner:
     def close(self):
         if self._h:
             lib.pmx_aligner_free(self.ctx._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dist:
+    """One rank of the multi-GPU exchange (pmx_dist_*: RCCL over xGMI behind the C ABI).
+    `uid` = the 128 bytes rank 0 made with Dist.unique_id() and shipped to every rank."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Dist.ID_BYTES)
+        check(lib.pmx_dist_unique_id(buf), "pmx_dist_unique_id")
+        return buf.raw
+
+    def __init__(self, ctx: Context, uid: bytes, rank: int, world: int):
+        assert len(uid) == Dist.ID_BYTES
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self._h = C.c_void_p()
+        self._uid = C.create_string_buffer(bytes(uid), Dist.ID_BYTES)
+        check(lib.pmx_dist_init(ctx._h, self._uid, self.rank, self.world, C.byref(self._h)), "pmx_dist_init")
+
+    def barrier(self):
+        check(lib.pmx_dist_barrier(self._h), "pmx_dist_barrier")
+
+    def merge_histograms(self, placer: Placer):
+        """all-gather + merge: every rank's placer then holds the histogram of the whole sample"""
+        check(lib.pmx_dist_merge_histograms(self._h, placer._h), "pmx_dist_merge_histograms")
+
+    def gather_alignments(self, aligner: "Aligner", root: int = 0):
+        """records + CIGAR arena of the aligner's last call to `root` -> (n_records, n_words) there, (0, 0) elsewhere"""
+        nr, nw = C.c_int64(0), C.c_int64(0)
+        check(lib.pmx_dist_gather_alignments(self._h, aligner._h, int(root), C.byref(nr), C.byref(nw)), "pmx_dist_gather_alignments")
+        return int(nr.value), int(nw.value)
+
+    def gathered_device_pointers(self):
+        return int(lib.pmx_dist_gathered_records(self._h) or 0), int(lib.pmx_dist_gathered_cigars(self._h) or 0)
+
+    def rank_counts(self):
+        r, w = np.zeros(self.world, np.int64), np.zeros(self.world, np.int64)
+        check(lib.pmx_dist_rank_counts(self._h, r.ctypes.data, w.ctypes.data), "pmx_dist_rank_counts")
+        return r, w
+
+    def fetch_gathered(self, n_records: int, n_words: int):
+        recs = np.zeros(max(n_records, 1), REC_DTYPE)
+        cig = np.zeros(max(n_words, 1), np.uint32)
+        check(lib.pmx_dist_fetch_gathered(self._h, recs.ctypes.data, len(recs), cig.ctypes.data, len(cig)), "pmx_dist_fetch_gathered")
+        return recs[:n_records], cig[:n_words]
+
+    def fetch_gathered_async(self, host_records_ptr: int, n_records: int, host_cigars_ptr: int, cigar_cap: int, stream: int = 0):
+        check(lib.pmx_dist_fetch_gathered_async(self._h, host_records_ptr, n_records, host_cigars_ptr, cigar_cap, stream or None), "pmx_dist_fetch_gathered_async")
+
+    def close(self):
+        if self._h:
+            lib.pmx_dist_free(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -65,6 +65,8 @@ struct pmx_aligner {
     double cigar_words_per_kbase = 0.0;   // CIGAR words per 1,000 read bases the last calls needed (sizes the next arena)
     unsigned long long last_cigar_used = 0;   // read back at the end of pmx_align_readset
     double last_occupancy = 0;
+    hipEvent_t ev_results = nullptr, ev_fetched = nullptr;   // pmx_align_fetch_async: results ready / download finished
+    bool fetch_pending = false;
 };
 
 // [0] += edit counts, [1] += records flagged invalid (pmx_align_score_reads)
@@ -224,6 +226,8 @@ int pmx_aligner_create(pmx_ctx* ctx, const char* reference, int64_t ref_len, int
 
 void pmx_aligner_free(pmx_ctx* ctx, pmx_aligner* al) {
     if (ctx) (void)hipSetDevice(ctx->device);
+    if (al && al->ev_results) (void)hipEventDestroy(al->ev_results);
+    if (al && al->ev_fetched) (void)hipEventDestroy(al->ev_fetched);
     delete al;
 }
 
@@ -231,6 +235,10 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     const int64_t n_items = paired ? rs->n / 2 : rs->n;   // an odd trailing read is ignored (src/mm_align.c:372)
+    if (al->fetch_pending) {   // a download of the previous results on another stream (pmx_align_fetch_async) reads the buffers this call overwrites
+        PMX_HIP(hipStreamWaitEvent(ctx->stream, al->ev_fetched, 0));
+        al->fetch_pending = false;
+    }
     al->n_records = rs->n;
     al->records.ensure((size_t)std::max<int64_t>(rs->n, 1));
     PMX_HIP(hipMemsetAsync(al->records.p, 0, sizeof(AlnRecord) * (size_t)std::max<int64_t>(rs->n, 1), ctx->stream));
@@ -708,6 +716,36 @@ int pmx_align_fetch(pmx_ctx* ctx, pmx_aligner* al, pmx_aln_record* records, int6
         PMX_HIP(hipMemcpyAsync(records, al->records.p, sizeof(AlnRecord) * (size_t)al->n_records, hipMemcpyDeviceToHost, ctx->stream));
     if (used > 0) PMX_HIP(hipMemcpyAsync(cigar_arena, al->cigars.p, sizeof(uint32_t) * (size_t)used, hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return PMX_OK;
+    PMX_CATCH
+}
+
+// The download of pmx_align_fetch on a stream of the caller's choice, without waiting for it: the copies start when the
+// results are complete (event on the context's stream) and the next pmx_align_readset on this aligner waits for them
+// before it overwrites the buffers.  The caller synchronises `stream` before it reads the host buffers (pinned memory, or
+// the copies are staged).  stream NULL = the context's stream.
+int pmx_align_fetch_async(pmx_ctx* ctx, pmx_aligner* al, pmx_aln_record* records, int64_t n_records, uint32_t* cigar_arena, int64_t arena_cap, void* stream) {
+    if (!ctx || !al || !records || n_records < al->n_records) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    const int64_t used = pmx_align_cigar_words(ctx, al);
+    if (used < 0) return (int)used;
+    if (used > arena_cap || (used > 0 && !cigar_arena)) return fail(PMX_ERR_CAPACITY, "CIGAR arena buffer too small");
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!al->ev_results) {
+        PMX_HIP(hipEventCreateWithFlags(&al->ev_results, hipEventDisableTiming));
+        PMX_HIP(hipEventCreateWithFlags(&al->ev_fetched, hipEventDisableTiming));
+    }
+    if (st != ctx->stream) {
+        PMX_HIP(hipEventRecord(al->ev_results, ctx->stream));
+        PMX_HIP(hipStreamWaitEvent(st, al->ev_results, 0));
+    }
+    if (al->n_records > 0) PMX_HIP(hipMemcpyAsync(records, al->records.p, sizeof(AlnRecord) * (size_t)al->n_records, hipMemcpyDeviceToHost, st));
+    if (used > 0) PMX_HIP(hipMemcpyAsync(cigar_arena, al->cigars.p, sizeof(uint32_t) * (size_t)used, hipMemcpyDeviceToHost, st));
+    if (st != ctx->stream) {
+        PMX_HIP(hipEventRecord(al->ev_fetched, st));
+        al->fetch_pending = true;
+    }
     return PMX_OK;
     PMX_CATCH
 }

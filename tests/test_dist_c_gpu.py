@@ -1,0 +1,55 @@
+"""The multi-GPU exchange behind the C ABI (pmx_dist_*, panmap_amd/csrc/api_dist.hip) on a one-GPU box: two ranks as two
+processes on the one device over the library's host-directory test transport (RCCL refuses two ranks on one device), and a
+one-rank group on RCCL itself (librccl loaded by the library, communicator, all-gather, the gather's local part)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(world, env_extra):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, PMX_RANK=str(r), PMX_WORLD=str(world), **env_extra)
+        procs.append(subprocess.Popen([sys.executable, os.path.join("tests", "dist_c_worker.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, (so[-1000:], se[-3000:])
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    return sorted(outs, key=lambda d: d["rank"])
+
+
+def test_two_ranks_through_the_c_abi_equal_a_single_rank(tmp_path):
+    """shards seeded on two ranks, histograms merged by pmx_dist_merge_histograms, replicated scoring, records + CIGAR arenas
+    gathered by pmx_dist_gather_alignments with cigar_off rebased: everything equals a single-rank run bit for bit"""
+    d0, d1 = _run_ranks(2, {"PMX_DIST_HOST_DIR": str(tmp_path)})
+    assert d0["placed"] == d1["placed"] == "node_7618"
+    assert d0["n_records"] == d0["n_expected"] == 40000 and d0["per_rank"] == [20000, 20000]
+    assert d0["hist_equal"] and d0["scores_equal"] and d0["fields_equal"] and d0["cigars_equal"] and d0["async_same"] and d0["flagged"] == 0
+    assert d0["words_per_rank"][1] > 0 and d0["multi_op_cigars"] > 1000
+    assert d1["n_records"] == 0 and d1["n_words"] == 0        # only the root holds the gathered set
+    assert not [f for f in os.listdir(tmp_path) if not f.endswith(".tmp")]   # the transport cleans up after itself
+
+
+@pytest.mark.parametrize("with_torch", [True, False])
+def test_one_rank_group_on_rccl(with_torch):
+    """the same calls on the real transport: the library loads librccl itself, makes the communicator and runs its
+    all-gathers in a group of one (a box of the pool has one GPU; the N > 1 run is the driver's) -- inside a torch process
+    (bench.py: the RCCL copy torch ships) and without torch (the panmap command line: the system's)"""
+    env = {k: v for k, v in os.environ.items() if k != "PMX_DIST_HOST_DIR"}
+    env.update(PMX_RANK="0", PMX_WORLD="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not with_torch:
+        env["PMX_WORKER_NO_TORCH"] = "1"
+    p = subprocess.run([sys.executable, os.path.join("tests", "dist_c_worker.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert d["placed"] == "node_7618" and d["n_records"] == d["n_expected"] == 40000
+    assert d["hist_equal"] and d["fields_equal"] and d["cigars_equal"] and d["async_same"] in (True, None) and d["flagged"] == 0
