@@ -374,6 +374,8 @@ void pmx_dist_free(pmx_dist *d);
 int pmx_dist_rank(const pmx_dist *d);
 int pmx_dist_world(const pmx_dist *d);
 int pmx_dist_barrier(pmx_dist *d);
+/* element-wise sum of every rank's n values, on every rank (--refine over shards: candidate scores add up) */
+int pmx_dist_sum_i64(pmx_dist *d, int64_t *vals, int64_t n);
 /* all-gather of the ranks' (hash, count) histograms + integer merge: afterwards every rank's placer holds the histogram of
  * the whole sample and pmx_place_score gives the same result on every rank (no floating-point reduction anywhere) */
 int pmx_dist_merge_histograms(pmx_dist *d, pmx_place *pl);

@@ -181,6 +181,7 @@ SIGNATURES = {
     "pmx_dist_rank": (_i32, [_vp]),
     "pmx_dist_world": (_i32, [_vp]),
     "pmx_dist_barrier": (_i32, [_vp]),
+    "pmx_dist_sum_i64": (_i32, [_vp, _vp, _i64]),
     "pmx_dist_merge_histograms": (_i32, [_vp, _vp]),
     "pmx_dist_gather_alignments": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "pmx_dist_gathered_records": (_vp, [_vp]),

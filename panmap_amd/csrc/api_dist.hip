@@ -280,6 +280,22 @@ int pmx_dist_barrier(pmx_dist* d) {
     PMX_CATCH
 }
 
+// element-wise sum of every rank's n int64 values, on every rank (--refine: a candidate's score is the sum over the shards)
+int pmx_dist_sum_i64(pmx_dist* d, int64_t* vals, int64_t n) {
+    if (!d || n < 0 || (n > 0 && !vals)) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(d->ctx->device));
+    if (n == 0 || d->tp->world == 1) return PMX_OK;
+    const std::vector<int64_t> all = d->exchange_counts(vals, (int)n);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t sum = 0;
+        for (int r = 0; r < d->tp->world; ++r) sum += all[(size_t)r * (size_t)n + (size_t)i];
+        vals[i] = sum;
+    }
+    return PMX_OK;
+    PMX_CATCH
+}
+
 // Exchange step 1: afterwards every rank's placer holds the histogram of the whole sample.
 int pmx_dist_merge_histograms(pmx_dist* d, pmx_place* pl) {
     if (!d || !pl) return PMX_ERR_ARG;

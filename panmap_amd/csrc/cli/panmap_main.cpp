@@ -10,6 +10,7 @@
 // reference derives it.  Exit code 130 on SIGINT.
 #include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <climits>
@@ -37,6 +38,7 @@ struct Config {
     double seed_mask_fraction = 0.0;
     bool dedup = false, force_leaf = false;
     int trim_start = 0, trim_end = 0, min_seed_quality = 0, min_read_support = -1;
+    int gpus = 1;          // --gpus N: one process per GPU, reads sharded, RCCL exchange (pmx_dist_*)
     bool refine = false;   // src/main.cpp:186-190, 2002-2011
     double refine_top_pct = 0.01;
     int refine_max_top_n = 150, refine_neighbor_radius = 2, refine_max_neighbor_n = 150;
@@ -61,6 +63,7 @@ void usage() {
           "  -t, --threads N            accepted (the GPU owns the parallelism)\n"
           "      --stop STAGE           index|place|align (later stages are not part of this build)\n"
           "      --batch FILE           one sample per line: reads1 [reads2] [prefix]; the index stays resident\n"
+          "      --gpus N               N processes, one per GPU: reads sharded, seed index replicated, RCCL exchange\n"
           "      --refine               re-rank the top candidates by aligning the reads against them\n"
           "      --refine-top-pct F / --refine-max-top-n N / --refine-neighbor-radius N / --refine-max-neighbor-n N\n"
           "  -i, --index PATH           load a pre-built index       --index-out PATH   write the built index here\n"
@@ -109,6 +112,7 @@ Config parse(int argc, char** argv) {
         else if (a == "-q" || a == "--quiet") c.quiet = true;
         else if (a == "-v" || a == "--verbose" || a == "--no-color" || a == "--no-progress") {}
         else if (a == "--batch") c.batch = v();
+        else if (a == "--gpus") c.gpus = atoi(v().c_str());
         else if (a == "--refine") c.refine = true;
         else if (a == "--refine-top-pct") c.refine_top_pct = atof(v().c_str());
         else if (a == "--refine-max-top-n") c.refine_max_top_n = atoi(v().c_str());
@@ -250,7 +254,12 @@ struct SampleGuard {
 
 // One sample through place (+ --refine) (+ align) against the resident index: c.reads1 / c.reads2 / c.output name it.
 // Returns the placed node; throws Fatal.
-std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* idx, pmx_ctx* ctx, pmx_place* pl, int dev) {
+// With `dist` (--gpus N) this process is one rank: it seeds and aligns ITS contiguous, pair-aligned shard of the reads; the
+// histograms are merged over the ranks before the (replicated) scoring, candidate scores of --refine are summed, and the
+// records + CIGAR arenas are gathered to rank 0, which writes every output file.
+std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* idx, pmx_ctx* ctx, pmx_place* pl, int dev, pmx_dist* dist = nullptr) {
+    const int rank = dist ? pmx_dist_rank(dist) : 0, world = dist ? pmx_dist_world(dist) : 1;
+    const bool writer = rank == 0;
     // ------------------------------------------------------------------------------------------------ reads
     SampleGuard g{ctx};
     pmx_fastx *&f1 = g.f1, *&f2 = g.f2;
@@ -280,19 +289,24 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
         }
     }
     off[(size_t)n_reads] = (int64_t)concat.size();
+    // this rank's shard: reads [lo, hi), mates together
+    const int64_t unit = paired ? 2 : 1, n_units = n_reads / unit;
+    const int64_t lo = n_units * rank / world * unit, hi = rank == world - 1 ? n_reads : n_units * (rank + 1) / world * unit;
+    if (c.dedup && world > 1) die("--dedup collapses duplicates over the whole sample: not available with --gpus yet (it would count a duplicate on two ranks twice)");
 
     // ------------------------------------------------------------------------------------------------ place
     pmx_readset*& rs = g.rs;
-    check(pmx_readset_upload(ctx, concat.data(), off.data(), n_reads, &rs), "uploading the reads");
+    check(pmx_readset_upload(ctx, concat.data(), off.data() + lo, hi - lo, &rs), "uploading the reads");
     check(pmx_readset_pack(ctx, rs), "packing the reads");
     pmx_place_params pp;
     memset(&pp, 0, sizeof(pp));
     pp.seed_mask_fraction = c.seed_mask_fraction; pp.min_read_support = c.min_read_support; pp.trim_start = c.trim_start; pp.trim_end = c.trim_end;
     pp.dedup_reads = c.dedup; pp.force_leaf = c.force_leaf; pp.min_seed_quality = c.min_seed_quality;
-    if (c.min_seed_quality > 0) check(pmx_readset_set_qualities(ctx, rs, quals.data()), "attaching the qualities");
+    if (c.min_seed_quality > 0) check(pmx_readset_set_qualities(ctx, rs, quals.data() + off[(size_t)lo]), "attaching the qualities");
     pmx_place_result res;
     check(pmx_place_reset(ctx, pl), "place reset");
     check(pmx_place_add_reads(ctx, pl, rs, &pp), "seeding the reads");
+    if (dist) check(pmx_dist_merge_histograms(dist, pl), "merging the ranks' seed histograms");
     check(pmx_place_score(ctx, pl, &pp, n_reads, &res), "scoring the tree");
     static const char* metric_names[5] = {"log_raw", "log_cosine", "containment", "weighted_containment", "log_containment"};
     // --refine (refineTopCandidates, src/placement.cpp:516-698, called at :1910-1914): every candidate's genome is indexed on the
@@ -324,11 +338,16 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
             std::string fail_msg;
             std::mutex fail_mu;
             auto score_range = [&](pmx_ctx* wctx, pmx_aligner*& al, int64_t i) {
-                std::string genome;
-                const int64_t len = pmx_panman_node_genome(pm, (int64_t)cands[(size_t)i], nullptr, 0);
+                // one reconstruction per candidate: the worker's buffer keeps the size of the previous genome (genomes of one
+                // tree differ by a few bases) and grows only when the returned length says so
+                thread_local std::string genome;
+                if (genome.size() < 1024) genome.resize(1024);
+                int64_t len = pmx_panman_node_genome(pm, (int64_t)cands[(size_t)i], &genome[0], (int64_t)genome.size());
+                if (len > (int64_t)genome.size()) {
+                    genome.resize((size_t)len + (size_t)len / 64);
+                    len = pmx_panman_node_genome(pm, (int64_t)cands[(size_t)i], &genome[0], (int64_t)genome.size());
+                }
                 if (len <= 0) { cand_score[(size_t)i] = 0; return PMX_OK; }   // (scoreNodeByAlignment returns 0 for an empty genome, src/placement.cpp:496-499)
-                genome.resize((size_t)len);
-                pmx_panman_node_genome(pm, (int64_t)cands[(size_t)i], &genome[0], len);
                 int rc2 = al ? pmx_aligner_set_reference(wctx, al, genome.data(), len, mean_len) : pmx_aligner_create(wctx, genome.data(), len, mean_len, &al);
                 if (rc2 != PMX_OK) return rc2;
                 return pmx_align_score_reads(wctx, al, rs, paired ? 1 : 0, 0, &cand_score[(size_t)i]);
@@ -362,6 +381,7 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
                 if (failed.load()) die("refining the placement: " + fail_msg);
             }
             if (al0) pmx_aligner_free(ctx, al0);
+            if (dist) check(pmx_dist_sum_i64(dist, cand_score.data(), (int64_t)cand_score.size()), "summing the candidate scores over the ranks");
             struct Lookup { const std::vector<uint32_t>* nodes; const std::vector<int64_t>* scores; } lk{&cands, &cand_score};
             auto lookup = [](void* user, uint32_t node, int64_t* score) -> int {
                 const Lookup& l = *(const Lookup*)user;
@@ -376,7 +396,7 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
             else say(c, "place", "refined against " + std::to_string(refined.n_candidates) + " candidates");
         }
     }
-    {
+    if (writer) {
         const std::string path = c.output + ".placement.tsv";
         FILE* f = fopen(path.c_str(), "w");
         if (!f) die("cannot write " + path);
@@ -408,7 +428,7 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
     std::string genome((size_t)pmx_panman_node_genome(pm, node, nullptr, 0), '\0');
     pmx_panman_node_genome(pm, node, &genome[0], (int64_t)genome.size());
     if (genome.empty()) die("Empty sequence for node '" + node_id + "', cannot align");
-    {
+    if (writer) {
         const std::string fa = c.output + ".ref.fa";
         FILE* f = fopen(fa.c_str(), "w");
         if (!f) die("Cannot write reference file: " + fa);
@@ -422,9 +442,19 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
     check(pmx_aligner_create(ctx, genome.data(), (int64_t)genome.size(), (int)(concat.size() / (size_t)std::max<int64_t>(n_reads, 1)), &al), "indexing the placed genome");
     check(pmx_align_readset(ctx, al, rs, paired ? 1 : 0, paired ? 1 : 0), "aligning");   // mate 2 reverse-complemented on the device
     std::vector<pmx_aln_record> recs((size_t)n_reads);
-    const int64_t words = pmx_align_cigar_words(ctx, al);
-    std::vector<uint32_t> arena((size_t)std::max<int64_t>(words, 1));
-    check(pmx_align_fetch(ctx, al, recs.data(), n_reads, arena.data(), (int64_t)arena.size()), "fetching the alignments");
+    std::vector<uint32_t> arena;
+    if (dist) {
+        int64_t g_records = 0, g_words = 0;
+        check(pmx_dist_gather_alignments(dist, al, 0, &g_records, &g_words), "gathering the ranks' alignments");
+        if (!writer) return node_id;
+        if (g_records != n_reads) die("the gathered alignment records do not cover the sample");
+        arena.resize((size_t)std::max<int64_t>(g_words, 1));
+        check(pmx_dist_fetch_gathered(dist, recs.data(), n_reads, arena.data(), (int64_t)arena.size()), "fetching the gathered alignments");
+    } else {
+        const int64_t words = pmx_align_cigar_words(ctx, al);
+        arena.resize((size_t)std::max<int64_t>(words, 1));
+        check(pmx_align_fetch(ctx, al, recs.data(), n_reads, arena.data(), (int64_t)arena.size()), "fetching the alignments");
+    }
     // what alignAndWriteBam holds after the aligner call: R2 reverse-complemented, its qualities reversed (src/seeding.cpp:231-269)
     std::vector<std::string> seq_s((size_t)n_reads), qual_s((size_t)n_reads), name_s((size_t)n_reads);
     for (int64_t r = 0; r < n_reads; ++r) {
@@ -494,6 +524,7 @@ int real_main(int argc, char** argv) {
     else if (!exists(c.index)) die("index file not found: " + c.index + " (--index expects a pre-built index; use --index-out to build at a custom path)");
     if (c.output.empty()) c.output = derive_prefix(c);
     if (!c.batch.empty() && !c.reads1.empty()) die("--batch takes the read files from the batch file, not from the command line");
+    if (c.gpus < 1) die("--gpus expects a positive number");
 
     // ------------------------------------------------------------------------------------------------ index
     pmx_panman* pm = nullptr;
@@ -509,15 +540,71 @@ int real_main(int argc, char** argv) {
     }
     if (stop == 0 || (c.reads1.empty() && c.batch.empty())) return 0;
 
+    // ------------------------------------------------------------------------------------------------ --gpus N
+    // One process per GPU, forked HERE: the index (and the PanMAN, when it was opened) is in memory and nothing has touched
+    // a GPU yet, so every rank inherits them and opens its own device.  The ranks meet through RCCL (pmx_dist_*); the
+    // communicator's id travels through a file in a private directory.  The parent only waits.
+    int rank = 0, world = 1;
+    std::string meet_dir;
+    if (c.gpus > 1) {
+        if (!c.batch.empty()) die("--gpus shards ONE sample over the GPUs; run --batch per GPU instead");
+        char tmpl[] = "/tmp/panmap_ranks_XXXXXX";
+        if (!mkdtemp(tmpl)) die("cannot create a rendezvous directory under /tmp");
+        meet_dir = tmpl;
+        fflush(stdout); fflush(stderr);
+        std::vector<pid_t> kids;
+        bool child = false;
+        for (int r = 0; r < c.gpus; ++r) {
+            const pid_t pid = fork();
+            if (pid < 0) die("fork failed");
+            if (pid == 0) { child = true; rank = r; world = c.gpus; break; }
+            kids.push_back(pid);
+        }
+        if (!child) {
+            int worst = 0;
+            for (pid_t k : kids) {
+                int st = 0;
+                if (waitpid(k, &st, 0) < 0) { worst = worst ? worst : 1; continue; }
+                const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+                if (code && !worst) worst = code;
+            }
+            unlink((meet_dir + "/uid").c_str());
+            rmdir(meet_dir.c_str());
+            pmx_index_close(idx);
+            if (pm) pmx_panman_close(pm);
+            return worst;
+        }
+        if (rank > 0) c.quiet = true;
+    }
+
     // ------------------------------------------------------------------------------------------------ samples
     pmx_ctx* ctx = nullptr;
     int dev = 0;
     if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
+    if (world > 1 && !getenv("PMX_DIST_SAME_DEVICE")) dev += rank;   // (PMX_DIST_SAME_DEVICE: functional test on a one-GPU box)
     check(pmx_ctx_create(dev, &ctx), "opening the GPU");
+    pmx_dist* dist = nullptr;
+    if (world > 1) {
+        char uid[PMX_DIST_ID_BYTES];
+        const std::string uid_path = meet_dir + "/uid";
+        if (rank == 0) {
+            check(pmx_dist_unique_id(uid), "creating the communicator id");
+            FILE* f = fopen((uid_path + ".tmp").c_str(), "wb");
+            if (!f || fwrite(uid, 1, sizeof(uid), f) != sizeof(uid)) die("cannot write the communicator id");
+            fclose(f);
+            if (rename((uid_path + ".tmp").c_str(), uid_path.c_str()) != 0) die("cannot publish the communicator id");
+        } else {
+            FILE* f = nullptr;
+            for (int tries = 0; tries < 600000 && !(f = fopen(uid_path.c_str(), "rb")); ++tries) usleep(500);
+            if (!f || fread(uid, 1, sizeof(uid), f) != sizeof(uid)) die("rank 0 never published the communicator id");
+            fclose(f);
+        }
+        check(pmx_dist_init(ctx, uid, rank, world, &dist), "joining the ranks (RCCL)");
+    }
     pmx_place* pl = nullptr;
     check(pmx_place_create(ctx, idx, &pl), "uploading the index");
     int rc = 0;
-    if (c.batch.empty()) run_sample(c, stop, pm, idx, ctx, pl, dev);
+    if (c.batch.empty()) run_sample(c, stop, pm, idx, ctx, pl, dev, dist);
     else {
         // runBatchPlacement (src/main.cpp:1464-1666): the samples of the batch file one after the other against the index
         // that stays on the device; one line per sample on stderr, a failed sample does not stop the batch
@@ -546,7 +633,8 @@ int real_main(int argc, char** argv) {
         fprintf(stderr, "Batch complete: %d placed, %d failed\n", ok, failed);
         rc = failed ? 1 : 0;
     }
-    if (stop > 2) fprintf(stderr, "panmap: note: stages after align (genotype, consensus) are not part of this build; stopped after align.\n");
+    if (stop > 2 && rank == 0) fprintf(stderr, "panmap: note: stages after align (genotype, consensus) are not part of this build; stopped after align.\n");
+    if (dist) { (void)pmx_dist_barrier(dist); pmx_dist_free(dist); }
     pmx_place_free(ctx, pl);
     pmx_ctx_destroy(ctx);
     pmx_index_close(idx);

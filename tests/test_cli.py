@@ -129,3 +129,30 @@ def test_batch_mode(pmx, tmp_path):
     (tmp_path / "b3.txt").write_text("nope.fastq\n")
     r = run(["sars_20000_twilight_dipper.panman", "--batch", "b3.txt", "--stop", "place"], tmp_path)
     assert r.returncode == 1 and "Batch line 1: reads file not found: nope.fastq" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpus_two_ranks_equal_one(pmx, tmp_path):
+    """`panmap --gpus 2`: two processes forked before any GPU call, each a rank of the pmx_dist_* exchange with its shard of
+    the reads (here both on the one device of the box, over the library's host-directory test transport) -- the placement TSV,
+    the placed genome and the BAM equal the one-GPU run's byte for byte; --refine sums the shards' candidate scores"""
+    for f in ("sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz"):
+        shutil.copy(os.path.join(GOLDEN, f), tmp_path / f)
+    reads = ["sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz"]
+    r1 = run(reads + ["--stop", "align", "-o", "one"], tmp_path)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    meet = tmp_path / "meet"
+    meet.mkdir()
+    env = dict(os.environ, PMX_DIST_SAME_DEVICE="1", PMX_DIST_HOST_DIR=str(meet))
+    r2 = subprocess.run([CLI] + reads + ["--stop", "align", "-o", "two", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=1200, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "41003 of 51169 pairs mapped" in r2.stderr
+    for ext in (".placement.tsv", ".ref.fa", ".bam", ".bam.bai"):
+        assert open(tmp_path / ("one" + ext), "rb").read() == open(tmp_path / ("two" + ext), "rb").read(), ext
+    r3 = run(reads + ["--stop", "place", "-o", "one_r", "--refine", "--refine-max-top-n", "4", "--refine-max-neighbor-n", "3"], tmp_path)
+    r4 = subprocess.run([CLI] + reads + ["--stop", "place", "-o", "two_r", "--refine", "--refine-max-top-n", "4", "--refine-max-neighbor-n", "3", "--gpus", "2"],
+                        cwd=tmp_path, capture_output=True, text=True, timeout=1200, env=env)
+    assert r3.returncode == 0 and r4.returncode == 0, (r3.stderr[-1000:], r4.stderr[-1000:])
+    assert open(tmp_path / "one_r.placement.tsv", "rb").read() == open(tmp_path / "two_r.placement.tsv", "rb").read()
+    r5 = subprocess.run([CLI] + reads + ["--stop", "place", "--dedup", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=1200, env=env)
+    assert r5.returncode == 1 and "--dedup" in r5.stderr
