@@ -73,6 +73,12 @@ int pmx_index_build(const pmx_panman *pm, int k, int s, int t, int l, int open_s
  * (the remaining nodes carry no changes) -- both exist for the cross-check tests of the producer */
 int pmx_index_build_ex(const pmx_panman *pm, int k, int s, int t, int l, int open_syncmer, int flank_mask,
                        int mode, int64_t max_nodes, pmx_index **out);
+/* mode | PMX_INDEX_ORIENTED: the --meta form of the index.  A k-min-mer that reads right-to-left on the node's genome
+ * (reverse rolled hash < forward rolled hash) is keyed hash ^ PMX_ORIENT_XOR: the per-node count changes then tell the
+ * two orientations of one hash apart -- what the reference's MGSR index keeps as seedInfos[].isReverse
+ * (src/mgsr.cpp:7225-7320 counts (forward, reverse) occurrences per hash).  Needs l >= 2. */
+#define PMX_INDEX_ORIENTED 0x100
+#define PMX_ORIENT_XOR 0x9e3779b97f4a7c15ULL
 /* adopt caller-provided SoA arrays (copied): parent[n], offsets[n+1], hash/pc/cc[offsets[n]] */
 int pmx_index_from_arrays(const pmx_index_info *info, const uint32_t *parent, const uint64_t *offsets,
                           const uint64_t *hash, const int16_t *parent_count, const int16_t *child_count,
@@ -389,6 +395,47 @@ int pmx_dist_rank_counts(const pmx_dist *d, int64_t *records_per_rank, int64_t *
 int pmx_dist_fetch_gathered(pmx_dist *d, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena, int64_t arena_cap);
 int pmx_dist_fetch_gathered_async(pmx_dist *d, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,
                                   int64_t arena_cap, void *stream);   /* see pmx_align_fetch_async */
+
+/* ------------------------------------------------------------------------------------------
+ * --meta: haplotype deconvolution of a mixed sample (BASELINE config 5; src/main.cpp:1192-1313 runDeconvolution,
+ * src/mgsr.cpp).  Reads -> seedmer lists (k-min-mer hash + orientation), merged by list; every node's overlap coefficient
+ * (:5685-5790); the nodes of the best top_oc distinct coefficients are the candidates (:8010-8060); a parsimony score per
+ * (read, candidate) = max(seedmers the node's genome holds in the read's orientation, in the other one) (:7225-7455);
+ * candidates with equal score columns merge; P(read | node) = err^(n - s) (1 - err)^s; SQUAREM EM (:4341-4443), nodes under
+ * prop_threshold dropped, again (<= em_max_rounds, :4445-4490).  csrc/api_meta.hip says how each step runs on the device.
+ * The node side is an ORIENTED index over the same tree as the place stage's index (PMX_INDEX_ORIENTED).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    double error_rate;          /* 0.005 (src/mgsr.hpp:1109) */
+    double em_convergence;      /* 1e-5  --em-convergence-threshold: |log-likelihood change| that ends the EM */
+    double em_delta_threshold;  /* 0     --em-delta-threshold: > 0 = stop on the largest proportion change instead */
+    double prop_threshold;      /* 0.005 propThresholdToRemove (src/mgsr.hpp:1108) */
+    double discard;             /* 0     --discard: reads whose best score < discard * seedmers carry no weight */
+    int32_t em_max_iterations;  /* 1000 */
+    int32_t em_max_rounds;      /* 5 */
+    int64_t reserved[2];
+} pmx_meta_params;
+typedef struct pmx_meta pmx_meta;
+int pmx_meta_create(pmx_ctx *ctx, const pmx_index *idx, const pmx_index *idx_oriented, pmx_meta **out);
+void pmx_meta_free(pmx_ctx *ctx, pmx_meta *m);
+/* reads (concatenated ASCII + n+1 offsets, mates as sequenced): seedmer lists, merge, overlap coefficients of all nodes */
+int pmx_meta_set_reads(pmx_ctx *ctx, pmx_meta *m, const char *concat, const int64_t *offsets, int64_t n_reads);
+/* candidates = the nodes of the top_oc best distinct overlap coefficients (1000: --top-oc), or exactly the given nodes when
+ * n_override > 0; then every (merged read, candidate) parsimony score on the device */
+int pmx_meta_score(pmx_ctx *ctx, pmx_meta *m, int64_t top_oc, const uint32_t *cand_override, int64_t n_override);
+int pmx_meta_em(pmx_ctx *ctx, pmx_meta *m, const pmx_meta_params *mp);
+int64_t pmx_meta_num_reads(const pmx_meta *m);        /* merged reads that have seedmers */
+int64_t pmx_meta_num_candidates(const pmx_meta *m);
+int pmx_meta_candidates(const pmx_meta *m, uint32_t *dfs_index, int64_t cap);          /* ascending */
+int pmx_meta_overlap_coefficients(const pmx_meta *m, double *oc, int64_t cap);         /* per node */
+int pmx_meta_read_info(const pmx_meta *m, int64_t *n_seedmers, int64_t *multiplicity, int64_t cap);
+int pmx_meta_read_seedmers(const pmx_meta *m, int64_t *offsets, uint64_t *hash, uint8_t *rev, int64_t cap_seedmers);
+int pmx_meta_scores(pmx_ctx *ctx, pmx_meta *m, uint16_t *scores, int64_t cap);         /* [reads][candidates] */
+/* the estimated haplotypes, by proportion (descending): representative node, proportion, the candidates merged into it */
+int64_t pmx_meta_num_haplotypes(const pmx_meta *m);
+int pmx_meta_haplotype(const pmx_meta *m, int64_t i, uint32_t *node, double *prop, int64_t *n_members, uint32_t *members,
+                       int64_t cap);
+int pmx_meta_em_info(const pmx_meta *m, int32_t *rounds, int32_t *iterations, double *log_likelihood);
 
 /* kernel timing: average duration (ms) of the dominant kernel of the last call, measured with HIP
    events on the context stream; name selects "seed", "score", "align" */

@@ -1,0 +1,122 @@
+"""ORACLE (test infrastructure only -- never imported by the product path): a direct restatement of the --meta scoring and
+EM of the reference (src/mgsr.cpp), written for clarity, not speed.
+
+  * node_seed_counts: the (forward, reverse) occurrence counts of every seedmer hash in a node's genome, by walking the
+    oriented index root -> node (what kminmerOnRefCount holds when scoreReadsHelper visits the node, src/mgsr.cpp:7246-7275);
+  * read_scores: per read, f = its seedmers the genome holds in the read's orientation, r = in the other one; score
+    max(f, r) (updateReadsForSeed, :7237-7259: a seedmer counts once per orientation whatever its number of occurrences);
+  * overlap_coefficient: distinct read seedmer hashes the genome holds / the genome's distinct hashes (:5685-5745);
+  * square_em: updateProps / normalizeProps / getExp / runSquareEM / removeLowPropNodes (:4341-4490), numpy float64.
+
+parity: UNPINNED against the reference itself -- the MGSR index and the EM need panman v0.1.4, TBB, Eigen and abseil, none of
+which can be built here; the reference holds no golden vector for this mode except the e2e expectation of
+src/test/e2e/run_e2e.sh:182-204 (a 70/30 mixture on rsv_4K recovered within stated ranges), which tests/test_meta_gpu.py
+reproduces.  The demo's reads (examples/data/reads/sars20000_5hap_*) are absent from the checkout (.MISSING_LARGE_BLOBS)."""
+import numpy as np
+
+ORIENT_XOR = 0x9e3779b97f4a7c15
+
+
+def node_seed_counts(arrays, node, read_hashes=None):
+    """{hash: [forward count, reverse count]} of `node` from the oriented index arrays (Index.arrays() of a
+    PMX_INDEX_ORIENTED build); an oriented key is told from a forward one through `read_hashes` when given (a key whose
+    XOR-ed form is a read hash is a reverse occurrence of that hash), else every key is kept as its own entry"""
+    parent, off = arrays["parent"], arrays["offsets"]
+    path, v = [], int(node)
+    while True:
+        path.append(v)
+        if v == 0:
+            break
+        v = int(parent[v])
+    state = {}
+    for v in reversed(path):
+        for h, cc in zip(arrays["hash"][off[v]:off[v + 1]].tolist(), arrays["child_count"][off[v]:off[v + 1]].tolist()):
+            if cc == 0:
+                state.pop(h, None)
+            else:
+                state[h] = cc
+    if read_hashes is None:
+        return state
+    out = {}
+    for key, c in state.items():
+        if key in read_hashes:
+            out.setdefault(key, [0, 0])[0] += c
+        elif (key ^ ORIENT_XOR) in read_hashes:
+            out.setdefault(key ^ ORIENT_XOR, [0, 0])[1] += c
+    return out
+
+
+def read_scores(counts, read_off, seed_hash, seed_rev):
+    """scores of every read at one node given node_seed_counts(..., read_hashes)"""
+    n = len(read_off) - 1
+    out = np.zeros(n, np.int64)
+    for r in range(n):
+        f = b = 0
+        for i in range(read_off[r], read_off[r + 1]):
+            c = counts.get(int(seed_hash[i]))
+            if c is None:
+                continue
+            rev = int(seed_rev[i])
+            f += c[rev] > 0          # the genome holds it the way the read does
+            b += c[1 - rev] > 0
+        out[r] = max(f, b)
+    return out
+
+
+def overlap_coefficient(arrays_unoriented, node, read_hashes):
+    st = node_seed_counts(arrays_unoriented, node)
+    return (sum(1 for h in st if h in read_hashes) / len(st)) if st else 0.0
+
+
+def _normalize(p):
+    p = np.where(p <= 0, 1e-12, p)
+    return p / p.sum()
+
+
+def square_em(scores, n_seedmers, weight, error_rate=0.005, eta=1e-5, delta_threshold=0.0, max_iterations=1000, max_rounds=5, prop_threshold=0.005):
+    """scores [reads][columns] (reads without any score excluded by the caller) -> (kept column indices, proportions)"""
+    scores = np.asarray(scores, np.int64)
+    n = np.asarray(n_seedmers, np.int64)[:, None]
+    probs = np.power(error_rate, (n - scores).astype(np.float64)) * np.power(1.0 - error_rate, scores.astype(np.float64))
+    w = np.asarray(weight, np.float64)
+    cols = np.arange(scores.shape[1])
+    inv_total = 1.0 / w.sum()
+    props = None
+    for _ in range(max(1, max_rounds)):
+        P = probs[:, cols]
+        k = len(cols)
+        props = np.full(k, 1.0 / k)
+
+        def step(p):
+            inv = 1.0 / (P @ p)
+            return np.array([(w * (P[:, i] * p[i] * inv)).sum() * inv_total for i in range(k)])
+
+        def llh_of(p):
+            return float((w * np.log(P @ p)).sum())
+        llh = 0.0
+        for _it in range(max_iterations):
+            p0 = props
+            p1 = _normalize(step(p0))
+            p2 = _normalize(step(p1))
+            r = p1 - p0
+            v = (p2 - p1) - r
+            with np.errstate(divide="ignore", invalid="ignore"):
+                alpha = -np.linalg.norm(r) / np.linalg.norm(v)
+                sq = _normalize(p0 - 2.0 * alpha * r + alpha * alpha * v)
+                l2, lsq = llh_of(p2), llh_of(sq)
+            if lsq > l2 - eta:
+                props, diff, llh = sq, lsq - llh, lsq
+            else:
+                props, diff, llh = p2, l2 - llh, l2
+            if delta_threshold == 0:
+                if abs(diff) < eta:
+                    break
+            elif np.abs(props - p0).max() < delta_threshold:
+                break
+        keep = props >= prop_threshold
+        if keep.all() or _ + 1 >= max(1, max_rounds):
+            break
+        if not keep.any():
+            break
+        cols = cols[keep]
+    return cols, props

@@ -175,6 +175,21 @@ SIGNATURES = {
     "pmx_align_device_records": (_vp, [_vp]),
     "pmx_align_device_cigars": (_vp, [_vp]),
     "pmx_last_kernel_ms": (C.c_double, [_vp, _cp]),
+    "pmx_meta_create": (_i32, [_vp, _vp, _vp, _vp]),
+    "pmx_meta_free": (None, [_vp, _vp]),
+    "pmx_meta_set_reads": (_i32, [_vp, _vp, _vp, _vp, _i64]),
+    "pmx_meta_score": (_i32, [_vp, _vp, _i64, _vp, _i64]),
+    "pmx_meta_em": (_i32, [_vp, _vp, _vp]),
+    "pmx_meta_num_reads": (_i64, [_vp]),
+    "pmx_meta_num_candidates": (_i64, [_vp]),
+    "pmx_meta_candidates": (_i32, [_vp, _vp, _i64]),
+    "pmx_meta_overlap_coefficients": (_i32, [_vp, _vp, _i64]),
+    "pmx_meta_read_info": (_i32, [_vp, _vp, _vp, _i64]),
+    "pmx_meta_read_seedmers": (_i32, [_vp, _vp, _vp, _vp, _i64]),
+    "pmx_meta_scores": (_i32, [_vp, _vp, _vp, _i64]),
+    "pmx_meta_num_haplotypes": (_i64, [_vp]),
+    "pmx_meta_haplotype": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64]),
+    "pmx_meta_em_info": (_i32, [_vp, _vp, _vp, _vp]),
     "pmx_dist_unique_id": (_i32, [_vp]),
     "pmx_dist_init": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "pmx_dist_free": (None, [_vp]),
@@ -190,6 +205,15 @@ SIGNATURES = {
     "pmx_dist_fetch_gathered": (_i32, [_vp, _vp, _i64, _vp, _i64]),
     "pmx_dist_fetch_gathered_async": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
 }
+
+class MetaParams(C.Structure):
+    _fields_ = [("error_rate", C.c_double), ("em_convergence", C.c_double), ("em_delta_threshold", C.c_double), ("prop_threshold", C.c_double),
+                ("discard", C.c_double), ("em_max_iterations", C.c_int32), ("em_max_rounds", C.c_int32), ("reserved", C.c_int64 * 2)]
+
+    def __init__(self, error_rate=0.005, em_convergence=1e-5, em_delta_threshold=0.0, prop_threshold=0.005, discard=0.0, em_max_iterations=1000,
+                 em_max_rounds=5):
+        super().__init__(error_rate, em_convergence, em_delta_threshold, prop_threshold, discard, em_max_iterations, em_max_rounds)
+
 
 MISSING = []
 for _name, (_res, _args) in SIGNATURES.items():

@@ -116,7 +116,10 @@ int pmx_index_build(const pmx_panman* pm, int k, int s, int t, int l, int open_s
 
 int pmx_index_build_ex(const pmx_panman* pm, int k, int s, int t, int l, int open_syncmer, int flank_mask, int mode, int64_t max_nodes,
                        pmx_index** out) {
+    const bool oriented = mode >= 0 && (mode & PMX_INDEX_ORIENTED) != 0;
+    if (mode >= 0) mode &= ~PMX_INDEX_ORIENTED;
     if (!pm || !out || mode < 0 || mode > 2) return PMX_ERR_ARG;
+    if (oriented && l < 2) { pmx::set_error("an oriented (--meta) index needs l >= 2"); return PMX_ERR_UNSUPPORTED; }
     // same validation as the CLI (src/main.cpp:2221-2235)
     if (k <= 0 || s <= 0 || s > k || t < 0 || t > k - s || l < 0 || k > 64) {
         pmx::set_error("invalid seeding parameters");
@@ -125,7 +128,7 @@ int pmx_index_build_ex(const pmx_panman* pm, int k, int s, int t, int l, int ope
     try {
         pmx_index* ix = new pmx_index();
         pmx::SyncmerParams p;
-        p.k = k; p.s = s; p.t = t; p.l = l; p.open = open_syncmer != 0;
+        p.k = k; p.s = s; p.t = t; p.l = l; p.open = open_syncmer != 0; p.oriented = oriented;
         pmx::build_lite_index(pm->pm, p, flank_mask, ix->ix, mode, max_nodes < 0 ? (size_t)-1 : (size_t)max_nodes);
         *out = ix;
         return PMX_OK;

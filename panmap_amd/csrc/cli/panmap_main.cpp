@@ -38,6 +38,10 @@ struct Config {
     double seed_mask_fraction = 0.0;
     bool dedup = false, force_leaf = false;
     int trim_start = 0, trim_end = 0, min_seed_quality = 0, min_read_support = -1;
+    bool meta = false;     // --meta: haplotype deconvolution (src/main.cpp:1192-1313)
+    int64_t top_oc = 1000;
+    double em_convergence = 0.00001, em_delta = 0.0, discard = 0.0;
+    int em_max_iterations = 1000, em_max_rounds = 5;
     int gpus = 1;          // --gpus N: one process per GPU, reads sharded, RCCL exchange (pmx_dist_*)
     bool refine = false;   // src/main.cpp:186-190, 2002-2011
     double refine_top_pct = 0.01;
@@ -63,6 +67,8 @@ void usage() {
           "  -t, --threads N            accepted (the GPU owns the parallelism)\n"
           "      --stop STAGE           index|place|align (later stages are not part of this build)\n"
           "      --batch FILE           one sample per line: reads1 [reads2] [prefix]; the index stays resident\n"
+          "      --meta                 estimate haplotype abundances of a mixed sample -> <prefix>.mgsr.abundance.out\n"
+          "      --top-oc N --em-convergence-threshold F --em-delta-threshold F --em-maximum-iterations N --em-maximum-rounds N --discard F\n"
           "      --gpus N               N processes, one per GPU: reads sharded, seed index replicated, RCCL exchange\n"
           "      --refine               re-rank the top candidates by aligning the reads against them\n"
           "      --refine-top-pct F / --refine-max-top-n N / --refine-neighbor-radius N / --refine-max-neighbor-n N\n"
@@ -118,7 +124,14 @@ Config parse(int argc, char** argv) {
         else if (a == "--refine-max-top-n") c.refine_max_top_n = atoi(v().c_str());
         else if (a == "--refine-neighbor-radius") c.refine_neighbor_radius = atoi(v().c_str());
         else if (a == "--refine-max-neighbor-n") c.refine_max_neighbor_n = atoi(v().c_str());
-        else if (a == "--meta" || a == "--impute" || a == "--extent-guard" || a == "--reference-node" ||
+        else if (a == "--meta") c.meta = true;
+        else if (a == "--top-oc") c.top_oc = atoll(v().c_str());
+        else if (a == "--em-convergence-threshold") c.em_convergence = atof(v().c_str());
+        else if (a == "--em-delta-threshold") c.em_delta = atof(v().c_str());
+        else if (a == "--em-maximum-iterations") c.em_max_iterations = atoi(v().c_str());
+        else if (a == "--em-maximum-rounds") c.em_max_rounds = atoi(v().c_str());
+        else if (a == "--discard") c.discard = atof(v().c_str());
+        else if (a == "--filter-and-assign" || a == "--impute" || a == "--extent-guard" || a == "--reference-node" ||
                  a == "--dump-sequence" || a == "--dump-all-scores")
             die("option " + a + " belongs to a part of panmap this build does not implement (index / place / align only)");
         else if (a.size() > 1 && a[0] == '-') die("unknown option " + a + " (see --help)");
@@ -511,6 +524,84 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
     return node_id;
 }
 
+// --meta (runDeconvolution, src/main.cpp:1192-1313): reads of a mixed sample -> `<prefix>.mgsr.abundance.out`, one line per
+// estimated haplotype: node id (+ the nodes merged into it, comma-joined) <TAB> proportion with five decimals, by proportion.
+// The two indexes of the tree (the place stage's and its oriented form, without flank mask) are built in memory.
+int run_meta(const Config& c) {
+    if (c.reads1.empty()) die("--meta needs reads");
+    if (c.discard < 0.0 || c.discard > 1.0) die("--discard must be between 0 and 1");   // src/main.cpp:1358-1361
+    if (c.l < 2) die("--meta needs l >= 2 in this build (the orientation of a lone syncmer is not indexed)");
+    if (c.gpus > 1) die("--meta runs on one GPU in this build");
+    pmx_panman* pm = nullptr;
+    check(pmx_panman_open(c.panman.c_str(), &pm), "opening the PanMAN");
+    pmx_index *idx = nullptr, *oidx = nullptr;
+    {   // the two builds are independent: side by side
+        int rc1 = PMX_OK, rc2 = PMX_OK;
+        std::string e2;
+        std::thread th([&]() { rc2 = pmx_index_build_ex(pm, c.k, c.s, c.t, c.l, c.open_syncmer ? 1 : 0, 0, PMX_INDEX_ORIENTED, -1, &oidx); if (rc2 != PMX_OK) e2 = pmx_last_error(); });
+        rc1 = pmx_index_build_ex(pm, c.k, c.s, c.t, c.l, c.open_syncmer ? 1 : 0, 0, 0, -1, &idx);
+        th.join();
+        check(rc1, "building the index");
+        if (rc2 != PMX_OK) die("building the oriented index: " + e2);
+    }
+    say(c, "index", "seed index + oriented seed index (in memory)");
+    pmx_fastx *f1 = nullptr, *f2 = nullptr;
+    check(pmx_fastx_read(c.reads1.c_str(), &f1), "reading reads1");
+    if (!c.reads2.empty()) check(pmx_fastx_read(c.reads2.c_str(), &f2), "reading reads2");
+    const char *s1, *q1, *nm1;
+    const int64_t *o1, *no1;
+    check(pmx_fastx_views(f1, &s1, &q1, &o1, &nm1, &no1), "reads1 views");
+    std::string concat(s1, (size_t)o1[pmx_fastx_num_reads(f1)]);
+    std::vector<int64_t> off(o1, o1 + pmx_fastx_num_reads(f1) + 1);
+    if (f2) {   // mates as sequenced, one after the other (the score of a read does not depend on its place in the list)
+        const char *s2, *q2, *nm2;
+        const int64_t *o2, *no2;
+        check(pmx_fastx_views(f2, &s2, &q2, &o2, &nm2, &no2), "reads2 views");
+        const int64_t n2 = pmx_fastx_num_reads(f2), base = (int64_t)concat.size();
+        concat.append(s2, (size_t)o2[n2]);
+        for (int64_t i = 1; i <= n2; ++i) off.push_back(base + o2[i]);
+    }
+    int dev = 0;
+    if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
+    pmx_ctx* ctx = nullptr;
+    check(pmx_ctx_create(dev, &ctx), "opening the GPU");
+    pmx_meta* m = nullptr;
+    check(pmx_meta_create(ctx, idx, oidx, &m), "uploading the indexes");
+    check(pmx_meta_set_reads(ctx, m, concat.data(), off.data(), (int64_t)off.size() - 1), "seeding the reads");
+    check(pmx_meta_score(ctx, m, c.top_oc, nullptr, 0), "scoring the reads against the candidate nodes");
+    say(c, "meta", std::to_string(pmx_meta_num_reads(m)) + " distinct reads x " + std::to_string(pmx_meta_num_candidates(m)) + " candidate nodes");
+    pmx_meta_params mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.error_rate = 0.005; mp.em_convergence = c.em_convergence; mp.em_delta_threshold = c.em_delta; mp.prop_threshold = 0.005; mp.discard = c.discard;
+    mp.em_max_iterations = c.em_max_iterations; mp.em_max_rounds = c.em_max_rounds;
+    check(pmx_meta_em(ctx, m, &mp), "estimating the abundances");
+    const std::string path = c.output + ".mgsr.abundance.out";
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) die("cannot write " + path);
+    const int64_t n_h = pmx_meta_num_haplotypes(m);
+    if (n_h == 0) fprintf(stderr, "No reads remain for node scoring and EM after discarding low-score reads... Exiting... \n");   // src/main.cpp:1244-1247
+    for (int64_t i = 0; i < n_h; ++i) {
+        uint32_t node = 0;
+        double prop = 0;
+        int64_t n_mem = 0;
+        check(pmx_meta_haplotype(m, i, &node, &prop, &n_mem, nullptr, 0), "haplotype");
+        std::vector<uint32_t> mem((size_t)std::max<int64_t>(n_mem, 1));
+        check(pmx_meta_haplotype(m, i, nullptr, nullptr, nullptr, mem.data(), (int64_t)mem.size()), "haplotype members");
+        std::string ids = pmx_index_node_id(idx, node);
+        for (int64_t k = 0; k < n_mem; ++k) { ids += ","; ids += pmx_index_node_id(idx, mem[(size_t)k]); }
+        fprintf(f, "%s\t%.5f\n", ids.c_str(), prop);
+    }
+    fclose(f);
+    say(c, "meta", path + " (" + std::to_string(n_h) + " haplotypes)");
+    pmx_meta_free(ctx, m);
+    pmx_ctx_destroy(ctx);
+    pmx_fastx_free(f1);
+    if (f2) pmx_fastx_free(f2);
+    pmx_index_close(idx); pmx_index_close(oidx);
+    pmx_panman_close(pm);
+    return 0;
+}
+
 int real_main(int argc, char** argv) {
     signal(SIGINT, on_sigint);
     Config c = parse(argc, argv);
@@ -525,6 +616,8 @@ int real_main(int argc, char** argv) {
     if (c.output.empty()) c.output = derive_prefix(c);
     if (!c.batch.empty() && !c.reads1.empty()) die("--batch takes the read files from the batch file, not from the command line");
     if (c.gpus < 1) die("--gpus expects a positive number");
+
+    if (c.meta) return run_meta(c);
 
     // ------------------------------------------------------------------------------------------------ index
     pmx_panman* pm = nullptr;

@@ -121,7 +121,7 @@ struct Builder {
                 if (lastcol < c) continue;
                 last_start = s->first;
                 uint64_t seed;
-                if (kminmer_seed(h, p.k, l, &seed)) seeds.push_back(seed);
+                if (kminmer_seed(h, p.k, l, &seed, p.oriented)) seeds.push_back(seed);
             }
         }
     }
@@ -381,7 +381,7 @@ void genome_seed_counts(const std::string& genome, const SyncmerParams& p, int f
     const int l = p.l < 1 ? 1 : p.l;
     for (size_t j = 0; j + l <= h.size(); ++j) {
         uint64_t seed;
-        if (kminmer_seed(&h[j], p.k, l, &seed)) ++cnt[seed];
+        if (kminmer_seed(&h[j], p.k, l, &seed, p.oriented)) ++cnt[seed];
     }
     sorted_counts.assign(cnt.begin(), cnt.end());
     std::sort(sorted_counts.begin(), sorted_counts.end());

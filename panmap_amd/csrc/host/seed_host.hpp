@@ -31,7 +31,11 @@ static inline uint64_t base_hash_comp(int code) { return code < 4 ? kBaseHash[3 
 struct SyncmerParams {
     int k = 19, s = 8, t = 0, l = 3;
     bool open = false;
+    // --meta: a k-min-mer that reads right-to-left on the genome (R < F) is keyed hash ^ kOrientXor, so that the index
+    // counts the two orientations of one hash apart (what the reference's MGSR index keeps as seedInfos[].isReverse)
+    bool oriented = false;
 };
+static const uint64_t kOrientXor = 0x9e3779b97f4a7c15ULL;   // == PMX_ORIENT_XOR (include/panmap_amd.h)
 
 // For every k-mer start i in [0, n-k]: is_sync[i] and, when set, hash[i] = min(F,R).
 // Windows with a non-ACGT base or F==R are never syncmers.
@@ -99,9 +103,10 @@ inline void host_syncmers(const char* seq, int64_t n, const SyncmerParams& p, st
 
 // k-min-mer seed of l consecutive syncmer hashes (src/placement.cpp:1650-1664,
 // src/index_single_mode.cpp:1990-2008).  Returns false when the window yields no seed (F == R).
-inline bool kminmer_seed(const uint64_t* h, int k, int l, uint64_t* out) {
+inline bool kminmer_seed(const uint64_t* h, int k, int l, uint64_t* out, bool oriented = false, bool* is_rev = nullptr) {
     if (l <= 1) {
-        *out = h[0];
+        *out = h[0];       // (the orientation of a lone syncmer is its k-mer's: not kept on this path, l >= 2 for --meta)
+        if (is_rev) *is_rev = false;
         return true;
     }
     uint64_t F = 0, R = 0;
@@ -110,7 +115,9 @@ inline bool kminmer_seed(const uint64_t* h, int k, int l, uint64_t* out) {
         R ^= h_rol(h[q], (unsigned)(k * q));
     }
     if (F == R) return false;
-    *out = F < R ? F : R;
+    const bool rev = R < F;
+    *out = (rev ? R : F) ^ (oriented && rev ? kOrientXor : 0ULL);
+    if (is_rev) *is_rev = rev;
     return true;
 }
 

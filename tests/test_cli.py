@@ -49,7 +49,7 @@ def test_argument_errors(tmp_path):
     assert r.returncode == 1 and "Invalid syncmer offset=12 (must be in 0..k-s = 0..11)" in r.stderr
     r = run(["rsv.panman", "-i", "missing.idx"], tmp_path)
     assert r.returncode == 1 and "index file not found: missing.idx" in r.stderr
-    for opt in (["--meta"], ["--hpc"], ["-a", "bwa"], ["--stop", "nowhere"], ["--no-such-option"]):
+    for opt in (["--filter-and-assign"], ["--hpc"], ["-a", "bwa"], ["--stop", "nowhere"], ["--no-such-option"], ["--meta"], ["--meta", "x.fq", "-l", "1"]):
         assert run(["rsv.panman"] + opt, tmp_path).returncode == 1
 
 
@@ -156,3 +156,27 @@ def test_gpus_two_ranks_equal_one(pmx, tmp_path):
     assert open(tmp_path / "one_r.placement.tsv", "rb").read() == open(tmp_path / "two_r.placement.tsv", "rb").read()
     r5 = subprocess.run([CLI] + reads + ["--stop", "place", "--dedup", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=1200, env=env)
     assert r5.returncode == 1 and "--dedup" in r5.stderr
+
+
+@pytest.mark.gpu
+def test_meta_mixture_through_the_cli(pmx, tmp_path):
+    """`panmap <panman> mix.fastq --meta`: the reference's e2e scenario 12 (src/test/e2e/run_e2e.sh:182-204) through the
+    command line -- the same greps and ranges on `<prefix>.mgsr.abundance.out`"""
+    shutil.copy(os.path.join(GOLDEN, "rsv_4K.panman"), tmp_path / "rsv_4K.panman")
+
+    def rd(p):
+        return "".join(l.strip() for l in open(p) if not l.startswith(">")).upper()
+    a, b = rd(os.path.join(GOLDEN, "MZ515733.1.fa")), rd(os.path.join(GOLDEN, "rsv_4K.panman.random.node_1330.fa"))
+    with open(tmp_path / "mix.fastq", "w") as out:
+        def emit(g, n, pre):
+            L = 150; step = max(1, (len(g) - L) // n); c = i = 0
+            while c < n and i + L <= len(g):
+                out.write("@%s%d\n%s\n+\n%s\n" % (pre, c, g[i:i + L], "I" * L)); c += 1; i += step
+        emit(a, 700, "A"); emit(b, 300, "B")
+    r = run(["rsv_4K.panman", "mix.fastq", "--meta", "-o", "mix"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.split("\t") for l in open(tmp_path / "mix.mgsr.abundance.out").read().splitlines() if l]
+    assert len(lines) == 2
+    got = {k: float(v) for k, v in lines}
+    assert 0.55 < got["MZ515733.1"] < 0.82 and 0.18 < got["node_1330"] < 0.45 and 0.99 < sum(got.values()) < 1.01
+    assert all(len(v.split(".")[1]) == 5 for _, v in lines)              # %.5f
