@@ -13,8 +13,11 @@
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
+#include <thread>
 
 namespace pmx {
 namespace {
@@ -157,90 +160,122 @@ Rec build_record(const std::string& qname_full, const std::string& seq, const st
 }
 
 // ----------------------------------------------------------------------------------------------- BGZF
-class Bgzf {
-public:
-    explicit Bgzf(const std::string& path) : f_(fopen(path.c_str(), "wb")) {
-        if (!f_) throw std::runtime_error("cannot open " + path);
+// A BGZF file is a sequence of independent gzip members of at most 64 KiB of payload (SAM spec 4.1): the blocks are laid
+// out first (which bytes go into which block: a cheap serial pass that also fixes every record's virtual offsets up to
+// the blocks' file positions), compressed by a pool of threads, and written in order.  htslib compresses with a pool of
+// workers as well (bgzf_mt, which samtools drives through the reference's `-@ threads`).
+constexpr size_t kBgzfBlock = 0xff00;   // htslib's BGZF_BLOCK_SIZE
+
+void deflate_block(const std::string& in, std::string& out) {
+    out.resize(in.size() + 1024);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
+    zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(in.data()));
+    zs.avail_in = (uInt)in.size();
+    zs.next_out = reinterpret_cast<Bytef*>(&out[18]);
+    zs.avail_out = (uInt)(out.size() - 18 - 8);
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("deflate"); }
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    const size_t bsize = clen + 18 + 8;
+    const unsigned char hdr[18] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, (unsigned char)((bsize - 1) & 0xff),
+                                   (unsigned char)((bsize - 1) >> 8)};
+    memcpy(&out[0], hdr, 18);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(in.data()), (uInt)in.size());
+    const uint32_t isize = (uint32_t)in.size();
+    memcpy(&out[18 + clen], &crc, 4);
+    memcpy(&out[18 + clen + 4], &isize, 4);
+    out.resize(bsize);
+}
+
+// the payload of the blocks, in file order, and where the next byte would go
+struct BlockLayout {
+    std::vector<std::string> blocks;   // closed blocks
+    std::string open;                  // the block being filled
+    struct Pos { size_t block; uint32_t off; };
+    Pos tell() const { return Pos{blocks.size(), (uint32_t)open.size()}; }
+    void close_block() {
+        if (open.empty()) return;
+        blocks.emplace_back();
+        blocks.back().swap(open);
     }
-    ~Bgzf() { if (f_) fclose(f_); }
-    // virtual offset of the next byte written
-    uint64_t tell() const { return (uint64_t)file_off_ << 16 | (uint64_t)buf_.size(); }
     void write(const char* p, size_t n) {
         while (n > 0) {
-            const size_t room = kBlock - buf_.size(), k = std::min(room, n);
-            buf_.append(p, k);
+            const size_t room = kBgzfBlock - open.size(), k = std::min(room, n);
+            open.append(p, k);
             p += k;
             n -= k;
-            if (buf_.size() == kBlock) flush_block();
+            if (open.size() == kBgzfBlock) close_block();
         }
     }
-    // keep a record inside one block when it fits (as htslib's bgzf_write does for BAM records), so the virtual
-    // offset of a record start never points at a block boundary mid-record; returns the record's virtual offset
-    uint64_t begin_record(size_t rec_size) {
-        if (buf_.size() + rec_size > kBlock && !buf_.empty() && rec_size <= kBlock) flush_block();
+    // a record stays inside one block when it fits (as htslib's bgzf_write does for BAM records), so that the virtual
+    // offset of a record start never points at a block boundary mid-record; returns where the record starts
+    Pos begin_record(size_t rec_size) {
+        if (open.size() + rec_size > kBgzfBlock && !open.empty() && rec_size <= kBgzfBlock) close_block();
         return tell();
     }
-    void close() {
-        if (!buf_.empty()) flush_block();
-        static const unsigned char eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (fwrite(eof, 1, 28, f_) != 28) throw std::runtime_error("BAM write failed");
-        if (fclose(f_) != 0) { f_ = nullptr; throw std::runtime_error("BAM close failed"); }
-        f_ = nullptr;
-    }
-    void flush_block() {
-        if (buf_.empty()) return;
-        unsigned char out[kBlock + 1024];
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
-        zs.next_in = reinterpret_cast<Bytef*>(&buf_[0]);
-        zs.avail_in = (uInt)buf_.size();
-        zs.next_out = out + 18;
-        zs.avail_out = sizeof(out) - 18 - 8;
-        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("deflate"); }
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        const size_t bsize = clen + 18 + 8;
-        const unsigned char hdr[18] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, (unsigned char)((bsize - 1) & 0xff),
-                                       (unsigned char)((bsize - 1) >> 8)};
-        memcpy(out, hdr, 18);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(buf_.data()), (uInt)buf_.size());
-        const uint32_t isize = (uint32_t)buf_.size();
-        memcpy(out + 18 + clen, &crc, 4);
-        memcpy(out + 18 + clen + 4, &isize, 4);
-        if (fwrite(out, 1, bsize, f_) != bsize) throw std::runtime_error("BAM write failed");
-        file_off_ += bsize;
-        buf_.clear();
-    }
-
-private:
-    static constexpr size_t kBlock = 0xff00;   // htslib's BGZF_BLOCK_SIZE
-    FILE* f_;
-    std::string buf_;
-    uint64_t file_off_ = 0;
 };
+
+unsigned worker_count(size_t n_items, size_t per_thread) {
+    unsigned n = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("PMX_BAM_THREADS")) n = (unsigned)std::max(1, atoi(e));
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(n, n_items / std::max<size_t>(per_thread, 1) + 1));
+}
+
+template <class F>
+void parallel_for(size_t n, size_t grain, F&& body) {   // body(begin, end) over [0, n) in pieces of `grain`, dynamic
+    const unsigned n_thr = worker_count(n, grain);
+    if (n_thr <= 1) { body((size_t)0, n); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::string> errs(n_thr);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < n_thr; ++t)
+        pool.emplace_back([&, t]() {
+            try {
+                for (;;) {
+                    const size_t b = next.fetch_add(grain);
+                    if (b >= n) break;
+                    body(b, std::min(n, b + grain));
+                }
+            } catch (const std::exception& e) { errs[t] = e.what(); if (errs[t].empty()) errs[t] = "worker failed"; }
+        });
+    for (auto& th : pool) th.join();
+    for (const std::string& e : errs)
+        if (!e.empty()) throw std::runtime_error(e);
+}
 
 }  // namespace
 
 int write_bam(const std::string& bam_path, const std::string& ref_name, int64_t ref_len, const std::vector<std::string>& seqs,
               const std::vector<std::string>& quals, const std::vector<std::string>& names, const align_pair_result_t* results, int64_t n_results,
               bool paired, bool write_index) {
-    std::vector<Rec> recs;
-    recs.reserve((size_t)(paired ? 2 * n_results : n_results));
-    for (int64_t k = 0; k < n_results; ++k) {
-        const align_pair_result_t& res = results[k];
-        if (!res.mapped) continue;
-        if (paired) {
-            const size_t i1 = (size_t)(2 * k), i2 = i1 + 1;
-            recs.push_back(build_record(names[i1], seqs[i1], quals[i1], res.r1, (int)seqs[i1].size(), true, true, (uint8_t)!res.r2.rev, res.r2.rs,
-                                        res.r1.rs, res.r1.re, res.r2.rs, res.r2.re, res.r1.proper_frag, false));
-            recs.push_back(build_record(names[i2], seqs[i2], quals[i2], res.r2, (int)seqs[i2].size(), true, false, res.r1.rev, res.r1.rs, res.r2.rs,
-                                        res.r2.re, res.r1.rs, res.r1.re, res.r2.proper_frag, false));
-        } else {
-            const size_t i = (size_t)k;
-            recs.push_back(build_record(names[i], seqs[i], quals[i], res.r1, (int)seqs[i].size(), false, false, 0, -1, 0, 0, 0, 0, 0, false));
+    // ---- records of the mapped results, in input order (built by the worker pool: two slots per pair)
+    const size_t per = paired ? 2 : 1;
+    std::vector<Rec> slots((size_t)n_results * per);
+    std::vector<uint8_t> used((size_t)n_results, 0);
+    parallel_for((size_t)n_results, 4096, [&](size_t b, size_t e) {
+        for (size_t k = b; k < e; ++k) {
+            const align_pair_result_t& res = results[k];
+            if (!res.mapped) continue;
+            used[k] = 1;
+            if (paired) {
+                const size_t i1 = 2 * k, i2 = i1 + 1;
+                slots[i1] = build_record(names[i1], seqs[i1], quals[i1], res.r1, (int)seqs[i1].size(), true, true, (uint8_t)!res.r2.rev, res.r2.rs,
+                                         res.r1.rs, res.r1.re, res.r2.rs, res.r2.re, res.r1.proper_frag, false);
+                slots[i2] = build_record(names[i2], seqs[i2], quals[i2], res.r2, (int)seqs[i2].size(), true, false, res.r1.rev, res.r1.rs, res.r2.rs,
+                                         res.r2.re, res.r1.rs, res.r1.re, res.r2.proper_frag, false);
+            } else {
+                slots[k] = build_record(names[k], seqs[k], quals[k], res.r1, (int)seqs[k].size(), false, false, 0, -1, 0, 0, 0, 0, 0, false);
+            }
         }
-    }
+    });
+    std::vector<Rec> recs;
+    recs.reserve(slots.size());
+    for (size_t k = 0; k < (size_t)n_results; ++k)
+        if (used[k])
+            for (size_t q = 0; q < per; ++q) recs.push_back(std::move(slots[k * per + q]));
+    slots.clear();
     // the reference sorts (pos, record) pairs with std::sort on pos only (src/conversion.cpp:499)
     std::vector<std::pair<int32_t, size_t>> order(recs.size());
     for (size_t i = 0; i < recs.size(); ++i) order[i] = {recs[i].sort_pos, i};
@@ -256,20 +291,44 @@ int write_bam(const std::string& bam_path, const std::string& ref_name, int64_t 
     hdr.push_back('\0');
     put32(hdr, (uint32_t)ref_len);
 
-    Bgzf bg(bam_path);
-    bg.write(hdr.data(), hdr.size());
-    bg.flush_block();   // records start in their own block, as sam_hdr_write leaves them
+    // ---- block layout + where every record begins and ends
+    BlockLayout lay;
+    lay.write(hdr.data(), hdr.size());
+    lay.close_block();   // records start in their own block, as sam_hdr_write leaves them
+    std::vector<BlockLayout::Pos> rec_beg(order.size()), rec_end(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        const Rec& r = recs[order[i].second];
+        rec_beg[i] = lay.begin_record(r.bytes.size());
+        lay.write(r.bytes.data(), r.bytes.size());
+        rec_end[i] = lay.tell();
+    }
+    lay.close_block();
+    // ---- compress (worker pool), place, write
+    std::vector<std::string> packed(lay.blocks.size());
+    parallel_for(lay.blocks.size(), 8, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) { deflate_block(lay.blocks[i], packed[i]); std::string().swap(lay.blocks[i]); }
+    });
+    std::vector<uint64_t> file_off(packed.size() + 1, 0);
+    for (size_t i = 0; i < packed.size(); ++i) file_off[i + 1] = file_off[i] + packed[i].size();
+    auto voff = [&](const BlockLayout::Pos& p) { return file_off[p.block] << 16 | (uint64_t)p.off; };
+    {
+        FILE* f = fopen(bam_path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot open " + bam_path);
+        bool ok = true;
+        for (const std::string& b : packed) ok = ok && fwrite(b.data(), 1, b.size(), f) == b.size();
+        static const unsigned char eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        ok = ok && fwrite(eof, 1, 28, f) == 28;
+        if (fclose(f) != 0 || !ok) throw std::runtime_error("BAM write failed");
+    }
 
     // BAI (SAM spec 5.2): bins -> chunks of virtual offsets, 16 kb linear index, htslib's metadata pseudo-bin
     std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
     std::vector<uint64_t> linear;
     uint64_t n_mapped = 0, off_beg = 0, off_end = 0;
     int64_t last_bin = -1;
-    for (const auto& o : order) {
-        const Rec& r = recs[o.second];
-        const uint64_t vbeg = bg.begin_record(r.bytes.size());
-        bg.write(r.bytes.data(), r.bytes.size());
-        const uint64_t vend = bg.tell();
+    for (size_t i = 0; i < order.size(); ++i) {
+        const Rec& r = recs[order[i].second];
+        const uint64_t vbeg = voff(rec_beg[i]), vend = voff(rec_end[i]);
         if (n_mapped == 0) off_beg = vbeg;
         off_end = vend;
         ++n_mapped;
@@ -283,7 +342,6 @@ int write_bam(const std::string& bam_path, const std::string& ref_name, int64_t 
         for (size_t wi = w0; wi <= w1; ++wi)
             if (linear[wi] == UINT64_MAX || vbeg < linear[wi]) linear[wi] = vbeg;
     }
-    bg.close();
     if (!write_index) return 0;
     for (size_t i = linear.size(); i-- > 1;)
         if (linear[i - 1] == UINT64_MAX) linear[i - 1] = linear[i];   // windows without a start inherit the next one (hts_idx_finish)

@@ -4,13 +4,34 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
 #include <stdexcept>
+#include <thread>
 
 namespace pmx {
 namespace {
 
 // whole inflated file (gzread also passes plain files through)
 std::vector<char> slurp(const std::string& path) {
+    {   // a plain file: one read of its size (gzread would pass it through in small buffers)
+        FILE* pf = fopen(path.c_str(), "rb");
+        if (!pf) throw std::runtime_error("cannot open " + path);
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, pf);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(pf, 0, SEEK_END) == 0) {
+            const long sz = ftell(pf);
+            if (sz >= 0 && fseek(pf, 0, SEEK_SET) == 0) {
+                std::vector<char> whole((size_t)sz);
+                const size_t rd = sz > 0 ? fread(whole.data(), 1, (size_t)sz, pf) : 0;
+                fclose(pf);
+                if (rd != (size_t)sz) throw std::runtime_error("read error in " + path);
+                return whole;
+            }
+        }
+        fclose(pf);
+    }
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open " + path);
     gzbuffer(f, 1 << 20);
@@ -51,13 +72,9 @@ void push_name(FastxReads& out, const Line& hdr) {   // header line without its 
 
 }  // namespace
 
-void read_fastx(const std::string& path, FastxReads& out) {
-    out = FastxReads();
-    out.off.push_back(0);
-    out.name_off.push_back(0);
-    const std::vector<char> data = slurp(path);
-    const char* cur = data.data();
-    const char* end = cur + data.size();
+namespace {
+// the general (kseq-compatible) parser over [cur, end): records appended to `out` (which holds its leading offsets)
+void parse_general(const char* cur, const char* end, FastxReads& out) {
     Line ln;
     bool have = next_line(cur, end, ln);
     while (have) {
@@ -92,6 +109,110 @@ void read_fastx(const std::string& path, FastxReads& out) {
         push_name(out, hdr);
         out.off.push_back((int64_t)out.seq.size());
     }
+}
+
+// Strict four-line FASTQ over [cur, end), `cur` at a record start, in two passes so that the pieces of a file can be written
+// straight into the final arrays: measure() counts records / bases / name bytes and returns false as soon as a record is not
+// "@name / bases / + / as many qualities" with non-empty bases (the caller then parses the whole file with the general
+// parser); fill() writes the piece at its place.
+struct PieceSize { size_t n_rec = 0, n_seq = 0, n_name = 0; };
+size_t name_len(const Line& hdr) {
+    size_t k = 1;
+    while (k < hdr.n && hdr.p[k] != ' ' && hdr.p[k] != '\t' && hdr.p[k] != '\v' && hdr.p[k] != '\f' && hdr.p[k] != '\r') ++k;
+    return hdr.n > 1 ? k - 1 : 0;
+}
+bool strict4_measure(const char* cur, const char* end, PieceSize& sz) {
+    Line h, sq, pl, ql;
+    while (cur < end) {
+        if (!next_line(cur, end, h)) break;
+        if (h.n == 0 && cur >= end) break;                     // trailing newline
+        if (h.n == 0 || h.p[0] != '@') return false;
+        if (!next_line(cur, end, sq) || !next_line(cur, end, pl) || !next_line(cur, end, ql)) return false;
+        if (sq.n == 0 || sq.p[0] == '@' || sq.p[0] == '+' || sq.p[0] == '>' || pl.n == 0 || pl.p[0] != '+' || ql.n != sq.n) return false;
+        ++sz.n_rec;
+        sz.n_seq += sq.n;
+        sz.n_name += name_len(h);
+    }
+    return true;
+}
+void strict4_fill(const char* cur, const char* end, FastxReads& out, size_t rec0, size_t seq0, size_t name0) {
+    Line h, sq, pl, ql;
+    size_t r = rec0, sp = seq0, np = name0;
+    while (cur < end) {
+        if (!next_line(cur, end, h)) break;
+        if (h.n == 0 && cur >= end) break;
+        next_line(cur, end, sq); next_line(cur, end, pl); next_line(cur, end, ql);
+        memcpy(&out.seq[sp], sq.p, sq.n);
+        memcpy(&out.qual[sp], ql.p, sq.n);
+        const size_t nl = name_len(h);
+        if (nl) memcpy(&out.names[np], h.p + 1, nl);
+        sp += sq.n; np += nl; ++r;
+        out.off[r] = (int64_t)sp;
+        out.name_off[r] = (int64_t)np;
+    }
+}
+
+// first record start at or after `from` (a line "@..." followed by a line, a "+..." line and a line as long as the second one;
+// what the reference's fqNextRecord accepts, src/placement.cpp:97-119), or `end`
+const char* next_record_start(const char* begin, const char* end, const char* from) {
+    const char* o = from;
+    if (o > begin)
+        while (o < end && o[-1] != '\n') ++o;
+    while (o < end) {
+        if (*o == '@') {
+            const char* c = o;
+            Line h, sq, pl, ql;
+            if (next_line(c, end, h) && next_line(c, end, sq) && next_line(c, end, pl) && pl.n > 0 && pl.p[0] == '+' && next_line(c, end, ql) && ql.n == sq.n && sq.n > 0)
+                return o;
+        }
+        const char* nl = (const char*)memchr(o, '\n', (size_t)(end - o));
+        if (!nl) return end;
+        o = nl + 1;
+    }
+    return end;
+}
+
+}  // namespace
+
+void read_fastx(const std::string& path, FastxReads& out) {
+    out = FastxReads();
+    out.off.push_back(0);
+    out.name_off.push_back(0);
+    const std::vector<char> data = slurp(path);
+    const char* begin = data.data();
+    const char* end = begin + data.size();
+    // Large four-line FASTQ (what sequencers and the benchmark write): the file is cut at record starts and the pieces are
+    // parsed side by side, in file order (the reference does the same for uncompressed input, src/placement.cpp:120-161;
+    // inflating a .gz stays serial there and here).  Anything else -- FASTA, wrapped records, a piece that does not parse as
+    // strict four-line records -- goes through the general parser as before: same result either way.
+    unsigned n_thr = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("PMX_FASTX_THREADS")) n_thr = (unsigned)std::max(1, atoi(e));
+    if (n_thr > 1 && data.size() >= ((size_t)8 << 20) && begin[0] == '@') {
+        std::vector<const char*> cut(n_thr + 1, end);
+        cut[0] = begin;
+        for (unsigned i = 1; i < n_thr; ++i) cut[i] = next_record_start(begin, end, begin + data.size() / n_thr * i);
+        for (unsigned i = 1; i < n_thr; ++i) cut[i] = std::max(cut[i], cut[i - 1]);
+        std::vector<PieceSize> size(n_thr);
+        std::vector<int> ok(n_thr, 1);
+        auto on_pieces = [&](const std::function<void(unsigned)>& body) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back([&, t]() { try { body(t); } catch (...) { ok[t] = 0; } });
+            for (auto& th : pool) th.join();
+        };
+        on_pieces([&](unsigned t) { ok[t] = strict4_measure(cut[t], cut[t + 1], size[t]) ? 1 : 0; });
+        if (std::all_of(ok.begin(), ok.end(), [](int v) { return v == 1; })) {
+            std::vector<size_t> rec0(n_thr + 1, 0), seq0(n_thr + 1, 0), name0(n_thr + 1, 0);
+            for (unsigned t = 0; t < n_thr; ++t) { rec0[t + 1] = rec0[t] + size[t].n_rec; seq0[t + 1] = seq0[t] + size[t].n_seq; name0[t + 1] = name0[t] + size[t].n_name; }
+            out.seq.resize(seq0[n_thr]); out.qual.resize(seq0[n_thr]); out.names.resize(name0[n_thr]);
+            out.off.assign(rec0[n_thr] + 1, 0); out.name_off.assign(rec0[n_thr] + 1, 0);
+            on_pieces([&](unsigned t) { strict4_fill(cut[t], cut[t + 1], out, rec0[t], seq0[t], name0[t]); });
+            if (std::all_of(ok.begin(), ok.end(), [](int v) { return v == 1; })) return;
+            out = FastxReads();
+            out.off.push_back(0);
+            out.name_off.push_back(0);
+        }
+    }
+    parse_general(begin, end, out);
 }
 
 void read_fastq_paired(const std::string& path1, const std::string& path2, FastxReads& out) {

@@ -20,7 +20,9 @@
 #include "index_build.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <stdexcept>
 #include <unordered_map>
 
@@ -344,23 +346,87 @@ void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, 
         build_from_scratch(pm, p, flank_mask, max_nodes, out);
         return;
     }
-    Builder b(pm, p, flank_mask);
-    // Pre-order numbering == node index, so visiting nodes in index order with an explicit
-    // ancestor stack is the DFS; undo when leaving a subtree.
-    std::vector<int32_t> stack;
-    std::vector<NodeUndo> undos;
     const size_t n_do = std::min(n, max_nodes);
-    for (size_t i = 0; i < n_do; ++i) {
-        int32_t par = pm.nodes[i].parent;
-        while (!stack.empty() && stack.back() != par) {
-            b.undo(undos.back());
-            undos.pop_back();
-            stack.pop_back();
+    // Pre-order numbering == node index, so visiting nodes in index order with an explicit ancestor stack is the DFS; undo
+    // when leaving a subtree.  `b` must be in the state of node `first`'s parent path: `stack` / `undos` hold that path.
+    auto run_range = [&](Builder& b, std::vector<int32_t>& stack, std::vector<NodeUndo>& undos, size_t first, size_t last, std::vector<uint64_t>& o_hash,
+                         std::vector<int16_t>& o_pc, std::vector<int16_t>& o_cc, std::vector<uint64_t>& o_end) {
+        for (size_t i = first; i < last; ++i) {
+            const int32_t par = pm.nodes[i].parent;
+            while (!stack.empty() && stack.back() != par) {
+                b.undo(undos.back());
+                undos.pop_back();
+                stack.pop_back();
+            }
+            undos.emplace_back();
+            stack.push_back((int32_t)i);
+            b.process((int32_t)i, undos.back(), o_hash, o_pc, o_cc);
+            o_end.push_back(o_hash.size());
         }
-        undos.emplace_back();
-        stack.push_back((int32_t)i);
-        b.process((int32_t)i, undos.back(), out.hash, out.parent_count, out.child_count);
-        out.offsets[i + 1] = out.hash.size();
+    };
+    unsigned n_thr = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("PMX_INDEX_THREADS")) n_thr = (unsigned)std::max(1, atoi(e));
+    if (n_thr <= 1 || n_do < 4096) {
+        Builder b(pm, p, flank_mask);
+        std::vector<int32_t> stack;
+        std::vector<NodeUndo> undos;
+        std::vector<uint64_t> ends;
+        run_range(b, stack, undos, 0, n_do, out.hash, out.parent_count, out.child_count, ends);
+        for (size_t i = 0; i < n_do; ++i) out.offsets[i + 1] = ends[i];
+    } else {
+        // Parallel producer (the reference splits the DFS the same way, src/index_single_mode.cpp:2291-2470): the nodes are
+        // cut into contiguous chunks of the pre-order; a worker starts from a copy of the state after the root (processed
+        // once: it builds every seed of the tree's first genome), replays the path from the root down to its chunk's first
+        // node -- the state of a node depends on its root path alone -- and then runs the serial procedure over the chunk.
+        // The chunks' outputs are concatenated in order: the same arrays as the serial build.
+        Builder root_b(pm, p, flank_mask);
+        std::vector<int32_t> root_stack;
+        std::vector<NodeUndo> root_undos;
+        std::vector<uint64_t> root_hash, root_ends;
+        std::vector<int16_t> root_pc, root_cc;
+        run_range(root_b, root_stack, root_undos, 0, 1, root_hash, root_pc, root_cc, root_ends);
+        const size_t n_chunks = std::min<size_t>((size_t)n_thr * 6, std::max<size_t>(1, (n_do - 1) / 512));
+        struct Chunk { size_t first, last; std::vector<uint64_t> hash, ends; std::vector<int16_t> pc, cc; std::string err; };
+        std::vector<Chunk> chunks(n_chunks);
+        for (size_t c = 0; c < n_chunks; ++c) { chunks[c].first = 1 + (n_do - 1) * c / n_chunks; chunks[c].last = 1 + (n_do - 1) * (c + 1) / n_chunks; }
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < std::min<size_t>(n_thr, n_chunks); ++t)
+            pool.emplace_back([&]() {
+                for (;;) {
+                    const size_t c = next.fetch_add(1);
+                    if (c >= n_chunks) break;
+                    Chunk& ck = chunks[c];
+                    if (ck.first >= ck.last) continue;
+                    try {
+                        Builder b(root_b);                                   // the state after the root
+                        std::vector<int32_t> stack(1, 0);
+                        std::vector<NodeUndo> undos(1);                      // (the root is never undone inside a chunk)
+                        std::vector<int32_t> path;                           // ancestors of the first node below the root, top down
+                        for (int32_t v = pm.nodes[ck.first].parent; v > 0; v = pm.nodes[(size_t)v].parent) path.push_back(v);
+                        std::vector<uint64_t> sink_h, sink_e;
+                        std::vector<int16_t> sink_p, sink_c;
+                        for (size_t k = path.size(); k-- > 0;) {
+                            undos.emplace_back();
+                            stack.push_back(path[k]);
+                            b.process(path[k], undos.back(), sink_h, sink_p, sink_c);
+                        }
+                        run_range(b, stack, undos, ck.first, ck.last, ck.hash, ck.pc, ck.cc, ck.ends);
+                    } catch (const std::exception& e) { ck.err = e.what(); if (ck.err.empty()) ck.err = "index build failed"; }
+                }
+            });
+        for (auto& th : pool) th.join();
+        for (const Chunk& ck : chunks)
+            if (!ck.err.empty()) throw std::runtime_error(ck.err);
+        out.hash = std::move(root_hash); out.parent_count = std::move(root_pc); out.child_count = std::move(root_cc);
+        out.offsets[1] = out.hash.size();
+        for (const Chunk& ck : chunks) {
+            const uint64_t base = out.hash.size();
+            out.hash.insert(out.hash.end(), ck.hash.begin(), ck.hash.end());
+            out.parent_count.insert(out.parent_count.end(), ck.pc.begin(), ck.pc.end());
+            out.child_count.insert(out.child_count.end(), ck.cc.begin(), ck.cc.end());
+            for (size_t i = ck.first; i < ck.last; ++i) out.offsets[i + 1] = base + ck.ends[i - ck.first];
+        }
     }
     for (size_t i = n_do; i < n; ++i) out.offsets[i + 1] = out.hash.size();
 }

@@ -274,3 +274,52 @@ def test_synthetic_reads_are_deterministic_and_fr(pmx, sars):
     c3, _ = pmx.simulate_paired_reads(g, 500, seed=42, sub_rate=0.0)
     r1 = bytes(c3[o1[0]:o1[1]]); r2 = bytes(c3[o1[1]:o1[2]])
     assert r1 in g and pmx.reverse_complement(r2) in g
+
+
+@pytest.mark.parametrize("name", ["sars_20000_twilight_dipper.panman", "rsv_4K.panman"])
+def test_parallel_index_build_equals_serial(pmx, name, monkeypatch):
+    """the reference's contract src/test/test_index.cpp:112-139 (4-thread build == 1-thread build): the chunked producer
+    (root state copied, path to the chunk's first node replayed; src/index_single_mode.cpp:2291-2470) gives the serial
+    producer's arrays, element for element -- on the SARS tree and on rsv_4K (inverted block insertions), for the place
+    stage's index with its 250-base flank mask and for the oriented (--meta) index"""
+    pm = pmx.Panman(os.path.join(GOLDEN, name))
+    for kw in (dict(), dict(mode=0x100, flank_mask=0)):
+        monkeypatch.setenv("PMX_INDEX_THREADS", "1")
+        one = pmx.Index.build(pm, **kw).arrays()
+        monkeypatch.setenv("PMX_INDEX_THREADS", "5")
+        many = pmx.Index.build(pm, **kw).arrays()
+        for k in ("parent", "offsets", "hash", "parent_count", "child_count"):
+            assert np.array_equal(one[k], many[k]), (kw, k)
+
+
+def test_parallel_fastq_scan_equals_serial(pmx, tmp_path, monkeypatch):
+    """the native reader cuts a large four-line FASTQ at record starts and parses the pieces side by side
+    (src/placement.cpp:97-161 does the same for uncompressed input): same arrays as the one-thread parse -- quality lines
+    that begin with '@', CRLF line ends and names with comments included -- and a file whose records are wrapped falls back
+    to the general parser"""
+    rng = np.random.default_rng(4)
+    path = tmp_path / "big.fastq"
+    with open(path, "wb") as f:
+        for i in range(70000):
+            n = int(rng.integers(40, 160))
+            seq = bytes(rng.choice(list(b"ACGTN"), n).astype(np.uint8))
+            qual = b"@" + bytes(rng.integers(33, 74, n - 1).astype(np.uint8)) if i % 7 == 0 else bytes(rng.integers(35, 74, n).astype(np.uint8))
+            eol = b"\r\n" if i % 1000 == 0 else b"\n"
+            f.write(b"@read%d comment %d" % (i, i) + eol + seq + eol + b"+" + eol + qual + eol)
+    assert os.path.getsize(path) > (8 << 20)
+
+    def read(threads, p=path):
+        monkeypatch.setenv("PMX_FASTX_THREADS", str(threads))
+        fx = pmx.read_fastx_native(str(p))
+        return (np.array(fx.off), np.array(fx.name_off), bytes(fx.seq), bytes(fx.qual), bytes(fx.names_concat))
+    one, many = read(1), read(7)
+    assert len(one[0]) == 70001
+    for a, b in zip(one, many):
+        assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+    wrapped = tmp_path / "wrapped.fastq"
+    with open(wrapped, "wb") as f:
+        for i in range(60000):
+            seq = bytes(rng.choice(list(b"ACGT"), 120).astype(np.uint8))
+            f.write(b"@w%d\n%s\n%s\n+\n%s\n%s\n" % (i, seq[:60], seq[60:], b"I" * 60, b"I" * 60))
+    w1, w7 = read(1, wrapped), read(7, wrapped)
+    assert len(w1[0]) == 60001 and all((np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b) for a, b in zip(w1, w7))
