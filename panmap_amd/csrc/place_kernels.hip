@@ -74,14 +74,28 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* _
         int nb = (int)(len - base0 < 32 ? len - base0 : 32);
         uint64_t v = 0;
         uint32_t a = 0;
-        for (int j = 0; j < nb; ++j) {
+        // the (up to) 32 bytes as aligned 32-bit words: nine loads instead of thirty-two byte loads (the word that holds a
+        // needed byte lies inside the buffer's last page whatever the buffer's end; no word without a needed byte is touched)
+        const uintptr_t addr = (uintptr_t)p;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)3);
+        const int sh = (int)(addr & 3u);
+        const int n_w = nb > 0 ? (sh + nb + 3) >> 2 : 0;
+        uint32_t wd[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wd[t] = t < n_w ? q[t] : 0u;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
             // A C G T (either case) -> 0 1 2 3 without a branch: with c = ch & 0xDF, ((c >> 1) ^ (c >> 2)) & 3 maps
             // 0x41 0x43 0x47 0x54 to 0 1 2 3 (and U = 0x55 to 3); anything else is ambiguous with code 0
-            const uint32_t c = (uint32_t)p[j] & 0xDFu;
+            // (static register indices: byte j sits in the 64-bit pair wd[j/4 + 1] : wd[j/4], shifted by the thread's offset)
+            const uint64_t pair = (uint64_t)wd[(j >> 2) + 1] << 32 | (uint64_t)wd[j >> 2];
+            const uint32_t ch = (uint32_t)(pair >> (8 * ((j & 3) + sh))) & 0xffu;
+            const uint32_t c = ch & 0xDFu;
             const uint32_t tr = ((c >> 1) ^ (c >> 2)) & 3u;
             const bool acgt = c == 0x41u || c == 0x43u || c == 0x47u || c == 0x54u;
             const bool is_u = c == 0x55u;
-            const uint32_t code = (acgt || is_u) ? tr : 0u, am = acgt ? 0u : 1u;
+            const bool in = j < nb;
+            const uint32_t code = (in && (acgt || is_u)) ? tr : 0u, am = (in && !acgt) ? 1u : 0u;
             v |= (uint64_t)code << (2 * j);
             a |= am << j;
         }
