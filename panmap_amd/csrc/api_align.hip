@@ -386,7 +386,9 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             // wave tier ~0.2 us per easy pair and ~0.9 us per hard one.  First round (pairs asking for their first DP: mostly
             // easy ones): the wave tier below 16,384 pairs.  Later rounds hold the pairs that needed a DP before, i.e.
             // hard ones: another service round pays down to a quarter of that (real 150 bp reads: 53.8 -> 50.3 ms).
-            int64_t small_rounds = 16384;
+            // (round 3, 10M reads: 13.9k first-round requests through the service + one replay: 34.4 ms for the stage, through
+            // the wave tier 35.9)
+            int64_t small_rounds = 8192;
             if (const char* e = getenv("PMX_ALIGN_TPP_MIN")) small_rounds = atoll(e);
             const int64_t dp_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dp_lds);
             const int small_qlen = 192, small_tlen = 192;   // ksw_extd2_reg<3>: up to three target columns per lane
