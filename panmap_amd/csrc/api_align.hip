@@ -42,6 +42,7 @@ struct pmx_aligner {
     DevBuf<uint8_t> slow, slow2, slab0, slab_raw;
     DevBuf<A128> mv_handover;
     DevBuf<uint32_t> pp_idx, pp_idx2;   // pair order of the thread-per-pair kernels
+    DevBuf<uint64_t> pp_key, pp_key2;
     DevBuf<char> pp_tmp;
     uint32_t mv_epoch = 0;
     DevBuf<uint32_t> retry_list2, bail_list;
@@ -87,6 +88,13 @@ __global__ void k_sum_edits(const AlnRecord* __restrict__ recs, const int32_t* _
 struct IsEvenRead {
     __host__ __device__ bool operator()(const uint32_t& r) const { return (r & 1u) == 0u; }
 };
+// pair key = locality key of mate 1 (fragment start) in the high half, of mate 2 (fragment end) in the low half
+__global__ void k_pair_keys(const uint32_t* __restrict__ read_key, int64_t n_pairs, uint64_t* key, uint32_t* idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * blockDim.x) {
+        key[i] = (uint64_t)read_key[2 * i] << 32 | (uint64_t)read_key[2 * i + 1];
+        idx[i] = (uint32_t)i;
+    }
+}
 __global__ void k_halve(const uint32_t* __restrict__ in, int64_t n, uint32_t* out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[i] >> 1;
 }
@@ -441,7 +449,20 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 // the read set's locality order (shared with the seeding stage); pairs: the even reads of it, in that order
                 const uint32_t* read_order = readset_locality_order(ctx, rs);
                 if (read_order && !paired) order = read_order;
-                else if (read_order) {
+                else if (read_order && !getenv("PMX_ALIGN_PAIR_KEY1")) {
+                    // pairs by (key of mate 1, key of mate 2): the 64 pairs of a wave then start AND end within a few bases
+                    // of each other -- same anchors, same overlap of the mates, same trip counts in every per-lane loop
+                    // (round 3, 10M reads: k_align_compact16 28.2 -> 25.0 ms against the order by mate 1 alone, which
+                    // PMX_ALIGN_PAIR_KEY1 still selects; the extra 64-bit sort of the pairs is ~1 ms of that)
+                    al->pp_key.ensure((size_t)n_items); al->pp_key2.ensure((size_t)n_items); al->pp_idx.ensure((size_t)n_items); al->pp_idx2.ensure((size_t)n_items + 1);
+                    hipLaunchKernelGGL(k_pair_keys, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                                       rs->loc_key.p, n_items, al->pp_key.p, al->pp_idx.p);
+                    size_t bytes = 0;
+                    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 64, ctx->stream));
+                    al->pp_tmp.ensure(bytes);
+                    PMX_HIP(rocprim::radix_sort_pairs(al->pp_tmp.p, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 64, ctx->stream));
+                    order = al->pp_idx2.p;
+                } else if (read_order) {
                     al->pp_idx.ensure((size_t)rs->n); al->pp_idx2.ensure((size_t)n_items + 1);
                     size_t bytes = 0;
                     PMX_HIP(rocprim::select(nullptr, bytes, read_order, al->pp_idx.p, al->pp_idx2.p + n_items, (size_t)rs->n, IsEvenRead(), ctx->stream));
