@@ -329,6 +329,11 @@ int pmx_align_readset(pmx_ctx *ctx, pmx_aligner *al, const pmx_readset *rs, int 
  * ambiguous bases; the read length without one).  Leaves the records of the run behind like pmx_align_readset.
  * Paired scoring needs an even number of reads. */
 int pmx_align_score_reads(pmx_ctx *ctx, pmx_aligner *al, const pmx_readset *rs, int paired, int revcomp_mate2, int64_t *score);
+/* Drop-in for the reference's scorer with its own signature (src/mm_align.h:13-17): host strings in (interleaved mates when
+ * paired_end, mate 2 as sequenced), minus the total edit distance out, 0 on failure.  An odd read of a paired set is mapped
+ * alone (src/mm_align.c:178-185); reads of flagged records count as unmapped (pmx_last_error() says how many). */
+int64_t pmx_score_reads_vs_reference(const char *reference, int n_reads, const char **reads, const int *r_lens, int kmer_size,
+                                     bool paired_end);
 int64_t pmx_align_num_records(const pmx_aligner *al);
 int64_t pmx_align_cigar_words(pmx_ctx *ctx, pmx_aligner *al);
 int pmx_align_fetch(pmx_ctx *ctx, pmx_aligner *al, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,
@@ -382,6 +387,15 @@ int pmx_dist_world(const pmx_dist *d);
 int pmx_dist_barrier(pmx_dist *d);
 /* element-wise sum of every rank's n values, on every rank (--refine over shards: candidate scores add up) */
 int pmx_dist_sum_i64(pmx_dist *d, int64_t *vals, int64_t n);
+/* --dedup over the whole sample (src/placement.cpp:1550-1620 collapses duplicates of ALL reads): every rank thins its shard
+ * (exact comparison), the ranks exchange the 128-bit hash pairs of the reads they keep, and a read whose pair a lower rank
+ * keeps is dropped.  Then pmx_place_add_reads(..., dedup_reads = 1) on the same read set seeds through that mask.
+ * Building blocks (also usable with another transport): pmx_place_dedup_local (mask + the kept reads' hash pairs into two
+ * device arrays of n_reads entries; returns their number), pmx_place_dedup_drop_seen, pmx_place_dedup_local_count. */
+int pmx_dist_dedup_reads(pmx_dist *d, pmx_place *pl, const pmx_readset *rs, int64_t *n_kept_local);
+int64_t pmx_place_dedup_local(pmx_ctx *ctx, pmx_place *pl, const pmx_readset *rs, void *d_h1, void *d_h2, int64_t cap);
+int pmx_place_dedup_drop_seen(pmx_ctx *ctx, pmx_place *pl, const pmx_readset *rs, void *d_seen_h1, void *d_seen_h2, int64_t n_seen);
+int64_t pmx_place_dedup_local_count(pmx_ctx *ctx, pmx_place *pl, const pmx_readset *rs);
 /* all-gather of the ranks' (hash, count) histograms + integer merge: afterwards every rank's placer holds the histogram of
  * the whole sample and pmx_place_score gives the same result on every rank (no floating-point reduction anywhere) */
 int pmx_dist_merge_histograms(pmx_dist *d, pmx_place *pl);

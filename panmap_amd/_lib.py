@@ -168,6 +168,7 @@ SIGNATURES = {
     "pmx_align_score_reads": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "pmx_refine_candidates": (_i64, [_vp, _i64, _vp, _vp, _vp, _vp, _i64]),
     "pmx_refine_top_candidates": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "pmx_score_reads_vs_reference": (_i64, [_cp, _i32, _vp, _vp, _i32, C.c_bool]),
     "pmx_align_num_records": (_i64, [_vp]),
     "pmx_align_cigar_words": (_i64, [_vp, _vp]),
     "pmx_align_fetch": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64]),
@@ -198,6 +199,10 @@ SIGNATURES = {
     "pmx_dist_barrier": (_i32, [_vp]),
     "pmx_dist_sum_i64": (_i32, [_vp, _vp, _i64]),
     "pmx_dist_merge_histograms": (_i32, [_vp, _vp]),
+    "pmx_dist_dedup_reads": (_i32, [_vp, _vp, _vp, _vp]),
+    "pmx_place_dedup_local": (_i64, [_vp, _vp, _vp, _vp, _vp, _i64]),
+    "pmx_place_dedup_drop_seen": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64]),
+    "pmx_place_dedup_local_count": (_i64, [_vp, _vp, _vp]),
     "pmx_dist_gather_alignments": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "pmx_dist_gathered_records": (_vp, [_vp]),
     "pmx_dist_gathered_cigars": (_vp, [_vp]),

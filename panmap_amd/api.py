@@ -809,6 +809,13 @@ class Dist:
         """all-gather + merge: every rank's placer then holds the histogram of the whole sample"""
         check(lib.pmx_dist_merge_histograms(self._h, placer._h), "pmx_dist_merge_histograms")
 
+    def dedup_reads(self, placer: Placer, rs: ReadSet) -> int:
+        """--dedup over the whole sample: prepares the placer's keep mask for `rs` (follow with add_reads(rs, dedupReads=True));
+        returns the reads this rank still keeps"""
+        kept = C.c_int64(0)
+        check(lib.pmx_dist_dedup_reads(self._h, placer._h, rs._h, C.byref(kept)), "pmx_dist_dedup_reads")
+        return int(kept.value)
+
     def gather_alignments(self, aligner: "Aligner", root: int = 0):
         """records + CIGAR arena of the aligner's last call to `root` -> (n_records, n_words) there, (0, 0) elsewhere"""
         nr, nw = C.c_int64(0), C.c_int64(0)
@@ -896,6 +903,14 @@ def align_reads_direct(reference: bytes, reads, paired: bool, n_threads: int = 1
             libc.free(C.cast(ra.cigar, C.c_void_p))
         return dict(pos=ra.pos, rs=ra.rs, re=ra.re, qs=ra.qs, qe=ra.qe, mapq=ra.mapq, rev=ra.rev, proper_frag=ra.proper_frag, cigar=cg)
     return [dict(mapped=res[i].mapped, r1=unpack(res[i].r1), r2=unpack(res[i].r2) if paired else None) for i in range(n_res)]
+
+
+def score_reads_vs_reference(reference: bytes, reads, paired: bool, kmer_size: int = 0) -> int:
+    """the reference's scorer boundary (src/mm_align.h:13-17) through libpanmap_amd.so"""
+    n = len(reads)
+    arr = (C.c_char_p * n)(*reads)
+    lens = (C.c_int * n)(*[len(r) for r in reads])
+    return int(lib.pmx_score_reads_vs_reference(reference, n, arr, lens, kmer_size, paired))
 
 
 def write_bam(bam_path: str, ref_name: str, ref_len: int, seqs, quals, names, results, paired: bool):

@@ -71,11 +71,14 @@ struct pmx_aligner {
 };
 
 // [0] += edit counts, [1] += records flagged invalid (pmx_align_score_reads)
-__global__ void k_sum_edits(const AlnRecord* __restrict__ recs, const int32_t* __restrict__ edits, int64_t n, unsigned long long* out) {
+// (off != NULL: a flagged record counts as an unmapped read -- its length -- the way the drop-in boundary reports it)
+__global__ void k_sum_edits(const AlnRecord* __restrict__ recs, const int32_t* __restrict__ edits, int64_t n, unsigned long long* out,
+                            const int64_t* __restrict__ off) {
     unsigned long long sum = 0, bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        sum += (unsigned long long)(uint32_t)edits[i];
-        bad += (recs[i].flags & 3u) ? 1ULL : 0ULL;
+        const bool flagged = (recs[i].flags & 3u) != 0;
+        sum += flagged && off ? (unsigned long long)(off[i + 1] - off[i]) : (unsigned long long)(uint32_t)edits[i];
+        bad += flagged ? 1ULL : 0ULL;
     }
     for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); bad += __shfl_xor(bad, o); }
     if ((threadIdx.x & 63) == 0) {
@@ -697,9 +700,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
 
 // score_reads_vs_reference (src/mm_align.c:144-199): minus the summed count_read_errors of every read against the
 // aligner's reference -- the alignment-based score of one --refine candidate (src/placement.cpp:489-514)
-int pmx_align_score_reads(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2, int64_t* score) {
-    if (!ctx || !al || !rs || !score) return PMX_ERR_ARG;
-    if (paired && (rs->n & 1)) return fail(PMX_ERR_UNSUPPORTED, "paired scoring of an odd number of reads (the reference maps the last one alone)");
+static int score_reads_impl(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2, int64_t* score, int64_t* n_flagged) {
     al->want_edits = true;
     const int rc = pmx_align_readset(ctx, al, rs, paired, revcomp_mate2);
     al->want_edits = false;
@@ -711,14 +712,67 @@ int pmx_align_score_reads(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, 
     const int64_t n = al->n_records;
     if (n > 0)
         hipLaunchKernelGGL(k_sum_edits, dim3((unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, al->records.p,
-                           al->edits.p, n, al->stats.p);
+                           al->edits.p, n, al->stats.p, n_flagged ? rs->off.p : (const int64_t*)nullptr);
     unsigned long long h[2] = {0, 0};
     PMX_HIP(hipMemcpyAsync(h, al->stats.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PMX_HIP(hipStreamSynchronize(ctx->stream));
-    if (h[1]) return fail(PMX_ERR_UNSUPPORTED, "reads with flagged (overflow / unsupported) records: their edit counts are not the reference's");
+    if (n_flagged) *n_flagged = (int64_t)h[1];
+    else if (h[1]) return fail(PMX_ERR_UNSUPPORTED, "reads with flagged (overflow / unsupported) records: their edit counts are not the reference's");
     *score = -(int64_t)h[0];
     return PMX_OK;
     PMX_CATCH
+}
+
+int pmx_align_score_reads(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2, int64_t* score) {
+    if (!ctx || !al || !rs || !score) return PMX_ERR_ARG;
+    if (paired && (rs->n & 1)) return fail(PMX_ERR_UNSUPPORTED, "paired scoring of an odd number of reads (the reference maps the last one alone: pmx_score_reads_vs_reference does)");
+    return score_reads_impl(ctx, al, rs, paired, revcomp_mate2, score, nullptr);
+}
+
+// Drop-in for score_reads_vs_reference (src/mm_align.h:13-17, src/mm_align.c:144-199), the reference's own signature: host
+// strings in, minus the total edit distance out; 0 on failure, as the reference returns 0 when its index cannot be built.
+// An odd read of a paired set is mapped alone (:178-185).  A pair whose record a kernel flagged invalid counts as unmapped
+// reads (their lengths), the way pmx_align_reads_direct reports such pairs; pmx_last_error() says how many there were.
+int64_t pmx_score_reads_vs_reference(const char* reference, int n_reads, const char** reads, const int* r_lens, int kmer_size, bool paired_end) {
+    (void)kmer_size;
+    if (!reference || !reads || !r_lens || n_reads <= 0) return 0;
+    pmx_ctx* ctx = nullptr;
+    int dev = 0;
+    if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
+    if (pmx_ctx_create(dev, &ctx) != PMX_OK) return 0;
+    pmx_aligner* al = nullptr;
+    int64_t total = 0, withheld = 0;
+    bool ok = false;
+    do {
+        std::vector<int64_t> off((size_t)n_reads + 1, 0);
+        for (int i = 0; i < n_reads; ++i) off[(size_t)i + 1] = off[(size_t)i] + r_lens[i];
+        std::string concat;
+        concat.reserve((size_t)off[(size_t)n_reads]);
+        for (int i = 0; i < n_reads; ++i) concat.append(reads[i], (size_t)r_lens[i]);
+        for (char& ch : concat)
+            if ((unsigned char)ch < 4) ch = "ACGT"[(unsigned char)ch];   // (pre-encoded bases, as in pmx_align_reads_direct)
+        const int avg_len = (int)(off[(size_t)n_reads] / n_reads);        // setup_minimap2 looks at every read (src/mm_align.c:124-130)
+        if (pmx_aligner_create(ctx, reference, (int64_t)strlen(reference), avg_len, &al) != PMX_OK) break;
+        const bool paired = paired_end && n_reads >= 2;
+        const int n_main = paired ? n_reads & ~1 : n_reads;
+        auto run = [&](int first, int count, int as_pairs) {
+            pmx_readset* rs = nullptr;
+            if (pmx_readset_upload(ctx, concat.data(), off.data() + first, count, &rs) != PMX_OK) return false;
+            int64_t sc = 0, flagged = 0;
+            const bool good = pmx_readset_pack(ctx, rs) == PMX_OK && score_reads_impl(ctx, al, rs, as_pairs, 0, &sc, &flagged) == PMX_OK;
+            pmx_readset_free(ctx, rs);
+            total += sc;
+            withheld += flagged;
+            return good;
+        };
+        if (!run(0, n_main, paired ? 1 : 0)) break;
+        if (n_main < n_reads && !run(n_main, 1, 0)) break;   // the odd read, alone
+        ok = true;
+    } while (0);
+    if (al) pmx_aligner_free(ctx, al);
+    pmx_ctx_destroy(ctx);
+    if (ok && withheld) set_error("pmx_score_reads_vs_reference: " + std::to_string(withheld) + " read(s) of flagged records counted as unmapped");
+    return ok ? total : 0;
 }
 
 int64_t pmx_align_num_records(const pmx_aligner* al) { return al ? al->n_records : 0; }

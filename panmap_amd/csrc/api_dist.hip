@@ -30,6 +30,7 @@ using namespace pmx;
 
 // pieces of the place / align objects this unit needs (defined next to them)
 int64_t pmx_place_histogram_entries(pmx_ctx* ctx, pmx_place* pl);
+extern "C" int64_t pmx_place_dedup_local_count(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs);
 
 namespace {
 int fail(int code, const std::string& msg) {
@@ -292,6 +293,57 @@ int pmx_dist_sum_i64(pmx_dist* d, int64_t* vals, int64_t n) {
         for (int r = 0; r < d->tp->world; ++r) sum += all[(size_t)r * (size_t)n + (size_t)i];
         vals[i] = sum;
     }
+    return PMX_OK;
+    PMX_CATCH
+}
+
+// --dedup over the whole sample: every distinct read string is counted once, by the lowest rank that holds a copy.  Each
+// rank thins its own shard first (exact byte comparison), then the ranks exchange the 128-bit hash pairs of the reads they
+// keep and a rank drops every read whose pair a LOWER rank keeps.  (Across ranks the identity of two reads is the equality of
+// two independent 64-bit hashes of their ASCII: a false merge needs a 128-bit collision among the sample's reads.)
+// Follow with pmx_place_add_reads(..., dedup_reads = 1) on the same read set: it seeds through the prepared mask.
+int pmx_dist_dedup_reads(pmx_dist* d, pmx_place* pl, const pmx_readset* rs, int64_t* n_kept_local) {
+    if (!d || !pl || !rs) return PMX_ERR_ARG;
+    PMX_TRY
+    pmx_ctx* ctx = d->ctx;
+    PMX_HIP(hipSetDevice(ctx->device));
+    const int world = d->tp->world, rank = d->tp->rank;
+    const int64_t n = pmx_readset_num_reads(rs);
+    DevBuf<uint64_t> mine;
+    // sizes first: the padded all-gather needs the largest count
+    mine.alloc(2 * (size_t)std::max<int64_t>(n, 1));
+    int64_t kept = pmx_place_dedup_local(ctx, pl, rs, mine.p, mine.p + std::max<int64_t>(n, 1), std::max<int64_t>(n, 1));
+    if (kept < 0) return (int)kept;
+    if (world > 1) {
+        const std::vector<int64_t> sizes = d->exchange_counts(&kept, 1);
+        int64_t mx = 1, lower = 0;
+        for (int r = 0; r < world; ++r) { mx = std::max(mx, sizes[r]); if (r < rank) lower += sizes[r]; }
+        DevBuf<uint64_t> padded, all, seen;
+        padded.alloc(2 * (size_t)mx);
+        all.alloc(2 * (size_t)mx * (size_t)world);
+        PMX_HIP(hipMemsetAsync(padded.p, 0, sizeof(uint64_t) * 2 * (size_t)mx, ctx->stream));
+        if (kept > 0) {
+            PMX_HIP(hipMemcpyAsync(padded.p, mine.p, sizeof(uint64_t) * (size_t)kept, hipMemcpyDeviceToDevice, ctx->stream));
+            PMX_HIP(hipMemcpyAsync(padded.p + mx, mine.p + std::max<int64_t>(n, 1), sizeof(uint64_t) * (size_t)kept, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        d->tp->all_gather(ctx->stream, padded.p, sizeof(uint64_t) * 2 * (size_t)mx, all.p);
+        if (lower > 0) {
+            seen.alloc(2 * (size_t)lower);
+            int64_t at = 0;
+            for (int r = 0; r < rank; ++r) {
+                if (sizes[r] == 0) continue;
+                PMX_HIP(hipMemcpyAsync(seen.p + at, all.p + (size_t)r * 2 * (size_t)mx, sizeof(uint64_t) * (size_t)sizes[r], hipMemcpyDeviceToDevice, ctx->stream));
+                PMX_HIP(hipMemcpyAsync(seen.p + lower + at, all.p + (size_t)r * 2 * (size_t)mx + (size_t)mx, sizeof(uint64_t) * (size_t)sizes[r], hipMemcpyDeviceToDevice, ctx->stream));
+                at += sizes[r];
+            }
+            const int rc = pmx_place_dedup_drop_seen(ctx, pl, rs, seen.p, seen.p + lower, lower);
+            if (rc != PMX_OK) return rc;
+            kept = pmx_place_dedup_local_count(ctx, pl, rs);
+            if (kept < 0) return (int)kept;
+        }
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (n_kept_local) *n_kept_local = kept;
     return PMX_OK;
     PMX_CATCH
 }

@@ -73,6 +73,8 @@ struct pmx_place {
     DevBuf<uint64_t> dd_h1, dd_h2, dd_h1s, dd_key;   // --dedup scratch
     DevBuf<uint32_t> dd_idx, dd_idx2;
     DevBuf<uint8_t> dd_keep;
+    const pmx_readset* dd_for = nullptr;   // the read set dd_keep / dd_h1 / dd_h2 were computed for (one-shot)
+    DevBuf<unsigned long long> dd_count;
     DevBuf<uint8_t> term_meta;
     DevBuf<int64_t> counts2;
     std::vector<double> h_scores;
@@ -594,6 +596,29 @@ int pmx_place_reset(pmx_ctx* ctx, pmx_place* pl) {
     PMX_CATCH
 }
 
+// keep[read] = 1 for the first copy of every distinct read string of the set: two independent 64-bit hashes of the raw
+// ASCII, a stable radix sort on the 128-bit key (by h2, then by h1), an exact byte comparison with the predecessor
+static void dedup_local(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs) {
+    const int64_t n = rs->n;
+    const int G = ctx->n_cu * 8;
+    pl->dd_h1.ensure((size_t)n); pl->dd_h2.ensure((size_t)n); pl->dd_h1s.ensure((size_t)n); pl->dd_key.ensure((size_t)n);
+    pl->dd_idx.ensure((size_t)n); pl->dd_idx2.ensure((size_t)n); pl->dd_keep.ensure((size_t)n);
+    if (n == 0) { pl->dd_for = rs; return; }
+    hipLaunchKernelGGL(k_read_hashes, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p, n, pl->dd_h1.p, pl->dd_h2.p, pl->dd_idx.p);
+    size_t bytes = 0;
+    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->dd_h2.p, pl->dd_key.p, pl->dd_idx.p, pl->dd_idx2.p, (size_t)n, 0, 64, ctx->stream));
+    pl->tmp.ensure(bytes);
+    PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->dd_h2.p, pl->dd_key.p, pl->dd_idx.p, pl->dd_idx2.p, (size_t)n, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, pl->dd_h1.p, pl->dd_idx2.p, n, pl->dd_key.p);
+    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->dd_key.p, pl->dd_h1s.p, pl->dd_idx2.p, pl->dd_idx.p, (size_t)n, 0, 64, ctx->stream));
+    pl->tmp.ensure(bytes);
+    PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->dd_key.p, pl->dd_h1s.p, pl->dd_idx2.p, pl->dd_idx.p, (size_t)n, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_mark_first_of_run, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p, pl->dd_h1s.p, pl->dd_h2.p, pl->dd_idx.p, n,
+                       pl->dd_keep.p);
+    PMX_HIP(hipGetLastError());
+    pl->dd_for = rs;
+}
+
 static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, int64_t rr0, int64_t rr1, const pmx_place_params* pp) {
     if (!ctx || !pl || !rs || !pp || rr0 < 0 || rr1 < rr0 || rr1 > rs->n) return PMX_ERR_ARG;
     const bool whole = rr0 == 0 && rr1 == rs->n;
@@ -620,25 +645,9 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         const bool quality_mode = pp->min_seed_quality > 0 && rs->has_qual;   // src/placement.cpp:1386: no dedup in this branch
         const uint8_t* keep = nullptr;
         if (pp->dedup_reads && !quality_mode) {   // --dedup: every distinct read sequence of this read set counts once
-            const int64_t n = rs->n;
-            const int G = ctx->n_cu * 8;
-            pl->dd_h1.ensure((size_t)n); pl->dd_h2.ensure((size_t)n); pl->dd_h1s.ensure((size_t)n); pl->dd_key.ensure((size_t)n);
-            pl->dd_idx.ensure((size_t)n); pl->dd_idx2.ensure((size_t)n); pl->dd_keep.ensure((size_t)n);
-            hipLaunchKernelGGL(k_read_hashes, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p, n, pl->dd_h1.p,
-                               pl->dd_h2.p, pl->dd_idx.p);
-            // stable LSD order: by h2 first, then by h1
-            size_t bytes = 0;
-            PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->dd_h2.p, pl->dd_key.p, pl->dd_idx.p, pl->dd_idx2.p, (size_t)n, 0, 64, ctx->stream));
-            pl->tmp.ensure(bytes);
-            PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->dd_h2.p, pl->dd_key.p, pl->dd_idx.p, pl->dd_idx2.p, (size_t)n, 0, 64, ctx->stream));
-            hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, pl->dd_h1.p, pl->dd_idx2.p, n, pl->dd_key.p);
-            PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, pl->dd_key.p, pl->dd_h1s.p, pl->dd_idx2.p, pl->dd_idx.p, (size_t)n, 0, 64, ctx->stream));
-            pl->tmp.ensure(bytes);
-            PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, pl->dd_key.p, pl->dd_h1s.p, pl->dd_idx2.p, pl->dd_idx.p, (size_t)n, 0, 64, ctx->stream));
-            hipLaunchKernelGGL(k_mark_first_of_run, dim3(grid_for(n, 256, G)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p, pl->dd_h1s.p,
-                               pl->dd_h2.p, pl->dd_idx.p, n, pl->dd_keep.p);
-            PMX_HIP(hipGetLastError());
+            if (pl->dd_for != rs) dedup_local(ctx, pl, rs);   // (pmx_place_dedup_* may have prepared -- and thinned -- the mask already)
             keep = pl->dd_keep.p;
+            pl->dd_for = nullptr;                               // one use: the next call starts over
         }
         int64_t chunk_mb = 64;   // (a group of three chunks = one table reservation: 1M x 150 bp is one group; 16 MB chunks measured 2.46 ms for the stage, one group 2.09)
         if (const char* e = getenv("PMX_SEED_CHUNK_MB")) chunk_mb = std::max<int64_t>(1, atoll(e));
@@ -728,6 +737,69 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
     pl->bases_added += (double)(rr1 - rr0) * (double)rs->max_len;
     pl->hist_sorted = false;
     pl->table_dirty = true;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+// --dedup over several ranks (pmx_dist_dedup_reads drives these): the local mask + the hash pairs of the kept reads, and
+// the removal of the reads whose pair another rank already keeps
+int64_t pmx_place_dedup_local(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, void* d_h1, void* d_h2, int64_t cap) {
+    if (!ctx || !pl || !rs) return PMX_ERR_ARG;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    dedup_local(ctx, pl, rs);
+    pl->dd_count.ensure(1);
+    PMX_HIP(hipMemsetAsync(pl->dd_count.p, 0, sizeof(unsigned long long), ctx->stream));
+    if (!d_h1 || !d_h2) {   // count only: a reduction of the mask through the same kernel into scratch is not worth a variant
+        unsigned long long kept = 0;
+        std::vector<uint8_t> h((size_t)rs->n);
+        if (rs->n > 0) PMX_HIP(hipMemcpyAsync(h.data(), pl->dd_keep.p, (size_t)rs->n, hipMemcpyDeviceToHost, ctx->stream));
+        PMX_HIP(hipStreamSynchronize(ctx->stream));
+        for (uint8_t v : h) kept += v;
+        return (int64_t)kept;
+    }
+    if (cap < rs->n) return fail(PMX_ERR_CAPACITY, "dedup export buffers must hold one pair per read");
+    if (rs->n > 0)
+        hipLaunchKernelGGL(k_kept_read_hashes, dim3(grid_for(rs->n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->dd_h1.p, pl->dd_h2.p, pl->dd_keep.p, rs->n,
+                           (uint64_t*)d_h1, (uint64_t*)d_h2, pl->dd_count.p);
+    unsigned long long kept = 0;
+    PMX_HIP(hipMemcpyAsync(&kept, pl->dd_count.p, sizeof(kept), hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    return (int64_t)kept;
+    PMX_CATCH
+}
+
+// reads the prepared mask still keeps (no recomputation)
+int64_t pmx_place_dedup_local_count(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs) {
+    if (!ctx || !pl || !rs) return PMX_ERR_ARG;
+    if (pl->dd_for != rs) return fail(PMX_ERR_ARG, "pmx_place_dedup_local must run on this read set first");
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    std::vector<uint8_t> h((size_t)rs->n);
+    if (rs->n > 0) PMX_HIP(hipMemcpyAsync(h.data(), pl->dd_keep.p, (size_t)rs->n, hipMemcpyDeviceToHost, ctx->stream));
+    PMX_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t kept = 0;
+    for (uint8_t v : h) kept += v;
+    return kept;
+    PMX_CATCH
+}
+
+int pmx_place_dedup_drop_seen(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, void* d_seen_h1, void* d_seen_h2, int64_t n_seen) {
+    if (!ctx || !pl || !rs || n_seen < 0 || (n_seen > 0 && (!d_seen_h1 || !d_seen_h2))) return PMX_ERR_ARG;
+    if (pl->dd_for != rs) return fail(PMX_ERR_ARG, "pmx_place_dedup_local must run on this read set first");
+    if (n_seen == 0 || rs->n == 0) return PMX_OK;
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    DevBuf<uint64_t> s1, s2;
+    s1.alloc((size_t)n_seen); s2.alloc((size_t)n_seen);
+    size_t bytes = 0;
+    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)d_seen_h1, s1.p, (uint64_t*)d_seen_h2, s2.p, (size_t)n_seen, 0, 64, ctx->stream));
+    pl->tmp.ensure(bytes);
+    PMX_HIP(rocprim::radix_sort_pairs(pl->tmp.p, bytes, (uint64_t*)d_seen_h1, s1.p, (uint64_t*)d_seen_h2, s2.p, (size_t)n_seen, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_drop_seen_reads, dim3(grid_for(rs->n, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, pl->dd_h1.p, pl->dd_h2.p, rs->n, s1.p, s2.p, n_seen,
+                       pl->dd_keep.p);
+    PMX_HIP(hipGetLastError());
+    PMX_HIP(hipStreamSynchronize(ctx->stream));   // (s1 / s2 go out of scope)
     return PMX_OK;
     PMX_CATCH
 }

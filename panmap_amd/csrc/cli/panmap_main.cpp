@@ -305,7 +305,6 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
     // this rank's shard: reads [lo, hi), mates together
     const int64_t unit = paired ? 2 : 1, n_units = n_reads / unit;
     const int64_t lo = n_units * rank / world * unit, hi = rank == world - 1 ? n_reads : n_units * (rank + 1) / world * unit;
-    if (c.dedup && world > 1) die("--dedup collapses duplicates over the whole sample: not available with --gpus yet (it would count a duplicate on two ranks twice)");
 
     // ------------------------------------------------------------------------------------------------ place
     pmx_readset*& rs = g.rs;
@@ -318,6 +317,7 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
     if (c.min_seed_quality > 0) check(pmx_readset_set_qualities(ctx, rs, quals.data() + off[(size_t)lo]), "attaching the qualities");
     pmx_place_result res;
     check(pmx_place_reset(ctx, pl), "place reset");
+    if (dist && c.dedup && c.min_seed_quality <= 0) check(pmx_dist_dedup_reads(dist, pl, rs, nullptr), "collapsing duplicate reads over the ranks");
     check(pmx_place_add_reads(ctx, pl, rs, &pp), "seeding the reads");
     if (dist) check(pmx_dist_merge_histograms(dist, pl), "merging the ranks' seed histograms");
     check(pmx_place_score(ctx, pl, &pp, n_reads, &res), "scoring the tree");

@@ -33,6 +33,10 @@ __global__ void k_seed_histogram_ks(const uint64_t* words, const uint32_t* amb, 
 __global__ void k_read_prefix_keys(const uint64_t* words, const int64_t* woff, int64_t r_begin, int64_t n_reads, uint32_t* key, uint32_t* idx);
 __global__ void k_read_hashes(const uint8_t* ascii, const int64_t* off, int64_t n_reads, uint64_t* h1, uint64_t* h2, uint32_t* idx);
 __global__ void k_gather_u64(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst);
+__global__ void k_kept_read_hashes(const uint64_t* h1, const uint64_t* h2, const uint8_t* keep, int64_t n, uint64_t* out_h1, uint64_t* out_h2,
+                                   unsigned long long* n_out);
+__global__ void k_drop_seen_reads(const uint64_t* h1, const uint64_t* h2, int64_t n, const uint64_t* seen_h1, const uint64_t* seen_h2, int64_t n_seen,
+                                  uint8_t* keep);
 __global__ void k_mark_first_of_run(const uint8_t* ascii, const int64_t* off, const uint64_t* h1s, const uint64_t* h2, const uint32_t* perm,
                                     int64_t n, uint8_t* keep);
 __global__ void k_table_merge(const uint64_t* hash, const int64_t* count, int64_t n, uint64_t* keys, unsigned long long* vals,

@@ -147,6 +147,33 @@ __global__ void k_mark_first_of_run(const uint8_t* __restrict__ ascii, const int
     }
 }
 
+// --dedup over ranks: the (h1, h2) of the reads a rank keeps, appended in any order
+__global__ void k_kept_read_hashes(const uint64_t* __restrict__ h1, const uint64_t* __restrict__ h2, const uint8_t* __restrict__ keep, int64_t n,
+                                   uint64_t* out_h1, uint64_t* out_h2, unsigned long long* n_out) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        if (!keep[r]) continue;
+        const unsigned long long at = atomicAdd(n_out, 1ULL);
+        out_h1[at] = h1[r];
+        out_h2[at] = h2[r];
+    }
+}
+// ... and a kept read whose hash pair occurs among `seen` (sorted by h1; the kept reads of the lower ranks) is dropped
+__global__ void k_drop_seen_reads(const uint64_t* __restrict__ h1, const uint64_t* __restrict__ h2, int64_t n, const uint64_t* __restrict__ seen_h1,
+                                  const uint64_t* __restrict__ seen_h2, int64_t n_seen, uint8_t* keep) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        if (!keep[r]) continue;
+        const uint64_t a = h1[r], b = h2[r];
+        int64_t lo = 0, hi = n_seen;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (seen_h1[mid] < a) lo = mid + 1;
+            else hi = mid;
+        }
+        for (; lo < n_seen && seen_h1[lo] == a; ++lo)
+            if (seen_h2[lo] == b) { keep[r] = 0; break; }
+    }
+}
+
 // --------------------------------------------------------------------------------- seeding
 __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long* vals, uint64_t mask, uint64_t key,
                                              unsigned long long mult, unsigned long long* counters) {

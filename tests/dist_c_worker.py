@@ -100,6 +100,29 @@ def main():
                    flagged=int(np.sum((m["flags"] & 3) != 0)))
     else:
         out.update(n_records=n_rec, n_words=n_words)
+    # --dedup over the ranks: a read set whose second half repeats its first half (every duplicate pair straddles the two
+    # shards) plus duplicates inside a shard; the merged histogram must equal the single-rank --dedup histogram
+    dd = reads[:6000] + reads[100:160] + reads[:6000] + reads[200:260]
+    lo, hi = shard_bounds(len(dd), world, rank)
+    rs_d = pmx.ReadSet(ctx, dd[lo:hi])
+    kept = dist.dedup_reads(placer, rs_d)
+    placer.reset()
+    placer.add_reads(rs_d, pmx.TraversalParams(dedupReads=True))
+    dist.merge_histograms(placer)
+    dh, dc = placer.histogram()
+    out["dedup_kept"] = kept
+    if rank == 0:
+        rs_all = pmx.ReadSet(ctx, dd)
+        p2 = pmx.Placer(ctx, index)
+        p2.reset()
+        p2.add_reads(rs_all, pmx.TraversalParams(dedupReads=True))
+        wh, wc2 = p2.histogram()
+        p2.reset()
+        p2.add_reads(rs_all, pmx.TraversalParams())
+        _, wc_nodedup = p2.histogram()
+        out["dedup_hist_equal"] = bool(np.array_equal(dh, wh) and np.array_equal(dc, wc2))
+        out["dedup_matters"] = bool(int(wc_nodedup.sum()) > int(wc2.sum()))
+        out["distinct_reads"] = len(set(dd))
     dist.barrier()
     dist.close()
     print("RESULT " + json.dumps(out), flush=True)

@@ -154,8 +154,12 @@ def test_gpus_two_ranks_equal_one(pmx, tmp_path):
                         cwd=tmp_path, capture_output=True, text=True, timeout=1200, env=env)
     assert r3.returncode == 0 and r4.returncode == 0, (r3.stderr[-1000:], r4.stderr[-1000:])
     assert open(tmp_path / "one_r.placement.tsv", "rb").read() == open(tmp_path / "two_r.placement.tsv", "rb").read()
-    r5 = subprocess.run([CLI] + reads + ["--stop", "place", "--dedup", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=1200, env=env)
-    assert r5.returncode == 1 and "--dedup" in r5.stderr
+    # --dedup: duplicates are collapsed over the whole sample, whichever rank holds the copies
+    r5 = run(reads + ["--stop", "place", "--dedup", "-o", "one_d"], tmp_path)
+    r6 = subprocess.run([CLI] + reads + ["--stop", "place", "--dedup", "-o", "two_d", "--gpus", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=1200, env=env)
+    assert r5.returncode == 0 and r6.returncode == 0, (r5.stderr[-1000:], r6.stderr[-1000:])
+    assert open(tmp_path / "one_d.placement.tsv", "rb").read() == open(tmp_path / "two_d.placement.tsv", "rb").read()
+    assert open(tmp_path / "one_d.placement.tsv", "rb").read() != open(tmp_path / "one.placement.tsv", "rb").read()   # (the flag changes the scores)
 
 
 @pytest.mark.gpu

@@ -36,6 +36,8 @@ def test_two_ranks_through_the_c_abi_equal_a_single_rank(tmp_path):
     assert d0["hist_equal"] and d0["scores_equal"] and d0["fields_equal"] and d0["cigars_equal"] and d0["async_same"] and d0["flagged"] == 0
     assert d0["words_per_rank"][1] > 0 and d0["multi_op_cigars"] > 1000
     assert d1["n_records"] == 0 and d1["n_words"] == 0        # only the root holds the gathered set
+    # --dedup over the ranks (pmx_dist_dedup_reads): every distinct read counted once although its copies sit on two ranks
+    assert d0["dedup_hist_equal"] and d0["dedup_matters"] and d0["dedup_kept"] + d1["dedup_kept"] == d0["distinct_reads"]
     assert not [f for f in os.listdir(tmp_path) if not f.endswith(".tmp")]   # the transport cleans up after itself
 
 

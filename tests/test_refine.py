@@ -125,6 +125,17 @@ def test_score_reads_equals_the_reference_aligner(pmx):
     rs = pmx.ReadSet(ctx, cases["real_single"][0][:5])
     with pytest.raises(pmx.PmxError):
         al.score_reads(rs, True, False)
+    # the drop-in with the reference's own signature (src/mm_align.h:13-17): same numbers from host strings, and an odd
+    # paired set maps its last read alone (src/mm_align.c:178-185) -- against the compiled reference itself
+    from oracle import oracle as orc
+    for name in ("synthetic_paired", "real_single"):
+        reads, paired = cases[name]
+        nd = next(iter(gold[name]))
+        assert pmx.score_reads_vs_reference(pm.genome(nd), reads, paired) == gold[name][nd], name
+    reads, _ = cases["synthetic_paired"]
+    odd = reads[:301]
+    g = pm.genome("node_7618")
+    assert pmx.score_reads_vs_reference(g, odd, True) == orc.ref_score_reads(g, odd, True)
 
 
 @pytest.mark.gpu
