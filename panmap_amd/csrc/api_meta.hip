@@ -28,7 +28,7 @@
 //     chunk order).  HBM-bound: 2 B per (read, candidate) per pass, six passes per SQUAREM iteration.
 // Read-side seedmer extraction is host C++ here (threads; the k-min-mer definitions of host/seed_host.hpp); moving it into
 // the seeding kernel is the next step.  parity: the reference's own MGSR index and EM cannot be built here (panman / TBB /
-// Eigen / abseil are absent): scores and EM are checked against oracle/oracle_meta.py (a direct restatement: per-node seed
+// Eigen / abseil are absent): scores and EM are checked by the test suite against a direct restatement (per-node seed
 // sets by walking the tree, numpy EM), the end result against the reference's e2e expectation on rsv_4K (70 / 30 mixture
 // recovered within its ranges, src/test/e2e/run_e2e.sh:182-204).
 #include <hip/hip_runtime.h>
