@@ -46,6 +46,38 @@ def node_seed_counts(arrays, node, read_hashes=None):
     return out
 
 
+def _rol(x, r):
+    r &= 63
+    return ((x << r) | (x >> (64 - r))) & 0xFFFFFFFFFFFFFFFF if r else x
+
+
+def seedmers(seq: bytes, k, s, l, open_syncmer=False, t=0):
+    """the seedmers of a sequence as the reference's query side lists them (src/mgsr.cpp:1855-1950): over every window of l
+    consecutive syncmers F = rol-xor of the hashes left to right, R right to left; a window with F != R gives
+    (min(F, R), R < F).  The syncmers come from the oracle's rollingSyncmers restatement (oracle/oracle_place.c, pinned by the
+    compiled reference's known answers) -- nothing of the product is involved."""
+    from . import oracle as orc
+    assert l >= 2
+    sy = [h for h, _, is_s, _ in orc.rolling_syncmers(seq, k, s, open_syncmer, t, return_all=True) if is_s]
+    out = []
+    for i in range(len(sy) - l + 1):
+        f = r = 0
+        for q in range(l):
+            f = _rol(f, k) ^ sy[i + q]
+            r = _rol(r, k) ^ sy[i + l - 1 - q]
+        if f != r:
+            out.append((min(f, r), r < f))
+    return out
+
+
+def genome_seed_counts(genome: bytes, k, s, l, open_syncmer=False, t=0):
+    """{hash: [forward, reverse]} occurrence counts of a genome's seedmers, from the genome string alone"""
+    out = {}
+    for h, rev in seedmers(genome, k, s, l, open_syncmer, t):
+        out.setdefault(h, [0, 0])[1 if rev else 0] += 1
+    return out
+
+
 def read_scores(counts, read_off, seed_hash, seed_rev):
     """scores of every read at one node given node_seed_counts(..., read_hashes)"""
     n = len(read_off) - 1
