@@ -1,0 +1,347 @@
+// ALIGN stage, grouped DP service for gfx950: the ksw_extd2 requests of the thread-per-pair tier (short reads: extensions and
+// gap fills of a few dozen to 128 bases), EIGHT LANES PER REQUEST, eight requests per wave.
+//
+// The wave-per-request service (k_align_dp_serve) walks the anti-diagonals of one matrix with one wave: a diagonal of a
+// 100 x 100 extension has 10-50 cells, so most lanes idle, and every diagonal pays the wave-wide maximum and the boundary
+// reads (round-2 counters: 250-535 wave instructions per diagonal, 32 GCUPS).  Here a lane owns SW consecutive target
+// columns (SW = 4, 8, 12, 16 by target length) with their state in REGISTERS and walks the query rows one after the other;
+// lane k of a group starts row i one step after lane k-1 finished it (a systolic pipeline: the only exchange is the row's
+// right edge -- x, v, x2 and H of the lane's last column -- handed to the next lane through one DPP row_shr:1 per value).
+// Every lane of the wave is busy except during the 7-step skew.
+//
+// Exactness.  The cell function is ksw2_extd2_sse.c:168-321 applied to the same neighbours; what differs is the ORDER the
+// cells are visited in (row by row instead of diagonal by diagonal), which cannot change a cell's value as long as the band
+// never cuts the matrix: the service takes a request only if w >= max(qlen, tlen) - 1 (then st/en are the matrix edges on
+// every diagonal, and the 16-aligned rounding of the SSE loops only ever touches cells outside the matrix that no cell
+// inside depends on).  Everything the reference derives diagonal by diagonal IN ORDER -- the exact maximum with the SSE
+// loop's candidate order, mqe / mte, the Z-drop test and its early exit (:323-366) -- is replayed after the fill from three
+// small LDS arrays: the per-diagonal maximum (value and candidate rank in one word, collected with LDS atomics), H along the
+// last column and H along the last row.  Cells past a Z-drop are computed and ignored (the reference stops; the traceback
+// starts at or before the drop, so their bytes are never read).  The int8 lanes of the reference never wrap for the scoring
+// parameters the host admits (checked there), so the arithmetic is plain 32-bit.
+#include <hip/hip_runtime.h>
+
+#include "align_kernel.h"
+#include "align_kernel_dpg.h"
+
+namespace pmx {
+namespace aln {
+
+#define PMX_DPG_BIAS (1 << 20)
+
+__global__ void __launch_bounds__(256) k_dpg_collect(DpgArgs D) {
+    __shared__ uint32_t h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t n = D.n_slots * PMX_DP_REQ_PER_PASS;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t slot = D.worklist ? (int64_t)D.worklist[idx % D.n_slots] : idx % D.n_slots;
+        const uint32_t ent = (uint32_t)(slot * PMX_DP_REQ_PER_PASS + idx / D.n_slots);
+        const DpReq* rq = reinterpret_cast<const DpReq*>(D.dp_req_base + (size_t)ent * sizeof(DpReq));
+        uint32_t key = (uint32_t)PMX_DPG_NO_BUCKET << 8 | 0xffu;
+        if (rq->call != 0xffffffffu) {
+            const int qlen = rq->qlen, tlen = rq->tlen, w = rq->w, flag = rq->flag;
+            const int longer = qlen > tlen ? qlen : tlen;
+            const int kind = flag == PMX_EZ_APPROX_MAX ? 0 : flag == PMX_EZ_EXTZ_ONLY ? 1 : flag == (PMX_EZ_EXTZ_ONLY | PMX_EZ_RIGHT | PMX_EZ_REV_CIGAR) ? 2 : -1;
+            if (kind >= 0 && qlen >= 1 && tlen >= 1 && longer <= PMX_DPG_MAXLEN && (w < 0 || w >= longer - 1)) {
+                const int cls = (tlen - 1) / (4 * PMX_DPG_G);   // 0..3
+                const uint32_t bucket = (uint32_t)(cls * PMX_DPG_KINDS + kind);
+                key = bucket << 8 | (uint32_t)(PMX_DPG_MAXLEN - qlen);
+                atomicAdd(&h[bucket], 1u);
+            }
+        }
+        D.keys[idx] = key;
+        D.ids[idx] = ent;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(&D.counts[threadIdx.x], h[threadIdx.x]);
+}
+
+__device__ __forceinline__ int dpg_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); }   // row_shr:1
+
+// (not inlined: twelve instantiations in one kernel body let the compiler hoist every variant's lane-invariant values out of
+//  the task loop, ~1,000 spilled registers; as functions each variant has its own allocation)
+template <int SW, int KIND>
+__device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint32_t* ids, int n_here, uint8_t* lds, uint8_t* tb_wave) {
+    constexpr int ROW = PMX_DPG_G * SW;   // bytes of one traceback row
+    constexpr bool exact = KIND != 0, RIGHT = KIND == 2;
+    const int lane = (int)(threadIdx.x & 63u), k = lane & (PMX_DPG_G - 1), g = lane / PMX_DPG_G;
+    uint8_t* blk = lds + (size_t)g * PMX_DPG_LDS_PER_REQ;
+    uint8_t* qs = blk;
+    uint32_t* diag = reinterpret_cast<uint32_t*>(blk + PMX_DPG_MAXLEN);
+    int32_t* lastcol = reinterpret_cast<int32_t*>(diag + 2 * PMX_DPG_MAXLEN);
+    int32_t* lastrow = lastcol + PMX_DPG_MAXLEN;
+    uint32_t* cig = reinterpret_cast<uint32_t*>(lastrow + PMX_DPG_MAXLEN);
+    int32_t* dummy = reinterpret_cast<int32_t*>(cig + 24) + k * 16;   // where the rows that are not the last one put their H values
+    uint8_t* tb = tb_wave + (size_t)g * PMX_DPG_TB_PER_REQ;
+
+    bool valid = g < n_here;
+    DpReq* rq = nullptr;
+    uint32_t ent = 0;
+    int qlen = 0, tlen = 0;
+    if (valid) {
+        ent = ids[g];
+        if (ent < D.n_entries) {
+            rq = reinterpret_cast<DpReq*>(D.dp_req_base + (size_t)ent * sizeof(DpReq));
+            qlen = rq->qlen;
+            tlen = rq->tlen;
+        }
+        // (what k_dpg_collect admitted; anything else would index past the per-request arrays: counted, left to the wave service)
+        if (ent >= D.n_entries || qlen < 1 || tlen < 1 || qlen > PMX_DPG_MAXLEN || tlen > PMX_DPG_G * SW) {
+            if (k == 0) atomicAdd(&D.counts[PMX_DPG_NO_BUCKET], 1u);
+            valid = false;
+            qlen = tlen = 0;
+        }
+    }
+    const int t0 = k * SW;
+    const int q = D.q, qe = D.q + D.e, q2 = D.q2, qe2 = D.q2 + D.e2;
+    const int init_ue = -qe, init_ue2 = -qe2;
+    const int sc_mch = D.sc_mch, sc_mis = D.sc_mis, sc_N = D.sc_N;
+    auto gap_head = [&](int r) { return r == 0 ? init_ue : r < D.long_thres ? -D.e : r == D.long_thres ? D.long_diff : -D.e2; };
+
+    // the query to LDS (one byte per row and lane later), the lane's target bases to registers
+    int u[SW], y[SW], y2[SW];
+    uint32_t sfw[SW / 4];   // four bases per register (the compares select the byte)
+#pragma unroll
+    for (int c4 = 0; c4 < SW / 4; ++c4) sfw[c4] = 0;
+    if (valid) {
+        *reinterpret_cast<uint4*>(qs + k * 16) = *reinterpret_cast<const uint4*>(rq->seq + k * 16);
+        const int t_off = (qlen + 15) & ~15;
+#pragma unroll
+        for (int c4 = 0; c4 < SW / 4; ++c4) sfw[c4] = *reinterpret_cast<const uint32_t*>(rq->seq + t_off + t0 + 4 * c4);
+    }
+#pragma unroll
+    for (int c = 0; c < SW; ++c) {   // first row: the boundary values of ksw2_extd2_sse.c:160-166
+        u[c] = gap_head(t0 + c);
+        y[c] = init_ue;
+        y2[c] = init_ue2;
+    }
+    if (exact)
+        for (int j = k; j < 2 * PMX_DPG_MAXLEN; j += PMX_DPG_G) diag[j] = 0;
+    int n_steps = valid ? qlen + PMX_DPG_G - 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(n_steps, o); n_steps = other > n_steps ? other : n_steps; }
+    __syncthreads();
+
+    int xo = 0, vo = 0, x2o = 0, Ho = 0;   // the right edge of the row this lane finished last
+    int H0 = -qe;                          // H of column 0 (first lane of the group): H[0] = v[0] - qe on the first row, += v after (:326-340)
+    const bool owns_last = valid && (tlen - 1) / SW == k;
+    for (int tau = 0; tau < n_steps; ++tau) {
+        int xl = dpg_shr1(xo), vl = dpg_shr1(vo), x2l = dpg_shr1(x2o), Hl = dpg_shr1(Ho);
+        const int i = tau - k;
+        // (opaque copies: everything the cells derive from the lane's column range and the lengths is a one-instruction
+        //  value; hoisted out of the row loop as loop invariants -- two or three registers per column -- they spill)
+        int t0v = t0, tlv = tlen, qlv = qlen;
+        asm volatile("" : "+v"(t0v), "+v"(tlv), "+v"(qlv));
+#pragma unroll
+        for (int c4 = 0; c4 < SW / 4; ++c4) asm volatile("" : "+v"(sfw[c4]));
+        if (i >= 0 && i < qlv && t0v < tlv) {
+            const int qb = (int)qs[i];
+            if (k == 0) { xl = init_ue; x2l = init_ue2; vl = gap_head(i); Hl = 0; }
+            const int rem_q = qlv - 1 - i;
+            int hcol = 0, tcur = t0v;
+            uint32_t* drow = diag + i + t0v;   // the diagonals of this row's cells
+            int32_t* lr = i == qlv - 1 ? lastrow + t0v : dummy;
+            uint32_t tbw[SW / 4];
+#pragma unroll
+            for (int c4 = 0; c4 < SW / 4; ++c4) tbw[c4] = 0;
+#pragma unroll
+            for (int c = 0; c < SW; ++c) {
+                const int t = tcur;
+                const int sq = (int)(sfw[c >> 2] >> (8 * (c & 3)) & 0xffu);
+                int z = sq == qb ? sc_mch : sc_mis;
+                if (sq == 4 || qb == 4) z = sc_N;
+                const int ut = u[c];
+                int a = xl + vl, b = y[c] + ut, a2 = x2l + vl, b2 = y2[c] + ut;
+                uint32_t d;
+                if (!RIGHT) {
+                    d = a > z ? 1u : 0u;
+                    z = z > a ? z : a;
+                    d = b > z ? 2u : d;
+                    z = z > b ? z : b;
+                    d = a2 > z ? 3u : d;
+                    z = z > a2 ? z : a2;
+                    d = b2 > z ? 4u : d;
+                    z = z > b2 ? z : b2;
+                } else {
+                    d = z > a ? 0u : 1u;
+                    z = z > a ? z : a;
+                    d = z > b ? d : 2u;
+                    z = z > b ? z : b;
+                    d = z > a2 ? d : 3u;
+                    z = z > a2 ? z : a2;
+                    d = z > b2 ? d : 4u;
+                    z = z > b2 ? z : b2;
+                }
+                z = z < sc_mch ? z : sc_mch;
+                const int un = z - vl, vn = z - ut;
+                int tmp = z - q;
+                a -= tmp;
+                b -= tmp;
+                tmp = z - q2;
+                a2 -= tmp;
+                b2 -= tmp;
+                int xn, yn, x2n, y2n;
+                if (!RIGHT) {
+                    xn = (a > 0 ? a : 0) - qe;   d |= a > 0 ? 0x08u : 0u;
+                    yn = (b > 0 ? b : 0) - qe;   d |= b > 0 ? 0x10u : 0u;
+                    x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 > 0 ? 0x20u : 0u;
+                    y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 > 0 ? 0x40u : 0u;
+                } else {
+                    xn = (0 > a ? 0 : a) - qe;   d |= 0 > a ? 0u : 0x08u;
+                    yn = (0 > b ? 0 : b) - qe;   d |= 0 > b ? 0u : 0x10u;
+                    x2n = (0 > a2 ? 0 : a2) - qe2; d |= 0 > a2 ? 0u : 0x20u;
+                    y2n = (0 > b2 ? 0 : b2) - qe2; d |= 0 > b2 ? 0u : 0x40u;
+                }
+                // H of the cell.  The reference adds v along the query (H[t] += v, :326-340); H(t-1, q) + u is the same number
+                // (both are H(t-1, q-1) + z: u = z - v(t-1, q), v = z - u(t, q-1)), and that one is already in a register:
+                // the left neighbour's H travels along the row with x and v.  Column 0 has no left neighbour: += v there.
+                const int Hn = c == 0 ? (k == 0 ? H0 + vn : Hl + un) : Hl + un;
+                if (c == 0) H0 = Hn;
+                hcol = t == tlv - 1 ? Hn : hcol;
+                u[c] = un; y[c] = yn; y2[c] = y2n;
+                xl = xn; vl = vn; x2l = x2n; Hl = Hn;
+                ++tcur;
+                if (exact) lr[c] = Hn;
+                tbw[c >> 2] |= d << (8 * (c & 3));
+                if (exact) {
+                    // the cell as a candidate of its diagonal's maximum: value, then the SSE loop's candidate order (en0 first,
+                    // the vector part [st0, en1) class by class, the scalar tail [en1, en0) last), as one comparable word
+                    const int dt = t < rem_q ? t : rem_q;                    // t - st0
+                    const int dn = tlv - 1 - t < i ? tlv - 1 - t : i;      // en0 - t
+                    const int n3 = (dt + dn) & 3;
+                    const uint32_t kv = 1u + ((uint32_t)(dt & 3) << 7 | (uint32_t)(dt >> 2));
+                    const uint32_t kt = 513u + (uint32_t)dt;
+                    const uint32_t kp = (dn <= n3 ? kt : kv) & (uint32_t)-(int)(dn != 0);   // (no branch: en0 itself ranks first)
+                    uint32_t key = (uint32_t)(Hn + PMX_DPG_BIAS) << 10 | (1023u - kp);
+                    atomicMax(&drow[c], t < tlv ? key : 0u);   // (always: a branch per cell would cut the row into SW blocks)
+                }
+                // (the cells of a row form one dependency chain.  Left alone the compiler runs the chain of several cells first and
+                //  the rest of each -- traceback flags, candidate ranks -- afterwards, and the intermediates of all of them spill
+                //  (measured: a quarter of the loop's instructions were scratch traffic); a scheduling barrier does not help, the
+                //  order is already fixed when the instructions are selected.  Passing every value a cell hands on through one
+                //  empty asm statement makes the cell complete before the next one starts)
+                asm volatile("" : "+v"(xl), "+v"(vl), "+v"(x2l), "+v"(Hl), "+v"(tbw[c >> 2]), "+v"(u[c]), "+v"(y[c]), "+v"(y2[c]), "+v"(tcur), "+v"(hcol));
+            }
+            xo = xl; vo = vl; x2o = x2l; Ho = Hl;
+            uint8_t* trow = tb + (size_t)i * ROW + t0v;
+            if constexpr (SW == 16) *reinterpret_cast<uint4*>(trow) = make_uint4(tbw[0], tbw[1], tbw[2], tbw[3]);
+            else
+#pragma unroll
+                for (int c4 = 0; c4 < SW / 4; ++c4) reinterpret_cast<uint32_t*>(trow)[c4] = tbw[c4];
+            if (owns_last) lastcol[i] = hcol;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // replay of the per-diagonal bookkeeping, traceback and hand-over: the first lane of every group
+    if (valid && k == 0) {
+        Ez ez;
+        ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
+        ez.max = 0;
+        ez.score = ez.mqe = ez.mte = PMX_KSW_NEG_INF;
+        ez.n_cigar = 0;
+        ez.zdropped = 0;
+        ez.reach_end = 0;
+        const int flag = rq->flag, zdrop = rq->zdrop, end_bonus = rq->end_bonus;
+        if (exact) {
+            for (int r = 0; r < qlen + tlen - 1; ++r) {
+                const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = tlen - 1 < r ? tlen - 1 : r;
+                const uint32_t key = diag[r];
+                const int32_t max_H = (int32_t)(key >> 10) - PMX_DPG_BIAS;
+                const uint32_t kp = 1023u - (key & 1023u);
+                int max_t;
+                if (kp == 0) max_t = en0;
+                else if (kp <= 512u) { const uint32_t v = kp - 1u; max_t = st0 + (int)((v & 127u) << 2 | v >> 7); }
+                else max_t = st0 + (int)(kp - 513u);
+                if (en0 == tlen - 1) { const int32_t h = lastcol[r - en0]; if (h > ez.mte) { ez.mte = h; ez.mte_q = r - en0; } }
+                if (r - st0 == qlen - 1) { const int32_t h = lastrow[st0]; if (h > ez.mqe) { ez.mqe = h; ez.mqe_t = st0; } }
+                if (ez_apply_zdrop(ez, max_H, r, max_t, zdrop, (int8_t)D.e2)) break;
+                if (r == qlen + tlen - 2) ez.score = lastcol[qlen - 1];
+            }
+        } else ez.score = lastcol[qlen - 1];   // the approximate maximum follows one path to the corner: H there (:367-383)
+        // ksw_backtrack (ksw2.h:127-162): no cell of the walk lies outside the band here
+        int bi = -1, bj = -1;
+        if (!ez.zdropped && !(flag & PMX_EZ_EXTZ_ONLY)) { bi = tlen - 1; bj = qlen - 1; }
+        else if (!ez.zdropped && (flag & PMX_EZ_EXTZ_ONLY) && ez.mqe + end_bonus > (int)ez.max) { ez.reach_end = 1; bi = ez.mqe_t; bj = qlen - 1; }
+        else if (ez.max_t >= 0 && ez.max_q >= 0) { bi = ez.max_t; bj = ez.max_q; }
+        bool bad = false;
+        int n_cigar = 0;
+        if (bi >= 0 && bj >= 0) {
+            auto push = [&](uint32_t op, int len) {
+                if (n_cigar == 0 || op != (cig[n_cigar - 1] & 0xfu)) {
+                    if (n_cigar < PMX_DP_MAX_CIGAR) cig[n_cigar++] = (uint32_t)len << 4 | op;
+                    else bad = true;
+                } else cig[n_cigar - 1] += (uint32_t)len << 4;
+            };
+            int i = bi, j = bj, state = 0;
+            while (i >= 0 && j >= 0 && !bad) {
+                const uint32_t tmp = tb[(size_t)j * ROW + i];
+                if (state == 0) state = (int)(tmp & 7u);
+                else if (!(tmp >> (state + 2) & 1u)) state = 0;
+                if (state == 0) state = (int)(tmp & 7u);
+                if (state == 0) { push(0, 1); --i; --j; }
+                else if (state == 1 || state == 3) { push(2, 1); --i; }
+                else { push(1, 1); --j; }
+            }
+            if (i >= 0) push(2, i + 1);
+            if (j >= 0) push(1, j + 1);
+            if (!(flag & PMX_EZ_REV_CIGAR))
+                for (int a = 0; a < n_cigar >> 1; ++a) { const uint32_t t_ = cig[a]; cig[a] = cig[n_cigar - 1 - a]; cig[n_cigar - 1 - a] = t_; }
+        }
+        ez.n_cigar = n_cigar;
+        const uint32_t call = rq->call;
+        if (call < PMX_DP_MAX_CALLS) {
+            DpRes& R = D.dp_res_base[(size_t)(ent / PMX_DP_REQ_PER_PASS) * PMX_DP_MAX_CALLS + call];
+            R.ez = ez;
+            R.key = bad ? 0xffffffffu : rq->key;
+            if (!bad) for (int a = 0; a < n_cigar; ++a) R.cigar[a] = cig[a];
+        }
+        if (D.stats) {
+            atomicAdd(&D.stats[0], 1ULL);
+            atomicAdd(&D.stats[1], (unsigned long long)dp_cells(qlen, tlen, rq->w));
+        }
+        if (!D.shadow) rq->call = 0xffffffffu;   // served
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_align_dp_group(DpgArgs D) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dpg_lds[];
+    uint8_t* tb_wave = D.tb + (size_t)blockIdx.x * PMX_DPG_TB_BYTES;
+    // buckets: requests of one (columns per lane, kind) class sit together in the sorted list; a wave takes eight of ONE bucket
+    constexpr uint32_t per_wave = 64 / PMX_DPG_G;
+    uint32_t n_tasks = 0;
+    for (int b = 0; b < PMX_DPG_BUCKETS; ++b) n_tasks += (D.counts[b] + per_wave - 1) / per_wave;
+    for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        uint32_t fb = 0, wb = 0, nb = 0;
+        int b = 0;
+        for (;; ++b) {   // (ends: task < n_tasks)
+            nb = D.counts[b];
+            const uint32_t wn = (nb + per_wave - 1) / per_wave;
+            if (task < wb + wn) break;
+            wb += wn;
+            fb += nb;
+        }
+        const uint32_t at = (task - wb) * per_wave;
+        const int n_here = (int)(nb - at < per_wave ? nb - at : per_wave);
+        const uint32_t* ids = D.sorted_ids + fb + at;
+        switch (b) {
+            case 0: dpg_serve<4, 0>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 1: dpg_serve<4, 1>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 2: dpg_serve<4, 2>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 3: dpg_serve<8, 0>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 4: dpg_serve<8, 1>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 5: dpg_serve<8, 2>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 6: dpg_serve<12, 0>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 7: dpg_serve<12, 1>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 8: dpg_serve<12, 2>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 9: dpg_serve<16, 0>(D, ids, n_here, dpg_lds, tb_wave); break;
+            case 10: dpg_serve<16, 1>(D, ids, n_here, dpg_lds, tb_wave); break;
+            default: dpg_serve<16, 2>(D, ids, n_here, dpg_lds, tb_wave); break;
+        }
+    }
+}
+
+}  // namespace aln
+}  // namespace pmx

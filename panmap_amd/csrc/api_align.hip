@@ -8,10 +8,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <tuple>
 
 #include "align/aln_compact_defs.hpp"
 #include "align_kernel.h"
+#include "align_kernel_dpg.h"
 #include "device/dev_util.hpp"
 #include "readset.hpp"
 #include "ref_index_device.h"
@@ -49,6 +52,10 @@ struct pmx_aligner {
     DevBuf<uint8_t> dp_req;
     DevBuf<DpRes> dp_res;
     DevBuf<uint32_t> dp_ncached, dp_slot_pairs, dp_list_a, dp_list_b;
+    DevBuf<uint32_t> dpg_keys, dpg_keys2, dpg_ids, dpg_ids2, dpg_counts;   // grouped DP service (align_kernel_dpg.hip)
+    DevBuf<char> dpg_tmp;
+    DevBuf<uint8_t> dpg_tb;
+    DevBuf<DpRes> dpg_shadow;
     int64_t last_dp_requests = 0;
     int last_dp_rounds = 0;
     DevBuf<uint32_t> retry_list;
@@ -408,6 +415,28 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             const int64_t dps_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dps_lds);
             const size_t dps_stride = (dps_layout.slow_bytes + 255) & ~(size_t)255;
             const bool dp_two_class = !getenv("PMX_ALIGN_DP_ONE_CLASS");
+            // grouped service: plain 32-bit arithmetic stands for the reference's int8 lanes, so the scoring parameters must keep
+            // every intermediate far from the int8 range (any preset does; otherwise the wave service takes everything)
+            DpgArgs DG;
+            memset(&DG, 0, sizeof(DG));
+            bool dpg_ok = !getenv("PMX_ALIGN_NO_DP_GROUP");
+            int dpg_waves = 8;
+            if (const char* e = getenv("PMX_ALIGN_DPG_WAVES")) dpg_waves = std::max(1, atoi(e));
+            {
+                const Opt& o = al->opt;
+                int q = o.q, e = o.e, q2 = o.q2, e2 = o.e2;
+                if (q2 + e2 < q + e) { std::swap(q, q2); std::swap(e, e2); }
+                int min_sc = o.mat[1], max_abs = 0;
+                for (int t = 0; t < 25; ++t) { if (t >= 1) min_sc = std::min<int>(min_sc, o.mat[t]); max_abs = std::max(max_abs, std::abs((int)o.mat[t])); }
+                if (-min_sc > 2 * (q + e)) dpg_ok = false;   // (ksw2_extd2_sse.c:100: the reference returns without aligning)
+                if (2 * (q2 + e2) + 2 * max_abs > 100 || q < 0 || e < 0 || q2 < 0 || e2 < 0) dpg_ok = false;
+                DG.q = q; DG.e = e; DG.q2 = q2; DG.e2 = e2;
+                DG.sc_mch = o.mat[0]; DG.sc_mis = o.mat[1]; DG.sc_N = o.mat[24] == 0 ? -e2 : o.mat[24];
+                int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
+                if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
+                DG.long_thres = long_thres;
+                DG.long_diff = long_thres * (e - e2) - (q2 - q) - e2;
+            }
             if (use_dp_service) {
                 al->dp_req.ensure((size_t)n_items * PMX_DP_REQ_PER_PASS * sizeof(DpReq));
                 al->dp_res.ensure((size_t)n_items * PMX_DP_MAX_CALLS);
@@ -540,6 +569,71 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     break;
                 }
                 al->last_dp_requests += n_dp;
+                if (getenv("PMX_DP_HIST")) {   // diagnostic: the shapes of the posted requests
+                    std::vector<DpReq> h((size_t)n_dp * PMX_DP_REQ_PER_PASS);
+                    PMX_HIP(hipMemcpyAsync(h.data(), A.dp_req_base, h.size() * sizeof(DpReq), hipMemcpyDeviceToHost, ctx->stream));
+                    PMX_HIP(hipStreamSynchronize(ctx->stream));
+                    std::map<std::tuple<int, int, int, int>, std::pair<long, long>> hist;   // (flag, q bucket, t bucket, band-free) -> (n, cells)
+                    long n_req = 0;
+                    for (const DpReq& r : h) {
+                        if (r.call == 0xffffffffu) continue;
+                        ++n_req;
+                        const int w = r.w < 0 ? std::max(r.qlen, r.tlen) : r.w;
+                        const int free_band = w >= std::max(r.qlen, r.tlen) - 1;
+                        auto& e = hist[std::make_tuple(r.flag, (r.qlen + 15) / 16 * 16, (r.tlen + 31) / 32 * 32, free_band)];
+                        ++e.first;
+                        e.second += (long)r.qlen * r.tlen;
+                    }
+                    fprintf(stderr, "[pmx dp requests, round %d] %ld\n  flag  qlen<= tlen<= bandfree        n      cells\n", round, n_req);
+                    for (auto& kv : hist)
+                        fprintf(stderr, "  0x%02x %6d %6d %8d %8ld %10ld\n", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), kv.second.first, kv.second.second);
+                }
+                if (dpg_ok) {
+                    // the grouped service first (eight lanes per request: align_kernel_dpg.hip): it takes every request whose band
+                    // never cuts its matrix and whose sides are <= 128 bases -- on 150 bp reads all of them -- and marks them served;
+                    // the wave-per-request launches below see what is left
+                    const int64_t n_ent = n_dp * PMX_DP_REQ_PER_PASS;
+                    al->dpg_keys.ensure((size_t)n_ent); al->dpg_keys2.ensure((size_t)n_ent); al->dpg_ids.ensure((size_t)n_ent); al->dpg_ids2.ensure((size_t)n_ent);
+                    al->dpg_counts.ensure(16);
+                    const int64_t dpg_grid = std::min<int64_t>((int64_t)ctx->n_cu * dpg_waves, (n_ent + 7) / 8 + PMX_DPG_BUCKETS);
+                    al->dpg_tb.ensure((size_t)ctx->n_cu * dpg_waves * PMX_DPG_TB_BYTES);
+                    DG.dp_req_base = al->dp_req.p; DG.dp_res_base = al->dp_res.p; DG.worklist = cur; DG.n_slots = n_dp;
+                    DG.keys = al->dpg_keys.p; DG.ids = al->dpg_ids.p; DG.sorted_ids = al->dpg_ids2.p; DG.counts = al->dpg_counts.p;
+                    DG.tb = al->dpg_tb.p; DG.stats = A.stats;
+                    DG.n_entries = (uint32_t)std::min<size_t>(al->dp_req.n / sizeof(DpReq), UINT32_MAX);
+                    if (!DG.dp_req_base || !DG.dp_res_base || !DG.keys || !DG.ids || !DG.sorted_ids || !DG.counts || !DG.tb) return fail(PMX_ERR_DEVICE, "grouped DP service: a buffer is missing");
+                    const bool dpg_shadow = getenv("PMX_DPG_SHADOW") != nullptr;   // diagnostic: both services run, results compared
+                    if (dpg_shadow) {
+                        al->dpg_shadow.ensure((size_t)n_items * PMX_DP_MAX_CALLS);
+                        PMX_HIP(hipMemsetAsync(al->dpg_shadow.p, 0xee, sizeof(DpRes) * (size_t)n_items * PMX_DP_MAX_CALLS, ctx->stream));
+                        DG.dp_res_base = al->dpg_shadow.p; DG.stats = nullptr; DG.shadow = 1;
+                    }
+                    PMX_HIP(hipMemsetAsync(al->dpg_counts.p, 0, 16 * sizeof(uint32_t), ctx->stream));
+                    hipLaunchKernelGGL(k_dpg_collect, dim3((unsigned)std::min<int64_t>((n_ent + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, DG);
+                    size_t bytes = 0;
+                    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, al->dpg_keys.p, al->dpg_keys2.p, al->dpg_ids.p, al->dpg_ids2.p, (size_t)n_ent, 0, 12, ctx->stream));
+                    al->dpg_tmp.ensure(bytes);
+                    PMX_HIP(rocprim::radix_sort_pairs(al->dpg_tmp.p, bytes, al->dpg_keys.p, al->dpg_keys2.p, al->dpg_ids.p, al->dpg_ids2.p, (size_t)n_ent, 0, 12, ctx->stream));
+                    if (getenv("PMX_DPG_CHECK_LIST")) {   // diagnostic: the sorted request list against the bucket counts
+                        std::vector<uint32_t> k2((size_t)n_ent), i2((size_t)n_ent), cn(16);
+                        PMX_HIP(hipStreamSynchronize(ctx->stream));
+                        PMX_HIP(hipMemcpy(k2.data(), al->dpg_keys2.p, (size_t)n_ent * 4, hipMemcpyDeviceToHost));
+                        PMX_HIP(hipMemcpy(i2.data(), al->dpg_ids2.p, (size_t)n_ent * 4, hipMemcpyDeviceToHost));
+                        PMX_HIP(hipMemcpy(cn.data(), al->dpg_counts.p, 64, hipMemcpyDeviceToHost));
+                        long unsorted = 0, bad_id = 0, cnt[16] = {0};
+                        for (int64_t i = 0; i < n_ent; ++i) {
+                            if (i && k2[(size_t)i] < k2[(size_t)i - 1]) ++unsorted;
+                            if (i2[(size_t)i] >= DG.n_entries) ++bad_id;
+                            ++cnt[(k2[(size_t)i] >> 8) & 15];
+                        }
+                        fprintf(stderr, "[dpg list] %lld entries, %ld out of order, %ld ids out of range; buckets (device/host):", (long long)n_ent, unsorted, bad_id);
+                        for (int b = 0; b < 16; ++b) fprintf(stderr, " %u/%ld", cn[(size_t)b], cnt[b]);
+                        fprintf(stderr, "\n");
+                    }
+                    if (!getenv("PMX_DPG_NO_SERVE"))
+                    hipLaunchKernelGGL(k_align_dp_group, dim3((unsigned)dpg_grid), dim3(64), PMX_DPG_LDS_BYTES, ctx->stream, DG);
+                    PMX_HIP(hipGetLastError());
+                }
                 A.layout = dp_layout;
                 A.slow_stride = dp_stride;
                 A.slow_base = al->slow.p;
@@ -558,6 +652,49 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dps_max_grid, n_dp * PMX_DP_REQ_PER_PASS)), dim3(64), dps_lds, ctx->stream, A);
                 }
                 PMX_HIP(hipGetLastError());
+                if (dpg_ok && getenv("PMX_DPG_SHADOW")) {
+                    const size_t n_ent = (size_t)n_dp * PMX_DP_REQ_PER_PASS, n_res = (size_t)n_items * PMX_DP_MAX_CALLS;
+                    std::vector<uint32_t> keys(n_ent), ids(n_ent);
+                    std::vector<DpRes> a(n_res), b(n_res);
+                    std::vector<DpReq> rq((size_t)n_items * PMX_DP_REQ_PER_PASS);
+                    PMX_HIP(hipStreamSynchronize(ctx->stream));
+                    PMX_HIP(hipMemcpy(keys.data(), al->dpg_keys.p, n_ent * 4, hipMemcpyDeviceToHost));
+                    PMX_HIP(hipMemcpy(ids.data(), al->dpg_ids.p, n_ent * 4, hipMemcpyDeviceToHost));
+                    PMX_HIP(hipMemcpy(a.data(), al->dp_res.p, n_res * sizeof(DpRes), hipMemcpyDeviceToHost));
+                    PMX_HIP(hipMemcpy(b.data(), al->dpg_shadow.p, n_res * sizeof(DpRes), hipMemcpyDeviceToHost));
+                    // (the requests were marked served by the wave service: their headers are intact apart from `call`, which the
+                    //  collect pass read before; the call index is recovered from the result that carries the request's key)
+                    long n_cmp = 0, n_bad = 0, shown = 0;
+                    for (size_t i = 0; i < n_ent; ++i) {
+                        if ((keys[i] >> 8) >= PMX_DPG_NO_BUCKET) continue;
+                        const size_t slot = ids[i] / PMX_DP_REQ_PER_PASS;
+                        for (int c = 0; c < PMX_DP_MAX_CALLS; ++c) {
+                            const DpRes& y = b[slot * PMX_DP_MAX_CALLS + c];
+                            if (y.key == 0xeeeeeeeeu) continue;   // not written by the grouped service
+                            const DpRes& x = a[slot * PMX_DP_MAX_CALLS + c];
+                            ++n_cmp;
+                            bool same = x.key == y.key;
+                            if (same && x.key != 0xffffffffu) {
+                                same = memcmp(&x.ez, &y.ez, sizeof(Ez)) == 0;
+                                for (int k = 0; same && k < x.ez.n_cigar && k < PMX_DP_MAX_CIGAR; ++k) same = x.cigar[k] == y.cigar[k];
+                            }
+                            if (!same) {
+                                ++n_bad;
+                                if (shown++ < 12) {
+                                    fprintf(stderr, "[dpg shadow] slot %zu call %d key %08x/%08x\n  wave : max %u zd %d maxq %d maxt %d mqe %d mqe_t %d mte %d mte_q %d score %d ncig %d reach %d\n  group: max %u zd %d maxq %d maxt %d mqe %d mqe_t %d mte %d mte_q %d score %d ncig %d reach %d\n",
+                                            slot, c, x.key, y.key, x.ez.max, x.ez.zdropped, x.ez.max_q, x.ez.max_t, x.ez.mqe, x.ez.mqe_t, x.ez.mte, x.ez.mte_q, x.ez.score, x.ez.n_cigar, x.ez.reach_end,
+                                            y.ez.max, y.ez.zdropped, y.ez.max_q, y.ez.max_t, y.ez.mqe, y.ez.mqe_t, y.ez.mte, y.ez.mte_q, y.ez.score, y.ez.n_cigar, y.ez.reach_end);
+                                    fprintf(stderr, "  wave cigar:");
+                                    for (int k = 0; k < x.ez.n_cigar && k < PMX_DP_MAX_CIGAR; ++k) fprintf(stderr, " %u%c", x.cigar[k] >> 4, "MID"[x.cigar[k] & 3]);
+                                    fprintf(stderr, "\n  group cigar:");
+                                    for (int k = 0; k < y.ez.n_cigar && k < PMX_DP_MAX_CIGAR; ++k) fprintf(stderr, " %u%c", y.cigar[k] >> 4, "MID"[y.cigar[k] & 3]);
+                                    fprintf(stderr, "\n");
+                                }
+                            }
+                        }
+                    }
+                    fprintf(stderr, "[dpg shadow] round %d: %ld results compared, %ld differ\n", round, n_cmp, n_bad);
+                }
                 uint32_t* next = lists[round & 1];
                 A.layout = tpp_layout;
                 launch_tpp(round, n_dp, cur, next);
