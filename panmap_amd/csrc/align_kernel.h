@@ -43,6 +43,7 @@ struct AlignArgs {
     int dp_class;               // k_align_dp_serve: 0 = every request, 1 = only small ones, 2 = only the others
     int dp_small_qlen, dp_small_tlen;   // register-DP class: qlen <=, tlen <=, traceback bytes <= dp_small_tb
     uint32_t dp_small_tb;
+    const uint32_t* dp_left;    // k_align_dp_serve: NULL, or two counters of the requests the grouped service left (both zero: nothing to do)
 
 
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_dpg_collect(DpgArgs D) {
                 const uint32_t bucket = (uint32_t)(cls * PMX_DPG_KINDS + kind);
                 key = bucket << 8 | (uint32_t)(PMX_DPG_MAXLEN - qlen);
                 atomicAdd(&h[bucket], 1u);
-            }
+            } else atomicAdd(&h[PMX_DPG_NO_BUCKET - 1], 1u);   // a request for the wave service
         }
         D.keys[idx] = key;
         D.ids[idx] = ent;
@@ -72,9 +72,9 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
     int32_t* lastcol = reinterpret_cast<int32_t*>(diag + 2 * PMX_DPG_MAXLEN);
     int32_t* lastrow = lastcol + PMX_DPG_MAXLEN;
     uint32_t* cig = reinterpret_cast<uint32_t*>(lastrow + PMX_DPG_MAXLEN);
-    int32_t* dummy = reinterpret_cast<int32_t*>(cig + 24) + k * 16;   // where the rows that are not the last one put their H values
     uint8_t* tb = tb_wave + (size_t)g * PMX_DPG_TB_PER_REQ;
 
+    const unsigned long long pt0 = D.prof ? (unsigned long long)clock64() : 0ULL;
     bool valid = g < n_here;
     DpReq* rq = nullptr;
     uint32_t ent = 0;
@@ -122,6 +122,7 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
     for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(n_steps, o); n_steps = other > n_steps ? other : n_steps; }
     __syncthreads();
 
+    const unsigned long long pt1 = D.prof ? (unsigned long long)clock64() : 0ULL;
     int xo = 0, vo = 0, x2o = 0, Ho = 0;   // the right edge of the row this lane finished last
     int H0 = -qe;                          // H of column 0 (first lane of the group): H[0] = v[0] - qe on the first row, += v after (:326-340)
     const bool owns_last = valid && (tlen - 1) / SW == k;
@@ -140,7 +141,7 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
             const int rem_q = qlv - 1 - i;
             int hcol = 0, tcur = t0v;
             uint32_t* drow = diag + i + t0v;   // the diagonals of this row's cells
-            int32_t* lr = i == qlv - 1 ? lastrow + t0v : dummy;
+            int32_t* lr = lastrow + t0v;   // every row leaves its H values here: what stays is the last row's
             uint32_t tbw[SW / 4];
 #pragma unroll
             for (int c4 = 0; c4 < SW / 4; ++c4) tbw[c4] = 0;
@@ -233,9 +234,14 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
     }
     __threadfence_block();
     __syncthreads();
+    const unsigned long long pt2 = D.prof ? (unsigned long long)clock64() : 0ULL;
+    unsigned long long pt3 = pt2;
 
-    // replay of the per-diagonal bookkeeping, traceback and hand-over: the first lane of every group
-    if (valid && k == 0) {
+    // Replay of the per-diagonal bookkeeping, traceback and hand-over.  All eight lanes of a group run it, in step and on the
+    // same values (they would idle otherwise): that way they can fetch the traceback matrix together -- a window of 16 rows x
+    // 32 columns at a time into LDS (the per-diagonal array is free by then), one HBM round trip per >= 16 steps of the walk
+    // instead of one per step (a 150-step walk was ~150 dependent loads: longer than the fill).  Only lane 0 writes.
+    if (valid) {
         Ez ez;
         ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
         ez.max = 0;
@@ -260,6 +266,7 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
                 if (r == qlen + tlen - 2) ez.score = lastcol[qlen - 1];
             }
         } else ez.score = lastcol[qlen - 1];   // the approximate maximum follows one path to the corner: H there (:367-383)
+        if (D.prof) pt3 = (unsigned long long)clock64();
         // ksw_backtrack (ksw2.h:127-162): no cell of the walk lies outside the band here
         int bi = -1, bj = -1;
         if (!ez.zdropped && !(flag & PMX_EZ_EXTZ_ONLY)) { bi = tlen - 1; bj = qlen - 1; }
@@ -268,15 +275,35 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
         bool bad = false;
         int n_cigar = 0;
         if (bi >= 0 && bj >= 0) {
-            auto push = [&](uint32_t op, int len) {
-                if (n_cigar == 0 || op != (cig[n_cigar - 1] & 0xfu)) {
-                    if (n_cigar < PMX_DP_MAX_CIGAR) cig[n_cigar++] = (uint32_t)len << 4 | op;
-                    else bad = true;
-                } else cig[n_cigar - 1] += (uint32_t)len << 4;
+            // (ksw_push_cigar with the open operation kept in registers)
+            int cur_op = -1, cur_len = 0;
+            auto flush = [&]() {
+                if (cur_op < 0) return;
+                if (n_cigar < PMX_DP_MAX_CIGAR) { if (k == 0) cig[n_cigar] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++n_cigar; }
+                else bad = true;
             };
+            auto push = [&](int op, int len) {
+                if (op == cur_op) cur_len += len;
+                else { flush(); cur_op = op; cur_len = len; }
+            };
+            uint8_t* win = reinterpret_cast<uint8_t*>(diag);   // [16][32]
+            int wi0 = 1 << 30, wj0 = 1 << 30;
             int i = bi, j = bj, state = 0;
             while (i >= 0 && j >= 0 && !bad) {
-                const uint32_t tmp = tb[(size_t)j * ROW + i];
+                if (i < wi0 || j < wj0) {   // (the walk only ever moves up and to the left)
+                    wi0 = (i & ~15) - 16 > 0 ? (i & ~15) - 16 : 0;
+                    wj0 = j - 15 > 0 ? j - 15 : 0;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int row = k + 8 * h;
+                        const uint4* src = reinterpret_cast<const uint4*>(tb + (size_t)(wj0 + row) * ROW + wi0);
+                        const uint4 v0 = src[0], v1 = src[1];
+                        *reinterpret_cast<uint4*>(win + row * 32) = v0;
+                        *reinterpret_cast<uint4*>(win + row * 32 + 16) = v1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                }
+                const uint32_t tmp = win[(j - wj0) * 32 + (i - wi0)];
                 if (state == 0) state = (int)(tmp & 7u);
                 else if (!(tmp >> (state + 2) & 1u)) state = 0;
                 if (state == 0) state = (int)(tmp & 7u);
@@ -286,24 +313,32 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
             }
             if (i >= 0) push(2, i + 1);
             if (j >= 0) push(1, j + 1);
-            if (!(flag & PMX_EZ_REV_CIGAR))
+            flush();
+            if (k == 0 && !(flag & PMX_EZ_REV_CIGAR))
                 for (int a = 0; a < n_cigar >> 1; ++a) { const uint32_t t_ = cig[a]; cig[a] = cig[n_cigar - 1 - a]; cig[n_cigar - 1 - a] = t_; }
         }
         ez.n_cigar = n_cigar;
-        const uint32_t call = rq->call;
-        if (call < PMX_DP_MAX_CALLS) {
-            DpRes& R = D.dp_res_base[(size_t)(ent / PMX_DP_REQ_PER_PASS) * PMX_DP_MAX_CALLS + call];
-            R.ez = ez;
-            R.key = bad ? 0xffffffffu : rq->key;
-            if (!bad) for (int a = 0; a < n_cigar; ++a) R.cigar[a] = cig[a];
+        if (k == 0) {
+            const uint32_t call = rq->call;
+            if (call < PMX_DP_MAX_CALLS) {
+                DpRes& R = D.dp_res_base[(size_t)(ent / PMX_DP_REQ_PER_PASS) * PMX_DP_MAX_CALLS + call];
+                R.ez = ez;
+                R.key = bad ? 0xffffffffu : rq->key;
+                if (!bad) for (int a = 0; a < n_cigar; ++a) R.cigar[a] = cig[a];
+            }
+            if (D.stats) {
+                atomicAdd(&D.stats[0], 1ULL);
+                atomicAdd(&D.stats[1], (unsigned long long)dp_cells(qlen, tlen, rq->w));
+            }
+            if (!D.shadow) rq->call = 0xffffffffu;   // served
         }
-        if (D.stats) {
-            atomicAdd(&D.stats[0], 1ULL);
-            atomicAdd(&D.stats[1], (unsigned long long)dp_cells(qlen, tlen, rq->w));
-        }
-        if (!D.shadow) rq->call = 0xffffffffu;   // served
     }
     __syncthreads();
+    if (D.prof && lane == 0) {
+        const unsigned long long pt4 = (unsigned long long)clock64();
+        atomicAdd(&D.prof[0], pt1 - pt0); atomicAdd(&D.prof[1], pt2 - pt1); atomicAdd(&D.prof[2], pt3 - pt2); atomicAdd(&D.prof[3], pt4 - pt3);
+        atomicAdd(&D.prof[4], 1ULL); atomicAdd(&D.prof[5], (unsigned long long)n_steps);
+    }
 }
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_align_dp_group(DpgArgs D) {

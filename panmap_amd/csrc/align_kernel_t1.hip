@@ -16,6 +16,7 @@ __global__ void __launch_bounds__(64, 4) k_align_reads_t1_w4(AlignArgs A) { alig
 // its arrays in LDS (traceback matrix in LDS when it fits, else in the wave's HBM slab).  The result is
 // appended to the slot's result list.
 __global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
+    if (A.dp_left && A.dp_left[0] + A.dp_left[1] == 0) return;   // the grouped service (align_kernel_dpg.hip) took every request
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     Work& W = *reinterpret_cast<Work*>(lds);
     PMX_LDS(&W);

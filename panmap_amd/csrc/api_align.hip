@@ -56,6 +56,7 @@ struct pmx_aligner {
     DevBuf<char> dpg_tmp;
     DevBuf<uint8_t> dpg_tb;
     DevBuf<DpRes> dpg_shadow;
+    DevBuf<unsigned long long> dpg_prof;
     int64_t last_dp_requests = 0;
     int last_dp_rounds = 0;
     DevBuf<uint32_t> retry_list;
@@ -369,7 +370,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     };
     A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
     A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
-    A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.dp_small_tb = 0; A.tpp_ring_w = 0;
+    A.dp_left = nullptr; A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.dp_small_tb = 0; A.tpp_ring_w = 0;
     A.sk_no_lane_ring = getenv("PMX_ALIGN_NO_LANE_RING") ? 1 : 0;
     A.mv_handover = nullptr; A.mv_stride = 0; A.mv_slots = 0; A.mv_epoch = ++al->mv_epoch;
     A.pair_perm = nullptr;
@@ -630,10 +631,19 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                         for (int b = 0; b < 16; ++b) fprintf(stderr, " %u/%ld", cn[(size_t)b], cnt[b]);
                         fprintf(stderr, "\n");
                     }
+                    if (getenv("PMX_DPG_PROF")) { al->dpg_prof.ensure(8); PMX_HIP(hipMemsetAsync(al->dpg_prof.p, 0, 64, ctx->stream)); DG.prof = al->dpg_prof.p; }
                     if (!getenv("PMX_DPG_NO_SERVE"))
                     hipLaunchKernelGGL(k_align_dp_group, dim3((unsigned)dpg_grid), dim3(64), PMX_DPG_LDS_BYTES, ctx->stream, DG);
                     PMX_HIP(hipGetLastError());
+                    if (DG.prof) {
+                        unsigned long long h[8];
+                        PMX_HIP(hipMemcpyAsync(h, al->dpg_prof.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+                        PMX_HIP(hipStreamSynchronize(ctx->stream));
+                        const double t = (double)std::max<unsigned long long>(h[4], 1);
+                        fprintf(stderr, "[dpg prof] %llu tasks; cycles per task (lane 0 of the wave): set-up %.0f fill %.0f replay %.0f traceback %.0f; fill steps %.1f\n", h[4], h[0] / t, h[1] / t, h[2] / t, h[3] / t, h[5] / t);
+                    }
                 }
+                A.dp_left = dpg_ok && !getenv("PMX_DPG_SHADOW") && !getenv("PMX_DPG_NO_SERVE") ? al->dpg_counts.p + PMX_DPG_NO_BUCKET - 1 : nullptr;
                 A.layout = dp_layout;
                 A.slow_stride = dp_stride;
                 A.slow_base = al->slow.p;
