@@ -354,10 +354,22 @@ PMX_HDN void ksw_extd2_t(Work& W, int qlen, QP query, int tlen, TP target, const
 }
 
 
+}  // namespace aln
+}  // namespace pmx
+#include "aln_ksw_rows.hpp"
+namespace pmx {
+namespace aln {
+
 template <class QP, class TP>
 PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const int8_t* mat, int8_t q, int8_t e,
                       int8_t q2, int8_t e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
 #if !defined(PMX_INTERLEAVED) && !defined(PMX_ALL_LDS)
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+    // long reads: row by row with the columns in registers (aln_ksw_rows.hpp) whenever the band never cuts the matrix
+    if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && !W.no_rows_dp &&
+        ksw_extd2_rows(W, W.dp_fast, (size_t)9 * (PMX_DP_FAST_TLEN + 32) + 64, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez))
+        return;
+#endif
     if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && (tlen + 15) / 16 * 16 <= PMX_DP_FAST_TLEN && qlen <= PMX_DP_FAST_TLEN) {
         if (flag & PMX_EZ_RIGHT) ksw_extd2_t<true, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
         else ksw_extd2_t<true, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);

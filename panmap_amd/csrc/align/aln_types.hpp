@@ -462,6 +462,7 @@ struct Work {
     uint32_t dp_run_calls;
     uint64_t dp_run_cells;
     int sk_no_lane_ring;   // wave models: 1 = sketch with the ring in LDS (comparison / fallback switch)
+    int no_rows_dp;        // wave-per-read kernels: 1 = never the row-by-row DP (aln_ksw_rows.hpp; comparison switch)
     int mv_ready;          // mv[] / n_mv already hold this pair's minimizers (handed over by the thread-per-pair kernel)   // [0..11] phases, [16..23] sub-phases of seeding / chaining / align1 (PMX_ALIGN_PROF)
 };
 

@@ -29,6 +29,7 @@ struct AlignArgs {
     int dp_round;
     int tpp_ring_w;             // k_align_reads_tpp: minimizer window length when the ring lives in LDS, else 0
     int sk_no_lane_ring;        // wave-per-pair kernels: 1 = sketch with the window ring in LDS instead of across the lanes
+    int no_rows_dp;             // wave-per-read kernels: 1 = never the row-by-row DP (PMX_ALIGN_NO_ROWS_DP)
     // Minimizer hand-over: a pair that posts a DP request in the thread-per-pair kernel leaves its minimizer list here
     // (slot s: entry [s * mv_stride] holds the count in .x, the list follows), so the wave-per-pair tier does not have to
     // sketch the reads again when it takes the pair over (the sketch is ~40 % of a pair's time there).  Slots >= mv_slots

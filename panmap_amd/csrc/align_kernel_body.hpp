@@ -44,6 +44,7 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
         W.n_segs = n_segs;
         W.prof = A.prof;
         W.sk_no_lane_ring = A.sk_no_lane_ring;
+        W.no_rows_dp = A.no_rows_dp;
         W.mv_ready = 0;
         if (A.mv_handover && ho_slot >= 0 && ho_slot < (int64_t)A.mv_slots) {   // minimizers left by the thread-per-pair kernel
             const A128* src = A.mv_handover + (size_t)ho_slot * A.mv_stride;
