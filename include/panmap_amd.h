@@ -334,6 +334,26 @@ int pmx_align_score_reads(pmx_ctx *ctx, pmx_aligner *al, const pmx_readset *rs, 
  * alone (src/mm_align.c:178-185); reads of flagged records count as unmapped (pmx_last_error() says how many). */
 int64_t pmx_score_reads_vs_reference(const char *reference, int n_reads, const char **reads, const int *r_lens, int kmer_size,
                                      bool paired_end);
+/* The DP kernel on its own (A9: ksw_extd2_sse, src/3rdparty/minimap2/ksw2_extd2_sse.c:28-400, with the aligner's scoring
+ * parameters): a batch of (query, target) pairs of nt4 codes (0..3, 4 = N) through the GROUPED DP SERVICE of the short-read
+ * tiers (align_kernel_dpg.hip) -- the entry point of its parity tests against the reference function and of its throughput
+ * measurement (bench.py `dp_service`).  Sequence i is seqs[q_off[i] .. q_off[i+1]) / seqs[t_off[i] .. t_off[i+1]); w,
+ * zdrop, end_bonus, flag (KSW_EZ_* bits) per request as the reference takes them.  out[i].served = 0 for a request the
+ * service does not take (a side longer than 128 bases, a band that cuts the matrix, other flag combinations, more than 20
+ * CIGAR operations): the align tiers run those on the wave-per-request kernels.  `reps` > 1 repeats the launch (timing);
+ * *kernel_ms (may be NULL) receives the duration of one launch of the service kernel. */
+typedef struct {
+    int32_t served;
+    uint32_t max;
+    int32_t zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, n_cigar, reach_end;
+    uint32_t cigar[20];
+} pmx_dp_result;
+/* the aligner's DP scoring: out[0..8] = a, b, q, e, q2, e2, sc_ambi, zdrop, end_bonus (mm_mapopt_t of the preset the mean
+ * read length selected, src/mm_align.c:140-166) */
+int pmx_align_scoring(const pmx_aligner *al, int32_t out[9]);
+int pmx_align_dp_batch(pmx_ctx *ctx, pmx_aligner *al, const uint8_t *seqs, const int64_t *q_off, const int64_t *t_off, int64_t n,
+                       const int32_t *w, const int32_t *zdrop, const int32_t *end_bonus, const int32_t *flag, pmx_dp_result *out,
+                       int reps, double *kernel_ms);
 int64_t pmx_align_num_records(const pmx_aligner *al);
 int64_t pmx_align_cigar_words(pmx_ctx *ctx, pmx_aligner *al);
 int pmx_align_fetch(pmx_ctx *ctx, pmx_aligner *al, pmx_aln_record *records, int64_t n_records, uint32_t *cigar_arena,

@@ -251,3 +251,36 @@ def ref_score_reads(reference: bytes, reads, paired: bool) -> int:
     arr = (C.c_char_p * n)(*reads)
     lens = (C.c_int * n)(*[len(r) for r in reads])
     return int(L.score_reads_vs_reference(reference, n, arr, lens, 0, bool(paired)))
+
+
+# ------------------------------------------------------------------ the reference's DP kernel on its own (A9)
+class _KswExtz(C.Structure):   # ksw_extz_t (src/3rdparty/minimap2/ksw2.h:27-36)
+    _fields_ = [("max_zdropped", C.c_uint32), ("max_q", C.c_int), ("max_t", C.c_int), ("mqe", C.c_int), ("mqe_t", C.c_int), ("mte", C.c_int),
+                ("mte_q", C.c_int), ("score", C.c_int), ("m_cigar", C.c_int), ("n_cigar", C.c_int), ("reach_end", C.c_int),
+                ("cigar", C.POINTER(C.c_uint32))]
+
+
+def simple_mat(a: int, b: int, sc_ambi: int):
+    """ksw_gen_simple_mat(5, ...) (src/3rdparty/minimap2/options.c / ksw2.h): the 5 x 5 score matrix minimap2 aligns with"""
+    a, b, sc_ambi = abs(a), -abs(b), -abs(sc_ambi)
+    m = [[(a if i == j else b) if i < 4 and j < 4 else sc_ambi for j in range(5)] for i in range(5)]
+    return (C.c_int8 * 25)(*[v for row in m for v in row])
+
+
+def ref_ksw_extd2(query, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag):
+    """ksw_extd2_sse of the compiled reference (src/3rdparty/minimap2/ksw2_extd2_sse.c:28-400) on nt4 codes.
+    -> dict of the ksw_extz_t fields, cigar as a list"""
+    L = rlib()
+    fn = L.ksw_extd2_sse
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int8, C.POINTER(C.c_int8), C.c_int8, C.c_int8, C.c_int8, C.c_int8,
+                   C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_KswExtz)]
+    ez = _KswExtz()
+    qb, tb = bytes(bytearray(query)), bytes(bytearray(target))
+    fn(None, len(qb), qb, len(tb), tb, 5, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, C.byref(ez))
+    out = dict(max=ez.max_zdropped & 0x7fffffff, zdropped=ez.max_zdropped >> 31, max_q=ez.max_q, max_t=ez.max_t, mqe=ez.mqe, mqe_t=ez.mqe_t,
+               mte=ez.mte, mte_q=ez.mte_q, score=ez.score, n_cigar=ez.n_cigar, reach_end=ez.reach_end,
+               cigar=[int(ez.cigar[i]) for i in range(ez.n_cigar)])
+    if ez.cigar:
+        C.CDLL(None).free(ez.cigar)
+    return out

@@ -146,6 +146,8 @@ SIGNATURES = {
     "pmx_index_node_id": (_cp, [_vp, _i64]),
     "pmx_align_copy_cigars_device": (_i32, [_vp, _vp, _vp, _i64]),
     "pmx_align_get_stats": (_i32, [_vp, _vp, C.POINTER(AlignStats)]),
+    "pmx_align_scoring": (_i32, [_vp, C.POINTER(C.c_int32)]),
+    "pmx_align_dp_batch": (_i32, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _i32, C.POINTER(C.c_double)]),
     "pmx_place_score": (_i32, [_vp, _vp, C.POINTER(PlaceParams), _i64, C.POINTER(PlaceResult)]),
     "pmx_place_tied": (_i32, [_vp, _i32, _vp, _i64]),
     "pmx_place_node_outputs": (_i32, [_vp, _vp, _vp, _vp, _vp]),

@@ -693,6 +693,8 @@ def last_error() -> bytes:
     return lib.pmx_last_error()
 
 
+DP_RESULT_DTYPE = np.dtype([("served", "<i4"), ("max", "<u4"), ("zdropped", "<i4"), ("max_q", "<i4"), ("max_t", "<i4"), ("mqe", "<i4"), ("mqe_t", "<i4"),
+                            ("mte", "<i4"), ("mte_q", "<i4"), ("score", "<i4"), ("n_cigar", "<i4"), ("reach_end", "<i4"), ("cigar", "<u4", (20,))])
 REC_DTYPE = np.dtype([("rs", "<i4"), ("re", "<i4"), ("qs", "<i4"), ("qe", "<i4"), ("mapq", "u1"), ("rev", "u1"),
                       ("proper_frag", "u1"), ("mapped", "u1"), ("n_cigar", "<u2"), ("flags", "<u2"), ("cigar_off", "<u4"),
                       ("score", "<i4")])
@@ -753,6 +755,34 @@ class Aligner:
 
     def cigar_words(self) -> int:
         return int(lib.pmx_align_cigar_words(self.ctx._h, self._h))
+
+    def scoring(self) -> dict:
+        """the DP scoring of the preset in force: a, b, q, e, q2, e2, sc_ambi, zdrop, end_bonus"""
+        v = (C.c_int32 * 9)()
+        check(lib.pmx_align_scoring(self._h, v), "pmx_align_scoring")
+        return dict(zip(("a", "b", "q", "e", "q2", "e2", "sc_ambi", "zdrop", "end_bonus"), (int(x) for x in v)))
+
+    def dp_batch(self, queries, targets, w, zdrop, end_bonus, flag, reps: int = 1):
+        """ksw_extd2 on (query, target) pairs of nt4 codes through the grouped DP service (pmx_align_dp_batch).
+        -> (structured array of DP_RESULT_DTYPE, milliseconds of one service launch)"""
+        n = len(queries)
+        qa = [np.asarray(a, np.uint8) for a in queries]
+        ta = [np.asarray(b, np.uint8) for b in targets]
+        qs, ts = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        if n:
+            qs[1:] = np.cumsum([len(a) for a in qa])
+            ts[1:] = np.cumsum([len(b) for b in ta])
+        ts += qs[-1]                                       # all queries first, then all targets
+        seqs = np.ascontiguousarray(np.concatenate(qa + ta)) if n else np.zeros(1, np.uint8)
+        out = np.zeros(n, DP_RESULT_DTYPE)
+        ms = C.c_double(0)
+
+        def arr(x):
+            return np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.int32), (n,)))
+        w_, z_, e_, f_ = arr(w), arr(zdrop), arr(end_bonus), arr(flag)
+        check(lib.pmx_align_dp_batch(self.ctx._h, self._h, seqs.ctypes.data, qs.ctypes.data, ts.ctypes.data, n, w_.ctypes.data, z_.ctypes.data,
+                                     e_.ctypes.data, f_.ctypes.data, out.ctypes.data, int(reps), C.byref(ms)), "pmx_align_dp_batch")
+        return out, float(ms.value)
 
     def stats(self) -> dict:
         """work statistics of the last align_readset call (DP cells = q * min(t, 2w+1) per ksw2 call)"""

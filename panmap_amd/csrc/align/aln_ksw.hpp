@@ -366,18 +366,35 @@ PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const in
 #if !defined(PMX_INTERLEAVED) && !defined(PMX_ALL_LDS)
 #if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
     // long reads: row by row with the columns in registers (aln_ksw_rows.hpp) whenever the band never cuts the matrix
+    const unsigned long long pt0 = W.prof && W.dp_fast ? (unsigned long long)clock64() : 0ULL;   // diagnostic (long reads): which kernel ran the DP
+    auto account = [&](int slot) {
+        if (W.prof && W.dp_fast && lane_id() == 0) {
+            atomicAdd(&W.prof[slot], 1ULL);
+            atomicAdd(&W.prof[slot + 1], (unsigned long long)qlen * (unsigned long long)tlen);
+            atomicAdd(&W.prof[slot + 2], (unsigned long long)clock64() - pt0);
+        }
+    };
     if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && !W.no_rows_dp &&
-        ksw_extd2_rows(W, W.dp_fast, (size_t)9 * (PMX_DP_FAST_TLEN + 32) + 64, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez))
+        ksw_extd2_rows(W, W.dp_fast, (size_t)9 * (PMX_DP_FAST_TLEN + 32) + 64, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) {
+        account(12);
         return;
+    }
+#else
+    auto account = [&](int) {};
 #endif
     if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && (tlen + 15) / 16 * 16 <= PMX_DP_FAST_TLEN && qlen <= PMX_DP_FAST_TLEN) {
         if (flag & PMX_EZ_RIGHT) ksw_extd2_t<true, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
         else ksw_extd2_t<true, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+        account(15);
         return;
     }
-#endif
     if (flag & PMX_EZ_RIGHT) ksw_extd2_t<false, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
     else ksw_extd2_t<false, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+    account(18);
+#else
+    if (flag & PMX_EZ_RIGHT) ksw_extd2_t<false, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+    else ksw_extd2_t<false, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
+#endif
 }
 
 #if PMX_W == 64
