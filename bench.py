@@ -663,6 +663,36 @@ def main():
                     inputs="resident in HBM (one batch at a time)",
                     workload="tests/golden/isolate_R{1,2}.fastq.gz (2 x 51,169 real reads, mean %d bp, indels / N / adapters) x8, place + align" % r_mean)
 
+    # ------------------------------------------------------------------------------- the DP kernel on its own (one GPU only)
+    # ksw_extd2 requests as the real reads post them (extensions of ~60-110 query bases against targets up to 128, 4 %
+    # substitutions, 1 % indels; one in three a gap fill) through the grouped DP service: cells = sum of qlen * tlen
+    dp_service = None
+    if world == 1 and not long_reads and main_pipe.aligner is not None:
+        rng_dp = np.random.default_rng(99)
+        n_req = 65536
+        tl = rng_dp.integers(96, 129, n_req)
+        ql = np.minimum(tl, rng_dp.integers(60, 113, n_req))
+        t_all = rng_dp.integers(0, 4, int(tl.sum()), dtype=np.uint8)
+        t_off2 = np.concatenate([[0], np.cumsum(tl)])
+        qs_, ts_ = [], []
+        for i in range(n_req):
+            t = t_all[t_off2[i]:t_off2[i + 1]]
+            q = t[:ql[i]].copy()
+            hit = rng_dp.random(len(q)) < 0.04
+            q[hit] = (q[hit] + 1 + rng_dp.integers(0, 3, int(hit.sum()))) % 4
+            if rng_dp.random() < 0.5:
+                cut = int(rng_dp.integers(1, len(q)))
+                q = np.delete(q, cut)
+            qs_.append(q); ts_.append(t)
+        kinds = np.array([0x08, 0x40, 0xc2], np.int32)[np.arange(n_req) % 3]
+        sc = main_pipe.aligner.scoring()
+        res_dp, dp_ms = main_pipe.aligner.dp_batch(qs_, ts_, -1, sc["zdrop"], sc["end_bonus"], kinds, reps=5)
+        cells = float(sum(len(a) * len(b) for a, b in zip(qs_, ts_)))
+        dp_service = dict(kernel="k_align_dp_group (eight lanes per request, rows as a systolic pipeline)", requests=n_req, served=int(res_dp["served"].sum()),
+                          cells=cells, kernel_ms=dp_ms, gcups=cells / max(dp_ms, 1e-9) / 1e6,
+                          note="ksw_extd2 cells (qlen * tlen, full matrix: the band never cuts these) / duration of the service kernel, best of 5 launches; "
+                               "results equal ksw_extd2_sse of the reference (tests/test_dp_service_gpu.py)")
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_reads * args.steps / elapsed
@@ -756,6 +786,7 @@ def main():
             out.update({"roofline": None, "roofline_valu": None})
         out.update({
             "real_reads": real,
+            "dp_service": dp_service,
             "checks": {"placed_node": placed_id, "mapped_fraction": mapped_frac, "records_flagged": flagged,
                        "unique_seeds": int(res.n_unique_seeds), "kept_seeds": int(res.readUniqueSeedCount),
                        "tiers": dp_stats[-1], "rank0_gather_has_every_cigar": gather_ok},

@@ -43,7 +43,12 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
     int32_t* lastrow = lastcol + qlen;
     uint32_t* diag = reinterpret_cast<uint32_t*>(lastrow + tlen);
     uint32_t* spare = diag + qlen + tlen;   // where the columns past the target put what they compute
-    uint8_t* tb = W.tb;
+    // (the traceback matrix of a long read's DP is in the wave's HBM slab: say so -- through a generic pointer the row's bytes leave
+    //  as flat_store, which counts on lgkmcnt too, and the next step's LDS read of the query base waits for the HBM round trip)
+    typedef __attribute__((address_space(1))) uint8_t g_u8;
+    typedef __attribute__((address_space(1))) uint32_t g_u32;
+    typedef __attribute__((address_space(1))) uint4 g_u4;
+    g_u8* tb = (g_u8*)(uint8_t*)W.tb;
 
     const int qe = q + e, qe2 = q2 + e2;
     const int init_ue = -qe, init_ue2 = -qe2;
@@ -171,9 +176,9 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
                 asm volatile("" : "+v"(xl), "+v"(vl), "+v"(x2l), "+v"(Hl), "+v"(tbw[c >> 2]), "+v"(u[c]), "+v"(y[c]), "+v"(y2[c]), "+v"(tcur), "+v"(hcol));
             }
             xo = xl; vo = vl; x2o = x2l; Ho = Hl;
-            uint8_t* trow = tb + (size_t)i * ROW + t0v;
+            g_u32* trow = (g_u32*)(tb + (size_t)i * ROW + t0v);
 #pragma unroll
-            for (int c4 = 0; c4 < SW / 4; ++c4) reinterpret_cast<uint32_t*>(trow)[c4] = tbw[c4];
+            for (int c4 = 0; c4 < SW / 4; ++c4) trow[c4] = tbw[c4];
             if (EXACT && owns_last) lastcol[i] = hcol;
         }
     }
@@ -225,7 +230,7 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
                 wi0 = (i & ~15) - 16 > 0 ? (i & ~15) - 16 : 0;
                 wj0 = j - 63 > 0 ? j - 63 : 0;
                 if (wj0 + k <= j) {
-                    const uint4* src = reinterpret_cast<const uint4*>(tb + (size_t)(wj0 + k) * ROW + wi0);
+                    const g_u4* src = (const g_u4*)(tb + (size_t)(wj0 + k) * ROW + wi0);
                     const uint4 v0 = src[0], v1 = src[1];
                     *reinterpret_cast<uint4*>(win + k * 32) = v0;
                     *reinterpret_cast<uint4*>(win + k * 32 + 16) = v1;

@@ -367,7 +367,23 @@ __device__ void sketch_segment_wave(Work& W, const uint8_t* seq, int len, int w,
 // (sketch_slice above: w + k + 1 bases of run-in reproduce the sequential state, tests/test_align_host.py) -- ~36 steps
 // per lane for a 150-base read instead of 150 wave-uniform steps with the ring across the lanes.  A lane keeps its (few)
 // minimizers in registers; a wave prefix sum gives every lane its place in W.mv.
-struct SliceBase { const uint8_t* seq; __device__ int operator()(int i) const { return (int)seq[i]; } };
+// (the bases of a long read sit in the wave's HBM slab: one byte load per base was one memory round trip per step of a lane's
+//  walk; the walk is sequential, so four bases come per load and the next word is requested while these are used)
+struct SliceBase {
+    const uint8_t* seq;
+    int cur = -2;
+    uint32_t wd = 0, nxt = 0;
+    __device__ int operator()(int i) {
+        const int wi = i >> 2;
+        if (wi != cur) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(seq);   // (the sequence arrays are 16-byte aligned and padded by 16)
+            wd = wi == cur + 1 ? nxt : p[wi];
+            nxt = p[wi + 1];
+            cur = wi;
+        }
+        return (int)(wd >> (8 * (i & 3)) & 0xffu);
+    }
+};
 struct SliceKeep {   // a lane's own minimizers: a handful at most for a slice of a few bases
     uint64_t x0, y0, x1, y1, x2, y2, x3, y3;
     int n;
@@ -384,7 +400,8 @@ __device__ void sketch_segment_lanes(Work& W, const uint8_t* seq, int len, int w
     const int lane = lane_id();
     const int per = (len + 63) / 64;
     const int begin = lane * per, end = begin + per < len ? begin + per : len;
-    SliceBase base{seq};
+    SliceBase base;
+    base.seq = seq;
     SliceKeep kp;
     kp.n = 0; kp.x0 = kp.y0 = kp.x1 = kp.y1 = kp.x2 = kp.y2 = kp.x3 = kp.y3 = 0;
     if (begin < len) sketch_slice<WMAX>(begin, end, len, w, k, base, kp);
@@ -449,7 +466,11 @@ PMX_HD void collect_minimizers(Work& W, const Opt& o) {
     for (int s = 0; s < W.n_segs; ++s) {
         const int n0 = W.n_mv;
         sketch_segment(W, W.qseq[s][0], W.qlen[s], o.w, o.k, (uint32_t)s);
-        for (int j = n0; j < W.n_mv; ++j) mvp[j].y += (uint64_t)sum << 1;
+        if (sum != 0) {   // (a single segment -- every long read -- has nothing to shift: ~1,800 dependent read-modify-writes in the slab)
+            wave_sync();
+            for (int j = n0 + lane_id(); j < W.n_mv; j += PMX_W) mvp[j].y += (uint64_t)sum << 1;
+            wave_sync();
+        }
         sum += W.qlen[s];
     }
 }

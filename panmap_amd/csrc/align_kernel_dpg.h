@@ -39,6 +39,7 @@ struct DpgArgs {
 
 __global__ void k_dpg_collect(DpgArgs D);
 __global__ void k_align_dp_group(DpgArgs D);
+__global__ void k_dpg_refuse_left(DpgArgs D);
 
 }  // namespace aln
 }  // namespace pmx

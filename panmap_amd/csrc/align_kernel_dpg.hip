@@ -57,6 +57,21 @@ __global__ void __launch_bounds__(256) k_dpg_collect(DpgArgs D) {
     if (threadIdx.x < 16 && h[threadIdx.x]) atomicAdd(&D.counts[threadIdx.x], h[threadIdx.x]);
 }
 
+// The few requests the grouped service left (a side beyond 128 bases, ...) when they are too few to be worth a launch of the
+// wave-per-request service (a full launch lasts as long as its longest request, ~0.4 ms): their results are marked invalid, and
+// the replay hands those pairs to the wave-per-pair tier, which runs its own DPs.
+__global__ void __launch_bounds__(256) k_dpg_refuse_left(DpgArgs D) {
+    const int64_t n = D.n_slots * PMX_DP_REQ_PER_PASS;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t slot = D.worklist ? (int64_t)D.worklist[idx % D.n_slots] : idx % D.n_slots;
+        DpReq* rq = reinterpret_cast<DpReq*>(D.dp_req_base + ((size_t)slot * PMX_DP_REQ_PER_PASS + (size_t)(idx / D.n_slots)) * sizeof(DpReq));
+        const uint32_t call = rq->call;
+        if (call == 0xffffffffu) continue;
+        if (call < PMX_DP_MAX_CALLS) D.dp_res_base[(size_t)slot * PMX_DP_MAX_CALLS + call].key = 0xffffffffu;
+        rq->call = 0xffffffffu;
+    }
+}
+
 __device__ __forceinline__ int dpg_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); }   // row_shr:1
 
 // (not inlined: twelve instantiations in one kernel body let the compiler hoist every variant's lane-invariant values out of

@@ -652,7 +652,23 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                         fprintf(stderr, "[dpg prof] %llu tasks; cycles per task (lane 0 of the wave): set-up %.0f fill %.0f replay %.0f traceback %.0f; fill steps %.1f\n", h[4], h[0] / t, h[1] / t, h[2] / t, h[3] / t, h[5] / t);
                     }
                 }
-                A.dp_left = dpg_ok && !getenv("PMX_DPG_SHADOW") && !getenv("PMX_DPG_NO_SERVE") ? al->dpg_counts.p + PMX_DPG_NO_BUCKET - 1 : nullptr;
+                A.dp_left = nullptr;
+                bool wave_service = true;
+                if (dpg_ok && !getenv("PMX_DPG_SHADOW") && !getenv("PMX_DPG_NO_SERVE")) {
+                    // what did the grouped service leave?  Nothing: no launch of the wave service.  A handful (a side beyond 128
+                    // bases on 150 bp reads: ~8 requests per 400k pairs): those pairs go to the wave-per-pair tier instead
+                    uint32_t left[2] = {0, 0};
+                    PMX_HIP(hipMemcpyAsync(left, al->dpg_counts.p + PMX_DPG_NO_BUCKET - 1, sizeof(left), hipMemcpyDeviceToHost, ctx->stream));
+                    PMX_HIP(hipStreamSynchronize(ctx->stream));
+                    int64_t few = 256;
+                    if (const char* e = getenv("PMX_DPG_LEFT_TO_WAVE_TIER")) few = atoll(e);
+                    if (left[0] + left[1] == 0) wave_service = false;
+                    else if ((int64_t)left[0] + left[1] <= few) {
+                        hipLaunchKernelGGL(k_dpg_refuse_left, dim3((unsigned)std::min<int64_t>((n_dp * PMX_DP_REQ_PER_PASS + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, DG);
+                        wave_service = false;
+                    }
+                }
+                if (wave_service) {
                 A.layout = dp_layout;
                 A.slow_stride = dp_stride;
                 A.slow_base = al->slow.p;
@@ -669,6 +685,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     A.slow_base = al->slow2.p;
                     A.dp_class = 1;
                     hipLaunchKernelGGL(k_align_dp_serve, dim3((unsigned)std::min<int64_t>(dps_max_grid, n_dp * PMX_DP_REQ_PER_PASS)), dim3(64), dps_lds, ctx->stream, A);
+                }
                 }
                 PMX_HIP(hipGetLastError());
                 if (dpg_ok && getenv("PMX_DPG_SHADOW")) {
