@@ -470,8 +470,25 @@ PMX_HDN void chain_finish(Work& W, const int64_t n, const int min_cnt, const int
     // ---- backtrack (lchain.c:27-76)
     Ptr<A128> z = W.z; PMX_LDS(z);
     int64_t n_z = 0;
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+    // (long reads: ~1,800 cells in the wave's HBM slab -- 64 at a time, places from a ballot, same order)
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {
+        const int64_t i = i0 + lane_id();
+        const int32_t f = i < n ? c[i].f : 0;
+        const bool take = i < n && f >= min_sc;
+        const unsigned long long m = __ballot(take);
+        if (take) {
+            const int64_t at = n_z + (int64_t)__builtin_popcountll(m & ((1ULL << lane_id()) - 1ULL));
+            A128 e; e.x = (uint64_t)(int64_t)f; e.y = (uint64_t)i;
+            z[at] = e;
+        }
+        n_z += (int64_t)__builtin_popcountll(m);
+    }
+    wave_sync();
+#else
     for (int64_t i = 0; i < n; ++i)
         if (c[i].f >= min_sc) { z[n_z].x = (uint64_t)(int64_t)c[i].f; z[n_z].y = (uint64_t)i; ++n_z; }
+#endif
     if (n_z == 0) { W.n_a = 0; return; }
     radix_sort_128x(z, z + n_z, &W.status);
     int64_t n_v = 0;
@@ -519,6 +536,56 @@ PMX_HDN void chain_finish(Work& W, const int64_t n, const int min_cnt, const int
         // The reference walks a chain to its drop point with temporary marks, un-marks it and traces the best prefix in a
         // second pass; the predecessor links strictly decrease, so a walk never meets its own marks and one pass that
         // remembers how many of the visited anchors precede the best cut is the same thing.
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+        // Wave kernels (long reads: the cells live in the wave's HBM slab, every access a memory round trip).  Everything
+        // but the walk along the predecessor links is spread over the lanes -- clearing the marks, finding the next chain
+        // end that is still free (64 candidates per round trip: after the main chain of a long read nearly every remaining
+        // end is used), marking a kept chain -- and the walk itself reads ONE 16-byte cell per step (f, p and t of the
+        // predecessor arrive together) instead of three dependent fields.
+        for (int64_t i = lane_id(); i < n; i += 64) c[i].t = 0;
+        wave_sync();
+        for (int64_t k = n_z - 1; k >= 0; --k) {
+            A128 zk;
+            {
+                bool found = false;
+                while (k >= 0) {
+                    const int64_t kk = k - lane_id();
+                    A128 e; e.x = 0; e.y = 0;
+                    bool free_end = false;
+                    if (kk >= 0) { e = z[kk]; free_end = c[(int64_t)e.y].t == 0; }
+                    const unsigned long long m = __ballot(free_end);
+                    if (m == 0ULL) { k -= 64; continue; }
+                    const int first = __builtin_ctzll(m);
+                    k -= first;
+                    zk.x = rl64(e.x, first);
+                    zk.y = rl64(e.y, first);
+                    found = true;
+                    break;
+                }
+                if (!found) break;
+            }
+            int64_t i = (int64_t)zk.y;
+            const int32_t zx = (int32_t)zk.x;
+            const int64_t n_v0 = n_v;
+            int64_t seen = 0, keep = 0;
+            int32_t max_s = 0;
+            ChainCell cur = c[i];
+            do {
+                c[n_v0 + seen].v = (int32_t)i;
+                ++seen;
+                i = cur.p;
+                ChainCell nx; nx.f = 0; nx.p = -1; nx.t = 0; nx.v = 0;
+                if (i >= 0) nx = c[i];   // (one load: the walk needs f and t of the predecessor now and its p next)
+                const int32_t s_ = i < 0 ? zx : zx - nx.f;
+                if (s_ > max_s) { max_s = s_; keep = seen; }
+                else if (max_s - s_ > max_drop) break;
+                if (!(i >= 0 && nx.t == 0)) break;
+                cur = nx;
+            } while (true);
+            wave_sync();
+            for (int64_t q = lane_id(); q < keep; q += 64) c[c[n_v0 + q].v].t = 1;   // used, whether or not the chain is then accepted
+            wave_sync();
+#else
         for (int64_t i = 0; i < n; ++i) c[i].t = 0;
         wave_sync();
         for (int64_t k = n_z - 1; k >= 0; --k) {
@@ -540,6 +607,7 @@ PMX_HDN void chain_finish(Work& W, const int64_t n, const int min_cnt, const int
             wave_sync();
             for (int64_t q = 0; q < keep; ++q) c[c[n_v0 + q].v].t = 1;   // used, whether or not the chain is then accepted
             wave_sync();
+#endif
             n_v = n_v0 + keep;
             if (max_s >= min_sc && keep > 0 && keep >= min_cnt) {
                 if (n_u < W.caps.max_reg * 4) u[n_u++] = (uint64_t)(uint32_t)max_s << 32 | (uint64_t)keep;

@@ -376,7 +376,7 @@ PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const in
     };
     if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && !W.no_rows_dp &&
         ksw_extd2_rows(W, W.dp_fast, (size_t)9 * (PMX_DP_FAST_TLEN + 32) + 64, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) {
-        account(12);
+        account(23);
         return;
     }
 #else
@@ -385,12 +385,12 @@ PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const in
     if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && (tlen + 15) / 16 * 16 <= PMX_DP_FAST_TLEN && qlen <= PMX_DP_FAST_TLEN) {
         if (flag & PMX_EZ_RIGHT) ksw_extd2_t<true, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
         else ksw_extd2_t<true, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
-        account(15);
+        account(26);
         return;
     }
     if (flag & PMX_EZ_RIGHT) ksw_extd2_t<false, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
     else ksw_extd2_t<false, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
-    account(18);
+    account(29);
 #else
     if (flag & PMX_EZ_RIGHT) ksw_extd2_t<false, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
     else ksw_extd2_t<false, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);

@@ -86,9 +86,12 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
     int H0 = -qe;                          // H of column 0 (lane 0): v[0] - qe on the first row, += v after (:326-340)
     int hcol = 0;                          // H of the last column, row by row (its owner lane)
     const bool owns_last = (tlen - 1) / SW == k;
+    int qb_next = (int)qs[0];   // the query base of the lane's next row, requested one step ahead (an LDS round trip per step otherwise)
     for (int tau = 0; tau < n_steps; ++tau) {
         int xl = rows_shr1(xo), vl = rows_shr1(vo), x2l = rows_shr1(x2o), Hl = rows_shr1(Ho);
         const int i = tau - k;
+        const int qb = qb_next;
+        qb_next = (int)qs[i + 1 > 0 ? i + 1 : 0];
         // (opaque copies, and one empty asm statement per cell below: see align_kernel_dpg.hip -- without them the compiler hoists
         //  every per-column invariant out of the row loop and interleaves the cells of a row, and the live values spill)
         int t0v = t0, tlv = tlen, qlv = qlen;
@@ -96,7 +99,6 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
 #pragma unroll
         for (int c4 = 0; c4 < SW / 4; ++c4) asm volatile("" : "+v"(sfw[c4]));
         if (i >= 0 && i < qlv && t0v < tlv) {
-            const int qb = (int)qs[i];
             if (k == 0) { xl = init_ue; x2l = init_ue2; vl = gap_head(i); Hl = 0; }
             const int rem_q = qlv - 1 - i;
             int tcur = t0v;

@@ -28,6 +28,29 @@ PMX_HD void rs_insertsort(Ptr<T> beg, Ptr<T> end) {
     }
 }
 
+#if PMX_W > 1
+// n <= 64: one element per lane, rank = number of elements that precede it in a STABLE ascending order.
+// The reference's insertion sort is stable, so the result is identical; the n^2/4 dependent LDS moves of
+// the insertion sort become n scalar broadcasts.
+template <class T, class K>
+__device__ __forceinline__ void wave_rank_sort(T* beg, int n) {
+    const int lane = lane_id();
+    T val;
+    uint64_t key = 0;
+    if (lane < n) { val = beg[lane]; key = K::key(val); }
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)klo, j), jh = (uint32_t)__builtin_amdgcn_readlane((int)khi, j);
+        const uint64_t kj = (uint64_t)jh << 32 | jl;
+        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+    }
+    wave_sync();
+    if (lane < n) beg[rank] = val;
+    wave_sync();
+}
+#endif
+
 // one level of the American-flag pass on byte `s/8`; iterative over an explicit stack of pending
 // sub-ranges (the reference recurses; the visiting order of disjoint buckets does not matter)
 template <class T, class K>
@@ -61,33 +84,19 @@ PMX_HDN void rs_sort_level(Ptr<T> beg, Ptr<T> end, int s, Ptr<T>* stk_b, Ptr<T>*
             if (n > 64) {
                 if (sp < stk_cap) { stk_b[sp] = beg + bb[k]; stk_e[sp] = beg + be[k]; stk_s[sp] = s2; ++sp; }
                 else *overflow |= PMX_ST_OVERFLOW;
-            } else if (n > 1) rs_insertsort<T, K>(beg + bb[k], beg + be[k]);
+            } else if (n > 1) {
+#if PMX_W > 1
+                // (the reference's insertion sort is stable: the rank sort over the lanes leaves the same order, without the
+                //  n^2/4 dependent moves -- in the wave's HBM slab for a long read's ~1,800 chain ends, where the thirty-odd
+                //  buckets of a level were most of the chaining stage's time)
+                wave_rank_sort<T, K>(beg + bb[k], n);
+#else
+                rs_insertsort<T, K>(beg + bb[k], beg + be[k]);
+#endif
+            }
         }
     }
 }
-
-#if PMX_W > 1
-// n <= 64: one element per lane, rank = number of elements that precede it in a STABLE ascending order.
-// The reference's insertion sort is stable, so the result is identical; the n^2/4 dependent LDS moves of
-// the insertion sort become n scalar broadcasts.
-template <class T, class K>
-__device__ __forceinline__ void wave_rank_sort(T* beg, int n) {
-    const int lane = lane_id();
-    T val;
-    uint64_t key = 0;
-    if (lane < n) { val = beg[lane]; key = K::key(val); }
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-        const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)klo, j), jh = (uint32_t)__builtin_amdgcn_readlane((int)khi, j);
-        const uint64_t kj = (uint64_t)jh << 32 | jl;
-        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
-    }
-    wave_sync();
-    if (lane < n) beg[rank] = val;
-    wave_sync();
-}
-#endif
 
 template <class T, class K>
 PMX_HDN void radix_sort(Ptr<T> beg, Ptr<T> end, uint32_t* status) {
@@ -103,7 +112,21 @@ PMX_HDN void radix_sort(Ptr<T> beg, Ptr<T> end, uint32_t* status) {
     Ptr<T> stk_e[64];
     int stk_s[64];
     int sp = 0;
-    stk_b[0] = beg; stk_e[0] = end; stk_s[0] = 56; sp = 1;
+    int s0 = 56;
+#if PMX_W > 1
+    // A level at which every key holds the same byte moves nothing and hands the whole range to the next level (one bucket
+    // of more than 64 elements): start at the first byte in which the keys differ.  (Chain scores, positions within one
+    // reference: the top five or six bytes are equal, and every such level was a counting pass plus a walk over the range
+    // in the wave's HBM slab -- 13.7 M of a 10 kb read's 86 M cycles went into the sort of its ~1,800 chain ends.)
+    {
+        uint64_t all_or = 0, all_and = ~0ULL;
+        for (int64_t i = lane_id(); i < (int64_t)(end - beg); i += PMX_W) { const uint64_t kx = K::key(beg[i]); all_or |= kx; all_and &= kx; }
+        for (int o = PMX_W / 2; o > 0; o >>= 1) { all_or |= __shfl_xor(all_or, o); all_and &= __shfl_xor(all_and, o); }
+        const uint64_t diff = all_or ^ all_and;   // bits in which some two keys differ
+        while (s0 > 0 && ((diff >> s0) & 255ULL) == 0ULL) s0 -= 8;
+    }
+#endif
+    stk_b[0] = beg; stk_e[0] = end; stk_s[0] = s0; sp = 1;
     while (sp > 0) {
         --sp;
         Ptr<T> b = stk_b[sp];

@@ -137,7 +137,7 @@ __device__ __forceinline__ void align_reads_body(const AlignArgs& A) {
         if (A.prof) {
             PMX_STAMP(W, 11);
             __syncthreads();
-            if (lane < 16) atomicAdd(&A.prof[lane], W.prof_acc[lane]);
+            if (lane < 23 && (lane < 12 || lane >= 16 || !A.dp_req_base)) atomicAdd(&A.prof[lane], W.prof_acc[lane]);   // (12..15: the DP service's own counters)
         }
     }
 }

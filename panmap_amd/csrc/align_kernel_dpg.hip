@@ -141,9 +141,12 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
     int xo = 0, vo = 0, x2o = 0, Ho = 0;   // the right edge of the row this lane finished last
     int H0 = -qe;                          // H of column 0 (first lane of the group): H[0] = v[0] - qe on the first row, += v after (:326-340)
     const bool owns_last = valid && (tlen - 1) / SW == k;
+    int qb_next = (int)qs[0];   // the query base of the lane's next row, requested one step ahead (an LDS round trip per step otherwise)
     for (int tau = 0; tau < n_steps; ++tau) {
         int xl = dpg_shr1(xo), vl = dpg_shr1(vo), x2l = dpg_shr1(x2o), Hl = dpg_shr1(Ho);
         const int i = tau - k;
+        const int qb = qb_next;
+        qb_next = (int)qs[i + 1 > 0 ? i + 1 : 0];
         // (opaque copies: everything the cells derive from the lane's column range and the lengths is a one-instruction
         //  value; hoisted out of the row loop as loop invariants -- two or three registers per column -- they spill)
         int t0v = t0, tlv = tlen, qlv = qlen;
@@ -151,7 +154,6 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
 #pragma unroll
         for (int c4 = 0; c4 < SW / 4; ++c4) asm volatile("" : "+v"(sfw[c4]));
         if (i >= 0 && i < qlv && t0v < tlv) {
-            const int qb = (int)qs[i];
             if (k == 0) { xl = init_ue; x2l = init_ue2; vl = gap_head(i); Hl = 0; }
             const int rem_q = qlv - 1 - i;
             int hcol = 0, tcur = t0v;

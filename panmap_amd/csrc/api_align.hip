@@ -341,8 +341,8 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     al->last_stats.n_items = n_items;
     A.prof = nullptr;
     if (getenv("PMX_ALIGN_PROF")) {
-        al->prof.ensure(24);
-        PMX_HIP(hipMemsetAsync(al->prof.p, 0, 24 * sizeof(unsigned long long), ctx->stream));
+        al->prof.ensure(32);
+        PMX_HIP(hipMemsetAsync(al->prof.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
         A.prof = al->prof.p;
     }
 
@@ -554,7 +554,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     unsigned long long h[8];
                     PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
                     PMX_HIP(hipStreamSynchronize(ctx->stream));
-                    PMX_HIP(hipMemsetAsync(al->prof.p, 0, 24 * sizeof(unsigned long long), ctx->stream));
+                    PMX_HIP(hipMemsetAsync(al->prof.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
                     static const char* cn[8] = {"sketch", "probes", "merge", "chain fill", "backtrack", "regions", "align+mapq", "pairing"};
                     const double waves = (double)((n_items + 63) / 64);
                     fprintf(stderr, "[pmx compact tier: cycles per wave (lane 0)]");
@@ -812,7 +812,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     }
     timer_end(ctx, "align", 1);
     if (A.prof) {
-        unsigned long long h[24];
+        unsigned long long h[32];
         PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         PMX_HIP(hipStreamSynchronize(ctx->stream));
         static const char* names[16] = {"decode", "sketch", "seed+heap", "chain", "gen_regs+post", "seg_gen", "squeeze", "align1(all regs)", "filter/sort/parent", "mapq", "pair", "output", "", "", "", ""};
@@ -829,10 +829,10 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 (double)h[15] / std::max<double>(1, (double)al->last_dp_requests));
         fprintf(stderr, " dp_requests=%lld dp_rounds=%d tpp_retry=%lld retry=%lld\n", (long long)al->last_dp_requests, al->last_dp_rounds,
                 (long long)al->last_tpp_retry, (long long)al->last_retry);
-        if (!tier1_fits)   // wave-per-read kernels: slots 12..20 count the DPs by the kernel that ran them
+        if (!tier1_fits)   // wave-per-read kernels: slots 23..31 count the DPs by the kernel that ran them
             fprintf(stderr, "[pmx long-read DPs] row by row: %llu calls, %.1f Mcells, %.0f cycles each; anti-diagonals in LDS: %llu calls, %.1f Mcells, %.0f cycles each; anti-diagonals, general arrays: %llu calls, %.1f Mcells, %.0f cycles each\n",
-                    h[12], h[13] / 1e6, (double)h[14] / std::max<double>(1, (double)h[12]), h[15], h[16] / 1e6, (double)h[17] / std::max<double>(1, (double)h[15]),
-                    h[18], h[19] / 1e6, (double)h[20] / std::max<double>(1, (double)h[18]));
+                    h[23], h[24] / 1e6, (double)h[25] / std::max<double>(1, (double)h[23]), h[26], h[27] / 1e6, (double)h[28] / std::max<double>(1, (double)h[26]),
+                    h[29], h[30] / 1e6, (double)h[31] / std::max<double>(1, (double)h[29]));
     }
     PMX_HIP(hipGetLastError());
     return PMX_OK;
