@@ -158,6 +158,39 @@ struct DropScan {
     }
 };
 
+// Length of the run of equal, unambiguous base pairs at the start of t[t0 .. t0+len) / q[q0 .. q0+len): the position of the
+// first pair that differs or whose target base is ambiguous (`len` if there is none); ct / cq receive the bases there.
+// Wave-per-read kernels: 64 pairs per round trip, the first bad one from a ballot -- the walks over a long read's alignment
+// (mm_test_zdrop per gap fill, mm_update_extra over the whole CIGAR: ~20,000 bases per 10 kb read, each a dependent byte load
+// from the wave's HBM slab in the scalar form) then cost a round trip per mismatch instead of one per base.
+template <class TRD, class QRD>
+PMX_HD int32_t equal_run(TRD& t_r, QRD& q_r, int32_t t0, int32_t q0, int32_t len, uint32_t& ct, uint32_t& cq) {
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+    const int lane = lane_id();
+    for (int32_t base = 0; base < len; base += 64) {
+        const int32_t i = base + lane;
+        uint32_t a = 0, b = 0;
+        bool bad = false;
+        if (i < len) { a = t_r[t0 + i]; b = q_r[q0 + i]; bad = a != b || a > 3; }
+        const unsigned long long m = __ballot(bad);
+        if (m != 0ULL) {
+            const int p = __builtin_ctzll(m);
+            ct = (uint32_t)__builtin_amdgcn_readlane((int)a, p);
+            cq = (uint32_t)__builtin_amdgcn_readlane((int)b, p);
+            return base + p;
+        }
+    }
+    return len;
+#else
+    int32_t run = 0;
+    for (; run < len; ++run) {
+        ct = t_r[t0 + run]; cq = q_r[q0 + run];
+        if (ct != cq || ct > 3) break;
+    }
+    return run;
+#endif
+}
+
 PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const uint8_t> tseq, int n_ops, Ptr<const uint32_t> ops) {
     PMX_LDS(&W); PMX_LDS(qseq); PMX_LDS(tseq); PMX_LDS(ops);
     DropScan ds;
@@ -170,12 +203,8 @@ PMX_HDN int test_zdrop(Work& W, const Opt& o, Ptr<const uint8_t> qseq, Ptr<const
         if (kind == CG_M) {
             int32_t at = 0;
             while (at < len) {
-                int32_t run = 0;
                 uint32_t ct = 0, cq = 0;
-                for (; at + run < len; ++run) {
-                    ct = t_r[t + at + run]; cq = q_r[q + at + run];
-                    if (ct != cq || ct > 3) break;
-                }
+                const int32_t run = equal_run(t_r, q_r, t + at, q + at, len - at, ct, cq);
                 if (run > 0) ds.match_run(t + at + run - 1, q + at + run - 1, run * match);
                 at += run;
                 if (at < len) {   // a mismatch or an ambiguous base
@@ -313,12 +342,8 @@ PMX_HD void update_extra_core(Work& W, const Opt& o, Reg& r, Ptr<const uint8_t> 
         if (kind == CG_M) {
             int32_t at = 0, n_amb = 0, n_sub = 0;
             while (at < len) {
-                int32_t run = 0;
                 uint32_t ct = 0, cq = 0;
-                for (; at + run < len; ++run) {
-                    ct = t_r[t + at + run]; cq = q_r[qp + at + run];
-                    if (ct != cq || ct > 3) break;
-                }
+                const int32_t run = equal_run(t_r, q_r, t + at, qp + at, len - at, ct, cq);
                 if (run > 0) {
                     run_score += (double)(run * match);
                     peak = peak > run_score ? peak : run_score;
