@@ -219,9 +219,17 @@ __device__ void chain_fill_wide_wave(Work& W, const Opt& o, int max_dist_x, int 
     int64_t st = 0, max_ii = -1;
     uint64_t x_st = a[0].x, x_mi = 0;
     int32_t f_mi = 0;
+    A128 a_next = a[0];   // anchor i + 1 is requested while anchor i is worked on (the anchors live in the wave's HBM slab)
     for (int64_t i = 0; i < n; ++i) {
         int64_t max_j = -1;
-        const A128 ai = a[i];
+        const A128 ai = a_next;
+        if (i + 1 < n) a_next = a[i + 1];
+        // the first 64 candidates' cells too: their addresses depend on i alone (the window start only moves up, so
+        // whatever lies below it is masked afterwards) -- the load travels while the window start is advanced
+        CellWords q_first;
+        q_first.w0 = q_first.w1 = q_first.w2 = q_first.w3 = 0;
+        const int64_t j_first = i - 1 - lane;
+        if (j_first >= st) q_first = packed_cell_words(pk4, j_first >> 2, (int)(j_first & 3));
         PackedCell ci;
         ci.x_lo = (uint32_t)ai.x;
         ci.y_lo = (uint16_t)(uint32_t)ai.y;
@@ -243,7 +251,7 @@ __device__ void chain_fill_wide_wave(Work& W, const Opt& o, int max_dist_x, int 
             int32_t val = INT32_MIN, pj = -1;
             bool valid = false, marked = false;
             if (act) {
-                const CellWords q = packed_cell_words(pk4, j >> 2, (int)(j & 3));
+                const CellWords q = hi == i - 1 ? q_first : packed_cell_words(pk4, j >> 2, (int)(j & 3));
                 const int32_t sc0 = chain_score_sel(ci.x_lo, (int32_t)ci.y_lo, (int32_t)ci.seg, q.w0, (int32_t)(q.w1 & 0xffffu), (int32_t)(q.w1 >> 24),
                                                     (int32_t)(q.w1 >> 16 & 0xffu), max_dist_x, max_dist_y, bw, chn_pen_gap, chn_pen_skip, n_seg);
                 valid = sc0 != INT32_MIN;
@@ -251,26 +259,46 @@ __device__ void chain_fill_wide_wave(Work& W, const Opt& o, int max_dist_x, int 
                 pj = (int32_t)(q.w3 & 0xffffu) - 1;
                 marked = (q.w3 >> 16) == ((uint32_t)i & 0xffffu);
             }
-            unsigned long long todo = __ballot(valid);
-            unsigned long long mark = __ballot(marked);
-            while (todo) {
-                const int l = (int)__builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int32_t s_ = rl32(val, l);
-                if (s_ > max_f) {
-                    max_f = s_;
+            // The order-dependent part of the reference loop (strict-max update, the t[]-mark / n_skip early exit, lchain.c:176-190)
+            // over the chunk's candidates, lane 0 = the first visited.  What a candidate sees of the ones before it is a prefix
+            // maximum of their scores (is it a new best?) and a prefix OR of the marks they leave on their predecessors (is it
+            // marked?): two scans over the lanes, after which only the EVENTS -- a new best, a marked candidate that is not one
+            // -- have to be walked in order for n_skip (a long read's anchor has ~60 valid candidates per chunk and a
+            // handful of events; the walk over all of them was 11 M of a 10 kb read's 66 M cycles).  Everything before the
+            // stopping candidate is processed in full, so the prefixes are exact up to it; nothing after it is used.
+            int32_t pm = val;                                  // inclusive prefix maximum of the scores
+            unsigned long long bit = 0ULL;
+            int64_t dl_self = 0;
+            if (valid && pj >= 0) { dl_self = hi - (int64_t)pj; if (dl_self < PMX_W) bit = 1ULL << dl_self; }
+            unsigned long long po = bit;                       // inclusive prefix OR of the in-chunk marks
+            for (int o = 1; o < PMX_W; o <<= 1) {
+                const int32_t tm = __shfl_up(pm, o);
+                const uint32_t tlo = (uint32_t)__shfl_up((int)(uint32_t)po, o), thi = (uint32_t)__shfl_up((int)(uint32_t)(po >> 32), o);
+                if (lane >= o) { pm = tm > pm ? tm : pm; po |= (unsigned long long)thi << 32 | tlo; }
+            }
+            int32_t pm_ex = __shfl_up(pm, 1);
+            uint32_t elo = (uint32_t)__shfl_up((int)(uint32_t)po, 1), ehi = (uint32_t)__shfl_up((int)(uint32_t)(po >> 32), 1);
+            unsigned long long po_ex = (unsigned long long)ehi << 32 | elo;
+            if (lane == 0) { pm_ex = INT32_MIN; po_ex = 0ULL; }
+            const int32_t before = pm_ex > max_f ? pm_ex : max_f;   // the best score when this candidate is visited
+            const bool better = valid && val > before;
+            const unsigned long long mark_all = __ballot(marked);
+            const bool is_marked = valid && !better && (((mark_all | po_ex) >> lane) & 1ULL) != 0ULL;
+            const unsigned long long ev_better = __ballot(better);
+            unsigned long long events = ev_better | __ballot(is_marked);
+            int stop_lane = PMX_W;                             // the candidate the reference breaks at (none: PMX_W)
+            while (events) {
+                const int l = (int)__builtin_ctzll(events);
+                events &= events - 1;
+                if (ev_better >> l & 1ULL) {
+                    max_f = rl32(val, l);
                     max_j = hi - l;
                     if (n_skip > 0) --n_skip;
-                } else if (mark >> l & 1ULL) {
-                    if (++n_skip > max_skip) { stop = true; end_j = hi - l; break; }
-                }
-                const int32_t pp = rl32(pj, l);
-                if (pp >= 0) {
-                    const int64_t dl = hi - (int64_t)pp;   // lane that holds anchor pp in this chunk
-                    if (dl < PMX_W) mark |= 1ULL << dl;
-                    else packed_cell(pk4, (int64_t)pp).t = (uint16_t)i;
-                }
+                } else if (++n_skip > max_skip) { stop = true; end_j = hi - l; stop_lane = l; break; }
             }
+            // marks on predecessors beyond this chunk: every candidate visited before the stop leaves one (the reference breaks
+            // before marking p[j] of the candidate it stops at)
+            if (valid && pj >= 0 && dl_self >= PMX_W && lane < stop_lane) packed_cell(pk4, (int64_t)pj).t = (uint16_t)i;
         }
         // (unsigned, as lchain.c:197 compares: across a strand or target change the difference is huge and max_ii starts over)
         if (max_ii < 0 || (ai.x - x_mi) > (uint64_t)(int64_t)max_dist_x) {
@@ -292,12 +320,12 @@ __device__ void chain_fill_wide_wave(Work& W, const Opt& o, int max_dist_x, int 
             if (tmp != INT32_MIN && max_f < tmp + cm.f) { max_f = tmp + cm.f; max_j = max_ii; }
         }
         {
-            const int32_t vm = max_j >= 0 ? c[max_j].v : 0;
             ChainCell co;
             co.f = max_f;
             co.p = (int32_t)max_j;
             co.t = 0;
-            co.v = max_j >= 0 && vm > max_f ? vm : max_f;
+            co.v = max_f;   // (the reference's v[] -- the peak score along the chain -- is never read: mg_chain_backtrack takes
+                            //  the array as its output buffer, lchain.c:213; keeping it up cost one dependent HBM load per anchor)
             c[i] = co;
             ci.f = max_f;
             ci.p1 = (uint16_t)(max_j + 1);
