@@ -100,7 +100,23 @@ PMX_HD void append_cigar(Work& W, Reg& r, int n_new, Ptr<const uint32_t> ops) {
     if ((int)r.n_cigar + n_new > W.caps.max_cigar) { W.status |= PMX_ST_OVERFLOW; return; }
     Ptr<uint32_t> c = reg_cigar(W, r); PMX_LDS(c);
     uint32_t n = r.n_cigar;
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
+    // (wave kernels: the list of a long read's region lives in the wave's HBM slab -- the one join by hand, the rest 64
+    //  operations per round trip instead of a dependent read-modify-write each)
+    wave_sync();
+    const uint32_t first = ops[0];
+    int from = 0;
+    if (cg_len(first) == 0) from = 1;   // (never out of the backtrack; kept for the scalar form's sake)
+    else if (n > 0 && cg_kind(c[n - 1]) == cg_kind(first)) {
+        if (lane_id() == 0) c[n - 1] += cg_len(first) << 4;
+        from = 1;
+    }
+    for (int i = from + lane_id(); i < n_new; i += 64) c[n + (uint32_t)(i - from)] = ops[i];
+    n += (uint32_t)(n_new - from);
+    wave_sync();
+#else
     for (int i = 0; i < n_new; ++i) cg_push(c, n, cg_kind(ops[i]), cg_len(ops[i]));
+#endif
     r.n_cigar = n;
 }
 

@@ -216,9 +216,13 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
         const int cap = W.caps.max_cigar;
         bool ovf = false;
         int cur_op = -1, cur_len = 0;   // (ksw_push_cigar with the open operation kept in registers)
+        // (the walk meets the operations last to first.  A list wanted first to last is written from the end of the buffer
+        //  backwards and moved to the front 64 entries per round trip afterwards -- the buffer is in the wave's HBM slab for a
+        //  long read, and swapping it around in place was a dependent load and store per pair of entries)
+        const bool backwards = !(flag & PMX_EZ_REV_CIGAR);
         auto flush = [&]() {
             if (cur_op < 0) return;
-            if (n_cigar < cap) cig[n_cigar++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+            if (n_cigar < cap) { cig[backwards ? cap - 1 - n_cigar : n_cigar] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; ++n_cigar; }
             else ovf = true;
         };
         auto push = [&](int op, int len) {
@@ -251,8 +255,15 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
         if (j >= 0) push(1, j + 1);
         flush();
         if (ovf) W.status |= PMX_ST_OVERFLOW;
-        if (!(flag & PMX_EZ_REV_CIGAR))
-            for (int a = 0; a < n_cigar >> 1; ++a) { const uint32_t t_ = cig[a]; cig[a] = cig[n_cigar - 1 - a]; cig[n_cigar - 1 - a] = t_; }
+        if (backwards && n_cigar < cap) {   // (n_cigar == cap: the list already starts at the front)
+            __syncthreads();
+            for (int a0 = 0; a0 < n_cigar; a0 += 64) {
+                const int a = a0 + k;
+                uint32_t v = 0;
+                if (a < n_cigar) v = cig[cap - n_cigar + a];
+                if (a < n_cigar) cig[a] = v;   // (a chunk's sources lie above every entry written so far: cap - n_cigar > 0)
+            }
+        }
     }
     ez.n_cigar = n_cigar;
     __syncthreads();
