@@ -268,20 +268,78 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
         ez.reach_end = 0;
         const int flag = rq->flag, zdrop = rq->zdrop, end_bonus = rq->end_bonus;
         if (exact) {
-            for (int r = 0; r < qlen + tlen - 1; ++r) {
+            // The reference's loop over the diagonals (running maximum, Z-drop test, mqe / mte, :323-366) is sequential only in
+            // the running maximum, and that is a prefix operation: the eight lanes take eight runs of consecutive diagonals.
+            //  (1) every lane finds its run's first strict maximum; folding the runs before it (init: max = 0 at (-1, -1))
+            //      gives the state the reference has when it enters the run;
+            //  (2) with that state the lane walks its run as the reference does and notes the first diagonal where the Z-drop
+            //      fires; the smallest such diagonal over the lanes is where the reference stops (every run before it was
+            //      walked in full with the true state), and the state there is the result;
+            //  (3) mte / mqe are first maxima of H along the last column / row up to that diagonal (inclusive: the reference
+            //      updates them before the test), eight entries at a time.
+            const int gb = lane & ~(PMX_DPG_G - 1);
+            const int R = qlen + tlen - 1;
+            const int per = (R + PMX_DPG_G - 1) / PMX_DPG_G;
+            const int r0 = k * per, r1 = r0 + per < R ? r0 + per : R;
+            auto diag_max = [&](int r, int32_t& H, int& t) {
                 const int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0, en0 = tlen - 1 < r ? tlen - 1 : r;
                 const uint32_t key = diag[r];
-                const int32_t max_H = (int32_t)(key >> 10) - PMX_DPG_BIAS;
+                H = (int32_t)(key >> 10) - PMX_DPG_BIAS;
                 const uint32_t kp = 1023u - (key & 1023u);
-                int max_t;
-                if (kp == 0) max_t = en0;
-                else if (kp <= 512u) { const uint32_t v = kp - 1u; max_t = st0 + (int)((v & 127u) << 2 | v >> 7); }
-                else max_t = st0 + (int)(kp - 513u);
-                if (en0 == tlen - 1) { const int32_t h = lastcol[r - en0]; if (h > ez.mte) { ez.mte = h; ez.mte_q = r - en0; } }
-                if (r - st0 == qlen - 1) { const int32_t h = lastrow[st0]; if (h > ez.mqe) { ez.mqe = h; ez.mqe_t = st0; } }
-                if (ez_apply_zdrop(ez, max_H, r, max_t, zdrop, (int8_t)D.e2)) break;
-                if (r == qlen + tlen - 2) ez.score = lastcol[qlen - 1];
+                if (kp == 0) t = en0;
+                else if (kp <= 512u) { const uint32_t v = kp - 1u; t = st0 + (int)((v & 127u) << 2 | v >> 7); }
+                else t = st0 + (int)(kp - 513u);
+            };
+            int32_t cV = INT32_MIN;
+            int cT = -1, cR = -1;
+            for (int r = r0; r < r1; ++r) {
+                int32_t H; int t;
+                diag_max(r, H, t);
+                if (H > cV) { cV = H; cT = t; cR = r; }
             }
+            int32_t mx = 0;
+            int mt = -1, mq = -1;
+            for (int j = 0; j < PMX_DPG_G - 1; ++j) {
+                const int32_t V = __shfl(cV, gb + j);
+                const int T = __shfl(cT, gb + j), Rj = __shfl(cR, gb + j);
+                if (j < k && V > mx) { mx = V; mt = T; mq = Rj - T; }
+            }
+            int rb = INT32_MAX;
+            for (int r = r0; r < r1; ++r) {
+                int32_t H; int t;
+                diag_max(r, H, t);
+                if (H > mx) { mx = H; mt = t; mq = r - t; }
+                else if (t >= mt && r - t >= mq) {
+                    const int tl = t - mt, ql = (r - t) - mq;
+                    const int l = tl > ql ? tl - ql : ql - tl;
+                    if (zdrop >= 0 && mx - H > zdrop + l * D.e2) { rb = r; break; }
+                }
+            }
+            int r_stop = INT32_MAX, owner = PMX_DPG_G - 1;   // no Z-drop: the last lane's state is the state after the last diagonal
+            for (int j = 0; j < PMX_DPG_G; ++j) {
+                const int rj = __shfl(rb, gb + j);
+                if (rj < r_stop) { r_stop = rj; owner = j; }
+            }
+            ez.max = (uint32_t)__shfl(mx, gb + owner);
+            ez.max_t = __shfl(mt, gb + owner);
+            ez.max_q = __shfl(mq, gb + owner);
+            ez.zdropped = r_stop != INT32_MAX ? 1 : 0;
+            const int r_lim = ez.zdropped ? r_stop : R - 1;
+            {
+                int nq = r_lim - tlen + 2; nq = nq < qlen ? nq : qlen;      // rows whose last-column cell lies on a diagonal <= r_lim
+                int nt = r_lim - qlen + 2; nt = nt < tlen ? nt : tlen;      // columns whose last-row cell does
+                int32_t be = PMX_KSW_NEG_INF, bq = PMX_KSW_NEG_INF;
+                int be_at = -1, bq_at = -1;
+                for (int q_ = k; q_ < nq; q_ += PMX_DPG_G) { const int32_t h = lastcol[q_]; if (h > be) { be = h; be_at = q_; } }
+                for (int t_ = k; t_ < nt; t_ += PMX_DPG_G) { const int32_t h = lastrow[t_]; if (h > bq) { bq = h; bq_at = t_; } }
+                for (int j = 0; j < PMX_DPG_G; ++j) {   // first maximum = the largest value at the smallest position
+                    const int32_t e_ = __shfl(be, gb + j), q2_ = __shfl(bq, gb + j);
+                    const int ea = __shfl(be_at, gb + j), qa = __shfl(bq_at, gb + j);
+                    if (ea >= 0 && (e_ > ez.mte || (e_ == ez.mte && ea < ez.mte_q))) { ez.mte = e_; ez.mte_q = ea; }
+                    if (qa >= 0 && (q2_ > ez.mqe || (q2_ == ez.mqe && qa < ez.mqe_t))) { ez.mqe = q2_; ez.mqe_t = qa; }
+                }
+            }
+            if (!ez.zdropped) ez.score = lastcol[qlen - 1];
         } else ez.score = lastcol[qlen - 1];   // the approximate maximum follows one path to the corner: H there (:367-383)
         if (D.prof) pt3 = (unsigned long long)clock64();
         // ksw_backtrack (ksw2.h:127-162): no cell of the walk lies outside the band here
