@@ -167,7 +167,7 @@ __global__ void k_meta_column_digest(const uint16_t* __restrict__ score, int64_t
     }
 }
 
-// EM pass 1: denom[j] = sum_i P(j, i) * props[i] over the kept columns, in column order (lanes stride the columns, a fixed
+// EM pass 1: denom[j] = 1 / sum_i P(j, i) * props[i] over the kept columns, in column order (lanes stride the columns, a fixed
 // butterfly adds the lanes); llh[j] = weight[j] * log(denom[j]).  A wave per read.
 __global__ void k_meta_denoms(const uint16_t* __restrict__ score, int n_cand, const int* __restrict__ cols, int n_cols, const double* __restrict__ props,
                               const int64_t* __restrict__ rows, int64_t n_rows, const uint32_t* __restrict__ tab_off, const double* __restrict__ tab,
@@ -179,9 +179,22 @@ __global__ void k_meta_denoms(const uint16_t* __restrict__ score, int n_cand, co
         const uint16_t* srow = score + (size_t)r * (size_t)n_cand;
         const double* t = tab + tab_off[j];
         double acc = 0.0;
-        for (int i = lane; i < n_cols; i += 64) acc += t[srow[cols[i]]] * props[i];
+        // (same order of additions; four columns' loads are in flight at a time -- each entry is a chain of three dependent loads,
+        //  and one at a time the pass ran at an eighth of the HBM rate)
+        int i = lane;
+        for (; i + 192 < n_cols; i += 256) {
+            const int c0 = cols[i], c1 = cols[i + 64], c2 = cols[i + 128], c3 = cols[i + 192];
+            const uint16_t s0 = srow[c0], s1 = srow[c1], s2 = srow[c2], s3 = srow[c3];
+            const double p0 = props[i], p1 = props[i + 64], p2 = props[i + 128], p3 = props[i + 192];
+            const double t0 = t[s0], t1 = t[s1], t2 = t[s2], t3 = t[s3];
+            acc += t0 * p0;
+            acc += t1 * p1;
+            acc += t2 * p2;
+            acc += t3 * p3;
+        }
+        for (; i < n_cols; i += 64) acc += t[srow[cols[i]]] * props[i];
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) { denom[j] = acc; llh[j] = weight[j] * log(acc); }
+        if (lane == 0) { denom[j] = 1.0 / acc; llh[j] = weight[j] * log(acc); }   // (the reciprocal: pass 2 multiplies every entry of the row by it -- a division per entry before)
     }
 }
 
@@ -196,10 +209,19 @@ __global__ void k_meta_colsum(const uint16_t* __restrict__ score, int n_cand, co
     const int c = cols[i];
     const double pi = props[i];
     double acc = 0.0;
-    for (int64_t j = j0; j < j1; ++j) {
-        const double inv = 1.0 / denom[j];
-        acc += weight[j] * (tab[tab_off[j] + score[(size_t)rows[j] * (size_t)n_cand + (size_t)c]] * pi * inv);
+    int64_t j = j0;
+    for (; j + 3 < j1; j += 4) {   // (same order of additions, four reads' loads in flight)
+        const int64_t r0 = rows[j], r1 = rows[j + 1], r2 = rows[j + 2], r3 = rows[j + 3];
+        const uint32_t o0 = tab_off[j], o1 = tab_off[j + 1], o2 = tab_off[j + 2], o3 = tab_off[j + 3];
+        const uint16_t s0 = score[(size_t)r0 * (size_t)n_cand + (size_t)c], s1 = score[(size_t)r1 * (size_t)n_cand + (size_t)c],
+                       s2 = score[(size_t)r2 * (size_t)n_cand + (size_t)c], s3 = score[(size_t)r3 * (size_t)n_cand + (size_t)c];
+        const double t0 = tab[o0 + s0], t1 = tab[o1 + s1], t2 = tab[o2 + s2], t3 = tab[o3 + s3];
+        acc += weight[j] * (t0 * pi * denom[j]);
+        acc += weight[j + 1] * (t1 * pi * denom[j + 1]);
+        acc += weight[j + 2] * (t2 * pi * denom[j + 2]);
+        acc += weight[j + 3] * (t3 * pi * denom[j + 3]);
     }
+    for (; j < j1; ++j) acc += weight[j] * (tab[tab_off[j] + score[(size_t)rows[j] * (size_t)n_cand + (size_t)c]] * pi * denom[j]);   // denom = 1 / denominator
     part[(size_t)blockIdx.y * (size_t)n_cols + (size_t)i] = acc;
 }
 
@@ -211,15 +233,17 @@ __global__ void k_meta_fold(const double* __restrict__ part, int n_chunks, int n
     out[i] = acc * scale;
 }
 
-// sum of v[0..n) in index order by one thread (n = reads: once per likelihood evaluation; a fixed order, not a fast one)
+// sums of 1,024 contiguous values each, a wave per block in a FIXED order (lane l adds v[l], v[l + 64], ... in order, a fixed
+// butterfly adds the lanes); the host adds the block sums in order.  (One thread per block took 104 us per likelihood.)
 __global__ void k_meta_sum_blocks(const double* __restrict__ v, int64_t n, double* block_sums) {
-    // 1024 contiguous values per thread-block entry, each summed in order by one thread; the host adds the entries in order
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t lo = b * 1024, hi = lo + 1024 < n ? lo + 1024 : n;
     if (lo >= n) return;
     double acc = 0.0;
-    for (int64_t i = lo; i < hi; ++i) acc += v[i];
-    block_sums[b] = acc;
+    for (int64_t i = lo + lane; i < hi; i += 64) acc += v[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) block_sums[b] = acc;
 }
 }  // namespace
 
@@ -582,7 +606,7 @@ int pmx_meta_em(pmx_ctx* ctx, pmx_meta* m, const pmx_meta_params* mp) {
     PMX_HIP(hipMemcpy(d_tab_off.p, tab_off.data(), sizeof(uint32_t) * (size_t)n_rows, hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(d_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
     PMX_HIP(hipMemcpy(d_weight.p, weight.data(), sizeof(double) * (size_t)n_rows, hipMemcpyHostToDevice));
-    const int64_t chunk = 2048;
+    const int64_t chunk = 256;   // reads per partial column sum (2,048: 2,200 waves for 3,000 columns x 90k reads, each a serial walk: 373 us per pass)
     const int n_chunks = (int)((n_rows + chunk - 1) / chunk);
     const int64_t n_bsum = (n_rows + 1023) / 1024;
     d_bsum.alloc((size_t)n_bsum);
@@ -611,7 +635,7 @@ int pmx_meta_em(pmx_ctx* ctx, pmx_meta* m, const pmx_meta_params* mp) {
         };
         auto log_likelihood = [&](const std::vector<double>& pr) {                       // getExp (:4385-4388)
             denoms(pr);
-            hipLaunchKernelGGL(k_meta_sum_blocks, dim3((unsigned)((n_bsum + 63) / 64)), dim3(64), 0, st, d_llh.p, n_rows, d_bsum.p);
+            hipLaunchKernelGGL(k_meta_sum_blocks, dim3((unsigned)((n_bsum + 3) / 4)), dim3(256), 0, st, d_llh.p, n_rows, d_bsum.p);
             PMX_HIP(hipMemcpyAsync(h_bsum.data(), d_bsum.p, sizeof(double) * (size_t)n_bsum, hipMemcpyDeviceToHost, st));
             PMX_HIP(hipStreamSynchronize(st));
             double s = 0.0;
