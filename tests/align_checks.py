@@ -221,3 +221,26 @@ def smoke_align(ctx, pm, genome, reads):
     bad = compare_results(got, want)
     assert not bad, bad[:5]
     print("smoke: align OK (%d pairs, %d mapped)" % (len(want), sum(w["mapped"] for w in want)))
+    # the DP kernel on its own: a few requests of each call shape through the grouped service vs ksw_extd2_sse of the reference
+    rng = np.random.default_rng(3)
+    sc = al.scoring()
+    mat = orc.simple_mat(sc["a"], sc["b"], sc["sc_ambi"])
+    qs, ts, fl = [], [], []
+    for i in range(96):
+        t = [int(x) for x in rng.integers(0, 4, int(rng.integers(20, 129)))]
+        q = [int(c) if rng.random() > 0.06 else int((c + 1) % 4) for c in t[:int(rng.integers(10, len(t) + 1))]]
+        if i % 5 == 0 and len(q) > 12:
+            del q[6:9]
+        qs.append(q); ts.append(t); fl.append((0x08, 0x40, 0xc2)[i % 3])
+    res, _ = al.dp_batch(qs, ts, -1, sc["zdrop"], sc["end_bonus"], fl)
+    n_ok = 0
+    for i in range(len(qs)):
+        w = orc.ref_ksw_extd2(qs[i], ts[i], mat, sc["q"], sc["e"], sc["q2"], sc["e2"], -1, sc["zdrop"], sc["end_bonus"], fl[i])
+        if not res[i]["served"]:
+            assert w["n_cigar"] > 20, ("DP request not served", i)
+            continue
+        n_ok += 1
+        for f in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "n_cigar", "reach_end"):
+            assert int(res[i][f]) == w[f], ("DP kernel differs from ksw_extd2_sse", i, f, int(res[i][f]), w[f])
+        assert [int(x) for x in res[i]["cigar"][:w["n_cigar"]]] == w["cigar"], ("DP kernel CIGAR differs", i)
+    print("smoke: DP service OK (%d requests equal ksw_extd2_sse)" % n_ok)
