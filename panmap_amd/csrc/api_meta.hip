@@ -171,7 +171,8 @@ __global__ void k_meta_column_digest(const uint16_t* __restrict__ score, int64_t
 // butterfly adds the lanes); llh[j] = weight[j] * log(denom[j]).  A wave per read.
 __global__ void k_meta_denoms(const uint16_t* __restrict__ score, int n_cand, const int* __restrict__ cols, int n_cols, const double* __restrict__ props,
                               const int64_t* __restrict__ rows, int64_t n_rows, const uint32_t* __restrict__ tab_off, const double* __restrict__ tab,
-                              const double* __restrict__ weight, double* denom, double* llh) {
+                              const double* __restrict__ weight, double* denom, double* llh, const int* done) {
+    if (done && *done) return;   // (the SQUAREM loop runs ahead of the host: launches queued past convergence do nothing)
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t j = wave; j < n_rows; j += n_waves) {
@@ -202,7 +203,9 @@ __global__ void k_meta_denoms(const uint16_t* __restrict__ score, int n_cand, co
 // A thread per column; the chunks are added in chunk order by k_meta_fold.
 __global__ void k_meta_colsum(const uint16_t* __restrict__ score, int n_cand, const int* __restrict__ cols, int n_cols, const double* __restrict__ props,
                               const int64_t* __restrict__ rows, int64_t n_rows, int64_t chunk, const uint32_t* __restrict__ tab_off,
-                              const double* __restrict__ tab, const double* __restrict__ weight, const double* __restrict__ denom, double* part) {
+                              const double* __restrict__ tab, const double* __restrict__ weight, const double* __restrict__ denom, double* part,
+                              const int* done) {
+    if (done && *done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cols) return;
     const int64_t j0 = (int64_t)blockIdx.y * chunk, j1 = j0 + chunk < n_rows ? j0 + chunk : n_rows;
@@ -225,17 +228,27 @@ __global__ void k_meta_colsum(const uint16_t* __restrict__ score, int n_cand, co
     part[(size_t)blockIdx.y * (size_t)n_cols + (size_t)i] = acc;
 }
 
-__global__ void k_meta_fold(const double* __restrict__ part, int n_chunks, int n_cols, double scale, double* out) {
+__global__ void k_meta_fold(const double* __restrict__ part, int n_chunks, int n_cols, double scale, double* out, const int* done) {
+    if (done && *done) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cols) return;
     double acc = 0.0;
-    for (int c = 0; c < n_chunks; ++c) acc += part[(size_t)c * (size_t)n_cols + (size_t)i];
+    int c = 0;
+    for (; c + 8 <= n_chunks; c += 8) {   // (same order of additions, eight loads in flight)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u) * (size_t)n_cols + (size_t)i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; c < n_chunks; ++c) acc += part[(size_t)c * (size_t)n_cols + (size_t)i];
     out[i] = acc * scale;
 }
 
 // sums of 1,024 contiguous values each, a wave per block in a FIXED order (lane l adds v[l], v[l + 64], ... in order, a fixed
 // butterfly adds the lanes); the host adds the block sums in order.  (One thread per block took 104 us per likelihood.)
-__global__ void k_meta_sum_blocks(const double* __restrict__ v, int64_t n, double* block_sums) {
+__global__ void k_meta_sum_blocks(const double* __restrict__ v, int64_t n, double* block_sums, const int* done) {
+    if (done && *done) return;
     const int lane = threadIdx.x & 63;
     const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t lo = b * 1024, hi = lo + 1024 < n ? lo + 1024 : n;
@@ -244,6 +257,102 @@ __global__ void k_meta_sum_blocks(const double* __restrict__ v, int64_t n, doubl
     for (int64_t i = lo + lane; i < hi; i += 64) acc += v[i];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) block_sums[b] = acc;
+}
+
+// ---- the SQUAREM iteration's vector arithmetic on the device (runSquareEM, src/mgsr.cpp:4394-4443).  The vectors have a few
+// thousand entries; every sum runs in index order on one thread, exactly as the host loop they replace did, so the results are
+// the same numbers -- what is gone is four host round trips per iteration.  One block of 256 threads each.
+struct EmCtl {
+    double llh, llh2, llh_sq, difference;
+    int done, iterations;
+};
+// v <- v with non-positive entries raised to 1e-12, divided by its sum (normalizeProps, :4374-4383); src may equal dst
+// (the in-order sums run on one thread over a copy of the vector in LDS: straight from global memory a dependent load per
+//  element made each of them ~130 us)
+__device__ __forceinline__ double em_sum_in_order(const double* lds_v, int n) {
+    double s = 0.0;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const double a0 = lds_v[i], a1 = lds_v[i + 1], a2 = lds_v[i + 2], a3 = lds_v[i + 3], a4 = lds_v[i + 4], a5 = lds_v[i + 5], a6 = lds_v[i + 6], a7 = lds_v[i + 7];
+        s += a0; s += a1; s += a2; s += a3; s += a4; s += a5; s += a6; s += a7;
+    }
+    for (; i < n; ++i) s += lds_v[i];
+    return s;
+}
+__global__ void k_em_normalize(const double* src, double* dst, int n, const EmCtl* ctl, double* work) {
+    if (ctl->done) return;
+    extern __shared__ double em_lds_[];
+    double* em_lds = work ? work : em_lds_;   // (more columns than LDS holds: a scratch vector in global memory)
+    __shared__ double s_sum;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double x = src[i]; em_lds[i] = x <= 0 ? 1e-12 : x; }
+    __syncthreads();
+    if (threadIdx.x == 0) s_sum = em_sum_in_order(em_lds, n);
+    __syncthreads();
+    const double s = s_sum;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = em_lds[i] / s;
+}
+__global__ void k_em_copy(const double* src, double* dst, int n, const EmCtl* ctl) {
+    if (ctl->done) return;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+// the squared-extrapolation point: alpha = -|r| / |v|, sq = p0 - 2 alpha r + alpha^2 v, normalised
+__global__ void k_em_extrapolate(const double* p0, const double* p1, const double* p2, double* sq, int n, const EmCtl* ctl, double* work) {
+    if (ctl->done) return;
+    extern __shared__ double em_lds_[];   // r*r, then v*v, then the extrapolated point: n entries each
+    double* em_lds = work ? work : em_lds_;
+    __shared__ double s_alpha, s_sum;
+    double* rr = em_lds;
+    double* vv = em_lds + n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double r = p1[i] - p0[i], v = (p2[i] - p1[i]) - r;
+        rr[i] = r * r;
+        vv[i] = v * v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_alpha = -sqrt(em_sum_in_order(rr, n)) / sqrt(em_sum_in_order(vv, n));
+    __syncthreads();
+    const double alpha = s_alpha;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double r = p1[i] - p0[i], v = (p2[i] - p1[i]) - r;
+        const double x = p0[i] - 2.0 * alpha * r + alpha * alpha * v;
+        rr[i] = x <= 0 ? 1e-12 : x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_sum = em_sum_in_order(rr, n);
+    __syncthreads();
+    const double s = s_sum;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sq[i] = rr[i] / s;
+}
+// the block sums of a likelihood pass, added in order (getExp, :4385-4388): which = 0 -> llh2, 1 -> llh_sq
+__global__ void k_em_store_llh(const double* bsum, int64_t n_bsum, EmCtl* ctl, int which) {
+    if (ctl->done || threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int64_t i = 0; i < n_bsum; ++i) s += bsum[i];
+    if (which == 0) ctl->llh2 = s; else ctl->llh_sq = s;
+}
+// keep the extrapolated point unless it lost likelihood; count the iteration; test convergence (:4424-4441)
+__global__ void k_em_choose(const double* p0, const double* p2, const double* sq, double* props, int n, EmCtl* ctl, double convergence, double delta_threshold) {
+    if (ctl->done) return;
+    __shared__ int s_take_sq;
+    if (threadIdx.x == 0) s_take_sq = ctl->llh_sq > ctl->llh2 - convergence ? 1 : 0;
+    __syncthreads();
+    const double* from = s_take_sq ? sq : p2;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) props[i] = from[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double now = s_take_sq ? ctl->llh_sq : ctl->llh2;
+        const double difference = now - ctl->llh;
+        ctl->difference = difference;
+        ctl->llh = now;
+        ++ctl->iterations;
+        if (delta_threshold == 0) {
+            if (fabs(difference) < convergence) ctl->done = 1;
+        } else {
+            double mc = 0.0;
+            for (int i = 0; i < n; ++i) { const double d = fabs(from[i] - p0[i]); mc = mc > d ? mc : d; }   // (a maximum: any order)
+            if (mc < delta_threshold) ctl->done = 1;
+        }
+    }
 }
 }  // namespace
 
@@ -619,65 +728,69 @@ int pmx_meta_em(pmx_ctx* ctx, pmx_meta* m, const pmx_meta_params* mp) {
         const int n_cols = (int)cols.size();
         d_cols.ensure((size_t)n_cols); d_props.ensure((size_t)n_cols); d_out.ensure((size_t)n_cols); d_part.ensure((size_t)n_chunks * (size_t)n_cols);
         PMX_HIP(hipMemcpy(d_cols.p, cols.data(), sizeof(int) * (size_t)n_cols, hipMemcpyHostToDevice));
-        auto denoms = [&](const std::vector<double>& pr) {
-            PMX_HIP(hipMemcpyAsync(d_props.p, pr.data(), sizeof(double) * (size_t)n_cols, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_meta_denoms, dim3(grid_for(n_rows * 64, 256, ctx->n_cu * 8)), dim3(256), 0, st, m->score.p, n_cand, d_cols.p, n_cols, d_props.p,
-                               d_rows.p, n_rows, d_tab_off.p, d_tab.p, d_weight.p, d_denom.p, d_llh.p);
-        };
-        auto em_step = [&](const std::vector<double>& from, std::vector<double>& to) {   // updateProps (src/mgsr.cpp:4341-4372)
-            denoms(from);
-            hipLaunchKernelGGL(k_meta_colsum, dim3((n_cols + 63) / 64, n_chunks), dim3(64), 0, st, m->score.p, n_cand, d_cols.p, n_cols, d_props.p, d_rows.p,
-                               n_rows, chunk, d_tab_off.p, d_tab.p, d_weight.p, d_denom.p, d_part.p);
-            hipLaunchKernelGGL(k_meta_fold, dim3((n_cols + 63) / 64), dim3(64), 0, st, d_part.p, n_chunks, n_cols, inv_total, d_out.p);
-            to.resize((size_t)n_cols);
-            PMX_HIP(hipMemcpyAsync(to.data(), d_out.p, sizeof(double) * (size_t)n_cols, hipMemcpyDeviceToHost, st));
-            PMX_HIP(hipStreamSynchronize(st));
-        };
-        auto log_likelihood = [&](const std::vector<double>& pr) {                       // getExp (:4385-4388)
-            denoms(pr);
-            hipLaunchKernelGGL(k_meta_sum_blocks, dim3((unsigned)((n_bsum + 3) / 4)), dim3(256), 0, st, d_llh.p, n_rows, d_bsum.p);
-            PMX_HIP(hipMemcpyAsync(h_bsum.data(), d_bsum.p, sizeof(double) * (size_t)n_bsum, hipMemcpyDeviceToHost, st));
-            PMX_HIP(hipStreamSynchronize(st));
-            double s = 0.0;
-            for (double v : h_bsum) s += v;
-            return s;
-        };
-        auto normalize = [&](std::vector<double>& v) {                                   // normalizeProps (:4374-4383)
-            double s = 0.0;
-            for (double& x : v) { if (x <= 0) x = 1e-12; s += x; }
-            for (double& x : v) x /= s;
-        };
+        // The whole SQUAREM loop stays on the device: the proportion vectors never leave it, the small vector arithmetic runs in
+        // single-block kernels with the host loop's own order of operations, and the host only looks at the convergence flag
+        // every 16 iterations (launches queued past convergence return at once).  Per iteration: 6 passes over the score
+        // matrix (4 x k_meta_denoms, 2 x k_meta_colsum) and 13 small launches; before, 4 host round trips.
+        DevBuf<double> d_p0, d_p1, d_p2, d_sq;
+        DevBuf<EmCtl> d_ctl;
+        d_p0.alloc((size_t)n_cols); d_p1.alloc((size_t)n_cols); d_p2.alloc((size_t)n_cols); d_sq.alloc((size_t)n_cols);
+        d_ctl.alloc(1);
+        EmCtl h_ctl;
+        memset(&h_ctl, 0, sizeof(h_ctl));
+        PMX_HIP(hipMemcpyAsync(d_ctl.p, &h_ctl, sizeof(h_ctl), hipMemcpyHostToDevice, st));
         props.assign((size_t)n_cols, 1.0 / (double)n_cols);
-        std::vector<double> p0, p1, p2, sq((size_t)n_cols);
-        double llh = 0.0;
-        for (int iter = 0; iter < mp->em_max_iterations; ++iter) {                        // runSquareEM (:4394-4443)
-            p0 = props;
-            em_step(p0, p1); normalize(p1);
-            em_step(p1, p2); normalize(p2);
-            double rn = 0.0, vn = 0.0;
-            for (int i = 0; i < n_cols; ++i) {
-                const double r = p1[i] - p0[i], v = (p2[i] - p1[i]) - r;
-                rn += r * r; vn += v * v;
-            }
-            const double alpha = -std::sqrt(rn) / std::sqrt(vn);
-            for (int i = 0; i < n_cols; ++i) {
-                const double r = p1[i] - p0[i], v = (p2[i] - p1[i]) - r;
-                sq[(size_t)i] = p0[i] - 2.0 * alpha * r + alpha * alpha * v;
-            }
-            normalize(sq);
-            const double llh2 = log_likelihood(p2), llh_sq = log_likelihood(sq);
-            double difference;
-            if (llh_sq > llh2 - mp->em_convergence) { props = sq; difference = llh_sq - llh; llh = llh_sq; }
-            else { props = p2; difference = llh2 - llh; llh = llh2; }
-            ++m->em_iterations;
-            if (mp->em_delta_threshold == 0) {
-                if (std::fabs(difference) < mp->em_convergence) break;
-            } else {
-                double mc = 0.0;
-                for (int i = 0; i < n_cols; ++i) mc = std::max(mc, std::fabs(props[i] - p0[i]));
-                if (mc < mp->em_delta_threshold) break;
-            }
+        PMX_HIP(hipMemcpyAsync(d_props.p, props.data(), sizeof(double) * (size_t)n_cols, hipMemcpyHostToDevice, st));
+        const int* d_done = &d_ctl.p->done;
+        // the in-order sums of the small kernels read a copy of the vector in LDS (2 x n_cols doubles at most); beyond 160 KB a
+        // scratch vector in global memory stands in
+        DevBuf<double> d_em_work;
+        double* em_work = nullptr;
+        const size_t em_lds = 2 * sizeof(double) * (size_t)n_cols;
+        if (em_lds > (size_t)160 * 1024) { d_em_work.alloc(2 * (size_t)n_cols); em_work = d_em_work.p; }
+        else if (em_lds > (size_t)64 * 1024) {
+            PMX_HIP(hipFuncSetAttribute((const void*)k_em_normalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds));
+            PMX_HIP(hipFuncSetAttribute((const void*)k_em_extrapolate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)em_lds));
         }
+        auto denoms = [&](const double* pr) {
+            hipLaunchKernelGGL(k_meta_denoms, dim3(grid_for(n_rows * 64, 256, ctx->n_cu * 8)), dim3(256), 0, st, m->score.p, n_cand, d_cols.p, n_cols, pr,
+                               d_rows.p, n_rows, d_tab_off.p, d_tab.p, d_weight.p, d_denom.p, d_llh.p, d_done);
+        };
+        auto em_step = [&](const double* from, double* to) {   // updateProps (src/mgsr.cpp:4341-4372) + normalizeProps
+            denoms(from);
+            hipLaunchKernelGGL(k_meta_colsum, dim3((n_cols + 63) / 64, n_chunks), dim3(64), 0, st, m->score.p, n_cand, d_cols.p, n_cols, from, d_rows.p,
+                               n_rows, chunk, d_tab_off.p, d_tab.p, d_weight.p, d_denom.p, d_part.p, d_done);
+            hipLaunchKernelGGL(k_meta_fold, dim3((n_cols + 63) / 64), dim3(64), 0, st, d_part.p, n_chunks, n_cols, inv_total, d_out.p, d_done);
+            hipLaunchKernelGGL(k_em_normalize, dim3(1), dim3(256), em_work ? 0 : sizeof(double) * (size_t)n_cols, st, d_out.p, to, n_cols, d_ctl.p, em_work);
+        };
+        auto log_likelihood = [&](const double* pr, int which) {                          // getExp (:4385-4388)
+            denoms(pr);
+            hipLaunchKernelGGL(k_meta_sum_blocks, dim3((unsigned)((n_bsum + 3) / 4)), dim3(256), 0, st, d_llh.p, n_rows, d_bsum.p, d_done);
+            hipLaunchKernelGGL(k_em_store_llh, dim3(1), dim3(64), 0, st, d_bsum.p, n_bsum, d_ctl.p, which);
+        };
+        const int look_every = 16;
+        for (int iter = 0; iter < mp->em_max_iterations;) {                               // runSquareEM (:4394-4443)
+            const int batch = std::min(look_every, mp->em_max_iterations - iter);
+            for (int b = 0; b < batch; ++b) {
+                hipLaunchKernelGGL(k_em_copy, dim3(1), dim3(256), 0, st, d_props.p, d_p0.p, n_cols, d_ctl.p);
+                em_step(d_p0.p, d_p1.p);
+                em_step(d_p1.p, d_p2.p);
+                hipLaunchKernelGGL(k_em_extrapolate, dim3(1), dim3(256), em_work ? 0 : 2 * sizeof(double) * (size_t)n_cols, st, d_p0.p, d_p1.p, d_p2.p, d_sq.p, n_cols, d_ctl.p, em_work);
+                log_likelihood(d_p2.p, 0);
+                log_likelihood(d_sq.p, 1);
+                hipLaunchKernelGGL(k_em_choose, dim3(1), dim3(256), 0, st, d_p0.p, d_p2.p, d_sq.p, d_props.p, n_cols, d_ctl.p, mp->em_convergence,
+                                   mp->em_delta_threshold);
+            }
+            PMX_HIP(hipGetLastError());
+            PMX_HIP(hipMemcpyAsync(&h_ctl, d_ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
+            PMX_HIP(hipStreamSynchronize(st));
+            iter += batch;
+            if (h_ctl.done) break;
+        }
+        PMX_HIP(hipMemcpyAsync(props.data(), d_props.p, sizeof(double) * (size_t)n_cols, hipMemcpyDeviceToHost, st));
+        PMX_HIP(hipStreamSynchronize(st));
+        m->em_iterations += h_ctl.iterations;
+        const double llh = h_ctl.llh;
         m->llh = llh;
         ++m->em_rounds;
         // removeLowPropNodes (:4445-4490)
