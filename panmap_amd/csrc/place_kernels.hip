@@ -429,6 +429,21 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
 //  * the syncmer / k-min-mer bookkeeping is predicated instead of branched wherever that is cheap.
 // Results are identical to k_seed_histogram (same hashes, same syncmers, same counts).
 __device__ __forceinline__ constexpr uint64_t c_rotl64(uint64_t x, unsigned r) { return (r & 63u) ? (x << (r & 63u)) | (x >> (64u - (r & 63u))) : x; }
+// the same rotation at run time, by a compile-time amount, as two v_alignbit_b32 on the halves (the shift-and-or form compiles
+// to a 64-bit shift -- a slow-rate instruction on this chip -- plus a 32-bit shift and an or: four rotations per base in the
+// seeding loop)
+template <unsigned R>
+__device__ __forceinline__ uint64_t d_rotl64(uint64_t x) {
+    constexpr unsigned r = R & 63u;
+    if (r == 0) return x;
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (r >= 32) { const uint32_t t_ = lo; lo = hi; hi = t_; }   // rotate by 32: swap the halves
+    constexpr unsigned q = r & 31u;
+    if (q == 0) return (uint64_t)hi << 32 | lo;
+    const uint32_t nlo = __builtin_amdgcn_alignbit(lo, hi, 32u - q);   // (lo << q) | (hi >> (32 - q))
+    const uint32_t nhi = __builtin_amdgcn_alignbit(hi, lo, 32u - q);
+    return (uint64_t)nhi << 32 | nlo;
+}
 __device__ __forceinline__ constexpr uint64_t c_hb(uint32_t c) {
     return c == 0 ? 0x3c8bfbb395c60474ULL : c == 1 ? 0x3193c18562a02b4cULL : c == 2 ? 0x20323ed082572324ULL : 0x295549f54be24456ULL;
 }
@@ -536,10 +551,11 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
         const int valid_start = sp.trim_start, valid_end = ilen - sp.trim_end - K;
         const int n_words = (ilen + 31) >> 5;
         uint64_t fS = 0, rS = 0, fK = 0, rK = 0;
-        uint64_t hist2 = 0;            // last 32 base codes, newest in bits 1:0
+        uint32_t hist_lo = 0, hist_hi = 0;   // last 32 base codes, newest in bits 1:0 of hist_lo (two 32-bit halves: 64-bit shifts are slow-rate)
         uint32_t hista = 0xffffffffu;  // last 32 ambiguity bits, newest in bit 0; all set: no base leaves the first windows
         int last_amb = -1;
-        uint64_t cw = 0, cw_next = ilen > 0 ? rw[0] : 0;   // the next 32 bases are requested while these are processed
+        uint32_t cw_lo = 0, cw_hi = 0;                       // the 32 bases being processed, next one in bits 1:0 of cw_lo
+        uint64_t cw_next = ilen > 0 ? rw[0] : 0;             // the next 32 bases are requested while these are processed
         uint32_t ca = 0, ca_next = ilen > 0 ? ra[0] : 0;
         uint64_t F = 0, R = 0;  // k-min-mer rolling hashes
         int n_sync = 0;
@@ -559,14 +575,15 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
         uint64_t n_hb = 0, n_cS = 0, n_cK = 0, n_oS = 0, n_oSr = 0, n_oK = 0, n_oKr = 0;
         auto fetch_base = [&](int i) {
             if ((i & 31) == 0) {
-                cw = cw_next; ca = ca_next;
+                cw_lo = (uint32_t)cw_next; cw_hi = (uint32_t)(cw_next >> 32); ca = ca_next;
                 if ((i >> 5) + 1 < n_words) { cw_next = rw[(i >> 5) + 1]; ca_next = ra[(i >> 5) + 1]; }
             }
-            n_code = (uint32_t)(cw & 3u);
+            n_code = cw_lo & 3u;
             n_am = ca & 1u;
-            cw >>= 2; ca >>= 1;
-            const uint32_t ocS = (uint32_t)(hist2 >> (2 * (S - 1))) & 3u, oaS = (hista >> (S - 1)) & 1u;
-            const uint32_t ocK = (uint32_t)(hist2 >> (2 * (K - 1))) & 3u, oaK = (hista >> (K - 1)) & 1u;
+            cw_lo = __builtin_amdgcn_alignbit(cw_hi, cw_lo, 2); cw_hi >>= 2; ca >>= 1;
+            constexpr unsigned bS = 2u * (unsigned)(S - 1), bK = 2u * (unsigned)(K - 1);   // where the base that leaves the s-mer / k-mer sits
+            const uint32_t ocS = ((bS < 32u ? hist_lo : hist_hi) >> (bS & 31u)) & 3u, oaS = (hista >> (S - 1)) & 1u;
+            const uint32_t ocK = ((bK < 32u ? hist_lo : hist_hi) >> (bK & 31u)) & 3u, oaK = (hista >> (K - 1)) & 1u;
             const uint64_t* tc = hb_tab + (n_am ? 4u : n_code);   // tables: 0 hb, 1 comp << S-1, 2 comp << K-1, 3 << S, 4 comp << 63, 5 << K
             const uint64_t* tS = hb_tab + (oaS ? 4u : ocS);
             const uint64_t* tK = hb_tab + (oaK ? 4u : ocK);
@@ -576,11 +593,12 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
         };
         auto step_base = [&](int i) {
             last_amb = n_am ? i : last_amb;
-            fS = c_rotl64(fS, 1) ^ n_oS ^ n_hb;
-            rS = c_rotl64(rS, 63) ^ n_oSr ^ n_cS;
-            fK = c_rotl64(fK, 1) ^ n_oK ^ n_hb;
-            rK = c_rotl64(rK, 63) ^ n_oKr ^ n_cK;
-            hist2 = (hist2 << 2) | n_code;
+            fS = d_rotl64<1>(fS) ^ n_oS ^ n_hb;
+            rS = d_rotl64<63>(rS) ^ n_oSr ^ n_cS;
+            fK = d_rotl64<1>(fK) ^ n_oK ^ n_hb;
+            rK = d_rotl64<63>(rK) ^ n_oKr ^ n_cK;
+            hist_hi = __builtin_amdgcn_alignbit(hist_hi, hist_lo, 30);   // (hist_hi << 2) | (hist_lo >> 30)
+            hist_lo = (hist_lo << 2) | n_code;
             hista = (hista << 1) | n_am;
             fetch_base(i + 1);
         };
@@ -645,13 +663,13 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
                             have = true;
                             if (l > 1) {
                                 if (n_sync <= l) {
-                                    F = c_rotl64(F, rot_k) ^ h;
+                                    F = d_rotl64<rot_k>(F) ^ h;
                                     R ^= rotl64(h, (unsigned)(K * (n_sync - 1)) & 63u);
                                     have = n_sync == l;
                                 } else {
                                     const uint64_t prev = l == 2 ? sy1 : l == 3 ? sy2 : sy3;   // the syncmer that leaves the k-min-mer
-                                    F = c_rotl64(F, rot_k) ^ c_rotl64(prev, rot_kl) ^ h;
-                                    R = c_rotl64(R, 64u - rot_k) ^ c_rotl64(prev, 64u - rot_k) ^ c_rotl64(h, rot_kl1);
+                                    F = d_rotl64<rot_k>(F) ^ d_rotl64<rot_kl>(prev) ^ h;
+                                    R = d_rotl64<64u - rot_k>(R) ^ d_rotl64<64u - rot_k>(prev) ^ d_rotl64<rot_kl1>(h);
                                 }
                                 sy3 = sy2; sy2 = sy1; sy1 = sy0; sy0 = h;
                                 have = have && F != R;
