@@ -628,10 +628,10 @@ PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
             if (e < n_k) {
                 const int i = e + k - 1;
                 const int c = base_at(i);
-                kmer0 = (shl64c<2>(kmer0) | (uint64_t)c) & mask;
-                kmer1 = shr64c<2>(kmer1) | (uint64_t)(3 ^ c) << shift1;
+                kmer0 = (kmer0 << 2 | (uint64_t)c) & mask;
+                kmer1 = (kmer1 >> 2) | (uint64_t)(3 ^ c) << shift1;
                 const uint32_t z = kmer0 < kmer1 ? 0u : 1u;
-                x = shl64c<8>(mz_hash64(z ? kmer1 : kmer0, mask)) | (uint64_t)k;
+                x = mz_hash64(z ? kmer1 : kmer0, mask) << 8 | (uint64_t)k;
                 y = (uint32_t)i << 1 | z;
                 tie |= x == px;
                 if (x < px) { px = x; py = y; }

@@ -10,44 +10,8 @@
 namespace pmx {
 namespace aln {
 
-// 64-bit shifts by a compile-time amount.  On the device as two full-rate 32-bit instructions on the halves (v_alignbit_b32 +
-// a 32-bit shift): the compiler's own lowering is one v_lshlrev_b64 / v_lshrrev_b64, a slow-rate instruction on this chip, and
-// the sketch (k-mer update + hash64: fourteen such shifts per base) is a quarter of the dominant kernel.
-template <unsigned C>
-PMX_HD uint64_t shl64c(uint64_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(C > 0 && C < 64, "shift amount");
-    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    if (C >= 32) return (uint64_t)(lo << (C & 31u)) << 32;
-    return (uint64_t)__builtin_amdgcn_alignbit(hi, lo, 32u - (C & 31u)) << 32 | (lo << (C & 31u));
-#else
-    return x << C;
-#endif
-}
-template <unsigned C>
-PMX_HD uint64_t shr64c(uint64_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(C > 0 && C < 64, "shift amount");
-    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-    if (C >= 32) return (uint64_t)(hi >> (C & 31u));
-    return (uint64_t)(hi >> (C & 31u)) << 32 | __builtin_amdgcn_alignbit(hi, lo, C & 31u);
-#else
-    return x >> C;
-#endif
-}
-
 // invertible integer hash restricted to 2k bits (sketch.c:28-38)
 PMX_HD uint64_t mz_hash64(uint64_t key, uint64_t mask) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    key = (~key + shl64c<21>(key)) & mask;
-    key = key ^ shr64c<24>(key);
-    key = ((key + shl64c<3>(key)) + shl64c<8>(key)) & mask;
-    key = key ^ shr64c<14>(key);
-    key = ((key + shl64c<2>(key)) + shl64c<4>(key)) & mask;
-    key = key ^ shr64c<28>(key);
-    key = (key + shl64c<31>(key)) & mask;
-    return key;
-#endif
     key = (~key + (key << 21)) & mask;
     key = key ^ key >> 24;
     key = ((key + (key << 3)) + (key << 8)) & mask;
