@@ -374,10 +374,14 @@ PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const in
             atomicAdd(&W.prof[slot + 2], (unsigned long long)clock64() - pt0);
         }
     };
-    if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && !W.no_rows_dp &&
-        ksw_extd2_rows(W, W.dp_fast, (size_t)9 * (PMX_DP_FAST_TLEN + 32) + 64, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) {
-        account(23);
-        return;
+    if (W.dp_fast && W.caps.dp_fast_tlen == PMX_DP_FAST_TLEN && !W.no_rows_dp) {
+        // (the LDS copy of the DP arrays, 9 x 640 + 64 bytes: window + query first, the replay arrays behind them)
+        const size_t area = (size_t)9 * (PMX_DP_FAST_TLEN + 32) + 64, main_b = ksw_rows_lds_main(qlen);
+        if (main_b <= area &&
+            ksw_extd2_rows(W, W.dp_fast, main_b, W.dp_fast + main_b, area - main_b, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez)) {
+            account(23);
+            return;
+        }
     }
 #else
     auto account = [&](int) {};
@@ -392,6 +396,17 @@ PMX_HD void ksw_extd2(Work& W, int qlen, QP query, int tlen, TP target, const in
     else ksw_extd2_t<false, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
     account(29);
 #else
+#if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__) && defined(PMX_ALL_LDS)
+    // wave-per-pair tier, all-LDS layout: the row-by-row kernel on the DP arrays' own LDS (du | sf | qr are contiguous: window +
+    // query copy; H | off_ are: the replay arrays; tseq between them holds the target and is not touched)
+    if (!W.no_rows_dp) {
+        const size_t main_b = (size_t)7 * (W.caps.max_tlen + 32) + (size_t)(W.caps.max_tlen + 32) + (size_t)(W.caps.max_tlen + 64);
+        const size_t arr_b = (size_t)4 * (W.caps.max_tlen + 32) + (size_t)8 * (W.caps.max_qlen + W.caps.max_tlen);
+        if (((W.caps.max_tlen + 32) & 15) == 0 &&   // (the arrays are packed back to back only when their sizes are multiples of 16)
+            ksw_extd2_rows(W, (int8_t*)W.du, main_b, (int8_t*)W.H, arr_b, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez))
+            return;
+    }
+#endif
     if (flag & PMX_EZ_RIGHT) ksw_extd2_t<false, true>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
     else ksw_extd2_t<false, false>(W, qlen, query, tlen, target, mat, q, e, q2, e2, w, zdrop, end_bonus, flag, ez);
 #endif

@@ -24,22 +24,21 @@ namespace aln {
 #define PMX_ROWS_MAX_SW 16
 #define PMX_ROWS_WIN_BYTES 2048   // 64 rows x 32 columns
 
-// LDS bytes the mode needs behind the window and the query copy
-PMX_HD size_t ksw_rows_lds_bytes(int qlen, int tlen, bool exact) {
-    return (size_t)PMX_ROWS_WIN_BYTES + (size_t)((qlen + 15) & ~15) + (exact ? (size_t)8 * (size_t)(qlen + tlen) + 8 : 0);
-}
+// LDS the kernel needs: the traceback window and the query copy in one area, the replay arrays of the exact mode in another
+PMX_HD size_t ksw_rows_lds_main(int qlen) { return (size_t)PMX_ROWS_WIN_BYTES + (size_t)((qlen + 15) & ~15); }
+PMX_HD size_t ksw_rows_lds_arrays(int qlen, int tlen, bool exact) { return exact ? (size_t)8 * (size_t)(qlen + tlen) + 8 : 0; }
 
 __device__ __forceinline__ int rows_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
 
 template <int SW, bool RIGHT, bool EXACT, class QP, class TP>
-__device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds, int qlen, QP query, int tlen, TP target, int q, int e, int q2, int e2,
+__device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds, int8_t* lds_arr, int qlen, QP query, int tlen, TP target, int q, int e, int q2, int e2,
                                                            int sc_mch, int sc_mis, int sc_N, int zdrop, int end_bonus, int flag, Ez& ez) {
     constexpr int ROW = 64 * SW;
     const int k = (int)(threadIdx.x & 63u);
-    PMX_LDS_HERE(lds);
+    PMX_LDS_HERE(lds); PMX_LDS_HERE(lds_arr);
     uint8_t* win = reinterpret_cast<uint8_t*>(lds);
     uint8_t* qs = win + PMX_ROWS_WIN_BYTES;
-    int32_t* lastcol = reinterpret_cast<int32_t*>(qs + ((qlen + 15) & ~15));
+    int32_t* lastcol = reinterpret_cast<int32_t*>(lds_arr);
     int32_t* lastrow = lastcol + qlen;
     uint32_t* diag = reinterpret_cast<uint32_t*>(lastrow + tlen);
     uint32_t* spare = diag + qlen + tlen;   // where the columns past the target put what they compute
@@ -271,11 +270,13 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
 
 // The dispatcher: true = the request was served here.  Taken: band never cutting the matrix, scoring parameters that keep the
 // reference's int8 lanes far from wrapping (plain 32-bit arithmetic stands for them), a target of at most 1,024 columns, the
-// traceback matrix within the wave's slab and the replay arrays within `lds_bytes` of LDS at `lds`.
+// traceback matrix within the wave's slab, window + query copy within `lds_bytes` of LDS at `lds`, the replay arrays of the exact
+// mode within `arr_bytes` at `lds_arr`.
 template <class QP, class TP>
-__device__ __forceinline__ bool ksw_extd2_rows(Work& W, int8_t* lds, size_t lds_bytes, int qlen, QP query, int tlen, TP target, const int8_t* mat, int q, int e,
-                                               int q2, int e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
+__device__ __forceinline__ bool ksw_extd2_rows(Work& W, int8_t* lds, size_t lds_bytes, int8_t* lds_arr, size_t arr_bytes, int qlen, QP query, int tlen, TP target,
+                                               const int8_t* mat, int q, int e, int q2, int e2, int w, int zdrop, int end_bonus, int flag, Ez& ez) {
     if (qlen < 1 || tlen < 1 || tlen > 64 * PMX_ROWS_MAX_SW) return false;
+    if (__builtin_amdgcn_is_shared((const void*)(const uint8_t*)W.tb)) return false;   // (a traceback matrix in LDS: the DP service's small requests)
     const int longer = qlen > tlen ? qlen : tlen;
     if (!(w < 0 || w >= longer - 1)) return false;
     if (flag & ~(PMX_EZ_RIGHT | PMX_EZ_APPROX_MAX | PMX_EZ_EXTZ_ONLY | PMX_EZ_REV_CIGAR)) return false;
@@ -292,10 +293,10 @@ __device__ __forceinline__ bool ksw_extd2_rows(Work& W, int8_t* lds, size_t lds_
     if (q < 0 || e < 0 || q2 < 0 || e2 < 0 || 2 * (q2 + e2) + 2 * max_abs > 100) return false;
     const int sw = ((tlen + 63) / 64 + 3) & ~3;   // 4, 8, 12, 16 columns per lane
     if ((size_t)qlen * (size_t)(64 * sw) > W.tb_cap) return false;
-    if (ksw_rows_lds_bytes(qlen, tlen, exact) > lds_bytes) return false;
+    if (ksw_rows_lds_main(qlen) > lds_bytes || ksw_rows_lds_arrays(qlen, tlen, exact) > arr_bytes) return false;
     const int sc_mch = mat[0], sc_mis = mat[1], sc_N = mat[24] == 0 ? -e2 : mat[24];
     const bool right = (flag & PMX_EZ_RIGHT) != 0;
-#define PMX_ROWS_CALL(SWV, R, X) ksw_extd2_rows_t<SWV, R, X>(W, lds, qlen, query, tlen, target, q, e, q2, e2, sc_mch, sc_mis, sc_N, zdrop, end_bonus, flag, ez)
+#define PMX_ROWS_CALL(SWV, R, X) ksw_extd2_rows_t<SWV, R, X>(W, lds, lds_arr, qlen, query, tlen, target, q, e, q2, e2, sc_mch, sc_mis, sc_N, zdrop, end_bonus, flag, ez)
 #define PMX_ROWS_SW(SWV)                                         \
     do {                                                         \
         if (right) { if (exact) PMX_ROWS_CALL(SWV, true, true); else PMX_ROWS_CALL(SWV, true, false); }   \

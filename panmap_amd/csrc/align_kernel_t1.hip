@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(64, 3) k_align_dp_serve(AlignArgs A) {
         W.prof = A.prof;
         W.prof_t = 0;
         W.dp_run_calls = 0;
+        W.no_rows_dp = A.no_rows_dp;
         const int qlen = rq->qlen, tlen = rq->tlen;
         const int t_off = (qlen + 15) & ~15;
         const size_t tb_need = dp_request_tb_bytes(qlen, tlen, rq->w);
