@@ -44,6 +44,17 @@ PMX_HD void wave_sync() {}
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(PMX_ALL_LDS)
 #define PMX_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))
+#elif defined(__HIP_DEVICE_COMPILE__) && defined(PMX_THREAD_PER_PAIR)
+// Thread-per-pair kernel: the Work descriptor is a local object of the kernel (private memory) that every function of the
+// pipeline receives by reference, i.e. through a generic pointer -- 1,400 flat loads and 950 flat stores in the kernel, most
+// of them fields of W.  The statement every function already makes about W (PMX_LDS(&W): "in LDS" in the all-LDS tier)
+// says "private" here; everything else the macro is applied to is an IPtr (an arena offset, not a pointer) or a pointer
+// into global memory, and gets no statement.
+struct Work;
+__device__ __forceinline__ void pmx_private_hint(const Work* w) { __builtin_assume(__builtin_amdgcn_is_private((const void*)w)); }
+__device__ __forceinline__ void pmx_private_hint(Work* w) { __builtin_assume(__builtin_amdgcn_is_private((const void*)w)); }
+template <class T> __device__ __forceinline__ void pmx_private_hint(const T&) {}
+#define PMX_LDS(p) (pmx_private_hint(p))
 #else
 #define PMX_LDS(p) ((void)0)
 #endif
@@ -128,9 +139,13 @@ struct IPtr {
         typedef const __attribute__((address_space(4))) TppArena* KernargArena;
         const CPtr pkt = (CPtr)__builtin_amdgcn_dispatch_ptr();
         const KernargArena ka = *(const KernargArena __attribute__((address_space(4)))*)(pkt + 40);   // AlignArgs::tpp
-        uint8_t* wave_base = ka->base + (size_t)blockIdx.x * ka->wave_stride;   // uniform
+        // (the arena is global memory, and the address is built in that address space: handed out as a generic pointer the
+        //  optimizer still sees where it came from and emits global_load / global_store -- through a plain generic pointer
+        //  every arena access was a flat instruction, 2,400 of them in the kernel, each counted on the LDS queue as well)
+        typedef __attribute__((address_space(1))) uint8_t GByte;
+        GByte* wave_base = (GByte*)ka->base + (size_t)blockIdx.x * ka->wave_stride;   // uniform
         const uint32_t vo = ((threadIdx.x & 63u) << LG) + ((off >> LG) << (LG + 6)) + (off & ((1u << LG) - 1u));
-        return reinterpret_cast<T*>(wave_base + vo);
+        return reinterpret_cast<T*>((uint8_t*)(wave_base + vo));
     }
     __device__ __forceinline__ T& operator*() const { return *phys(o); }
     __device__ __forceinline__ T* operator->() const { return phys(o); }
