@@ -14,6 +14,7 @@
 // The traceback matrix is row-major in the wave's HBM slab; the walk reads it through 64-row x 32-column windows that the
 // lanes fetch together (one HBM round trip per >= 32 steps instead of one per step).
 #pragma once
+#include "aln_ksw_cell.hpp"
 #include "aln_types.hpp"
 
 #if PMX_W == 64 && defined(__HIP_DEVICE_COMPILE__)
@@ -50,6 +51,7 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
     g_u8* tb = (g_u8*)(uint8_t*)W.tb;
 
     const int qe = q + e, qe2 = q2 + e2;
+    const KswCellParams cellp{q, q2, qe, qe2, sc_mch, sc_mis, sc_N};
     const int init_ue = -qe, init_ue2 = -qe2;
     int long_thres = e != e2 ? (q2 - q) / (e - e2) - 1 : 0;
     if (q2 + e2 + long_thres * e2 > q + e + long_thres * e) ++long_thres;
@@ -110,50 +112,10 @@ __device__ __attribute__((noinline)) void ksw_extd2_rows_t(Work& W, int8_t* lds,
             for (int c = 0; c < SW; ++c) {
                 const int t = tcur;
                 const int sq = (int)(sfw[c >> 2] >> (8 * (c & 3)) & 0xffu);
-                int z = sq == qb ? sc_mch : sc_mis;
-                if (sq == 4 || qb == 4) z = sc_N;
                 const int ut = u[c];
-                int a = xl + vl, b = y[c] + ut, a2 = x2l + vl, b2 = y2[c] + ut;
+                int un, vn, xn, yn, x2n, y2n;
                 uint32_t d;
-                if (!RIGHT) {
-                    d = a > z ? 1u : 0u;
-                    z = z > a ? z : a;
-                    d = b > z ? 2u : d;
-                    z = z > b ? z : b;
-                    d = a2 > z ? 3u : d;
-                    z = z > a2 ? z : a2;
-                    d = b2 > z ? 4u : d;
-                    z = z > b2 ? z : b2;
-                } else {
-                    d = z > a ? 0u : 1u;
-                    z = z > a ? z : a;
-                    d = z > b ? d : 2u;
-                    z = z > b ? z : b;
-                    d = z > a2 ? d : 3u;
-                    z = z > a2 ? z : a2;
-                    d = z > b2 ? d : 4u;
-                    z = z > b2 ? z : b2;
-                }
-                z = z < sc_mch ? z : sc_mch;
-                const int un = z - vl, vn = z - ut;
-                int tmp = z - q;
-                a -= tmp;
-                b -= tmp;
-                tmp = z - q2;
-                a2 -= tmp;
-                b2 -= tmp;
-                int xn, yn, x2n, y2n;
-                if (!RIGHT) {
-                    xn = (a > 0 ? a : 0) - qe;   d |= a > 0 ? 0x08u : 0u;
-                    yn = (b > 0 ? b : 0) - qe;   d |= b > 0 ? 0x10u : 0u;
-                    x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 > 0 ? 0x20u : 0u;
-                    y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 > 0 ? 0x40u : 0u;
-                } else {
-                    xn = (0 > a ? 0 : a) - qe;   d |= 0 > a ? 0u : 0x08u;
-                    yn = (0 > b ? 0 : b) - qe;   d |= 0 > b ? 0u : 0x10u;
-                    x2n = (0 > a2 ? 0 : a2) - qe2; d |= 0 > a2 ? 0u : 0x20u;
-                    y2n = (0 > b2 ? 0 : b2) - qe2; d |= 0 > b2 ? 0u : 0x40u;
-                }
+                ksw_cell<RIGHT>(cellp, sq, qb, xl, vl, x2l, ut, y[c], y2[c], un, vn, xn, yn, x2n, y2n, d);
                 // H(t, q) = H(t-1, q) + u (the same number as the reference's H[t] += v: both are H(t-1, q-1) + z); column 0: += v
                 const int Hn = c == 0 ? (k == 0 ? H0 + vn : Hl + un) : Hl + un;
                 if (c == 0) H0 = Hn;

@@ -23,6 +23,7 @@
 
 #include "align_kernel.h"
 #include "align_kernel_dpg.h"
+#include "align/aln_ksw_cell.hpp"
 
 namespace pmx {
 namespace aln {
@@ -109,9 +110,9 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
         }
     }
     const int t0 = k * SW;
-    const int q = D.q, qe = D.q + D.e, q2 = D.q2, qe2 = D.q2 + D.e2;
+    const int qe = D.q + D.e, qe2 = D.q2 + D.e2;
     const int init_ue = -qe, init_ue2 = -qe2;
-    const int sc_mch = D.sc_mch, sc_mis = D.sc_mis, sc_N = D.sc_N;
+    const KswCellParams cellp{D.q, D.q2, D.q + D.e, D.q2 + D.e2, D.sc_mch, D.sc_mis, D.sc_N};
     auto gap_head = [&](int r) { return r == 0 ? init_ue : r < D.long_thres ? -D.e : r == D.long_thres ? D.long_diff : -D.e2; };
 
     // the query to LDS (one byte per row and lane later), the lane's target bases to registers
@@ -166,50 +167,10 @@ __device__ __attribute__((noinline)) void dpg_serve(const DpgArgs& D, const uint
             for (int c = 0; c < SW; ++c) {
                 const int t = tcur;
                 const int sq = (int)(sfw[c >> 2] >> (8 * (c & 3)) & 0xffu);
-                int z = sq == qb ? sc_mch : sc_mis;
-                if (sq == 4 || qb == 4) z = sc_N;
                 const int ut = u[c];
-                int a = xl + vl, b = y[c] + ut, a2 = x2l + vl, b2 = y2[c] + ut;
+                int un, vn, xn, yn, x2n, y2n;
                 uint32_t d;
-                if (!RIGHT) {
-                    d = a > z ? 1u : 0u;
-                    z = z > a ? z : a;
-                    d = b > z ? 2u : d;
-                    z = z > b ? z : b;
-                    d = a2 > z ? 3u : d;
-                    z = z > a2 ? z : a2;
-                    d = b2 > z ? 4u : d;
-                    z = z > b2 ? z : b2;
-                } else {
-                    d = z > a ? 0u : 1u;
-                    z = z > a ? z : a;
-                    d = z > b ? d : 2u;
-                    z = z > b ? z : b;
-                    d = z > a2 ? d : 3u;
-                    z = z > a2 ? z : a2;
-                    d = z > b2 ? d : 4u;
-                    z = z > b2 ? z : b2;
-                }
-                z = z < sc_mch ? z : sc_mch;
-                const int un = z - vl, vn = z - ut;
-                int tmp = z - q;
-                a -= tmp;
-                b -= tmp;
-                tmp = z - q2;
-                a2 -= tmp;
-                b2 -= tmp;
-                int xn, yn, x2n, y2n;
-                if (!RIGHT) {
-                    xn = (a > 0 ? a : 0) - qe;   d |= a > 0 ? 0x08u : 0u;
-                    yn = (b > 0 ? b : 0) - qe;   d |= b > 0 ? 0x10u : 0u;
-                    x2n = (a2 > 0 ? a2 : 0) - qe2; d |= a2 > 0 ? 0x20u : 0u;
-                    y2n = (b2 > 0 ? b2 : 0) - qe2; d |= b2 > 0 ? 0x40u : 0u;
-                } else {
-                    xn = (0 > a ? 0 : a) - qe;   d |= 0 > a ? 0u : 0x08u;
-                    yn = (0 > b ? 0 : b) - qe;   d |= 0 > b ? 0u : 0x10u;
-                    x2n = (0 > a2 ? 0 : a2) - qe2; d |= 0 > a2 ? 0u : 0x20u;
-                    y2n = (0 > b2 ? 0 : b2) - qe2; d |= 0 > b2 ? 0u : 0x40u;
-                }
+                ksw_cell<RIGHT>(cellp, sq, qb, xl, vl, x2l, ut, y[c], y2[c], un, vn, xn, yn, x2n, y2n, d);
                 // H of the cell.  The reference adds v along the query (H[t] += v, :326-340); H(t-1, q) + u is the same number
                 // (both are H(t-1, q-1) + z: u = z - v(t-1, q), v = z - u(t, q-1)), and that one is already in a register:
                 // the left neighbour's H travels along the row with x and v.  Column 0 has no left neighbour: += v there.
