@@ -114,6 +114,15 @@ struct CMemT {
     PMX_HD c_u8& GH(int i) const { return b(2 * (kGH + i) + 1); }   // one-byte lists in it
     PMX_HD uint64_t M(int i) const { return (uint64_t)w(2 * i) | (uint64_t)w(2 * i + 1) << 32; }
     PMX_HD void setM(int i, uint64_t v) const { w(2 * i) = (uint32_t)v; w(2 * i + 1) = (uint32_t)(v >> 32); }
+    // what a CSeeder asks of the memory it works on: a queue of waiting minimizers (here: the M entries that lie above X
+    // and Y, 14 of them) and a place for the seeds (here: X and Y themselves)
+    typedef PT PosT;
+    static constexpr int kQBase = (kGH / 2 + 1) / 2;
+    static constexpr int kQCap = kWords / 2 - kQBase;
+    PMX_HD uint64_t QM(int i) const { return M(kQBase + i); }
+    PMX_HD void setQM(int i, uint64_t v) const { setM(kQBase + i, v); }
+    PMX_HD void setSeed(int i, uint32_t x, uint32_t y) const { setX(i, x); h(kYH + i) = (c_u16)y; }
+    PMX_HD void orY(int i, uint32_t f) const { h(kYH + i) |= (c_u16)f; }
     // anchor x split: strand, reference position
     PMX_HD static uint32_t rev_of(uint32_t x) { return x >> (8 * sizeof(PT) - 1); }
     PMX_HD static uint32_t pos_of(uint32_t x) { return x & (kRevBit - 1u); }
@@ -126,6 +135,43 @@ struct CMemT {
 #define PMX_CQ_TANDEM 0x800u
 #define PMX_CQ_IGNORE 0x1000u
 #define PMX_CQ_LONG_JOIN 0x2000u
+
+// The seed hand-over of the two-kernel form (k_compact_seeds -> k_align_compact): the sketch and the index probes need
+// none of the pair's LDS state, only the short minimizer queue, so they run in a kernel of their own at twice the waves
+// per CU and leave the seeds -- the very X and Y words the fused form writes to LDS -- in HBM: block `b` of 64 launch
+// positions owns kCap * kWS * 64 words, word j of seed i of lane l at ((b * kCap + i) * kWS + j) * 64 + l (a wave
+// writing seed i of its pairs writes contiguous words; the chain kernel reads them back the same way).
+//   PT = u16: one word per seed, X | Y << 16;   PT = u32: two, X then Y.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) uint32_t c_g32;
+#else
+typedef uint32_t c_g32;
+#endif
+template <class PT>
+struct CSeedOutT {
+    typedef PT PosT;
+    static constexpr int kCap = PMX_C_CAP;
+    static constexpr int kWS = sizeof(PT) == 2 ? 1 : 2;
+    static constexpr int kQCap = PMX_C_SEEDQ;
+    static constexpr int kBlockWords = kCap * kWS * 64;      // per 64 launch positions
+    c_u32* q;         // the lane's queue words (LDS, word i at q[i * stride])
+    c_g32* out;       // the lane's column of its block
+    PMX_HD uint64_t QM(int i) const { return (uint64_t)q[2 * i * PMX_C_STRIDE] | (uint64_t)q[(2 * i + 1) * PMX_C_STRIDE] << 32; }
+    PMX_HD void setQM(int i, uint64_t v) const { q[2 * i * PMX_C_STRIDE] = (uint32_t)v; q[(2 * i + 1) * PMX_C_STRIDE] = (uint32_t)(v >> 32); }
+    PMX_HD void setSeed(int i, uint32_t x, uint32_t y) const {
+        if (kWS == 1) out[i * PMX_C_STRIDE] = x | y << 16;
+        else { out[2 * i * PMX_C_STRIDE] = x; out[(2 * i + 1) * PMX_C_STRIDE] = y; }
+    }
+    PMX_HD void orY(int i, uint32_t f) const {   // (the lane's own earlier store)
+        if (kWS == 1) out[i * PMX_C_STRIDE] |= f << 16;
+        else out[(2 * i + 1) * PMX_C_STRIDE] |= f;
+    }
+    PMX_HD void get(int i, uint32_t* x, uint32_t* y) const {
+        if (kWS == 1) { const uint32_t v = out[i * PMX_C_STRIDE]; *x = v & 0xffffu; *y = v >> 16; }
+        else { *x = out[2 * i * PMX_C_STRIDE]; *y = out[(2 * i + 1) * PMX_C_STRIDE]; }
+    }
+};
+#define PMX_C_NSEED_BAIL 0xffu   // the hand-over count of a pair the seeding already gave up on
 
 PMX_HD uint64_t c_bitrev64(uint64_t x) {
 #if defined(__clang__)
@@ -502,14 +548,13 @@ PMX_HD int c_filter_mapq(const Opt& o, const RefIndex& ri, int qlen, CReg& r, bo
 // wave drains its queues together -- four probes in flight per lane -- whenever some lane holds six (one base can add
 // up to w), so the drain is a uniform branch and the seeds never need a staging copy of the minimizer list.  The newest
 // entry stays queued until its right neighbour is known (the tandem mark compares adjacent minimizers, seed.c:40-46).
-template <class PT>
+template <class MS>
 struct CSeeder {
-    typedef CMemT<PT> MT;
-    static constexpr int kQBase = (MT::kGH / 2 + 1) / 2;              // first M entry that lies above X and Y
-    static constexpr int kQCap = MT::kWords / 2 - kQBase;             // 14
+    typedef typename MS::PosT PT;
+    static constexpr int kQCap = MS::kQCap;
     static constexpr int kQDrain = kQCap - 2;                         // drain threshold (sketch_distinct pushes at most one minimizer per base)
     static_assert(kQCap >= 8, "minimizer queue too short");
-    const MT& m;
+    const MS& m;
     const RefIndex& ri;
     CRead r;
     int seg, sum;          // segment, summed length of the segments before it
@@ -529,7 +574,7 @@ struct CSeeder {
             HtEnt e[4];
 #pragma unroll
             for (int b = 0; b < 5; ++b) {
-                const uint64_t mi = e0 + b < n_q ? m.M(kQBase + e0 + b) : 0ULL;
+                const uint64_t mi = e0 + b < n_q ? m.QM(e0 + b) : 0ULL;
                 key[b] = mi >> 11;
                 if (b < 4) yl[b] = (uint32_t)mi & 0x7ffu;
             }
@@ -551,17 +596,16 @@ struct CSeeder {
                     }
                     const uint32_t cnt = e[b].key == key[b] ? e[b].cnt : 0u;
                     bool tandem = have_prev && key[b] == prev_key;
-                    if (first_of_read && tandem && pending >= 0) m.Y(pending) |= PMX_CQ_TANDEM;   // ... of the previous read's last one
+                    if (first_of_read && tandem && pending >= 0) m.orY(pending, PMX_CQ_TANDEM);   // ... of the previous read's last one
                     const bool has_next = e0 + b + 1 < n_q;
                     if (has_next && key[b] == key[b + 1]) tandem = true;
                     if (first_of_read) pending = -1;
                     first_of_read = false;
                     if (cnt > 1) bail = true;                      // a repeated minimizer: general tier
                     else if (cnt == 1) {
-                        if (n_s >= MT::kCap || (pv[b] >> (8 * sizeof(PT) - 1) >> 1) != 0u) bail = true;
+                        if (n_s >= MS::kCap || (pv[b] >> (8 * sizeof(PT) - 1) >> 1) != 0u) bail = true;
                         else {
-                            m.setX(n_s, pv[b]);
-                            m.Y(n_s) = (c_u16)((yl[b] + ((uint32_t)sum << 1)) | (seg ? PMX_CQ_SEG : 0u) | (tandem ? PMX_CQ_TANDEM : 0u));
+                            m.setSeed(n_s, pv[b], (yl[b] + ((uint32_t)sum << 1)) | (seg ? PMX_CQ_SEG : 0u) | (tandem ? PMX_CQ_TANDEM : 0u));
                             pending = has_next ? -1 : n_s;   // (only the read's last minimizer has no right neighbour yet)
                             ++n_s;
                         }
@@ -572,8 +616,8 @@ struct CSeeder {
             }
         }
         if (!final && n_q > 0) {   // the newest entry moves to the front
-            const uint64_t last = m.M(kQBase + n_q - 1);
-            m.setM(kQBase, last);
+            const uint64_t last = m.QM(n_q - 1);
+            m.setQM(0, last);
             n_q = 1;
         } else if (final) n_q = 0;
     }
@@ -585,7 +629,7 @@ struct CSeeder {
         return r.flip ? 3 - c : c;
     }
     PMX_HD void operator()(uint64_t x, uint64_t y) {   // a minimizer
-        if (n_q < kQCap) { m.setM(kQBase + n_q, (x >> 8) << 11 | ((uint32_t)y & 0x7ffu)); ++n_q; }
+        if (n_q < kQCap) { m.setQM(n_q, (x >> 8) << 11 | ((uint32_t)y & 0x7ffu)); ++n_q; }
         else ovf = true;
     }
 };
@@ -663,19 +707,23 @@ PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
 #else
 #define PMX_C_STAMP(k) ((void)0)
 #endif
-// The pair.  rd / amb = the two mates as packed by the host; `out` is only meaningful when PMX_C_DONE is returned.
+// The pair, in two parts.  rd / amb = the two mates as packed by the host.
+// (1) compact_seed_pair: envelope checks, minimizers -> index probes -> seeds, into whatever `ms` is (CMemT: the pair's
+//     LDS block; CSeedOutT: the HBM hand-over).  PMX_C_DONE with the seed count in *n_seeds, or PMX_C_BAIL.
+// (2) compact_chain_pair: from the seeds in X / Y of the pair's LDS block to the records; `out` is only meaningful when
+//     PMX_C_DONE is returned.
+// compact_map_pair runs both on one memory block (the fused form: hostsim, PMX_ALIGN_COMPACT_FUSED).
 // prof: NULL, or 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
-template <class PT>
-PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
-                             const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false) {
-    typedef CMemT<PT> MT;
-    out.mapped = 0;
+template <class MS>
+PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, int* n_seeds,
+                              unsigned long long* prof = nullptr) {
+    typedef typename MS::PosT PT;
+    *n_seeds = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long prof_t = prof ? (unsigned long long)clock64() : 0ULL;
 #endif
     const int k = o.k, w = o.w;
-    const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
-    out.edit[0] = qlen0; out.edit[1] = qlen1;   // a mate without a region counts its whole length
+    const int qlen0 = rd[0].len, qlen1 = rd[1].len;
     if (qlen0 > PMX_C_MAXLEN || qlen1 > PMX_C_MAXLEN || qlen0 <= 0 || qlen1 <= 0 || w != PMX_C_W || !(k & 1) || 2 * k + 11 > 64 || k > 255 || !o.is_sr_like)
         return PMX_C_BAIL;
     if (sizeof(PT) == 2 ? ri.len > 32767 : ri.len > 0x3fffffff) return PMX_C_BAIL;   // position << 1 | strand must fit PT
@@ -684,7 +732,7 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             if (amb[s][c]) return PMX_C_BAIL;
 
     // ---------------------------------------------------------------- minimizers -> index probes -> seeds (X, Y)
-    CSeeder<PT> sd{m, ri};
+    CSeeder<MS> sd{ms, ri};
     sd.n_s = 0; sd.bail = false; sd.have_prev = false; sd.prev_key = 0; sd.pending = -1;
     {
         const CRead r0 = rd[0], r1 = rd[1];
@@ -699,9 +747,22 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
             PMX_C_STAMP(1);
         }
     }
-    const int n_s = sd.n_s;
-    const bool bail = sd.bail;
-    if (bail) return PMX_C_BAIL;
+    if (sd.bail) return PMX_C_BAIL;
+    *n_seeds = sd.n_s;
+    return PMX_C_DONE;
+}
+
+template <class PT>
+PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_s, CResult& out, const CPenTab& pen_tab,
+                               unsigned long long* prof = nullptr, bool want_edits = false) {
+    typedef CMemT<PT> MT;
+    out.mapped = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long prof_t = prof ? (unsigned long long)clock64() : 0ULL;
+#endif
+    const int k = o.k;
+    const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
+    out.edit[0] = qlen0; out.edit[1] = qlen1;   // a mate without a region counts its whole length
     if (n_s == 0) return PMX_C_DONE;   // no anchors: unmapped
 
     // ---------------------------------------------------------------- heap merge (map.c:102-166) -> anchors in place
@@ -1064,6 +1125,16 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
         t.mapq = (uint8_t)r.mapq; t.rev = (uint8_t)r.rev; t.proper_frag = (uint8_t)r.proper_frag; t.has_aln = 1;
     }
     return PMX_C_DONE;
+}
+
+template <class PT>
+PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
+                             const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false) {
+    out.mapped = 0;
+    out.edit[0] = rd[0].len; out.edit[1] = rd[1].len;
+    int n_s = 0;
+    if (compact_seed_pair(m, o, ri, rd, amb, &n_s, prof) != PMX_C_DONE) return PMX_C_BAIL;
+    return compact_chain_pair(m, o, ri, rd, n_s, out, pen_tab, prof, want_edits);
 }
 
 }  // namespace aln

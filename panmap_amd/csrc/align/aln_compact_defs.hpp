@@ -4,6 +4,7 @@
 #define PMX_C_CAP 56            // seeds / anchors per pair: six bytes each: the most that leaves seven waves per CU (0.1 % of 150 bp pairs -- mean 40
                                 // anchors -- run out; with 48, 0.9 % did and a tier of bails costs more than that; at most 63, see CMemT)
 #define PMX_C_MCAP 40           // minimizers of one read waiting for their probes
+#define PMX_C_SEEDQ 14           // k_compact_seeds: minimizers of one read waiting for their probes (LDS: 112 bytes per pair)
 #define PMX_C_NW 5              // 32-base words per read: reads up to 160 bases
 #define PMX_C_MAXLEN (32 * PMX_C_NW)
 // LDS words per pair (CMemT<PT>::kWords): X (PT) + Y (u16) + G (u16), PMX_C_CAP entries each

@@ -10,6 +10,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "../device/pmx_math.h"   // PMX_HD (the host build of the unit tests includes this header too)
+
 namespace pmx {
 namespace aln {
 
@@ -19,7 +21,7 @@ struct KswCellParams {
 };
 
 template <bool RIGHT>
-__device__ __forceinline__ void ksw_cell(const KswCellParams& P, int sq, int qb, int xl, int vl, int x2l, int ut, int yt, int y2t, int& un, int& vn, int& xn,
+PMX_HD void ksw_cell(const KswCellParams& P, int sq, int qb, int xl, int vl, int x2l, int ut, int yt, int y2t, int& un, int& vn, int& xn,
                                          int& yn, int& x2n, int& y2n, uint32_t& d) {
     int z = sq == qb ? P.sc_mch : P.sc_mis;
     if (sq == 4 || qb == 4) z = P.sc_N;

@@ -218,7 +218,23 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
         std::fill(lds.begin(), lds.end(), 0xdeadbeefu);
         CResult res;
         int rc;
-        if (ref_len <= 32767 && !getenv("PMX_HS_COMPACT_POS32")) { CMemT<uint16_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res, tab); }
+        const bool pos16 = ref_len <= 32767 && !getenv("PMX_HS_COMPACT_POS32");
+        if (getenv("PMX_HS_COMPACT_SPLIT")) {
+            // the two-kernel form: seeds through the hand-over words (k_compact_seeds), then the chain part from a copy
+            // of them in the pair's block (k_align_compact) -- the block itself never sees the sketch
+            std::vector<uint32_t> q(2 * PMX_C_SEEDQ, 0xdeadbeefu), ho((size_t)PMX_C_CAP * 2, 0xdeadbeefu);
+            auto split = [&](auto pt) {
+                typedef decltype(pt) PT;
+                CSeedOutT<PT> so{q.data(), ho.data()};
+                int n_s = 0;
+                res.mapped = 0;
+                if (compact_seed_pair(so, o, ri, rd, amb, &n_s) != PMX_C_DONE) return (int)PMX_C_BAIL;
+                CMemT<PT> m{lds.data()};
+                for (int i = 0; i < n_s; ++i) { uint32_t x, y; so.get(i, &x, &y); m.setSeed(i, x, y); }
+                return compact_chain_pair(m, o, ri, rd, n_s, res, tab);
+            };
+            rc = pos16 ? split((uint16_t)0) : split((uint32_t)0);
+        } else if (pos16) { CMemT<uint16_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res, tab); }
         else { CMemT<uint32_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res, tab); }
         done[it] = rc == PMX_C_DONE ? 1 : 0;
         for (int s = 0; s < 2; ++s) {

@@ -139,6 +139,22 @@ def test_compact_tier_equals_reference(pmx, oracle, cases):
     got_rc, done_rc = ac.hostsim_align_compact(g, raw, rc2=True)
     got, done = ac.hostsim_align_compact(g, clean)
     assert np.array_equal(done, done_rc) and not ac.compare_results(got_rc, got)
+    # the two-kernel form (seeds through the hand-over words of k_compact_seeds, chain part from a copy of them):
+    # same pairs finished, same records, with 16- and 32-bit position words
+    import os
+    for pos32 in (False, True):
+        if pos32:
+            os.environ["PMX_HS_COMPACT_POS32"] = "1"
+        try:
+            for reads in (clean, noisy, sets["real"], sets["real_as_sequenced"]):
+                os.environ["PMX_HS_COMPACT_SPLIT"] = "1"
+                split, done_s = ac.hostsim_align_compact(g, reads)
+                del os.environ["PMX_HS_COMPACT_SPLIT"]
+                fused, done_f = ac.hostsim_align_compact(g, reads)
+                assert np.array_equal(done_s, done_f) and not ac.compare_results(split, fused)
+        finally:
+            os.environ.pop("PMX_HS_COMPACT_SPLIT", None)
+            os.environ.pop("PMX_HS_COMPACT_POS32", None)
 
 
 def test_sliced_reference_sketch_equals_the_sequential_one(pmx, sars):
