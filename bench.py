@@ -550,7 +550,7 @@ def main():
     h2h_nodes = [None if pp.res is None else int(pp.res.best_index[4]) for pp in pipes]
 
     # ---------------------------------------------------------------- value_device_resident (one batch at a time, no PCIe)
-    kernel_ms = {"align": [], "align_dom": [], "seed": [], "score": []}
+    kernel_ms = {"align": [], "align_dom": [], "align_cseeds": [], "seed": [], "score": []}
     dp_stats = []
     resident = None
     d_concat = torch.from_numpy(concat).to(dev)
@@ -739,7 +739,9 @@ def main():
             if dom_ms <= 0:
                 dom_ms = align_ms
             achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-            dom_name = "k_align_compact16 (all pairs)" if not long_reads else "k_align_reads_w4 (wave per read)"
+            dom_name = "k_align_compact16 (all pairs; seeds from k_compact_seeds16)" if not long_reads else "k_align_reads_w4 (wave per read)"
+            cseeds_ms = float(np.mean(kernel_ms["align_cseeds"]))
+            cseeds_ms = cseeds_ms if cseeds_ms >= 0 else None   # (fused form / long reads: no such launch)
             # HBM traffic and wave-instruction counts of that kernel per launch from the PMC passes (rocprofv3 --pmc in separate
             # runs; profiles/rNN/make_pmc_traffic.py writes the json): quoted only for the workload AND the sources it was
             # collected on (source_digest), otherwise null.
@@ -780,6 +782,7 @@ def main():
                                "proved closed-form shortcuts run no DP and count no cells; GCUPS = cells / whole align-stage time"},
                 "kernels_ms": {"seed stage (k_seed_histogram, chunked)": seed_ms, "score stage (k_score_terms + k_score_chains)": score_ms,
                                "align stage (all tiers)": align_ms, "dominant align kernel": dom_ms,
+                               "compact tier, sketch + probes (k_compact_seeds16)": cseeds_ms,
                                "note": "HIP-event durations in the device-resident run (one batch at a time)"},
             })
         else:

@@ -703,7 +703,7 @@ PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
 #define PMX_C_COUNT(k, v) ((void)0)   // tests/hostsim counts work here
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-#define PMX_C_STAMP(k) do { if (prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
+#define PMX_C_STAMP(k) do { if (prof_on) { const unsigned long long t_ = (unsigned long long)clock64(); prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
 #else
 #define PMX_C_STAMP(k) ((void)0)
 #endif
@@ -713,20 +713,21 @@ PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
 // (2) compact_chain_pair: from the seeds in X / Y of the pair's LDS block to the records; `out` is only meaningful when
 //     PMX_C_DONE is returned.
 // compact_map_pair runs both on one memory block (the fused form: hostsim, PMX_ALIGN_COMPACT_FUSED).
-// prof: NULL, or 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
+// prof (read only when prof_on): 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
 template <class MS>
 PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, int* n_seeds,
-                              unsigned long long* prof = nullptr) {
+                              unsigned long long* prof = nullptr, bool prof_on = false) {
     typedef typename MS::PosT PT;
     *n_seeds = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long prof_t = prof ? (unsigned long long)clock64() : 0ULL;
+    unsigned long long prof_t = prof_on ? (unsigned long long)clock64() : 0ULL;
 #endif
     const int k = o.k, w = o.w;
     const int qlen0 = rd[0].len, qlen1 = rd[1].len;
     if (qlen0 > PMX_C_MAXLEN || qlen1 > PMX_C_MAXLEN || qlen0 <= 0 || qlen1 <= 0 || w != PMX_C_W || !(k & 1) || 2 * k + 11 > 64 || k > 255 || !o.is_sr_like)
         return PMX_C_BAIL;
     if (sizeof(PT) == 2 ? ri.len > 32767 : ri.len > 0x3fffffff) return PMX_C_BAIL;   // position << 1 | strand must fit PT
+#pragma unroll
     for (int s = 0; s < 2; ++s)   // an ambiguous base anywhere: general tier
         for (int c = 0; c < (rd[s].len + 31) >> 5; ++c)
             if (amb[s][c]) return PMX_C_BAIL;
@@ -754,11 +755,11 @@ PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, con
 
 template <class PT>
 PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_s, CResult& out, const CPenTab& pen_tab,
-                               unsigned long long* prof = nullptr, bool want_edits = false) {
+                               unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false) {
     typedef CMemT<PT> MT;
     out.mapped = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long prof_t = prof ? (unsigned long long)clock64() : 0ULL;
+    unsigned long long prof_t = prof_on ? (unsigned long long)clock64() : 0ULL;
 #endif
     const int k = o.k;
     const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
@@ -1129,12 +1130,12 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
 
 template <class PT>
 PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
-                             const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false) {
+                             const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false) {
     out.mapped = 0;
     out.edit[0] = rd[0].len; out.edit[1] = rd[1].len;
     int n_s = 0;
-    if (compact_seed_pair(m, o, ri, rd, amb, &n_s, prof) != PMX_C_DONE) return PMX_C_BAIL;
-    return compact_chain_pair(m, o, ri, rd, n_s, out, pen_tab, prof, want_edits);
+    if (compact_seed_pair(m, o, ri, rd, amb, &n_s, prof, prof_on) != PMX_C_DONE) return PMX_C_BAIL;
+    return compact_chain_pair(m, o, ri, rd, n_s, out, pen_tab, prof, want_edits, prof_on);
 }
 
 }  // namespace aln

@@ -47,6 +47,11 @@ struct AlignArgs {
     const uint32_t* dp_left;    // k_align_dp_serve: NULL, or two counters of the requests the grouped service left (both zero: nothing to do)
 
 
+    // Compact tier, two-kernel form (align_kernel_compact.hip): k_compact_seeds leaves the seeds of launch position `it` in
+    // the hand-over words (align/aln_compact.hpp CSeedOutT) and their number in cseed_n[it]; NULL = the fused kernel
+    uint32_t* cseeds;
+    uint8_t* cseed_n;
+
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
     int32_t* edits;             // NULL, or per read: count_read_errors (src/mm_align.c:122-133) of its first region, the read length without one
     unsigned long long* stats;  // [0] DP calls run, [1] DP cells (q * min(t, 2w+1)), [2] pairs the wave tiers ran a DP for
@@ -71,8 +76,12 @@ __global__ void k_align_reads_t1(AlignArgs A);
 __global__ void k_align_reads_t1_w4(AlignArgs A);
 __global__ void k_align_reads_tpp(AlignArgs A);
 __global__ void k_align_dp_serve(AlignArgs A);
-__global__ void k_align_compact16(AlignArgs A);   // retry_list / retry_count = its bail list; reference <= 32,767 bases
+__global__ void k_align_compact16(AlignArgs A);   // retry_list / retry_count = its bail list; reference <= 32,767 bases; seeds from cseeds
 __global__ void k_align_compact32(AlignArgs A);
+__global__ void k_align_compact16_fused(AlignArgs A);   // sketch and probes inside (PMX_ALIGN_COMPACT_FUSED)
+__global__ void k_align_compact32_fused(AlignArgs A);
+__global__ void k_compact_seeds16(AlignArgs A);   // sketch + index probes of every pair -> cseeds / cseed_n
+__global__ void k_compact_seeds32(AlignArgs A);
 
 // bytes of the traceback matrix ksw_extd2 needs for a request (same n_col as ksw2_extd2_sse.c:95-98)
 PMX_HD size_t dp_request_tb_bytes(int qlen, int tlen, int w) {

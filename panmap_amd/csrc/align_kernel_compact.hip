@@ -16,7 +16,51 @@
 namespace pmx {
 namespace aln {
 
+// The pair of launch position `it` (both kernels of the two-kernel form walk the positions the same way)
+__device__ __forceinline__ int64_t compact_item(const AlignArgs& A, int64_t it, CRead* rd, const uint32_t** amb) {
+    const int64_t item = A.pair_perm ? (int64_t)A.pair_perm[it] : it;
+    for (int s = 0; s < 2; ++s) {
+        const int64_t r = 2 * item + s;
+        const int64_t len = A.off[r + 1] - A.off[r];
+        rd[s].w = A.words + A.woff[r];
+        rd[s].len = len > 0x7fffffff ? 0x7fffffff : (int)len;
+        rd[s].flip = A.revcomp_mate2 && s == 1;
+        amb[s] = A.amb + A.woff[r];
+    }
+    return item;
+}
+
+// First kernel of the two-kernel form: sketch + index probes of every pair, thread per pair.  The only LDS is the
+// minimizer queue (112 bytes per pair, 7 KB per wave), so the CU holds as many waves as the registers allow (the fused
+// kernel: seven, by its 21 KB of work state per wave) -- this part is pure integer arithmetic plus a few probes.
+// Seeds go to the hand-over words (CSeedOutT), the count (or PMX_C_NSEED_BAIL) to cseed_n[position].
 template <class PT>
+__device__ __forceinline__ void compact_seeds_body(const AlignArgs& A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t c_lds[];
+    const int lane = (int)(threadIdx.x & 63u);
+    CSeedOutT<PT> so;
+    so.q = (c_u32*)c_lds + lane;
+    const int64_t n_threads = (int64_t)gridDim.x * 64;
+    for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < A.n_items; it0 += n_threads) {   // (uniform trip count: the drains are wave-wide)
+        const int64_t it = it0 + lane;
+        so.out = (c_g32*)(A.cseeds + (size_t)(it0 >> 6) * CSeedOutT<PT>::kBlockWords) + lane;
+        int n_s = 0, rc = PMX_C_DONE;
+        if (it < A.n_items) {
+            CRead rd[2];
+            const uint32_t* amb[2];
+            compact_item(A, it, rd, amb);
+            unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            rc = compact_seed_pair(so, A.opt, A.ri, rd, amb, &n_s, pacc, A.prof != nullptr);
+            if (A.prof && lane == 0)
+                for (int k = 0; k < 2; ++k) atomicAdd(&A.prof[k], pacc[k]);
+            A.cseed_n[it] = (uint8_t)(rc == PMX_C_DONE ? n_s : (int)PMX_C_NSEED_BAIL);
+        }
+    }
+}
+__global__ void __launch_bounds__(64) k_compact_seeds16(AlignArgs A) { compact_seeds_body<uint16_t>(A); }
+__global__ void __launch_bounds__(64) k_compact_seeds32(AlignArgs A) { compact_seeds_body<uint32_t>(A); }
+
+template <class PT, bool PRESEEDED>
 __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t c_lds[];
     const int lane = (int)(threadIdx.x & 63u);
@@ -42,20 +86,37 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
         int rc = PMX_C_DONE;
         CResult res;
         res.mapped = 0;
-        if (it < A.n_items) {
-            item = A.pair_perm ? (int64_t)A.pair_perm[it] : it;
-            CRead rd[2];
-            const uint32_t* amb[2];
-            for (int s = 0; s < 2; ++s) {
-                const int64_t r = 2 * item + s;
-                const int64_t len = A.off[r + 1] - A.off[r];
-                rd[s].w = A.words + A.woff[r];
-                rd[s].len = len > 0x7fffffff ? 0x7fffffff : (int)len;
-                rd[s].flip = A.revcomp_mate2 && s == 1;
-                amb[s] = A.amb + A.woff[r];
+        CRead rd[2];
+        const uint32_t* amb[2];
+        unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (PRESEEDED) {
+            // two-kernel form: the pairs' seeds wait in the hand-over words; a wave copies seed i of its 64 pairs with
+            // one contiguous load per word, four seeds requested together
+            int n_s = 0;
+            if (it < A.n_items) {
+                item = compact_item(A, it, rd, amb);
+                const uint32_t c = A.cseed_n[it];
+                if (c == PMX_C_NSEED_BAIL) rc = PMX_C_BAIL;
+                else n_s = (int)c;
             }
-            unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            rc = compact_map_pair(m, A.opt, A.ri, rd, amb, res, tab, A.prof ? pacc : nullptr, A.edits != nullptr);
+            CSeedOutT<PT> so;
+            so.q = nullptr;
+            so.out = (c_g32*)(A.cseeds + (size_t)(it0 >> 6) * CSeedOutT<PT>::kBlockWords) + lane;
+            for (int i0 = 0; __ballot(i0 < n_s) != 0ULL; i0 += 4) {
+                uint32_t x[4], y[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { x[b] = y[b] = 0; if (i0 + b < n_s) so.get(i0 + b, &x[b], &y[b]); }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (i0 + b < n_s) m.setSeed(i0 + b, x[b], y[b]);
+            }
+            if (item >= 0 && rc == PMX_C_DONE) {
+                rc = compact_chain_pair(m, A.opt, A.ri, rd, n_s, res, tab, pacc, A.edits != nullptr, A.prof != nullptr);
+                if (A.prof && lane == 0)
+                    for (int k = 2; k < 8; ++k) atomicAdd(&A.prof[k], pacc[k]);
+            }
+        } else if (it < A.n_items) {
+            item = compact_item(A, it, rd, amb);
+            rc = compact_map_pair(m, A.opt, A.ri, rd, amb, res, tab, pacc, A.edits != nullptr, A.prof != nullptr);
             if (A.prof && lane == 0)   // lane 0's stamps are the wave's phase timeline (diagnostic runs: PMX_ALIGN_PROF)
                 for (int k = 0; k < 8; ++k) atomicAdd(&A.prof[k], pacc[k]);
         }
@@ -107,8 +168,10 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
     }
 }
 
-__global__ void __launch_bounds__(64) k_align_compact16(AlignArgs A) { align_compact_body<uint16_t>(A); }
-__global__ void __launch_bounds__(64) k_align_compact32(AlignArgs A) { align_compact_body<uint32_t>(A); }
+__global__ void __launch_bounds__(64) k_align_compact16(AlignArgs A) { align_compact_body<uint16_t, true>(A); }
+__global__ void __launch_bounds__(64) k_align_compact32(AlignArgs A) { align_compact_body<uint32_t, true>(A); }
+__global__ void __launch_bounds__(64) k_align_compact16_fused(AlignArgs A) { align_compact_body<uint16_t, false>(A); }
+__global__ void __launch_bounds__(64) k_align_compact32_fused(AlignArgs A) { align_compact_body<uint32_t, false>(A); }
 
 }  // namespace aln
 }  // namespace pmx

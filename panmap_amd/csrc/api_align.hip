@@ -49,6 +49,8 @@ struct pmx_aligner {
     DevBuf<char> pp_tmp;
     uint32_t mv_epoch = 0;
     DevBuf<uint32_t> retry_list2, bail_list;
+    DevBuf<uint32_t> cseeds;            // compact tier, two-kernel form: seed hand-over (AlignArgs::cseeds / cseed_n)
+    DevBuf<uint8_t> cseed_n;
     DevBuf<uint8_t> dp_req;
     DevBuf<DpRes> dp_res;
     DevBuf<uint32_t> dp_ncached, dp_slot_pairs, dp_list_a, dp_list_b;
@@ -320,6 +322,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     AlignArgs A;
     A.tpp.base = nullptr; A.tpp.wave_stride = 0; A.tpp.pad = 0;
     A.work_queue = nullptr;
+    A.cseeds = nullptr; A.cseed_n = nullptr;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
     A.paired = paired ? 1 : 0;
     A.revcomp_mate2 = revcomp_mate2 ? 1 : 0;
@@ -534,11 +537,12 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             // back as the bail list, which is the launch order of the general thread-per-pair kernel below.
             int64_t n_t0 = n_items;
             const bool use_compact = paired && al->opt.is_sr_like && al->opt.w == PMX_C_W && (al->opt.k & 1) && rs->max_len <= PMX_C_MAXLEN && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_COMPACT");
-            timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
+            if (!use_compact) timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
             if (use_compact) {
                 al->bail_list.ensure((size_t)n_items);
                 const bool pos16 = al->ri.len <= 32767 && !getenv("PMX_ALIGN_COMPACT_POS32");
-                auto c_kern = pos16 ? k_align_compact16 : k_align_compact32;
+                const bool c_fused = getenv("PMX_ALIGN_COMPACT_FUSED") != nullptr;
+                auto c_kern = c_fused ? (pos16 ? k_align_compact16_fused : k_align_compact32_fused) : (pos16 ? k_align_compact16 : k_align_compact32);
                 const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
                 int c_waves = (int)((size_t)(160 * 1024) / c_lds);
                 if (const char* e = getenv("PMX_ALIGN_COMPACT_WAVES")) c_waves = atoi(e);
@@ -547,9 +551,30 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 A.pair_perm = order;
                 A.retry_list = al->bail_list.p;
                 A.retry_count = al->retry_count.p + 2;
+                // Two-kernel form (default): sketch + index probes in k_compact_seeds, whose only LDS is the minimizer queue
+                // -- 7 KB per wave against the 21 KB of the pairs' work state, so that part runs at the occupancy its
+                // registers allow instead of seven waves per CU; the seeds cross in HBM (224 bytes per pair with 16-bit
+                // position words).  PMX_ALIGN_COMPACT_FUSED keeps everything in k_align_compact.
+                if (!c_fused) {
+                    const size_t blocks = (size_t)((n_items + 63) / 64);
+                    al->cseeds.ensure(blocks * (size_t)PMX_C_CAP * (pos16 ? 1 : 2) * 64);
+                    al->cseed_n.ensure(blocks * 64);
+                    A.cseeds = al->cseeds.p;
+                    A.cseed_n = al->cseed_n.p;
+                    int s_waves = 16;
+                    if (const char* e = getenv("PMX_ALIGN_CSEED_WAVES")) s_waves = atoi(e);
+                    const int64_t s_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(s_waves, 1), (n_items + 63) / 64);
+                    timer_begin(ctx, "align_cseeds");
+                    hipLaunchKernelGGL(pos16 ? k_compact_seeds16 : k_compact_seeds32, dim3((unsigned)s_grid), dim3(64), (size_t)PMX_C_SEEDQ * 2 * 64 * sizeof(uint32_t),
+                                       ctx->stream, A);
+                    PMX_HIP(hipGetLastError());
+                    timer_end(ctx, "align_cseeds", 1);
+                }
+                timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
                 hipLaunchKernelGGL(c_kern, dim3((unsigned)c_grid), dim3(64), c_lds, ctx->stream, A);
                 PMX_HIP(hipGetLastError());
                 timer_end(ctx, "align_dom", 1);
+                A.cseeds = nullptr; A.cseed_n = nullptr;
                 if (A.prof) {   // the compact tier's own phase profile, then the accumulators start over for the general tiers
                     unsigned long long h[8];
                     PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

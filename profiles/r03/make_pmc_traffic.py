@@ -33,7 +33,7 @@ def main():
     import bench
     res = {"reads_per_gpu": reads, "read_len": read_len, "source_digest": bench.source_digest(),
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes), tools/profile_r03_pmc.sh"}
-    for name, sub in (("dominant_kernel", "k_align_compact"), ("k_align_reads_tpp", "k_align_reads_tpp"), ("k_align_reads_t1", "k_align_reads_t1"),
+    for name, sub in (("dominant_kernel", "k_align_compact"), ("k_compact_seeds", "k_compact_seeds"), ("k_align_reads_tpp", "k_align_reads_tpp"), ("k_align_reads_t1", "k_align_reads_t1"),
                       ("k_align_dp_serve", "k_align_dp_serve"), ("k_seed_histogram", "k_seed_histogram"), ("k_score_chains", "k_score_chains"),
                       ("k_pack_reads", "k_pack_reads")):
         f = per_launch(fetch_dir, "FETCH_SIZE", sub)

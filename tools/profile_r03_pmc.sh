@@ -16,7 +16,7 @@ find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 for d in fetch write sq; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); python3 - "$f" "$O/pmc_$d.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_align", "k_seed_histogram", "k_score", "k_pack_reads"))]
+keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_align", "k_compact_seeds", "k_seed_histogram", "k_score", "k_pack_reads"))]
 w = csv.DictWriter(open(sys.argv[2], "w"), fieldnames=["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name", "Counter_Value"], extrasaction="ignore")
 w.writeheader()
 for r in keep:
