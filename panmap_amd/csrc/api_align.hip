@@ -323,6 +323,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     A.tpp.base = nullptr; A.tpp.wave_stride = 0; A.tpp.pad = 0;
     A.work_queue = nullptr;
     A.cseeds = nullptr; A.cseed_n = nullptr;
+    A.tpp_lanes = 64;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
     A.paired = paired ? 1 : 0;
     A.revcomp_mate2 = revcomp_mate2 ? 1 : 0;
@@ -431,7 +432,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         if (use_tier0) {   // tier 0: thread per pair + DP service rounds
             int tpp_waves = 16;   // 4 per SIMD: what k_align_reads_tpp's register allocation targets (PMX_TPP_OCC)
             if (const char* e = getenv("PMX_ALIGN_TPP_WAVES")) tpp_waves = atoi(e);
-            const int64_t max_grid = std::min<int64_t>((int64_t)ctx->n_cu * tpp_waves, (n_items + 63) / 64);
+            const int64_t max_grid = std::min<int64_t>((int64_t)ctx->n_cu * tpp_waves, (n_items + 7) / 8);   // (down to eight pairs per wave: launch_tpp)
             // thread-per-pair layout: interleaved arena per wave + a small contiguous struct region per thread
             size_t tpp_tb = 0;   // in-lane DPs measured slower than request + replay (divergence): off
             if (const char* e = getenv("PMX_ALIGN_TPP_TB")) tpp_tb = (size_t)atoll(e);
@@ -494,7 +495,13 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             A.retry_count = al->retry_count.p;
             A.layout = tpp_layout;
             auto launch_tpp = [&](int round, int64_t n_work, const uint32_t* worklist, uint32_t* next_list) {
-                int64_t grid = std::min<int64_t>(max_grid, (n_work + 63) / 64);
+                // pairs per wave: 64, halved while the launch still fits the resident grid (k_align_reads_tpp: a small launch
+                // is latency-bound, its waves last as long as their slowest pair)
+                int lanes = 64;
+                while (lanes > 8 && (n_work + lanes / 2 - 1) / (lanes / 2) <= max_grid) lanes /= 2;
+                if (const char* e = getenv("PMX_ALIGN_TPP_LANES")) lanes = std::max(1, std::min(64, atoi(e)));
+                A.tpp_lanes = lanes;
+                int64_t grid = std::min<int64_t>(max_grid, (n_work + lanes - 1) / lanes);
                 A.slow_stride = tpp_raw_stride;
                 A.slow_base = al->slab_raw.p;
                 A.n_items = n_work;
@@ -544,9 +551,12 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 const bool c_fused = getenv("PMX_ALIGN_COMPACT_FUSED") != nullptr;
                 auto c_kern = c_fused ? (pos16 ? k_align_compact16_fused : k_align_compact32_fused) : (pos16 ? k_align_compact16 : k_align_compact32);
                 const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
-                int c_waves = (int)((size_t)(160 * 1024) / c_lds);
-                if (const char* e = getenv("PMX_ALIGN_COMPACT_WAVES")) c_waves = atoi(e);
-                const int64_t c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(c_waves, 1), (n_items + 63) / 64);
+                // One workgroup (wave) per 64 pairs, handed out by the dispatcher as CUs free up: the pairs of a wave cost what
+                // their worst lane costs, and with a resident grid striding over the positions (PMX_ALIGN_COMPACT_WAVES = waves
+                // per CU brings it back) the slowest stride set the kernel's end -- 10M reads: 17.05 -> 15.5 ms, and the seeds
+                // kernel below 4.77 -> 4.10 ms.  (The hardware keeps 160 KB / c_lds = seven waves per CU resident either way.)
+                int64_t c_grid = (n_items + 63) / 64;
+                if (const char* e = getenv("PMX_ALIGN_COMPACT_WAVES")) c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), c_grid);
                 A.n_items = n_items;
                 A.pair_perm = order;
                 A.retry_list = al->bail_list.p;
@@ -561,11 +571,14 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     al->cseed_n.ensure(blocks * 64);
                     A.cseeds = al->cseeds.p;
                     A.cseed_n = al->cseed_n.p;
-                    int s_waves = 16;
-                    if (const char* e = getenv("PMX_ALIGN_CSEED_WAVES")) s_waves = atoi(e);
-                    const int64_t s_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(s_waves, 1), (n_items + 63) / 64);
+                    // (four waves per SIMD by the kernel's 113 VGPRs; a resident grid of 8 / 12 / 16 waves per CU -- PMX_ALIGN_CSEED_WAVES --
+                    // takes 7.5 / 6.0 / 4.8 ms per 5M pairs, one workgroup per 64 pairs 4.1; the register budget of five waves per
+                    // SIMD spills and gains 1 %, of six loses)
+                    auto s_kern = pos16 ? k_compact_seeds16 : k_compact_seeds32;
+                    int64_t s_grid = (n_items + 63) / 64;
+                    if (const char* e = getenv("PMX_ALIGN_CSEED_WAVES")) s_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), s_grid);
                     timer_begin(ctx, "align_cseeds");
-                    hipLaunchKernelGGL(pos16 ? k_compact_seeds16 : k_compact_seeds32, dim3((unsigned)s_grid), dim3(64), (size_t)PMX_C_SEEDQ * 2 * 64 * sizeof(uint32_t),
+                    hipLaunchKernelGGL(s_kern, dim3((unsigned)s_grid), dim3(64), (size_t)PMX_C_SEEDQ * 2 * 64 * sizeof(uint32_t),
                                        ctx->stream, A);
                     PMX_HIP(hipGetLastError());
                     timer_end(ctx, "align_cseeds", 1);
