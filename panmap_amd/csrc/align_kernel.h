@@ -28,7 +28,6 @@ struct AlignArgs {
     uint32_t dp_slot_cap;
     int dp_round;
     int tpp_ring_w;             // k_align_reads_tpp: minimizer window length when the ring lives in LDS, else 0
-    int tpp_lanes;              // k_align_reads_tpp: pairs per wave (64; fewer when the launch is too small to fill the chip)
     int sk_no_lane_ring;        // wave-per-pair kernels: 1 = sketch with the window ring in LDS instead of across the lanes
     int no_rows_dp;             // wave-per-read kernels: 1 = never the row-by-row DP (PMX_ALIGN_NO_ROWS_DP)
     // Minimizer hand-over: a pair that posts a DP request in the thread-per-pair kernel leaves its minimizer list here

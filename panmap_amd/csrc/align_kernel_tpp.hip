@@ -26,6 +26,7 @@ namespace aln {
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PMX_TPP_OCC)))
 k_align_reads_tpp(AlignArgs A) {
     static_assert(offsetof(AlignArgs, tpp) == 0, "IPtr::phys reads the arena from the start of the kernarg segment");
+    const int64_t n_threads = (int64_t)gridDim.x * 64;
     uint8_t* raw = A.slow_base + (size_t)blockIdx.x * A.slow_stride + ((threadIdx.x & 63u) << 2);   // strided Reg region of this lane
     const int n_segs = A.paired ? 2 : 1;
     // minimizer window ring of this lane in LDS (dynamic LDS = 12 bytes x w x 64 lanes; 0 -> ring in the arena)
@@ -38,13 +39,11 @@ k_align_reads_tpp(AlignArgs A) {
     }
 
     const int lane = (int)(threadIdx.x & 63u);
-    // every lane of the wave runs the same number of iterations (the CIGAR arena is claimed once per wave).
-    // A.tpp_lanes < 64: a launch too small to fill the chip spreads its pairs over more waves, `tpp_lanes` of them per
-    // wave on the first lanes -- a wave lasts as long as its slowest pair and the few waves of a small launch leave every
-    // memory round trip exposed, so eight pairs per wave on eight times the waves finish sooner than 64 on a few
-    const int64_t per_wave = A.tpp_lanes > 0 && A.tpp_lanes < 64 ? A.tpp_lanes : 64;
-    for (int64_t it0 = (int64_t)blockIdx.x * per_wave; it0 < A.n_items; it0 += (int64_t)gridDim.x * per_wave) {
-        const int64_t it = lane < per_wave ? it0 + lane : A.n_items;
+    // every lane of the wave runs the same number of iterations (the CIGAR arena is claimed once per wave)
+    // (tried, round 3: a launch too small to fill the chip spread over more waves, eight pairs on each -- the 27.8k bails of a
+    // 10M-read batch: align stage 25.5 -> 26.4 ms, real reads 22.5 -> 21.7 ms; not kept)
+    for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < A.n_items; it0 += n_threads) {
+        const int64_t it = it0 + lane;
         int64_t item = -1, slot = -1;
         bool emit = false;
         Work W;

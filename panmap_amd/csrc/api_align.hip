@@ -323,7 +323,6 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     A.tpp.base = nullptr; A.tpp.wave_stride = 0; A.tpp.pad = 0;
     A.work_queue = nullptr;
     A.cseeds = nullptr; A.cseed_n = nullptr;
-    A.tpp_lanes = 64;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
     A.paired = paired ? 1 : 0;
     A.revcomp_mate2 = revcomp_mate2 ? 1 : 0;
@@ -432,7 +431,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         if (use_tier0) {   // tier 0: thread per pair + DP service rounds
             int tpp_waves = 16;   // 4 per SIMD: what k_align_reads_tpp's register allocation targets (PMX_TPP_OCC)
             if (const char* e = getenv("PMX_ALIGN_TPP_WAVES")) tpp_waves = atoi(e);
-            const int64_t max_grid = std::min<int64_t>((int64_t)ctx->n_cu * tpp_waves, (n_items + 7) / 8);   // (down to eight pairs per wave: launch_tpp)
+            const int64_t max_grid = std::min<int64_t>((int64_t)ctx->n_cu * tpp_waves, (n_items + 63) / 64);
             // thread-per-pair layout: interleaved arena per wave + a small contiguous struct region per thread
             size_t tpp_tb = 0;   // in-lane DPs measured slower than request + replay (divergence): off
             if (const char* e = getenv("PMX_ALIGN_TPP_TB")) tpp_tb = (size_t)atoll(e);
@@ -495,13 +494,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             A.retry_count = al->retry_count.p;
             A.layout = tpp_layout;
             auto launch_tpp = [&](int round, int64_t n_work, const uint32_t* worklist, uint32_t* next_list) {
-                // pairs per wave: 64, halved while the launch still fits the resident grid (k_align_reads_tpp: a small launch
-                // is latency-bound, its waves last as long as their slowest pair)
-                int lanes = 64;
-                while (lanes > 8 && (n_work + lanes / 2 - 1) / (lanes / 2) <= max_grid) lanes /= 2;
-                if (const char* e = getenv("PMX_ALIGN_TPP_LANES")) lanes = std::max(1, std::min(64, atoi(e)));
-                A.tpp_lanes = lanes;
-                int64_t grid = std::min<int64_t>(max_grid, (n_work + lanes - 1) / lanes);
+                int64_t grid = std::min<int64_t>(max_grid, (n_work + 63) / 64);
                 A.slow_stride = tpp_raw_stride;
                 A.slow_base = al->slab_raw.p;
                 A.n_items = n_work;

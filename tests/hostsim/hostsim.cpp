@@ -55,7 +55,13 @@ extern "C" int hs_align(const char* ref, int64_t ref_len, int n_reads, const cha
     if (verbose) fprintf(stderr, "hostsim: k=%d w=%d mid_occ=%d fast=%zu slow=%zu max_tlen=%d\n", o.k, o.w, o.mid_occ, L.fast_bytes, L.slow_bytes, L.caps.max_tlen);
     const int n_items = paired ? n_reads / 2 : n_reads;
     int64_t used = 0;
+    const char* poison = getenv("PMX_HS_POISON");   // fill the work arrays before every item: results must not depend on what a slab held
     for (int it = 0; it < n_items; ++it) {
+        if (poison) {
+            const int pat = (int)strtol(poison, nullptr, 0);
+            memset(fast.data(), pat, fast.size());
+            memset(slow.data(), pat, slow.size());
+        }
         W.n_segs = n_segs;
         W.status = 0;
         bool too_long = false;
