@@ -171,7 +171,7 @@ struct CSeedOutT {
         else { *x = out[2 * i * PMX_C_STRIDE]; *y = out[(2 * i + 1) * PMX_C_STRIDE]; }
     }
 };
-#define PMX_C_NSEED_BAIL 0xffu   // the hand-over count of a pair the seeding already gave up on
+#define PMX_C_NSEED_BAIL 0xffffu   // the hand-over count (seeds | seeds of mate 1 << 8) of a pair the seeding already gave up on
 
 PMX_HD uint64_t c_bitrev64(uint64_t x) {
 #if defined(__clang__)
@@ -715,10 +715,11 @@ PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
 // compact_map_pair runs both on one memory block (the fused form: hostsim, PMX_ALIGN_COMPACT_FUSED).
 // prof (read only when prof_on): 8 per-lane cycle accumulators (sketch, probes, merge, chain fill, backtrack, regions, align + mapq, pairing)
 template <class MS>
-PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, int* n_seeds,
+PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, int* n_seeds, int* n_first,
                               unsigned long long* prof = nullptr, bool prof_on = false) {
     typedef typename MS::PosT PT;
     *n_seeds = 0;
+    *n_first = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long prof_t = prof_on ? (unsigned long long)clock64() : 0ULL;
 #endif
@@ -745,6 +746,7 @@ PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, con
             PMX_C_STAMP(0);
             if (sd.ovf) sd.bail = true;
             sd.drain(true);
+            if (s == 0) *n_first = sd.n_s;
             PMX_C_STAMP(1);
         }
     }
@@ -754,7 +756,7 @@ PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, con
 }
 
 template <class PT>
-PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_s, CResult& out, const CPenTab& pen_tab,
+PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_s, int n_s0, CResult& out, const CPenTab& pen_tab,
                                unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false) {
     typedef CMemT<PT> MT;
     out.mapped = 0;
@@ -770,6 +772,44 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
     const int n = n_s;
     {
         // (heap of seed indices and, later, its pop order in the HIGH bytes of G; the destinations go to the LOW bytes)
+        // The usual pair first: the seeds of a mate arrive in query order, i.e. with strictly rising (or, on the other
+        // strand, strictly falling) reference position words, so the pair is two sorted runs.  While no two words are equal
+        // the heap can only pop them in ascending order, which a two-way merge gives in n steps -- GH(n-1-t) = t-th seed
+        // out, n_for as below.  Equal words (the same minimizer in both mates where they overlap: the pop order of the
+        // tie is the heap's) or a run that is not monotone (a seed from elsewhere) leave the pair to the heap.
+        int n_for = 0;
+        bool merged = false;
+        if (n_s0 >= 0 && n_s0 <= n) {
+            int ci = n_s0, cj = n - n_s0;
+            int i = 0, di = 1, j = n_s0, dj = 1;
+            if (ci > 1 && m.X(0) > m.X(ci - 1)) { i = ci - 1; di = -1; }
+            if (cj > 1 && m.X(n_s0) > m.X(n - 1)) { j = n - 1; dj = -1; }
+            uint32_t xi = ci ? m.X(i) : 0xffffffffu, xj = cj ? m.X(j) : 0xffffffffu;
+            bool ok = true;
+            int t = 0;
+            for (; t < n && ok; ++t) {
+                ok = xi != xj;
+                const bool first = xi < xj;
+                const int idx = first ? i : j;
+                m.GH(n - 1 - t) = (c_u8)idx;
+                n_for += ((first ? xi : xj) ^ m.Y(idx)) & 1u ? 0 : 1;
+                if (first) {
+                    --ci; i += di;
+                    const uint32_t nx = ci ? m.X(i) : 0xffffffffu;
+                    ok = ok && nx > xi;
+                    xi = nx;
+                } else {
+                    --cj; j += dj;
+                    const uint32_t nx = cj ? m.X(j) : 0xffffffffu;
+                    ok = ok && nx > xj;
+                    xj = nx;
+                }
+            }
+            merged = ok;
+        }
+        PMX_C_COUNT(3, merged ? 1 : 0);
+        if (!merged) {
+        n_for = 0;
         for (int i = 0; i < n; ++i) m.GH(i) = (c_u8)i;
         auto heapdown = [&](int i, int sz) PMX_LAMBDA_INLINE {   // ks_heapdown with "less" = larger reference position word (min-heap)
             const uint32_t tmp = m.GH(i);
@@ -792,7 +832,6 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
         for (int q = (n >> 1) - 1; q >= 0; --q) heapdown(q, n);
         // pops: the root leaves, the last element takes its place (every occurrence list has one entry), the slot the
         // heap gave up keeps the popped seed -> GH(n-1-t) = t-th seed out
-        int n_for = 0;
         for (int sz = n; sz > 0;) {
             const uint32_t si = m.GH(0);
             const uint32_t last = m.GH(sz - 1);
@@ -800,6 +839,7 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
             if (sz > 0) { m.GH(0) = (c_u8)last; heapdown(0, sz); }
             m.GH(sz) = (c_u8)si;
             n_for += ((m.X((int)si) ^ m.Y((int)si)) & 1u) ? 0 : 1;   // strand of the reference copy == strand of the query copy
+        }
         }
         // destinations: forward-strand anchors first, in pop order, then the reverse-strand ones, in pop order
         {
@@ -1133,9 +1173,9 @@ PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri
                              const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false) {
     out.mapped = 0;
     out.edit[0] = rd[0].len; out.edit[1] = rd[1].len;
-    int n_s = 0;
-    if (compact_seed_pair(m, o, ri, rd, amb, &n_s, prof, prof_on) != PMX_C_DONE) return PMX_C_BAIL;
-    return compact_chain_pair(m, o, ri, rd, n_s, out, pen_tab, prof, want_edits, prof_on);
+    int n_s = 0, n_s0 = 0;
+    if (compact_seed_pair(m, o, ri, rd, amb, &n_s, &n_s0, prof, prof_on) != PMX_C_DONE) return PMX_C_BAIL;
+    return compact_chain_pair(m, o, ri, rd, n_s, n_s0, out, pen_tab, prof, want_edits, prof_on);
 }
 
 }  // namespace aln

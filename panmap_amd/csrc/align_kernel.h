@@ -50,7 +50,7 @@ struct AlignArgs {
     // Compact tier, two-kernel form (align_kernel_compact.hip): k_compact_seeds leaves the seeds of launch position `it` in
     // the hand-over words (align/aln_compact.hpp CSeedOutT) and their number in cseed_n[it]; NULL = the fused kernel
     uint32_t* cseeds;
-    uint8_t* cseed_n;
+    uint16_t* cseed_n;         // seeds | seeds of mate 1 << 8, or PMX_C_NSEED_BAIL
 
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
     int32_t* edits;             // NULL, or per read: count_read_errors (src/mm_align.c:122-133) of its first region, the read length without one

@@ -44,16 +44,16 @@ __device__ __forceinline__ void compact_seeds_body(const AlignArgs& A) {
     for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < A.n_items; it0 += n_threads) {   // (uniform trip count: the drains are wave-wide)
         const int64_t it = it0 + lane;
         so.out = (c_g32*)(A.cseeds + (size_t)(it0 >> 6) * CSeedOutT<PT>::kBlockWords) + lane;
-        int n_s = 0, rc = PMX_C_DONE;
+        int n_s = 0, n_s0 = 0, rc = PMX_C_DONE;
         if (it < A.n_items) {
             CRead rd[2];
             const uint32_t* amb[2];
             compact_item(A, it, rd, amb);
             unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            rc = compact_seed_pair(so, A.opt, A.ri, rd, amb, &n_s, pacc, A.prof != nullptr);
+            rc = compact_seed_pair(so, A.opt, A.ri, rd, amb, &n_s, &n_s0, pacc, A.prof != nullptr);
             if (A.prof && lane == 0)
                 for (int k = 0; k < 2; ++k) atomicAdd(&A.prof[k], pacc[k]);
-            A.cseed_n[it] = (uint8_t)(rc == PMX_C_DONE ? n_s : (int)PMX_C_NSEED_BAIL);
+            A.cseed_n[it] = (uint16_t)(rc == PMX_C_DONE ? (n_s | n_s0 << 8) : (int)PMX_C_NSEED_BAIL);
         }
     }
 }
@@ -92,12 +92,12 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
         if (PRESEEDED) {
             // two-kernel form: the pairs' seeds wait in the hand-over words; a wave copies seed i of its 64 pairs with
             // one contiguous load per word, four seeds requested together
-            int n_s = 0;
+            int n_s = 0, n_s0 = 0;
             if (it < A.n_items) {
                 item = compact_item(A, it, rd, amb);
                 const uint32_t c = A.cseed_n[it];
                 if (c == PMX_C_NSEED_BAIL) rc = PMX_C_BAIL;
-                else n_s = (int)c;
+                else { n_s = (int)(c & 0xffu); n_s0 = (int)(c >> 8); }
             }
             CSeedOutT<PT> so;
             so.q = nullptr;
@@ -110,7 +110,7 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
                 for (int b = 0; b < 4; ++b) if (i0 + b < n_s) m.setSeed(i0 + b, x[b], y[b]);
             }
             if (item >= 0 && rc == PMX_C_DONE) {
-                rc = compact_chain_pair(m, A.opt, A.ri, rd, n_s, res, tab, pacc, A.edits != nullptr, A.prof != nullptr);
+                rc = compact_chain_pair(m, A.opt, A.ri, rd, n_s, n_s0, res, tab, pacc, A.edits != nullptr, A.prof != nullptr);
                 if (A.prof && lane == 0)
                     for (int k = 2; k < 8; ++k) atomicAdd(&A.prof[k], pacc[k]);
             }

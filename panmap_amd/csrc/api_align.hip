@@ -50,7 +50,7 @@ struct pmx_aligner {
     uint32_t mv_epoch = 0;
     DevBuf<uint32_t> retry_list2, bail_list;
     DevBuf<uint32_t> cseeds;            // compact tier, two-kernel form: seed hand-over (AlignArgs::cseeds / cseed_n)
-    DevBuf<uint8_t> cseed_n;
+    DevBuf<uint16_t> cseed_n;
     DevBuf<uint8_t> dp_req;
     DevBuf<DpRes> dp_res;
     DevBuf<uint32_t> dp_ncached, dp_slot_pairs, dp_list_a, dp_list_b;

@@ -13,7 +13,7 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 #endif
 #include "align/aln_host.hpp"
 #ifndef PMX_HOSTSIM_TPP
-// work counters of the compact tier (0: anchors, 1: anchor pairs the chain fill evaluated, 2: run skips)
+// work counters of the compact tier (0: anchors, 1: anchor pairs the chain fill evaluated, 2: run skips, 3: pairs whose seeds the two-way merge ordered)
 static long long pmx_c_cnt[4];
 #define PMX_C_DUMP 1
 #define PMX_C_COUNT(k, v) (pmx_c_cnt[k] += (v))
@@ -232,12 +232,12 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
             auto split = [&](auto pt) {
                 typedef decltype(pt) PT;
                 CSeedOutT<PT> so{q.data(), ho.data()};
-                int n_s = 0;
+                int n_s = 0, n_s0 = 0;
                 res.mapped = 0;
-                if (compact_seed_pair(so, o, ri, rd, amb, &n_s) != PMX_C_DONE) return (int)PMX_C_BAIL;
+                if (compact_seed_pair(so, o, ri, rd, amb, &n_s, &n_s0) != PMX_C_DONE) return (int)PMX_C_BAIL;
                 CMemT<PT> m{lds.data()};
                 for (int i = 0; i < n_s; ++i) { uint32_t x, y; so.get(i, &x, &y); m.setSeed(i, x, y); }
-                return compact_chain_pair(m, o, ri, rd, n_s, res, tab);
+                return compact_chain_pair(m, o, ri, rd, n_s, n_s0, res, tab);
             };
             rc = pos16 ? split((uint16_t)0) : split((uint32_t)0);
         } else if (pos16) { CMemT<uint16_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res, tab); }
