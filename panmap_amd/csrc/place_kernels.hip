@@ -211,6 +211,10 @@ __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long*
 // Insert a wave's queued seeds: every active lane takes up to four queue entries at a time and issues their first
 // probes together (independent loads in flight), so a drain costs about one table round trip per four entries per
 // lane instead of one per entry.  A first probe that neither hits nor finds an empty slot continues in table_insert.
+// ABSORBED: the caller (k_seed_histogram_ks) overwrites the entries its block cache has taken with PMX_EMPTY_KEY and they
+// are skipped here; the generic kernel has no cache and hands every entry on.  (A seed whose hash IS the all-ones sentinel
+// -- 2^-64 per seed -- cannot be a key of the table in either kernel: the table's empty mark is that value.)
+template <bool ABSORBED>
 __device__ __forceinline__ void drain_seed_queue(const uint64_t* queue, int n_q, int rank, int n_act, uint64_t* keys, unsigned long long* vals,
                                                  uint64_t mask, unsigned long long* counters) {
     for (int q0 = rank; q0 < n_q; q0 += 4 * n_act) {
@@ -222,7 +226,7 @@ __device__ __forceinline__ void drain_seed_queue(const uint64_t* queue, int n_q,
             const int q = q0 + b * n_act;
             ok[b] = q < n_q;
             h[b] = ok[b] ? queue[q] : 0;
-            ok[b] = ok[b] && h[b] != PMX_EMPTY_KEY;   // (entries the block cache has absorbed)
+            if (ABSORBED) ok[b] = ok[b] && h[b] != PMX_EMPTY_KEY;   // (entries the block cache has absorbed)
             slot[b] = mix64(h[b]) & mask;
             cur[b] = 0;
             if (ok[b]) cur[b] = __hip_atomic_load((unsigned long long*)&keys[slot[b]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -262,7 +266,7 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
         const unsigned long long act = __ballot(1);
         const int rank = (int)__popcll(act & ((1ULL << (tid & 63)) - 1ULL)), n_act = (int)__popcll(act);
         const int n_q = (int)__hip_atomic_load(qcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        drain_seed_queue(queue, n_q, rank, n_act, keys, vals, mask, counters);
+        drain_seed_queue<false>(queue, n_q, rank, n_act, keys, vals, mask, counters);
         if (rank == 0) *qcnt = 0;
     };
     // base hashes A, C, G, T (src/seeding.hpp:100-112) picked with selects, not a table in memory
@@ -478,7 +482,7 @@ __device__ __forceinline__ void seed_queue_to_cache_and_table(uint64_t* queue, i
             queue[q] = PMX_EMPTY_KEY;
         }
     }
-    drain_seed_queue(queue, n_q, lane, 64, keys, vals, mask, counters);
+    drain_seed_queue<true>(queue, n_q, lane, 64, keys, vals, mask, counters);
 }
 
 template <int K, int S, int L>
