@@ -10,6 +10,7 @@
 #define PMX_DPG_KINDS 3        // 0: gap fill (approximate maximum), 1: extension to the right, 2: extension to the left
 #define PMX_DPG_BUCKETS (PMX_DPG_CLASSES * PMX_DPG_KINDS)
 #define PMX_DPG_NO_BUCKET 15
+#define PMX_DPG_WORK 13        // counts[]: the task counter of k_align_dp_group (entries 12, 13 belong to no bucket)
 #define PMX_DPG_LDS_PER_REQ (PMX_DPG_MAXLEN + 4 * 2 * PMX_DPG_MAXLEN + 4 * PMX_DPG_MAXLEN + 4 * PMX_DPG_MAXLEN + 4 * 24)
 #define PMX_DPG_LDS_BYTES (PMX_DPG_LDS_PER_REQ * (64 / PMX_DPG_G))
 #define PMX_DPG_TB_PER_REQ (PMX_DPG_MAXLEN * PMX_DPG_MAXLEN)

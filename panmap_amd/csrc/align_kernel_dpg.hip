@@ -384,16 +384,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     constexpr uint32_t per_wave = 64 / PMX_DPG_G;
     uint32_t n_tasks = 0;
     for (int b = 0; b < PMX_DPG_BUCKETS; ++b) n_tasks += (D.counts[b] + per_wave - 1) / per_wave;
-    for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    // Tasks are drawn from a counter (counts[PMX_DPG_WORK], zeroed with the bucket counts), the widest classes first and
+    // within a class the longest requests first: a resident grid striding over the task list gave every wave the same
+    // number of tasks whatever they cost and left the sixteen-column classes -- the list's end -- for last.
+    for (;;) {
+        uint32_t task = 0;
+        if ((threadIdx.x & 63u) == 0) task = atomicAdd(&D.counts[PMX_DPG_WORK], 1u);
+        task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
+        if (task >= n_tasks) break;
         uint32_t fb = 0, wb = 0, nb = 0;
-        int b = 0;
-        for (;; ++b) {   // (ends: task < n_tasks)
+        int b = PMX_DPG_BUCKETS - 1;
+        for (;; --b) {   // (ends: task < n_tasks)
             nb = D.counts[b];
             const uint32_t wn = (nb + per_wave - 1) / per_wave;
             if (task < wb + wn) break;
             wb += wn;
-            fb += nb;
         }
+        for (int c = 0; c < b; ++c) fb += D.counts[c];
         const uint32_t at = (task - wb) * per_wave;
         const int n_here = (int)(nb - at < per_wave ? nb - at : per_wave);
         const uint32_t* ids = D.sorted_ids + fb + at;
