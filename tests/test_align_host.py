@@ -157,6 +157,50 @@ def test_compact_tier_equals_reference(pmx, oracle, cases):
             os.environ.pop("PMX_HS_COMPACT_POS32", None)
 
 
+def test_compact_tier_seed_order_merge_and_heap(pmx, oracle):
+    """the compact tier orders a pair's seeds by a two-way merge when they are two strictly monotone runs without equal
+    reference position words and by the reference's heap (map.c:102-166) otherwise: short inserts make the mates overlap
+    (the same minimizer in both: equal words, the tie's pop order is the heap's), long ones never do -- both paths are
+    taken, and every pair the tier finishes carries the reference's result"""
+    import ctypes as C
+    g = _ref_genome()
+    L = ac.hostsim(False)
+    cnt = (C.c_longlong * 4)()
+    seen = {}
+    for name, ins in (("overlapping", 200.0), ("apart", 420.0)):
+        concat, off = pmx.simulate_paired_reads(g, 2000, seed=77, mean_insert=ins, sd_insert=15.0)
+        raw = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+        reads = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(raw)]
+        want = oracle.ref_align_reads_direct(g, reads, True, 8)
+        L.hs_compact_counts(cnt, 1)
+        got, done = ac.hostsim_align_compact(g, reads)
+        L.hs_compact_counts(cnt, 1)
+        idx = [i for i in range(len(want)) if done[i]]
+        assert len(idx) >= (0.6 if name == "overlapping" else 0.9) * len(want), (name, len(idx))
+        bad = ac.compare_results([got[i] for i in idx], [want[i] for i in idx])
+        assert not bad, (name, bad[:10])
+        seen[name] = (int(cnt[3]), len(want))
+    assert seen["apart"][0] >= 0.95 * seen["apart"][1], seen            # no shared minimizers: the merge orders them
+    assert seen["overlapping"][0] <= 0.5 * seen["overlapping"][1], seen  # 100 shared bases: the heap decides the ties
+
+
+def test_thread_per_pair_pipeline_ignores_what_its_work_arrays_held(pmx):
+    """the per-pair work arrays of the general tier are slabs that earlier pairs (or earlier calls) have written: filled
+    with different byte patterns before every pair (PMX_HS_POISON), the pipeline gives the same records"""
+    import os
+    g = _ref_genome()
+    concat, off = pmx.simulate_paired_reads(g, 400, seed=5, sub_rate=0.02)
+    reads = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+    reads = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(reads)]
+    base = ac.hostsim_align(g, reads, True, tpp=True)
+    try:
+        for pat in ("0xff", "0xa5"):
+            os.environ["PMX_HS_POISON"] = pat
+            assert not ac.compare_results(ac.hostsim_align(g, reads, True, tpp=True), base), pat
+    finally:
+        os.environ.pop("PMX_HS_POISON", None)
+
+
 def test_sliced_reference_sketch_equals_the_sequential_one(pmx, sars):
     """the device index build sketches the reference in independent 32-base slices with w + k + 1 bases of run-in
     (align/aln_seed.hpp sketch_slice); the host build runs sketch.c:77-143 from end to end: same minimizers in the same
