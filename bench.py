@@ -772,9 +772,11 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0,
                              "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": dom_ms,
                              "algorithmic_bytes_per_launch": alg_bytes, "source_digest": digest,
-                             "note": "mapping kernel (sketch, index probes, chaining, region logic, extension): integer/latency bound by "
+                             "note": "mapping kernel (heap merge, chaining, region logic, extension, mapq, pairing; short reads: the sketch and the "
+                                     "index probes run before it in k_compact_seeds16, see kernels_ms): integer/latency bound by "
                                      "construction (SURVEY 8d: S3/S4 are not HBM-bound), so the HBM fraction is low; `traffic` is what the "
-                                     "kernel really moves (PMC), `achieved` prices only the compulsory input + output"},
+                                     "kernel really moves (PMC; includes the seed hand-over it reads), `achieved` prices only the stage's "
+                                     "compulsory input + output (SURVEY 8d: 93 B per read)"},
                 "roofline_valu": valu,
                 "dp": {"pair_share": dp_pairs / n_items, "cells_per_step": dp_cells,
                        "gcups_align_stage": dp_cells / max(align_ms, 1e-9) / 1e6,
