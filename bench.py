@@ -48,14 +48,19 @@ import numpy as np  # noqa: E402
 
 
 def source_digest():
-    """digest of the kernel / library sources of this build: a PMC pass under profiles/ is only quoted when it carries it"""
+    """digest of the sources the align stage is compiled from and launched by (align/, align_kernel*, api_align.hip, device/):
+    a PMC pass under profiles/ is only quoted for the dominant kernel while it carries the digest of the build that runs.
+    (The place stage's files are not part of it: they cannot change that kernel's traffic or instruction counts.)"""
     h = hashlib.sha256()
     base = os.path.join(ROOT, "panmap_amd", "csrc")
     for dp, dn, fn in sorted(os.walk(base)):
         dn[:] = sorted(d for d in dn if d != "build")
         for f in sorted(fn):
+            rel = os.path.relpath(os.path.join(dp, f), base)
+            if not (rel.startswith(("align", "device" + os.sep)) or rel == "api_align.hip"):
+                continue
             if f.endswith((".hip", ".hpp", ".h", ".cpp")):
-                h.update(os.path.relpath(os.path.join(dp, f), base).encode())
+                h.update(rel.encode())
                 with open(os.path.join(dp, f), "rb") as fh:
                     h.update(fh.read())
     return h.hexdigest()[:16]

@@ -649,7 +649,10 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
             keep = pl->dd_keep.p;
             pl->dd_for = nullptr;                               // one use: the next call starts over
         }
-        int64_t chunk_mb = 64;   // (a group of three chunks = one table reservation: 1M x 150 bp is one group; 16 MB chunks measured 2.46 ms for the stage, one group 2.09)
+        // (a group of three chunks = one table reservation: 1M x 150 bp is one group; 16 MB chunks measured 2.46 ms for the stage,
+        //  one group 2.09).  A large range is cut into as few groups as 512 MB chunks allow: 10M x 150 bp in 24 launches of 64 MB
+        //  took 10.8 ms, in 16 of 96 MB 9.6 ms, in 4 of 384 MB 9.05 ms -- a third of the range per chunk, between 64 and 512 MB
+        int64_t chunk_mb = std::min<int64_t>(512, std::max<int64_t>(64, (((rr1 - rr0) * std::max<int64_t>(rs->max_len, 1) / 3) >> 20) + 1));
         if (const char* e = getenv("PMX_SEED_CHUNK_MB")) chunk_mb = std::max<int64_t>(1, atoll(e));
         const int64_t chunk_reads = std::max<int64_t>(1, (chunk_mb << 20) / std::max<int64_t>(rs->max_len, 1));
         // Table sizing.  The safe bound on the distinct keys a chunk can add is one per base; real reads add one seed per
@@ -702,7 +705,9 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
             // with 2 / 4 / 8 / 16 -- fewer, longer blocks fill the chip worse, and the atomics are not what bounds the kernel
             int seed_batches = 1;
             if (const char* e = getenv("PMX_SEED_BATCHES")) seed_batches = std::max(1, atoi(e));
-            const dim3 grid(ks_path ? grid_for(r1 - r0, PMX_SEED_BLOCK * seed_batches, ctx->n_cu * 16) : grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
+            // (the specialised kernel: one batch of reads per block whatever the chunk's size -- the dispatcher hands the blocks out;
+            //  a grid capped at what is resident made every block walk several batches, which measured slower, see above)
+            const dim3 grid(ks_path ? grid_for(r1 - r0, PMX_SEED_BLOCK * seed_batches, 1 << 30) : grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
             // the default seeding parameters run the kernel specialised for them (same results, ~3x fewer instructions)
             if (ks_path)
                 hipLaunchKernelGGL((l == 3 ? k_seed_histogram_ks<19, 8, 3> : k_seed_histogram_ks<19, 8, 1>), grid, block, lds_ks, st, rs->words.p, rs->amb.p,
