@@ -654,7 +654,10 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         //  took 10.8 ms, in 16 of 96 MB 9.6 ms, in 4 of 384 MB 9.05 ms -- a third of the range per chunk, between 64 and 512 MB
         int64_t chunk_mb = std::min<int64_t>(512, std::max<int64_t>(64, (((rr1 - rr0) * std::max<int64_t>(rs->max_len, 1) / 3) >> 20) + 1));
         if (const char* e = getenv("PMX_SEED_CHUNK_MB")) chunk_mb = std::max<int64_t>(1, atoll(e));
-        const int64_t chunk_reads = std::max<int64_t>(1, (chunk_mb << 20) / std::max<int64_t>(rs->max_len, 1));
+        const int64_t chunk_reads_opt = std::max<int64_t>(1, (chunk_mb << 20) / std::max<int64_t>(rs->max_len, 1));
+        // (with the safe bound -- one key per base of the group -- the groups stay three chunks of 64 MB: the table is grown by
+        //  what a group can add, and a 1.5 GB group would reserve a 68 GB table for a sample that overflowed the optimistic one)
+        const int64_t chunk_reads_safe = std::max<int64_t>(1, (std::min<int64_t>(chunk_mb, 64) << 20) / std::max<int64_t>(rs->max_len, 1));
         // Table sizing.  The safe bound on the distinct keys a chunk can add is one per base; real reads add one seed per
         // 5-6 bases and most of those repeat.  When the table is empty at the start of the call the chunks are first run
         // with an eighth of the safe bound (a smaller table to clear, probe and compact); an insert that finds no slot is
@@ -690,6 +693,7 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
                 PMX_HIP(hipEventCreateWithFlags(&pl->seed_done[j], hipEventDisableTiming));
             }
         }
+        const int64_t chunk_reads = bound_div > 1 ? chunk_reads_opt : chunk_reads_safe;
         for (int64_t g0 = rr0; g0 < rr1; g0 += chunk_reads * n_par) {
             const int64_t g1 = std::min<int64_t>(rr1, g0 + chunk_reads * n_par);
             const double safe_bound = (double)(g1 - g0) * (double)rs->max_len;
