@@ -47,23 +47,31 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 
-def source_digest():
-    """digest of the sources the align stage is compiled from and launched by (align/, align_kernel*, api_align.hip, device/):
-    a PMC pass under profiles/ is only quoted for the dominant kernel while it carries the digest of the build that runs.
-    (The place stage's files are not part of it: they cannot change that kernel's traffic or instruction counts.)"""
+def _digest(keep):
     h = hashlib.sha256()
     base = os.path.join(ROOT, "panmap_amd", "csrc")
     for dp, dn, fn in sorted(os.walk(base)):
         dn[:] = sorted(d for d in dn if d != "build")
         for f in sorted(fn):
             rel = os.path.relpath(os.path.join(dp, f), base)
-            if not (rel.startswith(("align", "device" + os.sep)) or rel == "api_align.hip"):
+            if not keep(rel):
                 continue
             if f.endswith((".hip", ".hpp", ".h", ".cpp")):
                 h.update(rel.encode())
                 with open(os.path.join(dp, f), "rb") as fh:
                     h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def source_digest():
+    """digest of the sources the align stage is compiled from and launched by (align/, align_kernel*, api_align.hip, device/):
+    a PMC pass under profiles/ is only quoted for an align kernel while it carries the digest of the build that runs."""
+    return _digest(lambda rel: rel.startswith(("align", "device" + os.sep)) or rel == "api_align.hip")
+
+
+def source_digest_place():
+    """the same for the place stage's kernels (pack, seeding, scoring): place_kernels.*, api_place.hip, readset.hpp, device/"""
+    return _digest(lambda rel: rel.startswith(("place_kernels", "device" + os.sep)) or rel in ("api_place.hip", "readset.hpp"))
 
 
 def usable_cpus():
@@ -89,9 +97,10 @@ def cpu_baseline(concat, off, index_arrays, placed_genome, sample_reads, threads
     panman/TBB/abseil), seeded on `threads` pthreads in ONE C call, then finalize + node scoring + best/tie rule;
     align leg = the reference's own aligner compiled from its sources (oracle/_ref: src/mm_align.c + vendored
     minimap2), timed around the bare align_reads_direct call with `threads` worker threads.  All ctypes marshalling
-    and unpacking happens outside the timed spans."""
+    and unpacking happens outside the timed spans.
+    Returns (the cpu_baseline object of the JSON line, what the CPU path computed: the same-run parity check compares the
+    GPU's results on the same reads with it -- SURVEY 8d "parity checks in the same run")."""
     from oracle import oracle as orc
-    import panmap_amd as pmx
     n = min(sample_reads, len(off) - 1)
     if paired:
         n &= ~1
@@ -107,28 +116,86 @@ def cpu_baseline(concat, off, index_arrays, placed_genome, sample_reads, threads
     kh, kl, st = orc.finalize_reads(uh, uc, 19)
     sc, _, _, _ = orc.score_nodes(index_arrays["parent"], index_arrays["offsets"], index_arrays["hash"], index_arrays["parent_count"],
                                   index_arrays["child_count"], kh, kl, st)
-    orc.best_ties(index_arrays["parent"], sc)
+    best, best_idx, ties = orc.best_ties(index_arrays["parent"], sc)
     t_score = time.perf_counter() - t0
-    # ---- align leg (R2 reverse-complemented as readFastqPaired does; marshalling not timed)
-    reads = [bytes(sub_concat[sub_off[i]:sub_off[i + 1]]) for i in range(n)]
-    if paired:
-        reads = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(reads)]
-    prep = orc.prepare_align_call(reads, paired)
+    # ---- align leg (R2 reverse-complemented as readFastqPaired does; marshalling in C, not timed)
+    prep = orc.prepare_align_call_flat(sub_concat, sub_off, paired, paired)
     t0 = time.perf_counter()
     orc.run_align_call(orc.rlib().align_reads_direct, placed_genome, prep, threads)
     t_align = time.perf_counter() - t0
-    res = orc.unpack_align_call(prep)
-    mapped = sum(r["mapped"] for r in res)
+    flat = orc.flatten_align_call(prep)
+    mapped = int(flat["mapped"].sum())
     total = t_seed + t_score + t_align
-    return dict(value=n / total, unit="reads/s", cores=threads, kind="reference",
+    # the CPUs this process can really run on: the affinity mask capped by the cgroup quota (256 threads under a 16-CPU
+    # quota are 16 cores' worth of work)
+    eff = threads if not quota else max(1, min(threads, int(round(quota))))
+    line = dict(value=n / total, unit="reads/s", cores=eff, threads_launched=threads, kind="reference",
                 kind_by_leg={"align": "reference (oracle/_ref: src/mm_align.c + vendored minimap2, compiled where they lie)",
                              "place": "port (oracle/oracle_place.c restatement; placement.cpp needs panman/TBB/abseil)"},
                 cgroup_cpu_quota=quota,
                 legs={"seed_reads_per_s": n / t_seed, "score_s_per_sample": t_score, "align_reads_per_s": n / t_align},
-                sample="%d of the workload's reads, %d threads (the CPUs this process may use): place leg = oracle port of seeding (one "
-                       "pthread-chunked C call, %.2fs) + node scoring (%.2fs, once per sample, single thread as a fixed cost); "
-                       "align leg = the reference's minimap2 via src/mm_align.c align_reads_direct, bare C call %.2fs; "
-                       "%d/%d %s mapped" % (n, threads, t_seed, t_score, t_align, mapped, len(res), "pairs" if paired else "reads"))
+                sample="%d of the workload's reads, %d threads on %d usable CPUs (affinity mask, capped by the cgroup quota): place leg = "
+                       "oracle port of seeding (one pthread-chunked C call, %.2fs) + node scoring (%.2fs, once per sample, single thread "
+                       "as a fixed cost); align leg = the reference's minimap2 via src/mm_align.c align_reads_direct, bare C call %.2fs; "
+                       "%d/%d %s mapped" % (n, threads, eff, t_seed, t_score, t_align, mapped, len(flat["mapped"]), "pairs" if paired else "reads"))
+    return line, dict(n=n, hist=(uh, uc), scores=sc, best=best, best_idx=best_idx, ties=ties, align=flat)
+
+
+def oracle_checks(pmx, gpu, cpu, node_id, paired):
+    """SURVEY 8d "parity checks in the same run": the GPU's results on the sample the CPU baseline ran on, against what the
+    CPU path (oracle restatement / the compiled reference aligner) computed on the same reads.
+    gpu = dict(hist=(hash, count), scores, result=PlacementResult, recs, cig); cpu = the second value of cpu_baseline()."""
+    n = cpu["n"]
+    hh, hc = gpu["hist"]
+    uh, uc = cpu["hist"]
+    out = {"reads": n,
+           "histogram_equal": bool(np.array_equal(hh, uh) and np.array_equal(hc, uc)), "histogram_entries": int(len(uh)),
+           "node_scores_bit_equal": bool(np.array_equal(np.ascontiguousarray(gpu["scores"]).view(np.uint64), np.ascontiguousarray(cpu["scores"]).view(np.uint64))),
+           "nodes_scored": int(len(cpu["scores"]))}
+    want_tsv = pmx.format_placement_tsv(pmx.PlacementResult(list(cpu["best"]), list(cpu["best_idx"]), cpu["ties"]), node_id)
+    out["tsv_equal"] = bool(pmx.format_placement_tsv(gpu["result"], node_id) == want_tsv)
+    # ---- per-read records: (pos, rs, re, qs, qe, mapq, rev, proper_frag) and the pair's / read's `mapped`, as
+    # extract_align_result / align_worker_func leave them (src/mm_align.c:271-354): an unmapped read is pos = INT_MAX, rest 0
+    recs, cig = gpu["recs"][:n], gpu["cig"]
+    flat = cpu["align"]
+    valid = (recs["mapped"] != 0) & ((recs["flags"] & 4) != 0)
+    g = np.zeros((n, 8), np.int32)
+    g[:, 0] = np.where(valid, recs["rs"] + 1, 2147483647)
+    for j, f in enumerate(("rs", "re", "qs", "qe", "mapq", "rev", "proper_frag")):
+        g[:, j + 1] = np.where(valid, recs[f].astype(np.int32), 0)
+    rec_ok = np.all(g == flat["fields"], axis=1)
+    g_mapped = recs["mapped"][0::2] if paired else recs["mapped"]
+    map_ok = (g_mapped != 0) == (flat["mapped"] != 0)
+    rec_ok &= np.repeat(map_ok, 2) if paired else map_ok
+    # ---- CIGARs: operation count and a position-weighted 64-bit digest of the operations of every read
+    def digests(ops, counts):
+        counts = counts.astype(np.int64)
+        tot = int(counts.sum())
+        if tot == 0:
+            return np.zeros(len(counts), np.uint64)
+        first = np.cumsum(counts) - counts
+        pos = np.arange(tot, dtype=np.int64) - np.repeat(first, counts)
+        with np.errstate(over="ignore"):
+            w = (ops[:tot].astype(np.uint64) + np.uint64(1)) * (np.uint64(0x9E3779B97F4A7C15) * (pos.astype(np.uint64) + np.uint64(1)) | np.uint64(1))
+            cs = np.concatenate([np.zeros(1, np.uint64), np.cumsum(w, dtype=np.uint64)])
+        return cs[first + counts] - cs[first]
+    g_n = np.where(valid, recs["n_cigar"].astype(np.int64), 0)
+    tot = int(g_n.sum())
+    first = np.cumsum(g_n) - g_n
+    idx = np.repeat(recs["cigar_off"].astype(np.int64) - first, g_n) + np.arange(tot, dtype=np.int64)
+    g_ops = np.asarray(cig).view(np.uint32)[idx] if tot else np.zeros(0, np.uint32)
+    cig_ok = (g_n == flat["n_cigar"].astype(np.int64)) & (digests(g_ops, g_n) == digests(flat["cigar"], flat["n_cigar"]))
+    out.update({"records_equal": "%d/%d" % (int(rec_ok.sum()), n), "cigars_equal": "%d/%d" % (int(cig_ok.sum()), n),
+                "records_all_equal": bool(rec_ok.all()), "cigars_all_equal": bool(cig_ok.all()),
+                "cigar_ops_compared": int(flat["n_cigar"].sum()), "mapped_reference": int(flat["mapped"].sum()),
+                "records_flagged_unsupported_or_overflow": int(np.sum((recs["flags"] & 3) != 0)),
+                "against": "place: oracle/oracle_place.c (restatement, pinned by the reference's golden TSV and unit-test contracts); align: "
+                           "oracle/_ref = the reference's src/mm_align.c + vendored minimap2 compiled where they lie; same reads, same run"})
+    if not rec_ok.all():
+        out["first_record_mismatches"] = [int(x) for x in np.nonzero(~rec_ok)[0][:8]]
+    if not cig_ok.all():
+        out["first_cigar_mismatches"] = [int(x) for x in np.nonzero(~cig_ok)[0][:8]]
+    return out
 
 
 class Sequencer:
@@ -294,6 +361,25 @@ def main():
         return out
 
     pcie = measure_pcie()
+
+    def measure_copy_ceiling(nbytes=1 << 30, reps=5):
+        """what this box's HBM sustains for the simplest streaming kernel there is: a device-to-device copy of 1 GB
+        (bytes read + bytes written per second), next to the 8 TB/s of the data sheet (SURVEY 8d "Metric")"""
+        a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del a, b
+        return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+    copy_ceiling = measure_copy_ceiling() if rank == 0 else None
 
     # ------------------------------------------------------------------------------------------------------ pipelines
     h_concat = torch.from_numpy(concat).pin_memory()
@@ -488,7 +574,7 @@ def main():
         for pi, pp in enumerate(pipes):
             box = [None, None]
             if rank == 0:
-                box = [pmx.Dist.unique_id() if not test_gloo else bytes(pmx.Dist.ID_BYTES), tempfile.mkdtemp(prefix="pmx_dist_%d_" % pi) if test_gloo else None]
+                box = [pmx.Dist.unique_id() if not test_gloo else os.urandom(pmx.Dist.ID_BYTES), tempfile.mkdtemp(prefix="pmx_dist_%d_" % pi) if test_gloo else None]
             dist.broadcast_object_list(box, src=0)
             if test_gloo:
                 os.environ["PMX_DIST_HOST_DIR"] = box[1]
@@ -555,7 +641,7 @@ def main():
     h2h_nodes = [None if pp.res is None else int(pp.res.best_index[4]) for pp in pipes]
 
     # ---------------------------------------------------------------- value_device_resident (one batch at a time, no PCIe)
-    kernel_ms = {"align": [], "align_dom": [], "align_cseeds": [], "seed": [], "score": []}
+    kernel_ms = {"align": [], "align_dom": [], "align_cseeds": [], "seed": [], "score": [], "pack": []}
     dp_stats = []
     resident = None
     d_concat = torch.from_numpy(concat).to(dev)
@@ -752,24 +838,88 @@ def main():
             # collected on (source_digest), otherwise null.
             traffic, valu = None, None
             digest = source_digest()
-            try:
-                with open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")) as fh:
-                    pt = json.load(fh)
-                if pt.get("reads_per_gpu") == n_reads and pt.get("read_len") == args.read_len and world == 1 and pt.get("source_digest") == digest:
-                    ent = pt["dominant_kernel"]
-                    traffic = float(ent["hbm_bytes_per_launch"])
-                    if ent.get("valu_wave_insts_per_launch"):
-                        props = torch.cuda.get_device_properties(dev)
-                        clock_hz = float(getattr(props, "clock_rate", 0)) * 1e3 or 2.4e9
-                        simds = props.multi_processor_count * 4
-                        # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD that holds >= 2 waves
-                        slots = simds * clock_hz / 2.0 * dom_ms * 1e-3
-                        valu = {"bound": "valu-issue", "kernel": dom_name, "valu_wave_insts": ent["valu_wave_insts_per_launch"],
-                                "salu_wave_insts": ent.get("salu_wave_insts_per_launch"), "simds": simds, "clock_hz": clock_hz,
-                                "cycles_per_wave64_valu": 2, "issue_slots": slots, "frac": ent["valu_wave_insts_per_launch"] / slots,
-                                "wait_any_share_of_wave_cycles": ent.get("wait_any_share")}
-            except (OSError, KeyError, ValueError, TypeError):
-                traffic, valu = None, None
+            digest_place = source_digest_place()
+            props = torch.cuda.get_device_properties(dev)
+            clock_hz = float(getattr(props, "clock_rate", 0)) * 1e3 or 2.4e9
+            simds = props.multi_processor_count * 4
+            pt = None
+            for rnd in ("r04", "r03"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as fh:
+                        cand = json.load(fh)
+                    if cand.get("reads_per_gpu") == n_reads and cand.get("read_len") == args.read_len and world == 1:
+                        pt = cand
+                        break
+                except (OSError, ValueError):
+                    pass
+
+            def pmc(key, stage_digest, which):
+                """the PMC entry of a kernel, only when it was collected on this workload AND on the sources of that stage"""
+                if pt is None or key not in pt:
+                    return None
+                want = pt.get("source_digest_place") if which == "place" else pt.get("source_digest")
+                return pt[key] if want == stage_digest else None
+
+            def valu_obj(ent, ms, name):
+                if not ent or not ent.get("valu_wave_insts_per_launch"):
+                    return None
+                # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD that holds >= 2 waves
+                slots = simds * clock_hz / 2.0 * ms * 1e-3
+                return {"bound": "valu-issue", "kernel": name, "valu_wave_insts": ent["valu_wave_insts_per_launch"],
+                        "salu_wave_insts": ent.get("salu_wave_insts_per_launch"), "simds": simds, "clock_hz": clock_hz,
+                        "cycles_per_wave64_valu": 2, "issue_slots": slots, "frac": ent["valu_wave_insts_per_launch"] / slots,
+                        "wait_any_share_of_wave_cycles": ent.get("wait_any_share")}
+            ent = pmc("dominant_kernel", digest, "align")
+            if ent:
+                traffic = float(ent["hbm_bytes_per_launch"])
+                valu = valu_obj(ent, dom_ms, dom_name)
+            # ---- every stage against the roofline that bounds it (SURVEY 8d "Binding roofline per stage" and its algorithmic
+            # bytes per unit; DESIGN.md section 4 states them).  kernel_ms = HIP events on the context stream in the resident run;
+            # traffic / instruction counts from the PMC passes of profiles/ when their digest matches this build.
+            pack_ms = float(np.mean(kernel_ms["pack"]))
+            n_changes = int(index.info.n_changes) if hasattr(index.info, "n_changes") else None
+
+            def stage(ms, alg_bytes, bound, kernels, ent=None, launches=1, extra=None):
+                if ms is None or ms <= 0:
+                    return None
+                ach = alg_bytes / (ms * 1e-3) / 1e9
+                o = {"kernels": kernels, "bound": bound, "kernel_ms": ms, "algorithmic_bytes": alg_bytes, "achieved": ach, "peak": 8000.0,
+                     "unit": "GB/s", "frac": ach / 8000.0, "frac_of_copy_ceiling": (ach / copy_ceiling) if copy_ceiling else None,
+                     "traffic": (float(ent["hbm_bytes_per_launch"]) * launches) if ent else None}
+                if ent and ent.get("valu_wave_insts_per_launch"):
+                    v = valu_obj({k: (v * launches if isinstance(v, (int, float)) and k.endswith("per_launch") else v) for k, v in ent.items()}, ms, kernels)
+                    o["valu_issue_frac"] = v["frac"]
+                    o["wait_any_share"] = ent.get("wait_any_share")
+                if extra:
+                    o.update(extra)
+                return o
+            seeds_per_read = 37.6 * mean_len / 150.0          # SURVEY 8d (probe: 33.2 per 133-bp read)
+            tail_ms = max(align_ms - dom_ms - (cseeds_ms or 0.0), 0.0)
+            by_stage = {
+                "pack (k_pack_reads)": stage(pack_ms, n_reads * (mean_len + mean_len * 3 / 8.0), "hbm", "k_pack_reads", pmc("k_pack_reads", digest_place, "place"),
+                                             extra={"bytes_per_read": mean_len + mean_len * 3 / 8.0}),
+                "seed (S1: syncmers + k-min-mers + histogram)": stage(
+                    seed_ms, n_reads * (mean_len * 3 / 8.0 + 8.0 * seeds_per_read), "hbm", "k_seed_* (+ read dedup, table clear)", None,
+                    extra={"bytes_per_read": mean_len * 3 / 8.0 + 8.0 * seeds_per_read,
+                           "rmw_variant": {"bytes_per_read": mean_len * 3 / 8.0 + 16.0 * seeds_per_read,
+                                           "achieved": n_reads * (mean_len * 3 / 8.0 + 16.0 * seeds_per_read) / (seed_ms * 1e-3) / 1e9,
+                                           "frac": n_reads * (mean_len * 3 / 8.0 + 16.0 * seeds_per_read) / (seed_ms * 1e-3) / 1e9 / 8000.0},
+                           "traffic": (float(pt["seed_stage"]["hbm_bytes_per_step"]) if pt and pt.get("seed_stage") and pt.get("source_digest_place") == digest_place else None)}),
+                "score (S2: k_score_terms + k_score_chains)": stage(
+                    score_ms, 28.0 * (n_changes or 0), "hbm/L2 latency (read-count independent)", "k_score_terms + k_score_chains",
+                    pmc("k_score_chains", digest_place, "place"), extra={"bytes_per_seed_change": 28.0, "seed_changes": n_changes}) if n_changes else None,
+                "compact-seeds (S3: sketch + index probes)": stage(
+                    cseeds_ms, n_reads * (mean_len * 3 / 8.0 + 4.0 * 20.0), "valu-issue (primary), hbm (secondary)", "k_compact_seeds16",
+                    pmc("k_compact_seeds", digest, "align"), extra={"bytes_per_read": mean_len * 3 / 8.0 + 80.0}) if cseeds_ms else None,
+                "compact-chain (S3/S4: merge, chain, regions, extension, mapq, pairing)": stage(
+                    dom_ms, alg_bytes, "valu-issue / LDS latency (primary), hbm (secondary)", dom_name, ent, extra={"bytes_per_read": alg_bytes / max(n_reads, 1)}),
+                "tail (bails of the compact tier: DP service + replay / wave tier)": (
+                    {"kernels": "k_align_compact_replay / k_align_dp_group / k_align_reads_*", "bound": "latency (fixed per step)", "kernel_ms": tail_ms,
+                     "pairs": int(dp_stats[-1]["n_items"] - dp_stats[-1]["compact_tier_items"]), "algorithmic_bytes": 0.0, "achieved": 0.0, "peak": 8000.0,
+                     "unit": "GB/s", "frac": 0.0, "traffic": None,
+                     "note": "align stage minus the two compact kernels (includes the pair-order sort); priced in ms, not bytes"} if not long_reads else None),
+            }
+            by_stage = {k: v for k, v in by_stage.items() if v is not None}
             dp_cells = float(np.mean([s["dp_cells"] for s in dp_stats]))
             dp_pairs = float(np.mean([s["dp_pairs"] for s in dp_stats]))
             n_items = max(dp_stats[-1]["n_items"], 1)
@@ -777,17 +927,21 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": 8000.0,
                              "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "kernel_ms": dom_ms,
                              "algorithmic_bytes_per_launch": alg_bytes, "source_digest": digest,
+                             "binding": "not HBM: VALU issue / LDS latency -- see roofline_valu and roofline_by_stage; the HBM-bound stages are pack and seed",
                              "note": "mapping kernel (heap merge, chaining, region logic, extension, mapq, pairing; short reads: the sketch and the "
                                      "index probes run before it in k_compact_seeds16, see kernels_ms): integer/latency bound by "
                                      "construction (SURVEY 8d: S3/S4 are not HBM-bound), so the HBM fraction is low; `traffic` is what the "
                                      "kernel really moves (PMC; includes the seed hand-over it reads), `achieved` prices only the stage's "
                                      "compulsory input + output (SURVEY 8d: 93 B per read)"},
                 "roofline_valu": valu,
+                "roofline_by_stage": by_stage,
+                "hbm_copy_ceiling": {"GBps": copy_ceiling, "spec_GBps": 8000.0,
+                                     "note": "device-to-device copy of 1 GB on this box (read + written bytes per second): what a pure streaming kernel gets"},
                 "dp": {"pair_share": dp_pairs / n_items, "cells_per_step": dp_cells,
                        "gcups_align_stage": dp_cells / max(align_ms, 1e-9) / 1e6,
                        "note": "ksw2 cells counted as q*min(t,2w+1) per DP actually run (SURVEY 8d); extensions / gap fills answered by the "
                                "proved closed-form shortcuts run no DP and count no cells; GCUPS = cells / whole align-stage time"},
-                "kernels_ms": {"seed stage (k_seed_histogram, chunked)": seed_ms, "score stage (k_score_terms + k_score_chains)": score_ms,
+                "kernels_ms": {"pack (k_pack_reads)": pack_ms, "seed stage (k_seed_histogram, chunked)": seed_ms, "score stage (k_score_terms + k_score_chains)": score_ms,
                                "align stage (all tiers)": align_ms, "dominant align kernel": dom_ms,
                                "compact tier, sketch + probes (k_compact_seeds16)": cseeds_ms,
                                "note": "HIP-event durations in the device-resident run (one batch at a time)"},
@@ -801,10 +955,28 @@ def main():
                        "unique_seeds": int(res.n_unique_seeds), "kept_seeds": int(res.readUniqueSeedCount),
                        "tiers": dp_stats[-1], "rank0_gather_has_every_cigar": gather_ok},
         })
-        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported by the 1-GPU run only
+        if not args.no_cpu_baseline and world == 1 and not dist_on:   # the CPU baseline is reported by the 1-GPU run only
             threads, quota = usable_cpus()
             sample = args.cpu_sample or (int(min(n_reads, max(20000, 60000 * threads))) if not long_reads else int(min(n_reads, max(200, 150 * threads))))
-            out["cpu_baseline"] = cpu_baseline(concat, off, index.arrays(), placed_ref, sample, threads, paired, quota)
+            n_s = min(sample, n_reads)
+            if paired:
+                n_s &= ~1
+            # the GPU's results on exactly the reads of the CPU sample (one untimed step of the same code path; on the driver's
+            # default run the sample is the whole batch) ...
+            rs_s = pmx.ReadSet.wrap_device(main_pipe.ctx, d_concat.data_ptr(), d_off.data_ptr(), n_s, int(off[n_s]), max_len, keepalive=(d_concat, d_off))
+            rs_s.pack()
+            main_pipe.placer.reset()
+            main_pipe.placer.add_reads(rs_s, params)
+            main_pipe.place_and_align(rs_s, n_s, mean_len, paired, paired)
+            main_pipe.ctx.synchronize()
+            g_recs, g_cig = main_pipe.aligner.fetch()
+            g_sc, _, _ = main_pipe.placer.node_outputs()
+            gpu_side = dict(hist=main_pipe.placer.histogram(), scores=g_sc, result=main_pipe.res, recs=g_recs, cig=g_cig)
+            # ... and the CPU path on them, timed (aligned against the genome the GPU placed the sample on; the placement itself
+            # is compared through the node scores and the TSV text)
+            out["cpu_baseline"], cpu_side = cpu_baseline(concat, off, index.arrays(), main_pipe.ref, n_s, threads, paired, quota)
+            out["checks"]["oracle"] = oracle_checks(pmx, gpu_side, cpu_side, pm.node_id, paired)
+            rs_s.close()
         else:
             out["cpu_baseline"] = None
     else:

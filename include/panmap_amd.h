@@ -470,9 +470,15 @@ int64_t pmx_meta_num_haplotypes(const pmx_meta *m);
 int pmx_meta_haplotype(const pmx_meta *m, int64_t i, uint32_t *node, double *prop, int64_t *n_members, uint32_t *members,
                        int64_t cap);
 int pmx_meta_em_info(const pmx_meta *m, int32_t *rounds, int32_t *iterations, double *log_likelihood);
+/* --dust T (src/main.cpp:2059-2061, default 100 = off): pmx_meta_set_reads drops every read whose DUST score is non-zero and
+ * greater than T (src/mgsr.cpp:1593-1594, 1833-1834).  pmx_read_dust = mgsr::getDust (src/mgsr.cpp:1505-1568; host, no
+ * device): Prinseq-scaled score over base triplets in a sliding window of `window` triplets (the reference uses 64). */
+int pmx_meta_set_dust(pmx_meta *m, double threshold);
+double pmx_read_dust(const char *seq, int64_t len, int32_t window);
 
 /* kernel timing: average duration (ms) of the dominant kernel of the last call, measured with HIP
-   events on the context stream; name selects "seed", "score", "align" */
+   events on the context stream; name selects a stage ("pack", "seed", "score", "align") or a kernel of the align stage
+   ("align_cseeds" = k_compact_seeds*, "align_dom" = the mapping kernel over every pair); < 0: no such span in the last call */
 double pmx_last_kernel_ms(pmx_ctx *ctx, const char *name);
 
 #ifdef __cplusplus

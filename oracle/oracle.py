@@ -220,6 +220,32 @@ def prepare_align_call(reads, paired: bool):
     return dict(n=n, arr=arr, quals=quals, names=names, lens=lens, n_res=n_res, res=res, paired=paired)
 
 
+def prepare_align_call_flat(concat, off, paired: bool, revcomp_mate2: bool):
+    """prepare_align_call from one flat read buffer without a Python object per read (oracle_alnflat.c): mate 2 reverse-
+    complemented on the way when asked (the orientation readFastqPaired hands to align_reads_direct)"""
+    L = olib()
+    L.orc_align_prepare_reads.restype = None
+    L.orc_align_prepare_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    concat = np.ascontiguousarray(concat, np.uint8); off = np.ascontiguousarray(off, np.int64)
+    n = len(off) - 1
+    base = int(off[0])
+    buf = np.zeros(int(off[-1]) - base + n + 1, np.uint8)
+    arr = (C.c_char_p * max(n, 1))()
+    lens = (C.c_int * max(n, 1))()
+    L.orc_align_prepare_reads(concat.ctypes.data, off.ctypes.data, n, int(bool(paired and revcomp_mate2)), buf.ctypes.data, C.addressof(arr), C.addressof(lens))
+    # qualities / names are accepted but unused by the minimap2 backend (src/mm_align.h:44-53): every entry points at one
+    # shared string (pointer arrays filled through numpy, no Python object per read)
+    q = C.create_string_buffer(b"I" * (int(np.max(np.diff(off))) if n else 1))
+    nm = C.create_string_buffer(b"r")
+    quals = (C.c_char_p * max(n, 1))()
+    names = (C.c_char_p * max(n, 1))()
+    C.memmove(C.addressof(quals), np.full(max(n, 1), C.addressof(q), np.uint64).ctypes.data, 8 * max(n, 1))
+    C.memmove(C.addressof(names), np.full(max(n, 1), C.addressof(nm), np.uint64).ctypes.data, 8 * max(n, 1))
+    n_res = n // 2 if paired else n
+    res = (AlignPairResult * max(n_res, 1))()
+    return dict(n=n, arr=arr, quals=quals, names=names, lens=lens, n_res=n_res, res=res, paired=paired, _keep=(buf, q, nm, concat, off))
+
+
 def run_align_call(fn, reference: bytes, prep, n_threads=1):
     """the bare C call"""
     fn(reference, b"ref", prep["n"], prep["arr"], prep["quals"], prep["names"], prep["lens"], prep["res"], prep["paired"], n_threads)
@@ -228,6 +254,29 @@ def run_align_call(fn, reference: bytes, prep, n_threads=1):
 def unpack_align_call(prep):
     res, paired = prep["res"], prep["paired"]
     return [dict(mapped=res[i].mapped, r1=_unpack(res[i].r1), r2=_unpack(res[i].r2) if paired else None) for i in range(prep["n_res"])]
+
+
+def flatten_align_call(prep):
+    """the results of run_align_call as flat numpy arrays (oracle_alnflat.c), CIGARs freed -- for comparisons at 10^7 reads,
+    where unpack_align_call's list of dicts is too slow:
+    dict(fields int32 [n_reads][8] = pos rs re qs qe mapq rev proper_frag, n_cigar int32 [n_reads], mapped u8 [n_res],
+         cigar u32 arena in record order)"""
+    L = olib()
+    L.orc_align_cigar_total.restype = C.c_int64
+    L.orc_align_cigar_total.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.orc_align_flatten.restype = C.c_int64
+    L.orc_align_flatten.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    res, paired, n_res, n = prep["res"], prep["paired"], prep["n_res"], prep["n"]
+    assert C.sizeof(AlignPairResult) == 104
+    tot = int(L.orc_align_cigar_total(C.addressof(res), n_res, int(paired)))
+    n_reads = n_res * (2 if paired else 1)
+    fields = np.zeros((max(n_reads, 1), 8), np.int32)
+    n_cig = np.zeros(max(n_reads, 1), np.int32)
+    mapped = np.zeros(max(n_res, 1), np.uint8)
+    arena = np.zeros(max(tot, 1), np.uint32)
+    used = int(L.orc_align_flatten(C.addressof(res), n_res, int(paired), fields.ctypes.data, n_cig.ctypes.data, mapped.ctypes.data, arena.ctypes.data, tot))
+    assert used == tot, (used, tot)
+    return dict(fields=fields[:n_reads], n_cigar=n_cig[:n_reads], mapped=mapped[:n_res], cigar=arena[:tot], paired=paired)
 
 
 def call_align_reads_direct(fn, reference: bytes, reads, paired: bool, n_threads=1):

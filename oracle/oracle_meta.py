@@ -145,10 +145,84 @@ def square_em(scores, n_seedmers, weight, error_rate=0.005, eta=1e-5, delta_thre
                     break
             elif np.abs(props - p0).max() < delta_threshold:
                 break
+        # removeLowPropNodes (src/mgsr.cpp:4445-4490) runs after every round, the last allowed one included
+        # (src/main.cpp:1263-1271); a removal resets the survivors' proportions to uniform
         keep = props >= prop_threshold
-        if keep.all() or _ + 1 >= max(1, max_rounds):
-            break
-        if not keep.any():
+        if keep.all():
             break
         cols = cols[keep]
+        props = np.full(len(cols), 1.0 / len(cols)) if len(cols) else np.zeros(0)
+        if not len(cols):
+            break
     return cols, props
+
+
+def discard_rows(max_score, n_seedmers, discard):
+    """reads that enter the EM (src/main.cpp:1229-1240): a positive best score that is not below int(n * discard)"""
+    mx = np.asarray(max_score, np.int64)
+    thr = (np.asarray(n_seedmers, np.float64) * float(discard)).astype(np.int64)    # static_cast<int>: truncation
+    return (mx > 0) & ~(mx < thr)
+
+
+def read_scores_np(counts, read_off, seed_hash, seed_rev):
+    """read_scores with the per-seedmer look-ups done by numpy (same numbers; for the 10^5-read cases)"""
+    read_off = np.asarray(read_off, np.int64)
+    seed_hash = np.asarray(seed_hash, np.uint64)
+    seed_rev = np.asarray(seed_rev).astype(bool)
+    if not counts:
+        return np.zeros(len(read_off) - 1, np.int64)
+    keys = np.fromiter(counts.keys(), np.uint64, len(counts))
+    fw = np.fromiter((c[0] > 0 for c in counts.values()), bool, len(counts))
+    rv = np.fromiter((c[1] > 0 for c in counts.values()), bool, len(counts))
+    order = np.argsort(keys)
+    keys, fw, rv = keys[order], fw[order], rv[order]
+    pos = np.minimum(np.searchsorted(keys, seed_hash), len(keys) - 1)
+    hit = keys[pos] == seed_hash
+    same = hit & np.where(seed_rev, rv[pos], fw[pos])       # the genome holds it the way the read does
+    other = hit & np.where(seed_rev, fw[pos], rv[pos])
+    cs = np.concatenate([[0], np.cumsum(same)])
+    co = np.concatenate([[0], np.cumsum(other)])
+    return np.maximum(cs[read_off[1:]] - cs[read_off[:-1]], co[read_off[1:]] - co[read_off[:-1]]).astype(np.int64)
+
+
+def get_dust(seq: bytes, window_size: int = 64) -> float:
+    """mgsr::getDust (src/mgsr.cpp:1505-1568): Prinseq-scaled DUST score over triplets.  Bases other than ACGT (either
+    case) are skipped altogether (the triplet register runs over them); while fewer than `window_size` triplets were seen
+    the score only accumulates; from then on the triplet that leaves the window is taken out first (its count decremented
+    when positive, the new count subtracted), the entering one added, and the maximum of the running score is kept.  Result:
+    200 max / (W (W - 1)) once a full window was seen, else 200 score / (v (v + 1)) with v = triplets - 1 when there are at
+    least two triplets, else 0.  `--dust T` (< 100) drops a read whose score is non-zero and > T (:1593-1594, :1833-1834)."""
+    assert window_size >= 3
+    code = {65: 0, 97: 0, 67: 1, 99: 1, 71: 2, 103: 2, 84: 3, 116: 3}
+    counts = [0] * 64
+    window = [0] * window_size
+    cur = best = 0
+    kmer = 0
+    valid = -3
+    for ch in seq:
+        b = code.get(ch)
+        if b is None:
+            continue
+        kmer = ((kmer << 2) | b) & 63
+        valid += 1
+        if valid < 0:
+            continue
+        slot = valid % window_size
+        if valid >= window_size:
+            out = window[slot]
+            if counts[out] > 0:
+                counts[out] -= 1
+                cur -= counts[out]
+            cur += counts[kmer]
+            counts[kmer] += 1
+            best = max(best, cur)
+        else:
+            cur += counts[kmer]
+            counts[kmer] += 1
+        window[slot] = kmer
+    n_kmers = valid + 1
+    if valid >= window_size:
+        return (200.0 * best) / (window_size * (window_size - 1))
+    if n_kmers > 1:
+        return (200.0 * cur) / (valid * (valid + 1))
+    return 0.0

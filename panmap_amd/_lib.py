@@ -193,6 +193,8 @@ SIGNATURES = {
     "pmx_meta_num_haplotypes": (_i64, [_vp]),
     "pmx_meta_haplotype": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _i64]),
     "pmx_meta_em_info": (_i32, [_vp, _vp, _vp, _vp]),
+    "pmx_meta_set_dust": (_i32, [_vp, C.c_double]),
+    "pmx_read_dust": (C.c_double, [_cp, _i64, _i32]),
     "pmx_dist_unique_id": (_i32, [_vp]),
     "pmx_dist_init": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "pmx_dist_free": (None, [_vp]),

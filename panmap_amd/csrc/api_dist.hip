@@ -123,13 +123,17 @@ struct RcclTransport : Transport {
     }
 };
 
-// Test transport: every operation is a round of files <dir>/<seq>.<rank> (written under a temporary name, then renamed).
-// A rank removes its file of round k once round k+1 is complete (everybody has read round k by then).
+// Test transport: every operation is a round of files <dir>/x<nonce>.<seq>.<rank> (written under a temporary name, then
+// renamed).  A rank removes its file of round k once round k+1 is complete (everybody has read round k by then).  The file
+// of the LAST round is never removed by the transport: only rounds before it are known to have been read by every peer (a
+// rank that returns from the final round first would otherwise unlink its file under a peer that still polls for it).
+// Whoever made the directory removes it.  `nonce` = the first bytes of the communicator id the ranks were given, so that a
+// reused directory with files of another (crashed) run is not taken for this run's round 0 when the caller ships an id.
 struct HostDirTransport : Transport {
-    std::string dir;
+    std::string dir, nonce;
     uint64_t seq = 0;
     std::string prev_file;
-    std::string name(uint64_t s, int r) const { return dir + "/x" + std::to_string(s) + "." + std::to_string(r); }
+    std::string name(uint64_t s, int r) const { return dir + "/x" + nonce + "." + std::to_string(s) + "." + std::to_string(r); }
     void publish(const std::vector<char>& buf) {
         const std::string fin = name(seq, rank), tmp = fin + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
@@ -156,9 +160,6 @@ struct HostDirTransport : Transport {
         if (!prev_file.empty()) (void)unlink(prev_file.c_str());
         prev_file = name(seq, rank);
         ++seq;
-    }
-    ~HostDirTransport() override {
-        if (!prev_file.empty()) (void)unlink(prev_file.c_str());
     }
     void all_gather(hipStream_t st, const void* d_mine, size_t bytes, void* d_all) override {
         std::vector<char> mine(bytes);
@@ -227,7 +228,19 @@ extern "C" {
 int pmx_dist_unique_id(char id[PMX_DIST_ID_BYTES]) {
     if (!id) return PMX_ERR_ARG;
     memset(id, 0, PMX_DIST_ID_BYTES);
-    if (getenv("PMX_DIST_HOST_DIR")) return PMX_OK;   // the test transport needs no id
+    if (getenv("PMX_DIST_HOST_DIR")) {
+        // the test transport needs no communicator, but its file names carry the id's first bytes as the run's nonce: a
+        // directory that still holds the last-round files of an earlier run (they are never unlinked, see HostDirTransport)
+        // can be used again
+        FILE* f = fopen("/dev/urandom", "rb");
+        const size_t got = f ? fread(id, 1, 16, f) : 0;
+        if (f) fclose(f);
+        if (got != 16) {
+            const uint64_t a = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(), b = (uint64_t)getpid();
+            memcpy(id, &a, 8); memcpy(id + 8, &b, 8);
+        }
+        return PMX_OK;
+    }
     PMX_TRY
     static_assert(sizeof(ncclUniqueId) == PMX_DIST_ID_BYTES, "unique id size");
     ncclUniqueId u;
@@ -246,6 +259,11 @@ int pmx_dist_init(pmx_ctx* ctx, const char id[PMX_DIST_ID_BYTES], int rank, int 
     if (const char* dir = getenv("PMX_DIST_HOST_DIR")) {
         auto* t = new HostDirTransport();
         t->dir = dir;
+        char hex[17];
+        uint64_t n8;
+        memcpy(&n8, id, sizeof(n8));
+        snprintf(hex, sizeof(hex), "%016llx", (unsigned long long)n8);
+        t->nonce = hex;
         d->tp.reset(t);
     } else {
         auto* t = new RcclTransport();

@@ -332,3 +332,41 @@ extern "C" int64_t pmx_refine_candidates(const uint32_t* parent, int64_t n_nodes
         return PMX_ERR_IO;
     }
 }
+
+// mgsr::getDust (src/mgsr.cpp:1505-1568; contract src/test/test_mgsr.cpp:12-29): Prinseq-scaled DUST score of a read over
+// its base triplets.  State: how often each of the 64 triplets occurs among the last `window` triplets (a ring of their
+// codes); the score of a window is the number of unordered pairs of equal triplets in it, kept incrementally (a triplet that
+// enters adds its current count, one that leaves takes away its count after leaving).  Everything but ACGT / acgt is skipped
+// as if it were not there.  Integer state, one double expression at the end: equal to the reference bit for bit.
+extern "C" double pmx_read_dust(const char* seq, int64_t len, int32_t window) {
+    if (!seq || len <= 0 || window < 3) return 0.0;
+    int32_t occ[64] = {0};
+    std::vector<uint8_t> ring((size_t)window, 0);
+    long long pairs = 0, most = 0;
+    unsigned code = 0;
+    long long seen = -3;                 // triplets completed so far, minus one
+    for (int64_t i = 0; i < len; ++i) {
+        unsigned b;
+        switch (seq[i]) {
+            case 'A': case 'a': b = 0; break;
+            case 'C': case 'c': b = 1; break;
+            case 'G': case 'g': b = 2; break;
+            case 'T': case 't': b = 3; break;
+            default: continue;
+        }
+        code = ((code << 2) | b) & 63u;
+        if (++seen < 0) continue;
+        const size_t slot = (size_t)(seen % window);
+        const bool full = seen >= window;
+        if (full) {
+            const unsigned old = ring[slot];
+            if (occ[old] > 0) pairs -= --occ[old];
+        }
+        pairs += occ[code]++;
+        if (full && pairs > most) most = pairs;
+        ring[slot] = (uint8_t)code;
+    }
+    if (seen >= window) return (200.0 * most) / (window * (window - 1));
+    if (seen + 1 > 1) return (200.0 * pairs) / (seen * (seen + 1));
+    return 0.0;
+}

@@ -394,6 +394,8 @@ struct pmx_meta {
     std::vector<pmx_meta_group> groups;     // sorted by proportion, descending
     int em_rounds = 0, em_iterations = 0;
     double llh = 0.0;
+    double dust_threshold = 100.0;          // --dust: 100 = no filter
+    int64_t n_dust_dropped = 0;
 };
 
 extern "C" {
@@ -453,6 +455,8 @@ int pmx_meta_set_reads(pmx_ctx* ctx, pmx_meta* m, const char* concat, const int6
     const int l = p.l;
     struct One { std::vector<uint64_t> hash; std::vector<uint8_t> rev; };
     std::vector<One> per((size_t)n_reads);
+    const double dust_thr = m->dust_threshold;
+    std::vector<uint8_t> dusty(dust_thr < 100.0 ? (size_t)n_reads : 0, 0);
     {
         unsigned n_thr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         if (n_reads < 4096) n_thr = 1;
@@ -463,6 +467,10 @@ int pmx_meta_set_reads(pmx_ctx* ctx, pmx_meta* m, const char* concat, const int6
                 std::vector<uint64_t> sh, h;
                 for (int64_t r = (int64_t)t; r < n_reads; r += n_thr) {
                     const int64_t len = offsets[r + 1] - offsets[r];
+                    if (dust_thr < 100.0) {   // src/mgsr.cpp:1593-1594: a read with a non-zero score above the threshold is left out
+                        const double d = pmx_read_dust(concat + offsets[r], len, 64);
+                        if (d != 0 && d > dust_thr) { dusty[(size_t)r] = 1; continue; }
+                    }
                     host_syncmers(concat + offsets[r], len, p, is_sync, sh);
                     h.clear();
                     for (size_t i = 0; i < is_sync.size(); ++i)
@@ -489,6 +497,8 @@ int pmx_meta_set_reads(pmx_ctx* ctx, pmx_meta* m, const char* concat, const int6
     };
     std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return less(a, b) || (!less(b, a) && a < b); });
     m->n_raw_reads = n_reads;
+    m->n_dust_dropped = 0;
+    for (uint8_t d : dusty) m->n_dust_dropped += d;
     m->h_read_off.assign(1, 0);
     m->h_seed_hash.clear(); m->h_seed_rev.clear(); m->h_mult.clear();
     for (size_t i = 0; i < order.size(); ++i) {
@@ -682,7 +692,9 @@ int pmx_meta_em(pmx_ctx* ctx, pmx_meta* m, const pmx_meta_params* mp) {
         for (int c = 0; c < n_cand; ++c) mx = std::max<int>(mx, h_score[(size_t)r * (size_t)n_cand + (size_t)c]);
         m->h_max_score[(size_t)r] = mx;
         const int64_t n_seed = m->h_read_off[(size_t)r + 1] - m->h_read_off[(size_t)r];
-        if (mx == 0 || (double)mx < (double)n_seed * mp->discard) continue;     // --discard (src/main.cpp:1229-1240)
+        // --discard (src/main.cpp:1229-1240): the threshold is TRUNCATED to an integer there,
+        // `maxScore < static_cast<int>(seedmers * discard)`, so a read with int(n * d) <= max < n * d stays in the EM
+        if (mx == 0 || mx < (int)((double)n_seed * mp->discard)) continue;
         rows.push_back(r);
     }
     const int64_t n_rows = (int64_t)rows.size();
@@ -793,17 +805,20 @@ int pmx_meta_em(pmx_ctx* ctx, pmx_meta* m, const pmx_meta_params* mp) {
         const double llh = h_ctl.llh;
         m->llh = llh;
         ++m->em_rounds;
-        // removeLowPropNodes (:4445-4490)
+        // removeLowPropNodes (:4445-4490), called after EVERY round including the last allowed one (src/main.cpp:1263-1271):
+        // when it removes anything the surviving nodes' proportions are reset to uniform, and if that was the last round
+        // the uniform vector is what the abundance file reports -- mirrored, not "fixed"
         std::vector<int> keep;
         for (int i = 0; i < n_cols; ++i)
             if (props[(size_t)i] >= mp->prop_threshold) keep.push_back(i);
-        if ((int)keep.size() == n_cols || round + 1 >= std::max(1, mp->em_max_rounds)) break;
+        if ((int)keep.size() == n_cols) break;
         std::vector<int> cols2;
         std::vector<std::vector<uint32_t>> members2;
         for (int i : keep) { cols2.push_back(cols[(size_t)i]); members2.push_back(members[(size_t)i]); }
-        if (cols2.empty()) break;
         cols.swap(cols2);
         members.swap(members2);
+        props.assign(cols.size(), cols.empty() ? 0.0 : 1.0 / (double)cols.size());
+        if (cols.empty()) break;
     }
     for (size_t i = 0; i < cols.size(); ++i) {
         pmx_meta_group g;
@@ -815,6 +830,12 @@ int pmx_meta_em(pmx_ctx* ctx, pmx_meta* m, const pmx_meta_params* mp) {
     std::stable_sort(m->groups.begin(), m->groups.end(), [](const pmx_meta_group& a, const pmx_meta_group& b) { return a.prop > b.prop; });
     return PMX_OK;
     PMX_CATCH
+}
+
+int pmx_meta_set_dust(pmx_meta* m, double threshold) {
+    if (!m || !(threshold <= 100.0)) return PMX_ERR_ARG;      // src/main.cpp:1353-1356: --dust must be <= 100
+    m->dust_threshold = threshold;
+    return PMX_OK;
 }
 
 int64_t pmx_meta_num_haplotypes(const pmx_meta* m) { return m ? (int64_t)m->groups.size() : 0; }

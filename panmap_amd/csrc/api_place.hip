@@ -432,10 +432,12 @@ int pmx_readset_pack(pmx_ctx* ctx, pmx_readset* rs) {
     if (!ctx || !rs) return PMX_ERR_ARG;
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
+    timer_begin(ctx, "pack");
     if (rs->n_words > 0)
         hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(rs->n_words, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p,
                            rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p, (int64_t)0, (int64_t)-1);
     PMX_HIP(hipGetLastError());
+    timer_end(ctx, "pack", 1);
     rs->packed = true;
     rs->has_order = false;   // (the buffer behind a wrapped read set may hold new reads)
     rs->packed_ranges.clear();

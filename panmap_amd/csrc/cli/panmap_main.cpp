@@ -13,6 +13,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -40,7 +41,7 @@ struct Config {
     int trim_start = 0, trim_end = 0, min_seed_quality = 0, min_read_support = -1;
     bool meta = false;     // --meta: haplotype deconvolution (src/main.cpp:1192-1313)
     int64_t top_oc = 1000;
-    double em_convergence = 0.00001, em_delta = 0.0, discard = 0.0;
+    double em_convergence = 0.00001, em_delta = 0.0, discard = 0.0, dust = 100.0;
     int em_max_iterations = 1000, em_max_rounds = 5;
     int gpus = 1;          // --gpus N: one process per GPU, reads sharded, RCCL exchange (pmx_dist_*)
     bool refine = false;   // src/main.cpp:186-190, 2002-2011
@@ -68,7 +69,7 @@ void usage() {
           "      --stop STAGE           index|place|align (later stages are not part of this build)\n"
           "      --batch FILE           one sample per line: reads1 [reads2] [prefix]; the index stays resident\n"
           "      --meta                 estimate haplotype abundances of a mixed sample -> <prefix>.mgsr.abundance.out\n"
-          "      --top-oc N --em-convergence-threshold F --em-delta-threshold F --em-maximum-iterations N --em-maximum-rounds N --discard F\n"
+          "      --top-oc N --em-convergence-threshold F --em-delta-threshold F --em-maximum-iterations N --em-maximum-rounds N --discard F --dust F\n"
           "      --gpus N               N processes, one per GPU: reads sharded, seed index replicated, RCCL exchange\n"
           "      --refine               re-rank the top candidates by aligning the reads against them\n"
           "      --refine-top-pct F / --refine-max-top-n N / --refine-neighbor-radius N / --refine-max-neighbor-n N\n"
@@ -131,6 +132,7 @@ Config parse(int argc, char** argv) {
         else if (a == "--em-maximum-iterations") c.em_max_iterations = atoi(v().c_str());
         else if (a == "--em-maximum-rounds") c.em_max_rounds = atoi(v().c_str());
         else if (a == "--discard") c.discard = atof(v().c_str());
+        else if (a == "--dust") c.dust = atof(v().c_str());
         else if (a == "--filter-and-assign" || a == "--impute" || a == "--extent-guard" || a == "--reference-node" ||
                  a == "--dump-sequence" || a == "--dump-all-scores")
             die("option " + a + " belongs to a part of panmap this build does not implement (index / place / align only)");
@@ -530,6 +532,7 @@ std::string run_sample(const Config& c, int stop, pmx_panman*& pm, pmx_index* id
 int run_meta(const Config& c) {
     if (c.reads1.empty()) die("--meta needs reads");
     if (c.discard < 0.0 || c.discard > 1.0) die("--discard must be between 0 and 1");   // src/main.cpp:1358-1361
+    if (c.dust > 100.0) die("--dust must be <= 100");                                    // src/main.cpp:1353-1356
     if (c.l < 2) die("--meta needs l >= 2 in this build (the orientation of a lone syncmer is not indexed)");
     if (c.gpus > 1) die("--meta runs on one GPU in this build");
     pmx_panman* pm = nullptr;
@@ -567,6 +570,7 @@ int run_meta(const Config& c) {
     check(pmx_ctx_create(dev, &ctx), "opening the GPU");
     pmx_meta* m = nullptr;
     check(pmx_meta_create(ctx, idx, oidx, &m), "uploading the indexes");
+    check(pmx_meta_set_dust(m, c.dust), "--dust");
     check(pmx_meta_set_reads(ctx, m, concat.data(), off.data(), (int64_t)off.size() - 1), "seeding the reads");
     check(pmx_meta_score(ctx, m, c.top_oc, nullptr, 0), "scoring the reads against the candidate nodes");
     say(c, "meta", std::to_string(pmx_meta_num_reads(m)) + " distinct reads x " + std::to_string(pmx_meta_num_candidates(m)) + " candidate nodes");
@@ -654,13 +658,30 @@ int real_main(int argc, char** argv) {
             kids.push_back(pid);
         }
         if (!child) {
+            // Wait for whichever rank ends first.  A rank that fails (no such device, unreadable reads, any die() between two
+            // collectives) leaves the others blocked in ncclCommInitRank / a collective for ever: the first failure ends the
+            // run -- the remaining children (and only they) get SIGTERM, are reaped, and its code is returned.
             int worst = 0;
-            for (pid_t k : kids) {
+            size_t left = kids.size();
+            while (left > 0) {
                 int st = 0;
-                if (waitpid(k, &st, 0) < 0) { worst = worst ? worst : 1; continue; }
+                const pid_t k = waitpid(-1, &st, 0);
+                if (k < 0) {
+                    if (errno == EINTR) continue;
+                    worst = worst ? worst : 1;
+                    break;
+                }
+                auto it = std::find(kids.begin(), kids.end(), k);
+                if (it == kids.end()) continue;
+                *it = -1;
+                --left;
                 const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
-                if (code && !worst) worst = code;
+                if (code && !worst) {
+                    worst = code;
+                    for (pid_t o : kids) if (o > 0) kill(o, SIGTERM);
+                }
             }
+            unlink((meet_dir + "/uid.tmp").c_str());
             unlink((meet_dir + "/uid").c_str());
             rmdir(meet_dir.c_str());
             pmx_index_close(idx);

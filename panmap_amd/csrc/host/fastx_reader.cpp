@@ -1,5 +1,8 @@
 #include "fastx_reader.hpp"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -13,27 +16,33 @@
 namespace pmx {
 namespace {
 
-// whole inflated file (gzread also passes plain files through)
+// whole inflated file (gzread also passes plain files through).  The path is opened ONCE: a FIFO / process substitution /
+// /dev/stdin cannot be rewound or reopened, so only a regular file takes the one-read fast path (magic read with pread,
+// which does not move the offset), and everything else hands the very same descriptor to zlib.
 std::vector<char> slurp(const std::string& path) {
-    {   // a plain file: one read of its size (gzread would pass it through in small buffers)
-        FILE* pf = fopen(path.c_str(), "rb");
-        if (!pf) throw std::runtime_error("cannot open " + path);
+    const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
         unsigned char magic[2] = {0, 0};
-        const size_t got = fread(magic, 1, 2, pf);
-        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(pf, 0, SEEK_END) == 0) {
-            const long sz = ftell(pf);
-            if (sz >= 0 && fseek(pf, 0, SEEK_SET) == 0) {
-                std::vector<char> whole((size_t)sz);
-                const size_t rd = sz > 0 ? fread(whole.data(), 1, (size_t)sz, pf) : 0;
-                fclose(pf);
-                if (rd != (size_t)sz) throw std::runtime_error("read error in " + path);
-                return whole;
+        const ssize_t got = pread(fd, magic, 2, 0);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+            // a plain regular file: one read of its size (gzread would pass it through in small buffers)
+            std::vector<char> whole((size_t)st.st_size);
+            size_t rd = 0;
+            while (rd < whole.size()) {
+                const ssize_t r = pread(fd, whole.data() + rd, whole.size() - rd, (off_t)rd);
+                if (r < 0) { close(fd); throw std::runtime_error("read error in " + path); }
+                if (r == 0) break;      // the file shrank under us: keep what is there
+                rd += (size_t)r;
             }
+            close(fd);
+            whole.resize(rd);
+            return whole;
         }
-        fclose(pf);
     }
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open " + path);
+    gzFile f = gzdopen(fd, "rb");       // owns fd from here on (gzclose closes it)
+    if (!f) { close(fd); throw std::runtime_error("cannot open " + path); }
     gzbuffer(f, 1 << 20);
     std::vector<char> buf;
     size_t used = 0;

@@ -35,6 +35,10 @@ class Meta:
         offsets = np.ascontiguousarray(offsets, np.int64)
         check(lib.pmx_meta_set_reads(self.ctx._h, self._h, concat.ctypes.data, offsets.ctypes.data, len(offsets) - 1), "pmx_meta_set_reads")
 
+    def set_dust(self, threshold: float):
+        """--dust: the next set_reads drops reads whose DUST score is non-zero and above `threshold` (100 = off)"""
+        check(lib.pmx_meta_set_dust(self._h, float(threshold)), "pmx_meta_set_dust")
+
     def score(self, top_oc: int = 1000, candidates=None):
         if candidates is not None:
             c = np.ascontiguousarray(candidates, np.uint32)
@@ -108,6 +112,11 @@ class Meta:
             self.close()
         except Exception:
             pass
+
+
+def read_dust(seq: bytes, window: int = 64) -> float:
+    """mgsr::getDust (src/mgsr.cpp:1505-1568) by the library (pmx_read_dust, host)"""
+    return float(lib.pmx_read_dust(seq, len(seq), window))
 
 
 def format_abundance(haplotypes, node_id) -> str:

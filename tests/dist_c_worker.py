@@ -44,7 +44,25 @@ def main():
     uid_path = os.environ.get("PMX_DIST_UID_FILE")
     if world > 1 and uid_path and not os.environ.get("PMX_DIST_HOST_DIR"):
         raise SystemExit("this worker shares one GPU: set PMX_DIST_HOST_DIR")
-    uid = pmx.Dist.unique_id()                 # (host transport / one rank: nothing to ship)
+    # rank 0 makes the id, the others read it from a file next to the transport's (as `panmap --gpus N` ships it); under the
+    # host transport the id only carries the nonce of the run's file names
+    host_dir = os.environ.get("PMX_DIST_HOST_DIR")
+    if world > 1 and host_dir:
+        import time
+        uid_file = os.path.join(host_dir, "uid.tmp")
+        if rank == 0:
+            uid = pmx.Dist.unique_id()
+            with open(uid_file + ".part", "wb") as f:
+                f.write(uid)
+            os.rename(uid_file + ".part", uid_file)
+        else:
+            t0 = time.time()
+            while not os.path.exists(uid_file):
+                assert time.time() - t0 < 300, "rank 0 never published the id"
+                time.sleep(0.01)
+            uid = open(uid_file, "rb").read()
+    else:
+        uid = pmx.Dist.unique_id()
     dist = pmx.Dist(ctx, uid, rank, world)
     dist.barrier()
     lo, hi = shard_bounds(len(reads), world, rank)

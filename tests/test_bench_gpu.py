@@ -36,6 +36,14 @@ def test_bench_single_rank_line():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
     assert d["checks"]["placed_node"] == "node_7618" and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
+    # SURVEY 8d "parity checks in the same run": the GPU's results on the CPU sample against the CPU path's own
+    o = d["checks"]["oracle"]
+    assert o["reads"] == 20000 and o["histogram_equal"] and o["node_scores_bit_equal"] and o["tsv_equal"]
+    assert o["records_equal"] == "20000/20000" and o["cigars_equal"] == "20000/20000" and o["cigar_ops_compared"] >= 20000
+    assert d["cpu_baseline"]["threads_launched"] >= d["cpu_baseline"]["cores"]
+    # per-stage rooflines: every stage with its kernel time, algorithmic bytes and fraction of its bound
+    for st in d["roofline_by_stage"].values():
+        assert set(("kernel_ms", "algorithmic_bytes", "achieved", "peak", "frac", "bound")) <= set(st), st
 
 
 def test_bench_two_ranks_functional():

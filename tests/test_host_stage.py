@@ -266,6 +266,28 @@ def test_native_fastx_reader_matches_python_reader(pmx, tmp_path):
         pmx.read_fastx_native(str(tmp_path / "missing.fq"))
 
 
+def test_native_fastx_reader_reads_pipes(pmx, tmp_path):
+    """a FIFO (process substitution, /dev/stdin) cannot be rewound or reopened: the reader opens the path once and takes the
+    one-read fast path for regular files only, as the reference's gzopen + kseq does (src/seeding.cpp:231-269) -- the first
+    record of a plain FASTQ from a pipe must not be lost, and a gzip stream from a pipe must inflate"""
+    import gzip
+    import threading
+    plain = b"".join(b"@p%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(3000))
+    for payload, data in (("plain", plain), ("gzip", gzip.compress(plain))):
+        fifo = tmp_path / ("in_%s.fq" % payload)
+        os.mkfifo(fifo)
+
+        def feed(path=fifo, blob=data):
+            with open(path, "wb") as f:
+                f.write(blob)
+        th = threading.Thread(target=feed)
+        th.start()
+        fx = pmx.read_fastx_native(str(fifo))
+        th.join()
+        seqs, quals, names = fx.lists()
+        assert len(seqs) == 3000 and names[0] == b"p0" and names[-1] == b"p2999" and set(seqs) == {b"ACGTACGTAC"}, payload
+
+
 def test_synthetic_reads_are_deterministic_and_fr(pmx, sars):
     g = sars.genome("node_7618")
     c1, o1 = pmx.simulate_paired_reads(g, 500, seed=42)

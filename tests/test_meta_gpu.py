@@ -130,3 +130,107 @@ def test_em_equals_the_restatement(pmx, rsv_meta):
         got = [(p, node) for node, p, _ in haps]
         assert [n for _, n in want] == [n for _, n in got]
         assert np.allclose([p for p, _ in want], [p for p, _ in got], rtol=0, atol=1e-9)
+
+
+def _merged_columns(sc):
+    """columns as the device merges them: equal score columns are one column (lowest candidate first)"""
+    cols, seen = [], {}
+    for j in range(sc.shape[1]):
+        key = sc[:, j].tobytes()
+        if key not in seen:
+            seen[key] = j
+            cols.append(j)
+    return cols
+
+
+def test_config5_sars_five_haplotypes(pmx):
+    """BASELINE configs[4] on its own tree: a 5-haplotype mixture against the SARS-CoV-2 20k PanMAN through pmx_meta_*.
+    The README demo's reads (examples/data/reads/sars20000_5hap_*) are absent from the reference checkout, so the mixture is
+    drawn here: 200,000 paired 150-bp reads, 50/20/15/10/5 %, from the five leaves that lead the reference's golden
+    abundance file (examples/expected/meta_abundance/example.mgsr.abundance.out -> tests/golden/), run as the demo command
+    runs (--em-delta-threshold 0.00001).
+      * read side: the seedmer lists + multiplicities of a 20,000-read slice equal the from-the-string restatement;
+      * scores: ALL distinct reads x 64 candidates (the five sources + 59 random nodes) equal scores computed from the
+        candidates' GENOME STRINGS (oracle_meta.genome_seed_counts: no index, no product code on the checker's side);
+      * overlap coefficients of the five sources equal the from-the-string value;
+      * EM on those 64 candidates equals the numpy restatement to 1e-9;
+      * the full run (top-oc 1000 -> ~2,700 candidates) reports exactly the five sources, in the order of their shares, each
+        within 0.03 of its share -- and, like the reference's golden file, within 0.03 of the golden proportions."""
+    from oracle import oracle_meta as om
+    from panmap_amd import _lib
+    pm = pmx.Panman(os.path.join(GOLDEN, "sars_20000_twilight_dipper.panman"))
+    ctx = pmx.Context(0)
+    meta = pmx.Meta.build(ctx, pm)
+    golden = [l.rstrip("\n").split("\t") for l in open(os.path.join(GOLDEN, "example.mgsr.abundance.out"))]
+    names = [g[0] for g in golden[:5]]
+    shares = [0.50, 0.20, 0.15, 0.10, 0.05]
+    src = [pm.find_node(n) for n in names]
+    n_reads = 200000
+    parts, offs, base = [], [np.zeros(1, np.int64)], 0
+    for i, (node, sh) in enumerate(zip(src, shares)):
+        c, o = pmx.simulate_paired_reads(pm.genome(node), int(n_reads * sh) // 2, seed=10 + i)
+        parts.append(c)
+        offs.append(np.asarray(o[1:], np.int64) + base)
+        base += int(o[-1])
+    concat, offsets = np.concatenate(parts), np.concatenate(offs)
+    assert len(offsets) - 1 == n_reads
+    meta.set_reads(concat=concat, offsets=offsets)
+    off, h, rev = meta.read_seedmers()
+    ns, mult = meta.read_info()
+    assert meta.n_reads > 50000 and int(mult.sum()) <= n_reads and np.array_equal(ns, np.diff(off))
+    # ---- read side, a slice of the raw reads (every tenth): its seedmer lists are among the merged reads'
+    got_reads = {}
+    hl, rl = h.tolist(), rev.tolist()
+    for i in range(len(ns)):
+        got_reads[tuple(zip(hl[off[i]:off[i + 1]], map(bool, rl[off[i]:off[i + 1]])))] = int(mult[i])
+    seen = {}
+    for r in range(0, n_reads, 10):
+        sm = tuple(om.seedmers(bytes(concat[offsets[r]:offsets[r + 1]]), 19, 8, 3))
+        if sm:
+            seen[sm] = seen.get(sm, 0) + 1
+    assert len(seen) > 5000
+    for sm, c in seen.items():
+        assert got_reads.get(sm, 0) >= c, sm[:2]
+    # ---- scores of all reads x 64 candidates, from the candidates' genome strings
+    rng = np.random.default_rng(55)
+    n_nodes = meta.index.info.n_nodes
+    cands = np.unique(np.concatenate([np.array(src), rng.integers(0, n_nodes, 59)])).astype(np.uint32)
+    meta.score(candidates=cands)
+    assert np.array_equal(meta.candidates(), cands)
+    got = meta.scores()
+    assert got.shape == (len(ns), len(cands))
+    read_hashes = set(hl)
+    for j, node in enumerate(cands.tolist()):
+        counts = {hh: c for hh, c in om.genome_seed_counts(pm.genome(node), 19, 8, 3).items() if hh in read_hashes}
+        want = om.read_scores_np(counts, off, h, rev)
+        assert np.array_equal(got[:, j].astype(np.int64), want), (node, np.nonzero(got[:, j] != want)[0][:5])
+    assert got.max() >= 30
+    oc = meta.overlap_coefficients()
+    for node in src:
+        gs = om.genome_seed_counts(pm.genome(node), 19, 8, 3)
+        assert abs(oc[node] - sum(1 for hh in gs if hh in read_hashes) / len(gs)) < 1e-12, node
+    # ---- EM on the 64 candidates against the numpy restatement (the demo's stop rule)
+    mp = _lib.MetaParams(em_delta_threshold=1e-5)
+    haps = meta.em(mp)
+    sc = got.astype(np.int64)
+    cols = _merged_columns(sc)
+    rows = sc.max(axis=1) > 0
+    kept, props = om.square_em(sc[rows][:, cols], ns[rows], mult[rows], delta_threshold=1e-5)
+    want = sorted(((float(p), int(cands[cols[k]])) for k, p in zip(kept, props)), reverse=True)
+    got_h = [(p, node) for node, p, _ in haps]
+    assert [n for _, n in want] == [n for _, n in got_h]
+    assert np.allclose([p for p, _ in want], [p for p, _ in got_h], rtol=0, atol=1e-9)
+    # ---- the full run, as the demo command
+    meta.score(top_oc=1000)
+    assert len(meta.candidates()) > 500 and set(src) <= set(meta.candidates().tolist())
+    haps = meta.em(_lib.MetaParams(em_delta_threshold=1e-5))
+    text = pmx.format_abundance(haps, pm.node_id)
+    lines = [l.split("\t") for l in text.splitlines()]
+    assert [l[0].split(",")[0] for l in lines] == names, text          # exactly the five sources, by share
+    for (ids, p), sh, g in zip(lines, shares, golden):
+        assert abs(float(p) - sh) <= 0.03, text
+        assert abs(float(p) - float(g[1])) <= 0.03, (text, golden)      # the reference's golden file has the same shape
+    assert abs(sum(float(p) for _, p in lines) - 1.0) < 1e-4
+    info = meta.em_info()
+    assert 1 <= info["rounds"] <= 5 and info["iterations"] < 1000
+    meta.close()
