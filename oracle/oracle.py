@@ -147,8 +147,9 @@ def score_nodes(parent, offsets, ch_hash, ch_par, ch_child, kept_hash, kept_log,
     return sc, met, cts, wc.value
 
 
-def best_ties(parent, scores, force_leaf=False, cap=1 << 16):
+def best_ties(parent, scores, force_leaf=False, cap=0):
     n = len(parent)
+    cap = max(cap, 2 * n + 2)     # (the tied list takes up to two entries per visited node before it is de-duplicated)
     parent = np.ascontiguousarray(parent, np.uint32); scores = np.ascontiguousarray(scores, np.float64)
     best = np.zeros(5); idx = np.zeros(5, np.uint32); ties = np.zeros((5, cap), np.uint32); nt = np.zeros(5, np.int64)
     olib().orc_best_ties(n, parent.ctypes.data, scores.ctypes.data, int(force_leaf), best.ctypes.data, idx.ctypes.data, ties.ctypes.data, cap,
@@ -239,8 +240,11 @@ def prepare_align_call_flat(concat, off, paired: bool, revcomp_mate2: bool):
     nm = C.create_string_buffer(b"r")
     quals = (C.c_char_p * max(n, 1))()
     names = (C.c_char_p * max(n, 1))()
-    C.memmove(C.addressof(quals), np.full(max(n, 1), C.addressof(q), np.uint64).ctypes.data, 8 * max(n, 1))
-    C.memmove(C.addressof(names), np.full(max(n, 1), C.addressof(nm), np.uint64).ctypes.data, 8 * max(n, 1))
+    fill_q = np.full(max(n, 1), C.addressof(q), np.uint64)      # (named: a temporary would be freed before memmove reads it)
+    fill_n = np.full(max(n, 1), C.addressof(nm), np.uint64)
+    C.memmove(C.addressof(quals), fill_q.ctypes.data, 8 * max(n, 1))
+    C.memmove(C.addressof(names), fill_n.ctypes.data, 8 * max(n, 1))
+    del fill_q, fill_n
     n_res = n // 2 if paired else n
     res = (AlignPairResult * max(n_res, 1))()
     return dict(n=n, arr=arr, quals=quals, names=names, lens=lens, n_res=n_res, res=res, paired=paired, _keep=(buf, q, nm, concat, off))

@@ -42,8 +42,11 @@ struct pmx_place {
     unsigned long long h_ctr[PMX_CTR_N];   // the counters as last read back; valid while nothing has been inserted since
     bool h_ctr_valid = false;
     double keys_per_base = 0;              // distinct seeds per read base of the last finished histogram (0: none yet): sizes the next table
-    hipStream_t seed_streams[3] = {nullptr, nullptr, nullptr};   // side streams: seeding launches of one group run concurrently
-    hipEvent_t seed_go = nullptr, seed_done[3] = {nullptr, nullptr, nullptr};
+    // distinct-read tiles of the seeding chunks in flight (k_collapse_reads -> k_seed_histogram_ks), one set per concurrent chunk
+    DevBuf<uint64_t> t_words[4];
+    DevBuf<uint32_t> t_amb[4], t_len[4], t_mult[4];
+    DevBuf<unsigned long long> t_count;    // [4]
+    bool collapse_attr_set = false;
     // finalised histogram
     DevBuf<uint64_t> hist_hash, hist_hash_tmp;
     DevBuf<int64_t> hist_count, hist_count_tmp;
@@ -216,10 +219,13 @@ static void order_range(pmx_ctx* ctx, const pmx_readset* rs, int64_t r0, int64_t
     if (m <= 0) return;
     hipLaunchKernelGGL(k_read_prefix_keys, dim3(grid_for(m, 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream, rs->words.p, rs->woff.p, r0, r1, rs->loc_key.p,
                        rs->loc_idx.p);
+    // (sorting on the key's top 20 bits alone -- three radix passes instead of four -- returned index arrays that were no
+    //  permutation on this rocprim: measured, not understood; the full key it is)
+    const unsigned lo_bit = 0u;
     size_t bytes = 0;
-    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, rs->loc_key.p + r0, rs->loc_key2.p + r0, rs->loc_idx.p + r0, rs->loc_perm.p + r0, (size_t)m, 0, 32, ctx->stream));
+    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, rs->loc_key.p + r0, rs->loc_key2.p + r0, rs->loc_idx.p + r0, rs->loc_perm.p + r0, (size_t)m, lo_bit, 32, ctx->stream));
     rs->loc_tmp.ensure(bytes);
-    PMX_HIP(rocprim::radix_sort_pairs(rs->loc_tmp.p, bytes, rs->loc_key.p + r0, rs->loc_key2.p + r0, rs->loc_idx.p + r0, rs->loc_perm.p + r0, (size_t)m, 0, 32, ctx->stream));
+    PMX_HIP(rocprim::radix_sort_pairs(rs->loc_tmp.p, bytes, rs->loc_key.p + r0, rs->loc_key2.p + r0, rs->loc_idx.p + r0, rs->loc_perm.p + r0, (size_t)m, lo_bit, 32, ctx->stream));
 }
 
 const uint32_t* readset_locality_order(pmx_ctx* ctx, const pmx_readset* rs) {
@@ -275,6 +281,11 @@ void pmx_ctx_destroy(pmx_ctx* ctx) {
         if (kv.second.e0) (void)hipEventDestroy(kv.second.e0);
         if (kv.second.e1) (void)hipEventDestroy(kv.second.e1);
     }
+    for (int j = 0; j < 3; ++j) {
+        if (ctx->seed_streams[j]) (void)hipStreamDestroy(ctx->seed_streams[j]);
+        if (ctx->seed_done[j]) (void)hipEventDestroy(ctx->seed_done[j]);
+    }
+    if (ctx->seed_go) (void)hipEventDestroy(ctx->seed_go);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -572,13 +583,6 @@ int pmx_place_create(pmx_ctx* ctx, const pmx_index* idx, pmx_place** out) {
 void pmx_place_free(pmx_ctx* ctx, pmx_place* pl) {
     if (ctx) (void)hipSetDevice(ctx->device);
     if (pl && pl->level_graph_exec) (void)hipGraphExecDestroy(pl->level_graph_exec);
-    if (pl) {
-        for (int j = 0; j < 3; ++j) {
-            if (pl->seed_streams[j]) (void)hipStreamDestroy(pl->seed_streams[j]);
-            if (pl->seed_done[j]) (void)hipEventDestroy(pl->seed_done[j]);
-        }
-        if (pl->seed_go) (void)hipEventDestroy(pl->seed_go);
-    }
     delete pl;
 }
 
@@ -682,17 +686,28 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         const uint32_t* perm = ks_path && !getenv("PMX_SEED_NO_SORT") ? (whole ? readset_locality_order(ctx, rs) : readset_locality_order_range(ctx, rs, rr0, rr1)) : nullptr;
         // the specialised kernel keeps its rings in registers: LDS = the waves' seed queues + the block cache (keys 8 B +
         // counts 4 B + admission tags 2 B per entry)
-        const size_t lds_ks = (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS * sizeof(uint64_t) + (size_t)PMX_SEED_CACHE * 14 + 35 * sizeof(uint64_t);   // + the base-hash tables
+        const size_t lds_ks = (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS * sizeof(uint64_t) + (size_t)PMX_SEED_CACHE * 14 + 35 * sizeof(uint64_t) +   // + the base-hash tables
+                              (size_t)(PMX_SEED_BLOCK / 64) * (64 * sizeof(uint32_t) + PMX_SEED_QCAP_KS);                                                   // + multiplicities, pushing lanes
+        // Read collapse ahead of the seeding kernel (k_collapse_reads: src/placement.cpp:1550-1593 seeds every distinct read once,
+        // with its multiplicity): reads of up to 160 bases on the specialised kernel's path
+        const bool collapse = ks_path && rs->max_len <= 160 && !getenv("PMX_SEED_NO_COLLAPSE");
+        if (collapse && !pl->collapse_attr_set) {
+            PMX_HIP(hipFuncSetAttribute((const void*)k_collapse_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PMX_DEDUP_LDS_BYTES));
+            pl->collapse_attr_set = true;
+        }
+        if (collapse) pl->t_count.ensure(4);
+        // every read of the set has max_len bases (total = n x max_len): word offsets follow from the read index
+        const int fixed_len = (rs->n > 0 && rs->total == rs->n * rs->max_len) ? (int)rs->max_len : 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
         // A launch of one chunk is latency-bound (every wave walks its 150 bases one after the other, a few waves per
         // SIMD): the chunks of a group run concurrently on side streams, sharing the table (all they do is atomics).
         int n_par = 3;
         if (const char* e = getenv("PMX_SEED_PAR")) n_par = std::max(1, std::min(4, atoi(e)));
-        if (n_par > 1 && !pl->seed_go) {
-            PMX_HIP(hipEventCreateWithFlags(&pl->seed_go, hipEventDisableTiming));
-            for (int j = 0; j < n_par - 1 && j < 3; ++j) {   // (own hardware queues: see create_dedicated_stream)
-                pl->seed_streams[j] = create_dedicated_stream(ctx->n_cu);
-                PMX_HIP(hipEventCreateWithFlags(&pl->seed_done[j], hipEventDisableTiming));
+        if (n_par > 1 && !ctx->seed_go) {
+            PMX_HIP(hipEventCreateWithFlags(&ctx->seed_go, hipEventDisableTiming));
+            for (int j = 0; j < 3; ++j) {   // (own hardware queues: see create_dedicated_stream)
+                ctx->seed_streams[j] = create_dedicated_stream(ctx->n_cu);
+                PMX_HIP(hipEventCreateWithFlags(&ctx->seed_done[j], hipEventDisableTiming));
             }
         }
         const int64_t chunk_reads = bound_div > 1 ? chunk_reads_opt : chunk_reads_safe;
@@ -700,12 +715,12 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
             const int64_t g1 = std::min<int64_t>(rr1, g0 + chunk_reads * n_par);
             const double safe_bound = (double)(g1 - g0) * (double)rs->max_len;
             table_reserve(ctx, pl, (uint64_t)(bound_div > 1 && bound_frac > 0 ? safe_bound * bound_frac : safe_bound / (double)bound_div) + 1);
-            if (n_par > 1) PMX_HIP(hipEventRecord(pl->seed_go, ctx->stream));
+            if (n_par > 1) PMX_HIP(hipEventRecord(ctx->seed_go, ctx->stream));
             int j = 0;
             for (int64_t r0 = g0; r0 < g1; r0 += chunk_reads, ++j) {
             const int64_t r1 = std::min<int64_t>(g1, r0 + chunk_reads);
-            hipStream_t st = j == 0 ? ctx->stream : pl->seed_streams[j - 1];
-            if (j > 0) PMX_HIP(hipStreamWaitEvent(st, pl->seed_go, 0));
+            hipStream_t st = j == 0 ? ctx->stream : ctx->seed_streams[j - 1];
+            if (j > 0) PMX_HIP(hipStreamWaitEvent(st, ctx->seed_go, 0));
             // batches of PMX_SEED_BLOCK reads per block of the specialised kernel, contiguous in the seeding order.  More than one
             // saves cache flushes (memory-side atomics) but measured slower: 1.55 ms for the stage with 1, 1.59 / 1.84 / 1.86 / 3.14
             // with 2 / 4 / 8 / 16 -- fewer, longer blocks fill the chip worse, and the atomics are not what bounds the kernel
@@ -715,17 +730,30 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
             //  a grid capped at what is resident made every block walk several batches, which measured slower, see above)
             const dim3 grid(ks_path ? grid_for(r1 - r0, PMX_SEED_BLOCK * seed_batches, 1 << 30) : grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
             // the default seeding parameters run the kernel specialised for them (same results, ~3x fewer instructions)
-            if (ks_path)
+            if (ks_path && collapse) {
+                const int64_t n_c = r1 - r0, n_tiles = (n_c + 63) / 64;
+                pl->t_words[j].ensure((size_t)n_tiles * 5 * 64); pl->t_amb[j].ensure((size_t)n_tiles * 5 * 64);
+                pl->t_len[j].ensure((size_t)n_tiles * 64); pl->t_mult[j].ensure((size_t)n_tiles * 64);
+                PMX_HIP(hipMemsetAsync(pl->t_count.p + j, 0, sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(k_collapse_reads, dim3((unsigned)((n_c + PMX_DEDUP_BLOCK - 1) / PMX_DEDUP_BLOCK)), dim3(PMX_DEDUP_BLOCK), PMX_DEDUP_LDS_BYTES, st,
+                                   rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, keep, perm, sp.k, fixed_len, pl->t_words[j].p, pl->t_amb[j].p, pl->t_len[j].p,
+                                   pl->t_mult[j].p, pl->t_count.p + j);
+                PMX_HIP(hipGetLastError());
+                hipLaunchKernelGGL((l == 3 ? k_seed_histogram_ks<19, 8, 3> : k_seed_histogram_ks<19, 8, 1>), grid, block, lds_ks, st, pl->t_words[j].p, pl->t_amb[j].p,
+                                   (const int64_t*)nullptr, (const int64_t*)nullptr, (int64_t)0, n_c, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p,
+                                   (const uint8_t*)nullptr, (const uint32_t*)nullptr, pl->t_len[j].p, pl->t_mult[j].p, pl->t_count.p + j);
+            } else if (ks_path)
                 hipLaunchKernelGGL((l == 3 ? k_seed_histogram_ks<19, 8, 3> : k_seed_histogram_ks<19, 8, 1>), grid, block, lds_ks, st, rs->words.p, rs->amb.p,
-                                   rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep, perm);
+                                   rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p, pl->vals.p, pl->cap - 1, pl->counters.p, keep, perm,
+                                   (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const unsigned long long*)nullptr);
             else
                 hipLaunchKernelGGL(k_seed_histogram, grid, block, lds, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p,
                                    pl->vals.p, pl->cap - 1, pl->counters.p, keep, quality_mode ? rs->qual.p : nullptr,
                                    quality_mode ? pp->min_seed_quality : 0);
             PMX_HIP(hipGetLastError());
             if (j > 0) {
-                PMX_HIP(hipEventRecord(pl->seed_done[j - 1], st));
-                PMX_HIP(hipStreamWaitEvent(ctx->stream, pl->seed_done[j - 1], 0));
+                PMX_HIP(hipEventRecord(ctx->seed_done[j - 1], st));
+                PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->seed_done[j - 1], 0));
             }
             }
         }

@@ -91,6 +91,11 @@ struct pmx_ctx {
     hipStream_t stream = nullptr;
     std::map<std::string, pmx::KernelTimer> timers;
     int n_cu = 256;
+    // Side streams of the seeding stage (hardware queues of their own, see create_dedicated_stream) and the events that order
+    // them against the context's stream.  They belong to the CONTEXT, made on first use and kept until it is destroyed: a
+    // placer that made and destroyed its own left the next placer's kernels on a recycled queue hanging (round 4).
+    hipStream_t seed_streams[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t seed_go = nullptr, seed_done[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace pmx {

@@ -7,6 +7,8 @@
 #define PMX_SEED_CACHE 512   // entries of a block's (seed, count) cache in LDS (k_seed_histogram_ks)
 #define PMX_SEED_QCAP 256   // seeds a wave queues in LDS before it inserts them 64 at a time (k_seed_histogram)
 #define PMX_SEED_QCAP_KS 1024   // k_seed_histogram_ks: drained once per block of k-s+1 bases
+#define PMX_DEDUP_BLOCK 1024   // reads a block of k_collapse_reads compares with each other
+#define PMX_DEDUP_LDS_BYTES (20 * PMX_DEDUP_BLOCK * 4)   // 16 record dwords + hash + count + two table slots per read
 #define PMX_SUM_BLOCK 1024
 #define PMX_CTR_NSHARD 256
 enum { PMX_CTR_ENTRIES = 0, PMX_CTR_OVERFLOW = 1, PMX_CTR_SEEDS = 2, PMX_CTR_COMPACT = 3, PMX_CTR_SHARD0 = 8, PMX_CTR_N = 8 + PMX_CTR_NSHARD };
@@ -29,7 +31,11 @@ __global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, con
 template <int K, int S, int L>
 __global__ void k_seed_histogram_ks(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin,
                                     int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask,
-                                    unsigned long long* counters, const uint8_t* keep, const uint32_t* perm);
+                                    unsigned long long* counters, const uint8_t* keep, const uint32_t* perm, const uint32_t* t_len,
+                                    const uint32_t* t_mult, const unsigned long long* t_count);
+__global__ void k_collapse_reads(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin, int64_t r_end,
+                                 const uint8_t* keep, const uint32_t* perm, int min_len, int fixed_len, uint64_t* t_words, uint32_t* t_amb, uint32_t* t_len,
+                                 uint32_t* t_mult, unsigned long long* n_out);
 __global__ void k_read_prefix_keys(const uint64_t* words, const int64_t* woff, int64_t r_begin, int64_t n_reads, uint32_t* key, uint32_t* idx);
 __global__ void k_read_hashes(const uint8_t* ascii, const int64_t* off, int64_t n_reads, uint64_t* h1, uint64_t* h2, uint32_t* idx);
 __global__ void k_gather_u64(const uint64_t* src, const uint32_t* idx, int64_t n, uint64_t* dst);

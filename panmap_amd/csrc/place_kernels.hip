@@ -216,16 +216,20 @@ __device__ __forceinline__ void table_insert(uint64_t* keys, unsigned long long*
 // -- 2^-64 per seed -- cannot be a key of the table in either kernel: the table's empty mark is that value.)
 template <bool ABSORBED>
 __device__ __forceinline__ void drain_seed_queue(const uint64_t* queue, int n_q, int rank, int n_act, uint64_t* keys, unsigned long long* vals,
-                                                 uint64_t mask, unsigned long long* counters) {
+                                                 uint64_t mask, unsigned long long* counters, const uint8_t* qlane = nullptr,
+                                                 const uint32_t* wmult = nullptr) {
+    // qlane / wmult (k_seed_histogram_ks over distinct-read tiles): entry q was pushed by lane qlane[q], whose read stands for
+    // wmult[lane] identical reads -- its seeds count that many times
     for (int q0 = rank; q0 < n_q; q0 += 4 * n_act) {
         uint64_t h[4], slot[4];
-        unsigned long long cur[4];
+        unsigned long long cur[4], m[4];
         bool ok[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int q = q0 + b * n_act;
             ok[b] = q < n_q;
             h[b] = ok[b] ? queue[q] : 0;
+            m[b] = (ok[b] && qlane) ? (unsigned long long)wmult[qlane[q]] : 1ULL;
             if (ABSORBED) ok[b] = ok[b] && h[b] != PMX_EMPTY_KEY;   // (entries the block cache has absorbed)
             slot[b] = mix64(h[b]) & mask;
             cur[b] = 0;
@@ -234,8 +238,8 @@ __device__ __forceinline__ void drain_seed_queue(const uint64_t* queue, int n_q,
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             if (!ok[b]) continue;
-            if (cur[b] == h[b]) atomicAdd(&vals[slot[b]], 1ULL);
-            else table_insert(keys, vals, mask, h[b], 1ULL, counters);   // empty slot or collision: the full probe sequence
+            if (cur[b] == h[b]) atomicAdd(&vals[slot[b]], m[b]);
+            else table_insert(keys, vals, mask, h[b], m[b], counters);   // empty slot or collision: the full probe sequence
         }
     }
 }
@@ -464,10 +468,12 @@ __device__ __forceinline__ uint64_t hb_rot(uint32_t c, uint32_t am) {
 // k_seed_histogram_ks: a wave's queued seeds go to the block's (seed, count) cache, or -- first sightings, slots taken by
 // another seed -- to the table.  Called by all 64 lanes.
 __device__ __forceinline__ void seed_queue_to_cache_and_table(uint64_t* queue, int n_q, int lane, unsigned long long* ckey, uint32_t* ccnt, uint16_t* ctag,
-                                                           uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters) {
+                                                           uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters,
+                                                           const uint8_t* qlane, const uint32_t* wmult) {
     for (int q = lane; q < n_q; q += 64) {
         const uint64_t h = queue[q];
-        if (h == PMX_EMPTY_KEY) { table_insert(keys, vals, mask, h, 1ULL, counters); continue; }   // (the sentinel value itself)
+        const uint32_t m = wmult[qlane[q]];
+        if (h == PMX_EMPTY_KEY) { table_insert(keys, vals, mask, h, (unsigned long long)m, counters); continue; }   // (the sentinel value itself)
         const uint64_t hm = mix64(h);
         const uint32_t cs = (uint32_t)hm & (PMX_SEED_CACHE - 1);
         const uint16_t tag = (uint16_t)((hm >> 40) | 1u);
@@ -478,18 +484,131 @@ __device__ __forceinline__ void seed_queue_to_cache_and_table(uint64_t* queue, i
             if (cur == PMX_EMPTY_KEY) cur = h;
         }
         if (cur == h) {
-            atomicAdd(&ccnt[cs], 1u);
+            atomicAdd(&ccnt[cs], m);
             queue[q] = PMX_EMPTY_KEY;
         }
     }
-    drain_seed_queue<true>(queue, n_q, lane, 64, keys, vals, mask, counters);
+    drain_seed_queue<true>(queue, n_q, lane, 64, keys, vals, mask, counters, qlane, wmult);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Read collapse (src/placement.cpp:1550-1593: the reference sorts the reads and seeds every DISTINCT sequence once with its
+// multiplicity -- counts are additive, so the histogram is the same).  Here, ahead of the seeding kernel: a block takes 1,024
+// consecutive reads of the locality order (reads that start within a few bases of each other: at depth, most of them are
+// copies of one another), keeps every read's packed form (five 2-bit words + five ambiguity words + its length = 64 bytes) in
+// LDS, and a 2,048-slot LDS hash table elects one owner per distinct record -- a candidate that meets an owner with the same
+// hash is compared with it DWORD FOR DWORD (exact: no read is merged on a hash alone) and adds one to the owner's count.  The
+// owners leave the block as TILES of 64 distinct reads laid out [tile][word][lane], which the seeding kernel then reads with
+// coalesced loads (the gather from the reads' own, scattered, places happens once, here, a whole read at a time: the seeding
+// kernel used to re-fetch a read's lines for every 32 bases).  Copies that fall into different blocks are simply seeded twice.
+// Reads shorter than min_len (no k-mer) and reads a --dedup mask drops are not emitted.  Reads of up to 160 bases.
+__global__ void __launch_bounds__(PMX_DEDUP_BLOCK)
+k_collapse_reads(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff, const int64_t* __restrict__ off,
+                 int64_t r_begin, int64_t r_end, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ perm, int min_len, int fixed_len,
+                 uint64_t* __restrict__ t_words, uint32_t* __restrict__ t_amb, uint32_t* __restrict__ t_len, uint32_t* __restrict__ t_mult,
+                 unsigned long long* n_out) {
+    // dynamic LDS, PMX_DEDUP_LDS_BYTES (80 KB for 1,024 reads: two blocks per CU)
+    extern __shared__ uint32_t lds32[];
+    uint32_t (*rec)[PMX_DEDUP_BLOCK] = reinterpret_cast<uint32_t (*)[PMX_DEDUP_BLOCK]>(lds32);   // [dword][thread]: words 0..4 (lo, hi), ambiguity words 0..4, length
+    uint32_t* rhash = lds32 + 16 * PMX_DEDUP_BLOCK;
+    uint32_t* mult = rhash + PMX_DEDUP_BLOCK;
+    uint32_t* tab = mult + PMX_DEDUP_BLOCK;              // 2 * PMX_DEDUP_BLOCK slots
+    __shared__ uint32_t wave_tot[PMX_DEDUP_BLOCK / 64];
+    __shared__ unsigned long long base_sh;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t j = r_begin + (int64_t)blockIdx.x * PMX_DEDUP_BLOCK + tid;
+    uint64_t w[5] = {0, 0, 0, 0, 0};
+    uint32_t a[5] = {0, 0, 0, 0, 0};
+    uint32_t len = 0;
+    if (j < r_end) {
+        const int64_t r = perm ? (int64_t)perm[j] : j;
+        // fixed_len > 0: every read of the set has that many bases (the host knows: total = n x max), so the read's place in
+        // the packed arrays follows from its index -- two scattered loads per read less
+        const int64_t l64 = fixed_len > 0 ? (int64_t)fixed_len : off[r + 1] - off[r];
+        if (l64 >= min_len && l64 <= 160 && !(keep && !keep[r])) {
+            len = (uint32_t)l64;
+            const int nw = (int)((l64 + 31) >> 5);
+            const int64_t w0 = fixed_len > 0 ? r * (int64_t)nw : woff[r];
+            const uint64_t* rw = words + w0;
+            const uint32_t* ra = amb + w0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                if (q < nw) { w[q] = rw[q]; a[q] = ra[q]; }
+        }
+    }
+    uint32_t d[16];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { d[2 * q] = (uint32_t)w[q]; d[2 * q + 1] = (uint32_t)(w[q] >> 32); d[10 + q] = a[q]; }
+    d[15] = len;
+    uint32_t h = 0x9747b28cu;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {   // murmur3-style mixing of the sixteen dwords
+        uint32_t k1 = d[q] * 0xcc9e2d51u;
+        k1 = (k1 << 15) | (k1 >> 17);
+        h ^= k1 * 0x1b873593u;
+        h = ((h << 13) | (h >> 19)) * 5u + 0xe6546b64u;
+        rec[q][tid] = d[q];
+    }
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    rhash[tid] = h;
+    mult[tid] = 1u;
+    tab[tid] = 0xffffffffu;
+    tab[tid + PMX_DEDUP_BLOCK] = 0xffffffffu;
+    __syncthreads();
+    bool owner = false;
+    if (len) {
+        uint32_t slot = h & (2 * PMX_DEDUP_BLOCK - 1);
+        for (;;) {
+            const uint32_t cur = atomicCAS(&tab[slot], 0xffffffffu, (uint32_t)tid);
+            if (cur == 0xffffffffu) { owner = true; break; }
+            if (rhash[cur] == h) {
+                bool same = true;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) same = same && rec[q][cur] == d[q];
+                if (same) { atomicAdd(&mult[cur], 1u); break; }
+            }
+            slot = (slot + 1) & (2 * PMX_DEDUP_BLOCK - 1);   // (at most PMX_DEDUP_BLOCK owners in twice as many slots: ends)
+        }
+    }
+    // owners -> consecutive places of the tile arrays (one cursor bump per block)
+    const unsigned long long ob = __ballot(owner);
+    const uint32_t in_wave = (uint32_t)__popcll(ob & ((1ULL << lane) - 1ULL));
+    if (lane == 0) wave_tot[tid >> 6] = (uint32_t)__popcll(ob);
+    __syncthreads();   // (also: every duplicate has added itself to its owner's count)
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < PMX_DEDUP_BLOCK / 64; ++q) {
+        const uint32_t t = wave_tot[q];
+        before += q < (tid >> 6) ? t : 0u;
+        total += t;
+    }
+    if (tid == 0) base_sh = total ? atomicAdd(n_out, (unsigned long long)total) : 0ULL;
+    __syncthreads();
+    if (owner) {
+        const uint64_t p = base_sh + before + in_wave;
+        const uint64_t tile = p >> 6, ln = p & 63;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            t_words[(tile * 5 + q) * 64 + ln] = w[q];
+            t_amb[(tile * 5 + q) * 64 + ln] = a[q];
+        }
+        t_len[p] = len;
+        // (--dedup: the mask has already dropped the later copies of every read STRING, src/placement.cpp:1619-1620; kept reads
+        //  that pack to the same record -- they differ in letter case only -- are different strings and each counts)
+        t_mult[p] = mult[tid];
+    }
 }
 
 template <int K, int S, int L>
 __global__ void __launch_bounds__(PMX_SEED_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))   // 170 VGPRs: the LDS footprint admits 12 waves per CU
 k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
                     const int64_t* __restrict__ off, int64_t r_begin, int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals,
-                    uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ perm) {
+                    uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ perm,
+                    const uint32_t* __restrict__ t_len, const uint32_t* __restrict__ t_mult, const unsigned long long* __restrict__ t_count) {
+    // Two input forms.  t_len == nullptr: the reads of a read set in place (words / amb / woff / off, visited through perm).
+    // t_len != nullptr: TILES of distinct reads from k_collapse_reads -- words / amb are the tile arrays [tile][word][lane]
+    // (a wave = one tile: every load is one coalesced line per word), t_len / t_mult the reads' lengths and multiplicities,
+    // *t_count how many there are (r_begin = 0; n_reads = the launch's capacity: blocks past the count leave at once).
     constexpr int W = K - S + 1;
     static_assert(K <= 32 && S >= 2 && W >= 2 && W <= 32, "window of 2..32 s-mers");
     static_assert(PMX_SEED_QCAP_KS >= 64 * W + 64, "the queue must take a block of W bases from every lane");
@@ -518,6 +637,12 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
     for (int i = tid; i < PMX_SEED_CACHE; i += PMX_SEED_BLOCK) { ckey[i] = PMX_EMPTY_KEY; ccnt[i] = 0; ctag[i] = 0; }
     // base-hash tables: seven rotations x (A, C, G, T, ambiguous = 0), read with one ds_read_b64 each instead of six selects
     uint64_t* hb_tab = reinterpret_cast<uint64_t*>(ctag + PMX_SEED_CACHE);
+    // who pushed a queue entry, and how many identical reads that lane's read stands for (1 without tiles)
+    uint32_t* wmult = reinterpret_cast<uint32_t*>(hb_tab + 35) + (size_t)(tid >> 6) * 64;
+    uint8_t* qlane = reinterpret_cast<uint8_t*>(reinterpret_cast<uint32_t*>(hb_tab + 35) + (PMX_SEED_BLOCK / 64) * 64) + (size_t)(tid >> 6) * PMX_SEED_QCAP_KS;
+    const bool tiles = t_len != nullptr;
+    const int wstride = tiles ? 64 : 1;
+    if (tiles) n_reads = (int64_t)*t_count < n_reads ? (int64_t)*t_count : n_reads;
     if (tid < 35) {
         const int t = tid / 5, c = tid % 5;
         const bool comp = t == 1 || t == 2 || t == 4 || t == 6;
@@ -527,7 +652,7 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
     __syncthreads();
     int n_q = 0;   // wave-uniform
     auto drain = [&]() {   // all 64 lanes; called once per block of W bases (inlined at every unrolled base it was most of the kernel's code)
-        seed_queue_to_cache_and_table(queue, n_q, lane, ckey, ccnt, ctag, keys, vals, mask, counters);
+        seed_queue_to_cache_and_table(queue, n_q, lane, ckey, ccnt, ctag, keys, vals, mask, counters, qlane, wmult);
         n_q = 0;
     };
     unsigned long long n_seeds = 0;
@@ -541,17 +666,27 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
     for (int64_t rb = blk_lo + (tid & ~63); rb < blk_hi; rb += PMX_SEED_BLOCK) {   // wave-uniform
         const int64_t rp = rb + lane;
         int ilen = 0;
+        uint32_t my_mult = 1u;
         const uint64_t* rw = words;
         const uint32_t* ra = amb;
+        if (n_q > 0) drain();   // (the lanes' multiplicities are about to change: nothing of the last batch may stay queued)
         if (rp < blk_hi) {
-            const int64_t r = perm ? (int64_t)perm[rp] : rp;
-            const int64_t len = off[r + 1] - off[r];
-            if (len >= K && !(keep && !keep[r])) {   // (--dedup: a later copy of an identical read is skipped)
-                ilen = (int)len;
-                rw = words + woff[r];
-                ra = amb + woff[r];
+            if (tiles) {
+                ilen = (int)t_len[rp];
+                my_mult = t_mult[rp];
+                rw = words + (size_t)(rb >> 6) * 5 * 64 + lane;   // (rb is a multiple of 64: the wave's tile)
+                ra = amb + (size_t)(rb >> 6) * 5 * 64 + lane;
+            } else {
+                const int64_t r = perm ? (int64_t)perm[rp] : rp;
+                const int64_t len = off[r + 1] - off[r];
+                if (len >= K && !(keep && !keep[r])) {   // (--dedup: a later copy of an identical read is skipped)
+                    ilen = (int)len;
+                    rw = words + woff[r];
+                    ra = amb + woff[r];
+                }
             }
         }
+        wmult[lane] = my_mult;
         const int valid_start = sp.trim_start, valid_end = ilen - sp.trim_end - K;
         const int n_words = (ilen + 31) >> 5;
         uint64_t fS = 0, rS = 0, fK = 0, rK = 0;
@@ -580,7 +715,7 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
         auto fetch_base = [&](int i) {
             if ((i & 31) == 0) {
                 cw_lo = (uint32_t)cw_next; cw_hi = (uint32_t)(cw_next >> 32); ca = ca_next;
-                if ((i >> 5) + 1 < n_words) { cw_next = rw[(i >> 5) + 1]; ca_next = ra[(i >> 5) + 1]; }
+                if ((i >> 5) + 1 < n_words) { cw_next = rw[((i >> 5) + 1) * wstride]; ca_next = ra[((i >> 5) + 1) * wstride]; }
             }
             n_code = cw_lo & 3u;
             n_am = ca & 1u;
@@ -684,8 +819,10 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
                 }
                 const unsigned long long pushers = __ballot(have);
                 if (have) {
-                    queue[n_q + (int)__popcll(pushers & ((1ULL << lane) - 1ULL))] = out;
-                    ++n_seeds;
+                    const int at = n_q + (int)__popcll(pushers & ((1ULL << lane) - 1ULL));
+                    queue[at] = out;
+                    qlane[at] = (uint8_t)lane;
+                    n_seeds += my_mult;
                 }
                 n_q += (int)__popcll(pushers);
             }
@@ -701,9 +838,11 @@ k_seed_histogram_ks(const uint64_t* __restrict__ words, const uint32_t* __restri
     if (lane == 0 && n_seeds) atomicAdd(&counters[PMX_CTR_SEEDS], n_seeds);
 }
 template __global__ void k_seed_histogram_ks<19, 8, 3>(const uint64_t*, const uint32_t*, const int64_t*, const int64_t*, int64_t, int64_t, SeedParams,
-                                                       uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*);
+                                                       uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*,
+                                                       const uint32_t*, const uint32_t*, const unsigned long long*);
 template __global__ void k_seed_histogram_ks<19, 8, 1>(const uint64_t*, const uint32_t*, const int64_t*, const int64_t*, int64_t, int64_t, SeedParams,
-                                                       uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*);
+                                                       uint64_t*, unsigned long long*, uint64_t, unsigned long long*, const uint8_t*, const uint32_t*,
+                                                       const uint32_t*, const uint32_t*, const unsigned long long*);
 
 // locality key of a read for the seeding order (read_locality_key: reads that start within a few bases of each other)
 __global__ void k_read_prefix_keys(const uint64_t* __restrict__ words, const int64_t* __restrict__ woff, int64_t r_begin, int64_t n_reads, uint32_t* key, uint32_t* idx) {

@@ -398,3 +398,28 @@ def test_scoring_redone_with_level_kernels_when_the_persistent_launch_starves(pm
     reads = _as_reads(concat, off)
     monkeypatch.setenv("PMX_PLACE_TEST_STARVED", "1")
     _check_place(pmx, oracle, ctx, sars_index, reads)
+
+
+def test_read_collapse_keeps_the_histogram(pmx, oracle, ctx, sars, sars_index):
+    """k_collapse_reads (src/placement.cpp:1550-1593: every distinct read seeded once with its multiplicity): deep coverage of a
+    short region -- most reads are copies of one another -- with reads of several lengths up to 160 bases, `N`s, lower case,
+    reads shorter than k, and copies spread over more than one 1,024-read block; fixed-length and ragged sets; with and
+    without --dedup.  The histogram, the kept seeds and every node score equal the oracle's, which seeds read by read."""
+    g = sars.genome("node_7618")[5000:5400]
+    rng = np.random.default_rng(17)
+    reads = []
+    for i in range(9000):
+        n = int(rng.choice([150, 150, 150, 151, 160, 100, 31, 19, 18, 5]))
+        st = int(rng.integers(0, 24))
+        r = bytearray(g[st:st + n])
+        if rng.random() < 0.15:
+            p = int(rng.integers(0, len(r)))
+            r[p] = rng.choice(list(b"ACGTN"))
+        if i % 50 == 0:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r))
+    _check_place(pmx, oracle, ctx, sars_index, reads)
+    _check_place(pmx, oracle, ctx, sars_index, reads, pmx.TraversalParams(dedupReads=True))
+    fixed = [r for r in reads if len(r) == 150]
+    assert len(fixed) > 4096
+    _check_place(pmx, oracle, ctx, sars_index, fixed)
