@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
-"""Benchmark of the panmap hot path on MI355X: reads placed + aligned per second, host memory to host memory.
+"""Benchmark of the panmap hot path on MI355X: reads placed + aligned per second.
 
-One "step" = one pass of the hot path over one batch of synthetic reads that starts as FASTQ text in (pinned) host
-memory and ends as alignment records + CIGARs in (pinned) host memory (SURVEY 8d "Metric"):
-  H2D of the ASCII bases in chunks on a copy stream (chunk c is packed 2 bit/base and seeded while chunk c+1 is in flight)
-  -> syncmer / k-min-mer seeding + seed histogram -> [N>1: RCCL all-gather + merge of the per-rank histograms]
+One "step" = one pass of the hot path over one batch of synthetic reads whose ASCII bases + offsets are RESIDENT IN HBM when
+the timed region starts, and which ends as alignment records + CIGARs in (pinned) host memory:
+  2-bit packing -> syncmer / k-min-mer seeding + seed histogram -> [N>1: RCCL all-gather + merge of the per-rank histograms]
   -> node scoring down the PanMAN tree -> materialise the placed genome + build its minimizer index
   -> map + align every read pair -> [N>1: RCCL gather of the records AND the CIGAR arena to rank 0]
-  -> D2H of the records + CIGAR arena on a second copy stream.
+  -> D2H of the records + CIGAR arena on a copy stream.
 `--pipelines` (default 2) batches are in flight at a time: each pipeline owns a context (= HIP stream), a placer, an
 aligner, device staging, pinned output buffers and a host thread, and the pipelines take the steps alternately, so the
-H2D of batch n+1 and the D2H of batch n-1 overlap the kernels of batch n.  `value` counts the reads of all K steps over
-the wall time of the whole timed region (barrier + synchronize on both sides, max over ranks).
+latency-bound parts of one batch (bail tail, host round trips, D2H) overlap the kernels of the other.  `value` counts the
+reads of all K steps over the wall time of the whole timed region (barrier + synchronize on both sides, max over ranks).
+`value_host_to_host` is the same step fed from pinned host memory (H2D included, double-buffered): the PCIe-inclusive rate.
 
 Workload (default = BASELINE.json configs[2], the one the metric string is quoted on): 10M x 150 bp synthetic paired
 reads vs the 20,000-genome SARS-CoV-2 PanMAN, `--scaling strong`: the 10M reads are split over the ranks (N=1: all 10M on
@@ -20,14 +20,17 @@ the one GPU, N=8: 1.25M each); the seed index is replicated per GPU.
   --read-len >= 500                           single-end long reads (configs[3]: `--scaling weak --reads-per-gpu 100000 --read-len 10000`)
 
 The ONE JSON line (rank 0) carries, next to the contract keys:
-  value_device_resident  the same step with its inputs already in HBM and its outputs left there (no PCIe), one batch at a time
+  value_host_to_host     the PCIe-inclusive figure (inputs from pinned host memory), never `value`
+  value_device_resident  one batch at a time, outputs left in HBM: the run the per-kernel timings come from
   pcie                   measured H2D / D2H GB/s of this box (pinned, 256 MB) and the PCIe-bound reads/s that follows
   roofline               dominant kernel vs the HBM peak (algorithmic bytes / its HIP-event duration in the resident run)
   roofline_valu          the same kernel against the VALU issue rate (wave-instructions from the PMC pass of profiles/,
                          only when that pass was collected on the sources of this build)
+  roofline_by_stage      every stage (pack, seed, score, compact-seeds, compact-chain, tail) against its bound
   dp                     share of pairs that ran a ksw2 DP, DP cells per step, GCUPS
   real_reads             the repository's real example reads x8 through the same step
   cpu_baseline           the CPU path on the host cores, timed around bare C calls (no Python in the timed spans)
+  checks.oracle          the GPU's results on the CPU baseline's sample against what the CPU path computed (same run)
 
 Launched for N>1 as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -254,7 +257,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads of the CPU baseline sample (0 = sized for ~10-20 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-reads", action="store_true")
-    ap.add_argument("--no-resident", action="store_true", help="skip the device-resident figure (and the roofline objects that need it)")
+    ap.add_argument("--no-resident", action="store_true", help="skip the one-batch-at-a-time figure (and the roofline objects that need it)")
+    ap.add_argument("--no-host-to-host", action="store_true", help="skip the PCIe-inclusive figure (value_host_to_host)")
     args = ap.parse_args()
 
     import torch
@@ -494,21 +498,33 @@ def main():
                     evs.append(ev)
             self.up_ev[slot] = (ev_off, evs)
 
-        def run_h2h(self, seq=None, batch=0, slot=0, prefetch_next=False):
+        def run_h2h(self, seq=None, batch=0, slot=0, prefetch_next=False, resident_inputs=False):
+            """one step.  resident_inputs: the batch's bases + offsets already lie in this staging slot (HBM) when the step
+            starts -- the step of `value`; otherwise they are uploaded from pinned host memory first (value_host_to_host).
+            Either way the records + CIGAR arena end in pinned host memory."""
             tr = [("start", time.perf_counter())] if trace is not None else None
-            if self.up_ev[slot] is None:
-                self.upload(slot)                 # the first batch of a run: nothing was prefetched
-            if prefetch_next:
-                self.upload(slot ^ 1)             # the next batch of this pipeline travels while this one computes
-            ev_off, evs = self.up_ev[slot]
-            self.up_ev[slot] = None
-            if tr is not None:
-                tr.append(("h2d_enqueued", time.perf_counter()))
-            self.placer.reset()
-            self.stream.wait_event(ev_off)
-            # ONE read set over the whole staging buffer (word offsets from the device-resident offsets)
-            whole = self.read_set(("whole", slot), self.d_concat[slot], self.d_off[slot].data_ptr(), n_reads)
-            if n_chunks == 1:
+            if resident_inputs:
+                self.placer.reset()
+                whole = self.read_set(("whole", slot), self.d_concat[slot], self.d_off[slot].data_ptr(), n_reads)
+                whole.pack()
+                self.placer.add_reads(whole, params)
+                ev_off, evs = None, []
+            else:
+                if self.up_ev[slot] is None:
+                    self.upload(slot)                 # the first batch of a run: nothing was prefetched
+                if prefetch_next:
+                    self.upload(slot ^ 1)             # the next batch of this pipeline travels while this one computes
+                ev_off, evs = self.up_ev[slot]
+                self.up_ev[slot] = None
+                if tr is not None:
+                    tr.append(("h2d_enqueued", time.perf_counter()))
+                self.placer.reset()
+                self.stream.wait_event(ev_off)
+                # ONE read set over the whole staging buffer (word offsets from the device-resident offsets)
+                whole = self.read_set(("whole", slot), self.d_concat[slot], self.d_off[slot].data_ptr(), n_reads)
+            if resident_inputs:
+                pass
+            elif n_chunks == 1:
                 self.stream.wait_event(evs[0])
                 whole.pack()
                 self.placer.add_reads(whole, params)
@@ -595,9 +611,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    def run_batches(n_batches):
-        """n_batches steps over the pipelines: pipeline p takes the batches p, p + P, p + 2P, ... and uploads its next batch
-        while it computes the current one; all downloads have landed when this returns"""
+    def run_batches(n_batches, resident_inputs=False):
+        """n_batches steps over the pipelines: pipeline p takes the batches p, p + P, p + 2P, ... (host -> host: and uploads
+        its next batch while it computes the current one); all downloads have landed when this returns"""
         seq = Sequencer(n_batches) if (dist_on and len(pipes) > 1) else None
         errs = []
 
@@ -606,7 +622,7 @@ def main():
                 torch.cuda.set_device(local_rank)
                 mine = list(range(p, n_batches, len(pipes)))
                 for j, b in enumerate(mine):
-                    pipes[p].run_h2h(seq, b, slot=j & 1, prefetch_next=j + 1 < len(mine))
+                    pipes[p].run_h2h(seq, b, slot=j & 1, prefetch_next=(not resident_inputs) and j + 1 < len(mine), resident_inputs=resident_inputs)
                 pipes[p].finish()
             except BaseException as e:   # noqa: BLE001
                 errs.append(e)
@@ -623,13 +639,31 @@ def main():
         if errs:
             raise errs[0]
 
-    # ------------------------------------------------------------------------------------------ value: host -> host
+    # ---------------------------------------------------------------------------- value_host_to_host (PCIe-inclusive)
     for pp in pipes:
         pp.alloc_outputs()
-    run_batches(max(args.warmup, len(pipes)))
+    h2h = None
+    if not args.no_host_to_host:
+        run_batches(max(args.warmup, len(pipes)))
+        sync_all()
+        t0 = time.perf_counter()
+        run_batches(args.steps)
+        sync_all()
+        el_h = max_over_ranks(time.perf_counter() - t0)
+        h2h = dict(value=total_reads * args.steps / el_h, ms_per_step=el_h / args.steps * 1e3)
+    # ------------------------------------------------------------------------------------------------------ value
+    # Inputs resident in HBM when the timed region starts (every staging slot of every pipeline holds the batch: uploaded
+    # here, untimed), the pipelines alternate the batches, records + CIGAR arena come back to pinned host memory.
+    for pp in pipes:
+        for slot in (0, 1):
+            pp.d_off[slot].copy_(h_off, non_blocking=True)
+            pp.d_concat[slot].copy_(h_concat, non_blocking=True)
+            pp.up_ev[slot] = None
+    torch.cuda.synchronize()
+    run_batches(max(args.warmup, len(pipes)), resident_inputs=True)
     sync_all()
     t0 = time.perf_counter()
-    run_batches(args.steps)
+    run_batches(args.steps, resident_inputs=True)
     sync_all()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     if trace is not None and rank == 0:
@@ -810,12 +844,16 @@ def main():
                        "index": "k=19,s=8,l=3,closed syncmers,flank-mask 250",
                        "aligner_preset": ("k=21,w=11,a=2,b=8,q=12,e=2,q2=24,e2=1 (src/mm_align.c:140-166)" if not long_reads else
                                           "map-hifi / map-ont branch of setup_minimap2 (src/mm_align.c:167-180)")},
-            "value_is": "host -> host: pinned FASTQ bases + offsets in host memory -> records + CIGAR arena in pinned host memory, %d batch(es) in flight" % len(pipes),
+            "value_is": "inputs (ASCII bases + offsets of the batch) resident in HBM when the timed region starts -> pack -> seed -> score -> "
+                        "genome -> reference index -> align -> records + CIGAR arena in pinned host memory; %d batch(es) in flight" % len(pipes),
             "equals_device_resident_run": same_as_resident,
+            "value_host_to_host": None if h2h is None else h2h["value"],
+            "host_to_host": None if h2h is None else dict(h2h, note="the same step fed from pinned host memory (H2D of the bases + offsets, double-buffered, "
+                                                                    "overlapping the other batch's kernels): PCIe-inclusive, never `value`"),
             "value_device_resident": None if resident is None else resident["value"],
-            "device_resident": resident,
+            "device_resident": None if resident is None else dict(resident, note="one batch at a time, outputs left in HBM: the run the kernel timings come from"),
             "pcie": pcie,
-            "value_over_min_of_resident_and_pcie_bound": None if resident is None else value / min(resident["value"], pcie["bound_reads_per_s"]),
+            "host_to_host_over_min_of_value_and_pcie_bound": None if h2h is None else h2h["value"] / min(value, pcie["bound_reads_per_s"]),
         }
         if resident is not None:
             align_ms = float(np.mean(kernel_ms["align"]))

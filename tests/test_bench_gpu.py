@@ -23,9 +23,9 @@ def test_bench_single_rank_line():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "roofline_valu", "cpu_baseline", "value_device_resident", "pcie", "dp", "real_reads"):
+              "config", "roofline", "roofline_valu", "cpu_baseline", "value_device_resident", "value_host_to_host", "pcie", "dp", "real_reads"):
         assert k in d, k
-    # `value` is the host -> host figure with two batches in flight; every batch equals the device-resident run bit for bit
+    # `value`: inputs resident in HBM, two batches in flight; every batch equals the one-batch-at-a-time run bit for bit
     assert d["config"]["batches_in_flight"] == 2 and d["equals_device_resident_run"] is True
     assert d["value_device_resident"] > 0 and d["pcie"]["h2d_GBps"] > 0 and d["pcie"]["d2h_GBps"] > 0 and d["pcie"]["bound_reads_per_s"] > 0
     assert d["scaling"] == "strong" and d["config"]["total_reads"] == 400000 and "0.4M×150bp" in d["metric"]
