@@ -702,6 +702,9 @@ PMX_HD bool sketch_distinct(int len, int k, BaseFn& base_at, PushFn& push) {
 #ifndef PMX_C_COUNT
 #define PMX_C_COUNT(k, v) ((void)0)   // tests/hostsim counts work here
 #endif
+#ifndef PMX_C_TRACE
+#define PMX_C_TRACE(i, trips, rescan) ((void)0)   // tests/hostsim: per-anchor trip counts of the chain fill's inner loops
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PMX_C_STAMP(k) do { if (prof_on) { const unsigned long long t_ = (unsigned long long)clock64(); prof[k] += t_ - prof_t; prof_t = t_; } } while (0)
 #else
@@ -944,8 +947,11 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
                 }
             }
             PMX_C_COUNT(0, 1);
+            int trace_trips = 0, trace_rescan = 0;
+            (void)trace_trips; (void)trace_rescan;
             for (int32_t j = j_from; j >= st && !stop; --j) {
                 PMX_C_COUNT(1, 1);
+                ++trace_trips;
                 const uint32_t axj = m.X(j);
                 const uint32_t ayj = m.Y(j);
                 const uint32_t fj = m.G(j);
@@ -1002,6 +1008,7 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
                 for (int32_t j = i - 1; j >= st; --j) {
                     const int32_t fj = (int32_t)(m.G(j) & 0x3ffu);
                     if (mx < fj) { mx = fj; max_ii = j; }
+                    ++trace_rescan;
                 }
                 if (max_ii >= 0) { x_mi = MT::x64(m.X(max_ii)); f_mi = mx; }
             }
@@ -1014,6 +1021,7 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
                 if (tmp != INT32_MIN && max_f < tmp + fm) { max_f = tmp + fm; max_j = max_ii; }
             }
             if (max_f < 0 || max_f > 1023) return PMX_C_BAIL;
+            PMX_C_TRACE(i, trace_trips, trace_rescan);
             m.G(i) = (c_u16)((uint32_t)max_f | (uint32_t)(max_j + 1) << 10);
             if (max_ii < 0 || ((xi - x_mi) <= (uint64_t)(int64_t)max_dist_x && f_mi < max_f)) { max_ii = i; x_mi = xi; f_mi = max_f; }
             if (!(extends && max_j == i - 1)) { r0 = i; jv = i; }

@@ -444,7 +444,12 @@ int pmx_readset_pack(pmx_ctx* ctx, pmx_readset* rs) {
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
     timer_begin(ctx, "pack");
-    if (rs->n_words > 0)
+    // every read has max_len bases (total = n x max_len): the word -> read mapping is a division (k_pack_reads_fixed)
+    const bool fixed = rs->n > 0 && rs->max_len > 0 && rs->total == rs->n * rs->max_len;
+    if (rs->n_words > 0 && fixed)
+        hipLaunchKernelGGL(k_pack_reads_fixed, dim3(grid_for(rs->n_words, 256, 1 << 30)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off0, (int)rs->max_len,
+                           (int64_t)0, rs->n_words, rs->words.p, rs->amb.p);
+    else if (rs->n_words > 0)
         hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(rs->n_words, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p,
                            rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p, (int64_t)0, (int64_t)-1);
     PMX_HIP(hipGetLastError());

@@ -22,6 +22,7 @@ struct SeedParams {
 
 __global__ void k_pack_reads(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int64_t n_reads, int64_t n_words,
                              uint64_t* words, uint32_t* amb, int64_t r0, int64_t r1);
+__global__ void k_pack_reads_fixed(const uint8_t* ascii, int64_t off0, int len, int64_t w_lo, int64_t w_hi, uint64_t* words, uint32_t* amb);
 // read -> its number of 32-base words, plus the checks a wrapped read set needs (stats: [0] max length, [1] 1 if offsets are
 // not monotone or leave [0, total_bytes])
 __global__ void k_read_word_counts(const int64_t* off, int64_t n_reads, int64_t total_bytes, int64_t* nwords, unsigned long long* stats);

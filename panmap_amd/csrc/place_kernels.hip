@@ -104,6 +104,60 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* _
     }
 }
 
+// The same for a read set whose reads all have `len` bases (the host knows: total = n x max): read and word follow from
+// the word index by a division, and the word's 32 bytes arrive as three aligned 16-byte loads -- no offset look-ups, a
+// third of the load instructions: the kernel is a stream and sits near the device-to-device copy rate.
+__global__ void k_pack_reads_fixed(const uint8_t* __restrict__ ascii, int64_t off0, int len, int64_t w_lo, int64_t w_hi,
+                                   uint64_t* __restrict__ words, uint32_t* __restrict__ amb) {
+    const int nw = (len + 31) >> 5;
+    for (int64_t w = w_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w_hi; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = w / nw;
+        const int base0 = (int)(w - r * nw) * 32;
+        const int nb = len - base0 < 32 ? len - base0 : 32;
+        const uintptr_t addr = (uintptr_t)(ascii + off0 + r * (int64_t)len + base0);
+        const uint4* q = reinterpret_cast<const uint4*>(addr & ~(uintptr_t)15);
+        const int sh = (int)(addr & 15u);
+        // (a 16-byte block that holds a needed byte lies inside the buffer's allocation granule; none without one is touched)
+        const int n_q = (sh + nb + 15) >> 4;
+        uint32_t wd[12];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (t < n_q) v = q[t];
+            wd[4 * t] = v.x; wd[4 * t + 1] = v.y; wd[4 * t + 2] = v.z; wd[4 * t + 3] = v.w;
+        }
+        // shift the 48 bytes down by sh bytes: byte j of the word's bases = byte sh + j of wd
+        uint32_t bs[8];
+        const int sw = sh >> 2, sb = (sh & 3) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {   // (sw is 0..3: selects instead of a dynamic register index)
+                lo = sw == c ? wd[t + c] : lo;
+                hi = sw == c ? wd[t + c + 1] : hi;
+            }
+            bs[t] = sb ? (lo >> sb) | (hi << (32 - sb)) : lo;
+        }
+        uint64_t v = 0;
+        uint32_t a = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t ch = (bs[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            const uint32_t c = ch & 0xDFu;
+            const uint32_t tr = ((c >> 1) ^ (c >> 2)) & 3u;
+            const bool acgt = c == 0x41u || c == 0x43u || c == 0x47u || c == 0x54u;
+            const bool is_u = c == 0x55u;
+            const bool in = j < nb;
+            const uint32_t code = (in && (acgt || is_u)) ? tr : 0u, am = (in && !acgt) ? 1u : 0u;
+            v |= (uint64_t)code << (2 * j);
+            a |= am << j;
+        }
+        words[w] = v;
+        amb[w] = a;
+    }
+}
+
 // --------------------------------------------------------------------------------- read dedup (--dedup)
 // The reference sorts the read strings and counts every distinct sequence once (src/placement.cpp:1550-1620).
 // Here: two independent 64-bit hashes of the raw ASCII of each read, a stable radix sort on the 128-bit key,

@@ -17,7 +17,14 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 static long long pmx_c_cnt[4];
 #define PMX_C_DUMP 1
 #define PMX_C_COUNT(k, v) (pmx_c_cnt[k] += (v))
+// per-anchor trip counts of the chain fill (inner loop, max_ii rescan) of the pair being processed: hs_compact_trace
+static int pmx_c_trace_on = 0, pmx_c_trace_n = 0;
+static unsigned char pmx_c_trace_trips[64], pmx_c_trace_rescan[64];
+#define PMX_C_TRACE(i, trips, rescan) do { if (pmx_c_trace_on && (i) < 64) { pmx_c_trace_trips[i] = (unsigned char)((trips) > 255 ? 255 : (trips)); pmx_c_trace_rescan[i] = (unsigned char)((rescan) > 255 ? 255 : (rescan)); pmx_c_trace_n = (i) + 1; } } while (0)
 #include "align/aln_compact.hpp"
+// trace[pair][0] = anchors, [1..64] trips, [65..128] rescans (set the buffer before hs_align_compact; NULL = off)
+static unsigned char* pmx_c_trace_out = nullptr;
+extern "C" void hs_compact_trace(unsigned char* out) { pmx_c_trace_out = out; pmx_c_trace_on = out != nullptr; }
 extern "C" void hs_compact_counts(long long* out, int reset) { for (int i = 0; i < 4; ++i) { out[i] = pmx_c_cnt[i]; if (reset) pmx_c_cnt[i] = 0; } }
 #endif
 
@@ -243,6 +250,13 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
         } else if (pos16) { CMemT<uint16_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res, tab); }
         else { CMemT<uint32_t> m{lds.data()}; rc = compact_map_pair(m, o, ri, rd, amb, res, tab); }
         done[it] = rc == PMX_C_DONE ? 1 : 0;
+        if (pmx_c_trace_out) {
+            unsigned char* t = pmx_c_trace_out + (size_t)it * 129;
+            t[0] = (unsigned char)pmx_c_trace_n;
+            memcpy(t + 1, pmx_c_trace_trips, 64);
+            memcpy(t + 65, pmx_c_trace_rescan, 64);
+        }
+        pmx_c_trace_n = 0;
         for (int s = 0; s < 2; ++s) {
             AlnRecord& rec = recs[2 * it + s];
             memset(&rec, 0, sizeof(rec));

@@ -408,7 +408,7 @@ def test_read_collapse_keeps_the_histogram(pmx, oracle, ctx, sars, sars_index):
     g = sars.genome("node_7618")[5000:5400]
     rng = np.random.default_rng(17)
     reads = []
-    for i in range(9000):
+    for i in range(16000):
         n = int(rng.choice([150, 150, 150, 151, 160, 100, 31, 19, 18, 5]))
         st = int(rng.integers(0, 24))
         r = bytearray(g[st:st + n])
