@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--no-real-reads", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the one-batch-at-a-time figure (and the roofline objects that need it)")
     ap.add_argument("--no-host-to-host", action="store_true", help="skip the PCIe-inclusive figure (value_host_to_host)")
+    ap.add_argument("--gather", choices=["sharded", "rccl"], default="sharded",
+                    help="N>1: how the records reach the host -- sharded: every rank downloads its own part over its own PCIe link into "
+                         "one shared-memory result set (pmx_dist_plan_alignments); rccl: everything to rank 0 over RCCL, then one download")
     args = ap.parse_args()
 
     import torch
@@ -388,8 +391,11 @@ def main():
     # ------------------------------------------------------------------------------------------------------ pipelines
     h_concat = torch.from_numpy(concat).pin_memory()
     h_off = torch.from_numpy(off).pin_memory()
-    n_out = total_reads if (dist_on and rank == 0) else n_reads       # rank 0 receives every rank's records
-    cig_words_cap = max(n_out * 4, int(concat.size) // 4 * (world if dist_on and rank == 0 else 1), 4096)
+    sharded = dist_on and args.gather == "sharded"
+    # (sharded: every rank maps the whole job's result set; rccl: rank 0 receives every rank's records)
+    n_out = total_reads if (dist_on and (rank == 0 or sharded)) else n_reads
+    cig_words_cap = max(n_out * 4, int(concat.size) // 4 * (world if dist_on and (rank == 0 or sharded) else 1), 4096)
+    shm_keep = []
 
     class Pipe:
         """one batch in flight: context (= stream), placer, aligner, device staging, pinned outputs"""
@@ -415,7 +421,32 @@ def main():
             self.nw = 0
 
         def alloc_outputs(self):
-            if self.out_recs is None and (not dist_on or rank == 0):
+            if self.out_recs is not None:
+                return
+            if sharded:
+                # ONE result set for the node: a shared-memory segment made by rank 0, mapped by every rank and registered
+                # with the HIP runtime (page-locked), so that each rank's download of ITS part is an asynchronous copy over
+                # ITS OWN PCIe link.  (collective: every rank calls this for its pipelines in the same order)
+                from multiprocessing import shared_memory
+                nbytes = [n_out * 32, cig_words_cap * 4]
+                names = [None, None]
+                segs = []
+                if rank == 0:
+                    segs = [shared_memory.SharedMemory(create=True, size=max(b, 64)) for b in nbytes]
+                    names = [sg.name for sg in segs]
+                dist.broadcast_object_list(names, src=0)
+                if rank != 0:
+                    segs = [shared_memory.SharedMemory(name=nm) for nm in names]
+                arrs = [np.ndarray((nbytes[0],), np.uint8, buffer=segs[0].buf), np.ndarray((nbytes[1],), np.uint8, buffer=segs[1].buf)]
+                for a_ in arrs:
+                    rc_ = torch.cuda.cudart().cudaHostRegister(a_.ctypes.data, a_.nbytes, 0)
+                    if int(rc_) != 0:
+                        raise RuntimeError("cudaHostRegister of the shared result set failed: %s" % rc_)
+                self.out_recs = torch.from_numpy(arrs[0]).view(n_out, 32)
+                self.out_cig = torch.from_numpy(arrs[1].view(np.int32))
+                shm_keep.append((segs, arrs))
+                dist.barrier()
+            elif not dist_on or rank == 0:
                 self.out_recs = torch.empty((n_out, 32), dtype=torch.uint8).pin_memory()
                 self.out_cig = torch.empty(cig_words_cap, dtype=torch.int32).pin_memory()
 
@@ -463,8 +494,14 @@ def main():
             self.res, self.ref = res, ref
 
         def gather_results(self):
-            """pmx_dist_gather_alignments: fixed-size records + the CIGAR arena of every rank to rank 0, cigar_off rebased"""
-            self.gathered = self.dist.gather_alignments(self.aligner, 0)       # (n_records, n_words) on rank 0
+            """sharded: pmx_dist_plan_alignments -- the ranks agree on every rank's place in the one result set (the download
+            follows, per rank); rccl: pmx_dist_gather_alignments -- fixed-size records + the CIGAR arena of every rank to rank
+            0, cigar_off rebased"""
+            if sharded:
+                rb, wb, tr_, tw_ = self.dist.plan_alignments(self.aligner)
+                self.gathered = (tr_, tw_)
+            else:
+                self.gathered = self.dist.gather_alignments(self.aligner, 0)       # (n_records, n_words) on rank 0
 
         # ---- the step with its inputs resident in HBM and its outputs left there (value_device_resident)
         def run_resident(self, rs):
@@ -552,12 +589,18 @@ def main():
                     seq.run("G", batch, self.gather_results)
                 else:
                     self.gather_results()
-                if rank != 0:
-                    return 0
-                n_rec, nw = self.gathered
-                if nw > self.out_cig.numel() or n_rec > self.out_recs.shape[0]:
-                    raise RuntimeError("pinned output buffers too small")
-                self.dist.fetch_gathered_async(self.out_recs.data_ptr(), self.out_recs.shape[0], self.out_cig.data_ptr(), self.out_cig.numel(), self.copy_out.cuda_stream)
+                if sharded:
+                    n_rec, nw = self.gathered
+                    if nw > self.out_cig.numel() or n_rec > self.out_recs.shape[0]:
+                        raise RuntimeError("shared output buffers too small")
+                    self.dist.fetch_shard_async(self.aligner, self.out_recs.data_ptr(), self.out_cig.data_ptr(), self.copy_out.cuda_stream)
+                else:
+                    if rank != 0:
+                        return 0
+                    n_rec, nw = self.gathered
+                    if nw > self.out_cig.numel() or n_rec > self.out_recs.shape[0]:
+                        raise RuntimeError("pinned output buffers too small")
+                    self.dist.fetch_gathered_async(self.out_recs.data_ptr(), self.out_recs.shape[0], self.out_cig.data_ptr(), self.out_cig.numel(), self.copy_out.cuda_stream)
             else:
                 nw = al.cigar_words()
                 if nw > self.out_cig.numel():
@@ -1021,6 +1064,26 @@ def main():
         out = None
     for pp in pipes:
         pp.close()
+    if shm_keep:
+        torch.cuda.synchronize()
+        for pp in pipes:
+            pp.out_recs = pp.out_cig = None
+        h2h_recs = None
+        if dist_on:
+            dist.barrier()
+        for segs, arrs in shm_keep:
+            for a_ in arrs:
+                torch.cuda.cudart().cudaHostUnregister(a_.ctypes.data)
+        for segs, arrs in shm_keep:
+            del arrs
+            for sg in segs:
+                try:
+                    sg.close()
+                except BufferError:
+                    pass          # (a view is still alive somewhere: the mapping goes with the process)
+                if rank == 0:
+                    sg.unlink()
+        shm_keep.clear()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -423,6 +423,14 @@ int pmx_dist_merge_histograms(pmx_dist *d, pmx_place *pl);
  * the root the records stand in rank order with cigar_off rebased onto the arenas laid back to back.  n_records / n_words:
  * totals on the root, 0 elsewhere. */
 int pmx_dist_gather_alignments(pmx_dist *d, pmx_aligner *al, int root, int64_t *n_records, int64_t *n_words);
+/* One-node form of step 2 (no traffic between the GPUs, no funnel through the root's PCIe link): the ranks agree on the
+ * place of every rank's records / CIGAR words in ONE result set (records in rank order, arenas back to back; one small
+ * all-gather of the counts) and each rank downloads its own part -- cigar_off rebased onto the merged arena on the device --
+ * to that place in host buffers all ranks map (shared memory; pinned / registered for the copies to be asynchronous).
+ * pmx_dist_rank_counts reports the sizes the plan exchanged. */
+int pmx_dist_plan_alignments(pmx_dist *d, pmx_aligner *al, int64_t *record_base, int64_t *word_base, int64_t *total_records,
+                             int64_t *total_words);
+int pmx_dist_fetch_shard_async(pmx_dist *d, pmx_aligner *al, pmx_aln_record *records_all, uint32_t *cigars_all, void *stream);
 const void *pmx_dist_gathered_records(const pmx_dist *d);   /* device pointers of the last gather (root) */
 const void *pmx_dist_gathered_cigars(const pmx_dist *d);
 int pmx_dist_rank_counts(const pmx_dist *d, int64_t *records_per_rank, int64_t *words_per_rank);   /* world entries each */

@@ -208,6 +208,8 @@ SIGNATURES = {
     "pmx_place_dedup_drop_seen": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64]),
     "pmx_place_dedup_local_count": (_i64, [_vp, _vp, _vp]),
     "pmx_dist_gather_alignments": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "pmx_dist_plan_alignments": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmx_dist_fetch_shard_async": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "pmx_dist_gathered_records": (_vp, [_vp]),
     "pmx_dist_gathered_cigars": (_vp, [_vp]),
     "pmx_dist_rank_counts": (_i32, [_vp, _vp, _vp]),

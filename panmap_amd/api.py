@@ -852,6 +852,17 @@ class Dist:
         check(lib.pmx_dist_gather_alignments(self._h, aligner._h, int(root), C.byref(nr), C.byref(nw)), "pmx_dist_gather_alignments")
         return int(nr.value), int(nw.value)
 
+    def plan_alignments(self, aligner: "Aligner"):
+        """one-node form of the gather: -> (record_base, word_base, total_records, total_words) of this rank's part in the one
+        result set of all ranks (pmx_dist_plan_alignments); follow with fetch_shard_async"""
+        v = [C.c_int64(0) for _ in range(4)]
+        check(lib.pmx_dist_plan_alignments(self._h, aligner._h, *[C.byref(x) for x in v]), "pmx_dist_plan_alignments")
+        return tuple(int(x.value) for x in v)
+
+    def fetch_shard_async(self, aligner: "Aligner", host_records_all_ptr: int, host_cigars_all_ptr: int, stream: int = 0):
+        """download this rank's records (cigar_off rebased) and CIGAR words to their place in the whole result set's host buffers"""
+        check(lib.pmx_dist_fetch_shard_async(self._h, aligner._h, host_records_all_ptr, host_cigars_all_ptr, stream or None), "pmx_dist_fetch_shard_async")
+
     def gathered_device_pointers(self):
         return int(lib.pmx_dist_gathered_records(self._h) or 0), int(lib.pmx_dist_gathered_cigars(self._h) or 0)
 

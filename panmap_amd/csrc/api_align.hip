@@ -307,7 +307,14 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     al->cigar_cap = cigar_cap;
     al->cigars.ensure(al->cigar_cap);
     PMX_HIP(hipMemsetAsync(al->cigar_used.p, 0, sizeof(unsigned long long), ctx->stream));
-    if (n_items <= 0) return PMX_OK;
+    // (the counters are read back after every call, an empty read set's too: a rank whose shard holds no read)
+    al->stats.ensure(4);
+    PMX_HIP(hipMemsetAsync(al->stats.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    if (n_items <= 0) {
+        al->last_dp_slots = 0; al->last_compact = 0; al->last_tpp_retry = 0; al->last_retry = 0; al->last_dp_rounds = 0; al->last_dp_requests = 0;
+        memset(&al->last_stats, 0, sizeof(al->last_stats));
+        return PMX_OK;
+    }
 
     // Tier 1: compact all-LDS layout (typical short-read pairs); tier 2: general capacities for the pairs
     // that overflowed tier 1 (and for everything when the compact layout does not fit LDS).

@@ -147,7 +147,7 @@ struct HostDirTransport : Transport {
         const auto t0 = std::chrono::steady_clock::now();
         struct stat sb;
         while (stat(fn.c_str(), &sb) != 0) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 300.0) throw std::runtime_error("host transport: rank " + std::to_string(r) + " did not arrive");
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) throw std::runtime_error("host transport: rank " + std::to_string(r) + " did not arrive");
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
         std::vector<char> buf((size_t)sb.st_size);
@@ -205,7 +205,9 @@ struct pmx_dist {
     DevBuf<uint64_t> hist_mine, hist_all;   // [2][max] per rank: hash plane, count plane
     DevBuf<pmx_aln_record> g_records;       // on the root: every rank's records, rank order
     DevBuf<uint32_t> g_cigars;              // ... and arenas back to back
+    DevBuf<pmx_aln_record> s_records;       // pmx_dist_plan_alignments: this rank's records with cigar_off rebased
     int64_t g_n_records = 0, g_n_words = 0;
+    int64_t shard_records = 0, shard_words = 0, shard_record_base = 0, shard_word_base = 0;   // pmx_dist_plan_alignments
     std::vector<int64_t> rank_records, rank_words;
     hipEvent_t ev_gathered = nullptr, ev_fetched = nullptr;   // pmx_dist_fetch_gathered_async
     bool fetch_pending = false;
@@ -442,6 +444,82 @@ int pmx_dist_gather_alignments(pmx_dist* d, pmx_aligner* al, int root, int64_t* 
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     if (n_records) *n_records = d->g_n_records;
     if (n_words) *n_words = d->g_n_words;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+// Exchange step 2, one-node form: nothing crosses between the GPUs.  The ranks agree (one small all-gather of their record
+// and CIGAR-word counts) on where every rank's part lies in ONE result set -- records in rank order, arenas back to back --
+// each rank copies its records aside with cigar_off rebased onto the merged arena, and downloads ITS OWN part over ITS OWN
+// PCIe link straight to its place in host buffers that all the ranks of the node map (a shared-memory segment).  The
+// gather above sends everything through the root's device and the root's link: 360 MB per 10M reads at ~57 GB/s = 6.3 ms,
+// a ceiling of ~1.6 G reads/s whatever the number of GPUs.
+int pmx_dist_plan_alignments(pmx_dist* d, pmx_aligner* al, int64_t* record_base, int64_t* word_base, int64_t* total_records, int64_t* total_words) {
+    if (!d || !al) return PMX_ERR_ARG;
+    PMX_TRY
+    pmx_ctx* ctx = d->ctx;
+    PMX_HIP(hipSetDevice(ctx->device));
+    const int world = d->tp->world, rank = d->tp->rank;
+    if (d->fetch_pending) {   // a download of the previous plan on another stream still reads the staging copy
+        PMX_HIP(hipStreamWaitEvent(ctx->stream, d->ev_fetched, 0));
+        d->fetch_pending = false;
+    }
+    const int64_t mine[2] = {pmx_align_num_records(al), pmx_align_cigar_words(ctx, al)};
+    if (mine[1] < 0) return (int)mine[1];
+    const std::vector<int64_t> all = d->exchange_counts(mine, 2);
+    d->rank_records.assign((size_t)world, 0);
+    d->rank_words.assign((size_t)world, 0);
+    int64_t tot_r = 0, tot_w = 0, my_r = 0, my_w = 0;
+    for (int r = 0; r < world; ++r) {
+        d->rank_records[r] = all[2 * r];
+        d->rank_words[r] = all[2 * r + 1];
+        if (r == rank) { my_r = tot_r; my_w = tot_w; }
+        tot_r += all[2 * r];
+        tot_w += all[2 * r + 1];
+    }
+    if (tot_w >= (int64_t)1 << 32) return fail(PMX_ERR_CAPACITY, "merged CIGAR arena exceeds the 32-bit cigar_off of pmx_aln_record");
+    d->shard_records = mine[0]; d->shard_words = mine[1]; d->shard_record_base = my_r; d->shard_word_base = my_w;
+    d->s_records.ensure((size_t)std::max<int64_t>(mine[0], 1));
+    if (mine[0] > 0) {
+        PMX_HIP(hipMemcpyAsync(d->s_records.p, pmx_align_device_records(al), sizeof(pmx_aln_record) * (size_t)mine[0], hipMemcpyDeviceToDevice, ctx->stream));
+        if (my_w > 0)
+            hipLaunchKernelGGL(k_rebase_cigars, dim3(grid_for(mine[0], 256, ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<pmx::aln::AlnRecord*>(d->s_records.p), mine[0], (uint32_t)my_w);
+        PMX_HIP(hipGetLastError());
+    }
+    if (record_base) *record_base = my_r;
+    if (word_base) *word_base = my_w;
+    if (total_records) *total_records = tot_r;
+    if (total_words) *total_words = tot_w;
+    return PMX_OK;
+    PMX_CATCH
+}
+
+// ... and the download of this rank's part to records_all + record_base / cigars_all + word_base (the WHOLE result set's
+// buffers, e.g. a shared-memory mapping; pinned or registered memory for the copies to be asynchronous) on `stream`
+// (NULL: the context's), without waiting for it.  The next plan waits for it before it reuses the staging copy.
+int pmx_dist_fetch_shard_async(pmx_dist* d, pmx_aligner* al, pmx_aln_record* records_all, uint32_t* cigars_all, void* stream) {
+    if (!d || !al || (d->shard_records > 0 && !records_all) || (d->shard_words > 0 && !cigars_all)) return PMX_ERR_ARG;
+    PMX_TRY
+    pmx_ctx* ctx = d->ctx;
+    PMX_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (!d->ev_gathered) {
+        PMX_HIP(hipEventCreateWithFlags(&d->ev_gathered, hipEventDisableTiming));
+        PMX_HIP(hipEventCreateWithFlags(&d->ev_fetched, hipEventDisableTiming));
+    }
+    if (st != ctx->stream) {
+        PMX_HIP(hipEventRecord(d->ev_gathered, ctx->stream));
+        PMX_HIP(hipStreamWaitEvent(st, d->ev_gathered, 0));
+    }
+    if (d->shard_records > 0)
+        PMX_HIP(hipMemcpyAsync(records_all + d->shard_record_base, d->s_records.p, sizeof(pmx_aln_record) * (size_t)d->shard_records, hipMemcpyDeviceToHost, st));
+    if (d->shard_words > 0)
+        PMX_HIP(hipMemcpyAsync(cigars_all + d->shard_word_base, pmx_align_device_cigars(al), sizeof(uint32_t) * (size_t)d->shard_words, hipMemcpyDeviceToHost, st));
+    if (st != ctx->stream) {
+        PMX_HIP(hipEventRecord(d->ev_fetched, st));
+        d->fetch_pending = true;
+    }
     return PMX_OK;
     PMX_CATCH
 }

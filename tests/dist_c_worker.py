@@ -65,7 +65,20 @@ def main():
         uid = pmx.Dist.unique_id()
     dist = pmx.Dist(ctx, uid, rank, world)
     dist.barrier()
+    # PMX_SHARD_MODE (two ranks): how the reads are cut -- the size exchange, the padded histogram planes and the rebase of
+    # cigar_off at their edges: "unequal" 70 / 30, "empty" rank 1 holds no read at all, "nocigar" rank 1 holds only reads
+    # that map nowhere (records, but not one CIGAR word)
+    mode = os.environ.get("PMX_SHARD_MODE", "equal")
     lo, hi = shard_bounds(len(reads), world, rank)
+    if mode != "equal":
+        assert world == 2
+        if mode == "nocigar":
+            junk = [bytes(rng.choice(list(b"ACGT"), 150).astype(np.uint8)) for _ in range(6000)]
+            reads = reads[:30000] + junk
+            cut = 30000
+        else:
+            cut = {"unequal": 2 * ((len(reads) // 2) * 7 // 10), "empty": len(reads)}[mode]
+        lo, hi = (0, cut) if rank == 0 else (cut, len(reads))
     rs = pmx.ReadSet(ctx, reads[lo:hi])
     placer = pmx.Placer(ctx, index)
     placer.reset()
@@ -77,7 +90,25 @@ def main():
     al = pmx.Aligner(ctx, ref, 150)
     al.align_readset(rs, paired=True, revcomp_mate2=True)
     n_rec, n_words = dist.gather_alignments(al, 0)
-    out = {"rank": rank, "placed": pm.node_id(int(res.best_index[4]))}
+    out = {"rank": rank, "placed": pm.node_id(int(res.best_index[4])), "mode": mode, "shard": [lo, hi]}
+    # the one-node form of the same step: every rank downloads ITS part to its place in buffers all ranks map (here: files
+    # in the transport's directory, mapped shared) -- no record crosses between the ranks
+    sh_rec = sh_cig = None
+    if world > 1 and host_dir:
+        rb, wb, tot_r, tot_w = dist.plan_alignments(al)
+        maps = []
+        for name, nbytes in (("shard_records.bin", max(tot_r, 1) * 32), ("shard_cigars.bin", max(tot_w, 1) * 4)):
+            fd = os.open(os.path.join(host_dir, name), os.O_RDWR | os.O_CREAT, 0o600)
+            os.ftruncate(fd, nbytes)       # (both ranks: same size)
+            maps.append(np.memmap(os.path.join(host_dir, name), dtype=np.uint8, mode="r+", shape=(nbytes,)))
+            os.close(fd)
+        dist.fetch_shard_async(al, maps[0].ctypes.data, maps[1].ctypes.data)
+        ctx.synchronize()
+        maps[0].flush(); maps[1].flush()
+        dist.barrier()
+        out["plan"] = [rb, wb, tot_r, tot_w]
+        sh_rec = np.frombuffer(maps[0], dtype=pmx.REC_DTYPE)[:tot_r]
+        sh_cig = np.frombuffer(maps[1], dtype=np.uint32)[:tot_w]
     if rank == 0:
         m, arena = dist.fetch_gathered(n_rec, n_words)
         per_rank, words_per_rank = dist.rank_counts()
@@ -111,6 +142,8 @@ def main():
                 same_cigars = False
                 break
             multi += k > 1
+        if sh_rec is not None:   # the sharded download holds the very bytes of the gathered set
+            out["sharded_equals_gathered"] = bool(len(sh_rec) == len(m) and sh_rec.tobytes() == m.tobytes() and np.array_equal(sh_cig, arena))
         out.update(n_records=int(len(m)), n_expected=int(len(w)), fields_equal=bool(ok_fields), cigars_equal=bool(same_cigars),
                    multi_op_cigars=int(multi), per_rank=[int(x) for x in per_rank], words_per_rank=[int(x) for x in words_per_rank],
                    hist_equal=bool(np.array_equal(hh, wh) and np.array_equal(hc, wcnt)), async_same=async_same,

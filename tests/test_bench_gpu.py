@@ -74,11 +74,13 @@ def test_bench_exchange_path_on_rccl_one_rank():
 
 
 def test_bench_strong_scaling_two_ranks():
-    """--scaling strong: the job's reads are split over the ranks (configs[2] shape, small here)"""
+    """--scaling strong: the job's reads are split over the ranks (configs[2] shape, small here); records through the gather
+    to rank 0 (--gather rccl: pmx_dist_gather_alignments) -- the other two-rank tests take the default, every rank downloading
+    its own part into the node's shared result set (pmx_dist_plan_alignments + pmx_dist_fetch_shard_async)"""
     env = dict(os.environ, PMX_BENCH_TEST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "strong",
-                        "--total-reads", "200000", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+                        "--total-reads", "200000", "--no-cpu-baseline", "--gather", "rccl"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     d = _line(r.stdout)
     assert d["scaling"] == "strong" and d["config"]["total_reads"] == 200000 and d["config"]["reads_per_gpu"] == 100000

@@ -19,10 +19,13 @@ def _run_ranks(world, env_extra):
         env = dict(os.environ, PMX_RANK=str(r), PMX_WORLD=str(world), **env_extra)
         procs.append(subprocess.Popen([sys.executable, os.path.join("tests", "dist_c_worker.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
-    outs = []
+    outs, done = [], []
     for p in procs:
         so, se = p.communicate(timeout=900)
-        assert p.returncode == 0, (so[-1000:], se[-3000:])
+        done.append((p.returncode, so, se))
+    # (every rank's end is reported: the rank that failed first is usually not the one whose wait timed out)
+    assert all(rc == 0 for rc, _, _ in done), [(rc, so[-500:], se[-1500:]) for rc, so, se in done]
+    for rc, so, se in done:
         outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
     return sorted(outs, key=lambda d: d["rank"])
 
@@ -42,6 +45,28 @@ def test_two_ranks_through_the_c_abi_equal_a_single_rank(tmp_path):
     # know that every peer has read its last file; the owner of the directory removes them): one per rank, same round
     left = sorted(f for f in os.listdir(tmp_path) if f.startswith("x"))
     assert len(left) == 2 and left[0].rsplit(".", 1)[0] == left[1].rsplit(".", 1)[0], left
+    # the one-node form (pmx_dist_plan_alignments + pmx_dist_fetch_shard_async): every rank downloads its own part to its
+    # place in buffers both ranks map; the result is byte for byte the gathered set
+    assert d0["sharded_equals_gathered"] and d0["plan"][:2] == [0, 0] and d1["plan"][0] == 20000 and d1["plan"][1] == d0["words_per_rank"][0]
+
+
+@pytest.mark.parametrize("mode", ["unequal", "empty", "nocigar"])
+def test_two_ranks_at_the_edges_of_the_size_exchange(tmp_path, mode):
+    """pmx_dist_* with ranks of UNEQUAL shard sizes, an EMPTY shard and a rank whose reads map nowhere (records without one
+    CIGAR word): the count exchange, the max-padded histogram planes, the exact-size point-to-point gather and the rebase
+    of cigar_off (api_dist.hip) at their edges -- merged histogram, placement, every record and every CIGAR still equal the
+    single-rank run, through the gather and through the sharded download"""
+    d0, d1 = _run_ranks(2, {"PMX_DIST_HOST_DIR": str(tmp_path), "PMX_SHARD_MODE": mode})
+    assert d0["placed"] == d1["placed"] == "node_7618" and d0["mode"] == mode
+    assert d0["n_records"] == d0["n_expected"] and d0["hist_equal"] and d0["scores_equal"] and d0["fields_equal"] and d0["cigars_equal"] and d0["flagged"] == 0
+    assert d0["sharded_equals_gathered"]
+    n0, n1 = d0["per_rank"]
+    if mode == "unequal":
+        assert n0 == 28000 and n1 == 12000 and d0["words_per_rank"][1] > 0 and d1["plan"][0] == 28000
+    elif mode == "empty":
+        assert n0 == 40000 and n1 == 0 and d0["words_per_rank"][1] == 0 and d1["shard"] == [40000, 40000]
+    else:
+        assert n0 == 30000 and n1 == 6000 and d0["words_per_rank"][1] == 0     # rank 1: records, no CIGAR
 
 
 @pytest.mark.parametrize("with_torch", [True, False])
