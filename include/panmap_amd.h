@@ -484,6 +484,13 @@ int pmx_meta_em_info(const pmx_meta *m, int32_t *rounds, int32_t *iterations, do
 int pmx_meta_set_dust(pmx_meta *m, double threshold);
 double pmx_read_dust(const char *seq, int64_t len, int32_t window);
 
+/* The library's tuning / testing / diagnostic switches are environment variables PMX_<NAME>, all of them listed with their
+ * class and meaning in ONE table (csrc/device/pmx_options.hpp).  The environment is read once, at the first use;
+ * pmx_options_reload reads it again (a test that changes a switch inside one process), pmx_options_describe writes the
+ * table with the current values ("PMX_NAME [class] meaning (= value)" lines) and returns the bytes it needs. */
+void pmx_options_reload(void);
+int64_t pmx_options_describe(char *buf, int64_t cap);
+
 /* kernel timing: average duration (ms) of the dominant kernel of the last call, measured with HIP
    events on the context stream; name selects a stage ("pack", "seed", "score", "align") or a kernel of the align stage
    ("align_cseeds" = k_compact_seeds*, "align_dom" = the mapping kernel over every pair); < 0: no such span in the last call */

@@ -9,6 +9,7 @@ from .api import (METRICS, Aligner, align_reads_direct, write_bam, records_to_re
                   read_fastx, reverse_complement, FastxReads, read_fastq_paired_native, read_fastx_native)
 from .meta import Meta, format_abundance, read_dust  # noqa: F401
 from ._lib import MetaParams  # noqa: F401
+from .api import reload_options, describe_options  # noqa: F401
 from .api import Dist, score_reads_vs_reference, last_error, refine_top_candidates, refine_candidates, refine_placement, format_refined_tsv  # noqa: F401
 from ._lib import RefineParams  # noqa: F401
 from .synth import simulate_paired_reads, simulate_long_reads  # noqa: F401

@@ -178,6 +178,8 @@ SIGNATURES = {
     "pmx_align_device_records": (_vp, [_vp]),
     "pmx_align_device_cigars": (_vp, [_vp]),
     "pmx_last_kernel_ms": (C.c_double, [_vp, _cp]),
+    "pmx_options_reload": (None, []),
+    "pmx_options_describe": (_i64, [_vp, _i64]),
     "pmx_meta_create": (_i32, [_vp, _vp, _vp, _vp]),
     "pmx_meta_free": (None, [_vp, _vp]),
     "pmx_meta_set_reads": (_i32, [_vp, _vp, _vp, _vp, _i64]),

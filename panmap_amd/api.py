@@ -205,6 +205,19 @@ def read_fastx(path: str):
 _RC = bytes.maketrans(b"ACGT", b"TGCA")
 
 
+def reload_options():
+    """read the PMX_* switches from the environment again (the library reads them once, at its first use)"""
+    lib.pmx_options_reload()
+
+
+def describe_options() -> str:
+    """the library's one table of switches: name, class, meaning, current value"""
+    n = int(lib.pmx_options_describe(None, 0))
+    buf = C.create_string_buffer(n)
+    lib.pmx_options_describe(buf, n)
+    return buf.value.decode()
+
+
 def reverse_complement(seq: bytes) -> bytes:
     """seeding::reverseComplement (src/seeding.cpp:271-284): only upper-case ACGT are complemented."""
     return seq.translate(_RC)[::-1]

@@ -185,7 +185,7 @@ int pmx_aligner_set_reference(pmx_ctx* ctx, pmx_aligner* al, const char* referen
     // trip.  PMX_ALIGN_HOST_INDEX=1, an even k, a reference of 2 Mb or more, or a repeat-rich reference whose mid_occ the
     // counters cannot decide: the host build.
     bool on_device = false;
-    if (!getenv("PMX_ALIGN_HOST_INDEX") && ref_index_device_supported(al->opt, ref_len))
+    if (!pmx::opt_str(pmx::O_ALIGN_HOST_INDEX) && ref_index_device_supported(al->opt, ref_len))
         on_device = build_ref_index_device(ctx->stream, reference, ref_len, al->opt, al->dev_index);
     if (on_device) {
         const bool new_tables = finish_ref_opt(al->opt, max_score, al->host) || !al->logf_uploaded;
@@ -320,9 +320,9 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     // that overflowed tier 1 (and for everything when the compact layout does not fit LDS).
     int waves_per_simd = 4;
     size_t lds_budget = 24 * 1024;
-    if (const char* e = getenv("PMX_ALIGN_LDS_KB")) lds_budget = (size_t)atoi(e) * 1024;
-    if (const char* e = getenv("PMX_ALIGN_WAVES")) waves_per_simd = atoi(e);
-    const bool use_tier1 = !getenv("PMX_ALIGN_NO_TIER1");
+    if (const char* e = pmx::opt_str(pmx::O_ALIGN_LDS_KB)) lds_budget = (size_t)atoi(e) * 1024;
+    if (const char* e = pmx::opt_str(pmx::O_ALIGN_WAVES)) waves_per_simd = atoi(e);
+    const bool use_tier1 = !pmx::opt_str(pmx::O_ALIGN_NO_TIER1);
     auto kern = waves_per_simd >= 4 ? k_align_reads_w4 : k_align_reads;
     const int n_segs = paired ? 2 : 1;
 
@@ -350,7 +350,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     memset(&al->last_stats, 0, sizeof(al->last_stats));
     al->last_stats.n_items = n_items;
     A.prof = nullptr;
-    if (getenv("PMX_ALIGN_PROF")) {
+    if (pmx::opt_str(pmx::O_ALIGN_PROF)) {
         al->prof.ensure(32);
         PMX_HIP(hipMemsetAsync(al->prof.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
         A.prof = al->prof.p;
@@ -360,7 +360,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     auto launch = [&](decltype(kern) kfn, const Layout& L, int64_t n_work, const uint32_t* worklist, uint32_t* retry_list, DevBuf<uint8_t>& slab,
                       int64_t max_grid = 0) {
         const size_t lds_bytes = PMX_ALIGN_WORK_BYTES + L.fast_bytes + 16;
-        if (getenv("PMX_ALIGN_VERBOSE")) fprintf(stderr, "[pmx align] wave-tier launch: %lld items, %zu LDS bytes per wave, %zu HBM slab bytes per wave\n", (long long)n_work, lds_bytes, (size_t)L.slow_bytes);
+        if (pmx::opt_str(pmx::O_ALIGN_VERBOSE)) fprintf(stderr, "[pmx align] wave-tier launch: %lld items, %zu LDS bytes per wave, %zu HBM slab bytes per wave\n", (long long)n_work, lds_bytes, (size_t)L.slow_bytes);
         if (lds_bytes > 160 * 1024) throw std::runtime_error("reads too long for the LDS work arena");
         if (lds_bytes > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         int waves_per_cu = (int)std::min<size_t>((size_t)(waves_per_simd >= 4 ? 16 : 8), (size_t)(160 * 1024) / lds_bytes);
@@ -368,7 +368,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         int64_t grid = (int64_t)ctx->n_cu * waves_per_cu;
         // a few thousand pairs: one workgroup each, so that the hardware hands a free slot the next pair (with a resident
         // grid and a strided loop a wave that drew two slow pairs decides the launch)
-        if (n_work <= 16384 && !getenv("PMX_ALIGN_RESIDENT_GRID")) grid = n_work;
+        if (n_work <= 16384 && !pmx::opt_str(pmx::O_ALIGN_RESIDENT_GRID)) grid = n_work;
         if (grid > n_work) grid = n_work;
         if (max_grid > 0 && grid > max_grid) grid = max_grid;
         A.layout = L;
@@ -384,7 +384,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             }
             const size_t total_b = al->dev_total_mem;
             size_t budget = std::max<size_t>(std::min<size_t>((size_t)96 << 30, total_b / 3), slab.n * sizeof(uint8_t));
-            if (const char* e = getenv("PMX_ALIGN_SLAB_MB")) budget = (size_t)std::max<long long>(atoll(e), 1) << 20;   // tests: force a small grid
+            if (const char* e = pmx::opt_str(pmx::O_ALIGN_SLAB_MB)) budget = (size_t)std::max<long long>(atoll(e), 1) << 20;   // tests: force a small grid
             const int64_t fit = (int64_t)(budget / std::max<size_t>(A.slow_stride, 1));
             if (grid > fit) grid = std::max<int64_t>(fit, 1);
         }
@@ -403,13 +403,13 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     // test hook: cap the CIGAR operations per region in EVERY tier, so that gapped alignments overflow and the
     // boundary's handling of invalid records can be exercised (tests/test_align_gpu.py)
     int test_max_cigar = 0;
-    if (const char* e = getenv("PMX_ALIGN_TEST_MAX_CIGAR")) test_max_cigar = atoi(e);
+    if (const char* e = pmx::opt_str(pmx::O_ALIGN_TEST_MAX_CIGAR)) test_max_cigar = atoi(e);
     auto hooked = [&](Layout L) { if (test_max_cigar > 0 && L.caps.max_cigar > test_max_cigar) L.caps.max_cigar = test_max_cigar; return L; };
     const Layout general = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget));
     const Layout compact = hooked(plan_layout_compact((int)rs->max_len, n_segs, al->opt));
     const bool tier1_fits = use_tier1 && al->opt.is_sr_like && PMX_ALIGN_WORK_BYTES + compact.fast_bytes + 16 <= 40 * 1024;
-    const bool use_tier0 = tier1_fits && !getenv("PMX_ALIGN_NO_TPP");
-    const bool use_dp_service = !getenv("PMX_ALIGN_NO_DP_SERVICE");
+    const bool use_tier0 = tier1_fits && !pmx::opt_str(pmx::O_ALIGN_NO_TPP);
+    const bool use_dp_service = !pmx::opt_str(pmx::O_ALIGN_NO_DP_SERVICE);
     // reads both counters; [1] is reset for the next round, [0] only when asked
     auto read_counts = [&](int64_t& n_next_tier, int64_t& n_dp, bool reset_next_tier) {
         unsigned long long h[2] = {0, 0};
@@ -422,8 +422,8 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr; A.dp_slot_pairs = nullptr;
     A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
     A.dp_left = nullptr; A.dp_class = 0; A.dp_small_qlen = 0; A.dp_small_tlen = 0; A.dp_small_tb = 0; A.tpp_ring_w = 0;
-    A.sk_no_lane_ring = getenv("PMX_ALIGN_NO_LANE_RING") ? 1 : 0;
-    A.no_rows_dp = getenv("PMX_ALIGN_NO_ROWS_DP") ? 1 : 0;
+    A.sk_no_lane_ring = pmx::opt_str(pmx::O_ALIGN_NO_LANE_RING) ? 1 : 0;
+    A.no_rows_dp = pmx::opt_str(pmx::O_ALIGN_NO_ROWS_DP) ? 1 : 0;
     A.mv_handover = nullptr; A.mv_stride = 0; A.mv_slots = 0; A.mv_epoch = ++al->mv_epoch;
     A.pair_perm = nullptr;
     timer_begin(ctx, "align");
@@ -437,11 +437,11 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         al->last_dp_rounds = 0;
         if (use_tier0) {   // tier 0: thread per pair + DP service rounds
             int tpp_waves = 16;   // 4 per SIMD: what k_align_reads_tpp's register allocation targets (PMX_TPP_OCC)
-            if (const char* e = getenv("PMX_ALIGN_TPP_WAVES")) tpp_waves = atoi(e);
+            if (const char* e = pmx::opt_str(pmx::O_ALIGN_TPP_WAVES)) tpp_waves = atoi(e);
             const int64_t max_grid = std::min<int64_t>((int64_t)ctx->n_cu * tpp_waves, (n_items + 63) / 64);
             // thread-per-pair layout: interleaved arena per wave + a small contiguous struct region per thread
             size_t tpp_tb = 0;   // in-lane DPs measured slower than request + replay (divergence): off
-            if (const char* e = getenv("PMX_ALIGN_TPP_TB")) tpp_tb = (size_t)atoll(e);
+            if (const char* e = pmx::opt_str(pmx::O_ALIGN_TPP_TB)) tpp_tb = (size_t)atoll(e);
             const Layout tpp_layout = hooked(plan_layout_tpp((int)rs->max_len, n_segs, al->opt, tpp_tb));
             const size_t tpp_wave_stride = tpp_arena_bytes(tpp_layout) * 64;
             const size_t tpp_raw_stride = (tpp_layout.raw_bytes + 255) & ~(size_t)255;
@@ -460,18 +460,18 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             // (round 3, 10M reads: 13.9k first-round requests through the service + one replay: 34.4 ms for the stage, through
             // the wave tier 35.9)
             int64_t small_rounds = 8192;
-            if (const char* e = getenv("PMX_ALIGN_TPP_MIN")) small_rounds = atoll(e);
+            if (const char* e = pmx::opt_str(pmx::O_ALIGN_TPP_MIN)) small_rounds = atoll(e);
             const int64_t dp_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dp_lds);
             const int small_qlen = 192, small_tlen = 192;   // ksw_extd2_reg<3>: up to three target columns per lane
             const Layout dps_layout = plan_layout_dp((int)rs->max_len, n_segs, al->opt, small_qlen, small_tlen);
             const size_t dps_lds = PMX_ALIGN_WORK_BYTES + dps_layout.fast_bytes + 16;
             const int64_t dps_max_grid = (int64_t)ctx->n_cu * (int64_t)std::min<size_t>(16, (size_t)(160 * 1024) / dps_lds);
             const size_t dps_stride = (dps_layout.slow_bytes + 255) & ~(size_t)255;
-            const bool dp_two_class = !getenv("PMX_ALIGN_DP_ONE_CLASS");
+            const bool dp_two_class = !pmx::opt_str(pmx::O_ALIGN_DP_ONE_CLASS);
             DpgArgs DG;
-            bool dpg_ok = dpg_setup(al->opt, DG) && !getenv("PMX_ALIGN_NO_DP_GROUP");
+            bool dpg_ok = dpg_setup(al->opt, DG) && !pmx::opt_str(pmx::O_ALIGN_NO_DP_GROUP);
             int dpg_waves = 8;
-            if (const char* e = getenv("PMX_ALIGN_DPG_WAVES")) dpg_waves = std::max(1, atoi(e));
+            if (const char* e = pmx::opt_str(pmx::O_ALIGN_DPG_WAVES)) dpg_waves = std::max(1, atoi(e));
             if (use_dp_service) {
                 al->dp_req.ensure((size_t)n_items * PMX_DP_REQ_PER_PASS * sizeof(DpReq));
                 al->dp_res.ensure((size_t)n_items * PMX_DP_MAX_CALLS);
@@ -485,7 +485,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 A.dp_req_base = al->dp_req.p; A.dp_res_base = al->dp_res.p; A.dp_ncached = al->dp_ncached.p;
                 A.dp_slot_pairs = al->dp_slot_pairs.p;
                 A.dp_slot_cap = (uint32_t)std::min<int64_t>(n_items, UINT32_MAX - 1);
-                if (!getenv("PMX_ALIGN_NO_MV_HANDOVER")) {
+                if (!pmx::opt_str(pmx::O_ALIGN_NO_MV_HANDOVER)) {
                     A.mv_stride = (uint32_t)tpp_layout.caps.max_mini + 1u;
                     A.mv_slots = (uint32_t)std::min<int64_t>(A.dp_slot_cap, 131072);
                     al->mv_handover.ensure((size_t)A.mv_slots * A.mv_stride);
@@ -494,7 +494,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             }
             // minimizer window ring in LDS when 16 waves per CU still fit (12 B x w x 64 lanes per wave)
             size_t tpp_lds_bytes = (size_t)al->opt.w * 64 * 12;
-            if (tpp_lds_bytes * (size_t)tpp_waves > (size_t)150 * 1024 || getenv("PMX_ALIGN_NO_LDS_RING")) tpp_lds_bytes = 0;
+            if (tpp_lds_bytes * (size_t)tpp_waves > (size_t)150 * 1024 || pmx::opt_str(pmx::O_ALIGN_NO_LDS_RING)) tpp_lds_bytes = 0;
             A.tpp_ring_w = tpp_lds_bytes ? al->opt.w : 0;
             A.dp_count = al->retry_count.p + 1;
             A.retry_list = al->retry_list2.p;
@@ -512,11 +512,11 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 PMX_HIP(hipGetLastError());
             };
             const uint32_t* order = nullptr;   // launch order of the first pass: pairs sorted by a locality key
-            if (!getenv("PMX_ALIGN_NO_PAIR_SORT")) {
+            if (!pmx::opt_str(pmx::O_ALIGN_NO_PAIR_SORT)) {
                 // the read set's locality order (shared with the seeding stage); pairs: the even reads of it, in that order
                 const uint32_t* read_order = readset_locality_order(ctx, rs);
                 if (read_order && !paired) order = read_order;
-                else if (read_order && !getenv("PMX_ALIGN_PAIR_KEY1")) {
+                else if (read_order && !pmx::opt_str(pmx::O_ALIGN_PAIR_KEY1)) {
                     // pairs by (key of mate 1, key of mate 2): the 64 pairs of a wave then start AND end within a few bases
                     // of each other -- same anchors, same overlap of the mates, same trip counts in every per-lane loop
                     // (round 3, 10M reads: k_align_compact16 28.2 -> 25.0 ms against the order by mate 1 alone, which
@@ -543,12 +543,12 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             // Compact tier (align_kernel_compact.hip): every pair first, work state in LDS; what it cannot finish comes
             // back as the bail list, which is the launch order of the general thread-per-pair kernel below.
             int64_t n_t0 = n_items;
-            const bool use_compact = paired && al->opt.is_sr_like && al->opt.w == PMX_C_W && (al->opt.k & 1) && rs->max_len <= PMX_C_MAXLEN && n_items < (int64_t)UINT32_MAX && !getenv("PMX_ALIGN_NO_COMPACT");
+            const bool use_compact = paired && al->opt.is_sr_like && al->opt.w == PMX_C_W && (al->opt.k & 1) && rs->max_len <= PMX_C_MAXLEN && n_items < (int64_t)UINT32_MAX && !pmx::opt_str(pmx::O_ALIGN_NO_COMPACT);
             if (!use_compact) timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
             if (use_compact) {
                 al->bail_list.ensure((size_t)n_items);
-                const bool pos16 = al->ri.len <= 32767 && !getenv("PMX_ALIGN_COMPACT_POS32");
-                const bool c_fused = getenv("PMX_ALIGN_COMPACT_FUSED") != nullptr;
+                const bool pos16 = al->ri.len <= 32767 && !pmx::opt_str(pmx::O_ALIGN_COMPACT_POS32);
+                const bool c_fused = pmx::opt_str(pmx::O_ALIGN_COMPACT_FUSED) != nullptr;
                 auto c_kern = c_fused ? (pos16 ? k_align_compact16_fused : k_align_compact32_fused) : (pos16 ? k_align_compact16 : k_align_compact32);
                 const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
                 // One workgroup (wave) per 64 pairs, handed out by the dispatcher as CUs free up: the pairs of a wave cost what
@@ -556,7 +556,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 // per CU brings it back) the slowest stride set the kernel's end -- 10M reads: 17.05 -> 15.5 ms, and the seeds
                 // kernel below 4.77 -> 4.10 ms.  (The hardware keeps 160 KB / c_lds = seven waves per CU resident either way.)
                 int64_t c_grid = (n_items + 63) / 64;
-                if (const char* e = getenv("PMX_ALIGN_COMPACT_WAVES")) c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), c_grid);
+                if (const char* e = pmx::opt_str(pmx::O_ALIGN_COMPACT_WAVES)) c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), c_grid);
                 A.n_items = n_items;
                 A.pair_perm = order;
                 A.retry_list = al->bail_list.p;
@@ -576,7 +576,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     // SIMD spills and gains 1 %, of six loses)
                     auto s_kern = pos16 ? k_compact_seeds16 : k_compact_seeds32;
                     int64_t s_grid = (n_items + 63) / 64;
-                    if (const char* e = getenv("PMX_ALIGN_CSEED_WAVES")) s_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), s_grid);
+                    if (const char* e = pmx::opt_str(pmx::O_ALIGN_CSEED_WAVES)) s_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), s_grid);
                     timer_begin(ctx, "align_cseeds");
                     hipLaunchKernelGGL(s_kern, dim3((unsigned)s_grid), dim3(64), (size_t)PMX_C_SEEDQ * 2 * 64 * sizeof(uint32_t),
                                        ctx->stream, A);
@@ -612,7 +612,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             // ~2 ms whatever the grid) before the wave-per-pair tier gets the pairs that need a DP; below 4096 bails the wave
             // tier takes all of them at once (measured with 2.8k bails of 500k pairs: 5.8 ms for the stage instead of 7.0).
             int64_t bail_tpp_min = 4096;
-            if (const char* e = getenv("PMX_ALIGN_BAIL_TPP_MIN")) bail_tpp_min = atoll(e);
+            if (const char* e = pmx::opt_str(pmx::O_ALIGN_BAIL_TPP_MIN)) bail_tpp_min = atoll(e);
             const bool skip_t0 = use_compact && n_t0 < bail_tpp_min;
             A.pair_perm = order;
             if (n_t0 > 0 && !skip_t0) launch_tpp(0, n_t0, nullptr, nullptr);
@@ -632,7 +632,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     break;
                 }
                 al->last_dp_requests += n_dp;
-                if (getenv("PMX_DP_HIST")) {   // diagnostic: the shapes of the posted requests
+                if (pmx::opt_str(pmx::O_DP_HIST)) {   // diagnostic: the shapes of the posted requests
                     std::vector<DpReq> h((size_t)n_dp * PMX_DP_REQ_PER_PASS);
                     PMX_HIP(hipMemcpyAsync(h.data(), A.dp_req_base, h.size() * sizeof(DpReq), hipMemcpyDeviceToHost, ctx->stream));
                     PMX_HIP(hipStreamSynchronize(ctx->stream));
@@ -658,15 +658,15 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     const int64_t n_ent = n_dp * PMX_DP_REQ_PER_PASS;
                     DG.dp_req_base = al->dp_req.p; DG.dp_res_base = al->dp_res.p; DG.stats = A.stats;
                     DG.n_entries = (uint32_t)std::min<size_t>(al->dp_req.n / sizeof(DpReq), UINT32_MAX);
-                    const bool dpg_shadow = getenv("PMX_DPG_SHADOW") != nullptr;   // diagnostic: both services run, results compared
+                    const bool dpg_shadow = pmx::opt_str(pmx::O_DPG_SHADOW) != nullptr;   // diagnostic: both services run, results compared
                     if (dpg_shadow) {
                         al->dpg_shadow.ensure((size_t)n_items * PMX_DP_MAX_CALLS);
                         PMX_HIP(hipMemsetAsync(al->dpg_shadow.p, 0xee, sizeof(DpRes) * (size_t)n_items * PMX_DP_MAX_CALLS, ctx->stream));
                         DG.dp_res_base = al->dpg_shadow.p; DG.stats = nullptr; DG.shadow = 1;
                     }
-                    if (getenv("PMX_DPG_PROF")) { al->dpg_prof.ensure(8); PMX_HIP(hipMemsetAsync(al->dpg_prof.p, 0, 64, ctx->stream)); DG.prof = al->dpg_prof.p; }
-                    dpg_launch(ctx, al, DG, n_dp, cur, dpg_waves, !getenv("PMX_DPG_NO_SERVE"));
-                    if (getenv("PMX_DPG_CHECK_LIST")) {   // diagnostic: the sorted request list against the bucket counts
+                    if (pmx::opt_str(pmx::O_DPG_PROF)) { al->dpg_prof.ensure(8); PMX_HIP(hipMemsetAsync(al->dpg_prof.p, 0, 64, ctx->stream)); DG.prof = al->dpg_prof.p; }
+                    dpg_launch(ctx, al, DG, n_dp, cur, dpg_waves, !pmx::opt_str(pmx::O_DPG_NO_SERVE));
+                    if (pmx::opt_str(pmx::O_DPG_CHECK_LIST)) {   // diagnostic: the sorted request list against the bucket counts
                         std::vector<uint32_t> k2((size_t)n_ent), i2((size_t)n_ent), cn(16);
                         PMX_HIP(hipStreamSynchronize(ctx->stream));
                         PMX_HIP(hipMemcpy(k2.data(), al->dpg_keys2.p, (size_t)n_ent * 4, hipMemcpyDeviceToHost));
@@ -692,14 +692,14 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 }
                 A.dp_left = nullptr;
                 bool wave_service = true;
-                if (dpg_ok && !getenv("PMX_DPG_SHADOW") && !getenv("PMX_DPG_NO_SERVE")) {
+                if (dpg_ok && !pmx::opt_str(pmx::O_DPG_SHADOW) && !pmx::opt_str(pmx::O_DPG_NO_SERVE)) {
                     // what did the grouped service leave?  Nothing: no launch of the wave service.  A handful (a side beyond 128
                     // bases on 150 bp reads: ~8 requests per 400k pairs): those pairs go to the wave-per-pair tier instead
                     uint32_t left[2] = {0, 0};
                     PMX_HIP(hipMemcpyAsync(left, al->dpg_counts.p + PMX_DPG_NO_BUCKET - 1, sizeof(left), hipMemcpyDeviceToHost, ctx->stream));
                     PMX_HIP(hipStreamSynchronize(ctx->stream));
                     int64_t few = 256;
-                    if (const char* e = getenv("PMX_DPG_LEFT_TO_WAVE_TIER")) few = atoll(e);
+                    if (const char* e = pmx::opt_str(pmx::O_DPG_LEFT_TO_WAVE_TIER)) few = atoll(e);
                     if (left[0] + left[1] == 0) wave_service = false;
                     else if ((int64_t)left[0] + left[1] <= few) {
                         hipLaunchKernelGGL(k_dpg_refuse_left, dim3((unsigned)std::min<int64_t>((n_dp * PMX_DP_REQ_PER_PASS + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, DG);
@@ -726,7 +726,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 }
                 }
                 PMX_HIP(hipGetLastError());
-                if (dpg_ok && getenv("PMX_DPG_SHADOW")) {
+                if (dpg_ok && pmx::opt_str(pmx::O_DPG_SHADOW)) {
                     const size_t n_ent = (size_t)n_dp * PMX_DP_REQ_PER_PASS, n_res = (size_t)n_items * PMX_DP_MAX_CALLS;
                     std::vector<uint32_t> keys(n_ent), ids(n_ent);
                     std::vector<DpRes> a(n_res), b(n_res);
@@ -820,19 +820,19 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
         // hundred bases wide: the first launch gives every wave 8 MB of traceback in HBM, the reads that need more come
         // back on the retry list and run in a second launch of few waves with the full capacity.
         size_t tb_small = (size_t)8 << 20;
-        if (const char* e = getenv("PMX_ALIGN_TB_KB")) tb_small = std::max<size_t>((size_t)atoll(e), 1) << 10;
+        if (const char* e = pmx::opt_str(pmx::O_ALIGN_TB_KB)) tb_small = std::max<size_t>((size_t)atoll(e), 1) << 10;
         // The arrays of a 10 kb read (anchors, chain cells, the DP arrays sized for the longest allowed target) live in the
         // wave's HBM slab whatever the LDS budget, and the kernel is bound by the latency of those accesses: what counts is
         // resident waves (16 per CU: 32.4 k reads/s, 8 per CU: 21.1 k) and that the DPs -- nearly all a few hundred bases
         // wide -- run on a small LDS copy of their arrays (plan_layout dp_fast_tlen)
         int dp_fast = PMX_DP_FAST_TLEN;
-        if (getenv("PMX_ALIGN_NO_DP_FAST")) dp_fast = 0;
+        if (pmx::opt_str(pmx::O_ALIGN_NO_DP_FAST)) dp_fast = 0;
         size_t lr_budget = 8900;
-        if (const char* e = getenv("PMX_ALIGN_LDS_KB")) lr_budget = (size_t)atoi(e) * 1024;
+        if (const char* e = pmx::opt_str(pmx::O_ALIGN_LDS_KB)) lr_budget = (size_t)atoi(e) * 1024;
         const Layout g1 = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lr_budget, tb_small, 1, dp_fast));
         al->retry_list.ensure((size_t)n_items);
         timer_begin(ctx, "align_dom");
-        if (!getenv("PMX_ALIGN_NO_WORK_QUEUE")) {
+        if (!pmx::opt_str(pmx::O_ALIGN_NO_WORK_QUEUE)) {
             PMX_HIP(hipMemsetAsync(al->retry_count.p + 3, 0, sizeof(unsigned long long), ctx->stream));
             A.work_queue = al->retry_count.p + 3;
         }
@@ -888,7 +888,7 @@ int pmx_align_readset(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int 
     // (a redo costs the whole stage again: 4.5 s per 100k reads of 10 kb)
     if (!al->opt.is_sr_like) cap = std::max<uint64_t>(cap, (uint64_t)rs->total / 8 + (uint64_t)rs->n * 16);
     if (al->cigar_words_per_kbase > 0.0) cap = std::max<uint64_t>(cap, (uint64_t)(al->cigar_words_per_kbase * 1.25 * (double)rs->total / 1000.0) + 4096);
-    if (const char* e = getenv("PMX_ALIGN_CIGAR_CAP")) cap = (uint64_t)std::max<long long>(atoll(e), 16);   // tests: force the redo
+    if (const char* e = pmx::opt_str(pmx::O_ALIGN_CIGAR_CAP)) cap = (uint64_t)std::max<long long>(atoll(e), 16);   // tests: force the redo
     for (int attempt = 0;; ++attempt) {
         const int rc = align_readset_once(ctx, al, rs, paired, revcomp_mate2, cap);
         if (rc != PMX_OK) return rc;
@@ -953,7 +953,7 @@ int64_t pmx_score_reads_vs_reference(const char* reference, int n_reads, const c
     if (!reference || !reads || !r_lens || n_reads <= 0) return 0;
     pmx_ctx* ctx = nullptr;
     int dev = 0;
-    if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
+    if (const char* e = pmx::opt_str(pmx::O_DEVICE)) dev = atoi(e);
     if (pmx_ctx_create(dev, &ctx) != PMX_OK) return 0;
     pmx_aligner* al = nullptr;
     int64_t total = 0, withheld = 0;
@@ -1057,7 +1057,7 @@ int pmx_align_dp_batch(pmx_ctx* ctx, pmx_aligner* al, const uint8_t* seqs, const
     DG.n_entries = (uint32_t)req.size();
     DG.shadow = 1;   // the requests stay posted: the launch can be repeated
     int dpg_waves = 8;
-    if (const char* e = getenv("PMX_ALIGN_DPG_WAVES")) dpg_waves = std::max(1, atoi(e));
+    if (const char* e = pmx::opt_str(pmx::O_ALIGN_DPG_WAVES)) dpg_waves = std::max(1, atoi(e));
     if (ok) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         PMX_HIP(hipEventCreate(&e0)); PMX_HIP(hipEventCreate(&e1));
@@ -1164,7 +1164,7 @@ void pmx_align_reads_direct(const char* reference, const char* refName, int n_re
     pmx_readset* rs = nullptr;
     pmx_aligner* al = nullptr;
     int dev = 0;
-    if (const char* e = getenv("PMX_DEVICE")) dev = atoi(e);
+    if (const char* e = pmx::opt_str(pmx::O_DEVICE)) dev = atoi(e);
     if (pmx_ctx_create(dev, &ctx) != PMX_OK) return;   // like the reference: results stay untouched on failure
     do {
         int64_t total = 0;

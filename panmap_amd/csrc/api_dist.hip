@@ -230,7 +230,7 @@ extern "C" {
 int pmx_dist_unique_id(char id[PMX_DIST_ID_BYTES]) {
     if (!id) return PMX_ERR_ARG;
     memset(id, 0, PMX_DIST_ID_BYTES);
-    if (getenv("PMX_DIST_HOST_DIR")) {
+    if (pmx::opt_str(pmx::O_DIST_HOST_DIR)) {
         // the test transport needs no communicator, but its file names carry the id's first bytes as the run's nonce: a
         // directory that still holds the last-round files of an earlier run (they are never unlinked, see HostDirTransport)
         // can be used again
@@ -258,7 +258,7 @@ int pmx_dist_init(pmx_ctx* ctx, const char id[PMX_DIST_ID_BYTES], int rank, int 
     PMX_HIP(hipSetDevice(ctx->device));
     std::unique_ptr<pmx_dist> d(new pmx_dist());
     d->ctx = ctx;
-    if (const char* dir = getenv("PMX_DIST_HOST_DIR")) {
+    if (const char* dir = pmx::opt_str(pmx::O_DIST_HOST_DIR)) {
         auto* t = new HostDirTransport();
         t->dir = dir;
         char hex[17];

@@ -370,3 +370,74 @@ extern "C" double pmx_read_dust(const char* seq, int64_t len, int32_t window) {
     if (seen + 1 > 1) return (200.0 * pairs) / (seen * (seen + 1));
     return 0.0;
 }
+
+// ------------------------------------------------------------------------------------------------- the options table
+// (device/pmx_options.hpp).  Readers take the current table through an atomic pointer; a reload builds a new one and swaps
+// it in (the old one is kept: a reader may still hold a value pointer into it; reloads are rare).
+#include <atomic>
+#include <mutex>
+
+#include "device/pmx_options.hpp"
+namespace pmx {
+namespace {
+struct OptTable {
+    std::string val[O_COUNT];
+    bool set[O_COUNT];
+};
+const char* const kOptName[O_COUNT] = {
+#define PMX_OPT_NAME(name, cls, doc) "PMX_" #name,
+    PMX_OPTION_TABLE(PMX_OPT_NAME)
+#undef PMX_OPT_NAME
+};
+const char* const kOptClass[O_COUNT] = {
+#define PMX_OPT_CLASS(name, cls, doc) cls,
+    PMX_OPTION_TABLE(PMX_OPT_CLASS)
+#undef PMX_OPT_CLASS
+};
+const char* const kOptDoc[O_COUNT] = {
+#define PMX_OPT_DOC(name, cls, doc) doc,
+    PMX_OPTION_TABLE(PMX_OPT_DOC)
+#undef PMX_OPT_DOC
+};
+std::atomic<const OptTable*> g_opt{nullptr};
+std::mutex g_opt_mu;
+const OptTable* read_env() {
+    OptTable* t = new OptTable();
+    for (int i = 0; i < O_COUNT; ++i) {
+        const char* v = getenv(kOptName[i]);
+        t->set[i] = v != nullptr;
+        if (v) t->val[i] = v;
+    }
+    return t;
+}
+const OptTable* table() {
+    const OptTable* t = g_opt.load(std::memory_order_acquire);
+    if (t) return t;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    t = g_opt.load(std::memory_order_acquire);
+    if (!t) { t = read_env(); g_opt.store(t, std::memory_order_release); }
+    return t;
+}
+}  // namespace
+const char* opt_str(OptId id) {
+    const OptTable* t = table();
+    return t->set[id] ? t->val[id].c_str() : nullptr;
+}
+void options_reload() {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    g_opt.store(read_env(), std::memory_order_release);
+}
+size_t options_describe(char* buf, size_t cap) {
+    const OptTable* t = table();
+    std::string s;
+    for (int i = 0; i < O_COUNT; ++i) {
+        s += kOptName[i]; s += " ["; s += kOptClass[i]; s += "] "; s += kOptDoc[i];
+        if (t->set[i]) { s += " (= "; s += t->val[i]; s += ")"; }
+        s += "\n";
+    }
+    if (buf && cap > 0) { const size_t n = std::min(cap - 1, s.size()); memcpy(buf, s.data(), n); buf[n] = 0; }
+    return s.size() + 1;
+}
+}  // namespace pmx
+extern "C" void pmx_options_reload(void) { pmx::options_reload(); }
+extern "C" int64_t pmx_options_describe(char* buf, int64_t cap) { return (int64_t)pmx::options_describe(buf, cap > 0 ? (size_t)cap : 0); }

@@ -664,7 +664,7 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         //  one group 2.09).  A large range is cut into as few groups as 512 MB chunks allow: 10M x 150 bp in 24 launches of 64 MB
         //  took 10.8 ms, in 16 of 96 MB 9.6 ms, in 4 of 384 MB 9.05 ms -- a third of the range per chunk, between 64 and 512 MB
         int64_t chunk_mb = std::min<int64_t>(512, std::max<int64_t>(64, (((rr1 - rr0) * std::max<int64_t>(rs->max_len, 1) / 3) >> 20) + 1));
-        if (const char* e = getenv("PMX_SEED_CHUNK_MB")) chunk_mb = std::max<int64_t>(1, atoll(e));
+        if (const char* e = pmx::opt_str(pmx::O_SEED_CHUNK_MB)) chunk_mb = std::max<int64_t>(1, atoll(e));
         const int64_t chunk_reads_opt = std::max<int64_t>(1, (chunk_mb << 20) / std::max<int64_t>(rs->max_len, 1));
         // (with the safe bound -- one key per base of the group -- the groups stay three chunks of 64 MB: the table is grown by
         //  what a group can add, and a 1.5 GB group would reserve a 68 GB table for a sample that overflowed the optimistic one)
@@ -679,23 +679,23 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         // cheaper to clear and to compact.
         int64_t bound_div = 1;
         double bound_frac = 0;   // > 0: optimistic bound as a fraction of the safe one (takes the place of 1 / bound_div)
-        if (!pl->table_dirty && !getenv("PMX_SEED_SAFE_BOUND")) {
+        if (!pl->table_dirty && !pmx::opt_str(pmx::O_SEED_SAFE_BOUND)) {
             bound_div = 8;
-            if (const char* e = getenv("PMX_SEED_BOUND_DIV")) bound_div = std::max<int64_t>(1, atoll(e));   // (tests force the redo with a large value)
-            else if (pl->keys_per_base > 0 && !getenv("PMX_SEED_NO_HINT")) bound_frac = std::min(1.0 / 8, std::max(2 * pl->keys_per_base, 1.0 / 64));
+            if (const char* e = pmx::opt_str(pmx::O_SEED_BOUND_DIV)) bound_div = std::max<int64_t>(1, atoll(e));   // (tests force the redo with a large value)
+            else if (pl->keys_per_base > 0 && !pmx::opt_str(pmx::O_SEED_NO_HINT)) bound_frac = std::min(1.0 / 8, std::max(2 * pl->keys_per_base, 1.0 / 64));
         }
         timer_begin(ctx, "seed");
         // seeding order (default-parameter kernel): reads that start with the same 16 bases next to each other, so that a
         // block's (seed, count) cache sees its seeds many times (k_seed_histogram_ks)
-        const bool ks_path = sp.k == 19 && sp.s == 8 && sp.t == 0 && (l == 3 || l == 1) && !quality_mode && !getenv("PMX_SEED_GENERIC");
-        const uint32_t* perm = ks_path && !getenv("PMX_SEED_NO_SORT") ? (whole ? readset_locality_order(ctx, rs) : readset_locality_order_range(ctx, rs, rr0, rr1)) : nullptr;
+        const bool ks_path = sp.k == 19 && sp.s == 8 && sp.t == 0 && (l == 3 || l == 1) && !quality_mode && !pmx::opt_str(pmx::O_SEED_GENERIC);
+        const uint32_t* perm = ks_path && !pmx::opt_str(pmx::O_SEED_NO_SORT) ? (whole ? readset_locality_order(ctx, rs) : readset_locality_order_range(ctx, rs, rr0, rr1)) : nullptr;
         // the specialised kernel keeps its rings in registers: LDS = the waves' seed queues + the block cache (keys 8 B +
         // counts 4 B + admission tags 2 B per entry)
         const size_t lds_ks = (size_t)(PMX_SEED_BLOCK / 64) * PMX_SEED_QCAP_KS * sizeof(uint64_t) + (size_t)PMX_SEED_CACHE * 14 + 35 * sizeof(uint64_t) +   // + the base-hash tables
                               (size_t)(PMX_SEED_BLOCK / 64) * (64 * sizeof(uint32_t) + PMX_SEED_QCAP_KS);                                                   // + multiplicities, pushing lanes
         // Read collapse ahead of the seeding kernel (k_collapse_reads: src/placement.cpp:1550-1593 seeds every distinct read once,
         // with its multiplicity): reads of up to 160 bases on the specialised kernel's path
-        const bool collapse = ks_path && rs->max_len <= 160 && !getenv("PMX_SEED_NO_COLLAPSE");
+        const bool collapse = ks_path && rs->max_len <= 160 && !pmx::opt_str(pmx::O_SEED_NO_COLLAPSE);
         if (collapse && !pl->collapse_attr_set) {
             PMX_HIP(hipFuncSetAttribute((const void*)k_collapse_reads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PMX_DEDUP_LDS_BYTES));
             pl->collapse_attr_set = true;
@@ -707,7 +707,7 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         // A launch of one chunk is latency-bound (every wave walks its 150 bases one after the other, a few waves per
         // SIMD): the chunks of a group run concurrently on side streams, sharing the table (all they do is atomics).
         int n_par = 3;
-        if (const char* e = getenv("PMX_SEED_PAR")) n_par = std::max(1, std::min(4, atoi(e)));
+        if (const char* e = pmx::opt_str(pmx::O_SEED_PAR)) n_par = std::max(1, std::min(4, atoi(e)));
         if (n_par > 1 && !ctx->seed_go) {
             PMX_HIP(hipEventCreateWithFlags(&ctx->seed_go, hipEventDisableTiming));
             for (int j = 0; j < 3; ++j) {   // (own hardware queues: see create_dedicated_stream)
@@ -730,7 +730,7 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
             // saves cache flushes (memory-side atomics) but measured slower: 1.55 ms for the stage with 1, 1.59 / 1.84 / 1.86 / 3.14
             // with 2 / 4 / 8 / 16 -- fewer, longer blocks fill the chip worse, and the atomics are not what bounds the kernel
             int seed_batches = 1;
-            if (const char* e = getenv("PMX_SEED_BATCHES")) seed_batches = std::max(1, atoi(e));
+            if (const char* e = pmx::opt_str(pmx::O_SEED_BATCHES)) seed_batches = std::max(1, atoi(e));
             // (the specialised kernel: one batch of reads per block whatever the chunk's size -- the dispatcher hands the blocks out;
             //  a grid capped at what is resident made every block walk several batches, which measured slower, see above)
             const dim3 grid(ks_path ? grid_for(r1 - r0, PMX_SEED_BLOCK * seed_batches, 1 << 30) : grid_for(r1 - r0, PMX_SEED_BLOCK, ctx->n_cu * 16)), block(PMX_SEED_BLOCK);
@@ -767,7 +767,7 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         PMX_HIP(hipStreamSynchronize(ctx->stream));
         pl->h_ctr_valid = true;
         const unsigned long long h_ovf = pl->h_ctr[PMX_CTR_OVERFLOW];
-        if (getenv("PMX_PLACE_PROF")) fprintf(stderr, "[pmx place] seeding with bound 1/%lld: table %llu slots, %llu failed inserts\n", (long long)bound_div, (unsigned long long)pl->cap, h_ovf);
+        if (pmx::opt_str(pmx::O_PLACE_PROF)) fprintf(stderr, "[pmx place] seeding with bound 1/%lld: table %llu slots, %llu failed inserts\n", (long long)bound_div, (unsigned long long)pl->cap, h_ovf);
         if (h_ovf == 0) break;
         // the optimistic table overflowed: start over with the safe bound
         PMX_HIP(hipMemsetAsync(pl->counters.p, 0, sizeof(unsigned long long) * PMX_CTR_N, ctx->stream));
@@ -1009,7 +1009,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     std::memset(res, 0, sizeof(*res));
     for (int m = 0; m < 5; ++m) res->best_index[m] = UINT32_MAX;
     // PMX_PLACE_PROF=1: host wall time of the sections of this call (each mark synchronises the stream first)
-    const bool prof = getenv("PMX_PLACE_PROF") != nullptr;
+    const bool prof = pmx::opt_str(pmx::O_PLACE_PROF) != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
         if (!prof) return;
@@ -1123,7 +1123,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
     };
     const void* sig[3] = {(const void*)t_mag, (const void*)pl->metrics5.p, (const void*)pl->term_meta.p};
     bool tree_kernel = false;
-    if (!getenv("PMX_PLACE_LEVEL_KERNELS")) {
+    if (!pmx::opt_str(pmx::O_PLACE_LEVEL_KERNELS)) {
         // one persistent launch, parent -> child through per-node flags (k_score_tree); one workgroup per CU so that
         // every wave is resident
         if (!pl->tree_done.p) {
@@ -1135,7 +1135,7 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
             PMX_HIP(hipMemsetAsync(pl->tree_done.p, 0, sizeof(uint32_t) * ((size_t)pl->n_nodes + 1), st));
             pl->tree_epoch = 1;
         }
-        if (getenv("PMX_PLACE_TREE_KERNEL")) {   // per-node flags in BFS order (kept for comparison)
+        if (pmx::opt_str(pmx::O_PLACE_TREE_KERNEL)) {   // per-node flags in BFS order (kept for comparison)
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ctx->n_cu, (pl->n_nodes + 3) / 4));
             hipLaunchKernelGGL(k_score_tree, dim3(grid), dim3(256), 0, st, pl->level_nodes.p, pl->n_nodes, pl->parent.p, pl->offsets.p, t_mag, t_raw,
                                t_cos, t_wc, t_lc, pl->term_meta.p, pl->metrics5.p, pl->counts2.p, pl->tree_done.p, pl->tree_epoch,
@@ -1147,11 +1147,11 @@ int pmx_place_score(pmx_ctx* ctx, pmx_place* pl, const pmx_place_params* pp, int
                                pl->tree_done.p, pl->tree_epoch, pl->tree_done.p + pl->n_nodes);
         }
         tree_kernel = true;
-        if (getenv("PMX_PLACE_TEST_STARVED")) {   // tests: pretend a wave gave up, so that the level-kernel redo runs
+        if (pmx::opt_str(pmx::O_PLACE_TEST_STARVED)) {   // tests: pretend a wave gave up, so that the level-kernel redo runs
             const uint32_t one = 1;
             PMX_HIP(hipMemcpyAsync(pl->tree_done.p + pl->n_nodes, &one, sizeof(one), hipMemcpyHostToDevice, st));
         }
-    } else if (getenv("PMX_PLACE_NO_GRAPH")) launch_levels();
+    } else if (pmx::opt_str(pmx::O_PLACE_NO_GRAPH)) launch_levels();
     else {
         if (!pl->level_graph_exec || pl->level_graph_sig[0] != sig[0] || pl->level_graph_sig[1] != sig[1] || pl->level_graph_sig[2] != sig[2]) {
             if (pl->level_graph_exec) { (void)hipGraphExecDestroy(pl->level_graph_exec); pl->level_graph_exec = nullptr; }

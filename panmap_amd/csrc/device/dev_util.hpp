@@ -1,5 +1,6 @@
 // Host-side helpers for the device translation units: error plumbing, RAII device buffers, context.
 #pragma once
+#include "pmx_options.hpp"
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -66,7 +67,7 @@ struct DevBuf {
 // (PMX_CTX_POOLED_QUEUE=1: ordinary pooled streams.)
 inline hipStream_t create_dedicated_stream(int n_cu) {
     hipStream_t st = nullptr;
-    if (!getenv("PMX_CTX_POOLED_QUEUE") && n_cu > 0) {
+    if (!pmx::opt_str(pmx::O_CTX_POOLED_QUEUE) && n_cu > 0) {
         std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0xffffffffu);
         if (n_cu % 32) mask.back() = (1u << (n_cu % 32)) - 1u;
         if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {

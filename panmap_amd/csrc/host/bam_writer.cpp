@@ -6,6 +6,7 @@
 // Byte parity of the compressed file is not a goal (it depends on the deflate implementation htslib was built
 // with); the decompressed BAM stream and the index contents are what tests/test_bam.py checks.
 #include "bam_writer.hpp"
+#include "device/pmx_options.hpp"
 
 #include <zlib.h>
 
@@ -219,7 +220,7 @@ struct BlockLayout {
 
 unsigned worker_count(size_t n_items, size_t per_thread) {
     unsigned n = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("PMX_BAM_THREADS")) n = (unsigned)std::max(1, atoi(e));
+    if (const char* e = pmx::opt_str(pmx::O_BAM_THREADS)) n = (unsigned)std::max(1, atoi(e));
     return (unsigned)std::max<size_t>(1, std::min<size_t>(n, n_items / std::max<size_t>(per_thread, 1) + 1));
 }
 

@@ -1,4 +1,5 @@
 #include "fastx_reader.hpp"
+#include "device/pmx_options.hpp"
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -195,7 +196,7 @@ void read_fastx(const std::string& path, FastxReads& out) {
     // inflating a .gz stays serial there and here).  Anything else -- FASTA, wrapped records, a piece that does not parse as
     // strict four-line records -- goes through the general parser as before: same result either way.
     unsigned n_thr = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("PMX_FASTX_THREADS")) n_thr = (unsigned)std::max(1, atoi(e));
+    if (const char* e = pmx::opt_str(pmx::O_FASTX_THREADS)) n_thr = (unsigned)std::max(1, atoi(e));
     if (n_thr > 1 && data.size() >= ((size_t)8 << 20) && begin[0] == '@') {
         std::vector<const char*> cut(n_thr + 1, end);
         cut[0] = begin;

@@ -18,6 +18,7 @@
 // The syncmer map and the k-min-mer counts are updated incrementally: only windows of l consecutive
 // syncmers whose column span contains a changed column are removed / re-added.
 #include "index_build.hpp"
+#include "device/pmx_options.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -365,7 +366,7 @@ void build_lite_index(const Panman& pm, const SyncmerParams& p, int flank_mask, 
         }
     };
     unsigned n_thr = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("PMX_INDEX_THREADS")) n_thr = (unsigned)std::max(1, atoi(e));
+    if (const char* e = pmx::opt_str(pmx::O_INDEX_THREADS)) n_thr = (unsigned)std::max(1, atoi(e));
     if (n_thr <= 1 || n_do < 4096) {
         Builder b(pm, p, flank_mask);
         std::vector<int32_t> stack;

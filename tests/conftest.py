@@ -51,3 +51,25 @@ def isolate_reads(pmx):
 @pytest.fixture(scope="session")
 def ctx(pmx):
     return pmx.Context(0)
+
+
+@pytest.fixture(autouse=True)
+def _library_options_follow_the_environment(monkeypatch, built):
+    """The library reads its PMX_* switches ONCE (csrc/device/pmx_options.hpp).  A test that changes one through
+    monkeypatch gets the table re-read at that moment, and once more when the test's changes are undone."""
+    import panmap_amd
+    real_set, real_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        real_set(name, value, *a, **k)
+        if name.startswith("PMX_"):
+            panmap_amd.reload_options()
+
+    def delenv(name, *a, **k):
+        real_del(name, *a, **k)
+        if name.startswith("PMX_"):
+            panmap_amd.reload_options()
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.undo()
+    panmap_amd.reload_options()

@@ -345,3 +345,25 @@ def test_parallel_fastq_scan_equals_serial(pmx, tmp_path, monkeypatch):
             f.write(b"@w%d\n%s\n%s\n+\n%s\n%s\n" % (i, seq[:60], seq[60:], b"I" * 60, b"I" * 60))
     w1, w7 = read(1, wrapped), read(7, wrapped)
     assert len(w1[0]) == 60001 and all((np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b) for a, b in zip(w1, w7))
+
+
+def test_one_table_of_switches(pmx, monkeypatch):
+    """every PMX_* switch of the library sits in one table (csrc/device/pmx_options.hpp), read once and re-read on request;
+    no library source calls getenv for a switch outside it"""
+    import re
+    text = pmx.describe_options()
+    names = [l.split(" ")[0] for l in text.splitlines()]
+    assert len(names) == len(set(names)) >= 50 and all(n.startswith("PMX_") for n in names)
+    assert all(re.match(r"PMX_\w+ \[(env|test|ab|tune|diag)\] \S", l) for l in text.splitlines())
+    monkeypatch.setenv("PMX_INDEX_THREADS", "3")          # (conftest re-reads the table)
+    assert "PMX_INDEX_THREADS [env]" in pmx.describe_options() and "(= 3)" in [l for l in pmx.describe_options().splitlines() if l.startswith("PMX_INDEX_THREADS")][0]
+    monkeypatch.delenv("PMX_INDEX_THREADS")
+    assert "(= 3)" not in pmx.describe_options()
+    src = os.path.join(ROOT, "panmap_amd", "csrc")
+    for dp, dn, fn in os.walk(src):
+        if os.path.basename(dp) in ("build", "cli"):
+            continue
+        for f in fn:
+            if f.endswith((".hip", ".hpp", ".cpp", ".h")):
+                for m in re.finditer(r'getenv\("(PMX_\w+)"\)', open(os.path.join(dp, f)).read()):
+                    assert m.group(1) == "PMX_C_DUMP", (f, m.group(1))      # (hostsim-only debug print in aln_compact.hpp)
