@@ -637,6 +637,7 @@ def main():
             dist.broadcast_object_list(box, src=0)
             if test_gloo:
                 os.environ["PMX_DIST_HOST_DIR"] = box[1]
+                pmx.reload_options()          # (the library reads its switches once: csrc/device/pmx_options.hpp)
             pp.dist = pmx.Dist(pp.ctx, box[0], rank, world)
 
     def sync_all():

@@ -106,7 +106,7 @@ static void dpg_launch(pmx_ctx* ctx, pmx_aligner* al, DpgArgs& DG, int64_t n_slo
     al->dpg_keys.ensure((size_t)n_ent); al->dpg_keys2.ensure((size_t)n_ent); al->dpg_ids.ensure((size_t)n_ent); al->dpg_ids2.ensure((size_t)n_ent);
     al->dpg_counts.ensure(16);
     const int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * waves_per_cu, (n_ent + 7) / 8 + PMX_DPG_BUCKETS);
-    al->dpg_tb.ensure((size_t)ctx->n_cu * waves_per_cu * PMX_DPG_TB_BYTES);
+    al->dpg_tb.ensure((size_t)grid * PMX_DPG_TB_BYTES);   // a traceback window per launched wave (not per wave the chip could hold: --refine keeps an aligner per worker)
     DG.worklist = worklist; DG.n_slots = n_slots;
     DG.keys = al->dpg_keys.p; DG.ids = al->dpg_ids.p; DG.sorted_ids = al->dpg_ids2.p; DG.counts = al->dpg_counts.p;
     DG.tb = al->dpg_tb.p;
