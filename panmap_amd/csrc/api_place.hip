@@ -675,14 +675,14 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         // counted (probe sequences are capped), and in that case the table is cleared and the call is redone with the safe
         // bound.  Same histogram either way.
         // Once a histogram has been finished its density (distinct seeds per read base) sizes the next optimistic table:
-        // twice that, at least 1/64 of the safe bound -- batches of one run look alike, and a table 16x smaller is 16x
+        // twice that, at least 1/256 of the safe bound (1/64 until round 4: 2^25 slots at a load of 3.5 % for 10M reads; every table atomic missed the L2 and the compaction scanned 512 MB) -- batches of one run look alike, and a table 16x smaller is 16x
         // cheaper to clear and to compact.
         int64_t bound_div = 1;
         double bound_frac = 0;   // > 0: optimistic bound as a fraction of the safe one (takes the place of 1 / bound_div)
         if (!pl->table_dirty && !pmx::opt_str(pmx::O_SEED_SAFE_BOUND)) {
             bound_div = 8;
             if (const char* e = pmx::opt_str(pmx::O_SEED_BOUND_DIV)) bound_div = std::max<int64_t>(1, atoll(e));   // (tests force the redo with a large value)
-            else if (pl->keys_per_base > 0 && !pmx::opt_str(pmx::O_SEED_NO_HINT)) bound_frac = std::min(1.0 / 8, std::max(2 * pl->keys_per_base, 1.0 / 64));
+            else if (pl->keys_per_base > 0 && !pmx::opt_str(pmx::O_SEED_NO_HINT)) bound_frac = std::min(1.0 / 8, std::max(2 * pl->keys_per_base, 1.0 / 256));
         }
         timer_begin(ctx, "seed");
         // seeding order (default-parameter kernel): reads that start with the same 16 bases next to each other, so that a
