@@ -305,10 +305,12 @@ def main():
     index = pmx.Index.build(pm, k=19, s=8, t=0, l=3, open_syncmer=False, flank_mask=250)
 
     # ---------------------------------------------------------------------------------------------- workload
-    # Source genome: node_7618 of the tree (the node the repository's example sample places on; SURVEY 8d asks for
-    # the splitmix64(42) mod 20000-th leaf and a splitmix64 stream -- this generator uses numpy's PCG64 and a fixed
-    # node instead, see panmap_amd/synth.py); every rank draws its own shard with its own seed.
-    src = pm.genome("node_7618")
+    # SURVEY 8d to the letter: the source genome is the (splitmix64(42) mod 20000)-th leaf of the tree, the reads come from ONE
+    # splitmix64(42) stream with a fixed draw order (panmap_amd/synth.py: simulate_paired_reads_8d).  The stream is
+    # counter-based, so a rank draws exactly its stretch of the job's pairs: the job's reads do not depend on N.
+    from panmap_amd import synth
+    src_node = synth.source_leaf_8d(np.array([pm.parent(i) if i else 0 for i in range(pm.num_nodes)]), 42)
+    src = pm.genome(src_node)
     long_reads = args.read_len >= 500
     paired = not long_reads
     unit = 2 if paired else 1
@@ -323,7 +325,8 @@ def main():
         concat = np.frombuffer(cb, np.uint8).copy()
         del lst, cb
     else:
-        concat, off = pmx.simulate_paired_reads(src, my_reads // 2, read_len=args.read_len, seed=42 + rank)
+        first_pair = (lo // 2) if args.scaling == "strong" else rank * (my_reads // 2)
+        concat, off = synth.simulate_paired_reads_8d(src, my_reads // 2, first_pair=first_pair, read_len=args.read_len, seed=42)
     n_reads = len(off) - 1
     max_len = int(np.max(np.diff(off))) if n_reads else 0
     mean_len = int(off[-1] // max(n_reads, 1))
@@ -830,6 +833,8 @@ def main():
                     dp_pair_share=st["dp_pairs"] / max(st["n_items"], 1), dp_cells_per_step=st["dp_cells"],
                     gcups_align_stage=st["dp_cells"] / max(float(np.mean(al_ms)), 1e-9) / 1e6, tiers=st,
                     inputs="resident in HBM (one batch at a time)",
+                    note="the sample is replicated x8 to fill the chip: every read is an 8-fold duplicate for the place stage's read collapse "
+                         "(its seeding runs on an eighth of the reads); the align stage -- most of this step -- does not collapse",
                     workload="tests/golden/isolate_R{1,2}.fastq.gz (2 x 51,169 real reads, mean %d bp, indels / N / adapters) x8, place + align" % r_mean)
 
     # ------------------------------------------------------------------------------- the DP kernel on its own (one GPU only)
@@ -884,6 +889,10 @@ def main():
                                                                         ("configs[1]" if n_reads == 1000000 else "custom size")),
                                        "" if world == 1 else "; seed index replicated, RCCL histogram all-gather + record/CIGAR gather")),
                        "reads_per_gpu": n_reads, "total_reads": total_reads, "read_len": args.read_len,
+                       "source_node": pm.node_id(src_node),
+                       "generator": ("SURVEY 8d: leaf number splitmix64(42) mod 20000 of the tree, one splitmix64(42) stream, 35 draws per pair "
+                                     "(start, insert ~ N(300,30) in [150,600], 0.2 % i.i.d. substitutions as geometric gaps), FR, no indels / N"
+                                     if not long_reads else "numpy PCG64 seed 43 + rank: 2 % sub, 1.5 % ins, 1.5 % del"),
                        "batches_in_flight": len(pipes), "h2d_chunks": n_chunks,
                        "index": "k=19,s=8,l=3,closed syncmers,flank-mask 250",
                        "aligner_preset": ("k=21,w=11,a=2,b=8,q=12,e=2,q2=24,e2=1 (src/mm_align.c:140-166)" if not long_reads else

@@ -35,7 +35,7 @@ def test_bench_single_rank_line():
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["unit"] == "reads/s" and d["value"] > 0
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
-    assert d["checks"]["placed_node"] == "node_7618" and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
+    assert d["checks"]["placed_node"] == d["config"]["source_node"] and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
     # SURVEY 8d "parity checks in the same run": the GPU's results on the CPU sample against the CPU path's own
     o = d["checks"]["oracle"]
     assert o["reads"] == 20000 and o["histogram_equal"] and o["node_scores_bit_equal"] and o["tsv_equal"]
@@ -55,7 +55,7 @@ def test_bench_two_ranks_functional():
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["batches_in_flight"] == 2
     assert d["equals_device_resident_run"] is True      # two pipelines per rank, collectives in ticket order
-    assert d["checks"]["placed_node"] == "node_7618" and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
+    assert d["checks"]["placed_node"] == d["config"]["source_node"] and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
     assert d["checks"]["rank0_gather_has_every_cigar"] is True
 
 
@@ -69,7 +69,7 @@ def test_bench_exchange_path_on_rccl_one_rank():
     assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout[:600]   # ONE JSON line (RCCL's banner goes to stderr)
     d = _line(r.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["equals_device_resident_run"] is True
-    assert d["checks"]["placed_node"] == "node_7618" and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
+    assert d["checks"]["placed_node"] == d["config"]["source_node"] and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
     assert d["checks"]["rank0_gather_has_every_cigar"] is True
 
 
