@@ -53,6 +53,22 @@ def test_argument_errors(tmp_path):
         assert run(["rsv.panman"] + opt, tmp_path).returncode == 1
 
 
+def test_a_failing_rank_ends_the_run(tmp_path):
+    """`panmap --gpus N`: a rank that fails -- here every rank asks for a device ordinal the box does not have (or, in a
+    container without a GPU, for any device) -- must END the run with its code: the parent reaps whichever child ends first and
+    terminates the others instead of waiting for ranks that are blocked in the rendezvous for ever"""
+    import time
+    shutil.copy(os.path.join(GOLDEN, "rsv_4K.panman"), tmp_path / "rsv.panman")
+    (tmp_path / "r.fastq").write_text("@a\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n")
+    assert run(["rsv.panman", "--stop", "index"], tmp_path).returncode == 0
+    env = dict(os.environ, PMX_DEVICE="63")
+    t0 = time.time()
+    r = subprocess.run([CLI, "rsv.panman", "r.fastq", "--stop", "place", "--gpus", "3"], cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 60, (r.returncode, r.stderr[-500:])
+    assert "opening the GPU" in r.stderr
+    assert not [d for d in os.listdir("/tmp") if d.startswith("panmap_ranks_") and os.path.exists(os.path.join("/tmp", d, "uid"))]
+
+
 @pytest.mark.gpu
 def test_readme_demo_through_the_cli(pmx, oracle, tmp_path):
     for f in ("sars_20000_twilight_dipper.panman", "isolate_R1.fastq.gz", "isolate_R2.fastq.gz"):
@@ -184,3 +200,12 @@ def test_meta_mixture_through_the_cli(pmx, tmp_path):
     got = {k: float(v) for k, v in lines}
     assert 0.55 < got["MZ515733.1"] < 0.82 and 0.18 < got["node_1330"] < 0.45 and 0.99 < sum(got.values()) < 1.01
     assert all(len(v.split(".")[1]) == 5 for _, v in lines)              # %.5f
+    # --dust (src/main.cpp:2059-2061, mgsr::getDust): low-complexity reads are left out before the seedmers are made --
+    # 200 poly-A / dinucleotide reads added to the sample change nothing once the filter is on
+    with open(tmp_path / "mix.fastq", "a") as out:
+        for i in range(100):
+            out.write("@L%d\n%s\n+\n%s\n@M%d\n%s\n+\n%s\n" % (i, "A" * 150, "I" * 150, i, "AC" * 75, "I" * 150))
+    r = run(["rsv_4K.panman", "mix.fastq", "--meta", "--dust", "20", "-o", "mixd"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(tmp_path / "mixd.mgsr.abundance.out").read() == open(tmp_path / "mix.mgsr.abundance.out").read()
+    assert run(["rsv_4K.panman", "mix.fastq", "--meta", "--dust", "101"], tmp_path).returncode == 1     # --dust must be <= 100

@@ -11,11 +11,21 @@ d=json.load(open("/tmp/o.json")); k=d["kernels_ms"]
 print("%-40s value %.1f M/s (%.2f ms/step)  one-at-a-time %.1f M/s  align %.2f seed %.2f same=%s" % (sys.argv[1], d["value"]/1e6, d["ms_per_step"], d["value_device_resident"]/1e6, k["align stage (all tiers)"], k["seed stage (k_seed_histogram, chunked)"], d["equals_device_resident_run"]))
 P
 }
+if [ "$1" = "scale" ]; then
+run "5M p2" X=1 -- --total-reads 5000000
+run "2.5M p2" X=1 -- --total-reads 2500000
+run "1.25M p2" X=1 -- --total-reads 1250000
+run "1.25M p3" X=1 -- --total-reads 1250000 --pipelines 3
+run "1.25M p2 bail_tpp_min=20000" PMX_ALIGN_BAIL_TPP_MIN=20000 -- --total-reads 1250000
+run "1.25M p2 tpp_min=100000" PMX_ALIGN_TPP_MIN=100000 -- --total-reads 1250000
+exit 0
+fi
 if [ "$1" = "10M" ]; then
 run "10M p2" X=1 --
 run "10M p3" X=1 -- --pipelines 3
+run "10M p4" X=1 -- --pipelines 4
 run "10M p2 again" X=1 --
-run "10M p1" X=1 -- --pipelines 1
+run "10M p3 again" X=1 -- --pipelines 3
 exit 0
 fi
 run "1.25M p2" X=1 -- --total-reads 1250000
