@@ -513,6 +513,8 @@ def main():
             tk = self.tick("pack", tk)
             self.placer.reset()
             self.placer.add_reads(rs, params)
+            if paired:
+                rs.order_pairs()          # (the align stage's pair order, beside the scoring: pmx_readset_order_pairs)
             tk = self.tick("seed", tk)
             self.place_and_align(rs, total_reads, mean_len, paired, paired)
             if dist_on:
@@ -548,6 +550,8 @@ def main():
                 whole = self.read_set(("whole", slot), self.d_concat[slot], self.d_off[slot].data_ptr(), n_reads)
                 whole.pack()
                 self.placer.add_reads(whole, params)
+                if paired:
+                    whole.order_pairs()
                 ev_off, evs = None, []
             else:
                 if self.up_ev[slot] is None:
@@ -568,6 +572,8 @@ def main():
                 self.stream.wait_event(evs[0])
                 whole.pack()
                 self.placer.add_reads(whole, params)
+                if paired:
+                    whole.order_pairs()
             else:
                 # its reads are packed and seeded range by range as the chunks land (pmx_readset_pack_range /
                 # pmx_place_add_reads_range)

@@ -135,6 +135,10 @@ int pmx_readset_pack_range(pmx_ctx *ctx, pmx_readset *rs, int64_t r0, int64_t r1
 /* FASTQ quality strings of the same reads (same offsets; one Phred+33 byte per base): only needed for
  * pmx_place_params.min_seed_quality > 0 (allReadQualities, src/placement.cpp:1386) */
 int pmx_readset_set_qualities(pmx_ctx *ctx, pmx_readset *rs, const char *qual_concat);
+/* Optional: enqueue the align stage's pair order (pairs by both mates' locality keys) of a packed, paired read set NOW, on a
+ * side stream of the context.  It depends on the reads alone, so made here it runs beside the place stage instead of between
+ * the placement and the first align kernel; an aligner that finds none makes it itself.  Same results either way. */
+int pmx_readset_order_pairs(pmx_ctx *ctx, pmx_readset *rs);
 void pmx_readset_free(pmx_ctx *ctx, pmx_readset *rs);
 int64_t pmx_readset_num_reads(const pmx_readset *rs);
 

@@ -122,6 +122,7 @@ SIGNATURES = {
     "pmx_readset_wrap_device": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _PP]),
     "pmx_readset_set_qualities": (_i32, [_vp, _vp, _vp]),
     "pmx_readset_pack": (_i32, [_vp, _vp]),
+    "pmx_readset_order_pairs": (_i32, [_vp, _vp]),
     "pmx_readset_pack_range": (_i32, [_vp, _vp, _i64, _i64]),
     "pmx_readset_free": (None, [_vp, _vp]),
     "pmx_readset_num_reads": (_i64, [_vp]),

@@ -402,6 +402,10 @@ class ReadSet:
     def pack(self):
         check(lib.pmx_readset_pack(self.ctx._h, self._h), "pmx_readset_pack")
 
+    def order_pairs(self):
+        """enqueue the align stage's pair order now, on a side stream (pmx_readset_order_pairs): optional, same results"""
+        check(lib.pmx_readset_order_pairs(self.ctx._h, self._h), "pmx_readset_order_pairs")
+
     def pack_range(self, r0: int, r1: int):
         """streaming: pack the reads [r0, r1) alone (their bases have landed in the wrapped buffer)"""
         check(lib.pmx_readset_pack_range(self.ctx._h, self._h, int(r0), int(r1)), "pmx_readset_pack_range")

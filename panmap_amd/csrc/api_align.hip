@@ -44,8 +44,7 @@ struct pmx_aligner {
     DevBuf<unsigned long long> cigar_used;
     DevBuf<uint8_t> slow, slow2, slab0, slab_raw;
     DevBuf<A128> mv_handover;
-    DevBuf<uint32_t> pp_idx, pp_idx2;   // pair order of the thread-per-pair kernels
-    DevBuf<uint64_t> pp_key, pp_key2;
+    DevBuf<uint32_t> pp_idx, pp_idx2;   // pair order from the read order alone (PMX_ALIGN_PAIR_KEY1)
     DevBuf<char> pp_tmp;
     uint32_t mv_epoch = 0;
     DevBuf<uint32_t> retry_list2, bail_list;
@@ -293,6 +292,55 @@ void pmx_aligner_free(pmx_ctx* ctx, pmx_aligner* al) {
     delete al;
 }
 
+// Pair order of a paired read set: pairs sorted by (locality key of mate 1, of mate 2) -- the 64 pairs of a wave then start
+// AND end within a few bases of each other.  side == nullptr: on the context's stream (or, when it was enqueued earlier on a
+// side stream, the context's stream waits for it); side != nullptr: enqueued there, behind everything the context's stream
+// holds now (the read order).  -> the permutation (device), or nullptr when the read set has no locality order.
+}  // extern "C"
+namespace pmx {
+const uint32_t* readset_pair_order(pmx_ctx* ctx, const pmx_readset* rs, hipStream_t side) {
+    const int64_t n_items = rs->n / 2;
+    if (rs->has_pair_order) {
+        if (rs->pair_ev_pending && !side) { PMX_HIP(hipStreamWaitEvent(ctx->stream, rs->pair_ev, 0)); rs->pair_ev_pending = false; }
+        return rs->pp_idx2.p;
+    }
+    if (!readset_locality_order(ctx, rs) || n_items < 1) return nullptr;
+    rs->pp_key.ensure((size_t)n_items); rs->pp_key2.ensure((size_t)n_items); rs->pp_idx.ensure((size_t)n_items); rs->pp_idx2.ensure((size_t)n_items + 1);
+    size_t bytes = 0;
+    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, rs->pp_key.p, rs->pp_key2.p, rs->pp_idx.p, rs->pp_idx2.p, (size_t)n_items, 0, 64, ctx->stream));
+    rs->pp_tmp.ensure(bytes);
+    hipStream_t st = ctx->stream;
+    if (side) {
+        if (!rs->pair_ev) PMX_HIP(hipEventCreateWithFlags(&rs->pair_ev, hipEventDisableTiming));
+        PMX_HIP(hipEventRecord(rs->pair_ev, ctx->stream));      // the read keys are in place behind this point
+        PMX_HIP(hipStreamWaitEvent(side, rs->pair_ev, 0));
+        st = side;
+    }
+    hipLaunchKernelGGL(k_pair_keys, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, st, rs->loc_key.p, n_items,
+                       rs->pp_key.p, rs->pp_idx.p);
+    PMX_HIP(rocprim::radix_sort_pairs(rs->pp_tmp.p, bytes, rs->pp_key.p, rs->pp_key2.p, rs->pp_idx.p, rs->pp_idx2.p, (size_t)n_items, 0, 64, st));
+    if (side) { PMX_HIP(hipEventRecord(rs->pair_ev, side)); rs->pair_ev_pending = true; }
+    rs->has_pair_order = true;
+    return rs->pp_idx2.p;
+}
+}  // namespace pmx
+extern "C" {
+
+// Enqueue the align stage's pair order of a packed, paired read set NOW, on a side stream of the context: it depends on the
+// reads alone, and made here it runs beside the place stage (scoring is latency-bound) instead of between the placement
+// and the first align kernel (10M reads: ~1 ms).  Optional: an aligner that finds none makes it itself.
+int pmx_readset_order_pairs(pmx_ctx* ctx, pmx_readset* rs) {
+    if (!ctx || !rs) return PMX_ERR_ARG;
+    if (!rs->packed) return fail(PMX_ERR_ARG, "read set is not packed");
+    PMX_TRY
+    PMX_HIP(hipSetDevice(ctx->device));
+    if (rs->n < 2 || rs->n / 2 >= (int64_t)UINT32_MAX) return PMX_OK;
+    if (!ctx->pair_stream) ctx->pair_stream = create_dedicated_stream(ctx->n_cu);
+    (void)readset_pair_order(ctx, rs, ctx->pair_stream);
+    return PMX_OK;
+    PMX_CATCH
+}
+
 static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, int paired, int revcomp_mate2, uint64_t cigar_cap) {
     PMX_TRY
     PMX_HIP(hipSetDevice(ctx->device));
@@ -521,14 +569,8 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     // of each other -- same anchors, same overlap of the mates, same trip counts in every per-lane loop
                     // (round 3, 10M reads: k_align_compact16 28.2 -> 25.0 ms against the order by mate 1 alone, which
                     // PMX_ALIGN_PAIR_KEY1 still selects; the extra 64-bit sort of the pairs is ~1 ms of that)
-                    al->pp_key.ensure((size_t)n_items); al->pp_key2.ensure((size_t)n_items); al->pp_idx.ensure((size_t)n_items); al->pp_idx2.ensure((size_t)n_items + 1);
-                    hipLaunchKernelGGL(k_pair_keys, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
-                                       rs->loc_key.p, n_items, al->pp_key.p, al->pp_idx.p);
-                    size_t bytes = 0;
-                    PMX_HIP(rocprim::radix_sort_pairs(nullptr, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 64, ctx->stream));
-                    al->pp_tmp.ensure(bytes);
-                    PMX_HIP(rocprim::radix_sort_pairs(al->pp_tmp.p, bytes, al->pp_key.p, al->pp_key2.p, al->pp_idx.p, al->pp_idx2.p, (size_t)n_items, 0, 64, ctx->stream));
-                    order = al->pp_idx2.p;
+                    // (made ahead of time by pmx_readset_order_pairs when the host asked for it: then only an event to wait for)
+                    order = readset_pair_order(ctx, rs, nullptr);
                 } else if (read_order) {
                     al->pp_idx.ensure((size_t)rs->n); al->pp_idx2.ensure((size_t)n_items + 1);
                     size_t bytes = 0;

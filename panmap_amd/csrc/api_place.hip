@@ -286,6 +286,7 @@ void pmx_ctx_destroy(pmx_ctx* ctx) {
         if (ctx->seed_done[j]) (void)hipEventDestroy(ctx->seed_done[j]);
     }
     if (ctx->seed_go) (void)hipEventDestroy(ctx->seed_go);
+    if (ctx->pair_stream) (void)hipStreamDestroy(ctx->pair_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -391,6 +392,7 @@ int pmx_readset_rewrap_device(pmx_ctx* ctx, pmx_readset* rs, const void* d_conca
     PMX_HIP(hipSetDevice(ctx->device));
     rs->packed = false;
     rs->has_order = false;
+    rs->has_pair_order = false;
     rs->packed_ranges.clear();
     rs->ordered_ranges.clear();
     rs->has_qual = false;
@@ -456,6 +458,7 @@ int pmx_readset_pack(pmx_ctx* ctx, pmx_readset* rs) {
     timer_end(ctx, "pack", 1);
     rs->packed = true;
     rs->has_order = false;   // (the buffer behind a wrapped read set may hold new reads)
+    rs->has_pair_order = false;
     rs->packed_ranges.clear();
     rs->packed_ranges.add(0, rs->n);
     rs->ordered_ranges.clear();
@@ -478,6 +481,7 @@ int pmx_readset_pack_range(pmx_ctx* ctx, pmx_readset* rs, int64_t r0, int64_t r1
     }
     if (rs->packed) {   // re-packing part of a packed set: the order of those reads may have changed
         rs->has_order = false;
+        rs->has_pair_order = false;
         rs->ordered_ranges.clear();
     }
     rs->packed_ranges.add(r0, r1);

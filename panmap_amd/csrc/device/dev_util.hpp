@@ -95,6 +95,7 @@ struct pmx_ctx {
     // Side streams of the seeding stage (hardware queues of their own, see create_dedicated_stream) and the events that order
     // them against the context's stream.  They belong to the CONTEXT, made on first use and kept until it is destroyed: a
     // placer that made and destroyed its own left the next placer's kernels on a recycled queue hanging (round 4).
+    hipStream_t pair_stream = nullptr;       // pmx_readset_order_pairs
     hipStream_t seed_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t seed_go = nullptr, seed_done[3] = {nullptr, nullptr, nullptr};
 };

@@ -52,6 +52,16 @@ struct pmx_readset {
     mutable pmx::DevBuf<uint32_t> loc_key, loc_key2, loc_idx, loc_perm;
     mutable pmx::DevBuf<char> loc_tmp;
     mutable bool has_order = false;
+    // pair order of the align stage (pairs by both mates' locality keys: api_align.hip), made ahead of time on a side stream
+    // by pmx_readset_order_pairs -- it depends on the reads alone, so it can run beside the place stage's scoring instead of
+    // between the placement and the first align kernel -- or by the aligner itself when nobody asked
+    mutable pmx::DevBuf<uint64_t> pp_key, pp_key2;
+    mutable pmx::DevBuf<uint32_t> pp_idx, pp_idx2;
+    mutable pmx::DevBuf<char> pp_tmp;
+    mutable bool has_pair_order = false;
+    mutable hipEvent_t pair_ev = nullptr;     // recorded behind the sort when it ran on a side stream
+    mutable bool pair_ev_pending = false;
+    ~pmx_readset() { if (pair_ev) (void)hipEventDestroy(pair_ev); }
     // streaming (pmx_readset_pack_range / pmx_place_add_reads_range): the ranges packed so far (`packed` once they cover the
     // set) and the ranges whose slice of loc_perm holds their reads in locality order (`has_order` once they cover the set:
     // a permutation sorted range by range serves the align stage as well as one sorted as a whole)
@@ -66,4 +76,5 @@ namespace pmx {
 const uint32_t* readset_locality_order(pmx_ctx* ctx, const pmx_readset* rs);
 // the same for the reads [r0, r1) alone: their slice of the permutation (absolute read indices), sorted by locality key
 const uint32_t* readset_locality_order_range(pmx_ctx* ctx, const pmx_readset* rs, int64_t r0, int64_t r1);
+const uint32_t* readset_pair_order(pmx_ctx* ctx, const pmx_readset* rs, hipStream_t side);   // api_align.hip
 }
