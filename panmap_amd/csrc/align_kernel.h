@@ -14,6 +14,7 @@ struct AlignArgs {
     const uint32_t* amb;
     const int64_t* woff;
     const int64_t* off;
+    const uint8_t* recs;    // read records (64 bytes per read: words, ambiguity words, length; readset.hpp) or NULL: the compact tier reads them
     int64_t n_items;        // pairs (paired) or reads, or worklist length
     const uint32_t* worklist;   // tier 2: item ids to (re)process; NULL = 0..n_items-1
     uint32_t* retry_list;       // tier 1: items whose capacities overflowed (NULL in tier 2); tier 0: pairs for the wave tiers

@@ -19,6 +19,18 @@ namespace aln {
 // The pair of launch position `it` (both kernels of the two-kernel form walk the positions the same way)
 __device__ __forceinline__ int64_t compact_item(const AlignArgs& A, int64_t it, CRead* rd, const uint32_t** amb) {
     const int64_t item = A.pair_perm ? (int64_t)A.pair_perm[it] : it;
+    if (A.recs) {
+        // the mates' records lie side by side: one aligned 128-byte stretch per pair instead of pieces of two arrays and
+        // four offset look-ups (the pairs are visited in locality order, i.e. scattered)
+        const uint8_t* rec = A.recs + (size_t)item * 128;
+        for (int s = 0; s < 2; ++s) {
+            rd[s].w = reinterpret_cast<const uint64_t*>(rec + 64 * s);
+            rd[s].len = (int)*reinterpret_cast<const uint32_t*>(rec + 64 * s + 60);
+            rd[s].flip = A.revcomp_mate2 && s == 1;
+            amb[s] = reinterpret_cast<const uint32_t*>(rec + 64 * s + 40);
+        }
+        return item;
+    }
     for (int s = 0; s < 2; ++s) {
         const int64_t r = 2 * item + s;
         const int64_t len = A.off[r + 1] - A.off[r];

@@ -379,6 +379,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     A.work_queue = nullptr;
     A.cseeds = nullptr; A.cseed_n = nullptr;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
+    A.recs = rs->has_recs && rs->packed ? rs->recs.p : nullptr;
     A.paired = paired ? 1 : 0;
     A.revcomp_mate2 = revcomp_mate2 ? 1 : 0;
     A.opt = al->opt;

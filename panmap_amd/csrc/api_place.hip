@@ -332,6 +332,8 @@ static int readset_finish(pmx_ctx* ctx, pmx_readset* rs, const int64_t* h_off) {
     PMX_HIP(hipMemcpyAsync(rs->woff.p, woff.data(), sizeof(int64_t) * ((size_t)rs->n + 1), hipMemcpyHostToDevice, ctx->stream));
     rs->words.alloc((size_t)w);
     rs->amb.alloc((size_t)w);
+    rs->has_recs = rs->n > 0 && maxlen <= 160;
+    if (rs->has_recs) rs->recs.alloc((size_t)rs->n * 64);
     PMX_HIP(hipStreamSynchronize(ctx->stream));
     return PMX_OK;
 }
@@ -424,6 +426,8 @@ int pmx_readset_rewrap_device(pmx_ctx* ctx, pmx_readset* rs, const void* d_conca
     rs->off0 = first;
     rs->words.ensure((size_t)std::max<int64_t>(h.n_words, 1));
     rs->amb.ensure((size_t)std::max<int64_t>(h.n_words, 1));
+    rs->has_recs = n_reads > 0 && rs->max_len <= 160;
+    if (rs->has_recs) rs->recs.ensure((size_t)n_reads * 64);
     return PMX_OK;
     PMX_CATCH
 }
@@ -448,12 +452,15 @@ int pmx_readset_pack(pmx_ctx* ctx, pmx_readset* rs) {
     timer_begin(ctx, "pack");
     // every read has max_len bases (total = n x max_len): the word -> read mapping is a division (k_pack_reads_fixed)
     const bool fixed = rs->n > 0 && rs->max_len > 0 && rs->total == rs->n * rs->max_len;
+    uint8_t* recs = rs->has_recs ? rs->recs.p : nullptr;
+    // (ragged sets: a read without a word gets no record written -- cleared first, so that it reads as length 0)
+    if (recs && !fixed) PMX_HIP(hipMemsetAsync(recs, 0, (size_t)rs->n * 64, ctx->stream));
     if (rs->n_words > 0 && fixed)
         hipLaunchKernelGGL(k_pack_reads_fixed, dim3(grid_for(rs->n_words, 256, 1 << 30)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off0, (int)rs->max_len,
-                           (int64_t)0, rs->n_words, rs->words.p, rs->amb.p);
+                           (int64_t)0, rs->n_words, rs->words.p, rs->amb.p, recs);
     else if (rs->n_words > 0)
         hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(rs->n_words, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p,
-                           rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p, (int64_t)0, (int64_t)-1);
+                           rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p, (int64_t)0, (int64_t)-1, recs);
     PMX_HIP(hipGetLastError());
     timer_end(ctx, "pack", 1);
     rs->packed = true;
@@ -475,8 +482,10 @@ int pmx_readset_pack_range(pmx_ctx* ctx, pmx_readset* rs, int64_t r0, int64_t r1
     if (r1 > r0 && rs->n_words > 0) {
         // grid sized by the range's share of the words (exact for reads of one length; any grid is correct: the kernel strides)
         const int64_t est = (int64_t)((double)rs->n_words * (double)(r1 - r0) / (double)std::max<int64_t>(rs->n, 1)) + 1;
+        // (a read without a word gets no record written: the range's records are cleared first)
+        if (rs->has_recs) PMX_HIP(hipMemsetAsync(rs->recs.p + (size_t)r0 * 64, 0, (size_t)(r1 - r0) * 64, ctx->stream));
         hipLaunchKernelGGL(k_pack_reads, dim3(grid_for(est, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, rs->ascii.p, rs->off.p,
-                           rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p, r0, r1);
+                           rs->woff.p, rs->n, rs->n_words, rs->words.p, rs->amb.p, r0, r1, rs->has_recs ? rs->recs.p : nullptr);
         PMX_HIP(hipGetLastError());
     }
     if (rs->packed) {   // re-packing part of a packed set: the order of those reads may have changed
@@ -745,7 +754,7 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
                 pl->t_len[j].ensure((size_t)n_tiles * 64); pl->t_mult[j].ensure((size_t)n_tiles * 64);
                 PMX_HIP(hipMemsetAsync(pl->t_count.p + j, 0, sizeof(unsigned long long), st));
                 hipLaunchKernelGGL(k_collapse_reads, dim3((unsigned)((n_c + PMX_DEDUP_BLOCK - 1) / PMX_DEDUP_BLOCK)), dim3(PMX_DEDUP_BLOCK), PMX_DEDUP_LDS_BYTES, st,
-                                   rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, keep, perm, sp.k, fixed_len, pl->t_words[j].p, pl->t_amb[j].p, pl->t_len[j].p,
+                                   rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, keep, perm, sp.k, fixed_len, rs->has_recs ? rs->recs.p : (const uint8_t*)nullptr, pl->t_words[j].p, pl->t_amb[j].p, pl->t_len[j].p,
                                    pl->t_mult[j].p, pl->t_count.p + j);
                 PMX_HIP(hipGetLastError());
                 hipLaunchKernelGGL((l == 3 ? k_seed_histogram_ks<19, 8, 3> : k_seed_histogram_ks<19, 8, 1>), grid, block, lds_ks, st, pl->t_words[j].p, pl->t_amb[j].p,

@@ -21,8 +21,8 @@ struct SeedParams {
 };
 
 __global__ void k_pack_reads(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int64_t n_reads, int64_t n_words,
-                             uint64_t* words, uint32_t* amb, int64_t r0, int64_t r1);
-__global__ void k_pack_reads_fixed(const uint8_t* ascii, int64_t off0, int len, int64_t w_lo, int64_t w_hi, uint64_t* words, uint32_t* amb);
+                             uint64_t* words, uint32_t* amb, int64_t r0, int64_t r1, uint8_t* recs);
+__global__ void k_pack_reads_fixed(const uint8_t* ascii, int64_t off0, int len, int64_t w_lo, int64_t w_hi, uint64_t* words, uint32_t* amb, uint8_t* recs);
 // read -> its number of 32-base words, plus the checks a wrapped read set needs (stats: [0] max length, [1] 1 if offsets are
 // not monotone or leave [0, total_bytes])
 __global__ void k_read_word_counts(const int64_t* off, int64_t n_reads, int64_t total_bytes, int64_t* nwords, unsigned long long* stats);
@@ -35,7 +35,7 @@ __global__ void k_seed_histogram_ks(const uint64_t* words, const uint32_t* amb, 
                                     unsigned long long* counters, const uint8_t* keep, const uint32_t* perm, const uint32_t* t_len,
                                     const uint32_t* t_mult, const unsigned long long* t_count);
 __global__ void k_collapse_reads(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin, int64_t r_end,
-                                 const uint8_t* keep, const uint32_t* perm, int min_len, int fixed_len, uint64_t* t_words, uint32_t* t_amb, uint32_t* t_len,
+                                 const uint8_t* keep, const uint32_t* perm, int min_len, int fixed_len, const uint8_t* recs, uint64_t* t_words, uint32_t* t_amb, uint32_t* t_len,
                                  uint32_t* t_mult, unsigned long long* n_out);
 __global__ void k_read_prefix_keys(const uint64_t* words, const int64_t* woff, int64_t r_begin, int64_t n_reads, uint32_t* key, uint32_t* idx);
 __global__ void k_read_hashes(const uint8_t* ascii, const int64_t* off, int64_t n_reads, uint64_t* h1, uint64_t* h2, uint32_t* idx);

@@ -39,10 +39,24 @@ __global__ void k_read_word_counts(const int64_t* __restrict__ off, int64_t n_re
     }
 }
 
+// word j of read r into the read's 64-byte record (reads of up to 160 bases: five words): 2-bit words at bytes 0..39,
+// ambiguity words at 40..59, the length at 60; the thread of word 0 also clears the slots the read does not use (records are
+// compared dword for dword by k_collapse_reads)
+__device__ __forceinline__ void pack_record(uint8_t* recs, int64_t r, int j, int len, uint64_t v, uint32_t a) {
+    if (len > 160 || j >= 5) return;
+    uint8_t* rec = recs + (size_t)r * 64;
+    reinterpret_cast<uint64_t*>(rec)[j] = v;
+    reinterpret_cast<uint32_t*>(rec + 40)[j] = a;
+    if (j == 0) {
+        reinterpret_cast<uint32_t*>(rec + 60)[0] = (uint32_t)len;
+        for (int q = (len + 31) >> 5; q < 5; ++q) { reinterpret_cast<uint64_t*>(rec)[q] = 0; reinterpret_cast<uint32_t*>(rec + 40)[q] = 0; }
+    }
+}
+
 // reads [r0, r1) only (r1 < 0: every read): the words woff[r0] .. woff[r1] - 1
 __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ off,
                              const int64_t* __restrict__ woff, int64_t n_reads, int64_t n_words,
-                             uint64_t* __restrict__ words, uint32_t* __restrict__ amb, int64_t r0, int64_t r1) {
+                             uint64_t* __restrict__ words, uint32_t* __restrict__ amb, int64_t r0, int64_t r1, uint8_t* __restrict__ recs) {
     const int64_t w_lo = r1 < 0 ? 0 : woff[r0], w_hi = r1 < 0 ? n_words : woff[r1];
     for (int64_t w = w_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w_hi; w += (int64_t)gridDim.x * blockDim.x) {
         // read r with woff[r] <= w < woff[r+1]: start from the proportional guess (exact for reads of one length: two
@@ -101,6 +115,7 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* _
         }
         words[w] = v;
         amb[w] = a;
+        if (recs) pack_record(recs, r, (int)(w - woff[r]), (int)len, v, a);
     }
 }
 
@@ -108,7 +123,7 @@ __global__ void k_pack_reads(const uint8_t* __restrict__ ascii, const int64_t* _
 // the word index by a division, and the word's 32 bytes arrive as three aligned 16-byte loads -- no offset look-ups, a
 // third of the load instructions: the kernel is a stream and sits near the device-to-device copy rate.
 __global__ void k_pack_reads_fixed(const uint8_t* __restrict__ ascii, int64_t off0, int len, int64_t w_lo, int64_t w_hi,
-                                   uint64_t* __restrict__ words, uint32_t* __restrict__ amb) {
+                                   uint64_t* __restrict__ words, uint32_t* __restrict__ amb, uint8_t* __restrict__ recs) {
     const int nw = (len + 31) >> 5;
     for (int64_t w = w_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < w_hi; w += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = w / nw;
@@ -155,6 +170,7 @@ __global__ void k_pack_reads_fixed(const uint8_t* __restrict__ ascii, int64_t of
         }
         words[w] = v;
         amb[w] = a;
+        if (recs) pack_record(recs, r, (int)(w - r * nw), len, v, a);
     }
 }
 
@@ -559,7 +575,7 @@ __device__ __forceinline__ void seed_queue_to_cache_and_table(uint64_t* queue, i
 __global__ void __launch_bounds__(PMX_DEDUP_BLOCK)
 k_collapse_reads(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff, const int64_t* __restrict__ off,
                  int64_t r_begin, int64_t r_end, const uint8_t* __restrict__ keep, const uint32_t* __restrict__ perm, int min_len, int fixed_len,
-                 uint64_t* __restrict__ t_words, uint32_t* __restrict__ t_amb, uint32_t* __restrict__ t_len, uint32_t* __restrict__ t_mult,
+                 const uint8_t* __restrict__ recs, uint64_t* __restrict__ t_words, uint32_t* __restrict__ t_amb, uint32_t* __restrict__ t_len, uint32_t* __restrict__ t_mult,
                  unsigned long long* n_out) {
     // dynamic LDS, PMX_DEDUP_LDS_BYTES (80 KB for 1,024 reads: two blocks per CU)
     extern __shared__ uint32_t lds32[];
@@ -578,6 +594,20 @@ k_collapse_reads(const uint64_t* __restrict__ words, const uint32_t* __restrict_
         const int64_t r = perm ? (int64_t)perm[j] : j;
         // fixed_len > 0: every read of the set has that many bases (the host knows: total = n x max), so the read's place in
         // the packed arrays follows from its index -- two scattered loads per read less
+        if (recs) {
+            // the read's record: one aligned 64-byte line, its length included (ragged sets: the host clears the records
+            // before packing, so a read without a single word -- length 0 -- reads as length 0)
+            const uint4* rp = reinterpret_cast<const uint4*>(recs + (size_t)r * 64);
+            const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+            const int64_t l64 = fixed_len > 0 ? (int64_t)fixed_len : (int64_t)q3.w;
+            if (l64 >= min_len && l64 <= 160 && !(keep && !keep[r])) {
+                w[0] = (uint64_t)q0.y << 32 | q0.x; w[1] = (uint64_t)q0.w << 32 | q0.z;
+                w[2] = (uint64_t)q1.y << 32 | q1.x; w[3] = (uint64_t)q1.w << 32 | q1.z;
+                w[4] = (uint64_t)q2.y << 32 | q2.x;
+                a[0] = q2.z; a[1] = q2.w; a[2] = q3.x; a[3] = q3.y; a[4] = q3.z;
+                len = (uint32_t)l64;
+            }
+        } else {
         const int64_t l64 = fixed_len > 0 ? (int64_t)fixed_len : off[r + 1] - off[r];
         if (l64 >= min_len && l64 <= 160 && !(keep && !keep[r])) {
             len = (uint32_t)l64;
@@ -588,6 +618,7 @@ k_collapse_reads(const uint64_t* __restrict__ words, const uint32_t* __restrict_
 #pragma unroll
             for (int q = 0; q < 5; ++q)
                 if (q < nw) { w[q] = rw[q]; a[q] = ra[q]; }
+        }
         }
     }
     uint32_t d[16];

@@ -41,6 +41,12 @@ struct pmx_readset {
     pmx::DevBuf<int64_t> woff;     // n+1 word offsets into words/amb
     pmx::DevBuf<uint64_t> words;   // 2 bits per base
     pmx::DevBuf<uint32_t> amb;     // 1 bit per base: not A/C/G/T
+    // Read RECORDS (reads of up to 160 bases): per read one aligned 64-byte line = its five 2-bit words, five ambiguity
+    // words and its length, written by the pack kernels next to the arrays above.  The kernels that visit reads in a
+    // scattered order (k_collapse_reads, the compact align tier) fetch ONE line per read instead of pieces of two arrays
+    // plus two offset look-ups (k_collapse_reads: 470 B fetched per read before, PMC)
+    pmx::DevBuf<uint8_t> recs;
+    bool has_recs = false;
     pmx::DevBuf<uint8_t> qual;     // optional: Phred+33 per base, same offsets as ascii (--min-seed-quality)
     bool has_qual = false;
     pmx::DevBuf<int64_t> nw_tmp;   // rewrap: words per read (scan input)
