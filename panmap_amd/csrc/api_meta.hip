@@ -49,6 +49,8 @@
 #include "device/dev_util.hpp"
 #include "host/index_build.hpp"
 #include "host/seed_host.hpp"
+#include "place_kernels.h"
+#include "readset.hpp"
 
 using namespace pmx;
 
@@ -226,6 +228,18 @@ __global__ void k_meta_colsum(const uint16_t* __restrict__ score, int n_cand, co
     }
     for (; j < j1; ++j) acc += weight[j] * (tab[tab_off[j] + score[(size_t)rows[j] * (size_t)n_cand + (size_t)c]] * pi * denom[j]);   // denom = 1 / denominator
     part[(size_t)blockIdx.y * (size_t)n_cols + (size_t)i] = acc;
+}
+
+// the seedmer lists of a chunk of reads from their slot stretches (k_seed_histogram, list mode: entry e of read r at
+// woff[r] * 32 + e) to contiguous arrays; eight lanes per read
+__global__ void __launch_bounds__(256) k_meta_gather_lists(const uint64_t* __restrict__ list_hash, const uint8_t* __restrict__ list_rev,
+                                                          const int64_t* __restrict__ woff, const int64_t* __restrict__ out_off, int64_t n_reads,
+                                                          uint64_t* __restrict__ out_hash, uint8_t* __restrict__ out_rev) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n_thr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = gid >> 3; r < n_reads; r += n_thr >> 3) {
+        const int64_t src = woff[r] * 32, dst = out_off[r], n = out_off[r + 1] - dst;
+        for (int64_t e = gid & 7; e < n; e += 8) { out_hash[dst + e] = list_hash[src + e]; out_rev[dst + e] = list_rev[src + e]; }
+    }
 }
 
 __global__ void k_meta_fold(const double* __restrict__ part, int n_chunks, int n_cols, double scale, double* out, const int* done) {
@@ -453,59 +467,136 @@ int pmx_meta_set_reads(pmx_ctx* ctx, pmx_meta* m, const char* concat, const int6
     PMX_HIP(hipSetDevice(ctx->device));
     const SyncmerParams p = m->params;
     const int l = p.l;
-    struct One { std::vector<uint64_t> hash; std::vector<uint8_t> rev; };
-    std::vector<One> per((size_t)n_reads);
+    // ---- the reads' seedmer lists ON THE DEVICE (round 4; src/mgsr.cpp:1774-2237): the reads are packed 2 bit/base like any
+    // read set and the generic seeding kernel runs in its list mode (k_seed_histogram: same syncmers, same k-min-mers as
+    // the place stage, orientation = R < F); a gather makes the lists contiguous.  Chunks of reads bound the list arrays
+    // (one slot per base).  The host only filters by DUST (integer state, a few operations per base) and merges equal lists.
     const double dust_thr = m->dust_threshold;
     std::vector<uint8_t> dusty(dust_thr < 100.0 ? (size_t)n_reads : 0, 0);
-    {
+    if (dust_thr < 100.0) {   // src/mgsr.cpp:1593-1594: a read with a non-zero score above the threshold is left out
         unsigned n_thr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         if (n_reads < 4096) n_thr = 1;
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < n_thr; ++t)
             pool.emplace_back([&, t]() {
-                std::vector<uint8_t> is_sync;
-                std::vector<uint64_t> sh, h;
                 for (int64_t r = (int64_t)t; r < n_reads; r += n_thr) {
-                    const int64_t len = offsets[r + 1] - offsets[r];
-                    if (dust_thr < 100.0) {   // src/mgsr.cpp:1593-1594: a read with a non-zero score above the threshold is left out
-                        const double d = pmx_read_dust(concat + offsets[r], len, 64);
-                        if (d != 0 && d > dust_thr) { dusty[(size_t)r] = 1; continue; }
-                    }
-                    host_syncmers(concat + offsets[r], len, p, is_sync, sh);
-                    h.clear();
-                    for (size_t i = 0; i < is_sync.size(); ++i)
-                        if (is_sync[i]) h.push_back(sh[i]);
-                    One& o = per[(size_t)r];
-                    for (size_t j = 0; j + (size_t)l <= h.size(); ++j) {
-                        uint64_t seed;
-                        bool rev;
-                        if (kminmer_seed(&h[j], p.k, l, &seed, false, &rev)) { o.hash.push_back(seed); o.rev.push_back(rev ? 1 : 0); }
-                    }
+                    const double d = pmx_read_dust(concat + offsets[r], offsets[r + 1] - offsets[r], 64);
+                    if (d != 0 && d > dust_thr) dusty[(size_t)r] = 1;
                 }
             });
         for (auto& th : pool) th.join();
     }
+    // the dusty reads leave the sample altogether (src/mgsr.cpp:1590-1597: they never enter seqToIndexVec), the overlap
+    // coefficients included: everything below sees the kept reads only
+    const int64_t n_raw = n_reads;
+    int64_t n_dusty = 0;
+    for (uint8_t d : dusty) n_dusty += d;
+    std::string kept_concat;
+    std::vector<int64_t> kept_off;
+    if (n_dusty > 0) {
+        kept_off.push_back(0);
+        for (int64_t r = 0; r < n_reads; ++r) {
+            if (dusty[(size_t)r]) continue;
+            kept_concat.append(concat + offsets[r], (size_t)(offsets[r + 1] - offsets[r]));
+            kept_off.push_back((int64_t)kept_concat.size());
+        }
+        concat = kept_concat.data();
+        offsets = kept_off.data();
+        n_reads = (int64_t)kept_off.size() - 1;
+        dusty.clear();
+    }
+    std::vector<int64_t> r_off((size_t)n_reads + 1, 0);   // flat seedmer lists of the raw reads
+    std::vector<uint64_t> r_hash;
+    std::vector<uint8_t> r_rev;
+    {
+        SeedParams sp;
+        sp.k = p.k; sp.s = p.s; sp.t = p.t; sp.l = l; sp.open = p.open ? 1 : 0; sp.trim_start = 0; sp.trim_end = 0;
+        const int w = sp.k - sp.s + 1;
+        const size_t lds = (size_t)(2 * w + l) * PMX_SEED_BLOCK * sizeof(uint64_t) + (size_t)(PMX_SEED_BLOCK / 64) * (PMX_SEED_QCAP * sizeof(uint64_t) + 8);
+        if (lds > 160 * 1024) return fail(PMX_ERR_UNSUPPORTED, "k-s+1 too large for the LDS ring");
+        if (lds > 64 * 1024) PMX_HIP(hipFuncSetAttribute((const void*)k_seed_histogram, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DevBuf<uint64_t> d_lh, d_oh;
+        DevBuf<uint8_t> d_lr, d_or, d_keep;
+        DevBuf<uint32_t> d_ln;
+        DevBuf<int64_t> d_ooff;
+        DevBuf<unsigned long long> d_ctr;
+        d_ctr.alloc(PMX_CTR_N);
+        PMX_HIP(hipMemsetAsync(d_ctr.p, 0, sizeof(unsigned long long) * PMX_CTR_N, ctx->stream));
+        const int64_t chunk = 2000000;
+        for (int64_t c0 = 0; c0 < n_reads; c0 += chunk) {
+            const int64_t c1 = std::min(n_reads, c0 + chunk), nc = c1 - c0;
+            pmx_readset* rs = nullptr;
+            int rc = pmx_readset_upload(ctx, concat, offsets + c0, nc, &rs);
+            if (rc != PMX_OK) return rc;
+            std::unique_ptr<pmx_readset, void (*)(pmx_readset*)> rs_guard(rs, [](pmx_readset* x) { delete x; });
+            rc = pmx_readset_pack(ctx, rs);
+            if (rc != PMX_OK) return rc;
+            const size_t slots = (size_t)std::max<int64_t>(rs->n_words, 1) * 32;
+            d_lh.ensure(slots); d_lr.ensure(slots); d_ln.ensure((size_t)nc);
+            PMX_HIP(hipMemsetAsync(d_ln.p, 0, sizeof(uint32_t) * (size_t)nc, ctx->stream));
+            const uint8_t* keep = nullptr;
+            if (!dusty.empty()) {
+                std::vector<uint8_t> k8((size_t)nc);
+                for (int64_t i = 0; i < nc; ++i) k8[(size_t)i] = dusty[(size_t)(c0 + i)] ? 0 : 1;
+                d_keep.ensure((size_t)nc);
+                PMX_HIP(hipMemcpyAsync(d_keep.p, k8.data(), (size_t)nc, hipMemcpyHostToDevice, ctx->stream));
+                PMX_HIP(hipStreamSynchronize(ctx->stream));   // (k8 goes out of scope)
+                keep = d_keep.p;
+            }
+            hipLaunchKernelGGL(k_seed_histogram, dim3(grid_for(nc, PMX_SEED_BLOCK, ctx->n_cu * 16)), dim3(PMX_SEED_BLOCK), lds, ctx->stream, rs->words.p, rs->amb.p,
+                               rs->woff.p, rs->off.p, (int64_t)0, nc, sp, (uint64_t*)nullptr, (unsigned long long*)nullptr, (uint64_t)0, d_ctr.p, keep,
+                               (const uint8_t*)nullptr, 0, d_lh.p, d_lr.p, d_ln.p);
+            PMX_HIP(hipGetLastError());
+            std::vector<uint32_t> h_n((size_t)nc);
+            PMX_HIP(hipMemcpyAsync(h_n.data(), d_ln.p, sizeof(uint32_t) * (size_t)nc, hipMemcpyDeviceToHost, ctx->stream));
+            PMX_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<int64_t> o_off((size_t)nc + 1, 0);
+            for (int64_t i = 0; i < nc; ++i) o_off[(size_t)i + 1] = o_off[(size_t)i] + (int64_t)h_n[(size_t)i];
+            const int64_t tot = o_off[(size_t)nc];
+            const size_t base = r_hash.size();
+            r_hash.resize(base + (size_t)tot);
+            r_rev.resize(base + (size_t)tot);
+            if (tot > 0) {
+                d_ooff.ensure((size_t)nc + 1); d_oh.ensure((size_t)tot); d_or.ensure((size_t)tot);
+                PMX_HIP(hipMemcpyAsync(d_ooff.p, o_off.data(), sizeof(int64_t) * ((size_t)nc + 1), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_meta_gather_lists, dim3(grid_for(nc * 8, 256, ctx->n_cu * 16)), dim3(256), 0, ctx->stream, d_lh.p, d_lr.p, rs->woff.p, d_ooff.p, nc,
+                                   d_oh.p, d_or.p);
+                PMX_HIP(hipGetLastError());
+                PMX_HIP(hipMemcpyAsync(r_hash.data() + base, d_oh.p, sizeof(uint64_t) * (size_t)tot, hipMemcpyDeviceToHost, ctx->stream));
+                PMX_HIP(hipMemcpyAsync(r_rev.data() + base, d_or.p, (size_t)tot, hipMemcpyDeviceToHost, ctx->stream));
+                PMX_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            for (int64_t i = 0; i < nc; ++i) r_off[(size_t)(c0 + i) + 1] = (int64_t)base + o_off[(size_t)i + 1];
+        }
+    }
     // reads with the same seedmer list (hash and orientation, in order) are one read with a multiplicity; a read without
     // seedmers scores 0 everywhere and carries no weight in the EM (src/mgsr.cpp:8170-8173): dropped here
+    struct View { const uint64_t* h; const uint8_t* v; int64_t n; };
+    auto view = [&](int64_t r) { return View{r_hash.data() + r_off[(size_t)r], r_rev.data() + r_off[(size_t)r], r_off[(size_t)r + 1] - r_off[(size_t)r]}; };
     std::vector<int64_t> order;
     for (int64_t r = 0; r < n_reads; ++r)
-        if (!per[(size_t)r].hash.empty()) order.push_back(r);
-    auto less = [&](int64_t a, int64_t b) {
-        const One &x = per[(size_t)a], &y = per[(size_t)b];
-        if (x.hash != y.hash) return x.hash < y.hash;
-        return x.rev < y.rev;
+        if (r_off[(size_t)r + 1] > r_off[(size_t)r]) order.push_back(r);
+    // (lexicographic on the hash list, then on the orientation list: the order the vector comparisons gave)
+    auto cmp3 = [&](int64_t a, int64_t b) {
+        const View x = view(a), y = view(b);
+        const int64_t nmin = std::min(x.n, y.n);
+        for (int64_t i = 0; i < nmin; ++i)
+            if (x.h[i] != y.h[i]) return x.h[i] < y.h[i] ? -1 : 1;
+        if (x.n != y.n) return x.n < y.n ? -1 : 1;
+        const int c = memcmp(x.v, y.v, (size_t)x.n);
+        return c < 0 ? -1 : c > 0 ? 1 : 0;
     };
-    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return less(a, b) || (!less(b, a) && a < b); });
-    m->n_raw_reads = n_reads;
-    m->n_dust_dropped = 0;
-    for (uint8_t d : dusty) m->n_dust_dropped += d;
+    auto less = [&](int64_t a, int64_t b) { return cmp3(a, b) < 0; };
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { const int c = cmp3(a, b); return c < 0 || (c == 0 && a < b); });
+    m->n_raw_reads = n_raw;
+    m->n_dust_dropped = n_dusty;
     m->h_read_off.assign(1, 0);
     m->h_seed_hash.clear(); m->h_seed_rev.clear(); m->h_mult.clear();
     for (size_t i = 0; i < order.size(); ++i) {
-        const One& o = per[(size_t)order[i]];
-        if (i > 0 && !less(order[i - 1], order[i]) && !less(order[i], order[i - 1])) { ++m->h_mult.back(); continue; }
-        m->h_seed_hash.insert(m->h_seed_hash.end(), o.hash.begin(), o.hash.end());
-        m->h_seed_rev.insert(m->h_seed_rev.end(), o.rev.begin(), o.rev.end());
+        const View o = view(order[i]);
+        if (i > 0 && cmp3(order[i - 1], order[i]) == 0) { ++m->h_mult.back(); continue; }
+        m->h_seed_hash.insert(m->h_seed_hash.end(), o.h, o.h + o.n);
+        m->h_seed_rev.insert(m->h_seed_rev.end(), o.v, o.v + o.n);
         m->h_read_off.push_back((int64_t)m->h_seed_hash.size());
         m->h_mult.push_back(1);
     }

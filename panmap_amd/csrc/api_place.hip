@@ -767,7 +767,7 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
             else
                 hipLaunchKernelGGL(k_seed_histogram, grid, block, lds, st, rs->words.p, rs->amb.p, rs->woff.p, rs->off.p, r0, r1, sp, pl->keys.p,
                                    pl->vals.p, pl->cap - 1, pl->counters.p, keep, quality_mode ? rs->qual.p : nullptr,
-                                   quality_mode ? pp->min_seed_quality : 0);
+                                   quality_mode ? pp->min_seed_quality : 0, (uint64_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
             PMX_HIP(hipGetLastError());
             if (j > 0) {
                 PMX_HIP(hipEventRecord(ctx->seed_done[j - 1], st));

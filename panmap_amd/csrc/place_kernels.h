@@ -28,7 +28,7 @@ __global__ void k_pack_reads_fixed(const uint8_t* ascii, int64_t off0, int len, 
 __global__ void k_read_word_counts(const int64_t* off, int64_t n_reads, int64_t total_bytes, int64_t* nwords, unsigned long long* stats);
 __global__ void k_seed_histogram(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin, int64_t n_reads,
                                  SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask, unsigned long long* counters,
-                                 const uint8_t* keep, const uint8_t* qual, int min_q);
+                                 const uint8_t* keep, const uint8_t* qual, int min_q, uint64_t* list_hash, uint8_t* list_rev, uint32_t* list_n);
 template <int K, int S, int L>
 __global__ void k_seed_histogram_ks(const uint64_t* words, const uint32_t* amb, const int64_t* woff, const int64_t* off, int64_t r_begin,
                                     int64_t n_reads, SeedParams sp, uint64_t* keys, unsigned long long* vals, uint64_t mask,

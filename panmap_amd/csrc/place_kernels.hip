@@ -320,7 +320,12 @@ __global__ void __launch_bounds__(PMX_SEED_BLOCK)
 k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict__ amb, const int64_t* __restrict__ woff,
                  const int64_t* __restrict__ off, int64_t r_begin, int64_t n_reads, SeedParams sp, uint64_t* keys,
                  unsigned long long* vals, uint64_t mask, unsigned long long* counters, const uint8_t* __restrict__ keep,
-                 const uint8_t* __restrict__ qual, int min_q) {
+                 const uint8_t* __restrict__ qual, int min_q, uint64_t* __restrict__ list_hash, uint8_t* __restrict__ list_rev,
+                 uint32_t* __restrict__ list_n) {
+    // list_hash != NULL (--meta, src/mgsr.cpp:1774-2237): no histogram -- every read's seedmers go, in read order and with
+    // their orientation (the k-min-mer read right to left is the smaller one: R < F), to the read's own stretch of the list
+    // arrays: entry e of read r at woff[r] * 32 + e (a read has fewer seedmers than bases), their number to list_n[r]
+    // (cleared by the host: a read too short for a k-mer writes nothing).  l >= 2, no quality filter.
     extern __shared__ uint64_t lds[];
     const int w = sp.k - sp.s + 1;
     const int l = sp.l < 1 ? 1 : sp.l;
@@ -371,6 +376,7 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
         int slot_w = 0;                        // (i - s + 1) mod w
         int s_first = first0, s_last = last0;  // (ks + t) mod w, (ks + k - s - t) mod w
         int slot_l = 0;                        // (n_sync - 1) mod l
+        uint32_t n_list = 0;                   // list mode: seedmers of this read so far
         // --min-seed-quality (src/placement.cpp:1386-1527): rolling sum of (qual - 33) over the k-mer, and the number
         // of consecutive syncmers (of the read's FULL syncmer list) that passed the trim + quality test
         const uint8_t* rq = qual ? qual + off[r] : nullptr;
@@ -478,10 +484,16 @@ k_seed_histogram(const uint64_t* __restrict__ words, const uint32_t* __restrict_
             ringS[(size_t)slot_l * PMX_SEED_BLOCK + tid] = h;
             slot_l = slot_l + 1 == l ? 0 : slot_l + 1;
             if (have && F != R) {
-                enqueue(F < R ? F : R);
+                if (list_hash) {
+                    const int64_t at = woff[r] * 32 + (int64_t)n_list;
+                    list_hash[at] = F < R ? F : R;
+                    list_rev[at] = R < F ? 1 : 0;
+                    ++n_list;
+                } else enqueue(F < R ? F : R);
                 ++n_seeds;
             }
         }
+        if (list_n) list_n[r] = n_list;
     }
     drain();   // every lane of the wave is here
     // one atomic per wave: a per-thread atomic on this single word was the whole cost of the kernel
