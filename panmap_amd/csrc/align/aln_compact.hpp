@@ -294,6 +294,7 @@ struct CList {
     int base, shift;
     PMX_HD int32_t x(int i) const { return (int32_t)CMemT<PT>::pos_of(m.X((int)m.G(base + i))); }
     PMX_HD int32_t y(int i) const { return (int32_t)(m.Y((int)m.G(base + i)) & 0x3ffu) - shift; }
+    PMX_HD uint32_t rev(int i) const { return CMemT<PT>::rev_of(m.X((int)m.G(base + i))); }
 };
 
 // mm_cal_fuzzy_len + mm_reg_set_coor (hit.c:8-40) on a per-mate anchor list
@@ -361,8 +362,12 @@ struct CRefFn {
 // mm_align1 (align.c:575-833) for a region that is its mate's only one (as == 0, n_a == cnt): every extension / fill is
 // answered by the closed forms or the pair bails.  All three lie on the diagonal of the first kept anchor, so one
 // mismatch mask per mate serves them and the statistics pass.
-template <class PT>
-PMX_HD int c_align1(const CList<PT>& al, const Opt& o, const RefIndex& ri, const CRead& rd, int qlen, CReg& r) {
+// MULTI (aln_compact_multi.hpp): the region is one of several of its mate; `al` is still the region's own list, `mate`
+// the mate's whole anchor list (n_a entries, the region's at [as, as + cnt)): neighbouring chains of the same strand
+// fence the end extensions off (align.c:636-691; extension_reach, aln_align.hpp).
+template <class PT, bool MULTI = false>
+PMX_HD int c_align1(const CList<PT>& al, const Opt& o, const RefIndex& ri, const CRead& rd, int qlen, CReg& r, const CList<PT>* mate = nullptr, int as = 0,
+                    int n_a = 0) {
     const int span = o.k;
     const int32_t rev = r.rev;
     const int32_t ref_len = ri.len;
@@ -383,6 +388,46 @@ PMX_HD int c_align1(const CList<PT>& al, const Opt& o, const RefIndex& ri, const
     int32_t rs = al.x(as1) - (o.k >> 1), qs = al.y(as1) - (o.k >> 1);                           // mm_adjust_minier, non-HPC
     int32_t re = al.x(as1 + cnt1 - 1) - (o.k >> 1), qe = al.y(as1 + cnt1 - 1) - (o.k >> 1);
     int32_t l, rs0, re0, qs0, qe0, rs1, qs1, re1, qe1;
+    if (MULTI) {
+        const int32_t own_t0 = al.x(0) + 1 - span, own_q0 = al.y(0) + 1 - span;
+        const int32_t own_t = own_t0 < 0 ? 0 : own_t0;
+        if (qs > 0 && rs > 0) {
+            Reach fence{qs, rs};
+            int seen = 0;
+            for (int32_t i = as - 1; i >= 0 && (int32_t)mate->rev(i) == rev; --i) {
+                const int32_t t_i = mate->x(i) + 1 - span, q_i = mate->y(i) + 1 - span;
+                if (t_i >= own_t || q_i >= own_q0) continue;
+                if (++seen > o.min_cnt) {
+                    const int32_t back = own_t - t_i > own_q0 - q_i ? own_t - t_i : own_q0 - q_i;
+                    fence.q = qs - (own_q0 - back);
+                    fence.t = rs - (own_t - back);
+                    break;
+                }
+            }
+            const Reach rch = extension_reach(o, qs, rs, fence, Reach{qs - own_q0, rs - own_t});
+            qs0 = qs - rch.q;
+            rs0 = rs - (rch.t < 0 ? 0 : rch.t);
+        } else { rs0 = rs; qs0 = qs; }
+        const int32_t own_t1 = al.x(r.cnt - 1) + 1, own_q1 = al.y(r.cnt - 1) + 1;
+        if (qe < qlen && re < ref_len) {
+            Reach fence{qlen - qe, ref_len - re};
+            int seen = 0;
+            for (int32_t i = as + r.cnt; i < n_a && (int32_t)mate->rev(i) == rev; ++i) {
+                const int32_t t_i = mate->x(i) + 1, q_i = mate->y(i) + 1;
+                if (t_i <= own_t1 || q_i <= own_q1) continue;
+                if (++seen > o.min_cnt) {
+                    const int32_t ahead = t_i - own_t1 > q_i - own_q1 ? t_i - own_t1 : q_i - own_q1;
+                    fence.q = own_q1 + ahead - qe;
+                    fence.t = own_t1 + ahead - re;
+                    break;
+                }
+            }
+            const Reach rch = extension_reach(o, qlen - qe, ref_len - re, fence, Reach{own_q1 - qe, own_t1 - re});
+            qe0 = qe + rch.q;
+            re0 = re + rch.t;
+        } else { re0 = re; qe0 = qe; }
+        rs1 = qs1 = re1 = qe1 = 0; l = 0; (void)l;
+    } else {
     // region to align (align.c:636-691); the region is the only one of its list: no neighbouring anchors to stop at
     rs0 = al.x(0) + 1 - span;
     qs0 = al.y(0) + 1 - span;
@@ -412,6 +457,7 @@ PMX_HD int c_align1(const CList<PT>& al, const Opt& o, const RefIndex& ri, const
         re1 = re1 < re + l ? re1 : re + l;
         re0 = re0 > re1 ? re0 : re1;
     } else { re0 = re; qe0 = qe; }
+    }
     if (re0 <= rs0 || qs0 < 0 || qe0 > qlen) return PMX_C_BAIL;
 
     // one mismatch mask for the whole mate along the diagonal of the first kept anchor
@@ -758,7 +804,14 @@ PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, con
     return PMX_C_DONE;
 }
 
-template <class PT>
+}  // namespace aln
+}  // namespace pmx
+#include "aln_compact_multi.hpp"
+namespace pmx {
+namespace aln {
+
+// MULTI: follow up to PMX_CM_MAXC fragment chains and several regions per mate (compact_regions_multi) instead of bailing
+template <class PT, bool MULTI = false>
 PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_s, int n_s0, CResult& out, const CPenTab& pen_tab,
                                unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false) {
     typedef CMemT<PT> MT;
@@ -1041,6 +1094,8 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
     int n_u = 0;
     int32_t u_sc0 = 0, u_sc1 = 0;
     uint64_t keep0 = 0, keep1 = 0;   // the members of the two chains (a chain walks to ever smaller indices: the set is the list)
+    int32_t u_scm[MULTI ? PMX_CM_MAXC : 1];
+    uint64_t u_keepm[MULTI ? PMX_CM_MAXC : 1];
     {
         uint64_t used = 0;
         int n_v = 0;
@@ -1072,8 +1127,12 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
             used |= keep;
             n_v = n_v0 + cnt;
             if (max_s >= min_sc && cnt > 0 && cnt >= min_cnt) {
-                if (n_u >= 2) return PMX_C_BAIL;   // a third chain: general tier
-                if (n_u == 0) { u_sc0 = max_s; keep0 = keep; }
+                if (n_u >= (MULTI ? PMX_CM_MAXC : 2)) return PMX_C_BAIL;   // a third (fifth) chain: general tier
+                if (MULTI) {
+#pragma unroll
+                    for (int q = 0; q < (MULTI ? PMX_CM_MAXC : 1); ++q)
+                        if (q == n_u) { u_scm[q] = max_s; u_keepm[q] = keep; }
+                } else if (n_u == 0) { u_sc0 = max_s; keep0 = keep; }
                 else { u_sc1 = max_s; keep1 = keep; }
                 ++n_u;
             } else n_v = n_v0;
@@ -1081,6 +1140,7 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
     }
     if (n_u == 0) return PMX_C_DONE;   // unmapped
     PMX_C_STAMP(4);
+    if (MULTI) return compact_regions_multi(m, o, ri, rd, n_u, u_scm, u_keepm, max_chain_gap_ref, out, want_edits);
 
     // ---------------------------------------------------------------- chains -> one region per mate (hit.c:54-94, 345-400)
     // anchors of segment s in chain c; a mate followed here has exactly one chain (then regs0's parent / secondary logic
@@ -1176,14 +1236,14 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
     return PMX_C_DONE;
 }
 
-template <class PT>
+template <class PT, bool MULTI = false>
 PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
                              const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false) {
     out.mapped = 0;
     out.edit[0] = rd[0].len; out.edit[1] = rd[1].len;
     int n_s = 0, n_s0 = 0;
     if (compact_seed_pair(m, o, ri, rd, amb, &n_s, &n_s0, prof, prof_on) != PMX_C_DONE) return PMX_C_BAIL;
-    return compact_chain_pair(m, o, ri, rd, n_s, n_s0, out, pen_tab, prof, want_edits, prof_on);
+    return compact_chain_pair<PT, MULTI>(m, o, ri, rd, n_s, n_s0, out, pen_tab, prof, want_edits, prof_on);
 }
 
 }  // namespace aln

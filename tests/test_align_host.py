@@ -157,6 +157,50 @@ def test_compact_tier_equals_reference(pmx, oracle, cases):
             os.environ.pop("PMX_HS_COMPACT_POS32", None)
 
 
+def test_compact_tier_several_regions_per_mate(cases, pmx, oracle):
+    """the compact tier's second form (align/aln_compact_multi.hpp, k_align_compact16_multi): up to four fragment chains and
+    several regions per mate -- what mates that overlap on the reference produce (amplicon reads: 55 % of the real example
+    pairs leave the one-region form for that reason).  Every pair it finishes carries the reference's record; it finishes
+    every pair the one-region form finishes, with the same record, and most of the real pairs; short inserts (mates that
+    overlap by design) and the two-kernel / 32-bit position forms included"""
+    import os
+    g, sets = cases
+    concat, off = pmx.simulate_paired_reads(g, 4000, seed=15, mean_insert=160.0, sd_insert=25.0, sub_rate=0.004)
+    raw = [bytes(concat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+    short_inserts = [r if i % 2 == 0 else pmx.reverse_complement(r) for i, r in enumerate(raw)]
+    seqs, _, _ = pmx.read_fastq_paired(os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz"))
+    floors = {"real": 0.60, "synthetic": 0.0, "real_as_sequenced": 0.0, "short_inserts": 0.5, "real_all": 0.70}
+    todo = dict(sets, short_inserts=short_inserts, real_all=seqs)
+    try:
+        for name, reads in todo.items():
+            want = oracle.ref_align_reads_direct(g, reads, True, 8)
+            os.environ.pop("PMX_HS_COMPACT_MULTI", None)
+            one, done_one = ac.hostsim_align_compact(g, reads)
+            os.environ["PMX_HS_COMPACT_MULTI"] = "1"
+            got, done = ac.hostsim_align_compact(g, reads)
+            idx = [i for i in range(len(want)) if done[i]]
+            bad = ac.compare_results([got[i] for i in idx], [want[i] for i in idx])
+            assert not bad, (name, bad[:10])
+            assert len(idx) >= floors[name] * len(want), (name, len(idx), len(want))
+            assert np.all(done[done_one == 1] == 1), name
+            if name == "real_all":
+                assert done.sum() > 2 * done_one.sum()
+                continue
+            for pos32 in (False, True):
+                if pos32:
+                    os.environ["PMX_HS_COMPACT_POS32"] = "1"
+                os.environ["PMX_HS_COMPACT_SPLIT"] = "1"
+                split, done_s = ac.hostsim_align_compact(g, reads)
+                del os.environ["PMX_HS_COMPACT_SPLIT"]
+                fused, done_f = ac.hostsim_align_compact(g, reads)
+                os.environ.pop("PMX_HS_COMPACT_POS32", None)
+                assert np.array_equal(done_s, done) and np.array_equal(done_f, done), (name, pos32)
+                assert not ac.compare_results(split, got) and not ac.compare_results(fused, got), (name, pos32)
+    finally:
+        for k in ("PMX_HS_COMPACT_MULTI", "PMX_HS_COMPACT_SPLIT", "PMX_HS_COMPACT_POS32"):
+            os.environ.pop(k, None)
+
+
 def test_compact_tier_seed_order_merge_and_heap(pmx, oracle):
     """the compact tier orders a pair's seeds by a two-way merge when they are two strictly monotone runs without equal
     reference position words and by the reference's heap (map.c:102-166) otherwise: short inserts make the mates overlap
