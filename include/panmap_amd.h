@@ -497,7 +497,8 @@ int64_t pmx_options_describe(char *buf, int64_t cap);
 
 /* kernel timing: average duration (ms) of the dominant kernel of the last call, measured with HIP
    events on the context stream; name selects a stage ("pack", "seed", "score", "align") or a kernel of the align stage
-   ("align_cseeds" = k_compact_seeds*, "align_dom" = the mapping kernel over every pair); < 0: no such span in the last call */
+   ("align_cseeds" = k_compact_seeds*, "align_dom" = the mapping kernel over every pair, "align_cmulti" = the compact
+   tier's second form, k_align_compact*_multi); < 0: no such span in the last call */
 double pmx_last_kernel_ms(pmx_ctx *ctx, const char *name);
 
 #ifdef __cplusplus

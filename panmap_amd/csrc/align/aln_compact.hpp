@@ -813,7 +813,7 @@ namespace aln {
 // MULTI: follow up to PMX_CM_MAXC fragment chains and several regions per mate (compact_regions_multi) instead of bailing
 template <class PT, bool MULTI = false>
 PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_s, int n_s0, CResult& out, const CPenTab& pen_tab,
-                               unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false) {
+                               unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false, const SWork* mw = nullptr) {
     typedef CMemT<PT> MT;
     out.mapped = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1094,8 +1094,7 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
     int n_u = 0;
     int32_t u_sc0 = 0, u_sc1 = 0;
     uint64_t keep0 = 0, keep1 = 0;   // the members of the two chains (a chain walks to ever smaller indices: the set is the list)
-    int32_t u_scm[MULTI ? PMX_CM_MAXC : 1];
-    uint64_t u_keepm[MULTI ? PMX_CM_MAXC : 1];
+
     {
         uint64_t used = 0;
         int n_v = 0;
@@ -1128,11 +1127,8 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
             n_v = n_v0 + cnt;
             if (max_s >= min_sc && cnt > 0 && cnt >= min_cnt) {
                 if (n_u >= (MULTI ? PMX_CM_MAXC : 2)) return PMX_C_BAIL;   // a third (fifth) chain: general tier
-                if (MULTI) {
-#pragma unroll
-                    for (int q = 0; q < (MULTI ? PMX_CM_MAXC : 1); ++q)
-                        if (q == n_u) { u_scm[q] = max_s; u_keepm[q] = keep; }
-                } else if (n_u == 0) { u_sc0 = max_s; keep0 = keep; }
+                if (MULTI) { mw->I(PMX_CMI_USC + n_u) = (uint32_t)max_s; s_set64(*mw, PMX_CMI_UKEEP + 2 * n_u, keep); }
+                else if (n_u == 0) { u_sc0 = max_s; keep0 = keep; }
                 else { u_sc1 = max_s; keep1 = keep; }
                 ++n_u;
             } else n_v = n_v0;
@@ -1140,7 +1136,7 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
     }
     if (n_u == 0) return PMX_C_DONE;   // unmapped
     PMX_C_STAMP(4);
-    if (MULTI) return compact_regions_multi(m, o, ri, rd, n_u, u_scm, u_keepm, max_chain_gap_ref, out, want_edits);
+    if (MULTI) return compact_regions_multi(*mw, m, o, ri, rd, n_u, max_chain_gap_ref, out, want_edits);
 
     // ---------------------------------------------------------------- chains -> one region per mate (hit.c:54-94, 345-400)
     // anchors of segment s in chain c; a mate followed here has exactly one chain (then regs0's parent / secondary logic
@@ -1238,12 +1234,12 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
 
 template <class PT, bool MULTI = false>
 PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
-                             const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false) {
+                             const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false, const SWork* mw = nullptr) {
     out.mapped = 0;
     out.edit[0] = rd[0].len; out.edit[1] = rd[1].len;
     int n_s = 0, n_s0 = 0;
     if (compact_seed_pair(m, o, ri, rd, amb, &n_s, &n_s0, prof, prof_on) != PMX_C_DONE) return PMX_C_BAIL;
-    return compact_chain_pair<PT, MULTI>(m, o, ri, rd, n_s, n_s0, out, pen_tab, prof, want_edits, prof_on);
+    return compact_chain_pair<PT, MULTI>(m, o, ri, rd, n_s, n_s0, out, pen_tab, prof, want_edits, prof_on, mw);
 }
 
 }  // namespace aln

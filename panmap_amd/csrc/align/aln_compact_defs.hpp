@@ -14,3 +14,8 @@
 #define PMX_C_PEN_SAME 128
 #define PMX_C_PEN_DIFF 1024
 #define PMX_C_PEN_BYTES (PMX_C_PEN_SAME + PMX_C_PEN_DIFF)
+// second form of the tier (several regions per mate, aln_compact_multi.hpp): its workspace in HBM
+#define PMX_CM_MAXC 4            // fragment chains of a pair (and therefore regions per mate) this form follows
+#define PMX_CM_SREGS (4 * PMX_CM_MAXC)   // region records per pair: fragment chains, mate 0, mate 1, the sorter's copy (24 words each)
+#define PMX_CM_INTS 64           // index words per pair
+#define PMX_CM_WS_WORDS (PMX_CM_SREGS * 24 + PMX_CM_INTS)   // 4-byte words per pair (x 64 lanes per wave: 114,688 bytes)

@@ -9,16 +9,59 @@
 // included by aln_compact.hpp (needs CList, CReg, c_align1, c_reg_set_coor)
 #pragma once
 
-#define PMX_CM_MAXC 4   // fragment chains of a pair (and therefore regions per mate) this form follows
 
 namespace pmx {
 namespace aln {
 
+// The region record.  On the device the records live in a per-wave workspace in HBM, STRIDED like Reg in the thread-per-pair
+// kernel (aln_types.hpp): every 4-byte field is followed by 252 bytes that belong to the other lanes, so that a wave touching
+// one field of its 64 records touches 256 contiguous bytes while the code keeps plain struct syntax (copies are field-wise).
+// (As private arrays the records were 1.7 KB of scratch per lane: a dispatch of that size makes the runtime allocate and
+// release the scratch around every launch, which serialised the two batches in flight -- bench `value` 320 -> 215 M reads/s.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PMX_CM_STRIDE 64
+#define PMX_SP(n) char pad_##n[252];
+#else
+#define PMX_CM_STRIDE 1
+#define PMX_SP(n)
+#endif
+#define PMX_SREG_FIELDS(X)                                                                                                          \
+    X(id) X(cnt) X(score) X(qs) X(qe) X(rs) X(re) X(parent) X(subsc) X(as) X(mlen) X(blen) X(n_sub) X(score0) X(hash) X(mapq) X(rev) \
+    X(sam_pri) X(proper_frag) X(has_p) X(dp_score) X(dp_max) X(dp_max2) X(m_len)
 struct SReg {
-    int32_t id, cnt, score, qs, qe, rs, re, parent, subsc, as, mlen, blen, n_sub, score0;
-    uint32_t hash;
-    int32_t mapq, rev, sam_pri, proper_frag, has_p, dp_score, dp_max, dp_max2, m_len;
+    int32_t id; PMX_SP(0) int32_t cnt; PMX_SP(1) int32_t score; PMX_SP(2) int32_t qs; PMX_SP(3) int32_t qe; PMX_SP(4) int32_t rs; PMX_SP(5)
+    int32_t re; PMX_SP(6) int32_t parent; PMX_SP(7) int32_t subsc; PMX_SP(8) int32_t as; PMX_SP(9) int32_t mlen; PMX_SP(10) int32_t blen; PMX_SP(11)
+    int32_t n_sub; PMX_SP(12) int32_t score0; PMX_SP(13) uint32_t hash; PMX_SP(14) int32_t mapq; PMX_SP(15) int32_t rev; PMX_SP(16)
+    int32_t sam_pri; PMX_SP(17) int32_t proper_frag; PMX_SP(18) int32_t has_p; PMX_SP(19) int32_t dp_score; PMX_SP(20) int32_t dp_max; PMX_SP(21)
+    int32_t dp_max2; PMX_SP(22) int32_t m_len; PMX_SP(23)
+#if defined(__HIP_DEVICE_COMPILE__)
+    SReg() = default;
+#define PMX_X(f) f = o.f;
+    __device__ __forceinline__ SReg(const SReg& o) { PMX_SREG_FIELDS(PMX_X) }
+    __device__ __forceinline__ SReg& operator=(const SReg& o) { PMX_SREG_FIELDS(PMX_X) return *this; }
+#undef PMX_X
+#endif
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+static_assert(sizeof(SReg) == 24 * 256, "strided SReg layout");
+#else
+static_assert(sizeof(SReg) == 24 * 4, "SReg has 24 four-byte fields");
+#endif
+// a pair's workspace: the records and a few short index lists (word i of the lane at ints[i * PMX_CM_STRIDE])
+struct SWork {
+    SReg* regs;
+    uint32_t* ints;
+    PMX_HD uint32_t& I(int i) const { return ints[i * PMX_CM_STRIDE]; }
+};
+// places in SWork::ints
+#define PMX_CMI_PRI 0        // [4] set_parent: the primaries so far
+#define PMX_CMI_NOW 4        // [4] sync_regs: id -> position
+#define PMX_CMI_HI 8         // [16] pair_hits: the pair scores
+#define PMX_CMI_ORD 24       // [4] chains by position
+#define PMX_CMI_KEY 28       // [8] order keys (low, high)
+#define PMX_CMI_KEEP 36      // [8] member sets of the fragment regions (low, high)
+#define PMX_CMI_AS 44        // [4] per-mate chain lists: offset
+#define PMX_CMI_CNT 48       // [4] anchors
 
 PMX_HD uint32_t c_wang_hash(uint32_t key) {   // __ac_Wang_hash (khash.h)
     key += ~(key << 15);
@@ -31,20 +74,20 @@ PMX_HD uint32_t c_wang_hash(uint32_t key) {   // __ac_Wang_hash (khash.h)
 }
 
 PMX_HD void s_clear(SReg& r) {
-    r.id = r.cnt = r.score = r.qs = r.qe = r.rs = r.re = r.subsc = r.as = r.mlen = r.blen = r.n_sub = r.score0 = 0;
+#define PMX_X(f) r.f = 0;
+    PMX_SREG_FIELDS(PMX_X)
+#undef PMX_X
     r.parent = PMX_PARENT_UNSET;
-    r.hash = 0;
-    r.mapq = r.rev = r.sam_pri = r.proper_frag = r.has_p = r.dp_score = r.dp_max = r.dp_max2 = r.m_len = 0;
 }
 
 // the part of [qs, qe) no primary covers (see uncovered_by_primaries, aln_hit.hpp)
-PMX_HD int32_t s_uncovered(const SReg* r, const int* pri, int n_pri, int32_t qs, int32_t qe) {
+PMX_HD int32_t s_uncovered(const SWork& W, const SReg* r, int n_pri, int32_t qs, int32_t qe) {
     int32_t reach = qs, uncovered = 0;
     int64_t last = -1;
     for (;;) {
         int64_t next = INT64_MAX;
         for (int j = 0; j < n_pri; ++j) {
-            const SReg& p = r[pri[j]];
+            const SReg& p = r[W.I(PMX_CMI_PRI + j)];
             if (p.qe <= qs || p.qs >= qe) continue;
             const int64_t v = (int64_t)(p.qs > qs ? p.qs : qs) << 32 | (uint32_t)(p.qe < qe ? p.qe : qe);
             if (v > last && v < next) next = v;
@@ -60,23 +103,22 @@ PMX_HD int32_t s_uncovered(const SReg* r, const int* pri, int n_pri, int32_t qs,
 }
 
 // mm_set_parent (hit.c:132-191)
-PMX_HD void s_set_parent(float mask_level, int mask_len, int n, SReg* r, int sub_diff) {
+PMX_HD void s_set_parent(const SWork& W, float mask_level, int mask_len, int n, SReg* r, int sub_diff) {
     if (n <= 0) return;
     for (int i = 0; i < n; ++i) r[i].id = i;
-    int pri[PMX_CM_MAXC];
     int n_pri = 1;
-    pri[0] = 0;
+    W.I(PMX_CMI_PRI) = 0;
     r[0].parent = 0;
     for (int i = 1; i < n; ++i) {
         SReg& me = r[i];
         const int32_t qs = me.qs, qe = me.qe, my_len = qe - qs;
         bool touches = false;
-        for (int j = 0; j < n_pri && !touches; ++j) touches = !(r[pri[j]].qe <= qs || r[pri[j]].qs >= qe);
+        for (int j = 0; j < n_pri && !touches; ++j) { const SReg& p = r[W.I(PMX_CMI_PRI + j)]; touches = !(p.qe <= qs || p.qs >= qe); }
         int owner = -1;
         if (touches) {
-            const int32_t uncov = s_uncovered(r, pri, n_pri, qs, qe);
+            const int32_t uncov = s_uncovered(W, r, n_pri, qs, qe);
             for (int j = 0; j < n_pri; ++j) {
-                const SReg& p = r[pri[j]];
+                const SReg& p = r[W.I(PMX_CMI_PRI + j)];
                 if (p.qe <= qs || p.qs >= qe) continue;
                 const int32_t p_len = p.qe - p.qs;
                 const int32_t shorter = p_len < my_len ? p_len : my_len, longer = p_len > my_len ? p_len : my_len;
@@ -86,12 +128,12 @@ PMX_HD void s_set_parent(float mask_level, int mask_len, int n, SReg* r, int sub
             }
         }
         if (owner < 0) {
-            pri[n_pri++] = i;
+            W.I(PMX_CMI_PRI + n_pri++) = (uint32_t)i;
             me.parent = i;
             me.n_sub = 0;
             continue;
         }
-        SReg& p = r[pri[owner]];
+        SReg& p = r[W.I(PMX_CMI_PRI + owner)];
         const int32_t p_len = p.qe - p.qs;
         const int32_t shorter = p_len < my_len ? p_len : my_len;
         const int32_t lo = qs > p.qs ? qs : p.qs, hi = qe < p.qe ? qe : p.qe;
@@ -118,38 +160,37 @@ PMX_HD void s_set_sam_pri(int n, SReg* r) {
 }
 
 // mm_sync_regs (hit.c:239-262); ids of a list never exceed its original length
-PMX_HD void s_sync_regs(int n, SReg* r) {
+PMX_HD void s_sync_regs(const SWork& W, int n, SReg* r) {
     if (n <= 0) return;
-    int now_at[PMX_CM_MAXC];
-    for (int i = 0; i < PMX_CM_MAXC; ++i) now_at[i] = -1;
+    for (int i = 0; i < PMX_CM_MAXC; ++i) W.I(PMX_CMI_NOW + i) = 0xffffffffu;
     for (int i = 0; i < n; ++i)
-        if (r[i].id >= 0 && r[i].id < PMX_CM_MAXC) now_at[r[i].id] = i;
+        if (r[i].id >= 0 && r[i].id < PMX_CM_MAXC) W.I(PMX_CMI_NOW + r[i].id) = (uint32_t)i;
     for (int i = 0; i < n; ++i) {
         const int32_t par = r[i].parent;
         r[i].id = i;
-        r[i].parent = (par >= 0 && par < PMX_CM_MAXC && now_at[par] >= 0) ? now_at[par] : PMX_PARENT_UNSET;
+        r[i].parent = (par >= 0 && par < PMX_CM_MAXC && (int32_t)W.I(PMX_CMI_NOW + par) >= 0) ? (int32_t)W.I(PMX_CMI_NOW + par) : PMX_PARENT_UNSET;
     }
     s_set_sam_pri(n, r);
 }
 
 // one in-place thinning pass (thin_regs, aln_hit.hpp: keep(i) sees the array as it is when i is reached)
 template <class Keep>
-PMX_HD int s_thin(int n, SReg* r, Keep keep) {
+PMX_HD int s_thin(const SWork& W, int n, SReg* r, Keep keep) {
     int k = 0;
     for (int i = 0; i < n; ++i) {
         if (!keep(i)) continue;
         if (k != i) r[k] = r[i];
         ++k;
     }
-    if (k != n) s_sync_regs(k, r);
+    if (k != n) s_sync_regs(W, k, r);
     return k;
 }
 
 // mm_select_sub (hit.c:264-285) with check_strand == 0
-PMX_HD int s_select_sub(float pri_ratio, int min_diff, int best_n, int n, SReg* r) {
+PMX_HD int s_select_sub(const SWork& W, float pri_ratio, int min_diff, int best_n, int n, SReg* r) {
     if (!(pri_ratio > 0.0f) || n <= 0) return n;
     int n_2nd = 0;
-    return s_thin(n, r, [&](int i) {
+    return s_thin(W, n, r, [&](int i) {
         const SReg& me = r[i];
         const int p = me.parent;
         if (p == i) return true;
@@ -164,12 +205,12 @@ PMX_HD int s_select_sub(float pri_ratio, int min_diff, int best_n, int n, SReg* 
 }
 
 // mm_select_sub_multi (pe.c:6-43) for two segments
-PMX_HD int s_select_sub_multi(float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int qlen0, int qlen1, int n, SReg* r) {
+PMX_HD int s_select_sub_multi(const SWork& W, float pri_ratio, float pri1, float pri2, int max_gap_ref, int min_diff, int best_n, int qlen0, int qlen1, int n, SReg* r) {
     if (!(pri_ratio > 0.0f) || n <= 0) return n;
     const int max_dist = qlen0 + qlen1 + max_gap_ref;
     const int32_t mate_border = qlen0;
     int n_2nd = 0;
-    return s_thin(n, r, [&](int i) {
+    return s_thin(W, n, r, [&](int i) {
         const SReg& q = r[i];
         if (q.parent == i) return true;
         const SReg& p = r[q.parent];
@@ -202,9 +243,9 @@ PMX_HD int s_filter_regs(const Opt& o, int qlen, int n, SReg* r) {
 }
 
 // mm_hit_sort (hit.c:193-225)
-PMX_HD int s_hit_sort(int n, SReg* r) {
+PMX_HD int s_hit_sort(const SWork& W, int n, SReg* r) {
     if (n <= 1) return n;
-    SReg t[PMX_CM_MAXC];
+    SReg* t = W.regs + 3 * PMX_CM_MAXC;
     auto listed = [&](int i) { return r[i].cnt > 0; };
     auto key_of = [&](int i) { return (uint64_t)(int64_t)(r[i].has_p ? r[i].dp_max : r[i].score) << 32 | r[i].hash; };
     int n_out = 0;
@@ -263,7 +304,7 @@ PMX_HD bool s_set_mapq(const RefIndex& ri, int n, SReg* regs, int min_chain_sc, 
 }
 
 // mm_pair (pe.c:76-177): see pair_hits (aln_map.hpp) for the sweep by selection.  false: outside the logf tables
-PMX_HD bool s_pair_hits(const RefIndex& ri, int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, int n0, SReg* m0, int n1, SReg* m1) {
+PMX_HD bool s_pair_hits(const SWork& W, const RefIndex& ri, int max_gap_ref, int pe_bonus, int sub_diff, int match_sc, int n0, SReg* m0, int n1, SReg* m1) {
     const int n_ends = n0 + n1;
     if (n0 == 0 || n1 == 0) return true;
     auto mate_of = [&](int e) { return e >= n0 ? 1 : 0; };
@@ -282,7 +323,6 @@ PMX_HD bool s_pair_hits(const RefIndex& ri, int max_gap_ref, int pe_bonus, int s
         floor_dp += top;
     }
     if (floor_dp < 0) floor_dp = 0;
-    uint32_t hi_scores[PMX_CM_MAXC * PMX_CM_MAXC];
     int n_pairs = 0;
     int64_t best = -1, second = -1;
     int best_end[2] = {-1, -1};
@@ -331,7 +371,7 @@ PMX_HD bool s_pair_hits(const RefIndex& ri, int max_gap_ref, int pe_bonus, int s
             const int64_t score = (int64_t)(rc.dp_max + q.dp_max) << 32 | (uint32_t)(rc.hash + q.hash);
             if (score > best) { second = best; best = score; best_end[mate_of(p)] = p; best_end[mate_of(c)] = c; }
             else if (score > second) second = score;
-            if (n_pairs < PMX_CM_MAXC * PMX_CM_MAXC) hi_scores[n_pairs] = (uint32_t)(rc.dp_max + q.dp_max);
+            if (n_pairs < PMX_CM_MAXC * PMX_CM_MAXC) W.I(PMX_CMI_HI + n_pairs) = (uint32_t)(rc.dp_max + q.dp_max);
             ++n_pairs;
         }
     }
@@ -359,7 +399,7 @@ PMX_HD bool s_pair_hits(const RefIndex& ri, int max_gap_ref, int pe_bonus, int s
         int pe_q = won[0]->mapq > won[1]->mapq ? won[0]->mapq : won[1]->mapq;
         if (n_pairs > 1) {
             int close = 0;
-            for (int i = 0; i < n_pairs; ++i) close += (uint64_t)hi_scores[i] + (uint64_t)sub_diff >= (uint64_t)best_hi;
+            for (int i = 0; i < n_pairs; ++i) close += (uint64_t)W.I(PMX_CMI_HI + i) + (uint64_t)sub_diff >= (uint64_t)best_hi;
             if (close >= ri.n_logf) return false;
             const int by_margin = (int)(6.02f * (float)((best >> 32) - (second >> 32)) / match_sc - 4.343f * ri.logf_int[close]);
             pe_q = pe_q < by_margin ? pe_q : by_margin;
@@ -375,17 +415,27 @@ PMX_HD bool s_pair_hits(const RefIndex& ri, int max_gap_ref, int pe_bonus, int s
 }
 
 // Place of entry i when n keys are listed in descending order, later entries first among equals (rank_desc_later_first)
-PMX_HD int s_rank(int n, int i, const uint64_t* key) {
+PMX_HD uint64_t s_key(const SWork& W, int i) { return (uint64_t)W.I(PMX_CMI_KEY + 2 * i) | (uint64_t)W.I(PMX_CMI_KEY + 2 * i + 1) << 32; }
+PMX_HD void s_set_key(const SWork& W, int i, uint64_t v) { W.I(PMX_CMI_KEY + 2 * i) = (uint32_t)v; W.I(PMX_CMI_KEY + 2 * i + 1) = (uint32_t)(v >> 32); }
+PMX_HD int s_rank(const SWork& W, int n, int i) {
+    const uint64_t ki = s_key(W, i);
     int before = 0;
-    for (int j = 0; j < n; ++j) before += (key[j] > key[i] || (key[j] == key[i] && j > i)) ? 1 : 0;
+    for (int j = 0; j < n; ++j) { const uint64_t kj = s_key(W, j); before += (kj > ki || (kj == ki && j > i)) ? 1 : 0; }
     return before;
 }
 
-// From the fragment chains of a pair (n_u of them in the order the backtrack found them: score, members as a set of anchor
-// indices) to the pair's result.  The anchors are in m.X / m.Y; m.G is free and receives the per-mate anchor lists.
+// From the fragment chains of a pair (n_u of them in the order the backtrack found them, in the workspace: score at
+// PMX_CMI_USC + c, the members as a set of anchor indices at PMX_CMI_UKEEP + 2c) to the pair's result.  The anchors are in
+// m.X / m.Y; m.G is free and receives the per-mate anchor lists.
+#define PMX_CMI_USC 52       // [4] chains as found: score
+#define PMX_CMI_UKEEP 56     // [8] member set (low, high)
+static_assert(PMX_CMI_UKEEP + 2 * PMX_CM_MAXC <= PMX_CM_INTS, "workspace index words");
+PMX_HD uint64_t s_get64(const SWork& W, int at) { return (uint64_t)W.I(at) | (uint64_t)W.I(at + 1) << 32; }
+PMX_HD void s_set64(const SWork& W, int at, uint64_t v) { W.I(at) = (uint32_t)v; W.I(at + 1) = (uint32_t)(v >> 32); }
+
 template <class PT>
-PMX_HD int compact_regions_multi(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_u, const int32_t* u_sc, const uint64_t* u_keep,
-                                 int max_chain_gap_ref, CResult& out, bool want_edits) {
+PMX_HD int compact_regions_multi(const SWork& W, const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_u, int max_chain_gap_ref,
+                                 CResult& out, bool want_edits) {
     typedef CMemT<PT> MT;
     const int k = o.k;
     const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
@@ -398,73 +448,65 @@ PMX_HD int compact_regions_multi(const CMemT<PT>& m, const Opt& o, const RefInde
                (uint64_t)(uint32_t)((int32_t)(y & 0x3ffu) - shift);
     };
     auto tie_of = [&](int ai, int shift) { return (uint32_t)hit_hash64((hit_hash64(anchor_x(ai)) + hit_hash64(anchor_y(ai, shift))) ^ hash); };
+    auto u_keep = [&](int c) { return s_get64(W, PMX_CMI_UKEEP + 2 * c); };
 
     // ---- the chains in the order mm_chain_dp leaves them: by the position word of their first anchor (lchain.c:78-111;
     //      its sorter is stable for a handful of entries)
-    int ord[PMX_CM_MAXC];
     for (int i = 0; i < n_u; ++i) {
-        const uint64_t xi = anchor_x(__builtin_ctzll(u_keep[i]));
+        const uint64_t xi = anchor_x(__builtin_ctzll(u_keep(i)));
         int at = 0;
         for (int j = 0; j < n_u; ++j) {
-            const uint64_t xj = anchor_x(__builtin_ctzll(u_keep[j]));
+            const uint64_t xj = anchor_x(__builtin_ctzll(u_keep(j)));
             at += (xj < xi || (xj == xi && j < i)) ? 1 : 0;
         }
-        ord[at] = i;
+        W.I(PMX_CMI_ORD + at) = (uint32_t)i;
     }
     // ---- mm_gen_regs on the fragment chains
-    SReg f[PMX_CM_MAXC];
-    uint64_t fkeep[PMX_CM_MAXC];
-    {
-        uint64_t key[PMX_CM_MAXC];
-        for (int i = 0; i < n_u; ++i) {
-            const int c = ord[i];
-            key[i] = ((uint64_t)(uint32_t)u_sc[c] << 32 | (uint32_t)__builtin_popcountll(u_keep[c])) ^ tie_of(__builtin_ctzll(u_keep[c]), 0);
-        }
-        for (int i = 0; i < n_u; ++i) {
-            const int c = ord[i];
-            const int at = s_rank(n_u, i, key);
-            SReg& g = f[at];
-            s_clear(g);
-            g.id = at;
-            g.score = g.score0 = (int32_t)(key[i] >> 32);
-            g.hash = (uint32_t)key[i];
-            g.cnt = __builtin_popcountll(u_keep[c]);
-            fkeep[at] = u_keep[c];
-            const int head = __builtin_ctzll(u_keep[c]), tail = 63 - __builtin_clzll(u_keep[c]);
-            const int32_t q_lo = (int32_t)(m.Y(head) & 0x3ffu) + 1 - k, q_hi = (int32_t)(m.Y(tail) & 0x3ffu) + 1;
-            const int32_t rp_h = (int32_t)MT::pos_of(m.X(head)), rp_t = (int32_t)MT::pos_of(m.X(tail));
-            g.rev = (int32_t)MT::rev_of(m.X(head));
-            g.rs = rp_h + 1 > k ? rp_h + 1 - k : 0;
-            g.re = rp_t + 1;
-            g.qs = g.rev ? qlen_sum - q_hi : q_lo;
-            g.qe = g.rev ? qlen_sum - q_lo : q_hi;
-        }
+    SReg* f = W.regs;
+    for (int i = 0; i < n_u; ++i) {
+        const int c = (int)W.I(PMX_CMI_ORD + i);
+        const uint64_t kp = u_keep(c);
+        s_set_key(W, i, ((uint64_t)W.I(PMX_CMI_USC + c) << 32 | (uint32_t)__builtin_popcountll(kp)) ^ tie_of(__builtin_ctzll(kp), 0));
+    }
+    for (int i = 0; i < n_u; ++i) {
+        const int c = (int)W.I(PMX_CMI_ORD + i);
+        const uint64_t kp = u_keep(c), key = s_key(W, i);
+        const int at = s_rank(W, n_u, i);
+        SReg& g = f[at];
+        s_clear(g);
+        g.id = at;
+        g.score = g.score0 = (int32_t)(key >> 32);
+        g.hash = (uint32_t)key;
+        g.cnt = __builtin_popcountll(kp);
+        s_set64(W, PMX_CMI_KEEP + 2 * at, kp);
+        const int head = __builtin_ctzll(kp), tail = 63 - __builtin_clzll(kp);
+        const int32_t q_lo = (int32_t)(m.Y(head) & 0x3ffu) + 1 - k, q_hi = (int32_t)(m.Y(tail) & 0x3ffu) + 1;
+        const int32_t rp_h = (int32_t)MT::pos_of(m.X(head)), rp_t = (int32_t)MT::pos_of(m.X(tail));
+        const int32_t rev = (int32_t)MT::rev_of(m.X(head));
+        g.rev = rev;
+        g.rs = rp_h + 1 > k ? rp_h + 1 - k : 0;
+        g.re = rp_t + 1;
+        g.qs = rev ? qlen_sum - q_hi : q_lo;
+        g.qe = rev ? qlen_sum - q_lo : q_hi;
     }
     int n_f = n_u;
     // ---- chain_post (map.c:206-213)
-    s_set_parent(o.mask_level, o.mask_len, n_f, f, o.a * 2 + o.b);
-    {
-        // (the thinning moves records: the member sets follow through the records' own `as` field)
-        for (int i = 0; i < n_f; ++i) f[i].as = i;
-        n_f = s_select_sub_multi(o.pri_ratio, 0.2f, 0.7f, max_chain_gap_ref, o.k * 2, o.best_n, qlen0, qlen1, n_f, f);
-    }
+    s_set_parent(W, o.mask_level, o.mask_len, n_f, f, o.a * 2 + o.b);
+    for (int i = 0; i < n_f; ++i) f[i].as = i;   // (the thinning moves records: the member sets follow through the records' `as` field)
+    n_f = s_select_sub_multi(W, o.pri_ratio, 0.2f, 0.7f, max_chain_gap_ref, o.k * 2, o.best_n, qlen0, qlen1, n_f, f);
 
     // ---- mm_seg_gen (hit.c:345-400): per mate, the chains that touch it (fragment order) and their anchors on it
-    SReg R[2][PMX_CM_MAXC];
     int n_r[2] = {0, 0}, base[2] = {0, 0}, n_a[2] = {0, 0};
     {
         int wr = 0;
         for (int s = 0; s < 2; ++s) {
-            base[s] = wr;
-            uint64_t key[PMX_CM_MAXC];
-            int as_[PMX_CM_MAXC], cnt_[PMX_CM_MAXC], sc_[PMX_CM_MAXC];
+            SReg* R = W.regs + (1 + s) * PMX_CM_MAXC;
+            const int base_s = wr;
             int nu = 0;
-            const int shift_f = 0;
-            (void)shift_f;
             for (int i = 0; i < n_f; ++i) {
-                const uint64_t kp = fkeep[f[i].as];
+                const uint64_t kp = s_get64(W, PMX_CMI_KEEP + 2 * f[i].as);
                 int on = 0, first = -1;
-                const int as0 = wr - base[s];
+                const int as0 = wr - base_s;
                 for (uint64_t wk = kp; wk; wk &= wk - 1) {
                     const int ai = __builtin_ctzll(wk);
                     if ((int)((m.Y(ai) >> 10) & 1u) != s) continue;
@@ -477,23 +519,24 @@ PMX_HD int compact_regions_multi(const CMemT<PT>& m, const Opt& o, const RefInde
                 const int32_t rev = (int32_t)MT::rev_of(m.X(first));
                 const int32_t my_len = s ? qlen1 : qlen0, before = s ? qlen0 : 0;
                 const int shift = rev ? qlen_sum - (my_len + before) : before;
-                key[nu] = ((uint64_t)(uint32_t)f[i].score << 32 | (uint32_t)on) ^ tie_of(first, shift);
-                as_[nu] = as0; cnt_[nu] = on; sc_[nu] = f[i].score;
+                s_set_key(W, nu, ((uint64_t)(uint32_t)f[i].score << 32 | (uint32_t)on) ^ tie_of(first, shift));
+                W.I(PMX_CMI_AS + nu) = (uint32_t)as0;
+                W.I(PMX_CMI_CNT + nu) = (uint32_t)on;
                 ++nu;
             }
-            n_a[s] = wr - base[s];
             for (int i = 0; i < nu; ++i) {
-                const int at = s_rank(nu, i, key);
-                SReg& g = R[s][at];
+                const int at = s_rank(W, nu, i);
+                const uint64_t key = s_key(W, i);
+                SReg& g = R[at];
                 s_clear(g);
                 g.id = at;
-                g.score = g.score0 = (int32_t)(key[i] >> 32);
-                g.hash = (uint32_t)key[i];
-                g.cnt = cnt_[i];
-                g.as = as_[i];
-                (void)sc_;
+                g.score = g.score0 = (int32_t)(key >> 32);
+                g.hash = (uint32_t)key;
+                g.cnt = (int32_t)W.I(PMX_CMI_CNT + i);
+                g.as = (int32_t)W.I(PMX_CMI_AS + i);
             }
-            n_r[s] = nu;
+            if (s == 0) { base[0] = base_s; n_a[0] = wr - base_s; n_r[0] = nu; }
+            else { base[1] = base_s; n_a[1] = wr - base_s; n_r[1] = nu; }
         }
     }
     if (n_r[0] == 0 || n_r[1] == 0) return want_edits ? PMX_C_BAIL : PMX_C_DONE;   // a mate without a region: unmapped (its partner's edit count: general tier)
@@ -501,51 +544,56 @@ PMX_HD int compact_regions_multi(const CMemT<PT>& m, const Opt& o, const RefInde
     // ---- per mate: coordinates, set_parent, alignment of every region, filter, sort, parents, secondaries, mapq
     for (int s = 0; s < 2; ++s) {
         const int qlen = s ? qlen1 : qlen0;
-        SReg* r = R[s];
-        int nr = n_r[s];
+        const int base_s = s ? base[1] : base[0], n_a_s = s ? n_a[1] : n_a[0];
+        SReg* r = W.regs + (1 + s) * PMX_CM_MAXC;
+        int nr = s ? n_r[1] : n_r[0];
         if (qlen >= o.rank_min_len) return PMX_C_BAIL;
+        const int32_t before = s ? qlen0 : 0;
         for (int i = 0; i < nr; ++i) {
             SReg& g = r[i];
-            const int first = (int)m.G(base[s] + g.as);
-            g.rev = (int32_t)MT::rev_of(m.X(first));
-            const int32_t my_len = qlen, before = s ? qlen0 : 0;
-            const CList<PT> L{m, base[s] + g.as, g.rev ? qlen_sum - (my_len + before) : before};
+            const int as = g.as;
+            const int32_t rev = (int32_t)MT::rev_of(m.X((int)m.G(base_s + as)));
+            const CList<PT> L{m, base_s + as, rev ? qlen_sum - (qlen + before) : before};
             CReg c;
-            c.cnt = g.cnt; c.rev = g.rev;
+            c.cnt = g.cnt; c.rev = rev;
             c_reg_set_coor(L, c, qlen, k);
+            g.rev = rev;
             g.rs = c.rs; g.re = c.re; g.qs = c.qs; g.qe = c.qe; g.mlen = c.mlen; g.blen = c.blen;
         }
-        s_set_parent(o.mask_level, o.mask_len, nr, r, o.a * 2 + o.b);
+        s_set_parent(W, o.mask_level, o.mask_len, nr, r, o.a * 2 + o.b);
         for (int i = 0; i < nr; ++i) {
             SReg& g = r[i];
-            const int32_t before = s ? qlen0 : 0;
-            const int shift = g.rev ? qlen_sum - (qlen + before) : before;
-            const CList<PT> L{m, base[s] + g.as, shift};
-            const CList<PT> Lm{m, base[s], shift};   // (the fence scan only visits anchors of the region's strand: same shift)
+            const int as = g.as;
             CReg c;
             c.cnt = g.cnt; c.score = g.score; c.rev = g.rev; c.qs = g.qs; c.qe = g.qe; c.rs = g.rs; c.re = g.re; c.mlen = g.mlen; c.blen = g.blen;
             c.has_p = 0; c.dp_score = c.dp_max = 0; c.mapq = 0; c.proper_frag = 0; c.m_len = 0;
-            if (c_align1<PT, true>(L, o, ri, rd[s], qlen, c, &Lm, g.as, n_a[s]) != PMX_C_DONE) return PMX_C_BAIL;
+            const int shift = c.rev ? qlen_sum - (qlen + before) : before;
+            const CList<PT> L{m, base_s + as, shift};
+            const CList<PT> Lm{m, base_s, shift};   // (the fence scan only visits anchors of the region's strand: same shift)
+            if (c_align1<PT, true>(L, o, ri, rd[s], qlen, c, &Lm, as, n_a_s) != PMX_C_DONE) return PMX_C_BAIL;
             g.rs = c.rs; g.re = c.re; g.qs = c.qs; g.qe = c.qe; g.mlen = c.mlen; g.blen = c.blen;
             g.has_p = c.has_p; g.dp_score = c.dp_score; g.dp_max = c.dp_max; g.m_len = c.m_len;
         }
         nr = s_filter_regs(o, qlen, nr, r);
-        nr = s_hit_sort(nr, r);
-        s_set_parent(o.mask_level, o.mask_len, nr, r, o.a * 2 + o.b);
-        nr = s_select_sub(o.pri_ratio, o.k * 2, o.best_n, nr, r);
+        nr = s_hit_sort(W, nr, r);
+        s_set_parent(W, o.mask_level, o.mask_len, nr, r, o.a * 2 + o.b);
+        nr = s_select_sub(W, o.pri_ratio, o.k * 2, o.best_n, nr, r);
         s_set_sam_pri(nr, r);
         if (!s_set_mapq(ri, nr, r, o.min_chain_score, o.a)) return PMX_C_BAIL;
-        n_r[s] = nr;
+        if (s == 0) n_r[0] = nr; else n_r[1] = nr;
     }
-    if (o.pe_ori >= 0 && !s_pair_hits(ri, max_chain_gap_ref, o.pe_bonus, o.a * 2 + o.b, o.a, n_r[0], R[0], n_r[1], R[1])) return PMX_C_BAIL;
+    SReg* R0 = W.regs + PMX_CM_MAXC;
+    SReg* R1 = W.regs + 2 * PMX_CM_MAXC;
+    if (o.pe_ori >= 0 && !s_pair_hits(W, ri, max_chain_gap_ref, o.pe_bonus, o.a * 2 + o.b, o.a, n_r[0], R0, n_r[1], R1)) return PMX_C_BAIL;
 
     // ---- the record (src/mm_align.c:271-354): the first region of each mate
-    for (int s = 0; s < 2; ++s)
-        if (n_r[s] > 0 && R[s][0].has_p && R[s][0].blen > 0) out.edit[s] = R[s][0].blen - R[s][0].mlen;
-    if (!(n_r[0] > 0 && n_r[1] > 0 && R[0][0].score > 0 && R[1][0].score > 0)) return PMX_C_DONE;   // unmapped pair (every region was aligned: the edit counts stand)
+    if (n_r[0] > 0 && R0[0].has_p && R0[0].blen > 0) out.edit[0] = R0[0].blen - R0[0].mlen;
+    if (n_r[1] > 0 && R1[0].has_p && R1[0].blen > 0) out.edit[1] = R1[0].blen - R1[0].mlen;
+    if (!(n_r[0] > 0 && n_r[1] > 0 && R0[0].score > 0 && R1[0].score > 0)) return PMX_C_DONE;   // unmapped pair (every region was aligned: the edit counts stand)
     out.mapped = 1;
+#pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const SReg& r = R[s][0];
+        const SReg& r = s ? R1[0] : R0[0];
         CMate& t = out.m[s];
         t.rs = r.rs; t.re = r.re; t.qs = r.qs; t.qe = r.qe;
         t.dp_max = r.dp_max;

@@ -52,6 +52,13 @@ struct AlignArgs {
     // the hand-over words (align/aln_compact.hpp CSeedOutT) and their number in cseed_n[it]; NULL = the fused kernel
     uint32_t* cseeds;
     uint16_t* cseed_n;         // seeds | seeds of mate 1 << 8, or PMX_C_NSEED_BAIL
+    // Second form of the compact tier (k_align_compact*_multi: several regions per mate, align/aln_compact_multi.hpp):
+    // k_align_compact* appends the LAUNCH POSITIONS of the pairs that leave it after the seeds (their hand-over words stay
+    // where they are) to multi_list, the second form runs over the list and appends what it cannot finish to retry_list.
+    // NULL = every bail goes to retry_list at once.
+    uint32_t* multi_list;
+    unsigned long long* multi_count;   // [0] length of multi_list, [1] pairs the second form finished
+    uint32_t* multi_ws;                // region records of the second form: PMX_CM_WS_WORDS * 64 words per wave of its grid
 
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
     int32_t* edits;             // NULL, or per read: count_read_errors (src/mm_align.c:122-133) of its first region, the read length without one
@@ -81,6 +88,8 @@ __global__ void k_align_compact16(AlignArgs A);   // retry_list / retry_count = 
 __global__ void k_align_compact32(AlignArgs A);
 __global__ void k_align_compact16_fused(AlignArgs A);   // sketch and probes inside (PMX_ALIGN_COMPACT_FUSED)
 __global__ void k_align_compact32_fused(AlignArgs A);
+__global__ void k_align_compact16_multi(AlignArgs A);   // over multi_list (grid-stride, the length is read on the device)
+__global__ void k_align_compact32_multi(AlignArgs A);
 __global__ void k_compact_seeds16(AlignArgs A);   // sketch + index probes of every pair -> cseeds / cseed_n
 __global__ void k_compact_seeds32(AlignArgs A);
 

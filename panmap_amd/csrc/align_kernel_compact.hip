@@ -72,6 +72,53 @@ __device__ __forceinline__ void compact_seeds_body(const AlignArgs& A) {
 __global__ void __launch_bounds__(64) k_compact_seeds16(AlignArgs A) { compact_seeds_body<uint16_t>(A); }
 __global__ void __launch_bounds__(64) k_compact_seeds32(AlignArgs A) { compact_seeds_body<uint32_t>(A); }
 
+// What a pair of either form leaves behind: an entry of the bail list (one atomic per wave), or its two records and CIGAR
+// words (one arena atomic per wave).  Called by every lane of the wave.
+__device__ __forceinline__ void compact_emit(const AlignArgs& A, int lane, int64_t item, bool bail, bool done, const CResult& res) {
+    const unsigned long long bmask = __ballot(bail);
+    if (bmask) {
+        unsigned long long bbase = 0;
+        if (lane == 0) bbase = atomicAdd(A.retry_count, (unsigned long long)__popcll(bmask));
+        bbase = __shfl(bbase, 0);
+        if (bail) A.retry_list[bbase + __popcll(bmask & ((1ULL << lane) - 1ULL))] = (uint32_t)item;
+    }
+    // CIGAR arena: one word per mapped mate, one atomic per wave
+    const uint32_t mine = done && res.mapped ? 2u : 0u;
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    const uint32_t wave_total = __shfl(incl, 63);
+    unsigned long long wave_base = 0;
+    if (wave_total) {
+        if (lane == 0) wave_base = atomicAdd(A.cigar_used, (unsigned long long)wave_total);
+        wave_base = __shfl(wave_base, 0);
+    }
+    if (done) {
+        uint64_t coff = wave_base + (incl - mine);
+        for (int s = 0; s < 2; ++s) {
+            AlnRecord rec;
+            memset(&rec, 0, sizeof(rec));
+            if (res.mapped) {
+                const CMate& t = res.m[s];
+                rec.mapped = 1;
+                rec.flags = PMX_REC_HAS_ALN;
+                rec.rs = t.rs; rec.re = t.re; rec.qs = t.qs; rec.qe = t.qe;
+                rec.mapq = t.mapq; rec.rev = t.rev; rec.proper_frag = t.proper_frag;
+                rec.n_cigar = 1;
+                rec.score = t.dp_max;
+                rec.cigar_off = (uint32_t)coff;
+                if (coff < A.cigar_cap) A.cigars[coff] = t.cigar;
+                else { rec.flags |= PMX_REC_OVERFLOW; rec.n_cigar = 0; }
+                ++coff;
+            }
+            A.records[2 * item + s] = rec;
+            if (A.edits) A.edits[2 * item + s] = res.edit[s];
+        }
+    }
+}
+
 template <class PT, bool PRESEEDED>
 __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t c_lds[];
@@ -132,51 +179,74 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
             if (A.prof && lane == 0)   // lane 0's stamps are the wave's phase timeline (diagnostic runs: PMX_ALIGN_PROF)
                 for (int k = 0; k < 8; ++k) atomicAdd(&A.prof[k], pacc[k]);
         }
-        // bail list: one atomic per wave
-        const bool bail = item >= 0 && rc != PMX_C_DONE;
-        const unsigned long long bmask = __ballot(bail);
-        if (bmask) {
-            unsigned long long bbase = 0;
-            if (lane == 0) bbase = atomicAdd(A.retry_count, (unsigned long long)__popcll(bmask));
-            bbase = __shfl(bbase, 0);
-            if (bail) A.retry_list[bbase + __popcll(bmask & ((1ULL << lane) - 1ULL))] = (uint32_t)item;
-        }
-        // CIGAR arena: one word per mapped mate, one atomic per wave
-        const bool done = item >= 0 && rc == PMX_C_DONE;
-        const uint32_t mine = done && res.mapped ? 2u : 0u;
-        uint32_t incl = mine;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        const uint32_t wave_total = __shfl(incl, 63);
-        unsigned long long wave_base = 0;
-        if (wave_total) {
-            if (lane == 0) wave_base = atomicAdd(A.cigar_used, (unsigned long long)wave_total);
-            wave_base = __shfl(wave_base, 0);
-        }
-        if (done) {
-            uint64_t coff = wave_base + (incl - mine);
-            for (int s = 0; s < 2; ++s) {
-                AlnRecord rec;
-                memset(&rec, 0, sizeof(rec));
-                if (res.mapped) {
-                    const CMate& t = res.m[s];
-                    rec.mapped = 1;
-                    rec.flags = PMX_REC_HAS_ALN;
-                    rec.rs = t.rs; rec.re = t.re; rec.qs = t.qs; rec.qe = t.qe;
-                    rec.mapq = t.mapq; rec.rev = t.rev; rec.proper_frag = t.proper_frag;
-                    rec.n_cigar = 1;
-                    rec.score = t.dp_max;
-                    rec.cigar_off = (uint32_t)coff;
-                    if (coff < A.cigar_cap) A.cigars[coff] = t.cigar;
-                    else { rec.flags |= PMX_REC_OVERFLOW; rec.n_cigar = 0; }
-                    ++coff;
-                }
-                A.records[2 * item + s] = rec;
-                if (A.edits) A.edits[2 * item + s] = res.edit[s];
+        // a pair that leaves after its seeds were made: the second form (several regions per mate) takes it from its hand-over words
+        bool bail = item >= 0 && rc != PMX_C_DONE;
+        if (PRESEEDED && A.multi_list) {
+            const bool again = bail && A.cseed_n[it] != PMX_C_NSEED_BAIL;
+            const unsigned long long mmask = __ballot(again);
+            if (mmask) {
+                unsigned long long mbase = 0;
+                if (lane == 0) mbase = atomicAdd(A.multi_count, (unsigned long long)__popcll(mmask));
+                mbase = __shfl(mbase, 0);
+                if (again) A.multi_list[mbase + __popcll(mmask & ((1ULL << lane) - 1ULL))] = (uint32_t)it;
             }
+            bail = bail && !again;
         }
+        compact_emit(A, lane, item, bail, item >= 0 && rc == PMX_C_DONE, res);
+    }
+}
+
+// Second form of the compact tier: the pairs of multi_list (launch positions), seeds from their hand-over words, up to
+// four fragment chains and several regions per mate (align/aln_compact_multi.hpp).  The list's length is only known on
+// the device: a resident grid strides over it, waves beyond its end leave at once.
+template <class PT>
+__device__ __forceinline__ void align_compact_multi_body(const AlignArgs& A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t c_lds[];
+    const int lane = (int)(threadIdx.x & 63u);
+    CMemT<PT> m;
+    c_u8* pen = (c_u8*)((c_u32*)c_lds + CMemT<PT>::kWords * 64);
+    CPenTab tab;
+    tab.same = pen; tab.diff = pen + PMX_C_PEN_SAME;
+    for (int dd = lane; dd < PMX_C_PEN_DIFF; dd += 64) {
+        int ps, pd;
+        c_pen_values(A.opt.chn_pen_gap, dd, &ps, &pd);
+        if (dd < PMX_C_PEN_SAME) pen[dd] = (uint8_t)(ps < 255 ? ps : 255);
+        pen[PMX_C_PEN_SAME + dd] = (uint8_t)(pd < 255 ? pd : 255);
+    }
+    __syncthreads();
+    m.base = (c_u32*)c_lds + lane;
+    // the wave's region records and index words (HBM, interleaved across the lanes; see SReg)
+    uint32_t* const wsb = A.multi_ws + (size_t)blockIdx.x * ((size_t)PMX_CM_WS_WORDS * 64);
+    const SWork mw{reinterpret_cast<SReg*>(wsb + lane), wsb + (size_t)PMX_CM_SREGS * 24 * 64 + lane};
+    const int64_t n_list = (int64_t)*A.multi_count;
+    const int64_t n_threads = (int64_t)gridDim.x * 64;
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n_list; e0 += n_threads) {
+        const int64_t e = e0 + lane;
+        int64_t item = -1;
+        int rc = PMX_C_DONE;
+        CResult res;
+        res.mapped = 0;
+        if (e < n_list) {
+            const int64_t it = (int64_t)A.multi_list[e];
+            CRead rd[2];
+            const uint32_t* amb[2];
+            item = compact_item(A, it, rd, amb);
+            const uint32_t c = A.cseed_n[it];
+            const int n_s = (int)(c & 0xffu), n_s0 = (int)(c >> 8);
+            CSeedOutT<PT> so;
+            so.q = nullptr;
+            so.out = (c_g32*)(A.cseeds + (size_t)(it >> 6) * CSeedOutT<PT>::kBlockWords) + (it & 63);
+            for (int i = 0; i < n_s; ++i) {
+                uint32_t x, y;
+                so.get(i, &x, &y);
+                m.setSeed(i, x, y);
+            }
+            rc = compact_chain_pair<PT, true>(m, A.opt, A.ri, rd, n_s, n_s0, res, tab, nullptr, A.edits != nullptr, false, &mw);
+        }
+        const bool done = item >= 0 && rc == PMX_C_DONE;
+        const unsigned long long dmask = __ballot(done);
+        if (dmask && lane == 0) atomicAdd(A.multi_count + 1, (unsigned long long)__popcll(dmask));
+        compact_emit(A, lane, item, item >= 0 && rc != PMX_C_DONE, done, res);
     }
 }
 
@@ -184,6 +254,8 @@ __global__ void __launch_bounds__(64) k_align_compact16(AlignArgs A) { align_com
 __global__ void __launch_bounds__(64) k_align_compact32(AlignArgs A) { align_compact_body<uint32_t, true>(A); }
 __global__ void __launch_bounds__(64) k_align_compact16_fused(AlignArgs A) { align_compact_body<uint16_t, false>(A); }
 __global__ void __launch_bounds__(64) k_align_compact32_fused(AlignArgs A) { align_compact_body<uint32_t, false>(A); }
+__global__ void __launch_bounds__(64) k_align_compact16_multi(AlignArgs A) { align_compact_multi_body<uint16_t>(A); }
+__global__ void __launch_bounds__(64) k_align_compact32_multi(AlignArgs A) { align_compact_multi_body<uint32_t>(A); }
 
 }  // namespace aln
 }  // namespace pmx

@@ -50,6 +50,9 @@ struct pmx_aligner {
     DevBuf<uint32_t> retry_list2, bail_list;
     DevBuf<uint32_t> cseeds;            // compact tier, two-kernel form: seed hand-over (AlignArgs::cseeds / cseed_n)
     DevBuf<uint16_t> cseed_n;
+    DevBuf<uint32_t> multi_list;        // compact tier, second form (several regions per mate): launch positions + counters
+    DevBuf<unsigned long long> multi_count;
+    DevBuf<uint32_t> multi_ws;
     DevBuf<uint8_t> dp_req;
     DevBuf<DpRes> dp_res;
     DevBuf<uint32_t> dp_ncached, dp_slot_pairs, dp_list_a, dp_list_b;
@@ -378,6 +381,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     A.tpp.base = nullptr; A.tpp.wave_stride = 0; A.tpp.pad = 0;
     A.work_queue = nullptr;
     A.cseeds = nullptr; A.cseed_n = nullptr;
+    A.multi_list = nullptr; A.multi_count = nullptr; A.multi_ws = nullptr;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
     A.recs = rs->has_recs && rs->packed ? rs->recs.p : nullptr;
     A.paired = paired ? 1 : 0;
@@ -626,11 +630,34 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     PMX_HIP(hipGetLastError());
                     timer_end(ctx, "align_cseeds", 1);
                 }
+                // Second form (k_align_compact*_multi): the pairs that leave the first one after their seeds -- a third chain, two
+                // regions on one mate (mates that overlap on the reference: 55 % of the real example pairs), ... -- are run again
+                // from their hand-over words with up to four chains and several regions per mate; what is still left goes to the
+                // thread-per-pair tier.  PMX_ALIGN_NO_MULTI: every bail goes there at once.
+                const bool c_multi = !c_fused && !pmx::opt_str(pmx::O_ALIGN_NO_MULTI);
+                if (c_multi) {
+                    al->multi_list.ensure((size_t)n_items);
+                    al->multi_count.ensure(2);
+                    PMX_HIP(hipMemsetAsync(al->multi_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+                    A.multi_list = al->multi_list.p;
+                    A.multi_count = al->multi_count.p;
+                }
                 timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
                 hipLaunchKernelGGL(c_kern, dim3((unsigned)c_grid), dim3(64), c_lds, ctx->stream, A);
                 PMX_HIP(hipGetLastError());
                 timer_end(ctx, "align_dom", 1);
+                if (c_multi) {
+                    // (the list's length stays on the device: a resident grid -- seven waves per CU by the LDS -- strides over it)
+                    const int64_t m_grid = std::min<int64_t>((n_items + 63) / 64, (int64_t)ctx->n_cu * 7);
+                    al->multi_ws.ensure((size_t)m_grid * PMX_CM_WS_WORDS * 64);
+                    A.multi_ws = al->multi_ws.p;
+                    timer_begin(ctx, "align_cmulti");
+                    hipLaunchKernelGGL(pos16 ? k_align_compact16_multi : k_align_compact32_multi, dim3((unsigned)m_grid), dim3(64), c_lds, ctx->stream, A);
+                    PMX_HIP(hipGetLastError());
+                    timer_end(ctx, "align_cmulti", 1);
+                }
                 A.cseeds = nullptr; A.cseed_n = nullptr;
+                A.multi_list = nullptr; A.multi_count = nullptr; A.multi_ws = nullptr;
                 if (A.prof) {   // the compact tier's own phase profile, then the accumulators start over for the general tiers
                     unsigned long long h[8];
                     PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

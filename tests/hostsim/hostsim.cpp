@@ -233,6 +233,9 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
         int rc;
         const bool pos16 = ref_len <= 32767 && !getenv("PMX_HS_COMPACT_POS32");
         const bool multi = getenv("PMX_HS_COMPACT_MULTI") != nullptr;   // several regions per mate (k_align_compact*_multi)
+        SReg mregs[PMX_CM_SREGS];
+        uint32_t mints[PMX_CM_INTS];
+        const SWork mw{mregs, mints};
         if (getenv("PMX_HS_COMPACT_SPLIT")) {
             // the two-kernel form: seeds through the hand-over words (k_compact_seeds), then the chain part from a copy
             // of them in the pair's block (k_align_compact) -- the block itself never sees the sketch
@@ -245,11 +248,11 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
                 if (compact_seed_pair(so, o, ri, rd, amb, &n_s, &n_s0) != PMX_C_DONE) return (int)PMX_C_BAIL;
                 CMemT<PT> m{lds.data()};
                 for (int i = 0; i < n_s; ++i) { uint32_t x, y; so.get(i, &x, &y); m.setSeed(i, x, y); }
-                return multi ? compact_chain_pair<PT, true>(m, o, ri, rd, n_s, n_s0, res, tab) : compact_chain_pair(m, o, ri, rd, n_s, n_s0, res, tab);
+                return multi ? compact_chain_pair<PT, true>(m, o, ri, rd, n_s, n_s0, res, tab, nullptr, false, false, &mw) : compact_chain_pair(m, o, ri, rd, n_s, n_s0, res, tab);
             };
             rc = pos16 ? split((uint16_t)0) : split((uint32_t)0);
-        } else if (pos16) { CMemT<uint16_t> m{lds.data()}; rc = multi ? compact_map_pair<uint16_t, true>(m, o, ri, rd, amb, res, tab) : compact_map_pair(m, o, ri, rd, amb, res, tab); }
-        else { CMemT<uint32_t> m{lds.data()}; rc = multi ? compact_map_pair<uint32_t, true>(m, o, ri, rd, amb, res, tab) : compact_map_pair(m, o, ri, rd, amb, res, tab); }
+        } else if (pos16) { CMemT<uint16_t> m{lds.data()}; rc = multi ? compact_map_pair<uint16_t, true>(m, o, ri, rd, amb, res, tab, nullptr, false, false, &mw) : compact_map_pair(m, o, ri, rd, amb, res, tab); }
+        else { CMemT<uint32_t> m{lds.data()}; rc = multi ? compact_map_pair<uint32_t, true>(m, o, ri, rd, amb, res, tab, nullptr, false, false, &mw) : compact_map_pair(m, o, ri, rd, amb, res, tab); }
         done[it] = rc == PMX_C_DONE ? 1 : 0;
         if (pmx_c_trace_out) {
             unsigned char* t = pmx_c_trace_out + (size_t)it * 129;

@@ -49,3 +49,31 @@ def test_compact_tier_forms_equal_reference(pmx, oracle, ctx, form, monkeypatch)
         assert all(x["flags"] & 3 == 0 for x in got), (form, name)
         st = al.stats()
         assert st["compact_tier_items"] >= floor * (len(reads) // 2), (form, name, st)
+
+
+def test_compact_second_form_on_example_reads(pmx, oracle, ctx, monkeypatch):
+    """k_align_compact16_multi (several regions per mate): on the real example pairs -- mates that overlap on the reference --
+    the compact tier finishes more than twice as many pairs with it as without (PMX_ALIGN_NO_MULTI), the records are the
+    reference's either way, and with 32-bit position words"""
+    g = _ref_genome()
+    seqs, _, _ = pmx.read_fastq_paired(os.path.join(GOLDEN, "isolate_R1.fastq.gz"), os.path.join(GOLDEN, "isolate_R2.fastq.gz"))
+    reads = seqs[:40000]
+    mean_len = int(sum(len(r) for r in reads) / len(reads))
+    want = oracle.ref_align_reads_direct(g, reads, True, 8)
+    al = pmx.Aligner(ctx, g, mean_len)
+    finished = {}
+    for mode in ("multi", "no_multi", "multi_pos32"):
+        if mode == "no_multi":
+            monkeypatch.setenv("PMX_ALIGN_NO_MULTI", "1")
+        if mode == "multi_pos32":
+            monkeypatch.setenv("PMX_ALIGN_COMPACT_POS32", "1")
+        got = al.align_reads(reads, paired=True)
+        monkeypatch.delenv("PMX_ALIGN_NO_MULTI", raising=False)
+        monkeypatch.delenv("PMX_ALIGN_COMPACT_POS32", raising=False)
+        bad = ac.compare_results(got, want)
+        assert not bad, (mode, bad[:10])
+        st = al.stats()
+        finished[mode] = st["compact_tier_items"]
+        assert st["n_items"] == len(reads) // 2
+    assert finished["multi"] > 2 * finished["no_multi"] and finished["multi"] >= 0.7 * (len(reads) // 2), finished
+    assert finished["multi_pos32"] == finished["multi"]
