@@ -331,7 +331,10 @@ def main():
     max_len = int(np.max(np.diff(off))) if n_reads else 0
     mean_len = int(off[-1] // max(n_reads, 1))
     total_reads = n_reads * world if args.scaling == "weak" else args.total_reads // unit * unit
-    n_pipes = args.pipelines or (1 if long_reads else 2)
+    # batches in flight: two; three when a rank's batch is small (a rank's share of a strong-scaling job: the fixed-latency
+    # kernels of a step -- histogram finalisation, scoring, reference index, the tail tiers -- leave more of the chip idle;
+    # measured at 1.25M reads: 156 -> 169 M reads/s, at 2.5M: 213 -> 220, at 10M three are not robustly better, four lose)
+    n_pipes = args.pipelines or (1 if long_reads else (3 if n_reads <= 2000000 else 2))
     # (one chunk by default: with two batches in flight the upload of a batch overlaps the kernels of the other one, and a
     # batch seeded as a whole sizes its seed table once; --h2d-chunks > 1 packs + seeds range by range behind the copies)
     n_chunks = args.h2d_chunks or 1
@@ -833,12 +836,46 @@ def main():
         el3 = time.perf_counter() - t0
         st = main_pipe.aligner.stats()
         rrecs, _ = main_pipe.aligner.fetch()
+        # the same step with two batches in flight, as `value` is measured (one pipeline per batch; the records stay in HBM):
+        # the thread-per-pair passes and the DP service of the pairs that need a DP fill a fraction of the chip and last as
+        # long as their slowest wave -- the other batch's kernels run beside them
+        real_two = None
+        if len(pipes) > 1:
+            sets = [rrs] + [pmx.ReadSet.wrap_device(pp.ctx, rd_concat.data_ptr(), rd_off.data_ptr(), len(rr), int(r_concat.size), int(np.max(np.diff(r_off))),
+                                                    keepalive=(rd_concat, rd_off)) for pp in pipes[1:]]
+            n_each = 4
+
+            def work_real(pi, n):
+                pp, rs_ = pipes[pi], sets[pi]
+                for _ in range(n):
+                    rs_.pack()
+                    pp.placer.reset()
+                    pp.placer.add_reads(rs_, params)
+                    pp.place_and_align(rs_, len(rr), r_mean, True, False)
+                pp.ctx.synchronize()
+
+            def both(n):
+                th = [threading.Thread(target=work_real, args=(pi, n)) for pi in range(len(pipes))]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+            both(1)
+            t0 = time.perf_counter()
+            both(n_each)
+            el4 = time.perf_counter() - t0
+            r2, _ = pipes[-1].aligner.fetch()
+            real_two = dict(value=len(rr) * n_each * len(pipes) / el4, ms_per_step=el4 / (n_each * len(pipes)) * 1e3, batches_in_flight=len(pipes),
+                            equals_one_at_a_time=bool(np.array_equal(r2[["rs", "re", "qs", "qe", "mapq", "rev", "proper_frag", "mapped", "n_cigar", "flags", "score"]],
+                                                                     rrecs[["rs", "re", "qs", "qe", "mapq", "rev", "proper_frag", "mapped", "n_cigar", "flags", "score"]])))
+            for s_ in sets[1:]:
+                s_.close()
         real = dict(value=len(rr) * n_real_steps / el3, unit="reads/s", reads=len(rr), ms_per_step=el3 / n_real_steps * 1e3,
                     align_stage_ms=float(np.mean(al_ms)), placed_node=pm.node_id(int(main_pipe.res.best_index[4])),
                     mapped_fraction=float(np.mean(rrecs["mapped"])), records_flagged=int(np.sum((rrecs["flags"] & 3) != 0)),
                     dp_pair_share=st["dp_pairs"] / max(st["n_items"], 1), dp_cells_per_step=st["dp_cells"],
                     gcups_align_stage=st["dp_cells"] / max(float(np.mean(al_ms)), 1e-9) / 1e6, tiers=st,
-                    inputs="resident in HBM (one batch at a time)",
+                    inputs="resident in HBM (one batch at a time)", batches_in_flight_run=real_two,
                     note="the sample is replicated x8 to fill the chip: every read is an 8-fold duplicate for the place stage's read collapse "
                          "(its seeding runs on an eighth of the reads); the align stage -- most of this step -- does not collapse",
                     workload="tests/golden/isolate_R{1,2}.fastq.gz (2 x 51,169 real reads, mean %d bp, indels / N / adapters) x8, place + align" % r_mean)

@@ -5,7 +5,7 @@ Study tool (CPU, no GPU): builds the host form of the kernel source (tests/hosts
 panmap_amd/csrc/align in which every bail site also records its line number, and runs the real read pairs of
 tests/golden (or synthetic ones) through `compact_map_pair`.  The product sources are not touched.
 
-  python tools/compact_bail_reasons.py [--pairs 20000] [--synthetic]
+  python tools/compact_bail_reasons.py [--pairs 20000] [--synthetic] [--multi]
 """
 import argparse
 import collections
@@ -52,7 +52,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=20000)
     ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--multi", action="store_true", help="the tier's second form (several regions per mate)")
     args = ap.parse_args()
+    if args.multi:
+        os.environ["PMX_HS_COMPACT_MULTI"] = "1"
     import panmap_amd as pmx
     import align_checks as ac
     golden = os.path.join(ROOT, "tests", "golden")

@@ -15,23 +15,17 @@ if [ "$1" = "scale" ]; then
 run "5M p2" X=1 -- --total-reads 5000000
 run "2.5M p2" X=1 -- --total-reads 2500000
 run "1.25M p2" X=1 -- --total-reads 1250000
-run "1.25M p3" X=1 -- --total-reads 1250000 --pipelines 3
-run "1.25M p2 bail_tpp_min=20000" PMX_ALIGN_BAIL_TPP_MIN=20000 -- --total-reads 1250000
-run "1.25M p2 tpp_min=100000" PMX_ALIGN_TPP_MIN=100000 -- --total-reads 1250000
 exit 0
 fi
 if [ "$1" = "10M" ]; then
 run "10M p2" X=1 --
 run "10M p3" X=1 -- --pipelines 3
-run "10M p4" X=1 -- --pipelines 4
 run "10M p2 again" X=1 --
-run "10M p3 again" X=1 -- --pipelines 3
 exit 0
 fi
 run "1.25M p2" X=1 -- --total-reads 1250000
-run "1.25M p2 bail_tpp_min=256" PMX_ALIGN_BAIL_TPP_MIN=256 -- --total-reads 1250000
 run "1.25M p3" X=1 -- --total-reads 1250000 --pipelines 3
-run "1.25M p3 bail_tpp_min=256" PMX_ALIGN_BAIL_TPP_MIN=256 -- --total-reads 1250000 --pipelines 3
-run "1.25M p4 bail_tpp_min=256" PMX_ALIGN_BAIL_TPP_MIN=256 -- --total-reads 1250000 --pipelines 4
-run "10M p3" X=1 -- --pipelines 3
-run "10M p4" X=1 -- --pipelines 4
+run "1.25M p4" X=1 -- --total-reads 1250000 --pipelines 4
+run "1.25M p2 no_multi" PMX_ALIGN_NO_MULTI=1 -- --total-reads 1250000
+run "2.5M p3" X=1 -- --total-reads 2500000 --pipelines 3
+run "2.5M p2" X=1 -- --total-reads 2500000
