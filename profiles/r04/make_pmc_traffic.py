@@ -14,16 +14,20 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
-def per_launch(d, counter, kernel_substr):
+def per_launch(d, counter, kernel_re):
+    """d: a rocprofv3 output directory, or one of the filtered pmc_*.csv copies kept under profiles/; kernel_re: a regular
+    expression on the kernel name (k_align_compact16 must not swallow k_align_compact16_multi)"""
     vals = {}
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    files = [d] if os.path.isfile(d) else glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    for f in files:
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and kernel_substr in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and re.search(kernel_re, r["Kernel_Name"]):
                 vals[int(r["Dispatch_Id"])] = vals.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     return [vals[k] for k in sorted(vals)]
 
@@ -33,7 +37,7 @@ def main():
     import bench
     res = {"reads_per_gpu": reads, "read_len": read_len, "source_digest": bench.source_digest(), "source_digest_place": bench.source_digest_place(),
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes), tools/profile_r04_pmc.sh"}
-    for name, sub in (("dominant_kernel", "k_align_compact"), ("k_compact_seeds", "k_compact_seeds"), ("k_align_reads_tpp", "k_align_reads_tpp"), ("k_align_reads_t1", "k_align_reads_t1"),
+    for name, sub in (("dominant_kernel", r"k_align_compact(16|32)\("), ("k_align_compact_multi", r"k_align_compact(16|32)_multi"), ("k_compact_seeds", "k_compact_seeds"), ("k_align_reads_tpp", "k_align_reads_tpp"), ("k_align_reads_t1", "k_align_reads_t1"),
                       ("k_align_dp_group", "k_align_dp_group"), ("k_seed_histogram", "k_seed_histogram"), ("k_collapse_reads", "k_collapse_reads"),
                       ("k_score_chains", "k_score_chains"), ("k_score_terms", "k_score_terms"), ("k_table_compact", "k_table_compact"), ("k_pack_reads", "k_pack_reads")):
         f = per_launch(fetch_dir, "FETCH_SIZE", sub)
@@ -43,7 +47,7 @@ def main():
         if name in ("k_align_reads_tpp", "k_seed_histogram"):      # several launches per step: the per-step sum over the largest ones is not
             pass                                                    # meaningful per launch; the mean is what is reported
         fetch_kb, write_kb = sum(f) / len(f), sum(w) / len(w)
-        ent = {"name": sub + ("16 (all pairs, one launch per step)" if name == "dominant_kernel" else ""), "launches_seen": len(f),
+        ent = {"name": "k_align_compact16 (all pairs, one launch per step)" if name == "dominant_kernel" else name, "launches_seen": len(f),
                "FETCH_SIZE_raw_bytes": fetch_kb * 1024, "WRITE_SIZE_raw_bytes": write_kb * 1024,
                "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024, "hbm_bytes_per_launch_uncorrected": fetch_kb * 1024 + write_kb * 1024}
         valu, salu = per_launch(sq_dir, "SQ_INSTS_VALU", sub), per_launch(sq_dir, "SQ_INSTS_SALU", sub)
