@@ -59,6 +59,12 @@ struct AlignArgs {
     uint32_t* multi_list;
     unsigned long long* multi_count;   // [0] length of multi_list, [1] pairs the second form finished
     uint32_t* multi_ws;                // region records of the second form: PMX_CM_WS_WORDS * 64 words per wave of its grid
+    // The pairs k_compact_seeds* gave up on (an ambiguous base, a sketch tie, ...) are known before the chain kernel starts:
+    // k_compact_list_seed_bails lists them (early_list / early_count, retry_list order = launch order) and the general tiers
+    // run them on a second stream BESIDE the chain kernel; seed_bails_listed != 0 tells k_align_compact* to pass them over.
+    uint32_t* early_list;
+    unsigned long long* early_count;
+    int seed_bails_listed;
 
     unsigned long long* prof;   // 16 phase-cycle accumulators (diagnostic; NULL = off)
     int32_t* edits;             // NULL, or per read: count_read_errors (src/mm_align.c:122-133) of its first region, the read length without one
@@ -90,6 +96,7 @@ __global__ void k_align_compact16_fused(AlignArgs A);   // sketch and probes ins
 __global__ void k_align_compact32_fused(AlignArgs A);
 __global__ void k_align_compact16_multi(AlignArgs A);   // over multi_list (grid-stride, the length is read on the device)
 __global__ void k_align_compact32_multi(AlignArgs A);
+__global__ void k_compact_list_seed_bails(AlignArgs A);   // cseed_n == PMX_C_NSEED_BAIL -> early_list / early_count
 __global__ void k_compact_seeds16(AlignArgs A);   // sketch + index probes of every pair -> cseeds / cseed_n
 __global__ void k_compact_seeds32(AlignArgs A);
 

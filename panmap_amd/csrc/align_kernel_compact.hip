@@ -72,6 +72,21 @@ __device__ __forceinline__ void compact_seeds_body(const AlignArgs& A) {
 __global__ void __launch_bounds__(64) k_compact_seeds16(AlignArgs A) { compact_seeds_body<uint16_t>(A); }
 __global__ void __launch_bounds__(64) k_compact_seeds32(AlignArgs A) { compact_seeds_body<uint32_t>(A); }
 
+// The pairs the seeds kernel gave up on, as a list of pair ids in launch order (one atomic per wave)
+__global__ void __launch_bounds__(256) k_compact_list_seed_bails(AlignArgs A) {
+    const int lane = (int)(threadIdx.x & 63u);
+    for (int64_t it0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63LL; it0 < A.n_items; it0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t it = it0 + lane;
+        const bool hit = it < A.n_items && A.cseed_n[it] == PMX_C_NSEED_BAIL;
+        const unsigned long long mask = __ballot(hit);
+        if (!mask) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(A.early_count, (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0);
+        if (hit) A.early_list[base + __popcll(mask & ((1ULL << lane) - 1ULL))] = A.pair_perm ? A.pair_perm[it] : (uint32_t)it;
+    }
+}
+
 // What a pair of either form leaves behind: an entry of the bail list (one atomic per wave), or its two records and CIGAR
 // words (one arena atomic per wave).  Called by every lane of the wave.
 __device__ __forceinline__ void compact_emit(const AlignArgs& A, int lane, int64_t item, bool bail, bool done, const CResult& res) {
@@ -155,8 +170,10 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
             if (it < A.n_items) {
                 item = compact_item(A, it, rd, amb);
                 const uint32_t c = A.cseed_n[it];
-                if (c == PMX_C_NSEED_BAIL) rc = PMX_C_BAIL;
-                else { n_s = (int)(c & 0xffu); n_s0 = (int)(c >> 8); }
+                if (c == PMX_C_NSEED_BAIL) {
+                    if (A.seed_bails_listed) item = -1;   // already with the general tiers (k_compact_list_seed_bails)
+                    else rc = PMX_C_BAIL;
+                } else { n_s = (int)(c & 0xffu); n_s0 = (int)(c >> 8); }
             }
             CSeedOutT<PT> so;
             so.q = nullptr;

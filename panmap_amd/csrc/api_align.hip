@@ -53,6 +53,7 @@ struct pmx_aligner {
     DevBuf<uint32_t> multi_list;        // compact tier, second form (several regions per mate): launch positions + counters
     DevBuf<unsigned long long> multi_count;
     DevBuf<uint32_t> multi_ws;
+    DevBuf<uint32_t> early_list;        // pairs the compact tier's seeds kernel gave up on (run beside the chain kernels)
     DevBuf<uint8_t> dp_req;
     DevBuf<DpRes> dp_res;
     DevBuf<uint32_t> dp_ncached, dp_slot_pairs, dp_list_a, dp_list_b;
@@ -382,6 +383,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     A.work_queue = nullptr;
     A.cseeds = nullptr; A.cseed_n = nullptr;
     A.multi_list = nullptr; A.multi_count = nullptr; A.multi_ws = nullptr;
+    A.early_list = nullptr; A.early_count = nullptr; A.seed_bails_listed = 0;
     A.words = rs->words.p; A.amb = rs->amb.p; A.woff = rs->woff.p; A.off = rs->off.p;
     A.recs = rs->has_recs && rs->packed ? rs->recs.p : nullptr;
     A.paired = paired ? 1 : 0;
@@ -483,11 +485,32 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
     if (tier1_fits) {
         al->retry_list.ensure((size_t)n_items);
         al->retry_list2.ensure((size_t)n_items);
-        int64_t n_t1 = n_items;
-        const uint32_t* t1_list = nullptr;
         al->last_tpp_retry = 0;
         al->last_dp_requests = 0;
         al->last_dp_rounds = 0;
+        al->last_dp_slots = 0;
+        al->last_retry = 0;
+        // the wave-per-pair tiers over a list of pairs (nullptr: every item)
+        auto run_wave_tiers = [&](int64_t n_t1, const uint32_t* t1_list) {
+            int64_t n_retry = 0, unused = 0;
+            if (n_t1 > 0) {
+                launch(kern_t1, compact, n_t1, t1_list, al->retry_list.p, al->slow);
+                read_counts(n_retry, unused, true);
+            }
+            al->last_retry += n_retry;
+            if (n_retry > 0) {
+                // general capacities; what overflows even those (a mate whose every minimizer hits a long repeat: hundreds of
+                // anchors per minimizer) runs once more with 16x the anchors (the chain cells index anchors with 16 bits), a few waves with their arrays in HBM
+                launch(kern, general, n_retry, al->retry_list.p, al->retry_list2.p, al->slow2);
+                int64_t n_huge = 0;
+                read_counts(n_huge, unused, true);
+                if (n_huge > 0) {
+                    const Layout huge = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget, 0, 16));
+                    launch(kern, huge, n_huge, al->retry_list2.p, nullptr, al->slow2, 64);
+                }
+            }
+        };
+        if (!use_tier0) run_wave_tiers(n_items, nullptr);
         if (use_tier0) {   // tier 0: thread per pair + DP service rounds
             int tpp_waves = 16;   // 4 per SIMD: what k_align_reads_tpp's register allocation targets (PMX_TPP_OCC)
             if (const char* e = pmx::opt_str(pmx::O_ALIGN_TPP_WAVES)) tpp_waves = atoi(e);
@@ -534,25 +557,35 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 al->dp_list_b.ensure((size_t)n_items);
                 al->slow.ensure(dp_stride * (size_t)dp_max_grid);
                 al->slow2.ensure(dps_stride * (size_t)dps_max_grid);
-                PMX_HIP(hipMemsetAsync(al->dp_ncached.p, 0, sizeof(uint32_t) * (size_t)n_items, ctx->stream));
-                A.dp_req_base = al->dp_req.p; A.dp_res_base = al->dp_res.p; A.dp_ncached = al->dp_ncached.p;
-                A.dp_slot_pairs = al->dp_slot_pairs.p;
-                A.dp_slot_cap = (uint32_t)std::min<int64_t>(n_items, UINT32_MAX - 1);
-                if (!pmx::opt_str(pmx::O_ALIGN_NO_MV_HANDOVER)) {
-                    A.mv_stride = (uint32_t)tpp_layout.caps.max_mini + 1u;
-                    A.mv_slots = (uint32_t)std::min<int64_t>(A.dp_slot_cap, 131072);
-                    al->mv_handover.ensure((size_t)A.mv_slots * A.mv_stride);
-                    A.mv_handover = al->mv_handover.p;
-                }
+                if (!pmx::opt_str(pmx::O_ALIGN_NO_MV_HANDOVER))
+                    al->mv_handover.ensure((size_t)std::min<int64_t>(std::min<int64_t>(n_items, UINT32_MAX - 1), 131072) * ((size_t)tpp_layout.caps.max_mini + 1u));
             }
             // minimizer window ring in LDS when 16 waves per CU still fit (12 B x w x 64 lanes per wave)
             size_t tpp_lds_bytes = (size_t)al->opt.w * 64 * 12;
             if (tpp_lds_bytes * (size_t)tpp_waves > (size_t)150 * 1024 || pmx::opt_str(pmx::O_ALIGN_NO_LDS_RING)) tpp_lds_bytes = 0;
-            A.tpp_ring_w = tpp_lds_bytes ? al->opt.w : 0;
-            A.dp_count = al->retry_count.p + 1;
-            A.retry_list = al->retry_list2.p;
-            A.retry_count = al->retry_count.p;
-            A.layout = tpp_layout;
+            // what the thread-per-pair passes and the DP service read from the launch arguments (a run of the tail clears them
+            // at its end; the tail may run twice per call: see run_tail)
+            auto tail_setup = [&]() {
+                if (use_dp_service) {
+                    PMX_HIP(hipMemsetAsync(al->dp_ncached.p, 0, sizeof(uint32_t) * (size_t)n_items, ctx->stream));
+                    A.dp_req_base = al->dp_req.p; A.dp_res_base = al->dp_res.p; A.dp_ncached = al->dp_ncached.p;
+                    A.dp_slot_pairs = al->dp_slot_pairs.p;
+                    A.dp_slot_cap = (uint32_t)std::min<int64_t>(n_items, UINT32_MAX - 1);
+                    if (!pmx::opt_str(pmx::O_ALIGN_NO_MV_HANDOVER)) {
+                        A.mv_stride = (uint32_t)tpp_layout.caps.max_mini + 1u;
+                        A.mv_slots = (uint32_t)std::min<int64_t>(A.dp_slot_cap, 131072);
+                        A.mv_handover = al->mv_handover.p;
+                        A.mv_epoch = ++al->mv_epoch;   // (a slot may hold an entry of an earlier run)
+                    }
+                }
+                A.tpp_ring_w = tpp_lds_bytes ? al->opt.w : 0;
+                A.dp_count = al->retry_count.p + 1;
+                A.retry_list = al->retry_list2.p;
+                A.retry_count = al->retry_count.p;
+                A.layout = tpp_layout;
+                A.worklist = nullptr;
+                A.dp_round = 0;
+            };
             auto launch_tpp = [&](int round, int64_t n_work, const uint32_t* worklist, uint32_t* next_list) {
                 int64_t grid = std::min<int64_t>(max_grid, (n_work + 63) / 64);
                 A.slow_stride = tpp_raw_stride;
@@ -592,92 +625,15 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             int64_t n_t0 = n_items;
             const bool use_compact = paired && al->opt.is_sr_like && al->opt.w == PMX_C_W && (al->opt.k & 1) && rs->max_len <= PMX_C_MAXLEN && n_items < (int64_t)UINT32_MAX && !pmx::opt_str(pmx::O_ALIGN_NO_COMPACT);
             if (!use_compact) timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
-            if (use_compact) {
-                al->bail_list.ensure((size_t)n_items);
-                const bool pos16 = al->ri.len <= 32767 && !pmx::opt_str(pmx::O_ALIGN_COMPACT_POS32);
-                const bool c_fused = pmx::opt_str(pmx::O_ALIGN_COMPACT_FUSED) != nullptr;
-                auto c_kern = c_fused ? (pos16 ? k_align_compact16_fused : k_align_compact32_fused) : (pos16 ? k_align_compact16 : k_align_compact32);
-                const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
-                // One workgroup (wave) per 64 pairs, handed out by the dispatcher as CUs free up: the pairs of a wave cost what
-                // their worst lane costs, and with a resident grid striding over the positions (PMX_ALIGN_COMPACT_WAVES = waves
-                // per CU brings it back) the slowest stride set the kernel's end -- 10M reads: 17.05 -> 15.5 ms, and the seeds
-                // kernel below 4.77 -> 4.10 ms.  (The hardware keeps 160 KB / c_lds = seven waves per CU resident either way.)
-                int64_t c_grid = (n_items + 63) / 64;
-                if (const char* e = pmx::opt_str(pmx::O_ALIGN_COMPACT_WAVES)) c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), c_grid);
-                A.n_items = n_items;
-                A.pair_perm = order;
-                A.retry_list = al->bail_list.p;
-                A.retry_count = al->retry_count.p + 2;
-                // Two-kernel form (default): sketch + index probes in k_compact_seeds, whose only LDS is the minimizer queue
-                // -- 7 KB per wave against the 21 KB of the pairs' work state, so that part runs at the occupancy its
-                // registers allow instead of seven waves per CU; the seeds cross in HBM (224 bytes per pair with 16-bit
-                // position words).  PMX_ALIGN_COMPACT_FUSED keeps everything in k_align_compact.
-                if (!c_fused) {
-                    const size_t blocks = (size_t)((n_items + 63) / 64);
-                    al->cseeds.ensure(blocks * (size_t)PMX_C_CAP * (pos16 ? 1 : 2) * 64);
-                    al->cseed_n.ensure(blocks * 64);
-                    A.cseeds = al->cseeds.p;
-                    A.cseed_n = al->cseed_n.p;
-                    // (four waves per SIMD by the kernel's 113 VGPRs; a resident grid of 8 / 12 / 16 waves per CU -- PMX_ALIGN_CSEED_WAVES --
-                    // takes 7.5 / 6.0 / 4.8 ms per 5M pairs, one workgroup per 64 pairs 4.1; the register budget of five waves per
-                    // SIMD spills and gains 1 %, of six loses)
-                    auto s_kern = pos16 ? k_compact_seeds16 : k_compact_seeds32;
-                    int64_t s_grid = (n_items + 63) / 64;
-                    if (const char* e = pmx::opt_str(pmx::O_ALIGN_CSEED_WAVES)) s_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), s_grid);
-                    timer_begin(ctx, "align_cseeds");
-                    hipLaunchKernelGGL(s_kern, dim3((unsigned)s_grid), dim3(64), (size_t)PMX_C_SEEDQ * 2 * 64 * sizeof(uint32_t),
-                                       ctx->stream, A);
-                    PMX_HIP(hipGetLastError());
-                    timer_end(ctx, "align_cseeds", 1);
-                }
-                // Second form (k_align_compact*_multi): the pairs that leave the first one after their seeds -- a third chain, two
-                // regions on one mate (mates that overlap on the reference: 55 % of the real example pairs), ... -- are run again
-                // from their hand-over words with up to four chains and several regions per mate; what is still left goes to the
-                // thread-per-pair tier.  PMX_ALIGN_NO_MULTI: every bail goes there at once.
-                const bool c_multi = !c_fused && !pmx::opt_str(pmx::O_ALIGN_NO_MULTI);
-                if (c_multi) {
-                    al->multi_list.ensure((size_t)n_items);
-                    al->multi_count.ensure(2);
-                    PMX_HIP(hipMemsetAsync(al->multi_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-                    A.multi_list = al->multi_list.p;
-                    A.multi_count = al->multi_count.p;
-                }
-                timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
-                hipLaunchKernelGGL(c_kern, dim3((unsigned)c_grid), dim3(64), c_lds, ctx->stream, A);
-                PMX_HIP(hipGetLastError());
-                timer_end(ctx, "align_dom", 1);
-                if (c_multi) {
-                    // (the list's length stays on the device: a resident grid -- seven waves per CU by the LDS -- strides over it)
-                    const int64_t m_grid = std::min<int64_t>((n_items + 63) / 64, (int64_t)ctx->n_cu * 7);
-                    al->multi_ws.ensure((size_t)m_grid * PMX_CM_WS_WORDS * 64);
-                    A.multi_ws = al->multi_ws.p;
-                    timer_begin(ctx, "align_cmulti");
-                    hipLaunchKernelGGL(pos16 ? k_align_compact16_multi : k_align_compact32_multi, dim3((unsigned)m_grid), dim3(64), c_lds, ctx->stream, A);
-                    PMX_HIP(hipGetLastError());
-                    timer_end(ctx, "align_cmulti", 1);
-                }
-                A.cseeds = nullptr; A.cseed_n = nullptr;
-                A.multi_list = nullptr; A.multi_count = nullptr; A.multi_ws = nullptr;
-                if (A.prof) {   // the compact tier's own phase profile, then the accumulators start over for the general tiers
-                    unsigned long long h[8];
-                    PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-                    PMX_HIP(hipStreamSynchronize(ctx->stream));
-                    PMX_HIP(hipMemsetAsync(al->prof.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
-                    static const char* cn[8] = {"sketch", "probes", "merge", "chain fill", "backtrack", "regions", "align+mapq", "pairing"};
-                    const double waves = (double)((n_items + 63) / 64);
-                    fprintf(stderr, "[pmx compact tier: cycles per wave (lane 0)]");
-                    for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.0f", cn[k], (double)h[k] / waves);
-                    fprintf(stderr, "\n");
-                }
-                unsigned long long h_bail = 0;
-                PMX_HIP(hipMemcpyAsync(&h_bail, al->retry_count.p + 2, sizeof(h_bail), hipMemcpyDeviceToHost, ctx->stream));
-                PMX_HIP(hipStreamSynchronize(ctx->stream));
-                n_t0 = (int64_t)h_bail;
-                order = al->bail_list.p;
-                al->last_compact = n_items - n_t0;
-                A.retry_list = al->retry_list2.p;
-                A.retry_count = al->retry_count.p;
-            }
+            bool early_running = false;
+            // THE TAIL: the general tiers over a list of pairs in launch order (`order`, n_t0 of them; nullptr = every item):
+            // thread-per-pair pass, DP service rounds with replays, then the wave-per-pair tiers for what is left.  With the
+            // compact tier it runs twice per call: once BESIDE the compact chain kernel, on the context's second stream, for
+            // the pairs the seeds kernel gave up on, and once after it for the pairs the chain kernels hand back.
+            auto run_tail = [&](const uint32_t* order, int64_t n_t0) {
+            tail_setup();
+            int64_t n_t1 = n_t0;
+            const uint32_t* t1_list = order;
             // Few bails: a thread-per-pair launch that small cannot fill the chip and lasts as long as a full one (a wave takes
             // ~2 ms whatever the grid) before the wave-per-pair tier gets the pairs that need a DP; below 4096 bails the wave
             // tier takes all of them at once (measured with 2.8k bails of 500k pairs: 5.8 ms for the stage instead of 7.0).
@@ -691,7 +647,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             int64_t n_dp = 0;
             if (!skip_t0) read_counts(n_t1, n_dp, false);
             n_dp = std::min<int64_t>(n_dp, (int64_t)A.dp_slot_cap);
-            al->last_dp_slots = n_dp;
+            al->last_dp_slots += n_dp;
             const uint32_t* cur = nullptr;   // round 1 serves slots 0..n_dp-1
             uint32_t* lists[2] = {al->dp_list_a.p, al->dp_list_b.p};
             int round = 1;
@@ -846,7 +802,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 cur = next;
                 ++round;
             }
-            al->last_dp_rounds = round - 1;
+            al->last_dp_rounds = std::max(al->last_dp_rounds, round - 1);
             A.dp_req_base = nullptr; A.dp_res_base = nullptr; A.dp_ncached = nullptr;
             A.dp_next_list = nullptr; A.dp_count = nullptr; A.dp_slot_cap = 0; A.dp_round = 0;
             if (n_small > 0) {   // their capacity overflows (rare) join the tier-1 retry list through counter [0]
@@ -865,23 +821,144 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
             PMX_HIP(hipMemsetAsync(al->retry_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
             t1_list = al->retry_list2.p;
             if (skip_t0) { t1_list = order; n_t1 = n_t0; }
-            al->last_tpp_retry = n_t1;
-        }
-        int64_t n_retry = 0, unused = 0;
-        if (n_t1 > 0) {
-            launch(kern_t1, compact, n_t1, t1_list, al->retry_list.p, al->slow);
-            read_counts(n_retry, unused, true);
-        }
-        al->last_retry = n_retry;
-        if (n_retry > 0) {
-            // general capacities; what overflows even those (a mate whose every minimizer hits a long repeat: hundreds of
-            // anchors per minimizer) runs once more with 16x the anchors (the chain cells index anchors with 16 bits), a few waves with their arrays in HBM
-            launch(kern, general, n_retry, al->retry_list.p, al->retry_list2.p, al->slow2);
-            int64_t n_huge = 0;
-            read_counts(n_huge, unused, true);
-            if (n_huge > 0) {
-                const Layout huge = hooked(plan_layout((int)rs->max_len, n_segs, al->opt, lds_budget, 0, 16));
-                launch(kern, huge, n_huge, al->retry_list2.p, nullptr, al->slow2, 64);
+            al->last_tpp_retry += n_t1;
+            A.mv_handover = nullptr; A.mv_stride = 0; A.mv_slots = 0;
+            run_wave_tiers(n_t1, t1_list);
+            };   // run_tail
+            if (use_compact) {
+                al->bail_list.ensure((size_t)n_items);
+                const bool pos16 = al->ri.len <= 32767 && !pmx::opt_str(pmx::O_ALIGN_COMPACT_POS32);
+                const bool c_fused = pmx::opt_str(pmx::O_ALIGN_COMPACT_FUSED) != nullptr;
+                auto c_kern = c_fused ? (pos16 ? k_align_compact16_fused : k_align_compact32_fused) : (pos16 ? k_align_compact16 : k_align_compact32);
+                const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
+                // One workgroup (wave) per 64 pairs, handed out by the dispatcher as CUs free up: the pairs of a wave cost what
+                // their worst lane costs, and with a resident grid striding over the positions (PMX_ALIGN_COMPACT_WAVES = waves
+                // per CU brings it back) the slowest stride set the kernel's end -- 10M reads: 17.05 -> 15.5 ms, and the seeds
+                // kernel below 4.77 -> 4.10 ms.  (The hardware keeps 160 KB / c_lds = seven waves per CU resident either way.)
+                int64_t c_grid = (n_items + 63) / 64;
+                if (const char* e = pmx::opt_str(pmx::O_ALIGN_COMPACT_WAVES)) c_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), c_grid);
+                A.n_items = n_items;
+                A.pair_perm = order;
+                A.retry_list = al->bail_list.p;
+                A.retry_count = al->retry_count.p + 2;
+                // Two-kernel form (default): sketch + index probes in k_compact_seeds, whose only LDS is the minimizer queue
+                // -- 7 KB per wave against the 21 KB of the pairs' work state, so that part runs at the occupancy its
+                // registers allow instead of seven waves per CU; the seeds cross in HBM (224 bytes per pair with 16-bit
+                // position words).  PMX_ALIGN_COMPACT_FUSED keeps everything in k_align_compact.
+                if (!c_fused) {
+                    const size_t blocks = (size_t)((n_items + 63) / 64);
+                    al->cseeds.ensure(blocks * (size_t)PMX_C_CAP * (pos16 ? 1 : 2) * 64);
+                    al->cseed_n.ensure(blocks * 64);
+                    A.cseeds = al->cseeds.p;
+                    A.cseed_n = al->cseed_n.p;
+                    // (four waves per SIMD by the kernel's 113 VGPRs; a resident grid of 8 / 12 / 16 waves per CU -- PMX_ALIGN_CSEED_WAVES --
+                    // takes 7.5 / 6.0 / 4.8 ms per 5M pairs, one workgroup per 64 pairs 4.1; the register budget of five waves per
+                    // SIMD spills and gains 1 %, of six loses)
+                    auto s_kern = pos16 ? k_compact_seeds16 : k_compact_seeds32;
+                    int64_t s_grid = (n_items + 63) / 64;
+                    if (const char* e = pmx::opt_str(pmx::O_ALIGN_CSEED_WAVES)) s_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), s_grid);
+                    timer_begin(ctx, "align_cseeds");
+                    hipLaunchKernelGGL(s_kern, dim3((unsigned)s_grid), dim3(64), (size_t)PMX_C_SEEDQ * 2 * 64 * sizeof(uint32_t),
+                                       ctx->stream, A);
+                    PMX_HIP(hipGetLastError());
+                    timer_end(ctx, "align_cseeds", 1);
+                }
+                // PMX_ALIGN_EARLY_TAIL (off by default): the pairs the seeds kernel gave up on (a read with an `N`, a sketch tie,
+                // a repeated minimizer, ...) are known now; list them and let the general tiers run them on the context's second
+                // stream while this stream runs the chain kernels.  Measured at 10M reads (profiles/r04/README.md): the first
+                // thread-per-pair pass does run beside k_align_compact16, the DP service behind it cannot (the chain kernel's
+                // seven waves per CU leave 9.5 KB of LDS) and waits for its end, and the pairs the chain kernels hand back then
+                // take a tail of their own instead of sharing one: 37.1 ms per step against 35.  Kept as a tested switch.
+                int64_t n_early = 0;
+                const bool c_early = !c_fused && pmx::opt_str(pmx::O_ALIGN_EARLY_TAIL) && !A.prof;
+                if (c_early) {
+                    al->early_list.ensure((size_t)n_items);
+                    al->multi_count.ensure(4);
+                    PMX_HIP(hipMemsetAsync(al->multi_count.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+                    A.early_list = al->early_list.p;
+                    A.early_count = al->multi_count.p + 2;
+                    hipLaunchKernelGGL(k_compact_list_seed_bails, dim3((unsigned)std::min<int64_t>((n_items + 255) / 256, (int64_t)ctx->n_cu * 8)), dim3(256), 0, ctx->stream, A);
+                    PMX_HIP(hipGetLastError());
+                    unsigned long long h_early = 0;
+                    PMX_HIP(hipMemcpyAsync(&h_early, A.early_count, sizeof(h_early), hipMemcpyDeviceToHost, ctx->stream));
+                    if (!ctx->tail_go) {
+                        PMX_HIP(hipEventCreateWithFlags(&ctx->tail_go, hipEventDisableTiming));
+                        PMX_HIP(hipEventCreateWithFlags(&ctx->tail_done, hipEventDisableTiming));
+                    }
+                    PMX_HIP(hipEventRecord(ctx->tail_go, ctx->stream));   // the list is made: what the second stream waits for
+                    PMX_HIP(hipStreamSynchronize(ctx->stream));
+                    n_early = (int64_t)h_early;
+                    A.seed_bails_listed = 1;
+                }
+                // Second form (k_align_compact*_multi): the pairs that leave the first one after their seeds -- a third chain, two
+                // regions on one mate (mates that overlap on the reference: 55 % of the real example pairs), ... -- are run again
+                // from their hand-over words with up to four chains and several regions per mate; what is still left goes to the
+                // thread-per-pair tier.  PMX_ALIGN_NO_MULTI: every bail goes there at once.
+                const bool c_multi = !c_fused && !pmx::opt_str(pmx::O_ALIGN_NO_MULTI);
+                if (c_multi) {
+                    al->multi_list.ensure((size_t)n_items);
+                    al->multi_count.ensure(4);
+                    PMX_HIP(hipMemsetAsync(al->multi_count.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+                    A.multi_list = al->multi_list.p;
+                    A.multi_count = al->multi_count.p;
+                }
+                timer_begin(ctx, "align_dom");   // the dominant kernel on its own (bench.py roofline)
+                hipLaunchKernelGGL(c_kern, dim3((unsigned)c_grid), dim3(64), c_lds, ctx->stream, A);
+                PMX_HIP(hipGetLastError());
+                timer_end(ctx, "align_dom", 1);
+                if (c_multi) {
+                    // (the list's length stays on the device: a resident grid -- seven waves per CU by the LDS -- strides over it)
+                    const int64_t m_grid = std::min<int64_t>((n_items + 63) / 64, (int64_t)ctx->n_cu * 7);
+                    al->multi_ws.ensure((size_t)m_grid * PMX_CM_WS_WORDS * 64);
+                    A.multi_ws = al->multi_ws.p;
+                    timer_begin(ctx, "align_cmulti");
+                    hipLaunchKernelGGL(pos16 ? k_align_compact16_multi : k_align_compact32_multi, dim3((unsigned)m_grid), dim3(64), c_lds, ctx->stream, A);
+                    PMX_HIP(hipGetLastError());
+                    timer_end(ctx, "align_cmulti", 1);
+                }
+                A.cseeds = nullptr; A.cseed_n = nullptr;
+                A.multi_list = nullptr; A.multi_count = nullptr; A.multi_ws = nullptr;
+                A.early_list = nullptr; A.early_count = nullptr; A.seed_bails_listed = 0;
+                if (n_early > 0) {
+                    // the early tail: same host code, enqueued on the second stream (every launch, copy and wait of the tail goes
+                    // through ctx->stream); the chain kernels are already queued on the first
+                    if (!ctx->pair_stream) ctx->pair_stream = create_dedicated_stream(ctx->n_cu);
+                    hipStream_t main_stream = ctx->stream;
+                    PMX_HIP(hipStreamWaitEvent(ctx->pair_stream, ctx->tail_go, 0));
+                    ctx->stream = ctx->pair_stream;
+                    try { run_tail(al->early_list.p, n_early); } catch (...) { ctx->stream = main_stream; throw; }
+                    PMX_HIP(hipEventRecord(ctx->tail_done, ctx->stream));
+                    ctx->stream = main_stream;
+                    early_running = true;
+                }
+                if (A.prof) {   // the compact tier's own phase profile, then the accumulators start over for the general tiers
+                    unsigned long long h[8];
+                    PMX_HIP(hipMemcpyAsync(h, al->prof.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+                    PMX_HIP(hipStreamSynchronize(ctx->stream));
+                    PMX_HIP(hipMemsetAsync(al->prof.p, 0, 32 * sizeof(unsigned long long), ctx->stream));
+                    static const char* cn[8] = {"sketch", "probes", "merge", "chain fill", "backtrack", "regions", "align+mapq", "pairing"};
+                    const double waves = (double)((n_items + 63) / 64);
+                    fprintf(stderr, "[pmx compact tier: cycles per wave (lane 0)]");
+                    for (int k = 0; k < 8; ++k) fprintf(stderr, " %s=%.0f", cn[k], (double)h[k] / waves);
+                    fprintf(stderr, "\n");
+                }
+                unsigned long long h_bail = 0;
+                PMX_HIP(hipMemcpyAsync(&h_bail, al->retry_count.p + 2, sizeof(h_bail), hipMemcpyDeviceToHost, ctx->stream));
+                PMX_HIP(hipStreamSynchronize(ctx->stream));
+                n_t0 = (int64_t)h_bail;
+                order = al->bail_list.p;
+                al->last_compact = n_items - n_t0 - n_early;
+                A.retry_list = al->retry_list2.p;
+                A.retry_count = al->retry_count.p;
+            }
+            if (!use_compact) run_tail(order, n_items);
+            else {
+                // the pairs the chain kernels hand back; the early tail (if one runs) must be through with the shared work buffers
+                if (early_running) {
+                    PMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->tail_done, 0));
+                    PMX_HIP(hipEventSynchronize(ctx->tail_done));
+                }
+                run_tail(al->bail_list.p, n_t0);
             }
         }
     } else {

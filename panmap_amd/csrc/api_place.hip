@@ -286,6 +286,8 @@ void pmx_ctx_destroy(pmx_ctx* ctx) {
         if (ctx->seed_done[j]) (void)hipEventDestroy(ctx->seed_done[j]);
     }
     if (ctx->seed_go) (void)hipEventDestroy(ctx->seed_go);
+    if (ctx->tail_go) (void)hipEventDestroy(ctx->tail_go);
+    if (ctx->tail_done) (void)hipEventDestroy(ctx->tail_done);
     if (ctx->pair_stream) (void)hipStreamDestroy(ctx->pair_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

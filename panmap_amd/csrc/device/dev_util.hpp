@@ -98,6 +98,9 @@ struct pmx_ctx {
     hipStream_t pair_stream = nullptr;       // pmx_readset_order_pairs
     hipStream_t seed_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t seed_go = nullptr, seed_done[3] = {nullptr, nullptr, nullptr};
+    // align stage: the general tiers of the pairs the compact tier's seeds kernel gave up on run on pair_stream beside the
+    // compact chain kernel (api_align.hip); these two events order that stream against the context's
+    hipEvent_t tail_go = nullptr, tail_done = nullptr;
 };
 
 namespace pmx {

@@ -37,6 +37,7 @@
     X(ALIGN_NO_COMPACT, "ab", "align: skip the compact tier (every pair through the general tiers)")                                           \
     X(ALIGN_COMPACT_FUSED, "ab", "align: compact tier as one kernel (sketch + probes inside k_align_compact)")                                 \
     X(ALIGN_COMPACT_POS32, "test", "align: compact tier with 32-bit position words whatever the reference length")                             \
+    X(ALIGN_EARLY_TAIL, "ab", "align: the pairs the compact tier's seeds kernel gave up on run on a second stream beside the chain kernels")   \
     X(ALIGN_NO_MULTI, "ab", "align: compact tier without its second form (several regions per mate): every bail to the thread-per-pair tier")  \
     X(ALIGN_COMPACT_WAVES, "tune", "align: compact chain kernel on a resident grid of N waves per CU (default: one workgroup per 64 pairs)")    \
     X(ALIGN_CSEED_WAVES, "tune", "align: compact seeds kernel on a resident grid of N waves per CU")                                           \

@@ -30,6 +30,8 @@ FORMS = {
     "pos32": {"PMX_ALIGN_COMPACT_POS32": "1"},
     "pos32_fused": {"PMX_ALIGN_COMPACT_POS32": "1", "PMX_ALIGN_COMPACT_FUSED": "1"},
     "resident_grids": {"PMX_ALIGN_COMPACT_WAVES": "7", "PMX_ALIGN_CSEED_WAVES": "16"},
+    # the general tiers of the pairs the seeds kernel gave up on, on the context's second stream beside the chain kernels
+    "early_tail": {"PMX_ALIGN_EARLY_TAIL": "1"},
 }
 
 
@@ -41,7 +43,8 @@ def test_compact_tier_forms_equal_reference(pmx, oracle, ctx, form, monkeypatch)
     clean = _pairs(pmx, g, 3000, 41)
     noisy = _pairs(pmx, g, 1500, 42, sub_rate=0.01)
     al = pmx.Aligner(ctx, g, 150)
-    for name, reads, floor in (("clean", clean, 0.95), ("noisy", noisy, 0.5)):
+    with_n = [r if i % 3 else r[:40] + b"NN" + r[42:] for i, r in enumerate(_pairs(pmx, g, 12000, 43))]   # enough bails for the thread-per-pair passes
+    for name, reads, floor in (("clean", clean, 0.95), ("noisy", noisy, 0.5), ("with_n", with_n, 0.2)):
         got = al.align_reads(reads, paired=True)
         want = oracle.ref_align_reads_direct(g, reads, True, 8)
         bad = ac.compare_results(got, want)
