@@ -80,3 +80,11 @@ def test_compact_second_form_on_example_reads(pmx, oracle, ctx, monkeypatch):
         assert st["n_items"] == len(reads) // 2
     assert finished["multi"] > 2 * finished["no_multi"] and finished["multi"] >= 0.7 * (len(reads) // 2), finished
     assert finished["multi_pos32"] == finished["multi"]
+    # the edit counts (score_reads_vs_reference, what --refine sums): the second form's equal the general tiers' and the reference's
+    rs = pmx.ReadSet(ctx, reads)
+    want_score = oracle.ref_score_reads(g, reads, True)
+    assert al.score_reads(rs, True, False) == want_score
+    monkeypatch.setenv("PMX_ALIGN_NO_MULTI", "1")
+    assert al.score_reads(rs, True, False) == want_score
+    monkeypatch.delenv("PMX_ALIGN_NO_MULTI", raising=False)
+    rs.close()
