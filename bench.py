@@ -336,7 +336,8 @@ def main():
     # measured at 1.25M reads: 156 M reads/s with two, 169-175 with three, 187 with four, 162 with six; at 2.5M three gain 3 %,
     # at 10M three are not better (249-356 M) and four lose).  Every context owns hardware queues: four pipelines work because
     # the place stage keeps small ranges on the context's own stream (api_place.hip)
-    n_pipes = args.pipelines or (1 if long_reads else (4 if n_reads <= 2000000 else 2))
+    # (2.5M reads: 212 M reads/s with two, 224 with three, 232 with four; 5M: 275 / 253 / 246)
+    n_pipes = args.pipelines or (1 if long_reads else (4 if n_reads <= 3000000 else 2))
     # (one chunk by default: with two batches in flight the upload of a batch overlaps the kernels of the other one, and a
     # batch seeded as a whole sizes its seed table once; --h2d-chunks > 1 packs + seeds range by range behind the copies)
     n_chunks = args.h2d_chunks or 1

@@ -722,10 +722,10 @@ static int add_reads_impl(pmx_ctx* ctx, pmx_place* pl, const pmx_readset* rs, in
         // A launch of one chunk is latency-bound (every wave walks its 150 bases one after the other, a few waves per
         // SIMD): the chunks of a group run concurrently on side streams, sharing the table (all they do is atomics).
         // (round 4, after the read collapse: one chunk at a time is as fast -- 10M reads 4.8 ms either way, 1.25M 1.42 against
-        //  1.53 -- so small ranges stay on the context's own stream: every side stream is a hardware queue, and a host that
-        //  keeps four batches of a small job in flight, bench.py under 2M reads, ran into the queue limit with them: its
+        //  1.53 -- so ranges under 4M reads stay on the context's own stream: every side stream is a hardware queue, and a host that
+        //  keeps four batches of a small job in flight, bench.py up to 3M reads, ran into the queue limit with them: its
         //  one-batch-at-a-time leg fell from 102 to 57-67 M reads/s)
-        int n_par = rr1 - rr0 >= 2000000 ? 3 : 1;
+        int n_par = rr1 - rr0 >= 4000000 ? 3 : 1;
         if (const char* e = pmx::opt_str(pmx::O_SEED_PAR)) n_par = std::max(1, std::min(4, atoi(e)));
         if (n_par > 1 && !ctx->seed_go) {
             PMX_HIP(hipEventCreateWithFlags(&ctx->seed_go, hipEventDisableTiming));

@@ -9,8 +9,11 @@ d=json.load(open("/tmp/o.json")); k=d["kernels_ms"]
 print("%-40s value %.1f M/s (%.2f ms/step)  one-at-a-time %.1f M/s  align %.2f seed %.2f pipes %d" % (sys.argv[1], d["value"]/1e6, d["ms_per_step"], d["value_device_resident"]/1e6, k["align stage (all tiers)"], k["seed stage (k_seed_histogram, chunked)"], d["config"]["batches_in_flight"]))
 P
 }
-run "1.25M default" X=1 -- --total-reads 1250000
-run "1.25M p4 seedpar1" PMX_SEED_PAR=1 -- --total-reads 1250000 --pipelines 4
-run "1.25M p3" X=1 -- --total-reads 1250000 --pipelines 3
-run "1.25M default again" X=1 -- --total-reads 1250000
-run "1.25M default steps40" X=1 -- --total-reads 1250000 --steps 40 --warmup 8
+run "2.5M p2" X=1 -- --total-reads 2500000
+run "2.5M p3 seedpar1" PMX_SEED_PAR=1 -- --total-reads 2500000 --pipelines 3
+run "2.5M p4 seedpar1" PMX_SEED_PAR=1 -- --total-reads 2500000 --pipelines 4
+run "5M p2" X=1 -- --total-reads 5000000
+run "5M p3 seedpar1" PMX_SEED_PAR=1 -- --total-reads 5000000 --pipelines 3
+run "5M p4 seedpar1" PMX_SEED_PAR=1 -- --total-reads 5000000 --pipelines 4
+run "10M p2 seedpar1" PMX_SEED_PAR=1 --
+run "10M p2" X=1 --
