@@ -703,7 +703,7 @@ def main():
         pp.alloc_outputs()
     h2h = None
     if not args.no_host_to_host:
-        run_batches(max(args.warmup, len(pipes)))
+        run_batches(max(args.warmup, 2 * len(pipes)))   # (untimed; two steps per pipeline: the second sizes what the first one's counts asked for)
         sync_all()
         t0 = time.perf_counter()
         run_batches(args.steps)
@@ -719,7 +719,7 @@ def main():
             pp.d_concat[slot].copy_(h_concat, non_blocking=True)
             pp.up_ev[slot] = None
     torch.cuda.synchronize()
-    run_batches(max(args.warmup, len(pipes)), resident_inputs=True)
+    run_batches(max(args.warmup, 2 * len(pipes)), resident_inputs=True)
     sync_all()
     t0 = time.perf_counter()
     run_batches(args.steps, resident_inputs=True)
@@ -935,6 +935,7 @@ def main():
                                                                         ("configs[1]" if n_reads == 1000000 else "custom size")),
                                        "" if world == 1 else "; seed index replicated, RCCL histogram all-gather + record/CIGAR gather")),
                        "reads_per_gpu": n_reads, "total_reads": total_reads, "read_len": args.read_len,
+                       "warmup_steps_run": max(args.warmup, 2 * len(pipes)),
                        "source_node": pm.node_id(src_node),
                        "generator": ("SURVEY 8d: leaf number splitmix64(42) mod 20000 of the tree, one splitmix64(42) stream, 35 draws per pair "
                                      "(start, insert ~ N(300,30) in [150,600], 0.2 % i.i.d. substitutions as geometric gaps), FR, no indels / N"
