@@ -1,5 +1,3 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-bash tools/profile_r04_pmc.sh > gpurun_out/pmc_r04.log 2>&1
-tail -4 gpurun_out/pmc_r04.log
-bash tools/prof_stats.sh r04p1 --steps 6 --warmup 2 --no-cpu-baseline --no-real-reads --no-host-to-host --pipelines 1 2>&1 | tail -3
 bash tools/run_final_bench.sh
+bash tools/run_gpu_suite.sh
