@@ -122,7 +122,8 @@ struct CMemT {
     PMX_HD uint64_t QM(int i) const { return M(kQBase + i); }
     PMX_HD void setQM(int i, uint64_t v) const { setM(kQBase + i, v); }
     PMX_HD void setSeed(int i, uint32_t x, uint32_t y) const { setX(i, x); h(kYH + i) = (c_u16)y; }
-    PMX_HD void orY(int i, uint32_t f) const { h(kYH + i) |= (c_u16)f; }
+    PMX_HD void orY(int i, uint32_t f, int /*seeds so far*/ = 0) const { h(kYH + i) |= (c_u16)f; }
+    PMX_HD void flush_tail(int /*seeds*/) const {}
     // anchor x split: strand, reference position
     PMX_HD static uint32_t rev_of(uint32_t x) { return x >> (8 * sizeof(PT) - 1); }
     PMX_HD static uint32_t pos_of(uint32_t x) { return x & (kRevBit - 1u); }
@@ -138,10 +139,13 @@ struct CMemT {
 
 // The seed hand-over of the two-kernel form (k_compact_seeds -> k_align_compact): the sketch and the index probes need
 // none of the pair's LDS state, only the short minimizer queue, so they run in a kernel of their own at twice the waves
-// per CU and leave the seeds -- the very X and Y words the fused form writes to LDS -- in HBM: block `b` of 64 launch
-// positions owns kCap * kWS * 64 words, word j of seed i of lane l at ((b * kCap + i) * kWS + j) * 64 + l (a wave
-// writing seed i of its pairs writes contiguous words; the chain kernel reads them back the same way).
-//   PT = u16: one word per seed, X | Y << 16;   PT = u32: two, X then Y.
+// per CU and leave the seeds -- the very X and Y words the fused form writes to LDS -- in HBM, launch position `it` owning
+// the kPairWords words from it * kPairWords on (PT = u16: one word per seed, X | Y << 16; PT = u32: two, X then Y).
+// (Until round 4 the words of the 64 pairs of a wave were interleaved, seed i of lane l at ((b * kCap + i) * kWS + j) * 64 + l:
+//  one contiguous store per seed index IF the lanes had reached the same index -- they have not, every lane is at its own
+//  count when the wave drains its queues, so the stores were single words scattered over as many lines, each a partial-line
+//  write the memory side completes by reading the line first: 5.6 GB of HBM traffic per 5M pairs for 0.8 GB of seeds.
+//  A pair's own stretch fills its lines one word after the other.)
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(1))) uint32_t c_g32;
 #else
@@ -153,22 +157,64 @@ struct CSeedOutT {
     static constexpr int kCap = PMX_C_CAP;
     static constexpr int kWS = sizeof(PT) == 2 ? 1 : 2;
     static constexpr int kQCap = PMX_C_SEEDQ;
-    static constexpr int kBlockWords = kCap * kWS * 64;      // per 64 launch positions
+    static constexpr int kPairWords = kCap * kWS;            // per launch position (a multiple of four: 16-byte loads)
+    static constexpr int kBlockWords = kPairWords * 64;      // per 64 launch positions
+    static_assert(kPairWords % 4 == 0, "a pair's hand-over words are read as 16-byte pieces");
     c_u32* q;         // the lane's queue words (LDS, word i at q[i * stride])
-    c_g32* out;       // the lane's column of its block
+    c_g32* out;       // the pair's hand-over words
+    // Seeds wait in eight staging words of the lane (LDS, word j at st[j * stride]) until a 32-byte piece of the pair's
+    // stretch is complete and leave as that piece: whole sectors, written once.  (Stored word by word they were partial
+    // writes: the lines of the 1,024 pairs a CU works on at a time are as large as its share of the L2, a line was gone
+    // before the pair's next seed arrived, and the memory side read it back to merge four bytes -- 7.6 GB per 5M pairs.)
+    c_u32* st;
+    static constexpr int kSPC = 8 / kWS;   // seeds per piece
     PMX_HD uint64_t QM(int i) const { return (uint64_t)q[2 * i * PMX_C_STRIDE] | (uint64_t)q[(2 * i + 1) * PMX_C_STRIDE] << 32; }
     PMX_HD void setQM(int i, uint64_t v) const { q[2 * i * PMX_C_STRIDE] = (uint32_t)v; q[(2 * i + 1) * PMX_C_STRIDE] = (uint32_t)(v >> 32); }
-    PMX_HD void setSeed(int i, uint32_t x, uint32_t y) const {
-        if (kWS == 1) out[i * PMX_C_STRIDE] = x | y << 16;
-        else { out[2 * i * PMX_C_STRIDE] = x; out[(2 * i + 1) * PMX_C_STRIDE] = y; }
+    PMX_HD void flush(int piece) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(1))) uint4 g_u4;
+        g_u4* dst = reinterpret_cast<g_u4*>(out + 8 * piece);
+        dst[0] = make_uint4(st[0], st[1 * PMX_C_STRIDE], st[2 * PMX_C_STRIDE], st[3 * PMX_C_STRIDE]);
+        dst[1] = make_uint4(st[4 * PMX_C_STRIDE], st[5 * PMX_C_STRIDE], st[6 * PMX_C_STRIDE], st[7 * PMX_C_STRIDE]);
+#else
+        for (int j = 0; j < 8; ++j) out[8 * piece + j] = st[j * PMX_C_STRIDE];
+#endif
     }
-    PMX_HD void orY(int i, uint32_t f) const {   // (the lane's own earlier store)
-        if (kWS == 1) out[i * PMX_C_STRIDE] |= f << 16;
-        else out[(2 * i + 1) * PMX_C_STRIDE] |= f;
+    PMX_HD void setSeed(int i, uint32_t x, uint32_t y) const {
+        const int j = i % kSPC;
+        if (kWS == 1) st[j * PMX_C_STRIDE] = x | y << 16;
+        else { st[2 * j * PMX_C_STRIDE] = x; st[(2 * j + 1) * PMX_C_STRIDE] = y; }
+        if (j == kSPC - 1) flush(i / kSPC);
+    }
+    PMX_HD void flush_tail(int n_seeds) const {   // the pair is through: its last, incomplete piece
+        if (n_seeds % kSPC) flush(n_seeds / kSPC);
+    }
+    // (seed i is one of the lane's own earlier ones; n_now seeds exist: its piece has left iff it is complete)
+    PMX_HD void orY(int i, uint32_t f, int n_now) const {
+        const int w = kWS == 1 ? i : 2 * i + 1;
+        const uint32_t v = kWS == 1 ? f << 16 : f;
+        if (n_now / kSPC > i / kSPC) out[w] |= v;
+        else st[(w % 8) * PMX_C_STRIDE] |= v;
     }
     PMX_HD void get(int i, uint32_t* x, uint32_t* y) const {
-        if (kWS == 1) { const uint32_t v = out[i * PMX_C_STRIDE]; *x = v & 0xffffu; *y = v >> 16; }
-        else { *x = out[2 * i * PMX_C_STRIDE]; *y = out[(2 * i + 1) * PMX_C_STRIDE]; }
+        if (kWS == 1) { const uint32_t v = out[i]; *x = v & 0xffffu; *y = v >> 16; }
+        else { *x = out[2 * i]; *y = out[2 * i + 1]; }
+    }
+    // seeds i0 .. i0 + 3 (i0 a multiple of four; entries past the pair's count are whatever the stretch holds)
+    PMX_HD void get4(int i0, uint32_t* x, uint32_t* y) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(1))) const uint4 g_u4;
+        if (kWS == 1) {
+            const uint4 v = *reinterpret_cast<g_u4*>(out + i0);
+            x[0] = v.x & 0xffffu; y[0] = v.x >> 16; x[1] = v.y & 0xffffu; y[1] = v.y >> 16;
+            x[2] = v.z & 0xffffu; y[2] = v.z >> 16; x[3] = v.w & 0xffffu; y[3] = v.w >> 16;
+        } else {
+            const uint4 a = *reinterpret_cast<g_u4*>(out + 2 * i0), b = *reinterpret_cast<g_u4*>(out + 2 * i0 + 4);
+            x[0] = a.x; y[0] = a.y; x[1] = a.z; y[1] = a.w; x[2] = b.x; y[2] = b.y; x[3] = b.z; y[3] = b.w;
+        }
+#else
+        for (int b = 0; b < 4; ++b) get(i0 + b, &x[b], &y[b]);
+#endif
     }
 };
 #define PMX_C_NSEED_BAIL 0xffffu   // the hand-over count (seeds | seeds of mate 1 << 8) of a pair the seeding already gave up on
@@ -610,6 +656,14 @@ struct CSeeder {
     int pending;           // seed of the previous read's last minimizer (its right neighbour is not known yet)
     uint64_t cw;
     int ck;
+    // the read's packed words, fetched together when the read starts (its record is one line: word by word, 32 bases apart in
+    // time, the line was gone from the L2 in between -- the records of the pairs a CU works on fill its share of the L2 --
+    // and came from HBM again: 3.8 line fetches per pair instead of one)
+    uint64_t rw[PMX_C_NW];
+    PMX_HD void load_words() {
+#pragma unroll
+        for (int c = 0; c < PMX_C_NW; ++c) rw[c] = c < (r.len + 31) >> 5 ? r.w[c] : 0ULL;
+    }
 
     // entries [0, lim) of the queue -> seeds; final: the read is over, the last entry has no right neighbour here
     PMX_HD void drain(bool final) {
@@ -642,7 +696,7 @@ struct CSeeder {
                     }
                     const uint32_t cnt = e[b].key == key[b] ? e[b].cnt : 0u;
                     bool tandem = have_prev && key[b] == prev_key;
-                    if (first_of_read && tandem && pending >= 0) m.orY(pending, PMX_CQ_TANDEM);   // ... of the previous read's last one
+                    if (first_of_read && tandem && pending >= 0) m.orY(pending, PMX_CQ_TANDEM, n_s);   // ... of the previous read's last one
                     const bool has_next = e0 + b + 1 < n_q;
                     if (has_next && key[b] == key[b + 1]) tandem = true;
                     if (first_of_read) pending = -1;
@@ -670,7 +724,12 @@ struct CSeeder {
     PMX_HD int operator()(int i) {   // base i of the read in the orientation the aligner sees
         if (c_wave_any(n_q >= kQDrain)) drain(false);
         const int j = r.flip ? r.len - 1 - i : i;
-        if ((j >> 5) != ck) { ck = j >> 5; cw = r.w[ck]; }
+        if ((j >> 5) != ck) {
+            ck = j >> 5;
+            cw = rw[0];
+#pragma unroll
+            for (int c = 1; c < PMX_C_NW; ++c) cw = ck == c ? rw[c] : cw;
+        }
         const int c = (int)(cw >> (2 * (j & 31))) & 3;
         return r.flip ? 3 - c : c;
     }
@@ -791,6 +850,7 @@ PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, con
             sd.r.w = s ? r1.w : r0.w; sd.r.len = s ? r1.len : r0.len; sd.r.flip = s ? r1.flip : r0.flip;
             sd.seg = s; sd.sum = s ? qlen0 : 0;
             sd.n_q = 0; sd.first_of_read = true; sd.ovf = false; sd.cw = 0; sd.ck = -1;
+            sd.load_words();
             if (!sketch_distinct<PMX_C_W>(sd.r.len, k, sd, sd)) sd.bail = true;
             PMX_C_STAMP(0);
             if (sd.ovf) sd.bail = true;
@@ -800,6 +860,7 @@ PMX_HD int compact_seed_pair(const MS& ms, const Opt& o, const RefIndex& ri, con
         }
     }
     if (sd.bail) return PMX_C_BAIL;
+    ms.flush_tail(sd.n_s);
     *n_seeds = sd.n_s;
     return PMX_C_DONE;
 }

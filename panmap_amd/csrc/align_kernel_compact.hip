@@ -45,17 +45,18 @@ __device__ __forceinline__ int64_t compact_item(const AlignArgs& A, int64_t it, 
 // First kernel of the two-kernel form: sketch + index probes of every pair, thread per pair.  The only LDS is the
 // minimizer queue (112 bytes per pair, 7 KB per wave), so the CU holds as many waves as the registers allow (the fused
 // kernel: seven, by its 21 KB of work state per wave) -- this part is pure integer arithmetic plus a few probes.
-// Seeds go to the hand-over words (CSeedOutT), the count (or PMX_C_NSEED_BAIL) to cseed_n[position].
+// Seeds go to the pair's hand-over words (CSeedOutT), the count (or PMX_C_NSEED_BAIL) to cseed_n[position].
 template <class PT>
 __device__ __forceinline__ void compact_seeds_body(const AlignArgs& A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t c_lds[];
     const int lane = (int)(threadIdx.x & 63u);
     CSeedOutT<PT> so;
     so.q = (c_u32*)c_lds + lane;
+    so.st = (c_u32*)c_lds + PMX_C_SEEDQ * 2 * 64 + lane;   // eight staging words per lane behind the queues
     const int64_t n_threads = (int64_t)gridDim.x * 64;
     for (int64_t it0 = (int64_t)blockIdx.x * 64; it0 < A.n_items; it0 += n_threads) {   // (uniform trip count: the drains are wave-wide)
         const int64_t it = it0 + lane;
-        so.out = (c_g32*)(A.cseeds + (size_t)(it0 >> 6) * CSeedOutT<PT>::kBlockWords) + lane;
+        so.out = (c_g32*)(A.cseeds + (size_t)it * CSeedOutT<PT>::kPairWords);
         int n_s = 0, n_s0 = 0, rc = PMX_C_DONE;
         if (it < A.n_items) {
             CRead rd[2];
@@ -176,12 +177,11 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
                 } else { n_s = (int)(c & 0xffu); n_s0 = (int)(c >> 8); }
             }
             CSeedOutT<PT> so;
-            so.q = nullptr;
-            so.out = (c_g32*)(A.cseeds + (size_t)(it0 >> 6) * CSeedOutT<PT>::kBlockWords) + lane;
+            so.q = nullptr; so.st = nullptr;
+            so.out = (c_g32*)(A.cseeds + (size_t)it * CSeedOutT<PT>::kPairWords);
             for (int i0 = 0; __ballot(i0 < n_s) != 0ULL; i0 += 4) {
-                uint32_t x[4], y[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { x[b] = y[b] = 0; if (i0 + b < n_s) so.get(i0 + b, &x[b], &y[b]); }
+                uint32_t x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
+                if (i0 < n_s) so.get4(i0, x, y);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) if (i0 + b < n_s) m.setSeed(i0 + b, x[b], y[b]);
             }
@@ -251,12 +251,13 @@ __device__ __forceinline__ void align_compact_multi_body(const AlignArgs& A) {
             const uint32_t c = A.cseed_n[it];
             const int n_s = (int)(c & 0xffu), n_s0 = (int)(c >> 8);
             CSeedOutT<PT> so;
-            so.q = nullptr;
-            so.out = (c_g32*)(A.cseeds + (size_t)(it >> 6) * CSeedOutT<PT>::kBlockWords) + (it & 63);
-            for (int i = 0; i < n_s; ++i) {
-                uint32_t x, y;
-                so.get(i, &x, &y);
-                m.setSeed(i, x, y);
+            so.q = nullptr; so.st = nullptr;
+            so.out = (c_g32*)(A.cseeds + (size_t)it * CSeedOutT<PT>::kPairWords);
+            for (int i0 = 0; i0 < n_s; i0 += 4) {
+                uint32_t x[4], y[4];
+                so.get4(i0, x, y);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) if (i0 + b < n_s) m.setSeed(i0 + b, x[b], y[b]);
             }
             rc = compact_chain_pair<PT, true>(m, A.opt, A.ri, rd, n_s, n_s0, res, tab, nullptr, A.edits != nullptr, false, &mw);
         }

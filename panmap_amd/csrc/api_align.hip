@@ -858,7 +858,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     int64_t s_grid = (n_items + 63) / 64;
                     if (const char* e = pmx::opt_str(pmx::O_ALIGN_CSEED_WAVES)) s_grid = std::min<int64_t>((int64_t)ctx->n_cu * std::max(atoi(e), 1), s_grid);
                     timer_begin(ctx, "align_cseeds");
-                    hipLaunchKernelGGL(s_kern, dim3((unsigned)s_grid), dim3(64), (size_t)PMX_C_SEEDQ * 2 * 64 * sizeof(uint32_t),
+                    hipLaunchKernelGGL(s_kern, dim3((unsigned)s_grid), dim3(64), ((size_t)PMX_C_SEEDQ * 2 + 8) * 64 * sizeof(uint32_t),   // queues + eight staging words per lane
                                        ctx->stream, A);
                     PMX_HIP(hipGetLastError());
                     timer_end(ctx, "align_cseeds", 1);

@@ -242,12 +242,17 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
             std::vector<uint32_t> q(2 * PMX_C_SEEDQ, 0xdeadbeefu), ho((size_t)PMX_C_CAP * 2, 0xdeadbeefu);
             auto split = [&](auto pt) {
                 typedef decltype(pt) PT;
-                CSeedOutT<PT> so{q.data(), ho.data()};
+                uint32_t stage[8];
+                CSeedOutT<PT> so{q.data(), ho.data(), stage};
                 int n_s = 0, n_s0 = 0;
                 res.mapped = 0;
                 if (compact_seed_pair(so, o, ri, rd, amb, &n_s, &n_s0) != PMX_C_DONE) return (int)PMX_C_BAIL;
                 CMemT<PT> m{lds.data()};
-                for (int i = 0; i < n_s; ++i) { uint32_t x, y; so.get(i, &x, &y); m.setSeed(i, x, y); }
+                for (int i0 = 0; i0 < n_s; i0 += 4) {   // (as the kernels copy them: four seeds per request)
+                    uint32_t x[4], y[4];
+                    so.get4(i0, x, y);
+                    for (int b = 0; b < 4 && i0 + b < n_s; ++b) m.setSeed(i0 + b, x[b], y[b]);
+                }
                 return multi ? compact_chain_pair<PT, true>(m, o, ri, rd, n_s, n_s0, res, tab, nullptr, false, false, &mw) : compact_chain_pair(m, o, ri, rd, n_s, n_s0, res, tab);
             };
             rc = pos16 ? split((uint16_t)0) : split((uint32_t)0);
