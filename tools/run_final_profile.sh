@@ -1,3 +1,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+bash tools/profile_r04_pmc.sh > gpurun_out/pmc_r04.log 2>&1
+tail -3 gpurun_out/pmc_r04.log
+cp gpurun_out/prof_r04_pmc/pmc_traffic.json profiles/r04/pmc_traffic.json
+bash tools/prof_stats.sh r04p1 --steps 6 --warmup 2 --no-cpu-baseline --no-real-reads --no-host-to-host --pipelines 1 2>&1 | tail -2
 bash tools/run_final_bench.sh
 bash tools/run_gpu_suite.sh
