@@ -331,13 +331,14 @@ def main():
     max_len = int(np.max(np.diff(off))) if n_reads else 0
     mean_len = int(off[-1] // max(n_reads, 1))
     total_reads = n_reads * world if args.scaling == "weak" else args.total_reads // unit * unit
-    # batches in flight: two; four when a rank's batch is small (a rank's share of a strong-scaling job: the fixed-latency
-    # kernels of a step -- histogram finalisation, scoring, reference index, the tail tiers -- leave more of the chip idle;
-    # measured at 1.25M reads: 156 M reads/s with two, 169-175 with three, 187 with four, 162 with six; at 2.5M three gain 3 %,
-    # at 10M three are not better (249-356 M) and four lose).  Every context owns hardware queues: four pipelines work because
-    # the place stage keeps small ranges on the context's own stream (api_place.hip)
-    # (2.5M reads: 212 M reads/s with two, 224 with three, 232 with four; 5M: 275 / 253 / 246)
-    n_pipes = args.pipelines or (1 if long_reads else (4 if n_reads <= 3000000 else 2))
+    # batches in flight: two; three when a rank's batch is small (a rank's share of a strong-scaling job: the fixed-latency
+    # kernels of a step -- histogram finalisation, scoring, reference index, the tail tiers -- leave more of the chip idle).
+    # Measured at 1.25M reads: 156 M reads/s with two, 179-187 with three, 196-213 with four, 162 with six; at 2.5M 212 / 224 /
+    # 232-251; at 5M 275 / 253 / 246; at 10M three are not better (249-356 M).  Four would be the pick for small batches, but
+    # three legs of twenty ran 17x slower with four pipelines (a whole leg at 107 or 142 ms per step, whatever the warm-up;
+    # ten runs in a row with three: none).  Suspected: the tier kernels' 5 KB of scratch per lane times four queues
+    # (profiles/r04/README.md item 16).  Every context also owns hardware queues, and those are a budget too (item 14).
+    n_pipes = args.pipelines or (1 if long_reads else (3 if n_reads <= 3000000 else 2))
     # (one chunk by default: with two batches in flight the upload of a batch overlaps the kernels of the other one, and a
     # batch seeded as a whole sizes its seed table once; --h2d-chunks > 1 packs + seeds range by range behind the copies)
     n_chunks = args.h2d_chunks or 1

@@ -25,8 +25,8 @@ def test_bench_single_rank_line():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "roofline_valu", "cpu_baseline", "value_device_resident", "value_host_to_host", "pcie", "dp", "real_reads"):
         assert k in d, k
-    # `value`: inputs resident in HBM, two or four batches in flight; every batch equals the one-batch-at-a-time run bit for bit
-    assert d["config"]["batches_in_flight"] == 4 and d["equals_device_resident_run"] is True   # (four for a batch this small, two from 2M reads)
+    # `value`: inputs resident in HBM, two or three batches in flight; every batch equals the one-batch-at-a-time run bit for bit
+    assert d["config"]["batches_in_flight"] == 3 and d["equals_device_resident_run"] is True   # (three for a batch this small, two above 3M reads)
     assert d["value_device_resident"] > 0 and d["pcie"]["h2d_GBps"] > 0 and d["pcie"]["d2h_GBps"] > 0 and d["pcie"]["bound_reads_per_s"] > 0
     assert d["scaling"] == "strong" and d["config"]["total_reads"] == 400000 and "0.4M×150bp" in d["metric"]
     assert set(("pair_share", "cells_per_step", "gcups_align_stage")) <= set(d["dp"])
@@ -53,8 +53,8 @@ def test_bench_two_ranks_functional():
                         "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["batches_in_flight"] == 4
-    assert d["equals_device_resident_run"] is True      # four pipelines per rank, collectives in ticket order
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["batches_in_flight"] == 3
+    assert d["equals_device_resident_run"] is True      # three pipelines per rank, collectives in ticket order
     assert d["checks"]["placed_node"] == d["config"]["source_node"] and d["checks"]["mapped_fraction"] > 0.99 and d["checks"]["records_flagged"] == 0
     assert d["checks"]["rank0_gather_has_every_cigar"] is True
 
