@@ -335,9 +335,9 @@ def main():
     # kernels of a step -- histogram finalisation, scoring, reference index, the tail tiers -- leave more of the chip idle).
     # Measured at 1.25M reads: 156 M reads/s with two, 179-187 with three, 196-213 with four, 162 with six; at 2.5M 212 / 224 /
     # 232-251; at 5M 275 / 253 / 246; at 10M three are not better (249-356 M).  Four would be the pick for small batches, but
-    # three legs of twenty ran 17x slower with four pipelines (a whole leg at 107 or 142 ms per step, whatever the warm-up;
-    # ten runs in a row with three: none).  Suspected: the tier kernels' 5 KB of scratch per lane times four queues
-    # (profiles/r04/README.md item 16).  Every context also owns hardware queues, and those are a budget too (item 14).
+    # four legs of forty-four ran 17x slower with four pipelines (a whole leg at 107 or 142 ms per step: 100 ms more per step
+    # to the half millisecond, whatever the warm-up; ten runs in a row with three pipelines: none; profiles/r04/README.md
+    # item 16).  Every context also owns hardware queues, and those are a budget too (item 14).
     n_pipes = args.pipelines or (1 if long_reads else (3 if n_reads <= 3000000 else 2))
     # (one chunk by default: with two batches in flight the upload of a batch overlaps the kernels of the other one, and a
     # batch seeded as a whole sizes its seed table once; --h2d-chunks > 1 packs + seeds range by range behind the copies)
