@@ -203,19 +203,22 @@ def oracle_checks(pmx, gpu, cpu, node_id, paired):
 
 class Sequencer:
     """Collectives issued from several host threads must reach the process group in ONE order on every rank.  The batches
-    are numbered; batch i has a histogram exchange H_i and a result gather G_i; the order is H0, H1, G0, H2, G1, H3, ...
-    (batch i+1 is seeded while batch i aligns), which every rank derives from the batch number alone."""
+    are numbered; batch i has a histogram exchange H_i and a result gather G_i; with P pipelines the order is H_0 .. H_{P-1},
+    G_0, H_P, G_1, H_{P+1}, ... (P batches between their exchange and their gather: batch i+1 .. i+P-1 are seeded while batch
+    i aligns), then the last P gathers; every rank derives it from the batch number alone."""
 
-    def __init__(self, n_batches):
+    def __init__(self, n_batches, n_pipes=2):
         self.n = n_batches
+        self.p = max(1, min(n_pipes, n_batches))
         self.next = 0
         self.cv = threading.Condition()
         self.failed = None
 
     def ticket(self, kind, i):
+        n, p = self.n, self.p
         if kind == "H":
-            return 0 if i == 0 else 2 * i - 1
-        return 2 * i + 2 if i < self.n - 1 else 2 * self.n - 1
+            return i if i < p else 2 * i - p + 1
+        return p + 2 * i if i <= n - p - 1 else n + i
 
     def run(self, kind, i, fn):
         t = self.ticket(kind, i)
@@ -674,7 +677,7 @@ def main():
     def run_batches(n_batches, resident_inputs=False):
         """n_batches steps over the pipelines: pipeline p takes the batches p, p + P, p + 2P, ... (host -> host: and uploads
         its next batch while it computes the current one); all downloads have landed when this returns"""
-        seq = Sequencer(n_batches) if (dist_on and len(pipes) > 1) else None
+        seq = Sequencer(n_batches, len(pipes)) if (dist_on and len(pipes) > 1) else None
         errs = []
 
         def work(p):

@@ -83,3 +83,27 @@ def test_histogram_exchange_world2(pmx, oracle, tmp_path):
     assert (int(a["lo"]), int(a["hi"]), int(b["lo"]), int(b["hi"])) == (0, 1500, 1500, 3002)   # pair-aligned shards
     hs, cn = oracle.histogram(reads, 19, 8, 3)
     assert np.array_equal(a["h"], hs) and np.array_equal(a["c"], cn)
+
+
+def test_bench_collective_order_for_any_number_of_pipelines():
+    """bench.py's Sequencer: the one order in which the host threads of a rank issue their collectives -- a permutation of the
+    2n tickets, every batch's exchange before its gather, and every pipeline's own operations in rising order (a thread runs its
+    batches one after the other: it must never wait for a ticket behind one of its own later operations)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n in (1, 2, 3, 4, 5, 7, 8, 20, 25):
+        for p in (1, 2, 3, 4, 6):
+            sq = bench.Sequencer(n, p)
+            tick = {("H", i): sq.ticket("H", i) for i in range(n)}
+            tick.update({("G", i): sq.ticket("G", i) for i in range(n)})
+            assert sorted(tick.values()) == list(range(2 * n)), (n, p)
+            assert all(tick[("H", i)] < tick[("G", i)] for i in range(n)), (n, p)
+            pp = max(1, min(p, n))
+            for q in range(pp):                      # pipeline q runs batches q, q + P, ...
+                mine = [t for b in range(q, n, pp) for t in (tick[("H", b)], tick[("G", b)])]
+                assert mine == sorted(mine), (n, p, q)
+    assert bench.Sequencer(7, 3).ticket("G", 0) == 3 and bench.Sequencer(7, 3).ticket("H", 3) == 4      # H0 H1 H2 G0 H3 G1 ...
+    assert [bench.Sequencer(5, 2).ticket("H", i) for i in range(5)] == [0, 1, 3, 5, 7]                  # the two-pipeline order of rounds 3-4
