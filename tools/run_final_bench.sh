@@ -1,3 +1,5 @@
+#!/bin/bash
+# The bench lines kept under profiles/rNN/: the driver's command and a rank's share of the 8-GPU strong-scaling job (GPU box).
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 timeout 1500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_default_r04.json 2> gpurun_out/bench_default_r04.err || tail -5 gpurun_out/bench_default_r04.err
 timeout 600 python3 bench.py --gpus 1 --total-reads 1250000 > gpurun_out/bench_1250k_r04.json 2> gpurun_out/bench_1250k_r04.err || tail -5 gpurun_out/bench_1250k_r04.err
