@@ -92,10 +92,10 @@ PMX_HD int32_t c_chain_score_tab(const CPenTab& T, uint32_t xi, int32_t yi, int3
     return bad ? INT32_MIN : r;
 }
 
-template <class PT>
+template <class PT, int CAP = PMX_C_CAP>
 struct CMemT {
     c_u32* base;
-    static constexpr int kCap = PMX_C_CAP;
+    static constexpr int kCap = CAP;
     static constexpr int kXH = 0;                                        // X in units of PT
     static constexpr int kYH = (int)(sizeof(PT) / 2) * kCap;             // Y, G in halves
     static constexpr int kGH = kYH + kCap;
@@ -334,18 +334,18 @@ PMX_HD bool c_wave_any(bool p) {
 // The anchors of one mate's only region, in chain order: anchor i of the list = anchor G(base + i) of the pair, its query
 // position rebased to the mate (hit.c:381).  (x: reference position, y: query position; flags never survive into this
 // tier's regions -- a LONG_JOIN / IGNORE mark needs the bad-seed filters, which make the pair bail.)
-template <class PT>
+template <class MT>
 struct CList {
-    const CMemT<PT>& m;
+    const MT& m;
     int base, shift;
-    PMX_HD int32_t x(int i) const { return (int32_t)CMemT<PT>::pos_of(m.X((int)m.G(base + i))); }
+    PMX_HD int32_t x(int i) const { return (int32_t)MT::pos_of(m.X((int)m.G(base + i))); }
     PMX_HD int32_t y(int i) const { return (int32_t)(m.Y((int)m.G(base + i)) & 0x3ffu) - shift; }
-    PMX_HD uint32_t rev(int i) const { return CMemT<PT>::rev_of(m.X((int)m.G(base + i))); }
+    PMX_HD uint32_t rev(int i) const { return MT::rev_of(m.X((int)m.G(base + i))); }
 };
 
 // mm_cal_fuzzy_len + mm_reg_set_coor (hit.c:8-40) on a per-mate anchor list
-template <class PT>
-PMX_HD void c_reg_set_coor(const CList<PT>& a, CReg& r, int32_t qlen, int span) {
+template <class MT>
+PMX_HD void c_reg_set_coor(const CList<MT>& a, CReg& r, int32_t qlen, int span) {
     const int32_t x0 = a.x(0), y0 = a.y(0);
     const int32_t xl = a.x(r.cnt - 1), yl = a.y(r.cnt - 1);
     r.rs = x0 + 1 > span ? x0 + 1 - span : 0;
@@ -364,8 +364,8 @@ PMX_HD void c_reg_set_coor(const CList<PT>& a, CReg& r, int32_t qlen, int span) 
 }
 
 // mm_fix_bad_ends (align.c:464-502) on a per-mate list (r.as == 0, no LONG_JOIN marks)
-template <class PT>
-PMX_HD void c_fix_bad_ends(const CList<PT>& a, const CReg& r, int span, int bw, int min_match, int32_t* as, int32_t* cnt) {
+template <class MT>
+PMX_HD void c_fix_bad_ends(const CList<MT>& a, const CReg& r, int span, int bw, int min_match, int32_t* as, int32_t* cnt) {
     *as = 0;
     *cnt = r.cnt;
     if (r.cnt < 3) return;
@@ -411,8 +411,8 @@ struct CRefFn {
 // MULTI (aln_compact_multi.hpp): the region is one of several of its mate; `al` is still the region's own list, `mate`
 // the mate's whole anchor list (n_a entries, the region's at [as, as + cnt)): neighbouring chains of the same strand
 // fence the end extensions off (align.c:636-691; extension_reach, aln_align.hpp).
-template <class PT, bool MULTI = false>
-PMX_HD int c_align1(const CList<PT>& al, const Opt& o, const RefIndex& ri, const CRead& rd, int qlen, CReg& r, const CList<PT>* mate = nullptr, int as = 0,
+template <bool MULTI = false, class MT>
+PMX_HD int c_align1(const CList<MT>& al, const Opt& o, const RefIndex& ri, const CRead& rd, int qlen, CReg& r, const CList<MT>* mate = nullptr, int as = 0,
                     int n_a = 0) {
     const int span = o.k;
     const int32_t rev = r.rev;
@@ -872,10 +872,10 @@ namespace pmx {
 namespace aln {
 
 // MULTI: follow up to PMX_CM_MAXC fragment chains and several regions per mate (compact_regions_multi) instead of bailing
-template <class PT, bool MULTI = false>
-PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_s, int n_s0, CResult& out, const CPenTab& pen_tab,
+template <bool MULTI = false, class PT, int CAP>
+PMX_HD int compact_chain_pair(const CMemT<PT, CAP>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_s, int n_s0, CResult& out, const CPenTab& pen_tab,
                                unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false, const SWork* mw = nullptr) {
-    typedef CMemT<PT> MT;
+    typedef CMemT<PT, CAP> MT;
     out.mapped = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long prof_t = prof_on ? (unsigned long long)clock64() : 0ULL;
@@ -884,6 +884,7 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
     const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
     out.edit[0] = qlen0; out.edit[1] = qlen1;   // a mate without a region counts its whole length
     if (n_s == 0) return PMX_C_DONE;   // no anchors: unmapped
+    if (n_s > MT::kCap) return PMX_C_BAIL;   // (the first form's memory holds fewer anchors than the hand-over: the second form takes the pair)
 
     // ---------------------------------------------------------------- heap merge (map.c:102-166) -> anchors in place
     const int n = n_s;
@@ -1276,8 +1277,8 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
             r.has_p = 0; r.dp_score = r.dp_max = 0; r.mapq = 0; r.proper_frag = 0; r.m_len = 0;
         }
     }
-    const CList<PT> L0{m, 0, R0.rev ? qlen_sum - qlen0 : 0};                     // hit.c:381: rev ? qlen_sum - (ql + acc) : acc
-    const CList<PT> L1{m, base1, R1.rev ? qlen_sum - (qlen1 + qlen0) : qlen0};
+    const CList<MT> L0{m, 0, R0.rev ? qlen_sum - qlen0 : 0};                     // hit.c:381: rev ? qlen_sum - (ql + acc) : acc
+    const CList<MT> L1{m, base1, R1.rev ? qlen_sum - (qlen1 + qlen0) : qlen0};
     c_reg_set_coor(L0, R0, qlen0, k);
     c_reg_set_coor(L1, R1, qlen1, k);
 
@@ -1337,14 +1338,14 @@ PMX_HD int compact_chain_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& 
     return PMX_C_DONE;
 }
 
-template <class PT, bool MULTI = false>
-PMX_HD int compact_map_pair(const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
+template <bool MULTI = false, class PT, int CAP>
+PMX_HD int compact_map_pair(const CMemT<PT, CAP>& m, const Opt& o, const RefIndex& ri, const CRead* rd, const uint32_t* const* amb, CResult& out,
                              const CPenTab& pen_tab, unsigned long long* prof = nullptr, bool want_edits = false, bool prof_on = false, const SWork* mw = nullptr) {
     out.mapped = 0;
     out.edit[0] = rd[0].len; out.edit[1] = rd[1].len;
     int n_s = 0, n_s0 = 0;
     if (compact_seed_pair(m, o, ri, rd, amb, &n_s, &n_s0, prof, prof_on) != PMX_C_DONE) return PMX_C_BAIL;
-    return compact_chain_pair<PT, MULTI>(m, o, ri, rd, n_s, n_s0, out, pen_tab, prof, want_edits, prof_on, mw);
+    return compact_chain_pair<MULTI>(m, o, ri, rd, n_s, n_s0, out, pen_tab, prof, want_edits, prof_on, mw);
 }
 
 }  // namespace aln

@@ -10,6 +10,12 @@
 // LDS words per pair (CMemT<PT>::kWords): X (PT) + Y (u16) + G (u16), PMX_C_CAP entries each
 #define PMX_C_LANE_WORDS16 84    // 336 bytes: reference position words of 16 bits
 #define PMX_C_LANE_WORDS32 112   // 448 bytes
+// The chain kernel's first form (k_align_compact16/32: seeds from the hand-over) keeps 48 anchors: 288 bytes per pair, 19.6 KB
+// per wave with the penalty tables, EIGHT waves per CU instead of seven (nine with 32-bit positions... six instead of five).
+// 0.9 % of 150 bp pairs have 49 .. 56 seeds (mean 39.9, sd 3.9): those go to the second form, whose memory holds all 56.
+#define PMX_C_CAP1 48
+#define PMX_C_LANE_WORDS16_1 72  // 288 bytes
+#define PMX_C_LANE_WORDS32_1 96  // 384 bytes
 // gap-penalty tables of the chain fill, per wave (aln_compact.hpp CPenTab)
 #define PMX_C_PEN_SAME 128
 #define PMX_C_PEN_DIFF 1024

@@ -433,10 +433,10 @@ static_assert(PMX_CMI_UKEEP + 2 * PMX_CM_MAXC <= PMX_CM_INTS, "workspace index w
 PMX_HD uint64_t s_get64(const SWork& W, int at) { return (uint64_t)W.I(at) | (uint64_t)W.I(at + 1) << 32; }
 PMX_HD void s_set64(const SWork& W, int at, uint64_t v) { W.I(at) = (uint32_t)v; W.I(at + 1) = (uint32_t)(v >> 32); }
 
-template <class PT>
-PMX_HD int compact_regions_multi(const SWork& W, const CMemT<PT>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_u, int max_chain_gap_ref,
+template <class PT, int CAP>
+PMX_HD int compact_regions_multi(const SWork& W, const CMemT<PT, CAP>& m, const Opt& o, const RefIndex& ri, const CRead* rd, int n_u, int max_chain_gap_ref,
                                  CResult& out, bool want_edits) {
-    typedef CMemT<PT> MT;
+    typedef CMemT<PT, CAP> MT;
     const int k = o.k;
     const int qlen0 = rd[0].len, qlen1 = rd[1].len, qlen_sum = qlen0 + qlen1;
     const uint32_t hash = c_wang_hash(c_wang_hash((uint32_t)qlen_sum) + c_wang_hash((uint32_t)o.seed));
@@ -553,7 +553,7 @@ PMX_HD int compact_regions_multi(const SWork& W, const CMemT<PT>& m, const Opt& 
             SReg& g = r[i];
             const int as = g.as;
             const int32_t rev = (int32_t)MT::rev_of(m.X((int)m.G(base_s + as)));
-            const CList<PT> L{m, base_s + as, rev ? qlen_sum - (qlen + before) : before};
+            const CList<MT> L{m, base_s + as, rev ? qlen_sum - (qlen + before) : before};
             CReg c;
             c.cnt = g.cnt; c.rev = rev;
             c_reg_set_coor(L, c, qlen, k);
@@ -568,9 +568,9 @@ PMX_HD int compact_regions_multi(const SWork& W, const CMemT<PT>& m, const Opt& 
             c.cnt = g.cnt; c.score = g.score; c.rev = g.rev; c.qs = g.qs; c.qe = g.qe; c.rs = g.rs; c.re = g.re; c.mlen = g.mlen; c.blen = g.blen;
             c.has_p = 0; c.dp_score = c.dp_max = 0; c.mapq = 0; c.proper_frag = 0; c.m_len = 0;
             const int shift = c.rev ? qlen_sum - (qlen + before) : before;
-            const CList<PT> L{m, base_s + as, shift};
-            const CList<PT> Lm{m, base_s, shift};   // (the fence scan only visits anchors of the region's strand: same shift)
-            if (c_align1<PT, true>(L, o, ri, rd[s], qlen, c, &Lm, as, n_a_s) != PMX_C_DONE) return PMX_C_BAIL;
+            const CList<MT> L{m, base_s + as, shift};
+            const CList<MT> Lm{m, base_s, shift};   // (the fence scan only visits anchors of the region's strand: same shift)
+            if (c_align1<true>(L, o, ri, rd[s], qlen, c, &Lm, as, n_a_s) != PMX_C_DONE) return PMX_C_BAIL;
             g.rs = c.rs; g.re = c.re; g.qs = c.qs; g.qe = c.qe; g.mlen = c.mlen; g.blen = c.blen;
             g.has_p = c.has_p; g.dp_score = c.dp_score; g.dp_max = c.dp_max; g.m_len = c.m_len;
         }

@@ -139,9 +139,10 @@ template <class PT, bool PRESEEDED>
 __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t c_lds[];
     const int lane = (int)(threadIdx.x & 63u);
-    CMemT<PT> m;
+    typedef CMemT<PT, PRESEEDED ? PMX_C_CAP1 : PMX_C_CAP> MT;   // (the seeds kernel's queue overlay needs the full block: fused form)
+    MT m;
     // gap-penalty tables behind the lanes' work memory (see CPenTab): 1152 bytes per wave
-    c_u8* pen = (c_u8*)((c_u32*)c_lds + CMemT<PT>::kWords * 64);
+    c_u8* pen = (c_u8*)((c_u32*)c_lds + MT::kWords * 64);
     CPenTab tab;
     tab.same = pen; tab.diff = pen + PMX_C_PEN_SAME;
     for (int dd = lane; dd < PMX_C_PEN_DIFF; dd += 64) {
@@ -151,7 +152,8 @@ __device__ __forceinline__ void align_compact_body(const AlignArgs& A) {
         pen[PMX_C_PEN_SAME + dd] = (uint8_t)(pd < 255 ? pd : 255);
     }
     __syncthreads();
-    static_assert(CMemT<PT>::kWords == (sizeof(PT) == 2 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32), "LDS size the host launches with");
+    static_assert(MT::kWords == (PRESEEDED ? (sizeof(PT) == 2 ? PMX_C_LANE_WORDS16_1 : PMX_C_LANE_WORDS32_1) : (sizeof(PT) == 2 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32)),
+                  "LDS size the host launches with");
     m.base = (c_u32*)c_lds + lane;
     const int64_t n_threads = (int64_t)gridDim.x * 64;
     // every lane of the wave runs the same number of iterations (arena and bail-list slots are claimed once per wave)
@@ -259,7 +261,7 @@ __device__ __forceinline__ void align_compact_multi_body(const AlignArgs& A) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) if (i0 + b < n_s) m.setSeed(i0 + b, x[b], y[b]);
             }
-            rc = compact_chain_pair<PT, true>(m, A.opt, A.ri, rd, n_s, n_s0, res, tab, nullptr, A.edits != nullptr, false, &mw);
+            rc = compact_chain_pair<true>(m, A.opt, A.ri, rd, n_s, n_s0, res, tab, nullptr, A.edits != nullptr, false, &mw);
         }
         const bool done = item >= 0 && rc == PMX_C_DONE;
         const unsigned long long dmask = __ballot(done);

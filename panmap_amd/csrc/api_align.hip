@@ -1,5 +1,7 @@
 // C ABI, device part 2: ALIGN stage (see include/panmap_amd.h).
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <string.h>
 
 #include <rocprim/rocprim.hpp>
@@ -830,7 +832,10 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                 const bool pos16 = al->ri.len <= 32767 && !pmx::opt_str(pmx::O_ALIGN_COMPACT_POS32);
                 const bool c_fused = pmx::opt_str(pmx::O_ALIGN_COMPACT_FUSED) != nullptr;
                 auto c_kern = c_fused ? (pos16 ? k_align_compact16_fused : k_align_compact32_fused) : (pos16 ? k_align_compact16 : k_align_compact32);
-                const size_t c_lds = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
+                // (the first form of the two-kernel chain kernel keeps 48 anchors per pair: eight waves per CU; the fused kernels
+                //  and the second form all 56)
+                const size_t c_lds_full = (size_t)(pos16 ? PMX_C_LANE_WORDS16 : PMX_C_LANE_WORDS32) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
+                const size_t c_lds = c_fused ? c_lds_full : (size_t)(pos16 ? PMX_C_LANE_WORDS16_1 : PMX_C_LANE_WORDS32_1) * 64 * sizeof(uint32_t) + PMX_C_PEN_BYTES;
                 // One workgroup (wave) per 64 pairs, handed out by the dispatcher as CUs free up: the pairs of a wave cost what
                 // their worst lane costs, and with a resident grid striding over the positions (PMX_ALIGN_COMPACT_WAVES = waves
                 // per CU brings it back) the slowest stride set the kernel's end -- 10M reads: 17.05 -> 15.5 ms, and the seeds
@@ -912,7 +917,7 @@ static int align_readset_once(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* 
                     al->multi_ws.ensure((size_t)m_grid * PMX_CM_WS_WORDS * 64);
                     A.multi_ws = al->multi_ws.p;
                     timer_begin(ctx, "align_cmulti");
-                    hipLaunchKernelGGL(pos16 ? k_align_compact16_multi : k_align_compact32_multi, dim3((unsigned)m_grid), dim3(64), c_lds, ctx->stream, A);
+                    hipLaunchKernelGGL(pos16 ? k_align_compact16_multi : k_align_compact32_multi, dim3((unsigned)m_grid), dim3(64), c_lds_full, ctx->stream, A);
                     PMX_HIP(hipGetLastError());
                     timer_end(ctx, "align_cmulti", 1);
                 }
@@ -1092,6 +1097,45 @@ int pmx_align_score_reads(pmx_ctx* ctx, pmx_aligner* al, const pmx_readset* rs, 
 }
 
 // Drop-in for score_reads_vs_reference (src/mm_align.h:13-17, src/mm_align.c:144-199), the reference's own signature: host
+}  // extern "C"
+
+// Contexts of the two drop-in boundaries below.  The reference calls them from several TBB workers at a time, call after
+// call; a context per call would create and destroy its hardware queues (CU-masked streams) over and over, beside the
+// running queues of the other workers -- the pattern behind the hang of round 4 (a destroyed stream's queue recycled under
+// the next one's kernels) and one hung run of tests/test_align_gpu.py::test_direct_boundary_is_reentrant.  The contexts are
+// kept: a call borrows one (or makes one: there are never more than the workers that were inside at the same time) and
+// hands it back; they live as long as the process.
+namespace {
+std::mutex g_ctx_pool_mu;
+std::vector<pmx_ctx*> g_ctx_pool;
+pmx_ctx* borrow_ctx(int dev) {
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_pool_mu);
+        for (size_t i = 0; i < g_ctx_pool.size(); ++i)
+            if (g_ctx_pool[i]->device == dev) {
+                pmx_ctx* c = g_ctx_pool[i];
+                g_ctx_pool.erase(g_ctx_pool.begin() + (long)i);
+                if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); g_ctx_pool.push_back(c); return nullptr; }
+                return c;
+            }
+    }
+    pmx_ctx* c = nullptr;
+    return pmx_ctx_create(dev, &c) == PMX_OK ? c : nullptr;
+}
+void return_ctx(pmx_ctx* c) {
+    if (!c) return;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {   // a context whose stream failed is not handed to the next caller
+        (void)hipGetLastError();
+        pmx_ctx_destroy(c);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_ctx_pool_mu);
+    g_ctx_pool.push_back(c);
+}
+}  // namespace
+
+extern "C" {
+
 // strings in, minus the total edit distance out; 0 on failure, as the reference returns 0 when its index cannot be built.
 // An odd read of a paired set is mapped alone (:178-185).  A pair whose record a kernel flagged invalid counts as unmapped
 // reads (their lengths), the way pmx_align_reads_direct reports such pairs; pmx_last_error() says how many there were.
@@ -1101,7 +1145,7 @@ int64_t pmx_score_reads_vs_reference(const char* reference, int n_reads, const c
     pmx_ctx* ctx = nullptr;
     int dev = 0;
     if (const char* e = pmx::opt_str(pmx::O_DEVICE)) dev = atoi(e);
-    if (pmx_ctx_create(dev, &ctx) != PMX_OK) return 0;
+    if (!(ctx = borrow_ctx(dev))) return 0;
     pmx_aligner* al = nullptr;
     int64_t total = 0, withheld = 0;
     bool ok = false;
@@ -1132,7 +1176,7 @@ int64_t pmx_score_reads_vs_reference(const char* reference, int n_reads, const c
         ok = true;
     } while (0);
     if (al) pmx_aligner_free(ctx, al);
-    pmx_ctx_destroy(ctx);
+    return_ctx(ctx);
     if (ok && withheld) set_error("pmx_score_reads_vs_reference: " + std::to_string(withheld) + " read(s) of flagged records counted as unmapped");
     return ok ? total : 0;
 }
@@ -1312,7 +1356,7 @@ void pmx_align_reads_direct(const char* reference, const char* refName, int n_re
     pmx_aligner* al = nullptr;
     int dev = 0;
     if (const char* e = pmx::opt_str(pmx::O_DEVICE)) dev = atoi(e);
-    if (pmx_ctx_create(dev, &ctx) != PMX_OK) return;   // like the reference: results stay untouched on failure
+    if (!(ctx = borrow_ctx(dev))) return;   // like the reference: results stay untouched on failure
     do {
         int64_t total = 0;
         std::vector<int64_t> off((size_t)n_reads + 1, 0);
@@ -1371,7 +1415,7 @@ void pmx_align_reads_direct(const char* reference, const char* refName, int n_re
     } while (0);
     if (al) pmx_aligner_free(ctx, al);
     if (rs) pmx_readset_free(ctx, rs);
-    pmx_ctx_destroy(ctx);
+    return_ctx(ctx);
 }
 
 }  // extern "C"

@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver at round end)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs must not hold the box: every `gpu` test gets a time limit (pytest-timeout, where it is installed;
+    the longest test of the suite takes under a minute, the whole suite three).  One run of round 4 sat in
+    test_direct_boundary_is_reentrant for 25 minutes until the outer `timeout` ended it."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(300))
+
+
 @pytest.fixture(scope="session")
 def built():
     """Make sure the HIP library and the oracle are built (cross-compiles without a GPU)."""

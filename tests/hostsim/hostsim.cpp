@@ -247,17 +247,28 @@ extern "C" int hs_align_compact(const char* ref, int64_t ref_len, int n_reads, c
                 int n_s = 0, n_s0 = 0;
                 res.mapped = 0;
                 if (compact_seed_pair(so, o, ri, rd, amb, &n_s, &n_s0) != PMX_C_DONE) return (int)PMX_C_BAIL;
+                // (the first form of the chain kernel keeps PMX_C_CAP1 anchors -- more seeds than that: the second form's pair)
+                if (!multi) {
+                    if (n_s > PMX_C_CAP1) return (int)PMX_C_BAIL;
+                    CMemT<PT, PMX_C_CAP1> m1{lds.data()};
+                    for (int i0 = 0; i0 < n_s; i0 += 4) {
+                        uint32_t x[4], y[4];
+                        so.get4(i0, x, y);
+                        for (int b = 0; b < 4 && i0 + b < n_s; ++b) m1.setSeed(i0 + b, x[b], y[b]);
+                    }
+                    return compact_chain_pair(m1, o, ri, rd, n_s, n_s0, res, tab);
+                }
                 CMemT<PT> m{lds.data()};
                 for (int i0 = 0; i0 < n_s; i0 += 4) {   // (as the kernels copy them: four seeds per request)
                     uint32_t x[4], y[4];
                     so.get4(i0, x, y);
                     for (int b = 0; b < 4 && i0 + b < n_s; ++b) m.setSeed(i0 + b, x[b], y[b]);
                 }
-                return multi ? compact_chain_pair<PT, true>(m, o, ri, rd, n_s, n_s0, res, tab, nullptr, false, false, &mw) : compact_chain_pair(m, o, ri, rd, n_s, n_s0, res, tab);
+                return multi ? compact_chain_pair<true>(m, o, ri, rd, n_s, n_s0, res, tab, nullptr, false, false, &mw) : compact_chain_pair(m, o, ri, rd, n_s, n_s0, res, tab);
             };
             rc = pos16 ? split((uint16_t)0) : split((uint32_t)0);
-        } else if (pos16) { CMemT<uint16_t> m{lds.data()}; rc = multi ? compact_map_pair<uint16_t, true>(m, o, ri, rd, amb, res, tab, nullptr, false, false, &mw) : compact_map_pair(m, o, ri, rd, amb, res, tab); }
-        else { CMemT<uint32_t> m{lds.data()}; rc = multi ? compact_map_pair<uint32_t, true>(m, o, ri, rd, amb, res, tab, nullptr, false, false, &mw) : compact_map_pair(m, o, ri, rd, amb, res, tab); }
+        } else if (pos16) { CMemT<uint16_t> m{lds.data()}; rc = multi ? compact_map_pair<true>(m, o, ri, rd, amb, res, tab, nullptr, false, false, &mw) : compact_map_pair(m, o, ri, rd, amb, res, tab); }
+        else { CMemT<uint32_t> m{lds.data()}; rc = multi ? compact_map_pair<true>(m, o, ri, rd, amb, res, tab, nullptr, false, false, &mw) : compact_map_pair(m, o, ri, rd, amb, res, tab); }
         done[it] = rc == PMX_C_DONE ? 1 : 0;
         if (pmx_c_trace_out) {
             unsigned char* t = pmx_c_trace_out + (size_t)it * 129;
