@@ -14,6 +14,8 @@
 //     smaller indices), per-mate anchor lists are two-byte indices in the dead chain cells;
 //   * 56 anchors per pair (99.9 % of 150 bp pairs; mean 40): 336 bytes per pair (448 with 32-bit positions),
 //     interleaved word-wise across the 64 lanes of a wave in LDS (conflict-free): 21 KB per wave, seven waves per CU;
+//     the first form of the two-kernel chain kernel keeps 48 (99.1 % of the pairs; the others are the second form's):
+//     288 bytes per pair, eight waves per CU (CMemT's CAP parameter, PMX_C_CAP1);
 //   * regions are a handful of scalars in registers: at most one region per mate is followed.
 // Everything outside that envelope -- an ambiguous base, a seed that occurs twice in the reference, more than 56 seeds,
 // a third chain, two regions on one mate, an extension or gap fill the closed forms (aln_ksw.hpp, ksw_shortcut_*) do

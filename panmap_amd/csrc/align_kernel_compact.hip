@@ -1,6 +1,8 @@
-// ALIGN stage, compact tier kernel for gfx950: THREAD per read pair, the pair's whole work state in LDS (336 bytes,
-// word-interleaved across the wave: 21 KB per wave, seven waves per CU; 448 bytes / five waves when the reference is
-// longer than 32,767 bases) and registers -- align/aln_compact.hpp.
+// ALIGN stage, compact tier kernel for gfx950: THREAD per read pair, the pair's whole work state in LDS (the first form of
+// the two-kernel chain kernel: 48 anchors, 288 bytes, word-interleaved across the wave: 19.6 KB per wave with the penalty
+// tables, eight waves per CU -- 384 bytes / six waves when the reference is longer than 32,767 bases; the second form and
+// the fused kernels: all 56 anchors the hand-over carries, 336 / 448 bytes, seven / five waves) and registers --
+// align/aln_compact.hpp.
 // It takes every pair of the batch first.  A pair it finishes has its records written here; a pair outside the tier's
 // envelope is appended to the bail list and run by the general thread-per-pair kernel (align_kernel_tpp.hip) and its
 // DP service.  HBM traffic per pair: the packed read words in (38 B per 150 bp read, + the ambiguity words), index /
