@@ -15,7 +15,13 @@ CLI = os.path.join(ROOT, "panmap_amd", "bin", "panmap")
 
 
 def run(args, cwd):
-    return subprocess.run([CLI] + args, cwd=cwd, capture_output=True, text=True, timeout=1200)
+    """one invocation of the command line.  A run that does not come back within two minutes (they take seconds) is started
+    once more: at the end of round 4 one `panmap --meta` on 1,000 reads sat for five minutes on a GPU box and ran in seconds on
+    the next one, on the same sources (profiles/r04/README.md item 20); a second hang fails the test."""
+    try:
+        return subprocess.run([CLI] + args, cwd=cwd, capture_output=True, text=True, timeout=120)
+    except subprocess.TimeoutExpired:
+        return subprocess.run([CLI] + args, cwd=cwd, capture_output=True, text=True, timeout=120)
 
 
 def test_index_stage_and_cache_rules(pmx, tmp_path):
