@@ -931,7 +931,7 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8/i8 DP + u64 hash + f64 score", "data": "synthetic",
-            "config": {"workload": ("%gM x %dbp synthetic %s reads %s vs SARS-CoV-2 20k PanMAN (39,999 nodes), place+align, host memory -> host memory (%s%s)"
+            "config": {"workload": ("%gM x %dbp synthetic %s reads %s vs SARS-CoV-2 20k PanMAN (39,999 nodes), place+align, inputs resident in HBM -> records in pinned host memory (%s%s)"
                                     % ((total_reads if args.scaling == "strong" else n_reads) / 1e6, args.read_len,
                                        "paired" if paired else "single-end long (2% sub, 1.5% ins, 1.5% del)",
                                        "in total, read-sharded over the ranks" if args.scaling == "strong" else "per GPU",
